@@ -1,0 +1,450 @@
+"""CPU oracle for the FAST Monte-Carlo hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+A numpy restatement, as pure functions of explicit arrays, of the reference's
+algorithm for SURVEY.md section 8 rows 1-12.  Each function cites the reference
+file:line it follows (paths relative to /root/reference).  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import
+this package; `fast_amd/` never does.
+
+Parity status: PINNED by outputs of the reference itself.  `tools/capture_golden/
+capture.py` imports /root/reference/fast in the build container and stores its
+inputs/outputs under `tests/golden/*.npz`; `tests/test_oracle_golden.py` checks
+every function here against them.  The reference's own tests hold no known-answer
+vectors.  Fixtures whose values pass through the absent
+third-party package `aotools` (pupil, fibre mode, pupil filter) were produced with
+our stand-ins and are labelled "stand-in dependent" in tests/golden/MANIFEST.md;
+the Monte-Carlo kernel fixtures (`kat_*`) are not.
+
+Third-party arithmetic the reference calls and this oracle calls identically:
+numpy.random.Generator.normal, numpy.fft, scipy.integrate.simpson, scipy.special.jv.
+"""
+import numpy as np
+from scipy.integrate import simpson
+from scipy.special import jv
+
+TWO_PI = 2.0 * np.pi
+
+
+# --------------------------------------------------------------------------
+# Row 11: frequency grids                      fast/fast.py:830-844, 877-921
+# --------------------------------------------------------------------------
+class FreqGrid:
+    """Angular spatial-frequency grid built from 1-D axes (fast/fast.py:877-921).
+
+    `fx[i, j] = axis_x[j]`, `fy[i, j] = axis_y[i]` (numpy.meshgrid default 'xy').
+    For stacked axes of shape (P, n) the grids are (P, n, n)  (fast.py:896-902).
+    """
+
+    def __init__(self, axis_x, axis_y=None):
+        axis_x = np.asarray(axis_x, dtype=float)
+        axis_y = axis_x if axis_y is None else np.asarray(axis_y, dtype=float)
+        self.axis_x, self.axis_y = axis_x, axis_y
+        self.df = axis_x[..., 1] - axis_x[..., 0]
+        if axis_x.ndim == 1:
+            self.fx, self.fy = np.meshgrid(axis_x, axis_y)
+        else:
+            self.fx = np.stack([np.meshgrid(ax, ay)[0] for ax, ay in zip(axis_x, axis_y)])
+            self.fy = np.stack([np.meshgrid(ax, ay)[1] for ax, ay in zip(axis_x, axis_y)])
+        self.fabs = np.sqrt(self.fx ** 2 + self.fy ** 2)
+
+
+def main_grid(N, dx):
+    """fast/fast.py:830-833: axis = arange(-N/2, N/2) * 2*pi/(N*dx)."""
+    df = TWO_PI / (N * dx)
+    return FreqGrid(np.arange(-N / 2.0, N / 2.0) * df)
+
+
+def subharm_grid(N, dx, pmax=3):
+    """fast/fast.py:835-844: per level p, axis = [-1, 0, 1] * 2*pi/(3^p * N*dx)."""
+    D = dx * N
+    axes = [np.arange(-1, 2) * (TWO_PI / (3 ** p * D)) for p in range(1, pmax + 1)]
+    return FreqGrid(np.array(axes))
+
+
+# --------------------------------------------------------------------------
+# Row 6: von Karman spectrum                              fast/funcs.py:138-173
+# --------------------------------------------------------------------------
+def von_karman(fabs, cn2, L0, l0, C=TWO_PI):
+    """0.033 cn2_l exp(-k^2/km^2) / (k^2 + k0^2)^(11/6), infinities -> 0 (funcs.py:152-170).
+
+    Returns shape (L, *fabs.shape).
+    """
+    cn2 = np.atleast_1d(np.asarray(cn2, dtype=float))
+    km = 5.92 / l0
+    k0 = C / L0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        base = 0.033 * np.exp(-fabs ** 2 / km ** 2) / (fabs ** 2 + k0 ** 2) ** (11 / 6.0)
+    out = cn2.reshape((-1,) + (1,) * base.ndim) * base[np.newaxis]
+    out[np.isinf(out)] = 0.0
+    return out
+
+
+# --------------------------------------------------------------------------
+# Row 7: low-frequency (corrected-region) mask   fast/ao_power_spectra.py:10-21,54-76,119-141
+# --------------------------------------------------------------------------
+def noll_to_nm(j):
+    """Noll index -> (n, m); aotools.functions.zernike.zernIndex (third party, absent)."""
+    n = int((-1.0 + np.sqrt(8 * (j - 1) + 1)) / 2.0)
+    p = j - (n * (n + 1)) / 2.0
+    k = n % 2
+    m = int((p + k) / 2.0) * 2 - k
+    if m != 0:
+        m *= 1 if j % 2 == 0 else -1
+    return n, m
+
+
+def zernike_sq_filter(fabs, fx, fy, D, n_noll):
+    """sum_{j=1..n_noll} |Z~_j(kappa)|^2 with the centre pixel forced to 1
+    (ao_power_spectra.py:54-76 with gamma=None, plusminus=False, n_noll_start=1)."""
+    phi = np.arctan2(fy, fx)
+    out = np.zeros(fabs.shape)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        x = fabs * D / 2
+        for j in range(1, n_noll + 1):
+            n, m = noll_to_nm(j)
+            radial = 2 * jv(n + 1, x) / x
+            if m == 0:
+                z2 = (n + 1) * radial ** 2
+            elif j % 2 == 0:
+                z2 = 2 * (n + 1) * (radial * np.cos(m * phi)) ** 2
+            else:
+                z2 = 2 * (n + 1) * (radial * np.sin(m * phi)) ** 2
+            out = out + z2
+    out[..., int(fabs.shape[-2] / 2), int(fabs.shape[-1] / 2)] = 1
+    return out
+
+
+def mask_lf(fx, fy, d_wfs, modal=False, modal_mult=1, zmax=None, D=None):
+    """ao_power_spectra.py:119-141 (Gtilt=False).  int64 0/1 for zonal / radial-modal,
+    float64 in [0, 1] for the Zernike-modal case."""
+    fmax = np.pi / d_wfs
+    wfs_space = np.logical_and(np.abs(fx) <= fmax, np.abs(fy) <= fmax)
+    if modal:
+        fabs = np.sqrt(fx ** 2 + fy ** 2)
+        if zmax is None:
+            dm_space = fabs <= fmax * modal_mult
+        else:
+            dm_space = zernike_sq_filter(fabs, fx, fy, D, zmax)
+    else:
+        dm_space = wfs_space
+    dm_space = np.where(dm_space < 1, dm_space, 1)
+    return wfs_space * dm_space
+
+
+# --------------------------------------------------------------------------
+# Row 8: anisoplanatic / servo-lag transfer function   ao_power_spectra.py:225-270
+# --------------------------------------------------------------------------
+def g_ao(fx, fy, fabs, mask, mode, h, wind, dtheta, D_tx, zmax, t_loop, t_exp):
+    """Per-layer (L, n, n) transfer function; the scalar 1 for 'NOAO' (235-236)."""
+    if mode not in ("NOAO", "AO", "TT", "LGSAO"):
+        raise Exception("Mode not recognised")
+    if mode == "NOAO":
+        return 1
+    h = np.asarray(h, dtype=float)
+    wind = np.asarray(wind, dtype=float)
+    dr = np.outer(h, np.asarray(dtype=float, a=dtheta) / 206265.0)        # (L, 2)  line 245
+    lead = (slice(None),) + (None,) * fx.ndim
+    dr_k = fx[None] * dr[:, 0][lead] + fy[None] * dr[:, 1][lead]          # line 247
+    v_k = fx[None] * wind[:, 0][lead] + fy[None] * wind[:, 1][lead]       # line 250
+    s = np.sinc(t_exp * v_k / TWO_PI)                                     # line 255
+    aniso = 1 - 2 * np.cos(dr_k - t_loop * v_k) * s + s ** 2              # lines 254-257
+    if mode in ("AO", "TT"):
+        return aniso * mask + (1 - mask)                                  # line 260
+    s_l = np.sinc(t_exp * v_k / TWO_PI)                                   # LGSAO, 262-267
+    aniso_lgs = 1 - 2 * np.cos(-t_loop * v_k) * s_l + s_l ** 2
+    Z = zernike_sq_filter(fabs, fx, fy, D_tx, 4)
+    return mask * (Z * aniso + (1 - Z) * aniso_lgs) + (1 - mask)
+
+
+# --------------------------------------------------------------------------
+# Row 9: WFS aliasing                               ao_power_spectra.py:163-223
+# --------------------------------------------------------------------------
+def alias_openloop(grid, d_wfs, cn2, mask, wind, t_exp, lmax, kmax, L0, l0):
+    """Sum over the (2*lmax+1)(2*kmax+1)-1 shifted von Karman spectra, with the
+    reference's special-cased centre row / column / pixel (208-213), times
+    sinc^2(t_exp v.kappa / 2pi) * mask (216), NaN -> 0 (221).  Shape (L, n, n)."""
+    fx, fy, fabs = grid.fx, grid.fy, grid.fabs
+    cn2 = np.asarray(cn2, dtype=float)
+    wind = np.asarray(wind, dtype=float)
+    mid_r = int(fx.shape[-2] / 2.0)
+    mid_c = int(fy.shape[-1] / 2.0)
+    v_k = fx[None] * wind[:, 0][:, None, None] + fy[None] * wind[:, 1][:, None, None]
+    alias = np.zeros((len(cn2),) + fabs.shape)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sinc2 = np.sinc(t_exp * v_k / TWO_PI) ** 2
+        term_0 = fx ** 2 * fy ** 2 / fabs ** 4
+        for l in range(-lmax, lmax + 1):
+            for k in range(-kmax, kmax + 1):
+                if l == 0 and k == 0:
+                    continue
+                sh = FreqGrid(grid.axis_x - TWO_PI * k / d_wfs, grid.axis_y - TWO_PI * l / d_wfs)
+                term_1 = (fx / sh.fy + fy / sh.fx) ** 2
+                term_2 = von_karman(sh.fabs, cn2, L0, l0)
+                mult = term_1 * term_2 * term_0
+                mult[..., mid_r, mid_c] = 0.0
+                if l == 0:
+                    mult[..., mid_r, :] = term_2[..., mid_r, :]
+                if k == 0:
+                    mult[..., mid_c] = term_2[..., mid_c]
+                    mult[..., mid_r, mid_c] = term_2[..., mid_r, mid_c]
+                alias += mult
+        alias *= sinc2 * mask
+    alias[np.isnan(alias)] = 0.0
+    return alias
+
+
+# --------------------------------------------------------------------------
+# Row 10: noise, assembly, Simpson scalars, log-amplitude spectrum
+# --------------------------------------------------------------------------
+def noise_openloop(fx, fy, fabs, d_wfs, noise_var, mask):
+    """ao_power_spectra.py:148-161 (freq_per_layer False)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ps = noise_var / (fabs ** 2 * np.sinc(d_wfs * fx / TWO_PI) ** 2 * np.sinc(d_wfs * fy / TWO_PI) ** 2)
+    ps[..., int(ps.shape[-2] / 2.0), int(ps.shape[-1] / 2.0)] = 0.0
+    return mask * ps
+
+
+def simpson2d(P, f):
+    """funcs.py:100-115: scipy Simpson over the last axis, then over the next."""
+    return simpson(simpson(P, x=f), x=f)
+
+
+def logamp_spectrum(fabs, h, cn2, wvl, pupil_filter, L0, l0):
+    """ao_power_spectra.py:272-301, ndarray pupil filter, layered path -> (n, n)."""
+    h = np.asarray(h, dtype=float)
+    ps = von_karman(fabs, cn2, L0, l0) * TWO_PI * (TWO_PI / wvl) ** 2
+    ps = ps * np.sin(wvl * h[:, None, None] * fabs[None] ** 2 / (4 * np.pi)) ** 2
+    if pupil_filter is not None:
+        ps = ps * pupil_filter
+    return ps.sum(0)
+
+
+def residual_powerspec(N, dx, cn2, h, wind, L0, l0, wvl, ao_mode, d_wfs, dtheta, D_ground,
+                       zmax, t_loop, t_exp, alias, noise, lf_mask, pupil_filter):
+    """Fast.compute_powerspec, fast/fast.py:445-492 (main grid only).
+
+    Returns a dict with `powerspec` (N, N), `powerspec_per_layer` (L, N, N) and the
+    Simpson scalars.  `lf_mask` comes from mask_lf(); `pupil_filter` is (N, N)."""
+    g = main_grid(N, dx)
+    k = TWO_PI / wvl
+    f = g.axis_x
+    hf_mask = 1 - lf_mask
+    turb = von_karman(g.fabs, cn2, L0, l0)                                      # 448-449
+    G = g_ao(g.fx, g.fy, g.fabs, lf_mask, ao_mode, h, wind, dtheta, D_ground, zmax, t_loop, t_exp)
+    out = {}
+    out["aniso_servo_error"] = simpson2d((G * turb).sum(0) * lf_mask * TWO_PI * k ** 2, f)   # 456-457
+    if alias and ao_mode != "NOAO":                                             # 459-468
+        alias_ps = alias_openloop(g, d_wfs, cn2, lf_mask, wind, t_exp, 5, 5, L0, l0)
+        out["alias_error"] = simpson2d((alias_ps * TWO_PI * k ** 2).sum(0), f)
+    else:
+        alias_ps = 0.0
+        out["alias_error"] = 0.0
+    if noise > 0 and ao_mode != "NOAO":                                         # 470-476
+        noise_ps = noise_openloop(g.fx, g.fy, g.fabs, d_wfs, noise, lf_mask)
+        out["noise_error"] = simpson2d(noise_ps, f)
+    else:
+        noise_ps = 0.0
+        out["noise_error"] = 0.0
+    per_layer = TWO_PI * k ** 2 * (turb * G + alias_ps) + noise_ps / len(h)      # 478-479
+    ps = per_layer.sum(0)                                                       # 481
+    out["powerspec_per_layer"] = per_layer
+    out["powerspec"] = ps
+    out["fitting_error"] = simpson2d(ps * hf_mask, f)                           # 483
+    out["phs_var"] = simpson2d(ps, f)                                           # 484
+    out["phs_var_weights"] = simpson2d(per_layer, f) / out["phs_var"]           # 485
+    la = logamp_spectrum(g.fabs, h, cn2, wvl, pupil_filter, L0, l0)             # 490-491
+    out["logamp_powerspec"] = la
+    out["logamp_var"] = simpson2d(la, f)                                        # 492
+    return out
+
+
+def subharm_powerspec(N, dx, cn2, h, wind, L0, l0, wvl, ao_mode, d_wfs, dtheta, D_ground,
+                      zmax, t_loop, t_exp, alias, noise, modal, modal_mult):
+    """fast/fast.py:494-523: the same assembly on the (3, 3, 3) sub-harmonic grids."""
+    g = subharm_grid(N, dx)
+    k = TWO_PI / wvl
+    mask = mask_lf(g.fx, g.fy, d_wfs, modal=modal, modal_mult=modal_mult, zmax=zmax, D=D_ground)
+    turb = _von_karman_stacked(g.fabs, cn2, L0, l0)
+    G = _g_ao_stacked(g, mask, ao_mode, h, wind, dtheta, D_ground, zmax, t_loop, t_exp)
+    if alias and ao_mode != "NOAO":
+        alias_ps = _alias_stacked(g, d_wfs, cn2, mask, wind, t_exp, L0, l0)
+    else:
+        alias_ps = 0.0
+    if noise > 0 and ao_mode != "NOAO":
+        noise_ps = noise_openloop(g.fx, g.fy, g.fabs, d_wfs, noise, mask)
+    else:
+        noise_ps = 0.0
+    per_layer = TWO_PI * k ** 2 * (turb * G + alias_ps) + noise_ps / len(h)
+    return per_layer.sum(0), g
+
+
+def _von_karman_stacked(fabs, cn2, L0, l0):
+    # funcs.py:164 with a (3,3,3) fabs: list*nlayers -> (L,3,3,3); .T * cn2 broadcasts on the
+    # last transposed axis = layer axis.
+    return von_karman(fabs, cn2, L0, l0)
+
+
+def _g_ao_stacked(g, mask, mode, h, wind, dtheta, D_tx, zmax, t_loop, t_exp):
+    # ao_power_spectra.py:242-260 with 3-D fx: tile -> (L,3,3,3); .T products hit the layer axis.
+    return g_ao(g.fx, g.fy, g.fabs, mask, mode, h, wind, dtheta, D_tx, zmax, t_loop, t_exp)
+
+
+def _alias_stacked(g, d_wfs, cn2, mask, wind, t_exp, L0, l0):
+    """Jol_alias_openloop on stacked (3, 3) axes (ao_power_spectra.py:163-223)."""
+    fx, fy, fabs = g.fx, g.fy, g.fabs
+    cn2 = np.asarray(cn2, dtype=float)
+    wind = np.asarray(wind, dtype=float)
+    mid_r = int(fx.shape[-2] / 2.0)
+    mid_c = int(fy.shape[-1] / 2.0)
+    lead = (slice(None),) + (None,) * fx.ndim
+    v_k = fx[None] * wind[:, 0][lead] + fy[None] * wind[:, 1][lead]
+    alias = np.zeros((len(cn2),) + fabs.shape)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sinc2 = np.sinc(t_exp * v_k / TWO_PI) ** 2
+        term_0 = fx ** 2 * fy ** 2 / fabs ** 4
+        for l in range(-5, 6):
+            for k in range(-5, 6):
+                if l == 0 and k == 0:
+                    continue
+                sh = FreqGrid(g.axis_x - TWO_PI * k / d_wfs, g.axis_y - TWO_PI * l / d_wfs)
+                term_1 = (fx / sh.fy + fy / sh.fx) ** 2
+                term_2 = von_karman(sh.fabs, cn2, L0, l0)
+                mult = term_1 * term_2 * term_0
+                mult[..., mid_r, mid_c] = 0.0
+                if l == 0:
+                    mult[..., mid_r, :] = term_2[..., mid_r, :]
+                if k == 0:
+                    mult[..., mid_c] = term_2[..., mid_c]
+                    mult[..., mid_r, mid_c] = term_2[..., mid_r, mid_c]
+                alias += mult
+        alias *= sinc2 * mask
+    alias[np.isnan(alias)] = 0.0
+    return alias
+
+
+# --------------------------------------------------------------------------
+# Rows 1-5c: the Monte-Carlo realisation pipeline
+# --------------------------------------------------------------------------
+def draw_coefficients(rng, shape):
+    """funcs.py:352-356: ALL real parts are drawn first, then all imaginary parts."""
+    re = rng.normal(0, 1, size=shape)
+    im = rng.normal(0, 1, size=shape)
+    return re + 1j * im
+
+
+def draw_logamp(rng, n_iter, logamp_var):
+    """fast.py:639-645 -> funcs.py:358-365 (non-temporal): Re(N + iN) * sqrt(var).
+    Consumes 2*n_iter normals; the imaginary draw is discarded but advances the stream."""
+    re = rng.normal(0, 1, size=(n_iter,))
+    rng.normal(0, 1, size=(n_iter,))
+    return re * np.sqrt(logamp_var)
+
+
+def screens_fftw(coloured, df):
+    """funcs.py:212-215 + fast.py:431-438: fftshift, unnormalised FORWARD DFT over the
+    last two axes, fftshift.  Canonical branch of this oracle."""
+    x = np.fft.fftshift(coloured * df, axes=(-1, -2))
+    return np.fft.fftshift(np.fft.fft2(x, axes=(-2, -1)), axes=(-1, -2))
+
+
+def screens_numpy_branch(coloured, df):
+    """funcs.py:218 -> aotools.fouriertransform.ift2(rand*df, 1) (third party, absent;
+    restated from its published form: N = shape[0], ALL-axes ifftshift).  NOT pinned
+    against the real aotools; kept for reference only."""
+    N0 = coloured.shape[0]
+    return np.fft.ifftshift(np.fft.ifft2(np.fft.ifftshift(coloured * df))) * (N0 * 1) ** 2
+
+
+def double_screens(z):
+    """funcs.py:220-221: vstack([Re, Im]) -- one complex FFT yields two real screens."""
+    return np.vstack([z.real, z.imag])
+
+
+def crop_lo(N, Np):
+    """fast.py:390: first row/column of the pupil window."""
+    return (N - Np) // 2
+
+
+def crop(screens, N, Np):
+    """fast.py:596 with pup_coords from fast.py:390."""
+    lo, hi = (N - Np) // 2, (N + Np) // 2
+    return screens[..., lo:hi, lo:hi]
+
+
+def subharm_screens(rand_lo, sh_grid, N, dx):
+    """funcs.py:225-258 (double=True): 3 levels x 3x3 modes evaluated on the full grid,
+    per-screen complex mean removed, Re/Im stacked."""
+    D = dx * N
+    coords = np.arange(-D / 2, D / 2, dx)
+    if len(coords) == N + 1:
+        coords = coords[:-1]
+    x, y = np.meshgrid(coords, coords)
+    acc = np.zeros((rand_lo.shape[0], N, N), dtype=complex)
+    for i in range(3):
+        c = rand_lo[:, i] * sh_grid.df[i]                                   # (B,3,3)
+        modes = np.exp(1j * (x[None, None] * sh_grid.fx[i][..., None, None]
+                             + y[None, None] * sh_grid.fy[i][..., None, None]))   # (3,3,N,N)
+        acc = acc + np.einsum("bij,ijxy->bxy", c, modes)
+    acc = acc - acc.mean((1, 2))[:, None, None]
+    return np.vstack([acc.real, acc.imag])
+
+
+def detector(phs, W, dx, logamp_chunk, coherent=False):
+    """fast.py:647-668: sum_pix W exp(i phi) dx^2 / (sum W dx^2) * exp(chi); |.|^2 unless coherent."""
+    a = (W * np.exp(1j * phs)).sum((1, 2)) * dx ** 2
+    a = np.exp(logamp_chunk) * a
+    a = a / (W.sum() * dx ** 2)
+    return a if coherent else np.abs(a) ** 2
+
+
+def powers_from_coefficients(coeffs, powerspec, df, W, dx, logamp_chunk, coherent=False,
+                             sub=None):
+    """One chunk of Fast.run from explicit coefficients (fast.py:589-605, 647-668).
+
+    coeffs: (B, N, N) complex standard normals -> 2B powers ordered [Re screens, Im screens].
+    sub: optional (rand_lo (B,3,3,3) complex, powerspec_subharm (3,3,3), sh_grid)."""
+    N = powerspec.shape[-1]
+    Np = W.shape[-1]
+    z = screens_fftw(coeffs * np.sqrt(powerspec), df)
+    phs = crop(double_screens(z), N, Np)
+    if sub is not None:
+        rand_lo, ps_lo, sh_grid = sub
+        phs = phs + crop(subharm_screens(rand_lo * np.sqrt(ps_lo), sh_grid, N, dx), N, Np)
+    return detector(phs, W, dx, logamp_chunk, coherent)
+
+
+def monte_carlo(seed_or_rng, n_iter, n_chunks, powerspec, df, W, dx, logamp_var,
+                coherent=False, sub=None, return_coeffs=False):
+    """Fast.run, fast.py:115-140 (non-temporal): log-amplitudes first, then per chunk
+    draw -> colour -> FFT -> crop -> detector.  Draw order == the reference's, so the
+    same numpy seed gives the same `_r`."""
+    rng = seed_or_rng if isinstance(seed_or_rng, np.random.Generator) else np.random.default_rng(seed_or_rng)
+    M = n_iter // n_chunks
+    N = powerspec.shape[-1]
+    chi = draw_logamp(rng, n_iter, logamp_var)
+    out = np.zeros((n_chunks, M), dtype=complex if coherent else float)
+    kept = []
+    for c in range(n_chunks):
+        coeffs = draw_coefficients(rng, (M // 2, N, N))
+        sub_c = None
+        if sub is not None:
+            ps_lo, sh_grid = sub
+            sub_c = (draw_coefficients(rng, (M // 2,) + ps_lo.shape), ps_lo, sh_grid)
+        out[c] = powers_from_coefficients(coeffs, powerspec, df, W, dx, chi[c * M:(c + 1) * M],
+                                          coherent, sub_c)
+        if return_coeffs:
+            kept.append(coeffs)
+    if return_coeffs:
+        return out.flatten(), chi, kept
+    return out.flatten()
+
+
+# --------------------------------------------------------------------------
+# Row 12: result statistics                               fast/fast.py:949-983
+# --------------------------------------------------------------------------
+def result_stats(r, dl):
+    p = dl * r
+    return {
+        "dB_rel": 10 * np.log10(r), "dB_abs": 10 * np.log10(r * dl), "dBm": 10 * np.log10(r * dl / 1e-3),
+        "power": p, "scintillation_index": (r / r.mean()).var(), "avg_power_W": p.mean(),
+    }

@@ -1,0 +1,108 @@
+"""Pins oracle/fastref.py against outputs of the reference itself (tests/golden)."""
+import numpy as np
+import pytest
+
+from conftest import E2E_CASES, load_golden, params_from_json
+from oracle import fastref as R
+
+
+@pytest.mark.parametrize("N", [16, 30, 33, 64, 128])
+def test_fft_branch_matches_reference(N):
+    g = load_golden(f"kat_fft_N{N}")
+    z = R.screens_fftw(g["coeffs"] * np.sqrt(g["powerspec"]), float(g["df"]))
+    scr = R.double_screens(z)
+    scale = np.abs(g["screens"]).max()
+    assert np.abs(scr - g["screens"]).max() <= 1e-13 * scale
+
+
+def test_detector_matches_reference():
+    g = load_golden("kat_detector")
+    M, c = int(g["M"]), int(g["chunk"])
+    la = g["logamp"][c * M:(c + 1) * M]
+    np.testing.assert_allclose(R.detector(g["phs"], g["W"], float(g["dx"]), la), g["incoherent"], rtol=1e-13)
+    np.testing.assert_allclose(R.detector(g["phs"], g["W"], float(g["dx"]), la, coherent=True),
+                               g["coherent"], rtol=1e-13)
+
+
+def test_von_karman_and_simpson():
+    g = load_golden("kat_vk")
+    grid = R.main_grid(int(g["N"]), float(g["dx"]))
+    np.testing.assert_allclose(R.von_karman(grid.fabs, g["cn2"], np.inf, 1e-6), g["vk_inf"], rtol=1e-14)
+    vk = R.von_karman(grid.fabs, g["cn2"], 25.0, 0.01)
+    np.testing.assert_allclose(vk, g["vk_L0"], rtol=1e-14)
+    np.testing.assert_allclose(R.simpson2d(vk, grid.axis_x), g["simpson_vk_L0"], rtol=1e-14)
+    assert g["vk_inf"][:, 12, 12].tolist() == [0.0, 0.0, 0.0]
+
+
+def test_subharm_screens():
+    g = load_golden("kat_subharm")
+    sh = R.subharm_grid(int(g["N"]), float(g["dx"]))
+    np.testing.assert_allclose(sh.fx, g["fx"], rtol=1e-15)
+    np.testing.assert_allclose(sh.fy, g["fy"], rtol=1e-15)
+    np.testing.assert_allclose(sh.df, g["df"], rtol=1e-15)
+    scr = R.subharm_screens(g["rand"], sh, int(g["N"]), float(g["dx"]))
+    np.testing.assert_allclose(scr, g["screens"], rtol=1e-10, atol=1e-12 * np.abs(g["screens"]).max())
+
+
+def test_masks():
+    g = load_golden("kat_masks")
+    grid = R.main_grid(int(g["N"]), float(g["dx"]))
+    assert np.array_equal(R.mask_lf(grid.fx, grid.fy, 0.08), g["zonal"])
+    assert np.array_equal(R.mask_lf(grid.fx, grid.fy, 0.08, modal=True, modal_mult=0.7), g["modal"])
+    np.testing.assert_allclose(R.mask_lf(grid.fx, grid.fy, 0.08, modal=True, zmax=3, D=0.4), g["zern3"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(R.mask_lf(grid.fx, grid.fy, 0.08, modal=True, zmax=9, D=0.4), g["zern9"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(R.zernike_sq_filter(grid.fabs, grid.fx, grid.fy, 0.4, 4), g["zsq4"], rtol=1e-12, atol=1e-15)
+
+
+def test_rng_anchor():
+    g = load_golden("kat_turbulence")
+    assert np.array_equal(np.random.default_rng(1).normal(0, 1, 3), g["rng_anchor"])
+
+
+def _spec_inputs(g):
+    p = params_from_json(g["params_json"])
+    ao_mode = p["AO_MODE"]
+    zmax = p["ZMAX"]
+    modal, mult = p["MODAL"], p["MODAL_MULT"]
+    if ao_mode == "TT":
+        zmax, modal, mult = 3, True, 1
+    return p, dict(N=int(g["Npxls"]), dx=float(g["dx"]), cn2=g["cn2"], h=g["h"], wind=g["wind_vector"],
+                   L0=p["L0"], l0=p["l0"], wvl=p["WVL"], ao_mode=ao_mode, d_wfs=p["DSUBAP"],
+                   dtheta=p["DTHETA"], D_ground=p["D_GROUND"], zmax=zmax, t_loop=p["TLOOP"],
+                   t_exp=p["TEXP"], alias=p["ALIAS"], noise=p["NOISE"]), (modal, mult)
+
+
+@pytest.mark.parametrize("case", E2E_CASES + ["default164"])
+def test_residual_powerspec_matches_reference(case):
+    g = load_golden("e2e_" + case)
+    p, kw, (modal, mult) = _spec_inputs(g)
+    grid = R.main_grid(kw["N"], kw["dx"])
+    mask = R.mask_lf(grid.fx, grid.fy, kw["d_wfs"], modal=modal, modal_mult=mult, zmax=kw["zmax"], D=kw["D_ground"])
+    np.testing.assert_allclose(mask, g["lf_mask"], rtol=1e-12, atol=1e-15)
+    out = R.residual_powerspec(lf_mask=g["lf_mask"], pupil_filter=g["pupil_filter"], **kw)
+    tiny = 1e-13 * np.abs(g["powerspec"]).max()
+    np.testing.assert_allclose(out["powerspec"], g["powerspec"], rtol=1e-11, atol=tiny)
+    np.testing.assert_allclose(out["powerspec_per_layer"], g["powerspec_per_layer"], rtol=1e-11, atol=tiny)
+    np.testing.assert_allclose(out["logamp_powerspec"], g["logamp_powerspec"], rtol=1e-11,
+                               atol=1e-13 * np.abs(g["logamp_powerspec"]).max())
+    for k in ("logamp_var", "phs_var", "fitting_error", "aniso_servo_error", "alias_error", "noise_error"):
+        np.testing.assert_allclose(out[k], g[k], rtol=1e-10, atol=1e-300, err_msg=k)
+    np.testing.assert_allclose(out["phs_var_weights"], g["phs_var_weights"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("case", E2E_CASES + ["default164"])
+def test_monte_carlo_matches_reference_same_seed(case):
+    """Identical numpy seed -> identical `result._r` (draw order restated exactly)."""
+    g = load_golden("e2e_" + case)
+    p, kw, (modal, mult) = _spec_inputs(g)
+    N, dx = kw["N"], kw["dx"]
+    W = g["pupil"] * g["pupil_mode"]
+    sub = None
+    if p["SUBHARM"]:
+        ps_lo, sh = R.subharm_powerspec(modal=modal, modal_mult=mult, **kw)
+        np.testing.assert_allclose(ps_lo, g["powerspec_subharm"], rtol=1e-11)
+        sub = (ps_lo, sh)
+    r = R.monte_carlo(p["SEED"], p["NITER"], p["NCHUNKS"], g["powerspec"], R.main_grid(N, dx).df, W, dx,
+                      float(g["logamp_var"]), coherent=p["COHERENT"], sub=sub)
+    np.testing.assert_allclose(r, g["r"], rtol=1e-10)
+    assert r.dtype == g["r"].dtype

@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the reference IN THIS CONTAINER.
+
+Runs only where /root/reference exists (the build container).  The reference needs
+aotools / astropy / skyfield / pyfftw, none of which is installed; `shims/` holds our
+own stand-ins (see shims/README.md).  Nothing of the reference travels: the fixtures
+are data -- inputs and the outputs the reference computed for them.
+
+    python tools/capture_golden/capture.py            # rewrites tests/golden/
+
+Fixture families (see tests/golden/MANIFEST.md, written by this script):
+  kat_fft_*      reference funcs.make_phase_fft (FFTW branch) on explicit coefficients
+  kat_detector   reference Fast.compute_detector on explicit phase cubes
+  kat_vk / kat_subharm / kat_simpson   small function-level known answers
+  e2e_*          full fast.Fast(config).run(): every init product + result._r
+  big_*          1024^2 runs: scalars, strided spectrum sample, first powers
+"""
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, "shims"))
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+import fast  # noqa: E402  (the reference)
+from fast import funcs, ao_power_spectra, turbulence_models  # noqa: E402
+
+OUT = os.path.abspath(os.path.join(HERE, "..", "..", "tests", "golden"))
+MANIFEST = []
+
+
+def save(name, note, standin, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    MANIFEST.append((name, os.path.getsize(path), "yes" if standin else "no", note))
+    print(f"  {name}.npz  {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def params_to_json(p):
+    out = {}
+    for k, v in p.items():
+        if isinstance(v, np.ndarray):
+            out[k] = {"__ndarray__": v.tolist()}
+        elif isinstance(v, float) and np.isinf(v):
+            out[k] = {"__float__": "inf"}
+        elif isinstance(v, (np.floating, np.integer)):
+            out[k] = v.item()
+        else:
+            out[k] = v
+    return json.dumps(out)
+
+
+def fftw_objs_for(shape):
+    import pyfftw  # the stand-in
+    o = {"IN": pyfftw.empty_aligned(shape, dtype="complex128"),
+         "OUT": pyfftw.empty_aligned(shape, dtype="complex128")}
+    o["FFT"] = pyfftw.FFTW(o["IN"], o["OUT"], axes=(-1, -2))
+    return o
+
+
+# ------------------------------------------------------------------ KATs
+def kat_fft():
+    rng = np.random.default_rng(20240601)
+    for N, L0 in ((16, np.inf), (30, 25.0), (33, np.inf), (64, 25.0), (128, np.inf)):
+        B = 2
+        dx = 0.02
+        freq = fast.fast.SpatialFrequencies(N, dx)
+        ps = funcs.turb_powerspectrum_vonKarman(freq.main, np.array([3e-13, 1e-13]), L0, 1e-3).sum(0)
+        ps = ps * 2 * np.pi * (2 * np.pi / 1550e-9) ** 2
+        coeffs = rng.normal(size=(B, N, N)) + 1j * rng.normal(size=(B, N, N))
+        rand = coeffs * np.sqrt(ps)
+        objs = fftw_objs_for((B, N, N))
+        scr = funcs.make_phase_fft(rand, freq.main.df, True, objs, double=True)
+        save(f"kat_fft_N{N}", f"make_phase_fft FFTW branch, N={N}, L0={L0}", False,
+             N=N, dx=dx, df=freq.main.df, powerspec=ps, coeffs=coeffs, screens=scr)
+
+
+def base_params(**over):
+    h = np.array([500.0, 4000.0, 9000.0, 15000.0])
+    cn2 = np.array([4e-13, 9e-14, 4e-14, 1e-14])
+    w = np.array([8.0, 15.0, 30.0, 12.0])
+    p = dict(fast.conf.DEFAULTS)
+    p.update({
+        "NPXLS": 64, "DX": 0.01, "NITER": 8, "NCHUNKS": 2, "TEMPORAL": False, "FFTW": True,
+        "SEED": 7, "LOGLEVEL": "ERROR", "W0": "opt", "D_GROUND": 0.2, "OBSC_GROUND": 0,
+        "D_SAT": 0.1, "H_SAT": 600e3, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w,
+        "WIND_DIR": np.array([0.0, 90.0, 180.0, 270.0]), "L0": np.inf, "l0": 1e-6,
+        "ZENITH_ANGLE": 30, "DTHETA": [4, 0], "AO_MODE": "AO", "DSUBAP": 0.05,
+        "TLOOP": 1e-3, "TEXP": 1e-3, "ALIAS": True, "NOISE": 0.0,
+    })
+    p.update(over)
+    return p
+
+
+def kat_detector():
+    sim = fast.Fast(base_params())
+    rng = np.random.default_rng(99)
+    M, Np = sim.Niter_per_chunk, sim.Npxls_pup
+    phs = rng.normal(scale=6.0, size=(M, Np, Np))
+    sim.phs[:] = phs
+    sim.logamp[:] = rng.normal(scale=0.2, size=sim.Niter)
+    inc = sim.compute_detector(chunk=1).copy()
+    sim.params["COHERENT"] = True
+    coh = sim.compute_detector(chunk=1).copy()
+    save("kat_detector", "Fast.compute_detector on an explicit phase cube (chunk=1)", True,
+         phs=phs, W=sim.pupil * sim.pupil_mode, dx=sim.dx, logamp=sim.logamp.copy(), chunk=1,
+         M=M, incoherent=inc, coherent=coh)
+
+
+def kat_small():
+    # von Karman, stacked and plain
+    freq = fast.fast.SpatialFrequencies(24, 0.05)
+    cn2 = np.array([2e-13, 5e-14, 1e-14])
+    save("kat_vk", "funcs.turb_powerspectrum_vonKarman", False,
+         N=24, dx=0.05, cn2=cn2,
+         vk_inf=funcs.turb_powerspectrum_vonKarman(freq.main, cn2, np.inf, 1e-6),
+         vk_L0=funcs.turb_powerspectrum_vonKarman(freq.main, cn2, 25.0, 0.01),
+         simpson_vk_L0=funcs.integrate_powerspectrum(
+             funcs.turb_powerspectrum_vonKarman(freq.main, cn2, 25.0, 0.01), freq.main.f))
+    # sub-harmonic screens
+    N, dx = 20, 0.03
+    freq = fast.fast.SpatialFrequencies(N, dx)
+    freq.make_subharm_freqs()
+    rng = np.random.default_rng(5)
+    rand = rng.normal(size=(2, 3, 3, 3)) + 1j * rng.normal(size=(2, 3, 3, 3))
+    save("kat_subharm", "funcs.make_phase_subharm(double=True) + subharm grids", False,
+         N=N, dx=dx, rand=rand, fx=freq.subharm.fx, fy=freq.subharm.fy, df=freq.subharm.df,
+         screens=funcs.make_phase_subharm(rand, freq, N, dx, double=True))
+    # turbulence models
+    h4, c4, w4 = turbulence_models.HV57_Bufton_profile(4)
+    h10, c10, w10 = turbulence_models.HV57_Bufton_profile(10, w=30, A=3e-14, vg=5)
+    hh = np.linspace(0, 20000, 10)
+    save("kat_turbulence", "turbulence_models.HV57 / Bufton_wind / HV57_Bufton_profile", False,
+         h4=h4, cn2_4=c4, w4=w4, h10=h10, cn2_10=c10, w10=w10, hh=hh,
+         hv57=turbulence_models.HV57(hh), bufton=turbulence_models.Bufton_wind(hh),
+         rng_anchor=np.random.default_rng(1).normal(0, 1, 3),
+         l_path=np.array([funcs.l_path(36e6, 55.0), funcs.l_path(600e3, 0.0), funcs.l_path(600e3, 70.0)]),
+         wind_corr=funcs.calculate_wind_correction(np.array([1e3, 1e4]), [30.0, -12.0], 1e-3))
+    # zernike filters / masks
+    freq = fast.fast.SpatialFrequencies(32, 0.02)
+    m = freq.main
+    save("kat_masks", "ao_power_spectra.mask_lf variants + zernike_squared_filter", True,
+         N=32, dx=0.02,
+         zonal=ao_power_spectra.mask_lf(m, 0.08),
+         modal=ao_power_spectra.mask_lf(m, 0.08, modal=True, modal_mult=0.7),
+         zern3=ao_power_spectra.mask_lf(m, 0.08, modal=True, modal_mult=1, Zmax=3, D=0.4),
+         zern9=ao_power_spectra.mask_lf(m, 0.08, modal=True, modal_mult=1, Zmax=9, D=0.4),
+         zsq4=ao_power_spectra.zernike_squared_filter(m.fabs, m.fx, m.fy, 0.4, 4).real)
+
+
+# ------------------------------------------------------------------ end-to-end
+E2E_KEYS_SCALAR = ["dx", "Npxls", "Npxls_pup", "L", "paa", "r0", "theta0", "tau0", "r0_los",
+                   "theta0_los", "tau0_los", "W0", "W0_sat", "diffraction_limit", "logamp_var",
+                   "phs_var", "fitting_error", "aniso_servo_error", "alias_error", "noise_error",
+                   "zenith_correction", "k", "dx_sat"]
+
+
+def capture_sim(name, p, note, full=True, stride=None):
+    t0 = time.time()
+    sim = fast.Fast(p)
+    t1 = time.time()
+    res = sim.run()
+    t2 = time.time()
+    d = {"params_json": np.array(params_to_json(p))}
+    for k in E2E_KEYS_SCALAR:
+        d[k] = np.array(getattr(sim, k))
+    d["h"] = sim.h
+    d["cn2"] = sim.cn2
+    d["wind_vector"] = sim.wind_vector
+    d["wind_speed"] = sim.wind_speed
+    d["pup_coords"] = sim.pup_coords
+    d["link_budget_keys"] = np.array(list(sim.link_budget.keys()))
+    d["link_budget_vals"] = np.array(list(sim.link_budget.values()), dtype=float)
+    d["phs_var_weights"] = np.asarray(sim.phs_var_weights)
+    d["r"] = res._r
+    d["logamp"] = sim.logamp.copy()
+    d["ref_init_s"] = np.array(t1 - t0)
+    d["ref_run_s"] = np.array(t2 - t1)
+    if full:
+        d["pupil"] = sim.pupil
+        d["pupil_mode"] = sim.pupil_mode
+        d["pupil_sat"] = sim.pupil_sat
+        d["pupil_mode_sat"] = sim.pupil_mode_sat
+        d["pupil_filter"] = sim.pupil_filter
+        d["lf_mask"] = np.asarray(sim.lf_mask)
+        d["powerspec"] = sim.powerspec
+        d["powerspec_per_layer"] = sim.powerspec_per_layer
+        d["turb_powerspec"] = sim.turb_powerspec
+        d["G_ao"] = np.asarray(sim.G_ao, dtype=float)
+        d["alias_powerspec"] = np.asarray(sim.alias_powerspec, dtype=float)
+        d["noise_powerspec"] = np.asarray(sim.noise_powerspec, dtype=float)
+        d["logamp_powerspec"] = sim.logamp_powerspec
+        d["phs_last_chunk"] = sim.phs.copy()
+        if sim.subharmonics:
+            d["powerspec_subharm"] = sim.powerspec_subharm
+            d["sh_fx"] = sim.freq.subharm.fx
+            d["sh_fy"] = sim.freq.subharm.fy
+            d["sh_df"] = sim.freq.subharm.df
+    else:
+        s = stride
+        d["stride"] = np.array(s)
+        d["powerspec_strided"] = sim.powerspec[::s, ::s].copy()
+        d["powerspec_centre"] = sim.powerspec[sim.Npxls // 2 - 16: sim.Npxls // 2 + 16,
+                                              sim.Npxls // 2 - 16: sim.Npxls // 2 + 16].copy()
+        d["powerspec_sum"] = np.array(sim.powerspec.sum())
+        d["W"] = sim.pupil * sim.pupil_mode
+        d["lf_mask_sum"] = np.array(np.asarray(sim.lf_mask).sum())
+    save(name, note + f" [ref init {t1-t0:.2f}s run {t2-t1:.2f}s]", True, **d)
+
+
+def e2e():
+    cases = {
+        "ao_alias": (dict(), "AO zonal + ALIAS"),
+        "noao": (dict(AO_MODE="NOAO"), "NOAO, L0=inf"),
+        "noao_L0": (dict(AO_MODE="NOAO", L0=25.0, l0=0.005), "NOAO, L0=25, l0=5mm"),
+        "tt": (dict(AO_MODE="TT"), "TT (modal, Zmax=3)"),
+        "noise": (dict(NOISE=0.3), "AO + ALIAS + NOISE 0.3"),
+        "noalias_noise": (dict(ALIAS=False, NOISE=1.0), "AO, no alias, NOISE 1"),
+        "modal": (dict(MODAL=True, MODAL_MULT=0.8), "AO modal radial cut"),
+        "modal_zmax": (dict(MODAL=True, ZMAX=10), "AO modal Zernike Zmax=10"),
+        "lgsao": (dict(AO_MODE="LGSAO"), "LGSAO"),
+        "subharm": (dict(SUBHARM=True, AO_MODE="NOAO", L0=40.0), "NOAO + SUBHARM, L0=40"),
+        "subharm_ao": (dict(SUBHARM=True), "AO + ALIAS + SUBHARM"),
+        "coherent": (dict(COHERENT=True), "AO, COHERENT detection"),
+        "down": (dict(PROP_DIR="down"), "downlink"),
+        "obsc": (dict(OBSC_GROUND=0.05, OBSC_SAT=0.03), "central obscurations"),
+        "axicon": (dict(W0=0.06, AXICON=True, OBSC_GROUND=0.05), "axicon launch, fixed W0"),
+        "w0fixed": (dict(W0=0.07), "fixed W0"),
+        "lsat_aniso": (dict(L_SAT=500e3, ANISO_DL=[20.0, -10.0], AZIMUT_SAT=35.0, DTHETA=[3.0, 2.0]),
+                       "L_SAT + ANISO_DL + AZIMUT_SAT optional keys"),
+        "oddNp": (dict(D_GROUND=0.205, NPXLS=48), "Np odd (23), N=48 (non power of two)"),
+        "autosize": (dict(NPXLS="auto", DX="auto", NITER=4, NCHUNKS=1), "auto DX and NPXLS"),
+    }
+    for name, (over, note) in cases.items():
+        capture_sim("e2e_" + name, base_params(**over), note)
+
+
+def default_cfg():
+    h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
+    p = dict(fast.conf.DEFAULTS)
+    p.update({"NPXLS": "auto", "DX": 0.01, "NITER": 20, "NCHUNKS": 2, "TEMPORAL": False, "FFTW": True,
+              "SEED": 1, "W0": "opt", "D_GROUND": 0.8, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w,
+              "WIND_DIR": [0, 90, 180, 270], "ZENITH_ANGLE": 55, "DSUBAP": 0.1, "LOGLEVEL": "ERROR",
+              "H_SAT": 36e6, "AO_MODE": "AO", "ALIAS": True})
+    capture_sim("e2e_default164", p, "test/test_params.py with TEMPORAL False, FFTW True, SEED 1 (auto N=164)")
+    p256 = dict(p)
+    p256.update({"NPXLS": 256, "NITER": 100, "NCHUNKS": 10})
+    capture_sim("cfg1_256", p256, "BASELINE config 1: NPXLS 256, NITER 100, NCHUNKS 10", full=False, stride=8)
+    return p
+
+
+def big(p):
+    pb = dict(p)
+    pb.update({"NPXLS": 1024, "NITER": 8, "NCHUNKS": 2, "AO_MODE": "NOAO", "SEED": 3})
+    capture_sim("big_noao_1024", pb, "BASELINE config 2 geometry, NITER 8", full=False, stride=16)
+    pb2 = dict(pb)
+    pb2.update({"L0": 25.0})
+    capture_sim("big_noao_L0_1024", pb2, "config 2 with L0=25", full=False, stride=16)
+    pb3 = dict(pb)
+    pb3.update({"AO_MODE": "AO", "ALIAS": True})
+    capture_sim("big_ao_1024", pb3, "BASELINE config 3 geometry (AO + ALIAS), NITER 8", full=False, stride=16)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    print("capturing into", OUT)
+    kat_fft()
+    kat_detector()
+    kat_small()
+    e2e()
+    p = default_cfg()
+    if "--no-big" not in sys.argv:
+        big(p)
+    with open(os.path.join(OUT, "MANIFEST.md"), "w") as f:
+        f.write("# Golden fixtures captured from the reference (tools/capture_golden/capture.py)\n\n")
+        f.write(f"numpy {np.__version__}; reference snapshot /root/reference (2025-04-04).\n")
+        f.write("'stand-in dependent' = values pass through our aotools stand-ins "
+                "(tools/capture_golden/shims/README.md).\n\n")
+        f.write("| fixture | bytes | stand-in dependent | content |\n|---|---|---|---|\n")
+        for name, size, st, note in MANIFEST:
+            f.write(f"| {name}.npz | {size} | {st} | {note} |\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,15 @@
+"""fast_amd -- the Monte-Carlo hot path of FAST (ojdf/fast) on AMD MI355X (gfx950).
+
+Public surface = the reference's for this path: `Fast`, `FastResult`, `conf`, `turbulence_models`.
+Compute lives in libfastmc.so (hand-written HIP behind the C-ABI of include/fastmc.h),
+loaded with ctypes; there is no CPU fallback.
+"""
+from .fast import Fast, FastResult
+from . import conf
+from . import turbulence_models
+from . import host
+from . import _lib
+from ._lib import FastMCError
+
+__version__ = "0.1.0"
+__all__ = ["Fast", "FastResult", "conf", "turbulence_models", "host", "FastMCError"]

@@ -1,0 +1,258 @@
+"""ctypes binding of libfastmc.so (include/fastmc.h).  No torch, no fallback: if the library
+is missing or no gfx950 device is visible, the calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfastmc.so")
+
+F64, F32 = 0, 1
+AO_MODES = {"NOAO": 0, "AO": 1, "TT": 2, "LGSAO": 3}
+PS_NSCALARS = 6
+
+EXPORTS = [
+    "fastmc_version", "fastmc_last_error", "fastmc_device_count", "fastmc_create", "fastmc_destroy",
+    "fastmc_set_spectrum", "fastmc_set_pupil", "fastmc_set_subharm", "fastmc_run", "fastmc_run_coeffs",
+    "fastmc_screens_coeffs", "fastmc_screens", "fastmc_rng_coeffs", "fastmc_rng_logamp", "fastmc_histogram",
+    "fastmc_last_timing", "fastmc_kernel_path", "fastmc_set_batch", "fastmc_powerspec",
+    "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_gather", "fastmc_comm_destroy",
+]
+
+
+class FastMCError(RuntimeError):
+    pass
+
+
+class PsParams(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("n_layers", C.c_int32), ("dx", C.c_double), ("wvl", C.c_double),
+        ("L0", C.c_double), ("l0", C.c_double), ("ao_mode", C.c_int32), ("alias", C.c_int32),
+        ("noise", C.c_double), ("d_wfs", C.c_double), ("t_loop", C.c_double), ("t_exp", C.c_double),
+        ("dtheta", C.c_double * 2), ("cn2", C.c_void_p), ("h", C.c_void_p), ("wind", C.c_void_p),
+        ("lf_mask", C.c_void_p), ("pupil_filter", C.c_void_p), ("lgs_z", C.c_void_p), ("simpson_w", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load libfastmc.so once.  Raises FastMCError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FastMCError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or `make -C fast_amd/csrc`).  fast_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    dp, vp, i64, u64 = C.POINTER(C.c_double), C.c_void_p, C.c_int64, C.c_uint64
+    L.fastmc_version.restype = C.c_int
+    L.fastmc_last_error.restype = C.c_char_p
+    L.fastmc_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.fastmc_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.fastmc_destroy.argtypes = [vp]
+    L.fastmc_destroy.restype = None
+    L.fastmc_set_spectrum.argtypes = [vp, dp, C.c_double]
+    L.fastmc_set_pupil.argtypes = [vp, dp, C.c_int, C.c_double]
+    L.fastmc_set_subharm.argtypes = [vp, dp, dp, dp, dp]
+    L.fastmc_run.argtypes = [vp, u64, i64, i64, dp, C.c_double, C.c_int, dp]
+    L.fastmc_run_coeffs.argtypes = [vp, dp, dp, i64, dp, dp, dp, C.c_int, dp]
+    L.fastmc_screens_coeffs.argtypes = [vp, dp, dp, i64, dp, dp, dp]
+    L.fastmc_screens.argtypes = [vp, u64, i64, i64, dp]
+    L.fastmc_rng_coeffs.argtypes = [vp, u64, i64, dp]
+    L.fastmc_rng_logamp.argtypes = [vp, u64, i64, i64, dp]
+    L.fastmc_histogram.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.POINTER(i64)]
+    L.fastmc_last_timing.argtypes = [vp, dp, C.POINTER(i64)]
+    L.fastmc_kernel_path.argtypes = [vp, C.c_int]
+    L.fastmc_set_batch.argtypes = [vp, C.c_int]
+    L.fastmc_powerspec.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp, dp]
+    L.fastmc_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+    L.fastmc_comm_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
+    L.fastmc_comm_gather.argtypes = [vp, i64, dp, C.POINTER(i64), C.c_double, C.c_double, C.c_int]
+    L.fastmc_comm_destroy.argtypes = [vp]
+    for name in EXPORTS:
+        if name not in ("fastmc_last_error", "fastmc_destroy"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc < 0:
+        raise FastMCError(f"libfastmc error {rc}: {lib().fastmc_last_error().decode()}")
+    return rc
+
+
+def _dptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().fastmc_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def default_device():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+class Handle:
+    """One GPU + one (N, Np) Monte-Carlo problem (fastmc_t)."""
+
+    def __init__(self, N, Np, precision="f64", device=None):
+        self._h = C.c_void_p()
+        self.N, self.Np = int(N), int(Np)
+        self.precision = precision
+        prec = {"f64": F64, "f32": F32}[precision]
+        dev = default_device() if device is None else int(device)
+        _chk(lib().fastmc_create(C.byref(self._h), dev, self.N, self.Np, prec))
+        self.device = dev
+
+    def close(self):
+        if self._h:
+            lib().fastmc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_spectrum(self, powerspec, df):
+        ps = _f64(powerspec)
+        assert ps.shape == (self.N, self.N)
+        _chk(lib().fastmc_set_spectrum(self._h, _dptr(ps), float(df)))
+
+    def set_pupil(self, W, crop_lo, dx):
+        W = _f64(W)
+        assert W.shape == (self.Np, self.Np)
+        _chk(lib().fastmc_set_pupil(self._h, _dptr(W), int(crop_lo), float(dx)))
+
+    def set_subharm(self, powerspec_sh, fx, fy, df):
+        if powerspec_sh is None:
+            _chk(lib().fastmc_set_subharm(self._h, None, None, None, None))
+            return
+        a, b, c, d = _f64(powerspec_sh), _f64(fx), _f64(fy), _f64(df)
+        assert a.shape == (3, 3, 3) and b.shape == (3, 3, 3) and c.shape == (3, 3, 3) and d.shape == (3,)
+        _chk(lib().fastmc_set_subharm(self._h, _dptr(a), _dptr(b), _dptr(c), _dptr(d)))
+
+    def run(self, seed, real0, n_real, logamp=None, logamp_var=0.0, coherent=False):
+        la = _f64(logamp)
+        if la is not None:
+            assert la.shape == (2 * n_real,)
+        out = np.empty(2 * n_real * (2 if coherent else 1), dtype=np.float64)
+        _chk(lib().fastmc_run(self._h, int(seed) & (2 ** 64 - 1), int(real0), int(n_real), _dptr(la), float(logamp_var),
+                              int(bool(coherent)), _dptr(out)))
+        return out.view(np.complex128) if coherent else out
+
+    def run_coeffs(self, coeff_re, coeff_im, logamp, coherent=False, sh_re=None, sh_im=None):
+        cr, ci, la = _f64(coeff_re), _f64(coeff_im), _f64(logamp)
+        n_real = cr.shape[0]
+        assert cr.shape == (n_real, self.N, self.N) and ci.shape == cr.shape and la.shape == (2 * n_real,)
+        sr, si = _f64(sh_re), _f64(sh_im)
+        out = np.empty(2 * n_real * (2 if coherent else 1), dtype=np.float64)
+        _chk(lib().fastmc_run_coeffs(self._h, _dptr(cr), _dptr(ci), n_real, _dptr(sr), _dptr(si), _dptr(la),
+                                     int(bool(coherent)), _dptr(out)))
+        return out.view(np.complex128) if coherent else out
+
+    def screens_coeffs(self, coeff_re, coeff_im, sh_re=None, sh_im=None):
+        cr, ci = _f64(coeff_re), _f64(coeff_im)
+        n_real = cr.shape[0]
+        sr, si = _f64(sh_re), _f64(sh_im)
+        phs = np.empty((2 * n_real, self.Np, self.Np), dtype=np.float64)
+        _chk(lib().fastmc_screens_coeffs(self._h, _dptr(cr), _dptr(ci), n_real, _dptr(sr), _dptr(si), _dptr(phs)))
+        return phs
+
+    def screens(self, seed, real0, n_real):
+        phs = np.empty((2 * n_real, self.Np, self.Np), dtype=np.float64)
+        _chk(lib().fastmc_screens(self._h, int(seed) & (2 ** 64 - 1), int(real0), int(n_real), _dptr(phs)))
+        return phs
+
+    def rng_coeffs(self, seed, real):
+        out = np.empty((self.N, self.N), dtype=np.complex128)
+        _chk(lib().fastmc_rng_coeffs(self._h, int(seed) & (2 ** 64 - 1), int(real), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def rng_logamp(self, seed, iter0, n_iter):
+        out = np.empty(n_iter, dtype=np.float64)
+        _chk(lib().fastmc_rng_logamp(self._h, int(seed) & (2 ** 64 - 1), int(iter0), int(n_iter), _dptr(out)))
+        return out
+
+    def histogram(self, lo_db, hi_db, nbins):
+        bins = np.zeros(nbins + 2, dtype=np.int64)
+        _chk(lib().fastmc_histogram(self._h, float(lo_db), float(hi_db), int(nbins), bins.ctypes.data_as(C.POINTER(C.c_int64))))
+        return bins
+
+    def last_timing(self):
+        t = np.zeros(4)
+        n = np.zeros(4, dtype=np.int64)
+        _chk(lib().fastmc_last_timing(self._h, _dptr(t), n.ctypes.data_as(C.POINTER(C.c_int64))))
+        return {"total_ms": t[0], "rows_ms": t[1], "cols_ms": t[2], "finalize_ms": t[3],
+                "rows_launches": int(n[1]), "cols_launches": int(n[2]), "finalize_launches": int(n[3])}
+
+    def kernel_path(self, force=-1):
+        return _chk(lib().fastmc_kernel_path(self._h, int(force)))
+
+    def set_batch(self, batch):
+        _chk(lib().fastmc_set_batch(self._h, int(batch)))
+
+    # ---- RCCL
+    def comm_init(self, unique_id, world_size, rank):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _chk(lib().fastmc_comm_init(self._h, buf, int(world_size), int(rank)))
+
+    def comm_gather(self, n_local, world_size, hist_range=None):
+        allp = np.empty(n_local * world_size, dtype=np.float64)
+        hist = None
+        lo = hi = 0.0
+        nb = 1
+        if hist_range is not None:
+            lo, hi, nb = hist_range
+            hist = np.zeros(nb + 2, dtype=np.int64)
+        _chk(lib().fastmc_comm_gather(self._h, int(n_local), _dptr(allp),
+                                      None if hist is None else hist.ctypes.data_as(C.POINTER(C.c_int64)),
+                                      float(lo), float(hi), int(nb)))
+        return allp, hist
+
+
+def comm_unique_id():
+    buf = (C.c_uint8 * 128)()
+    _chk(lib().fastmc_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def powerspec(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, dtheta, cn2, h, wind, lf_mask,
+              pupil_filter, simpson_w, lgs_z=None, per_layer=False, device=None):
+    """fastmc_powerspec: AO-residual PSD grid + Simpson scalars on the GPU.
+    Returns dict(powerspec, powerspec_per_layer|None, logamp_powerspec, scalars..., kernel_ms)."""
+    cn2, h, wind = _f64(cn2), _f64(h), _f64(wind)
+    Lr = len(cn2)
+    mask, pf, z, w = _f64(lf_mask), _f64(pupil_filter), _f64(lgs_z), _f64(simpson_w)
+    assert mask.shape == (N, N) and w.shape == (N,) and wind.shape == (Lr, 2)
+    p = PsParams()
+    p.N, p.n_layers, p.dx, p.wvl, p.L0, p.l0 = int(N), Lr, float(dx), float(wvl), float(L0), float(l0)
+    p.ao_mode, p.alias, p.noise, p.d_wfs = AO_MODES[ao_mode], int(bool(alias)), float(noise), float(d_wfs)
+    p.t_loop, p.t_exp = float(t_loop), float(t_exp)
+    p.dtheta[0], p.dtheta[1] = float(dtheta[0]), float(dtheta[1])
+    p.cn2, p.h, p.wind = cn2.ctypes.data, h.ctypes.data, wind.ctypes.data
+    p.lf_mask, p.simpson_w = mask.ctypes.data, w.ctypes.data
+    p.pupil_filter = None if pf is None else pf.ctypes.data
+    p.lgs_z = None if z is None else z.ctypes.data
+    ps = np.empty((N, N))
+    la = np.empty((N, N))
+    pl = np.empty((Lr, N, N)) if per_layer else None
+    sc = np.empty(PS_NSCALARS + Lr)
+    ms = C.c_double(0.0)
+    dev = default_device() if device is None else int(device)
+    _chk(lib().fastmc_powerspec(dev, C.byref(p), _dptr(ps), _dptr(pl), _dptr(la), _dptr(sc), C.byref(ms)))
+    return {"powerspec": ps, "powerspec_per_layer": pl, "logamp_powerspec": la,
+            "aniso_servo_error": sc[0], "alias_error": sc[1], "noise_error": sc[2], "fitting_error": sc[3],
+            "phs_var": sc[4], "logamp_var": sc[5], "phs_var_weights": sc[6:].copy(), "kernel_ms": ms.value}

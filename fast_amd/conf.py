@@ -1,0 +1,71 @@
+"""Configuration: dict or .py file defining `p`, defaults filled in with a warning.
+Mirrors fast/conf.py:11-116 of the reference (same keys, same defaults), plus the GPU keys."""
+import importlib.util
+import logging
+
+import numpy
+
+logger = logging.getLogger(__name__)
+
+DEFAULTS = {
+    # simulation
+    'NPXLS': 'auto', 'DX': 'auto', 'NITER': 1000, 'SUBHARM': False, 'FFTW': False, 'FFTW_THREADS': 1,
+    'NCHUNKS': 10, 'TEMPORAL': False, 'DT': 0.001, 'LOGFILE': None, 'LOGLEVEL': "INFO", 'SEED': None,
+    # transmitter / receiver
+    'W0': "opt", 'D_GROUND': 1.0, 'OBSC_GROUND': 0, 'D_SAT': 0.1, 'OBSC_SAT': 0, 'WVL': 1550e-9,
+    'AXICON': False, 'POWER': 1, 'SMF': True,
+    # turbulence and link
+    'H_SAT': 36e6, 'L_SAT': None, 'H_TURB': numpy.array([0, 10e3]), 'CN2_TURB': numpy.array([100e-15, 100e-15]),
+    'WIND_SPD': numpy.array([10, 10]), 'WIND_DIR': numpy.array([90., 0.]), 'L0': numpy.inf, 'l0': 1e-06,
+    'ZENITH_ANGLE': 0, 'PROP_DIR': 'up', 'DTHETA': [4, 0], 'TRANSMISSION': 1,
+    # adaptive optics
+    'AO_MODE': 'AO', 'DSUBAP': 0.02, 'TLOOP': 0.001, 'TEXP': 0.001, 'ALIAS': True, 'NOISE': 0.0,
+    'MODAL': False, 'MODAL_MULT': 1, 'ZMAX': None,
+    # comms
+    'COHERENT': False, 'MODULATION': None, 'EsN0': None,
+}
+
+# Keys of the MI355X backend (not in the reference).  Filled silently.
+GPU_DEFAULTS = {
+    'GPU_PRECISION': 'f64',   # 'f64' (complex128 pipeline, reference precision) or 'f32'
+    'GPU_RNG': 'device',      # 'device': Philox on the GPU; 'host': numpy draws, reference order (parity mode)
+    'GPU_DEVICE': None,       # HIP device index; None -> LOCAL_RANK or 0
+    'GPU_BATCH': 0,           # realisations in flight per launch (0 = library default)
+}
+
+
+class ConfigParser():
+
+    def __init__(self, fname_or_dict):
+        if type(fname_or_dict) == dict:
+            self.config = fname_or_dict
+            self.fname = None
+        elif type(fname_or_dict) == str:
+            self.fname = fname_or_dict
+            self.config = {}
+            self.load(fname_or_dict)
+        else:
+            raise Exception("Either config file name or params dict required")
+        self.defaults = {}
+        self.set_defaults()
+        self.check()
+
+    def load(self, fname):
+        if fname.split('.')[-1] == "py":
+            spec = importlib.util.spec_from_file_location("", fname)
+            module = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(module)
+            self.config = module.p
+            return
+        raise Exception("Require .py config file")
+
+    def check(self):
+        for key, val in self.defaults.items():
+            if key not in self.config:
+                logger.warning(f"Config parameter {key} not defined in {self.fname}, setting default value of {val}")
+                self.config[key] = val
+        for key, val in GPU_DEFAULTS.items():
+            self.config.setdefault(key, val)
+
+    def set_defaults(self):
+        self.defaults = DEFAULTS

@@ -1,0 +1,108 @@
+// emu_wavefft.cpp -- host-side lane emulation of fmc_wavefft.h (no GPU needed).
+// Runs every per-lane phase of pruned_row_fft in a loop over 64 lanes, with the LDS images in
+// ordinary arrays, and compares the window outputs with a naive O(N^2) DFT in long double,
+// including the fftshift semantics of the reference (fast/funcs.py:213-215).
+// Exit code 0 = all cases within tolerance.  Driven by tests/test_emu_wavefft.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "fmc_core.h"
+#include "fmc_wavefft.h"
+
+using namespace fmc;
+
+template <class R, int P, int NS>
+struct HostExec {
+  LaneRegs<R, P, NS> regs[WAVE];
+  template <class F> void each(F f) {
+    for (int l = 0; l < WAVE; ++l) f(l, regs[l]);
+  }
+  void sync() {}
+};
+
+static void cs_turns(double t, double* c, double* s) {
+  *c = std::cos(2.0 * M_PI * t);
+  *s = std::sin(2.0 * M_PI * t);
+}
+
+template <class R, int P, int NS>
+static double run_case(int lo, int Np, unsigned seed) {
+  constexpr int N = WAVE * P;
+  using G = WaveGeom<R, P>;
+  using E = typename Xch<R>::E;
+  std::mt19937_64 gen(seed);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  std::vector<double> inr(N), ini(N);
+  for (int k = 0; k < N; ++k) { inr[k] = nd(gen); ini[k] = nd(gen); }
+
+  const int omS = NS * WAVE;
+  std::vector<cpx<R>> tw1((size_t)P * WAVE), om((size_t)8 * omS);
+  build_tw1<R>(tw1.data(), P, cs_turns);
+  build_om<R>(om.data(), omS, P, lo, Np, true, cs_turns);
+  std::vector<E> xbuf(G::XELEMS);
+
+  static HostExec<R, P, NS> ex;
+  // the kernels fold the input-side fftshift sign (-1)^k into the spectrum amplitude
+  for (int l = 0; l < WAVE; ++l)
+    for (int j = 0; j < P; ++j) {
+      const int k = l + WAVE * j;
+      const double sg = (k & 1) ? -1.0 : 1.0;
+      ex.regs[l].v[j] = mk<R>((R)(sg * inr[k]), (R)(sg * ini[k]));
+    }
+  pruned_row_fft<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
+
+  // reference: fftshift(fft(fftshift(in)))[p], p = lo + oi   (even N: h = N/2 both ways)
+  double worst = 0.0, scale = 0.0;
+  const int h = N / 2;
+  for (int oi = 0; oi < Np; ++oi) {
+    const int p = lo + oi;
+    long double sr = 0, si = 0;
+    for (int k = 0; k < N; ++k) {
+      // out[p] = sum_k in[k] w^{(p-h)(k+h)}
+      const long long e = (((long long)(p - h) * (k + h)) % N + N) % N;
+      const long double a = -2.0L * M_PIl * (long double)e / N;
+      const long double c = cosl(a), s = sinl(a);
+      sr += inr[k] * c - ini[k] * s;
+      si += inr[k] * s + ini[k] * c;
+    }
+    const int l = oi % WAVE, s = oi / WAVE;
+    const double gr = ex.regs[l].xr[s], gi = ex.regs[l].xi[s];
+    worst = std::fmax(worst, std::fmax(std::fabs(gr - (double)sr), std::fabs(gi - (double)si)));
+    scale = std::fmax(scale, std::fmax(std::fabs((double)sr), std::fabs((double)si)));
+  }
+  return worst / scale;
+}
+
+template <class R, int P, int NS>
+static int sweep(const char* name, double tol) {
+  constexpr int N = WAVE * P;
+  int bad = 0;
+  const int cases[][2] = {{(N - 82) / 2, 82}, {0, 64 * NS < N ? 64 * NS : N}, {N - 5, 5}, {(N - 23) / 2, 23},
+                          {(N - 1) / 2, 1}, {7, 64 * NS - 3 < N - 7 ? 64 * NS - 3 : N - 7}, {(N - 128) / 2, NS >= 2 ? 128 : 64}};
+  for (auto& c : cases) {
+    if (c[1] > 64 * NS || c[0] + c[1] > N || c[1] < 1) continue;
+    const double err = run_case<R, P, NS>(c[0], c[1], 1234u + c[0]);
+    const bool ok = err <= tol;
+    std::printf("%s P=%d NS=%d lo=%d Np=%d relerr=%.3e %s\n", name, P, NS, c[0], c[1], err, ok ? "ok" : "FAIL");
+    bad += !ok;
+  }
+  return bad;
+}
+
+int main() {
+  int bad = 0;
+  bad += sweep<double, 8, 2>("f64", 1e-13);
+  bad += sweep<double, 16, 2>("f64", 1e-13);
+  bad += sweep<double, 32, 2>("f64", 1e-13);
+  bad += sweep<double, 8, 8>("f64", 1e-13);
+  bad += sweep<double, 16, 16>("f64", 1e-13);
+  bad += sweep<float, 8, 2>("f32", 2e-5);
+  bad += sweep<float, 16, 2>("f32", 2e-5);
+  bad += sweep<float, 32, 2>("f32", 2e-5);
+  bad += sweep<float, 16, 16>("f32", 2e-5);
+  std::printf("%s\n", bad ? "EMU FAILED" : "EMU OK");
+  return bad ? 1 : 0;
+}

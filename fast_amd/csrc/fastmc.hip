@@ -1,0 +1,811 @@
+// fastmc.hip -- C-ABI of libfastmc.so (include/fastmc.h): handle, device memory, launches.
+// gfx950 only.  No CPU fallback anywhere: every compute entry point needs a device.
+#include "../../include/fastmc.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fmc_kernels.h"
+#include "fmc_powerspec.h"
+
+using namespace fmc;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return fail(FASTMC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__));      \
+  } while (0)
+
+// ------------------------------------------------------------------ context
+struct TimedSpan {
+  hipEvent_t a, b;
+  int family;
+};
+
+struct fastmc_ctx {
+  int device = 0, N = 0, Np = 0, lo = 0, precision = 0;
+  int path = 0, P = 0, NS = 0, omS = 0;
+  int batch = 0;
+  double df = 0, dx = 0, wsum = 0;
+  bool have_spec = false, have_pupil = false, have_sh = false;
+  hipStream_t stream = nullptr;
+  size_t rsz = 8;   // sizeof(R)
+
+  void* amp = nullptr;     // R[N*N]  unsigned (direct family)
+  void* amp_s = nullptr;   // R[N*N]  with (-1)^(ky+kx)  (wave family)
+  void* tw = nullptr;      // direct: cpx<R>[N]
+  void* tw1 = nullptr;     // wave
+  void* om = nullptr;      // wave
+  double* W = nullptr;
+  void* V = nullptr;
+  size_t V_cap = 0;        // realisations
+  double* partial = nullptr;
+  size_t partial_cap = 0;
+  double* out = nullptr;   // device results of the last run
+  size_t out_cap = 0;      // doubles
+  int64_t last_n_iter = 0;
+  int last_coherent = 0;
+  double* logamp = nullptr;
+  size_t logamp_cap = 0;
+  double* cre = nullptr;
+  double* cim = nullptr;
+  size_t coef_cap = 0;     // realisations
+  double* phs = nullptr;
+  size_t phs_cap = 0;
+  // sub-harmonics
+  double* sh_scale = nullptr;  // [27]
+  double* sh_mu = nullptr;     // [27][2]
+  double* sh_ex = nullptr;     // [27][Np][2]
+  double* sh_ey = nullptr;
+  double* sh_coef = nullptr;   // [batch][27][2]
+  double* sh_mean = nullptr;
+  double* sh_in_re = nullptr;  // host-mode coefficients [batch][27]
+  double* sh_in_im = nullptr;
+  size_t sh_cap = 0;
+  unsigned long long* hist = nullptr;
+  size_t hist_cap = 0;
+  // timing
+  std::vector<TimedSpan> spans;
+  std::vector<hipEvent_t> pool;
+  size_t pool_used = 0;
+  double t_ms[4] = {0, 0, 0, 0};
+  int64_t t_n[4] = {0, 0, 0, 0};
+  // RCCL
+  void* rccl_lib = nullptr;
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0;
+  double* gather_buf = nullptr;
+  size_t gather_cap = 0;
+};
+
+static void cs_turns(double t, double* c, double* s) {
+  // exact at multiples of 1/8 turn, else libm on the reduced angle
+  const double a = 2.0 * M_PI * t;
+  *c = std::cos(a);
+  *s = std::sin(a);
+}
+
+template <class T>
+static int dev_alloc(T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+  return 0;
+}
+#define TRY(x)            \
+  do {                    \
+    int r__ = (x);        \
+    if (r__ != 0) return r__; \
+  } while (0)
+
+static int grow(double** p, size_t* cap, size_t need) {
+  if (*cap >= need) return 0;
+  if (*p) HIPCHK(hipFree(*p));
+  *p = nullptr;
+  *cap = 0;
+  HIPCHK(hipMalloc((void**)p, need * sizeof(double)));
+  *cap = need;
+  return 0;
+}
+
+static hipEvent_t next_event(fastmc_ctx* h) {
+  if (h->pool_used == h->pool.size()) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    h->pool.push_back(e);
+  }
+  return h->pool[h->pool_used++];
+}
+struct Span {
+  fastmc_ctx* h;
+  hipEvent_t a, b;
+  int fam;
+  Span(fastmc_ctx* h_, int fam_) : h(h_), fam(fam_) {
+    a = next_event(h);
+    b = next_event(h);
+    hipEventRecord(a, h->stream);
+  }
+  ~Span() {
+    hipEventRecord(b, h->stream);
+    h->spans.push_back({a, b, fam});
+  }
+};
+static void timing_begin(fastmc_ctx* h) {
+  h->spans.clear();
+  h->pool_used = 0;
+  for (int i = 0; i < 4; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+}
+static void timing_end(fastmc_ctx* h) {   // after stream sync
+  for (auto& s : h->spans) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, s.a, s.b);
+    h->t_ms[1 + s.family] += ms;
+    h->t_n[1 + s.family] += 1;
+  }
+  if (!h->spans.empty()) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, h->spans.front().a, h->spans.back().b);
+    h->t_ms[0] = ms;
+    h->t_n[0] = (int64_t)h->spans.size();
+  }
+}
+
+// ------------------------------------------------------------------ misc entry points
+extern "C" int fastmc_version(void) { return FASTMC_VERSION; }
+extern "C" const char* fastmc_last_error(void) { return g_err.c_str(); }
+extern "C" int fastmc_device_count(int* n) {
+  if (!n) return fail(FASTMC_EINVAL, "n is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { *n = 0; return fail(FASTMC_ENODEV, hipGetErrorString(e)); }
+  *n = c;
+  return 0;
+}
+
+static bool wave_supported(int N) { return N == 512 || N == 1024 || N == 2048; }
+
+extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int precision) {
+  if (!out) return fail(FASTMC_EINVAL, "handle pointer is NULL");
+  *out = nullptr;
+  if (N < 4 || N > 4096) return fail(FASTMC_EINVAL, "N must be in [4, 4096]");
+  if (Np < 1 || Np > N) return fail(FASTMC_EINVAL, "Np must be in [1, N]");
+  if (precision != FASTMC_F64 && precision != FASTMC_F32) return fail(FASTMC_EINVAL, "precision must be FASTMC_F64 or FASTMC_F32");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(FASTMC_ENODEV, "no HIP device visible: libfastmc has no CPU fallback");
+  if (device_id < 0 || device_id >= count) return fail(FASTMC_EINVAL, "device_id out of range");
+  HIPCHK(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device_id));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(FASTMC_ENODEV, std::string("device is ") + prop.gcnArchName + ", libfastmc is built for gfx950 only");
+  fastmc_ctx* h = new fastmc_ctx();
+  h->device = device_id;
+  h->N = N;
+  h->Np = Np;
+  h->precision = precision;
+  h->rsz = precision == FASTMC_F64 ? 8 : 4;
+  h->path = wave_supported(N) ? 1 : 0;
+  h->P = N / 64;
+  h->NS = (Np + 63) / 64;
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; return fail(FASTMC_EHIP, hipGetErrorString(e)); }
+  *out = h;
+  return 0;
+}
+
+extern "C" void fastmc_destroy(fastmc_t* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->comm) fastmc_comm_destroy(h);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->amp, h->amp_s, h->tw, h->tw1, h->om, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+                  h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_in_re,
+                  h->sh_in_im, h->hist, h->gather_buf};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  for (auto e : h->pool) hipEventDestroy(e);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  if (force == 1 && !wave_supported(h->N)) return fail(FASTMC_EINVAL, "wave kernels need N in {512, 1024, 2048}");
+  if (force == 0 || force == 1) h->path = force;
+  return h->path;
+}
+
+extern "C" int fastmc_set_batch(fastmc_t* h, int batch) {
+  if (!h || batch < 0) return fail(FASTMC_EINVAL, "bad batch");
+  h->batch = batch;
+  return 0;
+}
+
+static int default_batch(const fastmc_ctx* h) {
+  if (h->batch > 0) return h->batch;
+  // keep the V slab (batch * N * Np complex) around 128 MiB: resident in the 256 MiB Infinity Cache
+  const double per = (double)h->N * h->Np * 2 * h->rsz;
+  int b = (int)(128.0 * 1024 * 1024 / per);
+  b = std::max(1, std::min(b, 256));
+  if (b >= 8) b &= ~7;
+  return b;
+}
+
+// ------------------------------------------------------------------ set_spectrum / set_pupil
+template <class R>
+static int upload_spectrum(fastmc_ctx* h, const double* ps, double df) {
+  const int N = h->N;
+  std::vector<R> a((size_t)N * N), as((size_t)N * N);
+  for (int ky = 0; ky < N; ++ky)
+    for (int kx = 0; kx < N; ++kx) {
+      const double p = ps[(size_t)ky * N + kx];
+      const double v = std::sqrt(p) * df;
+      a[(size_t)ky * N + kx] = (R)v;
+      as[(size_t)ky * N + kx] = (R)(((ky + kx) & 1) ? -v : v);
+    }
+  if (!h->amp) HIPCHK(hipMalloc(&h->amp, sizeof(R) * N * N));
+  if (!h->amp_s) HIPCHK(hipMalloc(&h->amp_s, sizeof(R) * N * N));
+  HIPCHK(hipMemcpy(h->amp, a.data(), sizeof(R) * N * N, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->amp_s, as.data(), sizeof(R) * N * N, hipMemcpyHostToDevice));
+  // direct-family twiddles w_N^e
+  std::vector<cpx<R>> tw(N);
+  for (int e = 0; e < N; ++e) {
+    double c, s;
+    cs_turns((double)e / N, &c, &s);
+    tw[e] = mk<R>((R)c, (R)(-s));
+  }
+  if (!h->tw) HIPCHK(hipMalloc(&h->tw, sizeof(cpx<R>) * N));
+  HIPCHK(hipMemcpy(h->tw, tw.data(), sizeof(cpx<R>) * N, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int fastmc_set_spectrum(fastmc_t* h, const double* powerspec, double df) {
+  if (!h || !powerspec) return fail(FASTMC_EINVAL, "null argument");
+  const size_t n = (size_t)h->N * h->N;
+  for (size_t i = 0; i < n; ++i)
+    if (!(powerspec[i] >= 0.0) || std::isinf(powerspec[i]))
+      return fail(FASTMC_EINVAL, "powerspec must be finite and non-negative");
+  HIPCHK(hipSetDevice(h->device));
+  h->df = df;
+  TRY(h->precision == FASTMC_F64 ? upload_spectrum<double>(h, powerspec, df) : upload_spectrum<float>(h, powerspec, df));
+  h->have_spec = true;
+  return 0;
+}
+
+template <class R>
+static int upload_wave_tables(fastmc_ctx* h) {
+  const int P = h->P;
+  h->omS = h->NS * 64;
+  std::vector<cpx<R>> tw1((size_t)P * 64), om((size_t)8 * h->omS);
+  build_tw1<R>(tw1.data(), P, cs_turns);
+  build_om<R>(om.data(), h->omS, P, h->lo, h->Np, true, cs_turns);
+  if (h->tw1) HIPCHK(hipFree(h->tw1));
+  if (h->om) HIPCHK(hipFree(h->om));
+  HIPCHK(hipMalloc(&h->tw1, sizeof(cpx<R>) * tw1.size()));
+  HIPCHK(hipMalloc(&h->om, sizeof(cpx<R>) * om.size()));
+  HIPCHK(hipMemcpy(h->tw1, tw1.data(), sizeof(cpx<R>) * tw1.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->om, om.data(), sizeof(cpx<R>) * om.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, double dx) {
+  if (!h || !W) return fail(FASTMC_EINVAL, "null argument");
+  if (crop_lo < 0 || crop_lo + h->Np > h->N) return fail(FASTMC_EINVAL, "window [crop_lo, crop_lo+Np) outside the grid");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t n = (size_t)h->Np * h->Np;
+  double s = 0.0;
+  for (size_t i = 0; i < n; ++i) s += W[i];
+  h->wsum = s;
+  h->lo = crop_lo;
+  h->dx = dx;
+  if (!h->W) HIPCHK(hipMalloc((void**)&h->W, n * sizeof(double)));
+  HIPCHK(hipMemcpy(h->W, W, n * sizeof(double), hipMemcpyHostToDevice));
+  if (wave_supported(h->N))
+    TRY(h->precision == FASTMC_F64 ? upload_wave_tables<double>(h) : upload_wave_tables<float>(h));
+  h->have_pupil = true;
+  return 0;
+}
+
+extern "C" int fastmc_set_subharm(fastmc_t* h, const double* ps_sh, const double* fx, const double* fy, const double* df) {
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  if (!ps_sh) { h->have_sh = false; return 0; }
+  if (!fx || !fy || !df) return fail(FASTMC_EINVAL, "fx, fy, df required");
+  if (!h->have_pupil) return fail(FASTMC_ESTATE, "call fastmc_set_pupil first (window position and dx)");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N, Np = h->Np;
+  // pixel coordinates of funcs.py:229-231: arange(-D/2, D/2, dx), D = N dx
+  const double D = h->dx * N;
+  std::vector<double> coords(N);
+  for (int j = 0; j < N; ++j) coords[j] = -D / 2 + j * h->dx;
+  std::vector<double> scale(27), mu(54), ex((size_t)27 * Np * 2), ey((size_t)27 * Np * 2);
+  for (int m = 0; m < 27; ++m) {
+    const int lvl = m / 9;
+    scale[m] = std::sqrt(ps_sh[m]) * df[lvl];
+    double mxr = 0, mxi = 0, myr = 0, myi = 0;
+    for (int j = 0; j < N; ++j) {
+      mxr += std::cos(coords[j] * fx[m]); mxi += std::sin(coords[j] * fx[m]);
+      myr += std::cos(coords[j] * fy[m]); myi += std::sin(coords[j] * fy[m]);
+    }
+    mxr /= N; mxi /= N; myr /= N; myi /= N;
+    mu[2 * m] = mxr * myr - mxi * myi;
+    mu[2 * m + 1] = mxr * myi + mxi * myr;
+    for (int i = 0; i < Np; ++i) {
+      const double c = coords[h->lo + i];
+      ex[((size_t)m * Np + i) * 2] = std::cos(c * fx[m]);
+      ex[((size_t)m * Np + i) * 2 + 1] = std::sin(c * fx[m]);
+      ey[((size_t)m * Np + i) * 2] = std::cos(c * fy[m]);
+      ey[((size_t)m * Np + i) * 2 + 1] = std::sin(c * fy[m]);
+    }
+  }
+  if (!h->sh_scale) {
+    TRY(dev_alloc(&h->sh_scale, 27));
+    TRY(dev_alloc(&h->sh_mu, 54));
+    TRY(dev_alloc(&h->sh_ex, (size_t)27 * Np * 2));
+    TRY(dev_alloc(&h->sh_ey, (size_t)27 * Np * 2));
+  }
+  HIPCHK(hipMemcpy(h->sh_scale, scale.data(), 27 * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->sh_mu, mu.data(), 54 * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->sh_ex, ex.data(), ex.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->sh_ey, ey.data(), ey.size() * 8, hipMemcpyHostToDevice));
+  h->have_sh = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------ launches
+template <class R, int P, int NS, int MODE>
+static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
+  const size_t lds = wave_lds_bytes<R, P>(A.omS);
+  hipFuncSetAttribute((const void*)k_rows_wave<R, P, NS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int grid = A.nb * (A.N / (WAVES_PER_WG * ROWS_PER_WAVE));
+  hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE>), dim3(grid), dim3(WAVES_PER_WG * 64), lds, h->stream, A);
+}
+template <class R, int P, int NS, int EPI>
+static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
+  const size_t lds = wave_lds_bytes<R, P>(A.omS);
+  hipFuncSetAttribute((const void*)k_cols_wave<R, P, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int groups = (A.Np + WAVES_PER_WG - 1) / WAVES_PER_WG;
+  hipLaunchKernelGGL((k_cols_wave<R, P, NS, EPI>), dim3(A.nb * groups), dim3(WAVES_PER_WG * 64), lds, h->stream, A);
+}
+
+template <class R, int P, int NS>
+static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  {
+    Span s(h, 0);
+    if (mode == 0) launch_rows_wave<R, P, NS, 0>(h, RA);
+    else launch_rows_wave<R, P, NS, 1>(h, RA);
+  }
+  {
+    Span s(h, 1);
+    if (epi == 0) launch_cols_wave<R, P, NS, 0>(h, CA);
+    else launch_cols_wave<R, P, NS, 1>(h, CA);
+  }
+}
+
+template <class R, int P>
+static int dispatch_wave_ns(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  // two instantiations per (R, P): windows up to 128 pixels, and the general case
+  if (h->NS <= 2) dispatch_wave<R, P, 2>(h, RA, CA, mode, epi);
+  else if (h->NS <= P) dispatch_wave<R, P, P>(h, RA, CA, mode, epi);
+  else return fail(FASTMC_EINVAL, "window too large for the wave kernels");
+  return 0;
+}
+
+template <class R>
+static int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  const size_t lds = (size_t)2 * h->N * sizeof(cpx<R>);
+  if (lds > 160 * 1024 - 4096) return fail(FASTMC_EINVAL, "N too large for the direct kernels at this precision");
+  {
+    Span s(h, 0);
+    if (mode == 0) {
+      hipFuncSetAttribute((const void*)k_rows_direct<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_direct<R, 0>), dim3(RA.nb * h->N), dim3(DIRECT_THREADS), lds, h->stream, RA);
+    } else {
+      hipFuncSetAttribute((const void*)k_rows_direct<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_direct<R, 1>), dim3(RA.nb * h->N), dim3(DIRECT_THREADS), lds, h->stream, RA);
+    }
+  }
+  {
+    Span s(h, 1);
+    if (epi == 0) {
+      hipFuncSetAttribute((const void*)k_cols_direct<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_cols_direct<R, 0>), dim3(CA.nb * h->Np), dim3(DIRECT_THREADS), lds, h->stream, CA);
+    } else {
+      hipFuncSetAttribute((const void*)k_cols_direct<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_cols_direct<R, 1>), dim3(CA.nb * h->Np), dim3(DIRECT_THREADS), lds, h->stream, CA);
+    }
+  }
+  return 0;
+}
+
+struct RunSpec {
+  int mode;                 // 0 device RNG, 1 host coefficients
+  int epi;                  // 0 powers, 1 screens
+  uint64_t seed;
+  int64_t real0, n_real;
+  const double* coeff_re;   // host
+  const double* coeff_im;
+  const double* sh_re;
+  const double* sh_im;
+  const double* logamp;     // host, 2*n_real
+  double logamp_var;
+  int coherent;
+  double* out;              // host
+  double* phs;              // host
+};
+
+template <class R>
+static int run_impl(fastmc_ctx* h, const RunSpec& S) {
+  const int N = h->N, Np = h->Np;
+  const size_t N2 = (size_t)N * N;
+  int B = default_batch(h);
+  if (S.mode == 1) B = std::max(1, std::min<int>(B, (int)(256.0 * 1024 * 1024 / (N2 * 8.0))));
+  if (S.epi == 1) B = std::max(1, std::min<int>(B, (int)(256.0 * 1024 * 1024 / (2.0 * Np * Np * 8.0))));
+  B = (int)std::min<int64_t>(B, S.n_real);
+
+  // buffers
+  if (h->V_cap < (size_t)B) {
+    if (h->V) HIPCHK(hipFree(h->V));
+    h->V = nullptr; h->V_cap = 0;
+    HIPCHK(hipMalloc(&h->V, (size_t)B * N * Np * sizeof(cpx<R>)));
+    h->V_cap = B;
+  }
+  TRY(grow(&h->partial, &h->partial_cap, (size_t)B * Np * 4));
+  const size_t out_need = (size_t)S.n_real * 2 * (S.coherent ? 2 : 1);
+  if (S.epi == 0) TRY(grow(&h->out, &h->out_cap, out_need));
+  if (S.epi == 0 && S.logamp) {
+    TRY(grow(&h->logamp, &h->logamp_cap, (size_t)S.n_real * 2));
+    HIPCHK(hipMemcpyAsync(h->logamp, S.logamp, (size_t)S.n_real * 16, hipMemcpyHostToDevice, h->stream));
+  }
+  if (S.mode == 1 && h->coef_cap < (size_t)B) {
+    if (h->cre) HIPCHK(hipFree(h->cre));
+    if (h->cim) HIPCHK(hipFree(h->cim));
+    h->cre = h->cim = nullptr; h->coef_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->cre, (size_t)B * N2 * 8));
+    HIPCHK(hipMalloc((void**)&h->cim, (size_t)B * N2 * 8));
+    h->coef_cap = B;
+  }
+  if (S.epi == 1) TRY(grow(&h->phs, &h->phs_cap, (size_t)2 * B * Np * Np));
+  const bool sh = h->have_sh;
+  if (sh && h->sh_cap < (size_t)B) {
+    for (double** p : {&h->sh_coef, &h->sh_mean, &h->sh_in_re, &h->sh_in_im})
+      if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
+    TRY(dev_alloc(&h->sh_coef, (size_t)B * 54));
+    TRY(dev_alloc(&h->sh_mean, (size_t)B * 2));
+    TRY(dev_alloc(&h->sh_in_re, (size_t)B * 27));
+    TRY(dev_alloc(&h->sh_in_im, (size_t)B * 27));
+    h->sh_cap = B;
+  }
+  if (sh && S.mode == 1 && (!S.sh_re || !S.sh_im)) return fail(FASTMC_EINVAL, "sub-harmonics are set: sh_re / sh_im required");
+
+  RngKey key{(uint32_t)S.seed, (uint32_t)(S.seed >> 32)};
+  timing_begin(h);
+  for (int64_t bs = 0; bs < S.n_real; bs += B) {
+    const int nb = (int)std::min<int64_t>(B, S.n_real - bs);
+    if (S.mode == 1) {
+      HIPCHK(hipMemcpyAsync(h->cre, S.coeff_re + (size_t)bs * N2, (size_t)nb * N2 * 8, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipMemcpyAsync(h->cim, S.coeff_im + (size_t)bs * N2, (size_t)nb * N2 * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    if (sh) {
+      ShCoefArgs SA;
+      SA.nb = nb; SA.key = key; SA.g0 = (uint64_t)(S.real0 + bs);
+      SA.sh_re = SA.sh_im = nullptr;
+      if (S.mode == 1) {
+        HIPCHK(hipMemcpyAsync(h->sh_in_re, S.sh_re + (size_t)bs * 27, (size_t)nb * 27 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->sh_in_im, S.sh_im + (size_t)bs * 27, (size_t)nb * 27 * 8, hipMemcpyHostToDevice, h->stream));
+        SA.sh_re = h->sh_in_re; SA.sh_im = h->sh_in_im;
+      }
+      SA.scale = h->sh_scale; SA.mu = h->sh_mu; SA.coef = h->sh_coef; SA.mean = h->sh_mean;
+      hipLaunchKernelGGL(k_subharm_coeffs, dim3((nb + 63) / 64), dim3(64), 0, h->stream, SA);
+    }
+    RowArgs<R> RA;
+    RA.N = N; RA.Np = Np; RA.lo = h->lo; RA.nb = nb;
+    RA.amp = (const R*)(h->path == 1 ? h->amp_s : h->amp);
+    RA.tw = (const cpx<R>*)(h->path == 1 ? h->tw1 : h->tw);
+    RA.om = (const cpx<R>*)h->om; RA.omS = h->omS;
+    RA.V = (cpx<R>*)h->V; RA.key = key; RA.g0 = (uint64_t)(S.real0 + bs);
+    RA.cre = h->cre; RA.cim = h->cim;
+    ColArgs<R> CA;
+    CA.N = N; CA.Np = Np; CA.lo = h->lo; CA.nb = nb;
+    CA.V = (const cpx<R>*)h->V; CA.tw = RA.tw; CA.om = RA.om; CA.omS = h->omS;
+    CA.W = h->W;
+    CA.sh.enabled = sh ? 1 : 0; CA.sh.coef = h->sh_coef; CA.sh.mean = h->sh_mean; CA.sh.ex = h->sh_ex; CA.sh.ey = h->sh_ey;
+    CA.partial = h->partial; CA.phs = h->phs;
+    if (h->path == 1) {
+      if (h->P == 8) TRY((dispatch_wave_ns<R, 8>(h, RA, CA, S.mode, S.epi)));
+      else if (h->P == 16) TRY((dispatch_wave_ns<R, 16>(h, RA, CA, S.mode, S.epi)));
+      else TRY((dispatch_wave_ns<R, 32>(h, RA, CA, S.mode, S.epi)));
+    } else {
+      TRY(dispatch_direct<R>(h, RA, CA, S.mode, S.epi));
+    }
+    if (S.epi == 0) {
+      Span sp(h, 2);
+      FinArgs FA;
+      FA.nb = nb; FA.Np = Np; FA.coherent = S.coherent; FA.n_real = S.n_real; FA.j0 = bs;
+      FA.partial = h->partial; FA.logamp = S.logamp ? h->logamp : nullptr;
+      FA.logamp_sigma = std::sqrt(S.logamp_var); FA.key = key; FA.g0 = (uint64_t)(S.real0 + bs);
+      FA.dx2 = h->dx * h->dx; FA.norm = h->wsum * (h->dx * h->dx); FA.out = h->out;
+      hipLaunchKernelGGL(k_finalize, dim3((nb + 63) / 64), dim3(64), 0, h->stream, FA);
+    } else {
+      // screens of this batch -> host: Re planes of [bs, bs+nb), Im planes offset by n_real
+      const size_t plane = (size_t)Np * Np;
+      HIPCHK(hipMemcpyAsync(S.phs + (size_t)bs * plane, h->phs, (size_t)nb * plane * 8, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipMemcpyAsync(S.phs + (size_t)(S.n_real + bs) * plane, h->phs + (size_t)nb * plane, (size_t)nb * plane * 8,
+                            hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    HIPCHK(hipGetLastError());
+  }
+  if (S.epi == 0)
+    HIPCHK(hipMemcpyAsync(S.out, h->out, out_need * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  timing_end(h);
+  if (S.epi == 0) { h->last_n_iter = 2 * S.n_real; h->last_coherent = S.coherent; }
+  return 0;
+}
+
+static int run_checked(fastmc_ctx* h, const RunSpec& S) {
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  if (!h->have_spec || !h->have_pupil) return fail(FASTMC_ESTATE, "set_spectrum and set_pupil must be called first");
+  if (S.n_real <= 0) return fail(FASTMC_EINVAL, "n_real must be positive");
+  if (S.real0 < 0) return fail(FASTMC_EINVAL, "real0 must be non-negative");
+  HIPCHK(hipSetDevice(h->device));
+  return h->precision == FASTMC_F64 ? run_impl<double>(h, S) : run_impl<float>(h, S);
+}
+
+extern "C" int fastmc_run(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real, const double* logamp,
+                          double logamp_var, int coherent, double* out) {
+  if (!out) return fail(FASTMC_EINVAL, "out is NULL");
+  if (!(logamp_var >= 0.0)) return fail(FASTMC_EINVAL, "logamp_var must be >= 0");
+  RunSpec S{0, 0, seed, real0, n_real, nullptr, nullptr, nullptr, nullptr, logamp, logamp_var, coherent, out, nullptr};
+  return run_checked(h, S);
+}
+
+extern "C" int fastmc_run_coeffs(fastmc_t* h, const double* coeff_re, const double* coeff_im, int64_t n_real,
+                                 const double* sh_re, const double* sh_im, const double* logamp, int coherent,
+                                 double* out) {
+  if (!coeff_re || !coeff_im || !logamp || !out) return fail(FASTMC_EINVAL, "null argument");
+  RunSpec S{1, 0, 0, 0, n_real, coeff_re, coeff_im, sh_re, sh_im, logamp, 0.0, coherent, out, nullptr};
+  return run_checked(h, S);
+}
+
+extern "C" int fastmc_screens_coeffs(fastmc_t* h, const double* coeff_re, const double* coeff_im, int64_t n_real,
+                                     const double* sh_re, const double* sh_im, double* phs) {
+  if (!coeff_re || !coeff_im || !phs) return fail(FASTMC_EINVAL, "null argument");
+  RunSpec S{1, 1, 0, 0, n_real, coeff_re, coeff_im, sh_re, sh_im, nullptr, 0.0, 0, nullptr, phs};
+  return run_checked(h, S);
+}
+
+extern "C" int fastmc_screens(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real, double* phs) {
+  if (!phs) return fail(FASTMC_EINVAL, "null argument");
+  RunSpec S{0, 1, seed, real0, n_real, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0, nullptr, phs};
+  return run_checked(h, S);
+}
+
+extern "C" int fastmc_rng_coeffs(fastmc_t* h, uint64_t seed, int64_t real, double* out) {
+  if (!h || !out) return fail(FASTMC_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->N, H = (N + 1) / 2;
+  double* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, (size_t)N * N * 16));
+  RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * H + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, d);
+  HIPCHK(hipMemcpyAsync(out, d, (size_t)N * N * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipFree(d));
+  return 0;
+}
+
+extern "C" int fastmc_rng_logamp(fastmc_t* h, uint64_t seed, int64_t iter0, int64_t n_iter, double* out) {
+  if (!h || !out || n_iter <= 0) return fail(FASTMC_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  double* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, (size_t)n_iter * 8));
+  RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
+  hipLaunchKernelGGL(k_rng_logamp, dim3((unsigned)((n_iter + 255) / 256)), dim3(256), 0, h->stream, key, (uint64_t)iter0,
+                     n_iter, d);
+  HIPCHK(hipMemcpyAsync(out, d, (size_t)n_iter * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipFree(d));
+  return 0;
+}
+
+static int histogram_device(fastmc_ctx* h, double lo, double hi, int nbins) {
+  if (h->last_n_iter <= 0) return fail(FASTMC_ESTATE, "no run results on the device");
+  if (nbins < 1 || !(hi > lo)) return fail(FASTMC_EINVAL, "bad histogram range");
+  if (h->hist_cap < (size_t)nbins + 2) {
+    if (h->hist) HIPCHK(hipFree(h->hist));
+    HIPCHK(hipMalloc((void**)&h->hist, ((size_t)nbins + 2) * 8));
+    h->hist_cap = (size_t)nbins + 2;
+  }
+  HIPCHK(hipMemsetAsync(h->hist, 0, ((size_t)nbins + 2) * 8, h->stream));
+  const int64_t n = h->last_n_iter;
+  hipLaunchKernelGGL(k_histogram, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->out, n, h->last_coherent, lo,
+                     hi, nbins, h->hist);
+  return 0;
+}
+
+extern "C" int fastmc_histogram(fastmc_t* h, double lo_db, double hi_db, int nbins, int64_t* bins) {
+  if (!h || !bins) return fail(FASTMC_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(h->device));
+  TRY(histogram_device(h, lo_db, hi_db, nbins));
+  HIPCHK(hipMemcpyAsync(bins, h->hist, ((size_t)nbins + 2) * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches) {
+  if (!h || !times_ms || !launches) return fail(FASTMC_EINVAL, "null argument");
+  for (int i = 0; i < 4; ++i) { times_ms[i] = h->t_ms[i]; launches[i] = h->t_n[i]; }
+  return 0;
+}
+
+// ------------------------------------------------------------------ power spectrum
+extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double* powerspec, double* per_layer,
+                                double* logamp_ps, double* scalars, double* kernel_ms) {
+  if (!p) return fail(FASTMC_EINVAL, "params is NULL");
+  const int N = p->N, L = p->n_layers;
+  if (N < 2 || N > 16384) return fail(FASTMC_EINVAL, "bad N");
+  if (L < 1 || L > PS_MAX_LAYERS) return fail(FASTMC_EINVAL, "n_layers must be in [1, 64]");
+  if (!p->cn2 || !p->h || !p->wind || !p->lf_mask || !p->simpson_w) return fail(FASTMC_EINVAL, "null array in params");
+  if (p->ao_mode < 0 || p->ao_mode > 3) return fail(FASTMC_EINVAL, "bad ao_mode");
+  if (p->ao_mode == FASTMC_LGSAO && !p->lgs_z) return fail(FASTMC_EINVAL, "LGSAO needs lgs_z");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(FASTMC_ENODEV, "no HIP device visible: libfastmc has no CPU fallback");
+  if (device_id < 0 || device_id >= count) return fail(FASTMC_EINVAL, "device_id out of range");
+  HIPCHK(hipSetDevice(device_id));
+  const size_t N2 = (size_t)N * N;
+  const int nq = PS_NQ + L;
+  double *d_cn2 = nullptr, *d_h = nullptr, *d_wind = nullptr, *d_mask = nullptr, *d_pf = nullptr, *d_z = nullptr,
+         *d_w = nullptr, *d_ps = nullptr, *d_pl = nullptr, *d_la = nullptr, *d_rows = nullptr, *d_sc = nullptr;
+  std::vector<double*> owned;
+  auto A = [&](double** q, size_t n) -> int {
+    hipError_t e = hipMalloc((void**)q, n * 8);
+    if (e != hipSuccess) return fail(FASTMC_EHIP, hipGetErrorString(e));
+    owned.push_back(*q);
+    return 0;
+  };
+  auto cleanup = [&]() { for (double* q : owned) hipFree(q); };
+  int rc = 0;
+  do {
+    if ((rc = A(&d_cn2, L)) || (rc = A(&d_h, L)) || (rc = A(&d_wind, 2 * L)) || (rc = A(&d_mask, N2)) || (rc = A(&d_w, N)) ||
+        (rc = A(&d_ps, N2)) || (rc = A(&d_la, N2)) || (rc = A(&d_rows, (size_t)N * nq)) || (rc = A(&d_sc, nq)))
+      break;
+    if (p->pupil_filter && (rc = A(&d_pf, N2))) break;
+    if (p->lgs_z && (rc = A(&d_z, N2))) break;
+    if (per_layer && (rc = A(&d_pl, N2 * L))) break;
+    hipMemcpy(d_cn2, p->cn2, L * 8, hipMemcpyHostToDevice);
+    hipMemcpy(d_h, p->h, L * 8, hipMemcpyHostToDevice);
+    hipMemcpy(d_wind, p->wind, 2 * L * 8, hipMemcpyHostToDevice);
+    hipMemcpy(d_mask, p->lf_mask, N2 * 8, hipMemcpyHostToDevice);
+    hipMemcpy(d_w, p->simpson_w, N * 8, hipMemcpyHostToDevice);
+    if (d_pf) hipMemcpy(d_pf, p->pupil_filter, N2 * 8, hipMemcpyHostToDevice);
+    if (d_z) hipMemcpy(d_z, p->lgs_z, N2 * 8, hipMemcpyHostToDevice);
+    PsArgs K;
+    K.N = N; K.L = L; K.ao_mode = p->ao_mode; K.alias = p->alias;
+    K.dx = p->dx; K.wvl = p->wvl; K.L0 = p->L0; K.l0 = p->l0; K.noise = p->noise; K.d_wfs = p->d_wfs;
+    K.t_loop = p->t_loop; K.t_exp = p->t_exp; K.dth_x = p->dtheta[0]; K.dth_y = p->dtheta[1];
+    K.cn2 = d_cn2; K.h = d_h; K.wind = d_wind; K.mask = d_mask; K.pfilter = d_pf; K.lgs_z = d_z; K.w = d_w;
+    K.powerspec = d_ps; K.per_layer = d_pl; K.logamp_ps = d_la; K.rowsums = d_rows;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_powerspec, dim3(N), dim3(PS_THREADS), 0, 0, K);
+    hipLaunchKernelGGL(k_ps_scalars, dim3((nq + 63) / 64), dim3(64), 0, 0, d_rows, d_w, N, nq, d_sc);
+    hipEventRecord(e1, 0);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipGetLastError();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (e != hipSuccess) { rc = fail(FASTMC_EHIP, hipGetErrorString(e)); break; }
+    if (kernel_ms) *kernel_ms = ms;
+    if (powerspec) hipMemcpy(powerspec, d_ps, N2 * 8, hipMemcpyDeviceToHost);
+    if (per_layer) hipMemcpy(per_layer, d_pl, N2 * L * 8, hipMemcpyDeviceToHost);
+    if (logamp_ps) hipMemcpy(logamp_ps, d_la, N2 * 8, hipMemcpyDeviceToHost);
+    if (scalars) {
+      std::vector<double> sc(nq);
+      hipMemcpy(sc.data(), d_sc, nq * 8, hipMemcpyDeviceToHost);
+      for (int i = 0; i < PS_NQ; ++i) scalars[i] = sc[i];
+      for (int l = 0; l < L; ++l) scalars[PS_NQ + l] = sc[PS_NQ + l] / sc[4];   // phs_var_weights
+    }
+  } while (0);
+  cleanup();
+  return rc;
+}
+
+// ------------------------------------------------------------------ RCCL (loaded on demand)
+struct RcclApi {
+  decltype(&ncclGetUniqueId) GetUniqueId;
+  decltype(&ncclCommInitRank) CommInitRank;
+  decltype(&ncclCommDestroy) CommDestroy;
+  decltype(&ncclAllGather) AllGather;
+  decltype(&ncclAllReduce) AllReduce;
+  decltype(&ncclGetErrorString) GetErrorString;
+  void* lib = nullptr;
+};
+static RcclApi g_rccl;
+static int load_rccl() {
+  if (g_rccl.lib) return 0;
+  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return fail(FASTMC_ECOMM, std::string("cannot load librccl: ") + dlerror());
+#define SYM(n)                                                        \
+  g_rccl.n = (decltype(g_rccl.n))dlsym(lib, "nccl" #n);                \
+  if (!g_rccl.n) return fail(FASTMC_ECOMM, "librccl lacks nccl" #n);
+  SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllGather) SYM(AllReduce) SYM(GetErrorString)
+#undef SYM
+  g_rccl.lib = lib;
+  return 0;
+}
+#define NCCLCHK(expr)                                                                          \
+  do {                                                                                         \
+    ncclResult_t r__ = (expr);                                                                 \
+    if (r__ != ncclSuccess) return fail(FASTMC_ECOMM, std::string(#expr) + ": " + g_rccl.GetErrorString(r__)); \
+  } while (0)
+
+extern "C" int fastmc_comm_unique_id(uint8_t id128[128]) {
+  if (!id128) return fail(FASTMC_EINVAL, "null id");
+  TRY(load_rccl());
+  ncclUniqueId id;
+  NCCLCHK(g_rccl.GetUniqueId(&id));
+  static_assert(sizeof(id) == 128, "unique id size");
+  memcpy(id128, &id, 128);
+  return 0;
+}
+
+extern "C" int fastmc_comm_init(fastmc_t* h, const uint8_t id128[128], int world_size, int rank) {
+  if (!h || !id128 || world_size < 1 || rank < 0 || rank >= world_size) return fail(FASTMC_EINVAL, "bad argument");
+  TRY(load_rccl());
+  HIPCHK(hipSetDevice(h->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  NCCLCHK(g_rccl.CommInitRank(&h->comm, world_size, id, rank));
+  h->world = world_size;
+  h->rank = rank;
+  return 0;
+}
+
+extern "C" int fastmc_comm_gather(fastmc_t* h, int64_t n_local, double* all_powers, int64_t* hist, double lo_db,
+                                  double hi_db, int nbins) {
+  if (!h || !h->comm) return fail(FASTMC_ESTATE, "fastmc_comm_init not called");
+  if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds the last run");
+  HIPCHK(hipSetDevice(h->device));
+  if (all_powers) {
+    TRY(grow(&h->gather_buf, &h->gather_cap, (size_t)n_local * h->world));
+    NCCLCHK(g_rccl.AllGather(h->out, h->gather_buf, (size_t)n_local, ncclDouble, h->comm, h->stream));
+    HIPCHK(hipMemcpyAsync(all_powers, h->gather_buf, (size_t)n_local * h->world * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  if (hist) {
+    TRY(histogram_device(h, lo_db, hi_db, nbins));
+    NCCLCHK(g_rccl.AllReduce(h->hist, h->hist, (size_t)nbins + 2, ncclUint64, ncclSum, h->comm, h->stream));
+    HIPCHK(hipMemcpyAsync(hist, h->hist, ((size_t)nbins + 2) * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int fastmc_comm_destroy(fastmc_t* h) {
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  if (h->comm && g_rccl.lib) {
+    g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr;
+  }
+  return 0;
+}

@@ -1,0 +1,143 @@
+// fmc_core.h -- arithmetic shared by the gfx950 kernels and their host-side lane emulation.
+//
+// Everything here is __host__ __device__ so that tests/emu (a host program that runs the
+// per-lane phases of the wave pipeline in a loop over 64 lanes) executes the same index
+// arithmetic as the GPU.  Hardware transcendental intrinsics are confined to fmc_kernels.hip.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define FMC_HD __host__ __device__ __forceinline__
+#else
+#define FMC_HD inline
+#endif
+
+namespace fmc {
+
+constexpr int WAVE = 64;
+
+template <class R>
+struct cpx {
+  R x, y;
+};
+
+template <class R> FMC_HD cpx<R> mk(R x, R y) { cpx<R> r; r.x = x; r.y = y; return r; }
+template <class R> FMC_HD cpx<R> operator+(cpx<R> a, cpx<R> b) { return mk<R>(a.x + b.x, a.y + b.y); }
+template <class R> FMC_HD cpx<R> operator-(cpx<R> a, cpx<R> b) { return mk<R>(a.x - b.x, a.y - b.y); }
+template <class R> FMC_HD cpx<R> cmul(cpx<R> a, cpx<R> b) { return mk<R>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <class R> FMC_HD cpx<R> cfma(cpx<R> a, cpx<R> b, cpx<R> c) {  // a*b + c
+  return mk<R>(c.x + a.x * b.x - a.y * b.y, c.y + a.x * b.y + a.y * b.x);
+}
+template <class R> FMC_HD cpx<R> cscale(cpx<R> a, R s) { return mk<R>(a.x * s, a.y * s); }
+
+// cos(2*pi*k/64), k = 0..16, to double precision.
+FMC_HD constexpr double cos64_quarter(int k) {
+  switch (k) {
+    case 0: return 1.0;
+    case 1: return 0.9951847266721968862448;
+    case 2: return 0.9807852804032304491262;
+    case 3: return 0.9569403357322088649358;
+    case 4: return 0.9238795325112867561282;
+    case 5: return 0.8819212643483550297128;
+    case 6: return 0.8314696123025452370788;
+    case 7: return 0.7730104533627369608109;
+    case 8: return 0.7071067811865475244008;
+    case 9: return 0.6343932841636454982152;
+    case 10: return 0.5555702330196022247428;
+    case 11: return 0.4713967368259976485564;
+    case 12: return 0.3826834323650897717285;
+    case 13: return 0.2902846772544623676362;
+    case 14: return 0.1950903220161282678483;
+    case 15: return 0.0980171403295606019942;
+    default: return 0.0;
+  }
+}
+// cos / sin of 2*pi*k/64 for any integer k (symmetry of the quarter table).
+FMC_HD constexpr double cos64(int k) {
+  k &= 63;
+  if (k > 32) k = 64 - k;           // cos(2pi - t) = cos t
+  return k <= 16 ? cos64_quarter(k) : -cos64_quarter(32 - k);
+}
+FMC_HD constexpr double sin64(int k) { return cos64(k - 16); }
+
+// Multiply d by w_P^k = exp(-2*pi*i*k/P), P | 64, k a value the optimiser sees as constant
+// after unrolling: the trivial cases cost no multiplies.
+template <class R>
+FMC_HD cpx<R> mul_tw(cpx<R> d, int k, int P) {
+  const int k64 = (k * (64 / P)) & 63;
+  if (k64 == 0) return d;
+  if (k64 == 16) return mk<R>(d.y, -d.x);    // * (-i)
+  if (k64 == 32) return mk<R>(-d.x, -d.y);   // * (-1)
+  if (k64 == 48) return mk<R>(-d.y, d.x);    // * (+i)
+  const R h = (R)0.7071067811865475244008;
+  if (k64 == 8) return mk<R>((d.x + d.y) * h, (d.y - d.x) * h);     // (1 - i)/sqrt2
+  if (k64 == 24) return mk<R>((d.y - d.x) * h, -(d.x + d.y) * h);   // (-1 - i)/sqrt2
+  if (k64 == 40) return mk<R>(-(d.x + d.y) * h, (d.x - d.y) * h);   // (-1 + i)/sqrt2
+  if (k64 == 56) return mk<R>((d.x - d.y) * h, (d.x + d.y) * h);    // (1 + i)/sqrt2
+  const R c = (R)cos64(k64), s = (R)(-sin64(k64));                  // w = c + i s
+  return mk<R>(d.x * c - d.y * s, d.x * s + d.y * c);
+}
+
+FMC_HD constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
+FMC_HD constexpr int brev(int a, int bits) {
+  int r = 0;
+  for (int i = 0; i < bits; ++i) r |= ((a >> i) & 1) << (bits - 1 - i);
+  return r;
+}
+
+// In-register forward DFT of size P (power of two <= 64), decimation in frequency.
+// On return v[brev(a)] = sum_j v_in[j] * exp(-2*pi*i*j*a/P).
+template <int P, class R>
+FMC_HD void fft_dif(cpx<R> (&v)[P]) {
+#pragma unroll
+  for (int S = P / 2; S >= 1; S >>= 1) {
+#pragma unroll
+    for (int blk = 0; blk < P; blk += 2 * S) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        const cpx<R> u = v[blk + i], w = v[blk + i + S];
+        v[blk + i] = u + w;
+        v[blk + i + S] = mul_tw<R>(u - w, i * (P / (2 * S)), P);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct u32x4 {
+  uint32_t a, b, c, d;
+};
+
+FMC_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c0;
+    const uint64_t p1 = (uint64_t)M1 * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  u32x4 o; o.a = c0; o.b = c1; o.c = c2; o.d = c3;
+  return o;
+}
+
+// Streams of the device generator (counter word 1).
+constexpr uint32_t STREAM_SCREEN = 0;   // counter word 0 = pixel-pair index ky*H + kx', H = ceil(N/2)
+constexpr uint32_t STREAM_LOGAMP = 1;   // counter words 2,3 = global iteration index
+constexpr uint32_t STREAM_SUBHARM = 2;  // counter word 0 = mode-pair index m in [0,14)
+
+// ---------------------------------------------------------------- index helpers
+// Pupil-window output p (fft-shifted index) of an N-point transform of fft-shifted input k:
+//   out[p] = sum_k in[k] * w_N^{((p - h)(k + h)) mod N},  h = N//2   (numpy fftshift both sides)
+FMC_HD int shifted_exponent_step(int p, int N) {  // q = (p - h) mod N
+  const int h = N / 2;
+  int q = (p - h) % N;
+  return q < 0 ? q + N : q;
+}
+
+}  // namespace fmc

@@ -1,0 +1,468 @@
+// fmc_kernels.h -- gfx950 kernels of the FAST Monte-Carlo hot path (included by fastmc.hip).
+//
+// Per realisation g (one complex N x N transform = two Monte-Carlo iterations):
+//   rows kernel : draw/colour one spectrum row, N-point DFT along kx pruned to the Np window
+//                 columns  ->  V[b][ky][oi]                       (x half of 4)
+//   cols kernel : N-point DFT along ky of each window column pruned to the Np window rows,
+//                 + sub-harmonics, W * exp(i phi) and the pixel sum  ->  partial[b][xi][4]
+//                                                                 (rows 3-5, 5c)
+//   finalize    : sum the Np column partials, log-amplitude, |.|^2 (rows 5, 5b)
+// Two kernel families: "wave" (N = 512/1024/2048; fmc_wavefft.h) and "direct" (any N <= 4096).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fmc_core.h"
+#include "fmc_wavefft.h"
+
+namespace fmc {
+
+// ------------------------------------------------------------------ device RNG
+// Box-Muller on two 32-bit words:  r = sqrt(-2 ln U), U = (x0 + 0.5) 2^-32;  theta = 2 pi (x1 + 0.5) 2^-32
+// -> (r cos theta, r sin theta): a standard complex normal.  float32 hardware transcendentals
+// (v_log_f32 = log2, v_sqrt_f32, v_sin_f32 / v_cos_f32 take turns); the oracle restates the
+// same formula in float64 (oracle/devrng.py) and the two agree to ~1e-6 absolute.
+__device__ __forceinline__ void box_muller(uint32_t x0, uint32_t x1, float& re, float& im) {
+  const float u = fmaf((float)x0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);  // (x0 + .5) 2^-32
+  const float t = fmaf((float)x1, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));  // -2 ln2 log2 u
+  re = r * __builtin_amdgcn_cosf(t);
+  im = r * __builtin_amdgcn_sinf(t);
+}
+
+struct RngKey {
+  uint32_t k0, k1;   // seed
+};
+
+// The two coefficients of pixel pair (ky, kx') , kx' < H = ceil(N/2): (ky, kx') and (ky, kx'+H).
+template <class R>
+__device__ __forceinline__ void draw_pair(RngKey key, uint64_t g, int N, int ky, int kxp, cpx<R>& c0, cpx<R>& c1) {
+  const int H = (N + 1) >> 1;
+  const u32x4 x = philox4x32_10((uint32_t)(ky * H + kxp), STREAM_SCREEN, (uint32_t)g, (uint32_t)(g >> 32), key.k0, key.k1);
+  float a, b, c, d;
+  box_muller(x.a, x.b, a, b);
+  box_muller(x.c, x.d, c, d);
+  c0 = mk<R>((R)a, (R)b);
+  c1 = mk<R>((R)c, (R)d);
+}
+
+__device__ __forceinline__ float draw_logamp_normal(RngKey key, uint64_t iter) {
+  const u32x4 x = philox4x32_10(0u, STREAM_LOGAMP, (uint32_t)iter, (uint32_t)(iter >> 32), key.k0, key.k1);
+  float a, b;
+  box_muller(x.a, x.b, a, b);
+  return a;
+}
+
+// ------------------------------------------------------------------ shared parameter blocks
+template <class R>
+struct RowArgs {
+  int N, Np, lo, nb;            // grid size, window size, first window index, realisations in this launch
+  const R* amp;                 // [N][N] sqrt(powerspec)*df  (wave family: with (-1)^(ky+kx) folded in)
+  const cpx<R>* tw;             // wave: tw1 [P*64];  direct: w_N^e, e < N
+  const cpx<R>* om;             // wave: [8][omS]
+  int omS;
+  cpx<R>* V;                    // [nb][N][Np]
+  RngKey key;
+  uint64_t g0;                  // global index of realisation b = 0
+  const double* cre;            // host-coefficient mode: [nb][N][N] real parts
+  const double* cim;
+};
+
+struct SubharmArgs {
+  int enabled;
+  const double* coef;           // [nb][27][2] coloured, df-scaled coefficients c_m
+  const double* mean;           // [nb][2]     sum_m c_m mu_m
+  const double* ex;             // [27][Np][2] exp(i x fx_m) on the window columns
+  const double* ey;             // [27][Np][2] exp(i y fy_m) on the window rows
+};
+
+template <class R>
+struct ColArgs {
+  int N, Np, lo, nb;
+  const cpx<R>* V;              // [nb][N][Np]
+  const cpx<R>* tw;
+  const cpx<R>* om;
+  int omS;
+  const double* W;              // [Np][Np]
+  SubharmArgs sh;
+  double* partial;              // [nb][Np][4]  (EPI 0)
+  double* phs;                  // [2][nb][Np][Np] (EPI 1): Re screens then Im screens of this launch
+};
+
+// phi -> contribution of one window pixel to the four sums; sub-harmonics added first.
+template <class R>
+__device__ __forceinline__ void pixel_phase(const SubharmArgs& sh, int b, int Np, int yi, int xi, R& p1, R& p2) {
+  if (sh.enabled) {
+    double sr = -sh.mean[b * 2 + 0], si = -sh.mean[b * 2 + 1];
+    const double* cf = sh.coef + (size_t)b * 54;
+#pragma unroll 3
+    for (int m = 0; m < 27; ++m) {
+      const double exr = sh.ex[(m * Np + xi) * 2], exi = sh.ex[(m * Np + xi) * 2 + 1];
+      const double eyr = sh.ey[(m * Np + yi) * 2], eyi = sh.ey[(m * Np + yi) * 2 + 1];
+      const double er = exr * eyr - exi * eyi, ei = exr * eyi + exi * eyr;
+      sr += cf[2 * m] * er - cf[2 * m + 1] * ei;
+      si += cf[2 * m] * ei + cf[2 * m + 1] * er;
+    }
+    p1 = (R)((double)p1 + sr);
+    p2 = (R)((double)p2 + si);
+  }
+}
+
+__device__ __forceinline__ void sincos_r(double x, double& s, double& c) { sincos(x, &s, &c); }
+__device__ __forceinline__ void sincos_r(float x, double& s, double& c) {
+  float fs, fc;
+  sincosf(x, &fs, &fc);
+  s = fs; c = fc;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ================================================================== wave family
+template <class R, int P, int NS>
+struct GpuExec {
+  int lane;
+  LaneRegs<R, P, NS>& r;
+  template <class F> __device__ __forceinline__ void each(F f) { f(lane, r); }
+  __device__ __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+};
+
+constexpr int WAVES_PER_WG = 4;
+constexpr int ROWS_PER_WAVE = 8;   // rows kernel: consecutive ky per wave
+
+template <class R, int P>
+__device__ __forceinline__ void load_tables(cpx<R>* s_tw, cpx<R>* s_om, const cpx<R>* tw, const cpx<R>* om, int omS) {
+  for (int i = threadIdx.x; i < P * WAVE; i += blockDim.x) s_tw[i] = tw[i];
+  for (int i = threadIdx.x; i < 8 * omS; i += blockDim.x) s_om[i] = om[i];
+  __syncthreads();
+}
+
+// LDS carve (dynamic): [tw1 P*64 cpx][om 8*omS cpx][xbuf WAVES*XELEMS 8-byte]
+template <class R, int P>
+__host__ __device__ constexpr size_t wave_lds_bytes(int omS) {
+  return (size_t)(P * WAVE + 8 * omS) * sizeof(cpx<R>) + (size_t)WAVES_PER_WG * WaveGeom<R, P>::XELEMS * 8;
+}
+
+template <class R, int P, int NS, int MODE>
+__global__ __launch_bounds__(WAVES_PER_WG * 64) void k_rows_wave(RowArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using G = WaveGeom<R, P>;
+  using E = typename Xch<R>::E;
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  cpx<R>* s_om = s_tw + P * WAVE;
+  E* s_x = reinterpret_cast<E*>(s_om + 8 * A.omS);
+  load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  E* xbuf = s_x + w * G::XELEMS;
+  // consecutive blocks = the same rows of different realisations (amp rows shared in L2)
+  const int b = blockIdx.x % A.nb;
+  const int chunk = blockIdx.x / A.nb;
+  const int row0 = (chunk * WAVES_PER_WG + w) * ROWS_PER_WAVE;
+  const uint64_t g = A.g0 + (uint64_t)b;
+  const int N = G::N;
+
+  LaneRegs<R, P, NS> regs;
+  GpuExec<R, P, NS> ex{lane, regs};
+  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+    const int ky = row0 + rr;
+    const R* amp = A.amp + (size_t)ky * N;
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < P / 2; ++j) {
+        cpx<R> c0, c1;
+        draw_pair<R>(A.key, g, N, ky, lane + WAVE * j, c0, c1);
+        regs.v[j] = cscale(c0, amp[lane + WAVE * j]);
+        regs.v[j + P / 2] = cscale(c1, amp[lane + WAVE * (j + P / 2)]);
+      }
+    } else {
+      const size_t base = ((size_t)b * N + ky) * N;
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int kx = lane + WAVE * j;
+        regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
+      }
+    }
+    pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    cpx<R>* out = A.V + ((size_t)b * N + ky) * A.Np;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int oi = lane + WAVE * s;
+      if (oi < A.Np) out[oi] = mk<R>(regs.xr[s], regs.xi[s]);
+    }
+  }
+}
+
+// EPI 0: detector partial sums; EPI 1: write the cropped screens.
+template <class R, int P, int NS, int EPI>
+__global__ __launch_bounds__(WAVES_PER_WG * 64) void k_cols_wave(ColArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using G = WaveGeom<R, P>;
+  using E = typename Xch<R>::E;
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  cpx<R>* s_om = s_tw + P * WAVE;
+  E* s_x = reinterpret_cast<E*>(s_om + 8 * A.omS);
+  load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  E* xbuf = s_x + w * G::XELEMS;
+  const int groups = (A.Np + WAVES_PER_WG - 1) / WAVES_PER_WG;
+  const int b = blockIdx.x / groups;
+  const int xi = (blockIdx.x % groups) * WAVES_PER_WG + w;
+  if (xi >= A.Np) return;   // whole wave exits; no block barrier follows
+  const int N = G::N;
+
+  LaneRegs<R, P, NS> regs;
+  GpuExec<R, P, NS> ex{lane, regs};
+  const cpx<R>* col = A.V + (size_t)b * N * A.Np + xi;
+#pragma unroll
+  for (int j = 0; j < P; ++j) regs.v[j] = col[(size_t)(lane + WAVE * j) * A.Np];
+  pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int yi = lane + WAVE * s;
+    if (yi < A.Np) {
+      R p1 = regs.xr[s], p2 = regs.xi[s];
+      pixel_phase<R>(A.sh, b, A.Np, yi, xi, p1, p2);
+      if (EPI == 1) {
+        const size_t plane = (size_t)A.Np * A.Np;
+        A.phs[((size_t)b) * plane + (size_t)yi * A.Np + xi] = (double)p1;
+        A.phs[((size_t)(A.nb + b)) * plane + (size_t)yi * A.Np + xi] = (double)p2;
+      } else {
+        const double wgt = A.W[(size_t)yi * A.Np + xi];
+        double s1, c1, s2, c2;
+        sincos_r(p1, s1, c1);
+        sincos_r(p2, s2, c2);
+        acc[0] += wgt * c1; acc[1] += wgt * s1; acc[2] += wgt * c2; acc[3] += wgt * s2;
+      }
+    }
+  }
+  if (EPI == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane == 0) {
+      double* o = A.partial + ((size_t)b * A.Np + xi) * 4;
+      o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+    }
+  }
+}
+
+// ================================================================== direct family (any N <= 4096)
+constexpr int DIRECT_THREADS = 256;
+
+template <class R, int MODE>
+__global__ __launch_bounds__(DIRECT_THREADS) void k_rows_direct(RowArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int N = A.N;
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  cpx<R>* s_row = s_tw + N;
+  const int b = blockIdx.x % A.nb;
+  const int ky = blockIdx.x / A.nb;
+  const uint64_t g = A.g0 + (uint64_t)b;
+  const R* amp = A.amp + (size_t)ky * N;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) s_tw[i] = A.tw[i];
+  if (MODE == 0) {
+    const int H = (N + 1) >> 1;
+    for (int kxp = threadIdx.x; kxp < H; kxp += blockDim.x) {
+      cpx<R> c0, c1;
+      draw_pair<R>(A.key, g, N, ky, kxp, c0, c1);
+      s_row[kxp] = cscale(c0, amp[kxp]);
+      if (kxp + H < N) s_row[kxp + H] = cscale(c1, amp[kxp + H]);
+    }
+  } else {
+    const size_t base = ((size_t)b * N + ky) * N;
+    for (int kx = threadIdx.x; kx < N; kx += blockDim.x)
+      s_row[kx] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
+  }
+  __syncthreads();
+  const int h = N / 2;
+  for (int oi = threadIdx.x; oi < A.Np; oi += blockDim.x) {
+    const int q = shifted_exponent_step(A.lo + oi, N);
+    int e = (int)(((long long)q * h) % N);
+    cpx<R> acc = mk<R>((R)0, (R)0);
+    for (int k = 0; k < N; ++k) {
+      acc = cfma(s_row[k], s_tw[e], acc);
+      e += q;
+      if (e >= N) e -= N;
+    }
+    A.V[((size_t)b * N + ky) * A.Np + oi] = acc;
+  }
+}
+
+template <class R, int EPI>
+__global__ __launch_bounds__(DIRECT_THREADS) void k_cols_direct(ColArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ double s_red[4][DIRECT_THREADS / 64];
+  const int N = A.N;
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  cpx<R>* s_col = s_tw + N;
+  const int b = blockIdx.x / A.Np;
+  const int xi = blockIdx.x % A.Np;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    s_tw[i] = A.tw[i];
+    s_col[i] = A.V[((size_t)b * N + i) * A.Np + xi];
+  }
+  __syncthreads();
+  const int h = N / 2;
+  double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int yi = threadIdx.x; yi < A.Np; yi += blockDim.x) {
+    const int q = shifted_exponent_step(A.lo + yi, N);
+    int e = (int)(((long long)q * h) % N);
+    cpx<R> acc = mk<R>((R)0, (R)0);
+    for (int k = 0; k < N; ++k) {
+      acc = cfma(s_col[k], s_tw[e], acc);
+      e += q;
+      if (e >= N) e -= N;
+    }
+    R p1 = acc.x, p2 = acc.y;
+    pixel_phase<R>(A.sh, b, A.Np, yi, xi, p1, p2);
+    if (EPI == 1) {
+      const size_t plane = (size_t)A.Np * A.Np;
+      A.phs[((size_t)b) * plane + (size_t)yi * A.Np + xi] = (double)p1;
+      A.phs[((size_t)(A.nb + b)) * plane + (size_t)yi * A.Np + xi] = (double)p2;
+    } else {
+      const double wgt = A.W[(size_t)yi * A.Np + xi];
+      double s1, c1, s2, c2;
+      sincos_r(p1, s1, c1);
+      sincos_r(p2, s2, c2);
+      acc4[0] += wgt * c1; acc4[1] += wgt * s1; acc4[2] += wgt * c2; acc4[3] += wgt * s2;
+    }
+  }
+  if (EPI == 0) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double v = wave_sum(acc4[q]);
+      if (lane == 0) s_red[q][w] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double v = 0.0;
+      for (int i = 0; i < DIRECT_THREADS / 64; ++i) v += s_red[threadIdx.x][i];
+      A.partial[((size_t)b * A.Np + xi) * 4 + threadIdx.x] = v;
+    }
+  }
+}
+
+// ================================================================== sub-harmonic coefficients
+// coef[b][m] = rand_lo[b][m] * sqrt(ps_lo[m]) * df_lo[level(m)]  (fast/fast.py:600-601, funcs.py:243)
+// mean[b]    = sum_m coef[b][m] * mu[m],  mu[m] = grid mean of mode m (funcs.py:253)
+struct ShCoefArgs {
+  int nb;
+  RngKey key;
+  uint64_t g0;
+  const double* sh_re;   // host mode: [nb][27] or NULL -> device RNG
+  const double* sh_im;
+  const double* scale;   // [27] sqrt(ps_lo) * df_lo
+  const double* mu;      // [27][2]
+  double* coef;          // [nb][27][2]
+  double* mean;          // [nb][2]
+};
+
+__global__ void k_subharm_coeffs(ShCoefArgs A) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= A.nb) return;
+  const uint64_t g = A.g0 + (uint64_t)b;
+  double mr = 0.0, mi = 0.0;
+  double cr[27], ci[27];
+  if (A.sh_re) {
+    for (int m = 0; m < 27; ++m) { cr[m] = A.sh_re[b * 27 + m]; ci[m] = A.sh_im[b * 27 + m]; }
+  } else {
+    for (int mp = 0; mp < 14; ++mp) {   // pairs (mp, mp + 14), H = ceil(27/2)
+      const u32x4 x = philox4x32_10((uint32_t)mp, STREAM_SUBHARM, (uint32_t)g, (uint32_t)(g >> 32), A.key.k0, A.key.k1);
+      float a, bb, c, d;
+      box_muller(x.a, x.b, a, bb);
+      box_muller(x.c, x.d, c, d);
+      cr[mp] = a; ci[mp] = bb;
+      if (mp + 14 < 27) { cr[mp + 14] = c; ci[mp + 14] = d; }
+    }
+  }
+  for (int m = 0; m < 27; ++m) {
+    const double r = cr[m] * A.scale[m], i = ci[m] * A.scale[m];
+    A.coef[(b * 27 + m) * 2] = r;
+    A.coef[(b * 27 + m) * 2 + 1] = i;
+    mr += r * A.mu[2 * m] - i * A.mu[2 * m + 1];
+    mi += r * A.mu[2 * m + 1] + i * A.mu[2 * m];
+  }
+  A.mean[b * 2] = mr;
+  A.mean[b * 2 + 1] = mi;
+}
+
+// ================================================================== finalize (fast/fast.py:647-668)
+struct FinArgs {
+  int nb, Np, coherent;
+  int64_t n_real, j0;         // total realisations of the run, index of this launch's first one
+  const double* partial;      // [nb][Np][4]
+  const double* logamp;       // [2*n_real] in output order, or NULL -> device draw
+  double logamp_sigma;        // sqrt(logamp_var)
+  RngKey key;
+  uint64_t g0;                // global realisation index of j0
+  double dx2, norm;           // dx^2, sum(W) * dx^2
+  double* out;                // [2*n_real] or [2*n_real][2]
+};
+
+__global__ void k_finalize(FinArgs A) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= A.nb) return;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* p = A.partial + (size_t)b * A.Np * 4;
+  for (int xi = 0; xi < A.Np; ++xi)
+    for (int q = 0; q < 4; ++q) s[q] += p[xi * 4 + q];
+  const int64_t j = A.j0 + b;
+#pragma unroll
+  for (int part = 0; part < 2; ++part) {
+    const int64_t o = part * A.n_real + j;
+    double chi;
+    if (A.logamp) chi = A.logamp[o];
+    else chi = (double)draw_logamp_normal(A.key, 2 * (A.g0 + (uint64_t)b) + part) * A.logamp_sigma;
+    const double e = exp(chi);
+    const double ar = (e * (s[2 * part] * A.dx2)) / A.norm;
+    const double ai = (e * (s[2 * part + 1] * A.dx2)) / A.norm;
+    if (A.coherent) { A.out[2 * o] = ar; A.out[2 * o + 1] = ai; }
+    else A.out[o] = ar * ar + ai * ai;
+  }
+}
+
+// ================================================================== histogram of dB_rel
+__global__ void k_histogram(const double* out, int64_t n, int coherent, double lo, double hi, int nbins,
+                            unsigned long long* bins) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double pw = coherent ? out[2 * i] * out[2 * i] + out[2 * i + 1] * out[2 * i + 1] : out[i];
+  const double db = 10.0 * log10(pw);
+  int k;
+  if (!(db >= lo)) k = nbins;            // underflow (and NaN)
+  else if (db >= hi) k = nbins + 1;      // overflow
+  else { k = (int)((db - lo) / (hi - lo) * nbins); if (k >= nbins) k = nbins - 1; }
+  atomicAdd(&bins[k], 1ULL);
+}
+
+// ================================================================== generator read-back (parity tests)
+__global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, double* out) {
+  const int H = (N + 1) >> 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * H) return;
+  const int ky = idx / H, kxp = idx % H;
+  cpx<double> c0, c1;
+  draw_pair<double>(key, g, N, ky, kxp, c0, c1);
+  out[2 * ((size_t)ky * N + kxp)] = c0.x;
+  out[2 * ((size_t)ky * N + kxp) + 1] = c0.y;
+  if (kxp + H < N) {
+    out[2 * ((size_t)ky * N + kxp + H)] = c1.x;
+    out[2 * ((size_t)ky * N + kxp + H) + 1] = c1.y;
+  }
+}
+
+__global__ void k_rng_logamp(RngKey key, uint64_t it0, int64_t n, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (double)draw_logamp_normal(key, it0 + (uint64_t)i);
+}
+
+}  // namespace fmc

@@ -1,0 +1,188 @@
+// fmc_powerspec.h -- AO-residual phase power spectrum on the GPU.
+//
+// One thread per spectrum pixel, float64 throughout, the reference's operation order kept so
+// that the grid matches numpy to ~1e-13 relative:
+//   Fast.compute_powerspec                         fast/fast.py:445-492
+//   funcs.turb_powerspectrum_vonKarman             fast/funcs.py:138-173
+//   ao_power_spectra.G_AO_PAOLA                    fast/ao_power_spectra.py:225-270
+//   ao_power_spectra.Jol_alias_openloop            fast/ao_power_spectra.py:163-223  (only where lf_mask != 0)
+//   ao_power_spectra.Jol_noise_openloop            fast/ao_power_spectra.py:148-161
+//   ao_power_spectra.logamp_powerspec              fast/ao_power_spectra.py:272-301
+// The 2-D Simpson integrals (funcs.py:100-115) are weighted sums  sum_i w_i sum_j w_j P[i][j]
+// with the 1-D weights w supplied by the host: each block reduces one row, a second kernel
+// reduces the rows, both in a fixed order (deterministic).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace fmc {
+
+constexpr int PS_MAX_LAYERS = 64;
+constexpr int PS_THREADS = 256;
+constexpr int PS_NQ = 6;   // aniso_servo, alias, noise, fitting, phs_var, logamp_var (+ L per-layer)
+
+struct PsArgs {
+  int N, L, ao_mode, alias;
+  double dx, wvl, L0, l0, noise, d_wfs, t_loop, t_exp, dth_x, dth_y;
+  const double* cn2;
+  const double* h;
+  const double* wind;          // [L][2]
+  const double* mask;          // [N][N]
+  const double* pfilter;       // [N][N] or null
+  const double* lgs_z;         // [N][N] or null
+  const double* w;             // [N] Simpson weights
+  double* powerspec;           // [N][N]
+  double* per_layer;           // [L][N][N] or null
+  double* logamp_ps;           // [N][N] or null
+  double* rowsums;             // [N][PS_NQ + L]
+};
+
+__device__ __forceinline__ double np_sinc(double x) {   // numpy.sinc
+  const double y = M_PI * (x == 0.0 ? 1.0e-20 : x);
+  return sin(y) / y;
+}
+
+// 0.033 exp(-k^2/km^2) / (k^2 + k0^2)^(11/6); the caller multiplies by cn2 and zeroes infinities.
+__device__ __forceinline__ double vk_base(double fabs_, double km, double k0) {
+  return 0.033 * exp(-(fabs_ * fabs_) / (km * km)) / pow(fabs_ * fabs_ + k0 * k0, 11 / 6.0);
+}
+__device__ __forceinline__ double vk_layer(double base, double cn2) {
+  const double v = cn2 * base;
+  return isinf(v) ? 0.0 : v;
+}
+
+__global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
+  __shared__ double s_red[PS_THREADS / 64][PS_NQ + PS_MAX_LAYERS];
+  const int N = A.N, L = A.L;
+  const int iy = blockIdx.x;
+  const int mid = N / 2;   // int(N/2.) for both axes
+  const double TWO_PI = 2.0 * M_PI;
+  const double df = TWO_PI / (N * A.dx);
+  const double k = TWO_PI / A.wvl;
+  const double c2pk2 = 2 * M_PI * (k * k);
+  const double km = 5.92 / A.l0;
+  const double k0 = TWO_PI / A.L0;
+  const double c_la = TWO_PI * ((TWO_PI / A.wvl) * (TWO_PI / A.wvl));
+  const double fy = (iy - N / 2.0) * df;
+  const int nq = PS_NQ + L;
+
+  double q[PS_NQ + PS_MAX_LAYERS];
+  for (int i = 0; i < nq; ++i) q[i] = 0.0;
+
+  for (int ix = threadIdx.x; ix < N; ix += blockDim.x) {
+    const double fx = (ix - N / 2.0) * df;
+    const double fabs_ = sqrt(fx * fx + fy * fy);
+    const size_t pix = (size_t)iy * N + ix;
+    const double mask = A.mask[pix];
+    const bool centre = (iy == mid && ix == mid);
+    const double base = vk_base(fabs_, km, k0);
+
+    double noise_ps = 0.0;
+    if (A.noise > 0.0 && A.ao_mode != 0) {
+      if (!centre) {
+        const double sx = np_sinc(A.d_wfs * fx / TWO_PI), sy = np_sinc(A.d_wfs * fy / TWO_PI);
+        noise_ps = A.noise / (fabs_ * fabs_ * (sx * sx) * (sy * sy));
+      }
+      noise_ps = mask * noise_ps;
+    }
+
+    double ps = 0.0, la = 0.0, gt_sum = 0.0, alias_tot = 0.0;
+    const bool do_alias = A.alias && A.ao_mode != 0 && mask != 0.0;
+    const double term_0 = (fx * fx) * (fy * fy) / (fabs_ * fabs_ * fabs_ * fabs_);
+
+    // sum over the 120 shifted von Karman spectra (layer-independent part; the reference's
+    // per-layer term_2 = cn2_l * this), special-cased centre row / column / pixel (208-213)
+    double alias_base = 0.0;
+    if (do_alias) {
+      for (int sl = -5; sl <= 5; ++sl) {
+        const double fys = fy - TWO_PI * sl / A.d_wfs;
+        for (int sk = -5; sk <= 5; ++sk) {
+          if (sl == 0 && sk == 0) continue;
+          const double fxs = fx - TWO_PI * sk / A.d_wfs;
+          const double fabs_s = sqrt(fxs * fxs + fys * fys);
+          double term_2 = vk_base(fabs_s, km, k0);
+          if (isinf(term_2)) term_2 = 0.0;
+          double mult;
+          if ((sl == 0 && iy == mid) || (sk == 0 && ix == mid)) mult = term_2;
+          else if (centre) mult = 0.0;
+          else {
+            const double t = fx / fys + fy / fxs;
+            mult = (t * t) * term_2 * term_0;
+          }
+          alias_base += mult;
+        }
+      }
+    }
+
+    for (int l = 0; l < L; ++l) {
+      const double cn2 = A.cn2[l];
+      const double turb = vk_layer(base, cn2);
+      const double vx = A.wind[2 * l], vy = A.wind[2 * l + 1];
+      const double v_k = fx * vx + fy * vy;
+      double G = 1.0;
+      if (A.ao_mode != 0) {
+        const double drx = A.dth_x / 206265.0 * A.h[l], dry = A.dth_y / 206265.0 * A.h[l];
+        const double dr_k = fx * drx + fy * dry;
+        const double s = np_sinc(A.t_exp * v_k / TWO_PI);
+        const double aniso = 1 - 2 * cos(dr_k - A.t_loop * v_k) * s + s * s;
+        if (A.ao_mode == 3) {
+          const double aniso_lgs = 1 - 2 * cos(-A.t_loop * v_k) * s + s * s;
+          const double Z = A.lgs_z[pix];
+          G = mask * (Z * aniso + (1 - Z) * aniso_lgs) + (1 - mask);
+        } else {
+          G = aniso * mask + (1 - mask);
+        }
+      }
+      double alias = 0.0;
+      if (do_alias) {
+        const double sc = np_sinc(A.t_exp * v_k / TWO_PI);
+        alias = (cn2 * alias_base) * ((sc * sc) * mask);
+        if (isnan(alias)) alias = 0.0;
+      }
+      const double pl = c2pk2 * (turb * G + alias) + noise_ps / L;
+      if (A.per_layer) A.per_layer[(size_t)l * N * N + pix] = pl;
+      ps += pl;
+      gt_sum += G * turb;
+      alias_tot += alias * c2pk2;
+      const double sn = sin(A.wvl * A.h[l] * (fabs_ * fabs_) / (4 * M_PI));
+      double lal = turb * c_la;
+      lal *= sn * sn;
+      if (A.pfilter) lal *= A.pfilter[pix];
+      la += lal;
+      q[PS_NQ + l] += A.w[ix] * pl;
+    }
+    A.powerspec[pix] = ps;
+    if (A.logamp_ps) A.logamp_ps[pix] = la;
+    const double wj = A.w[ix];
+    q[0] += wj * (gt_sum * mask * c2pk2);
+    q[1] += wj * alias_tot;
+    q[2] += wj * noise_ps;
+    q[3] += wj * (ps * (1 - mask));
+    q[4] += wj * ps;
+    q[5] += wj * la;
+  }
+  // block reduction in a fixed order
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = 0; i < nq; ++i) {
+    double v = q[i];
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) s_red[wv][i] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+    double v = 0.0;
+    for (int w2 = 0; w2 < PS_THREADS / 64; ++w2) v += s_red[w2][i];
+    A.rowsums[(size_t)iy * nq + i] = v;
+  }
+}
+
+// scalars[i] = sum_iy w[iy] * rowsums[iy][i]
+__global__ void k_ps_scalars(const double* rowsums, const double* w, int N, int nq, double* scalars) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  double v = 0.0;
+  for (int iy = 0; iy < N; ++iy) v += w[iy] * rowsums[(size_t)iy * nq + i];
+  scalars[i] = v;
+}
+
+}  // namespace fmc

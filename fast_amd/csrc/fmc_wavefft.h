@@ -1,0 +1,185 @@
+// fmc_wavefft.h -- one wavefront = one N-point row: output-pruned forward DFT, N = 64*P.
+//
+// A lane holds P inputs in registers (k = lane + 64*j).  The transform is factored
+//     N = P x 8 x 8 :  in-register radix-P  ->  LDS exchange  ->  in-register radix-8
+//                      ->  LDS exchange  ->  8-term sums for the WANTED outputs only
+// because FAST keeps only the Np x Np pupil window of every N x N screen
+// (fast/fast.py:390,596): outputs lo .. lo+Np-1.  Output slot s of lane l is window
+// index oi = l + 64*s.
+//
+//   X[x] = sum_k c[k] w_N^{kx},  k = l + 64 j,  x = a + P b  (a < P, b < 64)
+//        = sum_l w_N^{l a} w_64^{l b} Z_l[a],          Z_l[a] = sum_j c[l+64j] w_P^{ja}   (stage 1)
+//   l = l0 + 8 l1, b = b0 + 8 b1:
+//        = sum_l0 w_64^{l0 b} U[a][l0][b0],   U[a][l0][b0] = sum_l1 w_8^{l1 b0} T_{l0+8 l1}[a] (stage 2a)
+//   with T_l[a] = w_N^{l a} Z_l[a].  The last sum (stage 2b) is evaluated only for window x.
+//
+// The per-lane phases are written once, against an executor: on the GPU `each` runs the
+// body for this lane and `sync` is a wave-level LDS fence; in tests/emu `each` loops over
+// 64 lanes on the host, so the index arithmetic below is unit-tested without a GPU.
+#pragma once
+#include "fmc_core.h"
+
+namespace fmc {
+
+// LDS exchange element: 8 bytes in both precisions (ds_write_b64 / ds_read_b64).
+//   float : one complex64 per element, one pass;
+//   double: one component per element, two passes (re, then im) through the same buffer.
+template <class R> struct Xch;
+template <> struct Xch<float> {
+  using E = cpx<float>;
+  static constexpr int NC = 1;
+  static FMC_HD E pack(cpx<float> v, int) { return v; }
+  static FMC_HD void unpack(cpx<float>& v, E e, int) { v = e; }
+  static FMC_HD void acc(float& xr, float& xi, cpx<float> om, E f, int) {
+    xr += om.x * f.x - om.y * f.y;
+    xi += om.x * f.y + om.y * f.x;
+  }
+};
+template <> struct Xch<double> {
+  using E = double;
+  static constexpr int NC = 2;
+  static FMC_HD E pack(cpx<double> v, int c) { return c ? v.y : v.x; }
+  static FMC_HD void unpack(cpx<double>& v, E e, int c) { if (c) v.y = e; else v.x = e; }
+  static FMC_HD void acc(double& xr, double& xi, cpx<double> om, E f, int c) {
+    if (c == 0) { xr += om.x * f; xi += om.y * f; }
+    else        { xr -= om.y * f; xi += om.x * f; }
+  }
+};
+
+template <class R, int P>
+struct WaveGeom {
+  static constexpr int N = WAVE * P;
+  static constexpr int LOGP = ilog2(P);
+  static constexpr int NB = P / 8;                 // radix-8 butterflies per lane in stage 2a
+  static constexpr int SE = 72;                    // row stride of exchange-1 image  E[a][l]
+  static constexpr int SF = 65;                    // row stride of exchange-2 image  F[a][b0*8+l0]
+  static constexpr int XELEMS = P * SE;            // 8-byte elements per wave
+  static_assert(P >= 8 && P <= 32, "wave FFT supports N = 512, 1024, 2048");
+};
+
+// Per-lane registers of the pipeline.
+template <class R, int P, int NS>
+struct LaneRegs {
+  cpx<R> v[P];   // inputs -> stage values -> (fp32) outputs
+  R xr[NS];      // outputs, real part       (slot s  <->  window index lane + 64 s)
+  R xi[NS];      // outputs, imaginary part
+};
+
+// Tables (precomputed on the host in float64, stored as R):
+//   tw1[a*64 + l]  = w_N^{l a}                                   (P*64 complex)
+//   om[m*omS + oi] = sgn(oi) * w_64^{m * b(oi)},  m < 8          (8*omS complex), b(oi) = (lo+oi) >> LOGP
+// `sgn` carries the output-side fftshift sign of fmc_core.h (even N): (-1)^(lo+oi).
+template <class R, int P, int NS, class Exec>
+FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
+                           int omS, int lo, int Np) {
+  using G = WaveGeom<R, P>;
+  using X = Xch<R>;
+  using E = typename X::E;
+  constexpr int NC = X::NC;
+  const int nslots = (Np + WAVE - 1) / WAVE;
+
+  // ---- stage 1: radix-P in registers, twiddle, to natural order
+  ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+    fft_dif<P, R>(r.v);
+    cpx<R> t[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+      const cpx<R> z = r.v[brev(a, G::LOGP)];
+      t[a] = (a == 0) ? z : cmul(z, tw1[a * WAVE + lane]);
+    }
+#pragma unroll
+    for (int a = 0; a < P; ++a) r.v[a] = t[a];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { r.xr[s] = (R)0; r.xi[s] = (R)0; }
+  });
+
+  // ---- exchange 1 (+ stage 2a after the last component)
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) xbuf[a * G::SE + lane] = X::pack(r.v[a], c);
+    });
+    ex.sync();
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int l0 = lane & 7, i = lane >> 3;
+#pragma unroll
+      for (int jj = 0; jj < G::NB; ++jj)
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+          X::unpack(r.v[jj * 8 + m], xbuf[(i + 8 * jj) * G::SE + l0 + 8 * m], c);
+    });
+    ex.sync();
+  }
+  ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+#pragma unroll
+    for (int jj = 0; jj < G::NB; ++jj) {
+      cpx<R> t[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) t[m] = r.v[jj * 8 + m];
+      fft_dif<8, R>(t);
+#pragma unroll
+      for (int b0 = 0; b0 < 8; ++b0) r.v[jj * 8 + b0] = t[brev(b0, 3)];   // natural b0 order
+    }
+  });
+
+  // ---- exchange 2 + stage 2b (pruned): 8-term sums for the window outputs
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int l0 = lane & 7, i = lane >> 3;
+#pragma unroll
+      for (int jj = 0; jj < G::NB; ++jj)
+#pragma unroll
+        for (int b0 = 0; b0 < 8; ++b0)
+          xbuf[(i + 8 * jj) * G::SF + b0 * 8 + l0] = X::pack(r.v[jj * 8 + b0], c);
+    });
+    ex.sync();
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s < nslots) {
+          const int oi = lane + WAVE * s;
+          if (oi < Np) {
+            const int x = lo + oi;
+            const int a = x & (P - 1);
+            const int b0 = (x >> G::LOGP) & 7;
+            const E* f = xbuf + a * G::SF + b0 * 8;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], f[m], c);
+          }
+        }
+      }
+    });
+    ex.sync();
+  }
+}
+
+// Host-side construction of the two tables (float64 trigonometry by the caller-supplied functor
+// `cs(turns, &c, &s)` = cos/sin(2*pi*turns)).
+template <class R, class CosSin>
+inline void build_tw1(cpx<R>* tw1, int P, CosSin cs) {
+  const int N = WAVE * P;
+  for (int a = 0; a < P; ++a)
+    for (int l = 0; l < WAVE; ++l) {
+      double c, s;
+      cs((double)((l * a) % N) / N, &c, &s);
+      tw1[a * WAVE + l] = mk<R>((R)c, (R)(-s));
+    }
+}
+template <class R, class CosSin>
+inline void build_om(cpx<R>* om, int omS, int P, int lo, int Np, bool out_sign, CosSin cs) {
+  const int logp = ilog2(P);
+  for (int m = 0; m < 8; ++m)
+    for (int oi = 0; oi < omS; ++oi) {
+      if (oi >= Np) { om[m * omS + oi] = mk<R>((R)0, (R)0); continue; }
+      const int x = lo + oi;
+      const int b = (x >> logp) & 63;
+      double c, s;
+      cs((double)((m * b) % 64) / 64.0, &c, &s);
+      const double sg = (out_sign && (x & 1)) ? -1.0 : 1.0;
+      om[m * omS + oi] = mk<R>((R)(sg * c), (R)(-sg * s));
+    }
+}
+
+}  // namespace fmc

@@ -1,0 +1,199 @@
+"""`fast_amd.Fast(config).run()` -> `FastResult`: the reference's public surface
+(fast/fast.py:20-140, 931-994) with the Monte-Carlo hot path on an MI355X.
+
+    sim = fast_amd.Fast(params)      # host init (host.py) + AO-residual PSD on the GPU
+    res = sim.run()                  # batched screens + detector on the GPU
+    res.dB_rel, res.power, res.scintillation_index, sim.I, sim.link_budget, sim.powerspec ...
+
+Differences from the reference, all deliberate:
+  * no CPU path: libfastmc.so and a gfx950 device are required (FastMCError otherwise);
+  * `GPU_RNG`: 'device' (default) draws the coefficients on the GPU with a counter-based
+    generator -- results depend only on (SEED, iteration index), not on NCHUNKS, batch size or
+    the number of GPUs; 'host' draws them with numpy in the reference's order, so the same
+    SEED reproduces the reference's `result._r` to ~1e-10 (parity mode, PCIe-bound);
+  * `GPU_PRECISION`: 'f64' (default, complex128 like the reference) or 'f32';
+  * `TEMPORAL` (frozen-flow time series, fast.py:607-637) is outside this path: NotImplementedError;
+  * `FFTW` / `FFTW_THREADS` are accepted and ignored (they select a CPU FFT in the reference).
+"""
+import logging
+import os
+
+import numpy
+
+from . import _lib, conf, host
+
+logger = logging.getLogger(__name__)
+
+# Host generator of parity mode: module-global like the reference's funcs._R (funcs.py:21),
+# so a second Fast with SEED=None continues the stream.
+_R = numpy.random.default_rng()
+
+
+class Fast():
+    """Drop-in for `fast.Fast` on the Monte-Carlo path.  `params`: config-file name or dict."""
+
+    def __init__(self, params):
+        self.conf = conf.ConfigParser(params)
+        self.params = p = self.conf.config
+        self.Niter, self.Nchunks = p['NITER'], p['NCHUNKS']
+        self.seed = p['SEED']
+        self.temporal, self.dt = p['TEMPORAL'], p['DT']
+        if self.seed != None:
+            self.set_seed(self.seed)
+        self.init_logging()
+
+        prob = host.build_problem(p)          # raises the reference's config Exceptions
+        self._prob = prob
+        if self.temporal:
+            raise NotImplementedError("TEMPORAL=True (frozen-flow time series) is not part of the GPU Monte-Carlo "
+                                      "path; set TEMPORAL=False")
+        self.Niter_per_chunk = prob.M
+        atm, pup = prob.atm, prob.pup
+        # attributes of the reference object (fast.py:49-64 and the init_* methods)
+        for k in ("zenith_correction", "h", "cn2", "L", "dtheta", "paa", "wind_dir", "wind_vector", "wind_speed",
+                  "r0", "theta0", "tau0", "rytov_variance", "r0_los", "theta0_los", "tau0_los", "rytov_variance_los"):
+            setattr(self, k, getattr(atm, k))
+        self.L0, self.l0 = p['L0'], p['l0']
+        self.power, self.wvl, self.k = p['POWER'], p['WVL'], prob.k
+        self.D_ground, self.obsc_ground, self.D_sat, self.obsc_sat = p['D_GROUND'], p['OBSC_GROUND'], p['D_SAT'], p['OBSC_SAT']
+        self.dx, self.Npxls, self.Npxls_pup = prob.dx, prob.N, prob.Np
+        self.subharmonics = prob.subharm
+        self.ao_mode, self.Dsubap, self.tloop, self.texp = prob.ao_mode, prob.d_wfs, p['TLOOP'], p['TEXP']
+        self.Zmax, self.alias, self.noise, self.modal, self.modal_mult = prob.zmax, p['ALIAS'], p['NOISE'], prob.modal, prob.modal_mult
+        self.lf_mask, self.hf_mask = prob.lf_mask, 1 - prob.lf_mask
+        self.dx_sat, self.pupil, self.pupil_sat = pup.dx_sat, pup.pupil, pup.pupil_sat
+        self.pupil_mode, self.pupil_mode_sat, self.W0, self.W0_sat = pup.pupil_mode, pup.pupil_mode_sat, pup.W0, pup.W0_sat
+        self.pupil_filter, self.pup_coords = pup.pupil_filter, pup.pup_coords
+        self.link_budget, self.diffraction_limit = prob.link_budget, prob.diffraction_limit
+        self.logamp = numpy.zeros((self.Niter))
+
+        self.precision = p['GPU_PRECISION']
+        self.rng_mode = p['GPU_RNG']
+        if self.precision not in ('f64', 'f32'):
+            raise Exception("GPU_PRECISION must be 'f64' or 'f32'")
+        if self.rng_mode not in ('device', 'host'):
+            raise Exception("GPU_RNG must be 'device' or 'host'")
+        self.device = _lib.default_device() if p['GPU_DEVICE'] is None else int(p['GPU_DEVICE'])
+        if p['FFTW']:
+            logger.info("FFTW flag ignored: the FFT runs on the GPU")
+
+        self.compute_powerspec()
+        self._handle = _lib.Handle(self.Npxls, self.Npxls_pup, self.precision, self.device)
+        if p['GPU_BATCH']:
+            self._handle.set_batch(p['GPU_BATCH'])
+        self._handle.set_spectrum(self.powerspec, prob.df)
+        self._handle.set_pupil(prob.W, pup.crop_lo, self.dx)
+        if self.subharmonics:
+            self._handle.set_subharm(self.powerspec_subharm, self._sh_fx, self._sh_fy, self._sh_df)
+
+    # ------------------------------------------------------------------ init pieces
+    def init_logging(self):
+        logging.basicConfig(filename=self.params['LOGFILE'], level=logging.getLevelName(self.params['LOGLEVEL']),
+                            format="[%(levelname)s] %(name)s.%(funcName)s | %(message)s")
+
+    def set_seed(self, seed):
+        global _R
+        _R = numpy.random.default_rng(seed)
+
+    def compute_powerspec(self):
+        """AO-residual phase PSD and its Simpson integrals on the GPU (replaces fast.py:445-492)."""
+        logger.info("Computing (residual) phase power spectra")
+        prob, p, atm = self._prob, self.params, self._prob.atm
+        out = _lib.powerspec(prob.N, prob.dx, prob.wvl, p['L0'], p['l0'], prob.ao_mode, p['ALIAS'], p['NOISE'],
+                             prob.d_wfs, p['TLOOP'], p['TEXP'], atm.dtheta, atm.cn2, atm.h, atm.wind_vector,
+                             numpy.asarray(prob.lf_mask, dtype=float), prob.pup.pupil_filter, prob.simpson_w,
+                             lgs_z=prob.lgs_z, per_layer=True, device=self.device)
+        self.powerspec = out["powerspec"]
+        self.powerspec_per_layer = out["powerspec_per_layer"]
+        self.logamp_powerspec = out["logamp_powerspec"]
+        for k in ("aniso_servo_error", "alias_error", "noise_error", "fitting_error", "phs_var", "logamp_var", "phs_var_weights"):
+            setattr(self, k, out[k])
+        self.powerspec_kernel_ms = out["kernel_ms"]
+        if self.subharmonics:
+            self.powerspec_subharm, self._sh_fx, self._sh_fy, self._sh_df = host.subharm_spectrum(prob)
+        else:
+            self.powerspec_subharm = None
+        self.temporal_powerspec = None
+        self.temporal_logamp_powerspec = None
+
+    # ------------------------------------------------------------------ Monte Carlo
+    def run(self):
+        """The chunk loop of fast.py:115-140 as GPU launches; returns a FastResult."""
+        M, half = self.Niter_per_chunk, self.Niter_per_chunk // 2
+        coherent = bool(self.params['COHERENT'])
+        I = numpy.zeros((self.Nchunks, M), dtype=complex if coherent else float)
+        if self.rng_mode == 'host':
+            self._run_host_rng(I, coherent)
+        else:
+            seed = self.seed if self.seed is not None else int(numpy.random.SeedSequence().generate_state(2, numpy.uint32).view(numpy.uint64)[0])
+            self._device_seed = seed
+            n_real = self.Niter // 2
+            out = self._handle.run(seed, 0, n_real, None, float(self.logamp_var), coherent)
+            re, im = out[:n_real].reshape(self.Nchunks, half), out[n_real:].reshape(self.Nchunks, half)
+            I[:, :half], I[:, half:] = re, im
+            # the log-amplitudes the device drew, in iteration order (global iteration 2g+s)
+            chi = self._handle.rng_logamp(seed, 0, self.Niter) * numpy.sqrt(self.logamp_var)
+            la = numpy.empty((self.Nchunks, M))
+            la[:, :half] = chi[0::2].reshape(self.Nchunks, half)
+            la[:, half:] = chi[1::2].reshape(self.Nchunks, half)
+            self.logamp[:] = la.ravel()
+        self.random_iters = I[-1]
+        self.timing = self._handle.last_timing()
+        self.result = FastResult(I.flatten(), self.diffraction_limit)
+        self.I = self.result.power
+        logger.info(self.result)
+        return self.result
+
+    def _run_host_rng(self, I, coherent):
+        """Parity mode: numpy draws in the reference's order (fast.py:123,593,600; funcs.py:352-365)."""
+        M, half, N = self.Niter_per_chunk, self.Niter_per_chunk // 2, self.Npxls
+        re = _R.normal(0, 1, size=(self.Niter,))
+        _R.normal(0, 1, size=(self.Niter,))
+        self.logamp[:] = re * numpy.sqrt(self.logamp_var)
+        for i in range(self.Nchunks):
+            cr = _R.normal(0, 1, size=(half, N, N))
+            ci = _R.normal(0, 1, size=(half, N, N))
+            sr = si = None
+            if self.subharmonics:
+                sr = _R.normal(0, 1, size=(half, 3, 3, 3))
+                si = _R.normal(0, 1, size=(half, 3, 3, 3))
+            I[i] = self._handle.run_coeffs(cr, ci, self.logamp[i * M:(i + 1) * M], coherent, sr, si)
+
+    def histogram(self, lo_db=-60.0, hi_db=10.0, nbins=4096):
+        """Histogram of dB_rel of the last run, computed on the device."""
+        return self._handle.histogram(lo_db, hi_db, nbins)
+
+    def calc_zenith_correction(self, zenith_angle):
+        return 1 / numpy.cos(numpy.radians(zenith_angle))
+
+
+class FastResult():
+    '''
+    Per-iteration coupled power relative to the diffraction limit, with lazy unit
+    conversions (same attributes as fast/fast.py:931-994):
+
+        dB_rel, dB_abs, dBm, power [W], scintillation_index, avg_power_*
+    '''
+    def __init__(self, random_iters, diffraction_limit, header=None):
+        self._r = random_iters
+        self._dl = diffraction_limit
+        if header != None:
+            self.hdr = header
+
+    dB_rel = property(lambda s: 10 * numpy.log10(s._r))
+    dB_abs = property(lambda s: 10 * numpy.log10(s._r * s._dl))
+    dBm = property(lambda s: 10 * numpy.log10(s._r * s._dl / 1e-3))
+    power = property(lambda s: s._dl * s._r)
+    scintillation_index = property(lambda s: (s._r / s._r.mean()).var())
+    avg_power_W = property(lambda s: s.power.mean())
+    avg_power_dBm = property(lambda s: 10 * numpy.log10(s.avg_power_W / 1e-3))
+    avg_power_dB_rel = property(lambda s: 10 * numpy.log10((s.power / s._dl).mean()))
+    avg_power_dB_abs = property(lambda s: 10 * numpy.log10(s.avg_power_W))
+
+    def __str__(self):
+        return ("FAST result statistics:\n"
+                f"            Avg. power (W): {self.avg_power_W}\n"
+                f"            Avg. power (dBm): {self.avg_power_dBm}\n"
+                f"            Avg. power (dB_rel): {self.avg_power_dB_rel}\n"
+                f"            Avg. power (dB_abs): {self.avg_power_dB_abs}\n"
+                f"            Scintillation index: {self.scintillation_index}\n        ")

@@ -1,0 +1,359 @@
+"""Host-side, one-off producers of the GPU kernels' inputs: atmosphere scalars, grid sizing,
+pupil and fibre mode, low-frequency mask, link budget, sub-harmonic spectrum.
+
+These are the "host-side producers" of SURVEY.md section 8a: cheap numpy work done once per
+`Fast` object, restated from the reference's init sequence (fast/fast.py:95-104), each
+function citing the lines it follows.  Nothing here is on the Monte-Carlo hot path and
+nothing here needs a GPU, so it is unit-tested on CPU against the golden fixtures.
+"""
+import logging
+from types import SimpleNamespace
+
+import numpy as np
+from scipy.optimize import minimize_scalar
+from scipy.special import jv
+
+from . import hostmath as hm
+
+logger = logging.getLogger(__name__)
+TWO_PI = 2 * np.pi
+
+
+# ----------------------------------------------------------------------------- geometry
+def l_path(h_sat, zeta):
+    """Slant range to a satellite at altitude h_sat, zenith angle zeta [deg] (funcs.py:388-399)."""
+    r_e = 6.371009e6
+    z = np.radians(zeta)
+    b = -2 * r_e * np.cos(np.pi - z)
+    c = r_e ** 2 - (r_e + h_sat) ** 2
+    disc = np.sqrt(b ** 2 - 4 * c)
+    r1 = (-b + disc) / 2
+    return r1 if r1 >= 0 else (-b - disc) / 2
+
+
+def wind_correction(h, theta_loop, t_loop):
+    """Apparent wind from the satellite's angular motion (funcs.py:403-406)."""
+    return -np.array([np.sin(np.radians(theta_loop[0] / 3600)) * h / t_loop,
+                      np.sin(np.radians(theta_loop[1] / 3600)) * h / t_loop]).T
+
+
+def atmosphere(p):
+    """Fast.init_atmos (fast.py:229-276)."""
+    a = SimpleNamespace()
+    a.zenith_correction = 1 / np.cos(np.radians(p['ZENITH_ANGLE']))            # fast.py:763-766
+    a.h = p['H_TURB'] * a.zenith_correction
+    a.cn2 = p['CN2_TURB'] * a.zenith_correction
+    a.L = p['L_SAT'] if p['L_SAT'] is not None else l_path(p['H_SAT'], p['ZENITH_ANGLE'])
+    a.dtheta = p['DTHETA']
+    a.paa = np.sqrt(a.dtheta[0] ** 2 + a.dtheta[1] ** 2)
+    wind_dir = p['WIND_DIR']
+    if 'AZIMUT_SAT' in p:
+        wind_dir = [(x - p['AZIMUT_SAT']) % 380 for x in wind_dir]              # sic: % 380 (fast.py:250)
+    a.wind_dir = wind_dir
+    ang = np.radians(wind_dir)
+    a.wind_vector = (p['WIND_SPD'] * np.array([np.cos(ang), np.sin(ang) / a.zenith_correction])).T
+    if 'ANISO_DL' in p:
+        a.wind_correction = wind_correction(a.h, p['ANISO_DL'], p['TLOOP'])
+        a.wind_vector = a.wind_vector + a.wind_correction
+    a.wind_speed = np.sqrt(a.wind_vector[:, 0] ** 2 + a.wind_vector[:, 1] ** 2)
+    a.r0 = hm.cn2_to_r0(p['CN2_TURB'].sum(), lamda=500e-9)
+    a.theta0 = hm.isoplanatic_angle(p['CN2_TURB'], p['H_TURB'], lamda=500e-9)
+    a.tau0 = hm.coherence_time(p['CN2_TURB'], p['WIND_SPD'], lamda=500e-9)
+    a.rytov_variance = hm.rytov_variance(p['CN2_TURB'], p['H_TURB'], lamda=500e-9)
+    a.r0_los = hm.cn2_to_r0(a.cn2.sum(), lamda=p['WVL'])
+    a.theta0_los = hm.isoplanatic_angle(a.cn2, a.h, lamda=p['WVL'])
+    a.tau0_los = hm.coherence_time(a.cn2, a.wind_speed, lamda=p['WVL'])
+    a.rytov_variance_los = hm.rytov_variance(a.cn2, a.h, lamda=p['WVL'])
+    return a
+
+
+def grid_size(p, atm):
+    """Pixel scale, grid size and pupil-window size (Fast.init_frequency_grid, fast.py:147-211)."""
+    D = p['D_GROUND']
+    if p['DX'] == 'auto':
+        dx = np.min([p['DSUBAP'] / 2, atm.r0_los / 2, D / 10])
+        if p['AO_MODE'] == 'NOAO':
+            dx = atm.r0_los / 2
+        logger.info(f"Auto set DX to {dx}")
+    else:
+        dx = p['DX']
+    if p['NPXLS'] == 'auto':
+        nyq = np.min([np.pi / (atm.h[-1] * atm.paa / 206265.),
+                      np.pi / (max(atm.wind_speed) * p['TLOOP']),
+                      np.pi / p['DSUBAP'] / 5])
+        n_nyq = int(2 * np.ceil(2 * np.pi / (nyq * dx) / 2))
+        n_ap = int(2 * np.ceil(D / dx / 2)) + 2
+        n_t = int(p['WIND_SPD'].max() * p['DT'] * p['NITER'] / p['DX'] / 2) if p['TEMPORAL'] else 0
+        N = np.max([n_nyq, n_ap, n_t])
+        logger.info(f"Auto set NPXLS to {N}")
+        if p['AO_MODE'] == 'NOAO' and not np.isinf(p['L0']):
+            n_l0 = int(2 * np.ceil((p['L0'] * 2) / dx) / 2)
+            if n_l0 > N:
+                logger.warning(f"L0 set with NOAO mode, low orders may be undersampled. Recommended NPXLS: {n_l0}")
+    else:
+        N = p['NPXLS']
+    if N > 2048:
+        logger.warning(f"NPXLS is large ({N}) and may cause very high memory usage")
+    Np = int(np.ceil(D / dx)) + 2
+    return dx, int(N), Np
+
+
+def freq_axis(N, dx):
+    """arange(-N/2, N/2) * 2 pi / (N dx)  (fast.py:830-833)."""
+    return np.arange(-N / 2., N / 2.) * (TWO_PI / (N * dx))
+
+
+def subharm_axes(N, dx, pmax=3):
+    """(3, 3) axes [-1, 0, 1] * 2 pi / (3^p N dx)  (fast.py:835-844)."""
+    D = dx * N
+    return np.array([np.arange(-1, 2) * (TWO_PI / (3 ** p * D)) for p in range(1, pmax + 1)])
+
+
+def mesh(axis):
+    """fx, fy, |f| for a 1-D axis or a stack of axes (fast.py:896-921)."""
+    if axis.ndim == 1:
+        fx, fy = np.meshgrid(axis, axis)
+    else:
+        fx = np.stack([np.meshgrid(a, a)[0] for a in axis])
+        fy = np.stack([np.meshgrid(a, a)[1] for a in axis])
+    return fx, fy, np.sqrt(fx ** 2 + fy ** 2)
+
+
+# ----------------------------------------------------------------------------- masks
+def zernike_sq(fabs, fx, fy, D, n_noll):
+    """sum_j |Z~_j|^2, centre forced to 1 (ao_power_spectra.py:10-21, 54-76)."""
+    phi = np.arctan2(fy, fx)
+    out = np.zeros(fabs.shape)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        x = fabs * D / 2
+        for j in range(1, n_noll + 1):
+            n, m = hm.noll_to_nm(j)
+            rad = 2 * jv(n + 1, x) / x
+            if m == 0:
+                out = out + (n + 1) * rad ** 2
+            elif j % 2 == 0:
+                out = out + 2 * (n + 1) * (rad * np.cos(m * phi)) ** 2
+            else:
+                out = out + 2 * (n + 1) * (rad * np.sin(m * phi)) ** 2
+    out[..., int(fabs.shape[-2] / 2), int(fabs.shape[-1] / 2)] = 1
+    return out
+
+
+def lf_mask(fx, fy, d_wfs, modal, modal_mult, zmax, D):
+    """Corrected region of the AO system (ao_power_spectra.mask_lf, 119-141)."""
+    fmax = np.pi / d_wfs
+    wfs = np.logical_and(np.abs(fx) <= fmax, np.abs(fy) <= fmax)
+    if not modal:
+        dm = wfs
+    elif zmax is None:
+        dm = np.sqrt(fx ** 2 + fy ** 2) <= fmax * modal_mult
+    else:
+        dm = zernike_sq(np.sqrt(fx ** 2 + fy ** 2), fx, fy, D, zmax)
+    return wfs * np.where(dm < 1, dm, 1)
+
+
+# ----------------------------------------------------------------------------- pupil / fibre mode
+def aperture(N, dx, D, obsc=0):
+    """Unit-power annular aperture (funcs.compute_pupil, funcs.py:261-277, Ny=None)."""
+    ap = hm.circle(D / dx / 2, N) - hm.circle(obsc / dx / 2, N)
+    return ap / np.sqrt(ap.sum() * dx ** 2)
+
+
+def coupling_loss(W, shape, pupil, dx):
+    """funcs.py:347-350."""
+    field = hm.gaussian2d(shape, W / dx / np.sqrt(2)) * np.sqrt(2. / (np.pi * W ** 2))
+    return 1 - np.abs((field * pupil).sum() * dx ** 2) ** 2
+
+
+def best_gaussian(pupil, dx):
+    """Brent search for the fibre-mode radius (funcs.optimize_fibre, funcs.py:317-345)."""
+    shape = pupil.shape
+    lo, hi = dx, max(shape) * dx
+    f = lambda W: coupling_loss(W, shape, pupil, dx)
+    opt = minimize_scalar(f, bracket=[lo, hi]).x
+    if abs(opt) < dx:
+        logger.info("Gaussian mode optimisation failed, trying with different parameters")
+        opt = minimize_scalar(f, bracket=[lo, 2 * hi]).x
+        if abs(opt) < dx:
+            raise Exception("Cannot optimise gaussian mode, try changing DX?")
+    g = hm.gaussian2d(shape, opt / dx / np.sqrt(2)) * np.sqrt(2. / (np.pi * opt ** 2))
+    return g, np.abs(opt)
+
+
+def fibre_mode(pupil, dx, W0, D=None, obsc=None, ptype='gauss'):
+    """funcs.compute_gaussian_mode (funcs.py:280-305) -> (mode, W0)."""
+    nx, ny = pupil.shape
+    if ptype == 'gauss':
+        if W0 == "opt":
+            g, opt = best_gaussian(pupil, dx)
+            return g / pupil.max(), opt
+        return hm.gaussian2d((nx, ny), W0 / dx / np.sqrt(2)) * np.sqrt(2 / (np.pi * W0 ** 2)) / pupil.max(), W0
+    if ptype == 'axicon':
+        if W0 == "opt":
+            raise TypeError("Using 'axicon' and W0='opt' not supported, please set a value for W0")
+        x = np.arange(-nx / 2, nx / 2, 1) * dx
+        y = np.arange(-ny / 2, ny / 2, 1) * dx
+        xx, yy = np.meshgrid(y, x)
+        r = np.sqrt(xx ** 2 + yy ** 2)
+        ring = np.exp(-(r - (obsc / 2 + (D / 2 - obsc / 2) / 2)) ** 2 / W0 ** 2)
+        return ring / np.sqrt((ring ** 2).sum() * dx ** 2) / pupil.max(), W0
+    raise Exception('ptype must be one of "gauss" or "axicon"')
+
+
+def pupil_filter(field):
+    """|FT(field)|^2 / (sum field)^2 (funcs.pupil_filter, funcs.py:308-315, spline=False)."""
+    P = np.abs(hm.ft2(field, 1)) ** 2
+    return P / field.sum() ** 2
+
+
+def pupils(p, N, Np, dx):
+    """Fast.init_pupil_mask (fast.py:332-392), non-temporal part."""
+    o = SimpleNamespace()
+    D, obsc = p['D_GROUND'], p['OBSC_GROUND']
+    o.dx_sat = p['D_SAT'] / 32
+    full = aperture(N, dx, D, obsc)
+    o.pupil_sat = aperture(32, o.dx_sat, p['D_SAT'], p['OBSC_SAT'])
+    mode_full, o.W0 = fibre_mode(full, dx, p['W0'], D=D, obsc=obsc, ptype='axicon' if p['AXICON'] else 'gauss')
+    o.pupil_mode_sat, o.W0_sat = fibre_mode(o.pupil_sat, o.dx_sat, "opt", ptype="gauss")
+    o.pupil_filter = pupil_filter(full * mode_full)
+    lo, hi = (N - Np) // 2, (N + Np) // 2
+    o.crop_lo = lo
+    o.pup_coords = np.array((np.arange(lo, hi), np.arange(lo, hi))).astype(int)
+    o.pupil = full[lo:hi, lo:hi]
+    o.pupil_mode = mode_full[lo:hi, lo:hi]
+    return o
+
+
+# ----------------------------------------------------------------------------- link budget
+def link_budget(p, pup, atm, dx):
+    """Fast.compute_link_budget (fast.py:670-734) -> (dict, diffraction_limit [W])."""
+    wvl = p['WVL']
+    if p['PROP_DIR'] == "up":
+        D_t, D_r, obsc_t, obsc_r = p['D_GROUND'], p['D_SAT'], p['OBSC_GROUND'], p['OBSC_SAT']
+        mode, dx_r, pupil_r, w0 = pup.pupil_mode_sat, pup.dx_sat, pup.pupil_sat, pup.W0
+    else:
+        D_t, D_r, obsc_t, obsc_r = p['D_SAT'], p['D_GROUND'], p['OBSC_SAT'], p['OBSC_GROUND']
+        mode, dx_r, pupil_r, w0 = pup.pupil_mode, dx, pup.pupil, pup.W0_sat
+    lb = {}
+    lb['power'] = 10 * np.log10(p['POWER'] / 1e-3)
+    lb['free_space'] = 10 * np.log10((wvl / (4 * np.pi * atm.L)) ** 2)
+    alpha, gamma = D_t / (2 * w0), obsc_t / D_t
+    g_t = 2 / alpha ** 2 * (np.exp(-alpha ** 2) - np.exp(-gamma ** 2 * alpha ** 2)) ** 2
+    lb['transmitter_gain'] = 10 * np.log10((np.pi * D_t ** 2) * 4 * np.pi / wvl ** 2 * g_t)
+    area = np.pi * ((D_r / 2) ** 2 - (obsc_r / 2) ** 2)
+    lb['receiver_gain'] = 10 * np.log10(4 * np.pi * area / wvl ** 2)
+    lb['transmission_loss'] = 10 * np.log10(p['TRANSMISSION'])
+    lb['smf_coupling'] = 10 * np.log10(((pupil_r * mode).sum() * dx_r) ** 2 / (mode ** 2).sum())
+    return lb, 10 ** (sum(lb.values()) / 10) / 1e3
+
+
+# ----------------------------------------------------------------------------- sub-harmonic spectrum
+def _von_karman(fabs, cn2, L0, l0):
+    km, k0 = 5.92 / l0, TWO_PI / L0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        base = 0.033 * np.exp(-fabs ** 2 / km ** 2) / (fabs ** 2 + k0 ** 2) ** (11 / 6.)
+    out = np.asarray(cn2, dtype=float).reshape((-1,) + (1,) * base.ndim) * base[None]
+    out[np.isinf(out)] = 0.
+    return out
+
+
+def subharm_spectrum(prob):
+    """Residual PSD on the 27 sub-harmonic frequencies (fast.py:494-523): 3 x 3 x 3 points,
+    evaluated on the host (the N x N main grid is evaluated on the GPU)."""
+    p, atm = prob.params, prob.atm
+    axes = subharm_axes(prob.N, prob.dx)
+    fx, fy, fabs = mesh(axes)
+    k = TWO_PI / p['WVL']
+    L = len(atm.h)
+    mask = lf_mask(fx, fy, prob.d_wfs, prob.modal, prob.modal_mult, prob.zmax, p['D_GROUND'])
+    turb = _von_karman(fabs, atm.cn2, p['L0'], p['l0'])
+    lead = (slice(None),) + (None,) * fx.ndim
+    v_k = fx[None] * atm.wind_vector[:, 0][lead] + fy[None] * atm.wind_vector[:, 1][lead]
+    mode = prob.ao_mode
+    if mode == 'NOAO':
+        G = 1
+    else:
+        dr = np.outer(atm.h, np.asarray(atm.dtheta, dtype=float) / 206265.)
+        dr_k = fx[None] * dr[:, 0][lead] + fy[None] * dr[:, 1][lead]
+        s = np.sinc(p['TEXP'] * v_k / TWO_PI)
+        aniso = 1 - 2 * np.cos(dr_k - p['TLOOP'] * v_k) * s + s ** 2
+        if mode in ('AO', 'TT'):
+            G = aniso * mask + (1 - mask)
+        else:
+            aniso_l = 1 - 2 * np.cos(-p['TLOOP'] * v_k) * s + s ** 2
+            Z = zernike_sq(fabs, fx, fy, p['D_GROUND'], 4)
+            G = mask * (Z * aniso + (1 - Z) * aniso_l) + (1 - mask)
+    alias = 0.
+    if p['ALIAS'] and mode != 'NOAO':
+        alias = np.zeros((L,) + fabs.shape)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t0 = fx ** 2 * fy ** 2 / fabs ** 4
+            for l in range(-5, 6):
+                for kk in range(-5, 6):
+                    if l == 0 and kk == 0:
+                        continue
+                    sx, sy, sabs = _shifted(axes, kk, l, prob.d_wfs)
+                    t2 = _von_karman(sabs, atm.cn2, p['L0'], p['l0'])
+                    m = (fx / sy + fy / sx) ** 2 * t2 * t0
+                    m[..., 1, 1] = 0.
+                    if l == 0:
+                        m[..., 1, :] = t2[..., 1, :]
+                    if kk == 0:
+                        m[..., 1] = t2[..., 1]
+                        m[..., 1, 1] = t2[..., 1, 1]
+                    alias += m
+            alias *= np.sinc(p['TEXP'] * v_k / TWO_PI) ** 2 * mask
+        alias[np.isnan(alias)] = 0.
+    noise = 0.
+    if p['NOISE'] > 0 and mode != 'NOAO':
+        with np.errstate(divide="ignore", invalid="ignore"):
+            noise = p['NOISE'] / (fabs ** 2 * np.sinc(prob.d_wfs * fx / TWO_PI) ** 2 * np.sinc(prob.d_wfs * fy / TWO_PI) ** 2)
+        noise[..., 1, 1] = 0.
+        noise = mask * noise
+    per_layer = TWO_PI * k ** 2 * (turb * G + alias) + noise / L
+    df = axes[..., 1] - axes[..., 0]
+    return per_layer.sum(0), fx, fy, df
+
+
+def _shifted(axes, k, l, d):
+    ax = axes - TWO_PI * k / d
+    ay = axes - TWO_PI * l / d
+    sx = np.stack([np.meshgrid(a, b)[0] for a, b in zip(ax, ay)])
+    sy = np.stack([np.meshgrid(a, b)[1] for a, b in zip(ax, ay)])
+    return sx, sy, np.sqrt(sx ** 2 + sy ** 2)
+
+
+# ----------------------------------------------------------------------------- the whole host init
+def build_problem(params):
+    """Everything `Fast.__init__` computes on the host before the GPU is needed
+    (fast.py:71-103 minus compute_powerspec)."""
+    p = params
+    prob = SimpleNamespace(params=p)
+    prob.Niter, prob.Nchunks = p['NITER'], p['NCHUNKS']
+    if prob.Niter % prob.Nchunks != 0:
+        raise Exception('NCHUNKS must divide NITER without remainder')
+    prob.M = prob.Niter // prob.Nchunks
+    if prob.M % 2 != 0 and not p['TEMPORAL']:
+        raise Exception('NITER/NCHUNKS must be even number')
+    prob.atm = atmosphere(p)
+    prob.wvl = p['WVL']
+    prob.k = TWO_PI / prob.wvl
+    prob.dx, prob.N, prob.Np = grid_size(p, prob.atm)
+    prob.axis = freq_axis(prob.N, prob.dx)
+    prob.df = prob.axis[1] - prob.axis[0]
+    prob.subharm = bool(p['SUBHARM']) and not p['TEMPORAL']
+    # AO parameters (fast.py:297-315)
+    prob.ao_mode, prob.d_wfs = p['AO_MODE'], p['DSUBAP']
+    prob.zmax, prob.modal, prob.modal_mult = p['ZMAX'], p['MODAL'], p['MODAL_MULT']
+    if prob.ao_mode == 'TT':
+        prob.zmax, prob.modal, prob.modal_mult = 3, True, 1
+    if prob.ao_mode not in ('NOAO', 'AO', 'TT', 'LGSAO'):
+        raise Exception('Mode not recognised, note that "AO_PA", "TT_PA" and "LGS_PA" are now "AO" and "TT" and "LGSAO')
+    fx, fy, fabs = mesh(prob.axis)
+    prob.lf_mask = lf_mask(fx, fy, prob.d_wfs, prob.modal, prob.modal_mult, prob.zmax, p['D_GROUND'])
+    prob.lgs_z = zernike_sq(fabs, fx, fy, p['D_GROUND'], 4) if prob.ao_mode == 'LGSAO' else None
+    prob.pup = pupils(p, prob.N, prob.Np, prob.dx)
+    prob.W = prob.pup.pupil * prob.pup.pupil_mode
+    prob.link_budget, prob.diffraction_limit = link_budget(p, prob.pup, prob.atm, prob.dx)
+    prob.simpson_w = hm.simpson_weights(prob.axis)
+    return prob

@@ -1,0 +1,169 @@
+/* fastmc.h -- C-ABI of libfastmc.so: the MI355X (gfx950) implementation of the FAST
+ * Monte-Carlo hot path.  Plain C types only; loaded with ctypes / cgo / JNI / dlopen.
+ *
+ * The reference (ojdf/fast, /root/reference) is pure Python and has no FFI.  Each entry
+ * point below names the reference code it replaces (file:line, relative to the
+ * reference root); the Python binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative FASTMC_E* code; the message
+ *     for the calling thread is returned by fastmc_last_error();
+ *   - the caller owns every host buffer; the library copies in during set_* / run and
+ *     owns all device memory until fastmc_destroy();
+ *   - all host arrays are C-contiguous float64 unless stated otherwise;
+ *   - calls on one handle must be serialised by the caller; calls are blocking;
+ *   - nothing here ever falls back to a CPU implementation: without a gfx950 device
+ *     fastmc_create() fails with FASTMC_ENODEV.
+ */
+#ifndef FASTMC_H
+#define FASTMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FASTMC_VERSION 100
+
+#define FASTMC_OK 0
+#define FASTMC_EINVAL (-1)   /* bad argument */
+#define FASTMC_ENODEV (-2)   /* no usable GPU */
+#define FASTMC_EHIP (-3)     /* HIP runtime error (message has the HIP string) */
+#define FASTMC_ESTATE (-4)   /* spectrum / pupil not set */
+#define FASTMC_ECOMM (-5)    /* RCCL error */
+
+#define FASTMC_F64 0 /* complex128 pipeline: reference precision */
+#define FASTMC_F32 1 /* complex64 pipeline, float64 detector sums */
+
+typedef struct fastmc_ctx fastmc_t;
+
+int fastmc_version(void);
+const char* fastmc_last_error(void);
+int fastmc_device_count(int* n);
+
+/* One handle = one GPU + one (N, Np) problem.
+ * Replaces: Fast.init_fftw (fast/fast.py:419-438: plan + IN/OUT buffers) and
+ * Fast.init_phs_logamp (fast/fast.py:440-443).  N = Npxls, Np = Npxls_pup. */
+int fastmc_create(fastmc_t** h, int device_id, int N, int Np, int precision);
+void fastmc_destroy(fastmc_t* h);
+
+/* powerspec: (N, N) residual phase PSD in the reference's fft-shifted layout
+ * (`Fast.powerspec`, fast/fast.py:481); df = freq.main.df.  The library stores
+ * sqrt(powerspec)*df, i.e. the colouring of fast/fast.py:594 and the `rand * df`
+ * of fast/funcs.py:213. */
+int fastmc_set_spectrum(fastmc_t* h, const double* powerspec, double df);
+
+/* W = pupil * pupil_mode on the (Np, Np) window (fast/fast.py:649), crop_lo = first
+ * row/column of the window = pup_coords[0][0] (fast/fast.py:390), dx = pixel scale. */
+int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, double dx);
+
+/* Optional sub-harmonics (fast/funcs.py:225-258, fast/fast.py:598-603).
+ * powerspec_sh, fx, fy: (3, 3, 3) [level][row][col]; df: (3,).  NULL disables. */
+int fastmc_set_subharm(fastmc_t* h, const double* powerspec_sh, const double* fx,
+                       const double* fy, const double* df);
+
+/* Monte-Carlo run with the on-device counter-based generator (Philox4x32-10 keyed on
+ * (seed; realisation, pixel), Box-Muller) -- replaces the body of the chunk loop of
+ * Fast.run (fast/fast.py:130-134: compute_phs 589-605 + compute_detector 647-668) and
+ * Fast.compute_logamp (fast/fast.py:639-645).
+ *
+ * Realisation g (one complex N x N FFT) yields two iterations: its real and its
+ * imaginary screen (fast/funcs.py:220-221).  Realisations real0 .. real0+n_real-1 are
+ * computed; results do not depend on how a range is split over calls or GPUs.
+ *   logamp: 2*n_real log-amplitudes chi, ordered like `out`, or NULL to draw them on
+ *           the device as N(0, logamp_var) (stream keyed on the global iteration 2g+s).
+ *   out:    coherent == 0: 2*n_real float64, out[j] = |a|^2 of the REAL screen of
+ *           realisation real0+j, out[n_real+j] = of its IMAGINARY screen (the order of
+ *           vstack([Re, Im]) in fast/funcs.py:221);
+ *           coherent != 0: 2*n_real complex128 (interleaved re, im), same order. */
+int fastmc_run(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real,
+               const double* logamp, double logamp_var, int coherent, double* out);
+
+/* Parity mode: the same pipeline fed with host-drawn coefficients (numpy draw order of
+ * fast/funcs.py:352-356: all real parts, then all imaginary parts).
+ *   coeff_re, coeff_im: (n_real, N, N) standard normals;
+ *   sh_re, sh_im: (n_real, 3, 3, 3) sub-harmonic coefficients or NULL;
+ *   logamp: 2*n_real values (required: the host drew them, fast/fast.py:123). */
+int fastmc_run_coeffs(fastmc_t* h, const double* coeff_re, const double* coeff_im,
+                      int64_t n_real, const double* sh_re, const double* sh_im,
+                      const double* logamp, int coherent, double* out);
+
+/* Debug / parity: the cropped phase screens themselves, (2*n_real, Np, Np) float64 in
+ * the order of `out` above == Fast.phs after compute_phs (fast/fast.py:596-603). */
+int fastmc_screens_coeffs(fastmc_t* h, const double* coeff_re, const double* coeff_im,
+                          int64_t n_real, const double* sh_re, const double* sh_im,
+                          double* phs);
+int fastmc_screens(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real, double* phs);
+
+/* Debug / parity: the device generator's coefficients for one realisation,
+ * (N, N) complex128 interleaved; and device log-amplitude normals. */
+int fastmc_rng_coeffs(fastmc_t* h, uint64_t seed, int64_t real, double* coeff_interleaved);
+int fastmc_rng_logamp(fastmc_t* h, uint64_t seed, int64_t iter0, int64_t n_iter, double* normals);
+
+/* Fixed-bin histogram of 10*log10(power) of the last run's results kept on the device
+ * (FastResult.dB_rel, fast/fast.py:949-951): bins[k] counts lo + k*(hi-lo)/nbins <= x <
+ * ..., bins[nbins] = underflow, bins[nbins+1] = overflow.  bins: nbins+2 int64. */
+int fastmc_histogram(fastmc_t* h, double lo_db, double hi_db, int nbins, int64_t* bins);
+
+/* Timing of the last fastmc_run / fastmc_run_coeffs, measured with HIP events on the
+ * library's own stream: total ms, and per kernel family [rows, cols, finalize] ms and
+ * launch counts.  times_ms: 4 doubles, launches: 4 int64. */
+int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches);
+
+/* Which kernel family the handle uses: 0 = direct (any N), 1 = wave-FFT (N in 512..2048,
+ * power of two).  force: -1 query only, 0/1 select (1 fails with EINVAL if unsupported). */
+int fastmc_kernel_path(fastmc_t* h, int force);
+
+/* Realisations in flight per launch (batch).  0 = library default. */
+int fastmc_set_batch(fastmc_t* h, int batch);
+
+/* ---- AO-residual power spectrum (Fast.compute_powerspec, fast/fast.py:445-492) ---- */
+#define FASTMC_NOAO 0
+#define FASTMC_AO 1
+#define FASTMC_TT 2
+#define FASTMC_LGSAO 3
+
+typedef struct {
+  int32_t N;            /* Npxls */
+  int32_t n_layers;     /* L */
+  double dx;            /* pixel scale [m] */
+  double wvl;           /* wavelength [m] */
+  double L0, l0;        /* outer / inner scale [m] (L0 may be +inf) */
+  int32_t ao_mode;      /* FASTMC_NOAO .. FASTMC_LGSAO (fast/ao_power_spectra.py:232-267) */
+  int32_t alias;        /* include Jol_alias_openloop (ao_power_spectra.py:163-223), lmax=kmax=5 */
+  double noise;         /* WFS noise variance; >0 enables Jol_noise_openloop (148-161) */
+  double d_wfs;         /* sub-aperture pitch [m] */
+  double t_loop, t_exp; /* loop delay, WFS exposure [s] */
+  double dtheta[2];     /* point-ahead [arcsec] */
+  const double* cn2;    /* (L,) zenith-corrected cn2 dh */
+  const double* h;      /* (L,) zenith-corrected heights */
+  const double* wind;   /* (L, 2) wind vectors */
+  const double* lf_mask;      /* (N, N) mask_lf as float64 (ao_power_spectra.py:119-141) */
+  const double* pupil_filter; /* (N, N) funcs.pupil_filter (funcs.py:308-315) or NULL */
+  const double* lgs_z;        /* (N, N) zernike_squared_filter(Z<=4) for LGSAO or NULL */
+  const double* simpson_w;    /* (N,) Simpson weights of the frequency axis (funcs.py:100-115) */
+} fastmc_ps_params;
+
+#define FASTMC_PS_NSCALARS 6 /* aniso_servo, alias, noise, fitting, phs_var, logamp_var */
+
+/* Outputs (any may be NULL): powerspec (N,N); per_layer (L,N,N); logamp_ps (N,N);
+ * scalars: FASTMC_PS_NSCALARS values in the order above, then L phs_var_weights. */
+int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double* powerspec,
+                     double* per_layer, double* logamp_ps, double* scalars, double* kernel_ms);
+
+/* ---- multi-GPU result exchange: one process per GPU, RCCL over xGMI ---- */
+/* 128-byte RCCL unique id, created on rank 0 and distributed by the launcher. */
+int fastmc_comm_unique_id(uint8_t id128[128]);
+int fastmc_comm_init(fastmc_t* h, const uint8_t id128[128], int world_size, int rank);
+/* All-gather of each rank's last-run powers (equal count per rank) and all-reduce (sum)
+ * of its histogram, on the device buffers, then copied to the host arrays. */
+int fastmc_comm_gather(fastmc_t* h, int64_t n_local, double* all_powers /* world*n_local */,
+                       int64_t* hist /* nbins+2, in: unused, out: global */, double lo_db,
+                       double hi_db, int nbins);
+int fastmc_comm_destroy(fastmc_t* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTMC_H */

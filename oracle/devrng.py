@@ -1,0 +1,75 @@
+"""Oracle restatement of the DEVICE generator (test infrastructure, not product).
+
+The GPU path can draw its complex Gaussian coefficients on the device
+(fast_amd/csrc/fmc_core.h: philox4x32_10; fmc_kernels.h: box_muller, draw_pair).  That
+generator has no counterpart in the reference (which uses numpy's PCG64 stream,
+fast/funcs.py:21,352-356); this module restates OUR definition in numpy/float64 so that the
+device path can be checked deterministically, not only statistically:
+
+  pixel pair (ky, kx'), kx' < H = ceil(N/2):  x = Philox4x32-10(ctr=(ky*H+kx', STREAM, g_lo, g_hi), key=seed)
+  coefficient (ky, kx')   = BM(x0, x1),   coefficient (ky, kx'+H) = BM(x2, x3)
+  BM(a, b) = sqrt(-2 ln((a+.5)/2^32)) * exp(2 pi i (b+.5)/2^32)
+
+Philox4x32-10 is the published Random123 algorithm (Salmon et al., SC'11); `test_oracle_devrng`
+pins this implementation to Random123's known-answer vectors.
+The device evaluates BM in float32 with hardware log2/sqrt/sin/cos; agreement is ~1e-6 absolute.
+"""
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = 0x9E3779B9, 0xBB67AE85
+MASK = np.uint64(0xFFFFFFFF)
+STREAM_SCREEN, STREAM_LOGAMP, STREAM_SUBHARM = 0, 1, 2
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised over the counter words (uint32 arrays or scalars); key words are ints."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & MASK for c in (c0, c1, c2, c3))
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)
+        n1 = p1 & MASK
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)
+        n3 = p0 & MASK
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + W0) & 0xFFFFFFFF
+        k1 = (k1 + W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def box_muller(a, b):
+    u = (a.astype(np.float64) + 0.5) / 2.0 ** 32
+    t = (b.astype(np.float64) + 0.5) / 2.0 ** 32
+    r = np.sqrt(-2.0 * np.log(u))
+    return r * np.cos(2 * np.pi * t) + 1j * r * np.sin(2 * np.pi * t)
+
+
+def device_coefficients(seed, g, N):
+    """(N, N) complex coefficients of realisation g (== fastmc_rng_coeffs)."""
+    H = (N + 1) // 2
+    ky, kxp = np.meshgrid(np.arange(N), np.arange(H), indexing="ij")
+    x0, x1, x2, x3 = philox4x32_10(ky * H + kxp, STREAM_SCREEN, g & 0xFFFFFFFF, g >> 32, seed & 0xFFFFFFFF, seed >> 32)
+    out = np.empty((N, N), dtype=complex)
+    out[:, :H] = box_muller(x0, x1)
+    second = box_muller(x2, x3)
+    out[:, H:] = second[:, :N - H]
+    return out
+
+
+def device_logamp_normals(seed, it0, n):
+    it = np.arange(it0, it0 + n, dtype=np.uint64)
+    x0, x1, _, _ = philox4x32_10(0, STREAM_LOGAMP, it & MASK, it >> np.uint64(32), seed & 0xFFFFFFFF, seed >> 32)
+    return box_muller(x0, x1).real
+
+
+def device_subharm_coefficients(seed, g):
+    """(3, 3, 3) complex coefficients of realisation g (pairs (m, m+14))."""
+    m = np.arange(14)
+    x0, x1, x2, x3 = philox4x32_10(m, STREAM_SUBHARM, g & 0xFFFFFFFF, g >> 32, seed & 0xFFFFFFFF, seed >> 32)
+    out = np.empty(27, dtype=complex)
+    out[:14] = box_muller(x0, x1)
+    out[14:] = box_muller(x2, x3)[:13]
+    return out.reshape(3, 3, 3)

@@ -1,0 +1,100 @@
+"""CPU: fast_amd's host-side init (fast_amd/host.py) against the reference's init products."""
+import numpy as np
+import pytest
+
+from conftest import E2E_CASES, load_golden, params_from_json
+import fast_amd
+from fast_amd import host, hostmath, turbulence_models as tm
+
+
+def _problem(case):
+    g = load_golden("e2e_" + case)
+    p = params_from_json(g["params_json"])
+    c = fast_amd.conf.ConfigParser(dict(p))
+    return g, c.config, host.build_problem(c.config)
+
+
+@pytest.mark.parametrize("case", E2E_CASES + ["default164"])
+def test_host_init_matches_reference(case):
+    g, p, prob = _problem(case)
+    atm, pup = prob.atm, prob.pup
+    assert prob.N == int(g["Npxls"]) and prob.Np == int(g["Npxls_pup"])
+    for name, val in (("dx", prob.dx), ("L", atm.L), ("paa", atm.paa), ("r0", atm.r0), ("theta0", atm.theta0),
+                      ("tau0", atm.tau0), ("r0_los", atm.r0_los), ("theta0_los", atm.theta0_los),
+                      ("tau0_los", atm.tau0_los), ("zenith_correction", atm.zenith_correction), ("k", prob.k),
+                      ("dx_sat", pup.dx_sat), ("W0", pup.W0), ("W0_sat", pup.W0_sat),
+                      ("diffraction_limit", prob.diffraction_limit)):
+        np.testing.assert_allclose(val, g[name], rtol=1e-12, err_msg=name)
+    for name, val in (("h", atm.h), ("cn2", atm.cn2), ("wind_vector", atm.wind_vector), ("wind_speed", atm.wind_speed),
+                      ("pupil", pup.pupil), ("pupil_mode", pup.pupil_mode), ("pupil_sat", pup.pupil_sat),
+                      ("pupil_mode_sat", pup.pupil_mode_sat)):
+        np.testing.assert_allclose(val, g[name], rtol=1e-12, atol=1e-300, err_msg=name)
+    np.testing.assert_allclose(pup.pupil_filter, g["pupil_filter"], rtol=1e-9, atol=1e-18)
+    np.testing.assert_allclose(np.asarray(prob.lf_mask, dtype=float), g["lf_mask"], rtol=1e-12, atol=1e-15)
+    assert np.array_equal(pup.pup_coords, g["pup_coords"])
+    keys = [str(k) for k in g["link_budget_keys"]]
+    assert keys == list(prob.link_budget.keys())
+    np.testing.assert_allclose(list(prob.link_budget.values()), g["link_budget_vals"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["subharm", "subharm_ao"])
+def test_subharm_spectrum_matches_reference(case):
+    g, p, prob = _problem(case)
+    ps, fx, fy, df = host.subharm_spectrum(prob)
+    np.testing.assert_allclose(ps, g["powerspec_subharm"], rtol=1e-11)
+    np.testing.assert_allclose(fx, g["sh_fx"], rtol=1e-15)
+    np.testing.assert_allclose(fy, g["sh_fy"], rtol=1e-15)
+    np.testing.assert_allclose(df, g["sh_df"], rtol=1e-15)
+
+
+def test_simpson_weights_reproduce_scipy():
+    from scipy.integrate import simpson
+    rng = np.random.default_rng(0)
+    for n in (16, 23, 64, 164):
+        f = host.freq_axis(n, 0.013)
+        w = hostmath.simpson_weights(f)
+        P = rng.random((3, n, n))
+        np.testing.assert_allclose(np.einsum("i,lij,j->l", w, P, w), simpson(simpson(P, x=f), x=f), rtol=1e-12)
+
+
+def test_turbulence_models():
+    g = load_golden("kat_turbulence")
+    h4, c4, w4 = tm.HV57_Bufton_profile(4)
+    np.testing.assert_allclose(h4, g["h4"], rtol=1e-13)
+    np.testing.assert_allclose(c4, g["cn2_4"], rtol=1e-13)
+    np.testing.assert_allclose(w4, g["w4"], rtol=1e-13)
+    h10, c10, w10 = tm.HV57_Bufton_profile(10, w=30, A=3e-14, vg=5)
+    np.testing.assert_allclose(np.r_[h10, c10, w10], np.r_[g["h10"], g["cn2_10"], g["w10"]], rtol=1e-13)
+    np.testing.assert_allclose(tm.HV57(g["hh"]), g["hv57"], rtol=1e-14)
+    np.testing.assert_allclose(tm.Bufton_wind(g["hh"]), g["bufton"], rtol=1e-14)
+    assert len(tm.HV57(g["hh"])) == 10 and tm.HV57(g["hh"]).dtype == float          # reference test_HV57
+    np.testing.assert_allclose([host.l_path(36e6, 55.0), host.l_path(600e3, 0.0), host.l_path(600e3, 70.0)], g["l_path"], rtol=1e-14)
+    np.testing.assert_allclose(host.wind_correction(np.array([1e3, 1e4]), [30.0, -12.0], 1e-3), g["wind_corr"], rtol=1e-14)
+
+
+def test_config_parser_defaults_and_errors(tmp_path):
+    c = fast_amd.conf.ConfigParser({"NITER": 10})
+    assert c.config["NCHUNKS"] == 10 and c.config["AO_MODE"] == "AO" and c.config["GPU_RNG"] == "device"
+    cfg = tmp_path / "cfg.py"
+    cfg.write_text("p = {'NITER': 4, 'NCHUNKS': 2}\n")
+    assert fast_amd.conf.ConfigParser(str(cfg)).config["NITER"] == 4
+    with pytest.raises(Exception):
+        fast_amd.conf.ConfigParser(str(tmp_path / "cfg.yaml"))
+    with pytest.raises(Exception):
+        fast_amd.conf.ConfigParser(3)
+    base = dict(fast_amd.conf.DEFAULTS)
+    with pytest.raises(Exception, match="NCHUNKS must divide"):
+        host.build_problem({**base, "NITER": 10, "NCHUNKS": 3})
+    with pytest.raises(Exception, match="even"):
+        host.build_problem({**base, "NITER": 10, "NCHUNKS": 2})
+
+
+def test_fast_result_properties():
+    r = np.array([0.5, 0.25, 1.0, 0.125])
+    res = fast_amd.FastResult(r, 2e-6)
+    np.testing.assert_allclose(res.dB_rel, 10 * np.log10(r))
+    np.testing.assert_allclose(res.power, 2e-6 * r)
+    np.testing.assert_allclose(res.dBm, 10 * np.log10(r * 2e-6 / 1e-3))
+    np.testing.assert_allclose(res.scintillation_index, (r / r.mean()).var())
+    np.testing.assert_allclose(res.avg_power_dB_rel, 10 * np.log10(r.mean()))
+    assert "Scintillation index" in str(res)

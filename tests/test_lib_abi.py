@@ -1,0 +1,46 @@
+"""CPU: libfastmc.so loads, exports every symbol include/fastmc.h declares, and refuses to
+compute without a GPU (no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+import fast_amd
+from fast_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "fast_amd", "csrc"), "all"], check=True)
+    return _lib.lib()
+
+
+def test_header_symbols_are_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "fastmc.h")).read()
+    declared = set(re.findall(r"\b(fastmc_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"fastmc_ctx", "fastmc_t"}
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(built, name), name
+    assert built.fastmc_version() == 100
+
+
+def test_no_cpu_fallback_without_gpu(built):
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(fast_amd.FastMCError, match="no HIP device|no CPU fallback"):
+        _lib.Handle(64, 22)
+    with pytest.raises(fast_amd.FastMCError):
+        fast_amd.Fast({"NPXLS": 64, "DX": 0.01, "NITER": 4, "NCHUNKS": 1, "D_GROUND": 0.2, "LOGLEVEL": "ERROR"})
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fast_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

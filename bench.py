@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- Monte-Carlo iterations/s of the FAST hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 1024 x 1024 grid, Np = 82 pupil window (D = 0.8 m,
+DX = 0.01 m), pure von Karman spectrum (AO_MODE 'NOAO', HV5/7 + Bufton 4-layer profile at
+55 deg zenith), 10 000 Monte-Carlo iterations, on-device generator, float64 pipeline.
+One "step" = that whole 10 000-iteration job on each GPU (weak scaling: each rank owns a
+disjoint range of realisations); with N > 1 every step ends with the RCCL all-gather of the
+per-iteration powers and all-reduce of the dB histogram over xGMI.  Inputs (spectrum, pupil
+weights) are resident in HBM before the timed region; only the 80 kB of results per step
+crosses PCIe.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ITERS_PER_STEP = 10000
+HIST = (-60.0, 10.0, 4096)
+
+
+def workload_params(args):
+    import fast_amd
+    h, cn2, w = fast_amd.turbulence_models.HV57_Bufton_profile(4)
+    return {
+        "NPXLS": args.npxls, "DX": 0.01, "NITER": ITERS_PER_STEP, "NCHUNKS": 100, "TEMPORAL": False,
+        "SUBHARM": False, "SEED": 1, "LOGLEVEL": "ERROR", "W0": "opt", "D_GROUND": 0.8, "OBSC_GROUND": 0,
+        "D_SAT": 0.1, "H_SAT": 36e6, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w,
+        "WIND_DIR": np.array([0., 90., 180., 270.]), "L0": np.inf, "l0": 1e-6, "ZENITH_ANGLE": 55,
+        "DTHETA": [4, 0], "AO_MODE": args.ao_mode, "DSUBAP": 0.1, "TLOOP": 1e-3, "TEXP": 1e-3, "ALIAS": True,
+        "NOISE": 0, "GPU_PRECISION": args.precision, "GPU_RNG": "device",
+    }
+
+
+def cpu_baseline(sim, seconds_target=15.0):
+    """The oracle (numpy restatement of the reference's CPU path, FFTW-branch semantics) timed on
+    this host, one core, on a bounded sample of the same workload."""
+    from oracle import fastref as R
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    ps, df, W, dx, lv = sim.powerspec, sim._prob.df, sim._prob.W, sim.dx, float(sim.logamp_var)
+    t0 = time.perf_counter()
+    R.monte_carlo(123, 20, 1, ps, df, W, dx, lv)          # warm-up chunk: 20 iterations
+    t_probe = time.perf_counter() - t0
+    chunks = int(max(2, min(20, seconds_target / max(t_probe, 1e-3))))
+    n_it = 20 * chunks
+    t0 = time.perf_counter()
+    r = R.monte_carlo(124, n_it, chunks, ps, df, W, dx, lv)
+    dt = time.perf_counter() - t0
+    assert np.isfinite(r).all()
+    return {"value": n_it / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{n_it} iterations ({chunks} chunks of 20) of the same {ps.shape[0]}^2 workload, "
+                      f"oracle/fastref.py (numpy {np.__version__} pocketfft, float64, 1 thread), {dt:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--npxls", type=int, default=1024)
+    ap.add_argument("--ao-mode", default="NOAO")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import fast_amd
+    p = workload_params(args)
+    p["GPU_DEVICE"] = local_rank
+    t0 = time.perf_counter()
+    sim = fast_amd.Fast(p)
+    init_s = time.perf_counter() - t0
+    h = sim._handle
+    N, Np = sim.Npxls, sim.Npxls_pup
+    n_real = ITERS_PER_STEP // 2
+    lvar = float(sim.logamp_var)
+
+    gather = "none"
+    if world > 1:
+        # RCCL inside the library, on its own stream: unique id from rank 0 via the launcher's store
+        ids = [fast_amd._lib.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        try:
+            h.comm_init(ids[0], world, rank)
+            gather = "rccl(in-library)"
+        except fast_amd.FastMCError as e:      # keep the scaling run alive; say so in the JSON
+            gather = f"torch.distributed ({e})"
+
+    def sync_all():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    hist_total = None
+
+    def step(i):
+        nonlocal hist_total, gather
+        # disjoint realisation ranges: step i, rank r
+        real0 = (i * world + rank) * n_real
+        out = h.run(p["SEED"], real0, n_real, None, lvar, False)
+        if world > 1:
+            hist = None
+            if gather.startswith("rccl"):
+                try:
+                    allp, hist = h.comm_gather(2 * n_real, world, HIST)
+                except fast_amd.FastMCError as e:
+                    gather = f"torch.distributed ({e})"
+            if hist is None:
+                hist_l = torch.from_numpy(h.histogram(*HIST)).cuda()
+                dist.all_reduce(hist_l)
+                allp_t = [torch.empty(2 * n_real, dtype=torch.float64, device="cuda") for _ in range(world)]
+                dist.all_gather(allp_t, torch.from_numpy(out).cuda())
+                hist = hist_l.cpu().numpy()
+            hist_total = hist
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    tim = {"rows_ms": 0.0, "cols_ms": 0.0, "finalize_ms": 0.0, "rows_launches": 0, "cols_launches": 0}
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+        t = h.last_timing()
+        for k in tim:
+            tim[k] += t[k]
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert np.isfinite(out).all() and (out > 0).all()
+
+    if rank == 0:
+        bytes_per_iter = (20 if args.precision == "f64" else 10) * N * N
+        total_iters = ITERS_PER_STEP * args.steps * world
+        value = total_iters / dt
+        iters_per_launch = ITERS_PER_STEP * args.steps / max(tim["rows_launches"], 1)
+        avg_rows_ms = tim["rows_ms"] / max(tim["rows_launches"], 1)
+        achieved = bytes_per_iter * iters_per_launch / (avg_rows_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_rows_kernel.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("precision") == args.precision and tj.get("npxls") == N:
+                    traffic = tj["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        gpu_ms = tim["rows_ms"] + tim["cols_ms"] + tim["finalize_ms"]
+        line = {
+            "metric": "Monte-Carlo iterations/sec (1024^2 grid)", "value": value, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if args.precision == "f64" else "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {N}^2 grid, Np={Np}, {ITERS_PER_STEP} iters/step/GPU, "
+                                   f"{args.ao_mode} von Karman spectrum, device Philox4x32-10 generator",
+                       "iters_per_step_per_gpu": ITERS_PER_STEP, "kernel_path": "wave-fft" if h.kernel_path() == 1 else "direct",
+                       "parallelism": f"realisations sharded over {world} GPU(s)", "result_exchange": gather},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_rows_wave", "avg_launch_ms": avg_rows_ms,
+                         "iterations_per_launch": iters_per_launch, "algorithmic_bytes_per_iteration": bytes_per_iter},
+            "pipeline": {"gpu_busy_ms_per_step": gpu_ms / args.steps, "rows_ms": tim["rows_ms"] / args.steps,
+                         "cols_ms": tim["cols_ms"] / args.steps, "finalize_ms": tim["finalize_ms"] / args.steps,
+                         "algorithmic_GBps_whole_job": value / world * bytes_per_iter / 1e9,
+                         "frac_whole_job": value / world * bytes_per_iter / 1e9 / HBM_PEAK_GBS,
+                         "init_s": init_s, "powerspec_kernel_ms": sim.powerspec_kernel_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sim)
+            line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
+        if hist_total is not None:
+            line["config"]["histogram_total"] = int(np.sum(hist_total))
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,341 @@
+"""GPU parity: the HIP path (through the C-ABI) against the oracle and the golden fixtures.
+
+Tolerances (identical coefficients): f64 pipeline rtol 1e-9 on per-iteration power and 1e-11 of
+the screen's peak on phase; f32 pipeline rtol 1e-4 (atol 1e-9) on power; device generator vs the
+oracle's float64 restatement of it: 2e-3 on power (float32 hardware log2/sin/cos in Box-Muller).
+"""
+import numpy as np
+import pytest
+
+from conftest import E2E_CASES, load_golden, params_from_json
+import fast_amd
+from fast_amd import _lib
+from oracle import fastref as R
+from oracle import devrng
+
+pytestmark = pytest.mark.gpu
+
+
+def _vk_spectrum(N, dx, L0=np.inf):
+    g = R.main_grid(N, dx)
+    ps = R.von_karman(g.fabs, np.array([3e-13, 1e-13]), L0, 1e-3).sum(0) * 2 * np.pi * (2 * np.pi / 1550e-9) ** 2
+    return ps, g.df
+
+
+def _window_W(Np, seed=0):
+    y, x = np.mgrid[0:Np, 0:Np]
+    c = (Np - 1) / 2
+    rr = np.hypot(x - c, y - c)
+    return np.where(rr <= Np / 2 - 1, np.exp(-(rr / (0.45 * Np)) ** 2), 0.0)
+
+
+# ------------------------------------------------------------------ generator
+@pytest.mark.parametrize("N", [16, 33, 512])
+def test_device_generator_matches_oracle_restatement(N):
+    h = _lib.Handle(N, max(1, N // 4), "f64", 0)
+    for seed, g in ((1, 0), (0xDEADBEEFCAFE, 5), (7, 2 ** 33 + 3)):
+        got = h.rng_coeffs(seed, g)
+        want = devrng.device_coefficients(seed, g, N)
+        assert np.abs(got - want).max() < 1e-4
+    la = h.rng_logamp(9, 2 ** 32 - 4, 16)
+    assert np.abs(la - devrng.device_logamp_normals(9, 2 ** 32 - 4, 16)).max() < 1e-4
+    big = h.rng_coeffs(3, 1)
+    if N >= 512:
+        assert abs(big.real.mean()) < 0.01 and abs(big.real.std() - 1) < 0.01 and abs(big.imag.std() - 1) < 0.01
+        assert abs(np.mean(big.real * big.imag)) < 0.01
+
+
+# ------------------------------------------------------------------ screens: golden FFT KATs (direct family)
+@pytest.mark.parametrize("N", [16, 30, 33, 64, 128])
+@pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 3e-5)])
+def test_screens_match_reference_fft_kat(N, prec, tol):
+    g = load_golden(f"kat_fft_N{N}")
+    for Np in (N, max(1, N // 3), 5):
+        lo = (N - Np) // 2
+        h = _lib.Handle(N, Np, prec, 0)
+        h.set_spectrum(g["powerspec"], float(g["df"]))
+        h.set_pupil(np.ones((Np, Np)), lo, float(g["dx"]))
+        phs = h.screens_coeffs(g["coeffs"].real, g["coeffs"].imag)
+        want = g["screens"][:, lo:lo + Np, lo:lo + Np]
+        assert np.abs(phs - want).max() <= tol * np.abs(g["screens"]).max()
+
+
+# ------------------------------------------------------------------ screens: wave family vs numpy FFT
+@pytest.mark.parametrize("N,Np", [(512, 82), (1024, 82), (2048, 82), (512, 23), (1024, 200), (512, 512), (1024, 1), (2048, 129)])
+@pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 5e-5)])
+def test_wave_kernels_match_oracle_fft(N, Np, prec, tol):
+    ps, df = _vk_spectrum(N, 0.01, 25.0)
+    rng = np.random.default_rng(N + Np)
+    B = 2 if N < 2048 else 1
+    cr, ci = rng.normal(size=(B, N, N)), rng.normal(size=(B, N, N))
+    lo = (N - Np) // 2
+    want = R.crop(R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df)), N, Np)
+    h = _lib.Handle(N, Np, prec, 0)
+    assert h.kernel_path() == 1
+    h.set_spectrum(ps, df)
+    h.set_pupil(np.ones((Np, Np)), lo, 0.01)
+    got = h.screens_coeffs(cr, ci)
+    assert np.abs(got - want).max() <= tol * np.abs(want).max()
+    # the direct family on the same problem
+    h.kernel_path(0)
+    got_d = h.screens_coeffs(cr[:1], ci[:1])
+    assert np.abs(got_d[0] - want[0]).max() <= tol * np.abs(want).max()
+    assert np.abs(got_d[1] - want[B]).max() <= tol * np.abs(want).max()
+
+
+def test_wave_window_not_centred():
+    N, Np = 512, 70
+    ps, df = _vk_spectrum(N, 0.01, 25.0)
+    rng = np.random.default_rng(5)
+    cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
+    full = R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df))
+    for lo in (0, 3, N - Np):
+        h = _lib.Handle(N, Np, "f64", 0)
+        h.set_spectrum(ps, df)
+        h.set_pupil(np.ones((Np, Np)), lo, 0.01)
+        got = h.screens_coeffs(cr, ci)
+        assert np.abs(got - full[:, lo:lo + Np, lo:lo + Np]).max() <= 1e-11 * np.abs(full).max()
+
+
+# ------------------------------------------------------------------ detector + log-amplitude
+@pytest.mark.parametrize("N,Np", [(64, 22), (512, 82)])
+@pytest.mark.parametrize("prec,rtol", [("f64", 1e-9), ("f32", 1e-4)])
+@pytest.mark.parametrize("coherent", [False, True])
+def test_powers_match_oracle(N, Np, prec, rtol, coherent):
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    ps = ps * 0.02   # ~ few rad rms so that powers are not all tiny
+    rng = np.random.default_rng(3)
+    B = 3
+    cr, ci = rng.normal(size=(B, N, N)), rng.normal(size=(B, N, N))
+    la = rng.normal(scale=0.1, size=2 * B)
+    W = _window_W(Np)
+    want = R.powers_from_coefficients(cr + 1j * ci, ps, df, W, 0.01, la, coherent)
+    h = _lib.Handle(N, Np, prec, 0)
+    h.set_spectrum(ps, df)
+    h.set_pupil(W, (N - Np) // 2, 0.01)
+    got = h.run_coeffs(cr, ci, la, coherent)
+    if coherent:
+        assert got.dtype == complex
+        assert np.abs(got - want).max() <= rtol * np.abs(want).max() * 10
+    else:
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-9)
+
+
+def test_detector_kat_from_reference():
+    """kat_detector holds phases, not coefficients: check the oracle formula on the device by
+    feeding the equivalent problem (identity check of normalisation and exp(chi))."""
+    g = load_golden("kat_detector")
+    # zero spectrum -> phi = 0 -> power = exp(2 chi)
+    Np = g["W"].shape[0]
+    h = _lib.Handle(64, Np, "f64", 0)
+    h.set_spectrum(np.zeros((64, 64)), 1.0)
+    h.set_pupil(g["W"], (64 - Np) // 2, float(g["dx"]))
+    la = g["logamp"][:4]
+    got = h.run_coeffs(np.ones((2, 64, 64)), np.ones((2, 64, 64)), la)
+    np.testing.assert_allclose(got, np.exp(2 * la), rtol=1e-12)
+
+
+# ------------------------------------------------------------------ power spectrum kernel
+def _ps_call(g, p):
+    prob = fast_amd.host.build_problem(fast_amd.conf.ConfigParser(dict(p)).config)
+    atm = prob.atm
+    return prob, _lib.powerspec(prob.N, prob.dx, prob.wvl, p["L0"], p["l0"], prob.ao_mode, p["ALIAS"], p["NOISE"],
+                                prob.d_wfs, p["TLOOP"], p["TEXP"], atm.dtheta, atm.cn2, atm.h, atm.wind_vector,
+                                np.asarray(prob.lf_mask, dtype=float), prob.pup.pupil_filter, prob.simpson_w,
+                                lgs_z=prob.lgs_z, per_layer=True, device=0)
+
+
+@pytest.mark.parametrize("case", E2E_CASES + ["default164"])
+def test_powerspec_kernel_matches_reference(case):
+    g = load_golden("e2e_" + case)
+    p = params_from_json(g["params_json"])
+    prob, out = _ps_call(g, p)
+    peak = np.abs(g["powerspec"]).max()
+    np.testing.assert_allclose(out["powerspec"], g["powerspec"], rtol=1e-10, atol=1e-13 * peak)
+    np.testing.assert_allclose(out["powerspec_per_layer"], g["powerspec_per_layer"], rtol=1e-10, atol=1e-13 * peak)
+    np.testing.assert_allclose(out["logamp_powerspec"], g["logamp_powerspec"], rtol=1e-10,
+                               atol=1e-13 * np.abs(g["logamp_powerspec"]).max())
+    for k in ("logamp_var", "phs_var", "fitting_error", "aniso_servo_error", "alias_error", "noise_error"):
+        np.testing.assert_allclose(out[k], g[k], rtol=1e-9, atol=1e-300, err_msg=k)
+    np.testing.assert_allclose(out["phs_var_weights"], g["phs_var_weights"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["big_noao_1024", "big_noao_L0_1024", "big_ao_1024", "cfg1_256"])
+def test_powerspec_kernel_full_size(name):
+    g = load_golden(name)
+    p = params_from_json(g["params_json"])
+    prob, out = _ps_call(g, p)
+    s = int(g["stride"])
+    N = prob.N
+    peak = np.abs(g["powerspec_centre"]).max()
+    np.testing.assert_allclose(out["powerspec"][::s, ::s], g["powerspec_strided"], rtol=1e-10, atol=1e-13 * peak)
+    np.testing.assert_allclose(out["powerspec"][N // 2 - 16:N // 2 + 16, N // 2 - 16:N // 2 + 16], g["powerspec_centre"],
+                               rtol=1e-10, atol=1e-13 * peak)
+    np.testing.assert_allclose(out["powerspec"].sum(), g["powerspec_sum"], rtol=1e-10)
+    for k in ("logamp_var", "phs_var", "fitting_error", "aniso_servo_error", "alias_error"):
+        np.testing.assert_allclose(out[k], g[k], rtol=1e-9, atol=1e-300, err_msg=k)
+
+
+# ------------------------------------------------------------------ end to end: Fast(config).run()
+@pytest.mark.parametrize("case", E2E_CASES + ["default164"])
+def test_fast_run_reproduces_reference_same_seed(case):
+    """GPU_RNG='host': numpy draws in the reference's order -> the reference's result._r."""
+    g = load_golden("e2e_" + case)
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_RNG": "host", "GPU_DEVICE": 0})
+    sim = fast_amd.Fast(p)
+    res = sim.run()
+    assert res._r.dtype == g["r"].dtype
+    np.testing.assert_allclose(res._r, g["r"], rtol=1e-9)
+    np.testing.assert_allclose(sim.logamp, g["logamp"], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(sim.diffraction_limit, g["diffraction_limit"], rtol=1e-12)
+    assert np.isfinite(res.power).all() and np.isfinite(res.dB_rel).all() and np.isfinite(res.dB_abs).all()
+
+
+@pytest.mark.parametrize("case", ["ao_alias", "noao_L0", "subharm"])
+def test_fast_run_f32_close_to_reference(case):
+    g = load_golden("e2e_" + case)
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_RNG": "host", "GPU_DEVICE": 0, "GPU_PRECISION": "f32"})
+    np.testing.assert_allclose(fast_amd.Fast(p).run()._r, g["r"], rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["cfg1_256", "big_noao_1024", "big_noao_L0_1024", "big_ao_1024"])
+def test_fast_run_full_size_same_seed(name):
+    g = load_golden(name)
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_RNG": "host", "GPU_DEVICE": 0})
+    sim = fast_amd.Fast(p)
+    np.testing.assert_allclose(sim._prob.W, g["W"], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(sim.run()._r, g["r"], rtol=1e-8)
+
+
+# ------------------------------------------------------------------ device-RNG mode
+def _small_problem(N=512, Np=82, prec="f64", scale=0.02):
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    h = _lib.Handle(N, Np, prec, 0)
+    h.set_spectrum(ps * scale, df)
+    W = _window_W(Np)
+    h.set_pupil(W, (N - Np) // 2, 0.01)
+    return h, ps * scale, df, W
+
+
+@pytest.mark.parametrize("N", [64, 512])
+def test_device_rng_run_matches_oracle_with_restated_generator(N):
+    Np = 22 if N == 64 else 82
+    h, ps, df, W = _small_problem(N, Np)
+    seed, real0, n = 42, 5, 4
+    got = h.run(seed, real0, n, None, 0.01)
+    coeffs = np.stack([devrng.device_coefficients(seed, real0 + j, N) for j in range(n)])
+    it = 2 * real0
+    chi = devrng.device_logamp_normals(seed, it, 2 * n) * 0.1
+    la = np.concatenate([chi[0::2], chi[1::2]])
+    want = R.powers_from_coefficients(coeffs, ps, df, W, 0.01, la)
+    np.testing.assert_allclose(got, want, rtol=2e-3)
+
+
+def test_device_rng_invariant_to_batch_and_split():
+    h, ps, df, W = _small_problem()
+    ref = h.run(7, 0, 24, None, 0.02)
+    h.set_batch(5)
+    np.testing.assert_array_equal(h.run(7, 0, 24, None, 0.02), ref)
+    h.set_batch(0)
+    a = h.run(7, 0, 10, None, 0.02)
+    b = h.run(7, 10, 14, None, 0.02)
+    np.testing.assert_array_equal(np.r_[a[:10], b[:14], a[10:], b[14:]], ref)
+    h.kernel_path(0)   # direct family: same generator, same answers to rounding
+    np.testing.assert_allclose(h.run(7, 0, 4, None, 0.02), np.r_[ref[:4], ref[24:28]], rtol=1e-9)
+
+
+def test_device_rng_statistics_match_host_mode():
+    """Same distribution as numpy-drawn coefficients: mean dB within 3 sigma, KS p > 0.01."""
+    from scipy import stats
+    N, Np, n = 512, 82, 600
+    h, ps, df, W = _small_problem(N, Np, "f32")
+    dev = h.run(123, 0, n, None, 0.01)
+    rng = np.random.default_rng(0)
+    host = []
+    for _ in range(n // 50):
+        cr, ci = rng.normal(size=(50, N, N)), rng.normal(size=(50, N, N))
+        host.append(h.run_coeffs(cr, ci, rng.normal(scale=0.1, size=100)))
+    host = np.concatenate(host)
+    d1, d2 = 10 * np.log10(dev), 10 * np.log10(host)
+    se = np.sqrt(d1.var() / len(d1) + d2.var() / len(d2))
+    assert abs(d1.mean() - d2.mean()) < 4 * se
+    assert stats.ks_2samp(d1, d2).pvalue > 0.01
+    si1, si2 = (dev / dev.mean()).var(), (host / host.mean()).var()
+    assert abs(si1 / si2 - 1) < 0.25
+
+
+def test_fast_device_mode_end_to_end():
+    g = load_golden("e2e_ao_alias")
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_DEVICE": 0, "NITER": 400, "NCHUNKS": 4, "SEED": 5})
+    sim = fast_amd.Fast(dict(p))
+    r1 = sim.run()._r
+    assert r1.shape == (400,) and np.isfinite(r1).all() and (r1 > 0).all()
+    p2 = dict(p)
+    p2["NCHUNKS"] = 2
+    r2 = fast_amd.Fast(p2).run()._r   # chunking only reorders [Re block | Im block] per chunk
+    np.testing.assert_allclose(np.sort(r1), np.sort(r2), rtol=0, atol=0)
+    ref = g["r"]
+    assert abs(10 * np.log10(r1.mean()) - 10 * np.log10(ref.mean())) < 1.0
+
+
+# ------------------------------------------------------------------ properties at BASELINE size
+def test_full_size_properties_1024():
+    N, Np = 1024, 82
+    ps, df = _vk_spectrum(N, 0.01, 25.0)
+    W = _window_W(Np)
+    h = _lib.Handle(N, Np, "f64", 0)
+    h.set_pupil(W, (N - Np) // 2, 0.01)
+    # zero spectrum: every power is exactly exp(2 chi)
+    h.set_spectrum(np.zeros((N, N)), df)
+    la = np.linspace(-0.3, 0.3, 8)
+    out = h.run(1, 0, 4, la, 0.0)
+    np.testing.assert_allclose(out, np.exp(2 * la), rtol=1e-12)
+    # linearity of the screens in the coefficients and in sqrt(powerspec)
+    h.set_spectrum(ps, df)
+    a = h.screens(9, 0, 1)
+    h.set_spectrum(4 * ps, df)
+    b = h.screens(9, 0, 1)
+    np.testing.assert_allclose(b, 2 * a, rtol=1e-12, atol=1e-12 * np.abs(a).max())
+    # Parseval-type check: in-window variance over many screens ~ integral of the PSD over the grid
+    h.set_spectrum(ps, df)
+    scr = h.screens(3, 0, 64)
+    expect = (ps * df ** 2).sum()
+    assert abs(scr.var() / expect - 1) < 0.5   # piston-dominated, large sample variance
+    # coherent vs incoherent consistency
+    inc = h.run(11, 0, 6, None, 0.01)
+    coh = h.run(11, 0, 6, None, 0.01, coherent=True)
+    np.testing.assert_allclose(np.abs(coh) ** 2, inc, rtol=1e-12)
+
+
+def test_histogram_matches_numpy():
+    h, ps, df, W = _small_problem()
+    out = h.run(5, 0, 500, None, 0.01)
+    bins = h.histogram(-30.0, 5.0, 70)
+    db = 10 * np.log10(out)
+    want, _ = np.histogram(db, bins=70, range=(-30.0, 5.0))
+    inside = (db >= -30) & (db < 5)
+    assert bins[:70].sum() == inside.sum() and bins[70] == (db < -30).sum() and bins[71] == (db >= 5).sum()
+    assert np.abs(bins[:70] - want).sum() <= 2   # numpy's last bin is closed; edges may move one count
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_errors_are_reported_not_fatal():
+    with pytest.raises(fast_amd.FastMCError):
+        _lib.Handle(8192, 10)
+    with pytest.raises(fast_amd.FastMCError):
+        _lib.Handle(64, 65)
+    h = _lib.Handle(64, 22, "f64", 0)
+    with pytest.raises(fast_amd.FastMCError, match="set_spectrum"):
+        h.run(1, 0, 2)
+    with pytest.raises(fast_amd.FastMCError):
+        h.set_pupil(np.ones((22, 22)), 60, 0.01)
+    with pytest.raises(fast_amd.FastMCError):
+        h.set_spectrum(-np.ones((64, 64)), 1.0)
+    with pytest.raises(Exception, match="NCHUNKS must divide"):
+        fast_amd.Fast({"NITER": 10, "NCHUNKS": 3, "LOGLEVEL": "ERROR"})
+    with pytest.raises(NotImplementedError):
+        fast_amd.Fast({"NITER": 4, "NCHUNKS": 1, "TEMPORAL": True, "NPXLS": 64, "DX": 0.01, "D_GROUND": 0.2, "LOGLEVEL": "ERROR"})

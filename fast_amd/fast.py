@@ -128,7 +128,21 @@ class Fast():
             seed = self.seed if self.seed is not None else int(numpy.random.SeedSequence().generate_state(2, numpy.uint32).view(numpy.uint64)[0])
             self._device_seed = seed
             n_real = self.Niter // 2
-            out = self._handle.run(seed, 0, n_real, None, float(self.logamp_var), coherent)
+            tr = self._transport()
+            if tr is None:
+                out = self._handle.run(seed, 0, n_real, None, float(self.logamp_var), coherent)
+            else:
+                # one process per GPU: this rank's contiguous realisation range, then one exchange
+                from . import dist as fdist
+                if coherent:
+                    raise NotImplementedError("COHERENT results are not exchanged across GPUs yet")
+                real0, n_loc = fdist.shard_range(n_real, tr.world, tr.rank)
+                loc = self._handle.run(seed, real0, n_loc, None, float(self.logamp_var), False)
+                if isinstance(tr, fdist.RcclTransport):
+                    gathered, _ = tr.gather(2 * n_loc)
+                else:
+                    gathered = tr.all_gather(loc)
+                out = fdist.assemble(gathered, tr.world, n_loc)
             re, im = out[:n_real].reshape(self.Nchunks, half), out[n_real:].reshape(self.Nchunks, half)
             I[:, :half], I[:, half:] = re, im
             # the log-amplitudes the device drew, in iteration order (global iteration 2g+s)
@@ -158,6 +172,27 @@ class Fast():
                 sr = _R.normal(0, 1, size=(half, 3, 3, 3))
                 si = _R.normal(0, 1, size=(half, 3, 3, 3))
             I[i] = self._handle.run_coeffs(cr, ci, self.logamp[i * M:(i + 1) * M], coherent, sr, si)
+
+    def _transport(self):
+        """The result exchange of a multi-process run, or None.  GPU_SHARD: 'auto' (default) shards
+        when a torch.distributed process group with more than one rank exists."""
+        import sys
+        mode = self.params.get('GPU_SHARD', 'auto')
+        if mode is False:
+            return None
+        tdist = getattr(sys.modules.get('torch'), 'distributed', None) if 'torch' in sys.modules else None
+        if tdist is None or not tdist.is_available() or not tdist.is_initialized() or tdist.get_world_size() < 2:
+            if mode is True:
+                raise Exception("GPU_SHARD=True needs an initialised torch.distributed process group")
+            return None
+        if getattr(self, '_tr', None) is None:
+            from . import dist as fdist
+            try:
+                self._tr = fdist.RcclTransport(self._handle)
+            except _lib.FastMCError as e:
+                logger.warning(f"RCCL exchange unavailable ({e}); using torch.distributed collectives")
+                self._tr = fdist.TorchTransport()
+        return self._tr
 
     def histogram(self, lo_db=-60.0, hi_db=10.0, nbins=4096):
         """Histogram of dB_rel of the last run, computed on the device."""

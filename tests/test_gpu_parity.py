@@ -339,3 +339,14 @@ def test_errors_are_reported_not_fatal():
         fast_amd.Fast({"NITER": 10, "NCHUNKS": 3, "LOGLEVEL": "ERROR"})
     with pytest.raises(NotImplementedError):
         fast_amd.Fast({"NITER": 4, "NCHUNKS": 1, "TEMPORAL": True, "NPXLS": 64, "DX": 0.01, "D_GROUND": 0.2, "LOGLEVEL": "ERROR"})
+
+
+def test_rccl_exchange_world_of_one():
+    """The in-library RCCL path (dlopen, communicator, all-gather, all-reduce) with one rank."""
+    h, ps, df, W = _small_problem()
+    out = h.run(5, 0, 100, None, 0.01)
+    h.comm_init(_lib.comm_unique_id(), 1, 0)
+    allp, hist = h.comm_gather(200, 1, (-30.0, 5.0, 70))
+    np.testing.assert_array_equal(allp, out)
+    np.testing.assert_array_equal(hist, h.histogram(-30.0, 5.0, 70))
+    assert hist.sum() == 200

@@ -31,6 +31,7 @@ class PsParams(C.Structure):
         ("L0", C.c_double), ("l0", C.c_double), ("ao_mode", C.c_int32), ("alias", C.c_int32),
         ("noise", C.c_double), ("d_wfs", C.c_double), ("t_loop", C.c_double), ("t_exp", C.c_double),
         ("dtheta", C.c_double * 2), ("cn2", C.c_void_p), ("h", C.c_void_p), ("wind", C.c_void_p),
+        ("mask_mode", C.c_int32), ("zmax", C.c_int32), ("modal_mult", C.c_double), ("D_ground", C.c_double),
         ("lf_mask", C.c_void_p), ("pupil_filter", C.c_void_p), ("lgs_z", C.c_void_p), ("simpson_w", C.c_void_p),
     ]
 
@@ -67,7 +68,7 @@ def lib():
     L.fastmc_last_timing.argtypes = [vp, dp, C.POINTER(i64)]
     L.fastmc_kernel_path.argtypes = [vp, C.c_int]
     L.fastmc_set_batch.argtypes = [vp, C.c_int]
-    L.fastmc_powerspec.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp, dp]
+    L.fastmc_powerspec.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp, dp, dp]
     L.fastmc_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     L.fastmc_comm_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
     L.fastmc_comm_gather.argtypes = [vp, i64, dp, C.POINTER(i64), C.c_double, C.c_double, C.c_int]
@@ -229,30 +230,51 @@ def comm_unique_id():
     return bytes(buf)
 
 
-def powerspec(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, dtheta, cn2, h, wind, lf_mask,
-              pupil_filter, simpson_w, lgs_z=None, per_layer=False, device=None):
-    """fastmc_powerspec: AO-residual PSD grid + Simpson scalars on the GPU.
-    Returns dict(powerspec, powerspec_per_layer|None, logamp_powerspec, scalars..., kernel_ms)."""
+def mask_spec(modal, modal_mult, zmax):
+    """(mask_mode, zmax, modal_mult) of fastmc_ps_params for the reference's mask_lf arguments."""
+    if not modal:
+        return 1, 0, 1.0
+    if zmax is None:
+        return 2, 0, float(modal_mult)
+    return 3, int(zmax), float(modal_mult)
+
+
+def powerspec(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, dtheta, cn2, h, wind, pupil_filter,
+              simpson_w, lf_mask=None, modal=False, modal_mult=1, zmax=None, D_ground=0.0, lgs_z=None,
+              per_layer=False, device=None):
+    """fastmc_powerspec: mask_lf, AO-residual PSD grid and Simpson scalars on the GPU.
+    `lf_mask=None`: the mask is evaluated on the device from (modal, modal_mult, zmax, D_ground);
+    otherwise the given (N, N) grid is used.  Returns dict(powerspec, powerspec_per_layer|None,
+    logamp_powerspec, lf_mask, scalars..., kernel_ms)."""
     cn2, h, wind = _f64(cn2), _f64(h), _f64(wind)
     Lr = len(cn2)
     mask, pf, z, w = _f64(lf_mask), _f64(pupil_filter), _f64(lgs_z), _f64(simpson_w)
-    assert mask.shape == (N, N) and w.shape == (N,) and wind.shape == (Lr, 2)
+    assert w.shape == (N,) and wind.shape == (Lr, 2)
     p = PsParams()
     p.N, p.n_layers, p.dx, p.wvl, p.L0, p.l0 = int(N), Lr, float(dx), float(wvl), float(L0), float(l0)
     p.ao_mode, p.alias, p.noise, p.d_wfs = AO_MODES[ao_mode], int(bool(alias)), float(noise), float(d_wfs)
     p.t_loop, p.t_exp = float(t_loop), float(t_exp)
     p.dtheta[0], p.dtheta[1] = float(dtheta[0]), float(dtheta[1])
     p.cn2, p.h, p.wind = cn2.ctypes.data, h.ctypes.data, wind.ctypes.data
-    p.lf_mask, p.simpson_w = mask.ctypes.data, w.ctypes.data
+    p.simpson_w = w.ctypes.data
+    if mask is None:
+        p.mask_mode, p.zmax, p.modal_mult = mask_spec(modal, modal_mult, zmax)
+        p.lf_mask = None
+    else:
+        assert mask.shape == (N, N)
+        p.mask_mode, p.zmax, p.modal_mult = 0, 0, 1.0
+        p.lf_mask = mask.ctypes.data
+    p.D_ground = float(D_ground)
     p.pupil_filter = None if pf is None else pf.ctypes.data
     p.lgs_z = None if z is None else z.ctypes.data
     ps = np.empty((N, N))
     la = np.empty((N, N))
+    mo = np.empty((N, N))
     pl = np.empty((Lr, N, N)) if per_layer else None
     sc = np.empty(PS_NSCALARS + Lr)
     ms = C.c_double(0.0)
     dev = default_device() if device is None else int(device)
-    _chk(lib().fastmc_powerspec(dev, C.byref(p), _dptr(ps), _dptr(pl), _dptr(la), _dptr(sc), C.byref(ms)))
-    return {"powerspec": ps, "powerspec_per_layer": pl, "logamp_powerspec": la,
+    _chk(lib().fastmc_powerspec(dev, C.byref(p), _dptr(ps), _dptr(pl), _dptr(la), _dptr(mo), _dptr(sc), C.byref(ms)))
+    return {"powerspec": ps, "powerspec_per_layer": pl, "logamp_powerspec": la, "lf_mask": mo,
             "aniso_servo_error": sc[0], "alias_error": sc[1], "noise_error": sc[2], "fitting_error": sc[3],
             "phs_var": sc[4], "logamp_var": sc[5], "phs_var_weights": sc[6:].copy(), "kernel_ms": ms.value}

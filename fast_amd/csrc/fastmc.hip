@@ -463,7 +463,9 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     HIPCHK(hipMalloc(&h->V, (size_t)B * N * Np * sizeof(cpx<R>)));
     h->V_cap = B;
   }
-  TRY(grow(&h->partial, &h->partial_cap, (size_t)B * Np * 4));
+  // detector partials are kept for FIN_SPAN realisations so that one finalize launch serves many batches
+  const int64_t FIN_SPAN = std::max<int64_t>(B, std::min<int64_t>(S.n_real, 32768));
+  TRY(grow(&h->partial, &h->partial_cap, (size_t)FIN_SPAN * Np * 4));
   const size_t out_need = (size_t)S.n_real * 2 * (S.coherent ? 2 : 1);
   if (S.epi == 0) TRY(grow(&h->out, &h->out_cap, out_need));
   if (S.epi == 0 && S.logamp) {
@@ -493,6 +495,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
 
   RngKey key{(uint32_t)S.seed, (uint32_t)(S.seed >> 32)};
   timing_begin(h);
+  int64_t fin_start = 0;
   for (int64_t bs = 0; bs < S.n_real; bs += B) {
     const int nb = (int)std::min<int64_t>(B, S.n_real - bs);
     if (S.mode == 1) {
@@ -523,7 +526,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     CA.V = (const cpx<R>*)h->V; CA.tw = RA.tw; CA.om = RA.om; CA.omS = h->omS;
     CA.W = h->W;
     CA.sh.enabled = sh ? 1 : 0; CA.sh.coef = h->sh_coef; CA.sh.mean = h->sh_mean; CA.sh.ex = h->sh_ex; CA.sh.ey = h->sh_ey;
-    CA.partial = h->partial; CA.phs = h->phs;
+    CA.partial = h->partial + (size_t)((bs - fin_start)) * Np * 4; CA.phs = h->phs;
     if (h->path == 1) {
       if (h->P == 8) TRY((dispatch_wave_ns<R, 8>(h, RA, CA, S.mode, S.epi)));
       else if (h->P == 16) TRY((dispatch_wave_ns<R, 16>(h, RA, CA, S.mode, S.epi)));
@@ -532,13 +535,17 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       TRY(dispatch_direct<R>(h, RA, CA, S.mode, S.epi));
     }
     if (S.epi == 0) {
-      Span sp(h, 2);
-      FinArgs FA;
-      FA.nb = nb; FA.Np = Np; FA.coherent = S.coherent; FA.n_real = S.n_real; FA.j0 = bs;
-      FA.partial = h->partial; FA.logamp = S.logamp ? h->logamp : nullptr;
-      FA.logamp_sigma = std::sqrt(S.logamp_var); FA.key = key; FA.g0 = (uint64_t)(S.real0 + bs);
-      FA.dx2 = h->dx * h->dx; FA.norm = h->wsum * (h->dx * h->dx); FA.out = h->out;
-      hipLaunchKernelGGL(k_finalize, dim3((nb + 63) / 64), dim3(64), 0, h->stream, FA);
+      const int64_t done = bs + nb;                 // realisations with partials ready: [fin_start, done)
+      if (done == S.n_real || done - fin_start + B > FIN_SPAN) {
+        Span sp(h, 2);
+        FinArgs FA;
+        FA.nb = (int)(done - fin_start); FA.Np = Np; FA.coherent = S.coherent; FA.n_real = S.n_real; FA.j0 = fin_start;
+        FA.partial = h->partial; FA.logamp = S.logamp ? h->logamp : nullptr;
+        FA.logamp_sigma = std::sqrt(S.logamp_var); FA.key = key; FA.g0 = (uint64_t)(S.real0 + fin_start);
+        FA.dx2 = h->dx * h->dx; FA.norm = h->wsum * (h->dx * h->dx); FA.out = h->out;
+        hipLaunchKernelGGL(k_finalize, dim3((FA.nb + 3) / 4), dim3(256), 0, h->stream, FA);
+        fin_start = done;
+      }
     } else {
       // screens of this batch -> host: Re planes of [bs, bs+nb), Im planes offset by n_real
       const size_t plane = (size_t)Np * Np;
@@ -654,15 +661,27 @@ extern "C" int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launch
 }
 
 // ------------------------------------------------------------------ power spectrum
+static void noll_to_nm(int j, int* n_out, int* m_out) {   // aotools zernIndex (third party; see hostmath.noll_to_nm)
+  const int n = (int)((-1.0 + std::sqrt(8.0 * (j - 1) + 1.0)) / 2.0);
+  const double pp = j - (n * (n + 1)) / 2.0;
+  const int k = n % 2;
+  int m = (int)((pp + k) / 2.0) * 2 - k;
+  if (m != 0 && (j % 2) != 0) m = -m;
+  *n_out = n;
+  *m_out = m;
+}
+
 extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double* powerspec, double* per_layer,
-                                double* logamp_ps, double* scalars, double* kernel_ms) {
+                                double* logamp_ps, double* lf_mask_out, double* scalars, double* kernel_ms) {
   if (!p) return fail(FASTMC_EINVAL, "params is NULL");
   const int N = p->N, L = p->n_layers;
   if (N < 2 || N > 16384) return fail(FASTMC_EINVAL, "bad N");
   if (L < 1 || L > PS_MAX_LAYERS) return fail(FASTMC_EINVAL, "n_layers must be in [1, 64]");
-  if (!p->cn2 || !p->h || !p->wind || !p->lf_mask || !p->simpson_w) return fail(FASTMC_EINVAL, "null array in params");
+  if (!p->cn2 || !p->h || !p->wind || !p->simpson_w) return fail(FASTMC_EINVAL, "null array in params");
+  if (p->mask_mode < 0 || p->mask_mode > 3) return fail(FASTMC_EINVAL, "bad mask_mode");
+  if (p->mask_mode == 0 && !p->lf_mask) return fail(FASTMC_EINVAL, "mask_mode 0 needs lf_mask");
+  if (p->mask_mode == 3 && (p->zmax < 1 || p->zmax > 1024)) return fail(FASTMC_EINVAL, "zmax must be in [1, 1024]");
   if (p->ao_mode < 0 || p->ao_mode > 3) return fail(FASTMC_EINVAL, "bad ao_mode");
-  if (p->ao_mode == FASTMC_LGSAO && !p->lgs_z) return fail(FASTMC_EINVAL, "LGSAO needs lgs_z");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     return fail(FASTMC_ENODEV, "no HIP device visible: libfastmc has no CPU fallback");
@@ -671,7 +690,8 @@ extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double
   const size_t N2 = (size_t)N * N;
   const int nq = PS_NQ + L;
   double *d_cn2 = nullptr, *d_h = nullptr, *d_wind = nullptr, *d_mask = nullptr, *d_pf = nullptr, *d_z = nullptr,
-         *d_w = nullptr, *d_ps = nullptr, *d_pl = nullptr, *d_la = nullptr, *d_rows = nullptr, *d_sc = nullptr;
+         *d_w = nullptr, *d_ps = nullptr, *d_pl = nullptr, *d_la = nullptr, *d_rows = nullptr, *d_sc = nullptr,
+         *d_mo = nullptr, *d_noll = nullptr;
   std::vector<double*> owned;
   auto A = [&](double** q, size_t n) -> int {
     hipError_t e = hipMalloc((void**)q, n * 8);
@@ -682,16 +702,24 @@ extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double
   auto cleanup = [&]() { for (double* q : owned) hipFree(q); };
   int rc = 0;
   do {
-    if ((rc = A(&d_cn2, L)) || (rc = A(&d_h, L)) || (rc = A(&d_wind, 2 * L)) || (rc = A(&d_mask, N2)) || (rc = A(&d_w, N)) ||
+    const int nmodes = std::max(p->mask_mode == 3 ? p->zmax : 0, 4);
+    if ((rc = A(&d_cn2, L)) || (rc = A(&d_h, L)) || (rc = A(&d_wind, 2 * L)) || (rc = A(&d_w, N)) || (rc = A(&d_noll, nmodes)) ||
         (rc = A(&d_ps, N2)) || (rc = A(&d_la, N2)) || (rc = A(&d_rows, (size_t)N * nq)) || (rc = A(&d_sc, nq)))
       break;
+    if (p->mask_mode == 0 && (rc = A(&d_mask, N2))) break;
+    if (lf_mask_out && (rc = A(&d_mo, N2))) break;
     if (p->pupil_filter && (rc = A(&d_pf, N2))) break;
     if (p->lgs_z && (rc = A(&d_z, N2))) break;
     if (per_layer && (rc = A(&d_pl, N2 * L))) break;
     hipMemcpy(d_cn2, p->cn2, L * 8, hipMemcpyHostToDevice);
     hipMemcpy(d_h, p->h, L * 8, hipMemcpyHostToDevice);
     hipMemcpy(d_wind, p->wind, 2 * L * 8, hipMemcpyHostToDevice);
-    hipMemcpy(d_mask, p->lf_mask, N2 * 8, hipMemcpyHostToDevice);
+    if (d_mask) hipMemcpy(d_mask, p->lf_mask, N2 * 8, hipMemcpyHostToDevice);
+    {
+      std::vector<int> nm(2 * nmodes);
+      for (int j = 1; j <= nmodes; ++j) noll_to_nm(j, &nm[j - 1], &nm[nmodes + j - 1]);
+      hipMemcpy(d_noll, nm.data(), 2 * nmodes * sizeof(int), hipMemcpyHostToDevice);
+    }
     hipMemcpy(d_w, p->simpson_w, N * 8, hipMemcpyHostToDevice);
     if (d_pf) hipMemcpy(d_pf, p->pupil_filter, N2 * 8, hipMemcpyHostToDevice);
     if (d_z) hipMemcpy(d_z, p->lgs_z, N2 * 8, hipMemcpyHostToDevice);
@@ -700,6 +728,8 @@ extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double
     K.dx = p->dx; K.wvl = p->wvl; K.L0 = p->L0; K.l0 = p->l0; K.noise = p->noise; K.d_wfs = p->d_wfs;
     K.t_loop = p->t_loop; K.t_exp = p->t_exp; K.dth_x = p->dtheta[0]; K.dth_y = p->dtheta[1];
     K.cn2 = d_cn2; K.h = d_h; K.wind = d_wind; K.mask = d_mask; K.pfilter = d_pf; K.lgs_z = d_z; K.w = d_w;
+    K.mask_mode = p->mask_mode; K.zmax = p->zmax; K.modal_mult = p->modal_mult; K.D_zern = p->D_ground;
+    K.noll_n = (const int*)d_noll; K.noll_m = (const int*)d_noll + nmodes; K.mask_out = d_mo;
     K.powerspec = d_ps; K.per_layer = d_pl; K.logamp_ps = d_la; K.rowsums = d_rows;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -719,6 +749,7 @@ extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double
     if (powerspec) hipMemcpy(powerspec, d_ps, N2 * 8, hipMemcpyDeviceToHost);
     if (per_layer) hipMemcpy(per_layer, d_pl, N2 * L * 8, hipMemcpyDeviceToHost);
     if (logamp_ps) hipMemcpy(logamp_ps, d_la, N2 * 8, hipMemcpyDeviceToHost);
+    if (lf_mask_out) hipMemcpy(lf_mask_out, d_mo, N2 * 8, hipMemcpyDeviceToHost);
     if (scalars) {
       std::vector<double> sc(nq);
       hipMemcpy(sc.data(), d_sc, nq * 8, hipMemcpyDeviceToHost);

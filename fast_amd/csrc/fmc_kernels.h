@@ -408,26 +408,31 @@ struct FinArgs {
   double* out;                // [2*n_real] or [2*n_real][2]
 };
 
-__global__ void k_finalize(FinArgs A) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront per realisation: lanes stride over the Np column partials (32 contiguous bytes
+// each), fixed-shape shuffle tree -> deterministic.
+__global__ __launch_bounds__(256) void k_finalize(FinArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= A.nb) return;
   double s[4] = {0.0, 0.0, 0.0, 0.0};
   const double* p = A.partial + (size_t)b * A.Np * 4;
-  for (int xi = 0; xi < A.Np; ++xi)
-    for (int q = 0; q < 4; ++q) s[q] += p[xi * 4 + q];
-  const int64_t j = A.j0 + b;
+  for (int xi = lane; xi < A.Np; xi += 64)
 #pragma unroll
-  for (int part = 0; part < 2; ++part) {
-    const int64_t o = part * A.n_real + j;
-    double chi;
-    if (A.logamp) chi = A.logamp[o];
-    else chi = (double)draw_logamp_normal(A.key, 2 * (A.g0 + (uint64_t)b) + part) * A.logamp_sigma;
-    const double e = exp(chi);
-    const double ar = (e * (s[2 * part] * A.dx2)) / A.norm;
-    const double ai = (e * (s[2 * part + 1] * A.dx2)) / A.norm;
-    if (A.coherent) { A.out[2 * o] = ar; A.out[2 * o + 1] = ai; }
-    else A.out[o] = ar * ar + ai * ai;
-  }
+    for (int q = 0; q < 4; ++q) s[q] += p[xi * 4 + q];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s[q] = wave_sum(s[q]);
+  if (lane >= 2) return;
+  const int part = lane;
+  const int64_t j = A.j0 + b;
+  const int64_t o = part * A.n_real + j;
+  double chi;
+  if (A.logamp) chi = A.logamp[o];
+  else chi = (double)draw_logamp_normal(A.key, 2 * (A.g0 + (uint64_t)b) + part) * A.logamp_sigma;
+  const double e = exp(chi);
+  const double ar = (e * (s[2 * part] * A.dx2)) / A.norm;
+  const double ai = (e * (s[2 * part + 1] * A.dx2)) / A.norm;
+  if (A.coherent) { A.out[2 * o] = ar; A.out[2 * o + 1] = ai; }
+  else A.out[o] = ar * ar + ai * ai;
 }
 
 // ================================================================== histogram of dB_rel

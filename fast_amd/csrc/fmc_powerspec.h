@@ -27,7 +27,13 @@ struct PsArgs {
   const double* cn2;
   const double* h;
   const double* wind;          // [L][2]
-  const double* mask;          // [N][N]
+  const double* mask;          // [N][N] host-supplied mask (mask_mode 0) or null
+  int mask_mode;               // 0 supplied, 1 zonal, 2 modal radial cut, 3 modal Zernike (ao_power_spectra.py:119-141)
+  int zmax;                    // Zernike modes 1..zmax (mask_mode 3)
+  double modal_mult, D_zern;
+  const int* noll_n;           // [max(zmax,4)] radial order of Noll mode j = index + 1
+  const int* noll_m;           // [max(zmax,4)] signed azimuthal order
+  double* mask_out;            // [N][N] or null
   const double* pfilter;       // [N][N] or null
   const double* lgs_z;         // [N][N] or null
   const double* w;             // [N] Simpson weights
@@ -49,6 +55,25 @@ __device__ __forceinline__ double vk_base(double fabs_, double km, double k0) {
 __device__ __forceinline__ double vk_layer(double base, double cn2) {
   const double v = cn2 * base;
   return isinf(v) ? 0.0 : v;
+}
+
+// sum_{j=1..n_noll} |Z~_j(kappa)|^2, centre forced to 1 by the caller
+// (ao_power_spectra.zernike_ft 10-21, zernike_squared_filter 54-76).
+__device__ __forceinline__ double zernike_sq(double fabs_, double fx, double fy, double D, int n_noll,
+                                             const int* nn, const int* mm) {
+  const double phi = atan2(fy, fx);
+  const double x = fabs_ * D / 2;
+  double out = 0.0;
+  for (int j = 1; j <= n_noll; ++j) {
+    const int n = nn[j - 1], m = mm[j - 1];
+    const double rad = 2 * jn(n + 1, x) / x;
+    double z2;
+    if (m == 0) z2 = (n + 1) * (rad * rad);
+    else if ((j & 1) == 0) { const double t = rad * cos(m * phi); z2 = 2 * (n + 1) * (t * t); }
+    else { const double t = rad * sin(m * phi); z2 = 2 * (n + 1) * (t * t); }
+    out = out + z2;
+  }
+  return out;
 }
 
 __global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
@@ -73,8 +98,19 @@ __global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
     const double fx = (ix - N / 2.0) * df;
     const double fabs_ = sqrt(fx * fx + fy * fy);
     const size_t pix = (size_t)iy * N + ix;
-    const double mask = A.mask[pix];
     const bool centre = (iy == mid && ix == mid);
+    double mask;
+    if (A.mask_mode == 0) mask = A.mask[pix];
+    else {
+      const double fmax = M_PI / A.d_wfs;
+      const bool wfs = fabs(fx) <= fmax && fabs(fy) <= fmax;
+      double dm;
+      if (A.mask_mode == 1) dm = wfs ? 1.0 : 0.0;
+      else if (A.mask_mode == 2) dm = (fabs_ <= fmax * A.modal_mult) ? 1.0 : 0.0;
+      else dm = centre ? 1.0 : zernike_sq(fabs_, fx, fy, A.D_zern, A.zmax, A.noll_n, A.noll_m);
+      mask = (wfs ? 1.0 : 0.0) * (dm < 1 ? dm : 1.0);
+    }
+    if (A.mask_out) A.mask_out[pix] = mask;
     const double base = vk_base(fabs_, km, k0);
 
     double noise_ps = 0.0;
@@ -127,7 +163,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
         const double aniso = 1 - 2 * cos(dr_k - A.t_loop * v_k) * s + s * s;
         if (A.ao_mode == 3) {
           const double aniso_lgs = 1 - 2 * cos(-A.t_loop * v_k) * s + s * s;
-          const double Z = A.lgs_z[pix];
+          const double Z = A.lgs_z ? A.lgs_z[pix] : (centre ? 1.0 : zernike_sq(fabs_, fx, fy, A.D_zern, 4, A.noll_n, A.noll_m));
           G = mask * (Z * aniso + (1 - Z) * aniso_lgs) + (1 - mask);
         } else {
           G = aniso * mask + (1 - mask);

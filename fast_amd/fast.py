@@ -60,7 +60,6 @@ class Fast():
         self.subharmonics = prob.subharm
         self.ao_mode, self.Dsubap, self.tloop, self.texp = prob.ao_mode, prob.d_wfs, p['TLOOP'], p['TEXP']
         self.Zmax, self.alias, self.noise, self.modal, self.modal_mult = prob.zmax, p['ALIAS'], p['NOISE'], prob.modal, prob.modal_mult
-        self.lf_mask, self.hf_mask = prob.lf_mask, 1 - prob.lf_mask
         self.dx_sat, self.pupil, self.pupil_sat = pup.dx_sat, pup.pupil, pup.pupil_sat
         self.pupil_mode, self.pupil_mode_sat, self.W0, self.W0_sat = pup.pupil_mode, pup.pupil_mode_sat, pup.W0, pup.W0_sat
         self.pupil_filter, self.pup_coords = pup.pupil_filter, pup.pup_coords
@@ -101,8 +100,13 @@ class Fast():
         prob, p, atm = self._prob, self.params, self._prob.atm
         out = _lib.powerspec(prob.N, prob.dx, prob.wvl, p['L0'], p['l0'], prob.ao_mode, p['ALIAS'], p['NOISE'],
                              prob.d_wfs, p['TLOOP'], p['TEXP'], atm.dtheta, atm.cn2, atm.h, atm.wind_vector,
-                             numpy.asarray(prob.lf_mask, dtype=float), prob.pup.pupil_filter, prob.simpson_w,
-                             lgs_z=prob.lgs_z, per_layer=True, device=self.device)
+                             prob.pup.pupil_filter, prob.simpson_w, lf_mask=None, modal=prob.modal,
+                             modal_mult=prob.modal_mult, zmax=prob.zmax, D_ground=p['D_GROUND'],
+                             per_layer=True, device=self.device)
+        # mask_lf (ao_power_spectra.py:119-141) was evaluated on the device; same dtype as the reference
+        m = out["lf_mask"]
+        self.lf_mask = m if (prob.modal and prob.zmax is not None) else m.astype(numpy.int64)
+        self.hf_mask = 1 - self.lf_mask
         self.powerspec = out["powerspec"]
         self.powerspec_per_layer = out["powerspec_per_layer"]
         self.logamp_powerspec = out["logamp_powerspec"]

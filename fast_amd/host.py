@@ -140,7 +140,8 @@ def zernike_sq(fabs, fx, fy, D, n_noll):
 
 
 def lf_mask(fx, fy, d_wfs, modal, modal_mult, zmax, D):
-    """Corrected region of the AO system (ao_power_spectra.mask_lf, 119-141)."""
+    """Corrected region of the AO system (ao_power_spectra.mask_lf, 119-141).  Host version: used for
+    the 27 sub-harmonic frequencies only; the N x N mask is evaluated by the GPU kernel."""
     fmax = np.pi / d_wfs
     wfs = np.logical_and(np.abs(fx) <= fmax, np.abs(fy) <= fmax)
     if not modal:
@@ -349,9 +350,6 @@ def build_problem(params):
         prob.zmax, prob.modal, prob.modal_mult = 3, True, 1
     if prob.ao_mode not in ('NOAO', 'AO', 'TT', 'LGSAO'):
         raise Exception('Mode not recognised, note that "AO_PA", "TT_PA" and "LGS_PA" are now "AO" and "TT" and "LGSAO')
-    fx, fy, fabs = mesh(prob.axis)
-    prob.lf_mask = lf_mask(fx, fy, prob.d_wfs, prob.modal, prob.modal_mult, prob.zmax, p['D_GROUND'])
-    prob.lgs_z = zernike_sq(fabs, fx, fy, p['D_GROUND'], 4) if prob.ao_mode == 'LGSAO' else None
     prob.pup = pupils(p, prob.N, prob.Np, prob.dx)
     prob.W = prob.pup.pupil * prob.pup.pupil_mode
     prob.link_budget, prob.diffraction_limit = link_budget(p, prob.pup, prob.atm, prob.dx)

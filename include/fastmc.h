@@ -139,18 +139,25 @@ typedef struct {
   const double* cn2;    /* (L,) zenith-corrected cn2 dh */
   const double* h;      /* (L,) zenith-corrected heights */
   const double* wind;   /* (L, 2) wind vectors */
-  const double* lf_mask;      /* (N, N) mask_lf as float64 (ao_power_spectra.py:119-141) */
+  int32_t mask_mode;    /* mask_lf (ao_power_spectra.py:119-141) evaluated on the device: 1 zonal, 2 modal
+                           radial cut (modal_mult), 3 modal Zernike (zmax, D_ground); 0 = use lf_mask below */
+  int32_t zmax;         /* highest Noll index (mask_mode 3) */
+  double modal_mult;
+  double D_ground;      /* telescope diameter for the Zernike filters (mask_mode 3, LGSAO) */
+  const double* lf_mask;      /* (N, N) mask as float64 when mask_mode == 0, else NULL */
   const double* pupil_filter; /* (N, N) funcs.pupil_filter (funcs.py:308-315) or NULL */
-  const double* lgs_z;        /* (N, N) zernike_squared_filter(Z<=4) for LGSAO or NULL */
+  const double* lgs_z;        /* (N, N) zernike_squared_filter(Z<=4) for LGSAO, or NULL = evaluate on the device */
   const double* simpson_w;    /* (N,) Simpson weights of the frequency axis (funcs.py:100-115) */
 } fastmc_ps_params;
 
 #define FASTMC_PS_NSCALARS 6 /* aniso_servo, alias, noise, fitting, phs_var, logamp_var */
 
-/* Outputs (any may be NULL): powerspec (N,N); per_layer (L,N,N); logamp_ps (N,N);
- * scalars: FASTMC_PS_NSCALARS values in the order above, then L phs_var_weights. */
+/* Outputs (any may be NULL): powerspec (N,N); per_layer (L,N,N); logamp_ps (N,N); lf_mask_out
+ * (N,N) the mask used; scalars: FASTMC_PS_NSCALARS values in the order above, then L
+ * phs_var_weights; kernel_ms: HIP-event time of the kernels. */
 int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double* powerspec,
-                     double* per_layer, double* logamp_ps, double* scalars, double* kernel_ms);
+                     double* per_layer, double* logamp_ps, double* lf_mask_out, double* scalars,
+                     double* kernel_ms);
 
 /* ---- multi-GPU result exchange: one process per GPU, RCCL over xGMI ---- */
 /* 128-byte RCCL unique id, created on rank 0 and distributed by the launcher. */

@@ -141,8 +141,9 @@ def _ps_call(g, p):
     atm = prob.atm
     return prob, _lib.powerspec(prob.N, prob.dx, prob.wvl, p["L0"], p["l0"], prob.ao_mode, p["ALIAS"], p["NOISE"],
                                 prob.d_wfs, p["TLOOP"], p["TEXP"], atm.dtheta, atm.cn2, atm.h, atm.wind_vector,
-                                np.asarray(prob.lf_mask, dtype=float), prob.pup.pupil_filter, prob.simpson_w,
-                                lgs_z=prob.lgs_z, per_layer=True, device=0)
+                                prob.pup.pupil_filter, prob.simpson_w, lf_mask=None, modal=prob.modal,
+                                modal_mult=prob.modal_mult, zmax=prob.zmax, D_ground=p["D_GROUND"],
+                                per_layer=True, device=0)
 
 
 @pytest.mark.parametrize("case", E2E_CASES + ["default164"])
@@ -151,6 +152,7 @@ def test_powerspec_kernel_matches_reference(case):
     p = params_from_json(g["params_json"])
     prob, out = _ps_call(g, p)
     peak = np.abs(g["powerspec"]).max()
+    np.testing.assert_allclose(out["lf_mask"], g["lf_mask"], rtol=1e-11, atol=1e-14)     # mask_lf on the device
     np.testing.assert_allclose(out["powerspec"], g["powerspec"], rtol=1e-10, atol=1e-13 * peak)
     np.testing.assert_allclose(out["powerspec_per_layer"], g["powerspec_per_layer"], rtol=1e-10, atol=1e-13 * peak)
     np.testing.assert_allclose(out["logamp_powerspec"], g["logamp_powerspec"], rtol=1e-10,
@@ -172,6 +174,7 @@ def test_powerspec_kernel_full_size(name):
     np.testing.assert_allclose(out["powerspec"][N // 2 - 16:N // 2 + 16, N // 2 - 16:N // 2 + 16], g["powerspec_centre"],
                                rtol=1e-10, atol=1e-13 * peak)
     np.testing.assert_allclose(out["powerspec"].sum(), g["powerspec_sum"], rtol=1e-10)
+    np.testing.assert_allclose(out["lf_mask"].sum(), g["lf_mask_sum"], rtol=1e-12)
     for k in ("logamp_var", "phs_var", "fitting_error", "aniso_servo_error", "alias_error"):
         np.testing.assert_allclose(out[k], g[k], rtol=1e-9, atol=1e-300, err_msg=k)
 
@@ -350,3 +353,20 @@ def test_rccl_exchange_world_of_one():
     np.testing.assert_array_equal(allp, out)
     np.testing.assert_array_equal(hist, h.histogram(-30.0, 5.0, 70))
     assert hist.sum() == 200
+
+
+def test_mask_kats_on_device():
+    """ao_power_spectra.mask_lf variants (kat_masks) evaluated by the power-spectrum kernel, and the
+    host-supplied-mask path (mask_mode 0) giving the same spectrum."""
+    g = load_golden("kat_masks")
+    N, dx = int(g["N"]), float(g["dx"])
+    w = fast_amd.hostmath.simpson_weights(fast_amd.host.freq_axis(N, dx))
+    common = dict(N=N, dx=dx, wvl=1550e-9, L0=25.0, l0=0.01, ao_mode="AO", alias=True, noise=0.2, d_wfs=0.08,
+                  t_loop=1e-3, t_exp=1e-3, dtheta=[4, 0], cn2=np.array([1e-13, 2e-14]), h=np.array([1e3, 8e3]),
+                  wind=np.array([[5.0, 0.0], [0.0, 20.0]]), pupil_filter=None, simpson_w=w, device=0)
+    for key, kw in (("zonal", {}), ("modal", dict(modal=True, modal_mult=0.7)),
+                    ("zern3", dict(modal=True, zmax=3, D_ground=0.4)), ("zern9", dict(modal=True, zmax=9, D_ground=0.4))):
+        out = _lib.powerspec(lf_mask=None, **kw, **common)
+        np.testing.assert_allclose(out["lf_mask"], g[key], rtol=1e-11, atol=1e-14, err_msg=key)
+        again = _lib.powerspec(lf_mask=np.asarray(g[key], dtype=float), **common)
+        np.testing.assert_allclose(again["powerspec"], out["powerspec"], rtol=1e-12)

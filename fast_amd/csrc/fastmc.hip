@@ -289,7 +289,7 @@ extern "C" int fastmc_set_spectrum(fastmc_t* h, const double* powerspec, double 
 template <class R>
 static int upload_wave_tables(fastmc_ctx* h) {
   const int P = h->P;
-  h->omS = h->NS * 64;
+  h->omS = (h->Np + 7) & ~7;
   std::vector<cpx<R>> tw1((size_t)P * 64), om((size_t)8 * h->omS);
   build_tw1<R>(tw1.data(), P, cs_turns);
   build_om<R>(om.data(), h->omS, P, h->lo, h->Np, true, cs_turns);
@@ -368,17 +368,19 @@ extern "C" int fastmc_set_subharm(fastmc_t* h, const double* ps_sh, const double
 // ------------------------------------------------------------------ launches
 template <class R, int P, int NS, int MODE>
 static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
-  const size_t lds = wave_lds_bytes<R, P>(A.omS);
+  const size_t lds = wave_lds_bytes<R, P, NS>(A.omS);
   hipFuncSetAttribute((const void*)k_rows_wave<R, P, NS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int grid = A.nb * (A.N / (WAVES_PER_WG * ROWS_PER_WAVE));
-  hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE>), dim3(grid), dim3(WAVES_PER_WG * 64), lds, h->stream, A);
+  constexpr int WPB = WaveCfg<R, P, NS>::WPB;
+  const int items = A.nb * (A.N / ROWS_PER_WAVE);
+  hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, A);
 }
 template <class R, int P, int NS, int EPI>
 static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
-  const size_t lds = wave_lds_bytes<R, P>(A.omS);
+  const size_t lds = wave_lds_bytes<R, P, NS>(A.omS);
   hipFuncSetAttribute((const void*)k_cols_wave<R, P, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int groups = (A.Np + WAVES_PER_WG - 1) / WAVES_PER_WG;
-  hipLaunchKernelGGL((k_cols_wave<R, P, NS, EPI>), dim3(A.nb * groups), dim3(WAVES_PER_WG * 64), lds, h->stream, A);
+  constexpr int WPB = WaveCfg<R, P, NS>::WPB;
+  const int items = A.nb * A.Np;
+  hipLaunchKernelGGL((k_cols_wave<R, P, NS, EPI>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, A);
 }
 
 template <class R, int P, int NS>
@@ -399,8 +401,7 @@ template <class R, int P>
 static int dispatch_wave_ns(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   // two instantiations per (R, P): windows up to 128 pixels, and the general case
   if (h->NS <= 2) dispatch_wave<R, P, 2>(h, RA, CA, mode, epi);
-  else if (h->NS <= P) dispatch_wave<R, P, P>(h, RA, CA, mode, epi);
-  else return fail(FASTMC_EINVAL, "window too large for the wave kernels");
+  else dispatch_wave<R, P, P>(h, RA, CA, mode, epi);
   return 0;
 }
 
@@ -527,7 +528,16 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     CA.W = h->W;
     CA.sh.enabled = sh ? 1 : 0; CA.sh.coef = h->sh_coef; CA.sh.mean = h->sh_mean; CA.sh.ex = h->sh_ex; CA.sh.ey = h->sh_ey;
     CA.partial = h->partial + (size_t)((bs - fin_start)) * Np * 4; CA.phs = h->phs;
-    if (h->path == 1) {
+    bool wave_ok = h->path == 1;
+    if (wave_ok) {
+      const size_t need = h->NS <= 2 ? (h->P == 8 ? wave_lds_bytes<R, 8, 2>(h->omS) : h->P == 16 ? wave_lds_bytes<R, 16, 2>(h->omS) : wave_lds_bytes<R, 32, 2>(h->omS))
+                                     : (h->P == 8 ? wave_lds_bytes<R, 8, 8>(h->omS) : h->P == 16 ? wave_lds_bytes<R, 16, 16>(h->omS) : wave_lds_bytes<R, 32, 32>(h->omS));
+      if (need > 160 * 1024 || h->NS > h->P) wave_ok = false;   // window tables exceed the LDS: direct family (still on the GPU)
+    }
+    RA.amp = (const R*)(wave_ok ? h->amp_s : h->amp);
+    RA.tw = (const cpx<R>*)(wave_ok ? h->tw1 : h->tw);
+    CA.tw = RA.tw;
+    if (wave_ok) {
       if (h->P == 8) TRY((dispatch_wave_ns<R, 8>(h, RA, CA, S.mode, S.epi)));
       else if (h->P == 16) TRY((dispatch_wave_ns<R, 16>(h, RA, CA, S.mode, S.epi)));
       else TRY((dispatch_wave_ns<R, 32>(h, RA, CA, S.mode, S.epi)));
@@ -605,11 +615,11 @@ extern "C" int fastmc_screens(fastmc_t* h, uint64_t seed, int64_t real0, int64_t
 extern "C" int fastmc_rng_coeffs(fastmc_t* h, uint64_t seed, int64_t real, double* out) {
   if (!h || !out) return fail(FASTMC_EINVAL, "null argument");
   HIPCHK(hipSetDevice(h->device));
-  const int N = h->N, H = (N + 1) / 2;
+  const int N = h->N;
   double* d = nullptr;
   HIPCHK(hipMalloc((void**)&d, (size_t)N * N * 16));
   RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
-  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * H + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, d);
+  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * WAVE + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, d);
   HIPCHK(hipMemcpyAsync(out, d, (size_t)N * N * 16, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipFree(d));

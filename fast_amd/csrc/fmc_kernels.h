@@ -2,7 +2,7 @@
 //
 // Per realisation g (one complex N x N transform = two Monte-Carlo iterations):
 //   rows kernel : draw/colour one spectrum row, N-point DFT along kx pruned to the Np window
-//                 columns  ->  V[b][ky][oi]                       (x half of 4)
+//                 columns  ->  V[b][oi][ky]                       (x half of 4)
 //   cols kernel : N-point DFT along ky of each window column pruned to the Np window rows,
 //                 + sub-harmonics, W * exp(i phi) and the pixel sum  ->  partial[b][xi][4]
 //                                                                 (rows 3-5, 5c)
@@ -32,16 +32,20 @@ struct RngKey {
   uint32_t k0, k1;   // seed
 };
 
-// The two coefficients of pixel pair (ky, kx') , kx' < H = ceil(N/2): (ky, kx') and (ky, kx'+H).
+// Coefficient stream of (realisation g, row ky, lane class l = kx mod 64): xoshiro128+ seeded with
+// one Philox block; its (2j)-th and (2j+1)-th words make coefficient (ky, l + 64 j).
+__device__ __forceinline__ xoshiro128p row_stream(RngKey key, uint64_t g, int ky, int l) {
+  xoshiro128p s;
+  s.seed(philox4x32_10((uint32_t)(ky * WAVE + l), STREAM_SCREEN, (uint32_t)g, (uint32_t)(g >> 32), key.k0, key.k1));
+  return s;
+}
 template <class R>
-__device__ __forceinline__ void draw_pair(RngKey key, uint64_t g, int N, int ky, int kxp, cpx<R>& c0, cpx<R>& c1) {
-  const int H = (N + 1) >> 1;
-  const u32x4 x = philox4x32_10((uint32_t)(ky * H + kxp), STREAM_SCREEN, (uint32_t)g, (uint32_t)(g >> 32), key.k0, key.k1);
-  float a, b, c, d;
-  box_muller(x.a, x.b, a, b);
-  box_muller(x.c, x.d, c, d);
-  c0 = mk<R>((R)a, (R)b);
-  c1 = mk<R>((R)c, (R)d);
+__device__ __forceinline__ cpx<R> draw_coeff(xoshiro128p& s) {
+  const uint32_t a = s.next();
+  const uint32_t b = s.next();
+  float re, im;
+  box_muller(a, b, re, im);
+  return mk<R>((R)re, (R)im);
 }
 
 __device__ __forceinline__ float draw_logamp_normal(RngKey key, uint64_t iter) {
@@ -59,7 +63,7 @@ struct RowArgs {
   const cpx<R>* tw;             // wave: tw1 [P*64];  direct: w_N^e, e < N
   const cpx<R>* om;             // wave: [8][omS]
   int omS;
-  cpx<R>* V;                    // [nb][N][Np]
+  cpx<R>* V;                    // [nb][Np][N]  (window column major)
   RngKey key;
   uint64_t g0;                  // global index of realisation b = 0
   const double* cre;            // host-coefficient mode: [nb][N][N] real parts
@@ -77,7 +81,7 @@ struct SubharmArgs {
 template <class R>
 struct ColArgs {
   int N, Np, lo, nb;
-  const cpx<R>* V;              // [nb][N][Np]
+  const cpx<R>* V;              // [nb][Np][N]
   const cpx<R>* tw;
   const cpx<R>* om;
   int omS;
@@ -125,6 +129,18 @@ struct GpuExec {
   int lane;
   LaneRegs<R, P, NS>& r;
   template <class F> __device__ __forceinline__ void each(F f) { f(lane, r); }
+  // 8-byte LDS accesses kept as single ds_read_b64 / ds_write_b64: hipcc otherwise pairs them into
+  // ds_read2_b64, which runs at half the bytes per clock (MI355X_MICROARCH.md, LDS table).
+  static __device__ __forceinline__ double ld(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+  static __device__ __forceinline__ cpx<float> ld(const cpx<float>* p) {
+    const double d = __hip_atomic_load(reinterpret_cast<const double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    cpx<float> o;
+    __builtin_memcpy(&o, &d, 8);
+    return o;
+  }
+  template <class E> static __device__ __forceinline__ void st(E* p, E v) { *p = v; }
   __device__ __forceinline__ void sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -132,8 +148,14 @@ struct GpuExec {
   }
 };
 
-constexpr int WAVES_PER_WG = 4;
 constexpr int ROWS_PER_WAVE = 8;   // rows kernel: consecutive ky per wave
+// Waves per workgroup: the twiddle tables are staged once per workgroup, so bigger groups leave
+// more LDS for exchange buffers: 12 waves = 3 per SIMD at 132 VGPRs (f64, P = 16).
+// P = 32 keeps 2 x 32 values per lane (>= 200 VGPRs) and 18 KiB of exchange buffer per wave: fewer waves.
+// The general-window instantiation (NS = P) carries a large `om` table: 4 waves.
+template <class R, int P, int NS> struct WaveCfg {
+  static constexpr int WPB = (NS != 2) ? 4 : (P == 32 ? (sizeof(R) == 8 ? 4 : 6) : 12);
+};
 
 template <class R, int P>
 __device__ __forceinline__ void load_tables(cpx<R>* s_tw, cpx<R>* s_om, const cpx<R>* tw, const cpx<R>* om, int omS) {
@@ -142,14 +164,14 @@ __device__ __forceinline__ void load_tables(cpx<R>* s_tw, cpx<R>* s_om, const cp
   __syncthreads();
 }
 
-// LDS carve (dynamic): [tw1 P*64 cpx][om 8*omS cpx][xbuf WAVES*XELEMS 8-byte]
-template <class R, int P>
+// LDS carve (dynamic): [tw1 P*64 cpx][om 8*omS cpx][xbuf WPB*XELEMS 8-byte]
+template <class R, int P, int NS>
 __host__ __device__ constexpr size_t wave_lds_bytes(int omS) {
-  return (size_t)(P * WAVE + 8 * omS) * sizeof(cpx<R>) + (size_t)WAVES_PER_WG * WaveGeom<R, P>::XELEMS * 8;
+  return (size_t)(P * WAVE + 8 * omS) * sizeof(cpx<R>) + (size_t)WaveCfg<R, P, NS>::WPB * WaveGeom<R, P>::XELEMS * 8;
 }
 
 template <class R, int P, int NS, int MODE>
-__global__ __launch_bounds__(WAVES_PER_WG * 64) void k_rows_wave(RowArgs<R> A) {
+__global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = WaveGeom<R, P>;
   using E = typename Xch<R>::E;
@@ -160,12 +182,14 @@ __global__ __launch_bounds__(WAVES_PER_WG * 64) void k_rows_wave(RowArgs<R> A) {
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   E* xbuf = s_x + w * G::XELEMS;
-  // consecutive blocks = the same rows of different realisations (amp rows shared in L2)
-  const int b = blockIdx.x % A.nb;
-  const int chunk = blockIdx.x / A.nb;
-  const int row0 = (chunk * WAVES_PER_WG + w) * ROWS_PER_WAVE;
-  const uint64_t g = A.g0 + (uint64_t)b;
+  // work item = (row group of 8 consecutive ky, realisation b), b fastest: the waves of a block
+  // colour the SAME spectrum rows for different realisations (amp rows shared in L1/L2)
   const int N = G::N;
+  const int item = blockIdx.x * WaveCfg<R, P, NS>::WPB + w;
+  if (item >= A.nb * (N / ROWS_PER_WAVE)) return;   // after the only block barrier
+  const int b = item % A.nb;
+  const int row0 = (item / A.nb) * ROWS_PER_WAVE;
+  const uint64_t g = A.g0 + (uint64_t)b;
 
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
@@ -173,13 +197,9 @@ __global__ __launch_bounds__(WAVES_PER_WG * 64) void k_rows_wave(RowArgs<R> A) {
     const int ky = row0 + rr;
     const R* amp = A.amp + (size_t)ky * N;
     if (MODE == 0) {
+      xoshiro128p rs = row_stream(A.key, g, ky, lane);
 #pragma unroll
-      for (int j = 0; j < P / 2; ++j) {
-        cpx<R> c0, c1;
-        draw_pair<R>(A.key, g, N, ky, lane + WAVE * j, c0, c1);
-        regs.v[j] = cscale(c0, amp[lane + WAVE * j]);
-        regs.v[j + P / 2] = cscale(c1, amp[lane + WAVE * (j + P / 2)]);
-      }
+      for (int j = 0; j < P; ++j) regs.v[j] = cscale(draw_coeff<R>(rs), amp[lane + WAVE * j]);
     } else {
       const size_t base = ((size_t)b * N + ky) * N;
 #pragma unroll
@@ -189,18 +209,20 @@ __global__ __launch_bounds__(WAVES_PER_WG * 64) void k_rows_wave(RowArgs<R> A) {
       }
     }
     pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
-    cpx<R>* out = A.V + ((size_t)b * N + ky) * A.Np;
+    // V is stored column-major per realisation, V[b][oi][ky], so that the column pass reads it
+    // coalesced; the 8 consecutive rows of this wave complete one 128-byte line per window column.
+    cpx<R>* out = A.V + (size_t)b * A.Np * N + ky;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int oi = lane + WAVE * s;
-      if (oi < A.Np) out[oi] = mk<R>(regs.xr[s], regs.xi[s]);
+      if (oi < A.Np) out[(size_t)oi * N] = mk<R>(regs.xr[s], regs.xi[s]);
     }
   }
 }
 
 // EPI 0: detector partial sums; EPI 1: write the cropped screens.
 template <class R, int P, int NS, int EPI>
-__global__ __launch_bounds__(WAVES_PER_WG * 64) void k_cols_wave(ColArgs<R> A) {
+__global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_cols_wave(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = WaveGeom<R, P>;
   using E = typename Xch<R>::E;
@@ -211,17 +233,18 @@ __global__ __launch_bounds__(WAVES_PER_WG * 64) void k_cols_wave(ColArgs<R> A) {
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   E* xbuf = s_x + w * G::XELEMS;
-  const int groups = (A.Np + WAVES_PER_WG - 1) / WAVES_PER_WG;
-  const int b = blockIdx.x / groups;
-  const int xi = (blockIdx.x % groups) * WAVES_PER_WG + w;
-  if (xi >= A.Np) return;   // whole wave exits; no block barrier follows
+  // work item = (realisation b, window column xi), xi fastest: adjacent waves read adjacent columns
+  const int item = blockIdx.x * WaveCfg<R, P, NS>::WPB + w;
+  if (item >= A.nb * A.Np) return;   // whole wave exits; no block barrier follows
+  const int b = item / A.Np;
+  const int xi = item % A.Np;
   const int N = G::N;
 
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
-  const cpx<R>* col = A.V + (size_t)b * N * A.Np + xi;
+  const cpx<R>* col = A.V + ((size_t)b * A.Np + xi) * N;
 #pragma unroll
-  for (int j = 0; j < P; ++j) regs.v[j] = col[(size_t)(lane + WAVE * j) * A.Np];
+  for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
   pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
 
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -269,12 +292,9 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_rows_direct(RowArgs<R> A) {
   const R* amp = A.amp + (size_t)ky * N;
   for (int i = threadIdx.x; i < N; i += blockDim.x) s_tw[i] = A.tw[i];
   if (MODE == 0) {
-    const int H = (N + 1) >> 1;
-    for (int kxp = threadIdx.x; kxp < H; kxp += blockDim.x) {
-      cpx<R> c0, c1;
-      draw_pair<R>(A.key, g, N, ky, kxp, c0, c1);
-      s_row[kxp] = cscale(c0, amp[kxp]);
-      if (kxp + H < N) s_row[kxp + H] = cscale(c1, amp[kxp + H]);
+    if (threadIdx.x < WAVE && (int)threadIdx.x < N) {   // one sequential stream per lane class
+      xoshiro128p rs = row_stream(A.key, g, ky, threadIdx.x);
+      for (int kx = threadIdx.x; kx < N; kx += WAVE) s_row[kx] = cscale(draw_coeff<R>(rs), amp[kx]);
     }
   } else {
     const size_t base = ((size_t)b * N + ky) * N;
@@ -292,7 +312,7 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_rows_direct(RowArgs<R> A) {
       e += q;
       if (e >= N) e -= N;
     }
-    A.V[((size_t)b * N + ky) * A.Np + oi] = acc;
+    A.V[((size_t)b * A.Np + oi) * N + ky] = acc;
   }
 }
 
@@ -307,7 +327,7 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_cols_direct(ColArgs<R> A) {
   const int xi = blockIdx.x % A.Np;
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     s_tw[i] = A.tw[i];
-    s_col[i] = A.V[((size_t)b * N + i) * A.Np + xi];
+    s_col[i] = A.V[((size_t)b * A.Np + xi) * N + i];
   }
   __syncthreads();
   const int h = N / 2;
@@ -451,17 +471,15 @@ __global__ void k_histogram(const double* out, int64_t n, int coherent, double l
 
 // ================================================================== generator read-back (parity tests)
 __global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, double* out) {
-  const int H = (N + 1) >> 1;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * H) return;
-  const int ky = idx / H, kxp = idx % H;
-  cpx<double> c0, c1;
-  draw_pair<double>(key, g, N, ky, kxp, c0, c1);
-  out[2 * ((size_t)ky * N + kxp)] = c0.x;
-  out[2 * ((size_t)ky * N + kxp) + 1] = c0.y;
-  if (kxp + H < N) {
-    out[2 * ((size_t)ky * N + kxp + H)] = c1.x;
-    out[2 * ((size_t)ky * N + kxp + H) + 1] = c1.y;
+  if (idx >= N * WAVE) return;
+  const int ky = idx / WAVE, l = idx % WAVE;
+  if (l >= N) return;
+  xoshiro128p rs = row_stream(key, g, ky, l);
+  for (int kx = l; kx < N; kx += WAVE) {
+    const cpx<double> c = draw_coeff<double>(rs);
+    out[2 * ((size_t)ky * N + kx)] = c.x;
+    out[2 * ((size_t)ky * N + kx) + 1] = c.y;
   }
 }
 

@@ -51,9 +51,12 @@ struct WaveGeom {
   static constexpr int N = WAVE * P;
   static constexpr int LOGP = ilog2(P);
   static constexpr int NB = P / 8;                 // radix-8 butterflies per lane in stage 2a
-  static constexpr int SE = 72;                    // row stride of exchange-1 image  E[a][l]
-  static constexpr int SF = 65;                    // row stride of exchange-2 image  F[a][b0*8+l0]
-  static constexpr int XELEMS = P * SE;            // 8-byte elements per wave
+  static constexpr int SE = 72;                    // row stride of exchange-1 image  E[a][l]: a*72 + l
+  // exchange-2 image F[a][b0][l0] at  a + FL*l0 + FB*b0 : conflict-free for the 16-lane write groups
+  // ((a mod 8) + 18 l0 covers 16 banks) and for the 32-lane read groups (a + 16*(b0 parity) covers 32)
+  static constexpr int FL = P + 2;
+  static constexpr int FB = 8 * FL;
+  static constexpr int XELEMS = (P * SE > 8 * FB) ? P * SE : 8 * FB;   // 8-byte elements per wave
   static_assert(P >= 8 && P <= 32, "wave FFT supports N = 512, 1024, 2048");
 };
 
@@ -98,7 +101,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
   for (int c = 0; c < NC; ++c) {
     ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
 #pragma unroll
-      for (int a = 0; a < P; ++a) xbuf[a * G::SE + lane] = X::pack(r.v[a], c);
+      for (int a = 0; a < P; ++a) ex.st(xbuf + a * G::SE + lane, X::pack(r.v[a], c));
     });
     ex.sync();
     ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
@@ -107,7 +110,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
       for (int jj = 0; jj < G::NB; ++jj)
 #pragma unroll
         for (int m = 0; m < 8; ++m)
-          X::unpack(r.v[jj * 8 + m], xbuf[(i + 8 * jj) * G::SE + l0 + 8 * m], c);
+          X::unpack(r.v[jj * 8 + m], ex.ld(xbuf + (i + 8 * jj) * G::SE + l0 + 8 * m), c);
     });
     ex.sync();
   }
@@ -132,7 +135,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
       for (int jj = 0; jj < G::NB; ++jj)
 #pragma unroll
         for (int b0 = 0; b0 < 8; ++b0)
-          xbuf[(i + 8 * jj) * G::SF + b0 * 8 + l0] = X::pack(r.v[jj * 8 + b0], c);
+          ex.st(xbuf + (i + 8 * jj) + G::FL * l0 + G::FB * b0, X::pack(r.v[jj * 8 + b0], c));
     });
     ex.sync();
     ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
@@ -144,9 +147,9 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
             const int x = lo + oi;
             const int a = x & (P - 1);
             const int b0 = (x >> G::LOGP) & 7;
-            const E* f = xbuf + a * G::SF + b0 * 8;
+            const E* f = xbuf + a + G::FB * b0;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], f[m], c);
+            for (int m = 0; m < 8; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + G::FL * m), c);
           }
         }
       }

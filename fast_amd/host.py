@@ -207,9 +207,18 @@ def pupil_filter(field):
     return P / field.sum() ** 2
 
 
+_PUPIL_CACHE = {}
+
+
 def pupils(p, N, Np, dx):
-    """Fast.init_pupil_mask (fast.py:332-392), non-temporal part."""
-    o = SimpleNamespace()
+    """Fast.init_pupil_mask (fast.py:332-392), non-temporal part.  The result depends only on
+    the aperture / grid parameters, so sweeps over atmospheric geometry reuse it."""
+    key = (N, Np, float(dx), p['D_GROUND'], p['OBSC_GROUND'], p['D_SAT'], p['OBSC_SAT'], str(p['W0']), bool(p['AXICON']))
+    if key in _PUPIL_CACHE:
+        return _PUPIL_CACHE[key]
+    if len(_PUPIL_CACHE) > 8:
+        _PUPIL_CACHE.clear()
+    o = _PUPIL_CACHE[key] = SimpleNamespace()
     D, obsc = p['D_GROUND'], p['OBSC_GROUND']
     o.dx_sat = p['D_SAT'] / 32
     full = aperture(N, dx, D, obsc)

@@ -1,0 +1,57 @@
+"""Many-configuration sweeps (the pattern of fast/complete_orbit_simulation.py:187-232 of the
+reference: one `Fast` object per geometry sample, few iterations each).
+
+BASELINE config 5 is a zenith-angle scan: 32 Cn2 geometries x 4096 iterations at N = 1024, AO
+corrected.  Per sample the reference rebuilds everything (`fast.Fast(params)`,
+complete_orbit_simulation.py:227) and its init is dominated by `compute_powerspec` (12-15 s at
+1024^2).  Here the power spectrum is one GPU kernel (< 1 ms), the pupil /
+fibre-mode products are cached across samples that share the aperture (host.pupils cache), and
+samples are dealt round-robin to the ranks of a torch.distributed group (one process per
+GPU); only the per-sample summary statistics are gathered.
+"""
+import copy
+import sys
+import time
+
+import numpy as np
+
+from . import host
+from .fast import Fast
+
+
+def zenith_scan(base_params, zenith_angles, niter=4096, nchunks=1, keep_power=False, rank=0, world=1):
+    """Run `Fast` for each zenith angle owned by this rank (angles[rank::world]).
+
+    L_SAT is recomputed from H_SAT for each angle (funcs.l_path via Fast.init_atmos,
+    fast.py:237-241) because base_params['L_SAT'] is left None.  Returns a list of dicts
+    (zenith, mean dB_rel, scintillation index, phs_var, logamp_var, timings)."""
+    out = []
+    for idx in range(rank, len(zenith_angles), world):
+        p = copy.copy(base_params)
+        p.update({"ZENITH_ANGLE": float(zenith_angles[idx]), "NITER": niter, "NCHUNKS": nchunks, "TEMPORAL": False,
+                  "GPU_SHARD": False})
+        if p.get("SEED") is not None:
+            p["SEED"] = int(p["SEED"]) + idx
+        t0 = time.perf_counter()
+        sim = Fast(p)
+        t1 = time.perf_counter()
+        res = sim.run()
+        t2 = time.perf_counter()
+        rec = {"index": idx, "zenith": float(zenith_angles[idx]), "mean_dB_rel": float(res.avg_power_dB_rel),
+               "scintillation_index": float(res.scintillation_index), "phs_var": float(sim.phs_var),
+               "logamp_var": float(sim.logamp_var), "r0_los": float(sim.r0_los), "L": float(sim.L),
+               "init_s": t1 - t0, "run_s": t2 - t1, "powerspec_kernel_ms": sim.powerspec_kernel_ms}
+        if keep_power:
+            rec["r"] = res._r
+        out.append(rec)
+    return out
+
+
+def gather_records(records):
+    """All ranks' records on every rank (torch.distributed object gather when a group exists)."""
+    tdist = getattr(sys.modules.get("torch"), "distributed", None) if "torch" in sys.modules else None
+    if tdist is None or not tdist.is_initialized() or tdist.get_world_size() < 2:
+        return sorted(records, key=lambda r: r["index"])
+    bucket = [None] * tdist.get_world_size()
+    tdist.all_gather_object(bucket, records)
+    return sorted([r for part in bucket for r in part], key=lambda r: r["index"])

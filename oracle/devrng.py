@@ -6,9 +6,10 @@ generator has no counterpart in the reference (which uses numpy's PCG64 stream,
 fast/funcs.py:21,352-356); this module restates OUR definition in numpy/float64 so that the
 device path can be checked deterministically, not only statistically:
 
-  pixel pair (ky, kx'), kx' < H = ceil(N/2):  x = Philox4x32-10(ctr=(ky*H+kx', STREAM, g_lo, g_hi), key=seed)
-  coefficient (ky, kx')   = BM(x0, x1),   coefficient (ky, kx'+H) = BM(x2, x3)
+  stream (g, ky, l = kx mod 64): xoshiro128+ seeded with Philox4x32-10(ctr=(ky*64+l, STREAM, g_lo, g_hi), key=seed)
+  coefficient (ky, l + 64 j) = BM(word 2j, word 2j+1) of that stream
   BM(a, b) = sqrt(-2 ln((a+.5)/2^32)) * exp(2 pi i (b+.5)/2^32)
+  (log-amplitude and sub-harmonic draws use Philox blocks directly)
 
 Philox4x32-10 is the published Random123 algorithm (Salmon et al., SC'11); `test_oracle_devrng`
 pins this implementation to Random123's known-answer vectors.
@@ -47,15 +48,40 @@ def box_muller(a, b):
     return r * np.cos(2 * np.pi * t) + 1j * r * np.sin(2 * np.pi * t)
 
 
+def xoshiro128p_next(s):
+    """One step of xoshiro128+ on four uint32 arrays (in place); returns the output words."""
+    s0, s1, s2, s3 = s
+    r = (s0 + s3).astype(np.uint32)
+    t = (s1 << np.uint32(9)).astype(np.uint32)
+    s2 ^= s0
+    s3 ^= s1
+    s1 ^= s2
+    s0 ^= s3
+    s2 ^= t
+    s[3] = ((s3 << np.uint32(11)) | (s3 >> np.uint32(21))).astype(np.uint32)
+    return r
+
+
 def device_coefficients(seed, g, N):
-    """(N, N) complex coefficients of realisation g (== fastmc_rng_coeffs)."""
-    H = (N + 1) // 2
-    ky, kxp = np.meshgrid(np.arange(N), np.arange(H), indexing="ij")
-    x0, x1, x2, x3 = philox4x32_10(ky * H + kxp, STREAM_SCREEN, g & 0xFFFFFFFF, g >> 32, seed & 0xFFFFFFFF, seed >> 32)
+    """(N, N) complex coefficients of realisation g (== fastmc_rng_coeffs).
+
+    Stream (g, ky, l = kx mod 64): state = Philox4x32-10(ctr = (ky*64 + l, STREAM_SCREEN, g_lo, g_hi),
+    key = seed) (s0 := 1 if the block is all zero); coefficient (ky, l + 64 j) = BM(word 2j, word 2j+1)
+    of xoshiro128+ (fmc_core.h: xoshiro128p, fmc_kernels.h: row_stream / draw_coeff)."""
+    lanes = min(64, N)
+    ky, l = np.meshgrid(np.arange(N), np.arange(lanes), indexing="ij")
+    x = philox4x32_10(ky * 64 + l, STREAM_SCREEN, g & 0xFFFFFFFF, g >> 32, seed & 0xFFFFFFFF, seed >> 32)
+    s = [np.array(w, dtype=np.uint64).astype(np.uint32) for w in x]
+    zero = (s[0] | s[1] | s[2] | s[3]) == 0
+    s[0][zero] = 1
     out = np.empty((N, N), dtype=complex)
-    out[:, :H] = box_muller(x0, x1)
-    second = box_muller(x2, x3)
-    out[:, H:] = second[:, :N - H]
+    with np.errstate(over="ignore"):
+        for j in range((N + 63) // 64):
+            a = xoshiro128p_next(s)
+            b = xoshiro128p_next(s)
+            c = box_muller(a, b)
+            w = min(64, N - 64 * j)
+            out[:, 64 * j:64 * j + w] = c[:, :w]
     return out
 
 

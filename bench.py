@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--npxls", type=int, default=1024)
     ap.add_argument("--ao-mode", default="NOAO")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="realisations per launch (0 = library default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,7 +83,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     torch = None
-    if world > 1:
+    # FASTMC_BENCH_FORCE_DIST=1 exercises the multi-process code path (process group, in-library
+    # RCCL communicator, gather) with a single rank: the only way to test it on a 1-GPU box.
+    dist_on = world > 1 or (os.environ.get("FASTMC_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if dist_on:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -91,6 +95,7 @@ def main():
     import fast_amd
     p = workload_params(args)
     p["GPU_DEVICE"] = local_rank
+    p["GPU_BATCH"] = args.batch
     t0 = time.perf_counter()
     sim = fast_amd.Fast(p)
     init_s = time.perf_counter() - t0
@@ -100,7 +105,7 @@ def main():
     lvar = float(sim.logamp_var)
 
     gather = "none"
-    if world > 1:
+    if dist_on:
         # RCCL inside the library, on its own stream: unique id from rank 0 via the launcher's store
         ids = [fast_amd._lib.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -111,7 +116,7 @@ def main():
             gather = f"torch.distributed ({e})"
 
     def sync_all():
-        if world > 1:
+        if dist_on:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -123,7 +128,7 @@ def main():
         # disjoint realisation ranges: step i, rank r
         real0 = (i * world + rank) * n_real
         out = h.run(p["SEED"], real0, n_real, None, lvar, False)
-        if world > 1:
+        if dist_on:
             hist = None
             if gather.startswith("rccl"):
                 try:
@@ -151,7 +156,7 @@ def main():
             tim[k] += t[k]
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -180,7 +185,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.precision == "f64" else "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: {N}^2 grid, Np={Np}, {ITERS_PER_STEP} iters/step/GPU, "
-                                   f"{args.ao_mode} von Karman spectrum, device Philox4x32-10 generator",
+                                   f"{args.ao_mode} von Karman spectrum, device generator (Philox4x32-10-seeded xoshiro128+ streams, Box-Muller)",
                        "iters_per_step_per_gpu": ITERS_PER_STEP, "kernel_path": "wave-fft" if h.kernel_path() == 1 else "direct",
                        "parallelism": f"realisations sharded over {world} GPU(s)", "result_exchange": gather},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -199,7 +204,7 @@ def main():
         if hist_total is not None:
             line["config"]["histogram_total"] = int(np.sum(hist_total))
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -43,11 +43,22 @@ def workload_params(args):
     }
 
 
-def cpu_baseline(sim, seconds_target=15.0):
-    """The oracle (numpy restatement of the reference's CPU path, FFTW-branch semantics) timed on
-    this host, one core, on a bounded sample of the same workload."""
+def _cpu_worker(args):
+    """One process of the all-cores baseline: `chunks` chunks of 20 iterations with its own seed."""
+    seed, chunks, ps, df, W, dx, lv = args
     from oracle import fastref as R
-    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    t0 = time.perf_counter()
+    r = R.monte_carlo(seed, 20 * chunks, chunks, ps, df, W, dx, lv)
+    return 20 * chunks, time.perf_counter() - t0, bool(np.isfinite(r).all())
+
+
+def cpu_baseline(sim, seconds_target=12.0):
+    """The oracle (numpy restatement of the reference's CPU path, FFTW-branch semantics) timed on
+    this host on a bounded sample of the same workload: one core (the reference's default,
+    FFTW_THREADS 1, fast/conf.py:71-72) and, as an extra, one process per core."""
+    from oracle import fastref as R
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(v, "1")
     ps, df, W, dx, lv = sim.powerspec, sim._prob.df, sim._prob.W, sim.dx, float(sim.logamp_var)
     t0 = time.perf_counter()
     R.monte_carlo(123, 20, 1, ps, df, W, dx, lv)          # warm-up chunk: 20 iterations
@@ -58,10 +69,24 @@ def cpu_baseline(sim, seconds_target=15.0):
     r = R.monte_carlo(124, n_it, chunks, ps, df, W, dx, lv)
     dt = time.perf_counter() - t0
     assert np.isfinite(r).all()
-    return {"value": n_it / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": f"{n_it} iterations ({chunks} chunks of 20) of the same {ps.shape[0]}^2 workload, "
-                      f"oracle/fastref.py (numpy {np.__version__} pocketfft, float64, 1 thread), {dt:.1f} s",
-            "host_cpus": os.cpu_count()}
+    out = {"value": n_it / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+           "sample": f"{n_it} iterations ({chunks} chunks of 20) of the same {ps.shape[0]}^2 workload, "
+                     f"oracle/fastref.py (numpy {np.__version__} pocketfft, float64, 1 thread), {dt:.1f} s",
+           "host_cpus": os.cpu_count()}
+    try:   # all cores: one process per core, 2 chunks each (bounded to ~2 x the single-chunk time)
+        import multiprocessing as mp
+        ncore = min(os.cpu_count() or 1, 64)
+        ctx = mp.get_context("fork")
+        t0 = time.perf_counter()
+        with ctx.Pool(ncore) as pool:
+            res = pool.map(_cpu_worker, [(1000 + i, 2, ps, df, W, dx, lv) for i in range(ncore)])
+        wall = time.perf_counter() - t0
+        if all(ok for _, _, ok in res):
+            out["all_cores"] = {"value": sum(n for n, _, _ in res) / wall, "unit": "iterations/s", "cores": ncore,
+                                "sample": f"{ncore} processes x 40 iterations, wall {wall:.1f} s (includes process start)"}
+    except Exception as e:   # the baseline of record is the single-core figure above
+        out["all_cores"] = {"error": str(e)}
+    return out
 
 
 def main():

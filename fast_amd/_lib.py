@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfastmc.so")
+# FASTMC_LIB selects another build of the same ABI (A/B timing of kernel variants: tools/ab.sh)
+LIB_PATH = os.environ.get("FASTMC_LIB") or os.path.join(_HERE, "libfastmc.so")
 
 F64, F32 = 0, 1
 AO_MODES = {"NOAO": 0, "AO": 1, "TT": 2, "LGSAO": 3}

@@ -141,10 +141,20 @@ struct GpuExec {
     return o;
   }
   template <class E> static __device__ __forceinline__ void st(E* p, E v) { *p = v; }
+  // Exchange-image hand-off between the lanes of ONE wavefront.  DS instructions of a wave are
+  // issued and executed by the LDS in program order, so a read issued after a write (or a write
+  // after a read) of the same wave needs no s_waitcnt: wavefront-scope fences only stop the
+  // compiler from moving or caching LDS accesses across this point.
   __device__ __forceinline__ void sync() {
+#ifdef FMC_SYNC_WORKGROUP   // A/B variant: waits for lgkmcnt(0) at every hand-off
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
   }
 };
 

@@ -111,6 +111,11 @@ static int dev_alloc(T** p, size_t n) {
     if (r__ != 0) return r__; \
   } while (0)
 
+struct ScratchBuf {   // device scratch freed on every return path
+  double* p = nullptr;
+  ~ScratchBuf() { if (p) hipFree(p); }
+};
+
 static int grow(double** p, size_t* cap, size_t need) {
   if (*cap >= need) return 0;
   if (*p) HIPCHK(hipFree(*p));
@@ -526,14 +531,12 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     }
     RowArgs<R> RA;
     RA.N = N; RA.Np = Np; RA.lo = h->lo; RA.nb = nb;
-    RA.amp = (const R*)(h->path == 1 ? h->amp_s : h->amp);
-    RA.tw = (const cpx<R>*)(h->path == 1 ? h->tw1 : h->tw);
     RA.om = (const cpx<R>*)h->om; RA.omS = h->omS;
     RA.V = (cpx<R>*)h->V; RA.key = key; RA.g0 = (uint64_t)(S.real0 + bs);
     RA.cre = h->cre; RA.cim = h->cim;
     ColArgs<R> CA;
     CA.N = N; CA.Np = Np; CA.lo = h->lo; CA.nb = nb;
-    CA.V = (const cpx<R>*)h->V; CA.tw = RA.tw; CA.om = RA.om; CA.omS = h->omS;
+    CA.V = (const cpx<R>*)h->V; CA.om = RA.om; CA.omS = h->omS;
     CA.W = h->W;
     CA.sh.enabled = sh ? 1 : 0; CA.sh.coef = h->sh_coef; CA.sh.mean = h->sh_mean; CA.sh.ex = h->sh_ex; CA.sh.ey = h->sh_ey;
     CA.partial = h->partial + (size_t)((bs - fin_start)) * Np * 4; CA.phs = h->phs;
@@ -624,28 +627,30 @@ extern "C" int fastmc_screens(fastmc_t* h, uint64_t seed, int64_t real0, int64_t
 extern "C" int fastmc_rng_coeffs(fastmc_t* h, uint64_t seed, int64_t real, double* out) {
   if (!h || !out) return fail(FASTMC_EINVAL, "null argument");
   HIPCHK(hipSetDevice(h->device));
+  if (real < 0) return fail(FASTMC_EINVAL, "realisation index must be non-negative");
   const int N = h->N;
-  double* d = nullptr;
-  HIPCHK(hipMalloc((void**)&d, (size_t)N * N * 16));
+  ScratchBuf d;
+  HIPCHK(hipMalloc((void**)&d.p, (size_t)N * N * 16));
   RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
-  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * WAVE + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, d);
-  HIPCHK(hipMemcpyAsync(out, d, (size_t)N * N * 16, hipMemcpyDeviceToHost, h->stream));
+  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * WAVE + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, d.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, d.p, (size_t)N * N * 16, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipFree(d));
   return 0;
 }
 
 extern "C" int fastmc_rng_logamp(fastmc_t* h, uint64_t seed, int64_t iter0, int64_t n_iter, double* out) {
   if (!h || !out || n_iter <= 0) return fail(FASTMC_EINVAL, "bad argument");
   HIPCHK(hipSetDevice(h->device));
-  double* d = nullptr;
-  HIPCHK(hipMalloc((void**)&d, (size_t)n_iter * 8));
+  if (iter0 < 0) return fail(FASTMC_EINVAL, "iteration index must be non-negative");
+  ScratchBuf d;
+  HIPCHK(hipMalloc((void**)&d.p, (size_t)n_iter * 8));
   RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
   hipLaunchKernelGGL(k_rng_logamp, dim3((unsigned)((n_iter + 255) / 256)), dim3(256), 0, h->stream, key, (uint64_t)iter0,
-                     n_iter, d);
-  HIPCHK(hipMemcpyAsync(out, d, (size_t)n_iter * 8, hipMemcpyDeviceToHost, h->stream));
+                     n_iter, d.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, d.p, (size_t)n_iter * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipFree(d));
   return 0;
 }
 

@@ -401,3 +401,20 @@ def test_config4_geometry_2048():
     assert r.shape == (512,) and np.isfinite(r).all() and (r > 0).all()
     hist = sim.histogram(-60.0, 10.0, 4096)
     assert hist.sum() == 512
+
+
+def test_many_realisations_cross_finalize_span():
+    """More than 32768 realisations in one call: detector partials are finalised in several spans."""
+    N, Np = 64, 10
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    h = _lib.Handle(N, Np, "f32", 0)
+    h.set_spectrum(ps * 0.02, df)
+    h.set_pupil(_window_W(Np), (N - Np) // 2, 0.01)
+    n = 33000
+    full = h.run(3, 0, n, None, 0.01)
+    assert np.isfinite(full).all() and (full > 0).all()
+    a = h.run(3, 0, 20000, None, 0.01)
+    b = h.run(3, 20000, 13000, None, 0.01)
+    np.testing.assert_array_equal(full, np.r_[a[:20000], b[:13000], a[20000:], b[13000:]])
+    one = h.run(3, 32999, 1, None, 0.01)
+    np.testing.assert_array_equal(one, [full[32999], full[n + 32999]])

@@ -18,9 +18,10 @@ def circle(radius, size):
 
 
 def gaussian2d(size, width):
-    """exp(-((xc-X)^2 + (yc-Y)^2) / (2 width^2)), centre at size/2 (aotools.gaussian2d)."""
+    """exp(-((xc-X)^2 + (yc-Y)^2) / (2 width^2)), centre at size/2, image of shape `size`
+    (rows, columns) (aotools.gaussian2d)."""
     try:
-        xs, ys = size[0], size[1]
+        ys, xs = size[0], size[1]
     except (TypeError, IndexError):
         xs = ys = size
     w = float(width)

@@ -448,3 +448,141 @@ def result_stats(r, dl):
         "dB_rel": 10 * np.log10(r), "dB_abs": 10 * np.log10(r * dl), "dBm": 10 * np.log10(r * dl / 1e-3),
         "power": p, "scintillation_index": (r / r.mean()).var(), "avg_power_W": p.mean(),
     }
+
+
+# --------------------------------------------------------------------------
+# Temporal (frozen-flow) mode -- SURVEY 8f rank 2
+#   fast/fast.py:846-864 (frequencies), 394-405 (high-resolution pupil filter),
+#   538-587 (shifts, temporal log-amplitude spectrum), 607-637 (shifted screens),
+#   fast/funcs.py:367-375 (coloured log-amplitude series)
+# --------------------------------------------------------------------------
+from scipy.interpolate import RectBivariateSpline  # noqa: E402  (third party the reference calls)
+
+
+def temporal_freqs(n_layers, Ny, Nx, wind_speed, wind_dir_deg, dt, dfy):
+    """fast.py:846-864: per layer, x axis in LINEAR frequency 1/(Nx v dt), y axis = main dfy grid,
+    rotated by the wind direction.  Returns axes_x (L,Nx), axes_y (L,Ny), fabs (L,Ny,Nx)."""
+    ax, ay, fabs = [], [], []
+    for i in range(n_layers):
+        dft = 1 / (Nx * wind_speed[i] * dt)
+        fx_axis = np.arange(-Nx / 2, Nx / 2) * dft
+        fy_axis = np.arange(-Ny / 2, Ny / 2) * dfy
+        fx, fy = np.meshgrid(fx_axis, fy_axis)
+        rot = np.radians(wind_dir_deg[i])
+        fxr = fx * np.cos(rot) - fy * np.sin(rot)
+        fyr = fx * np.sin(rot) + fy * np.cos(rot)
+        ax.append(fx_axis)
+        ay.append(fy_axis)
+        fabs.append(np.sqrt(fxr ** 2 + fyr ** 2))
+    return np.array(ax), np.array(ay), np.array(fabs)
+
+
+def _aperture(N, dx, D, obsc, Ny=None):
+    """funcs.compute_pupil (funcs.py:261-277) with aotools.circle restated (third party)."""
+    def circle(radius, size):
+        c = np.arange(0.5, size, 1.0) - size / 2.0
+        x, y = np.meshgrid(c, c)
+        return (x * x + y * y <= radius * radius).astype(float)
+    ap = circle(D / dx / 2, N) - circle(obsc / dx / 2, N)
+    if Ny is not None:
+        if Ny > N:
+            pad = (Ny - N) // 2
+            ap = np.pad(ap, [(0, 0), (pad, pad)])
+        if Ny < N:
+            cut = (N - Ny) // 2
+            ap = ap[:, cut:-cut]
+    return ap / np.sqrt(ap.sum() * dx ** 2)
+
+
+def temporal_pupil_filter(ax_t, ay_t, df_main, D, obsc, W0, Np, dx):
+    """fast.py:394-405: pupil filter on a grid fine enough for the temporal frequencies, as a
+    bilinear RectBivariateSpline (funcs.py:308-315, spline=True)."""
+    f_max = max(ax_t.max(), ay_t.max())
+    dx_req = np.pi / f_max
+    N_req = int(2 * np.ceil(2 * np.pi / (df_main * dx_req) / 2))
+    Ny = 2 * Np
+    pupil = _aperture(N_req, dx_req, D, obsc, Ny=Ny)
+    ys, xs = pupil.shape
+    Xg, Yg = np.meshgrid(np.arange(xs), np.arange(ys))
+    w = W0 / dx_req / np.sqrt(2)
+    mode = np.exp(-(((xs / 2.0 - Xg) / w) ** 2 + ((ys / 2.0 - Yg) / w) ** 2) / 2) * np.sqrt(2 / (np.pi * W0 ** 2)) / pupil.max()
+    field = pupil * mode
+    P = np.abs(np.fft.fftshift(np.fft.fft2(np.fft.fftshift(field, axes=(-1, -2))), axes=(-1, -2))) ** 2
+    P = P / field.sum() ** 2
+    fx_axis = np.arange(-N_req / 2., N_req / 2.) * (TWO_PI / (N_req * dx_req))
+    fy_axis = np.arange(-Ny / 2., Ny / 2.) * (TWO_PI / (Ny * dx))
+    return RectBivariateSpline(fx_axis, fy_axis, P, kx=1, ky=1, s=0)
+
+
+def temporal_logamp_spectrum(ax_t, ay_t, fabs_t, h, cn2, wvl, spline, L0, l0, dfy):
+    """fast.py:582-587 with ao_power_spectra.py:272-301 (freq_per_layer, spline pupil filter)."""
+    h = np.asarray(h, dtype=float)
+    cn2 = np.asarray(cn2, dtype=float)
+    km, k0 = 5.92 / l0, TWO_PI / L0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        vk = (0.033 * np.exp(-fabs_t ** 2 / km ** 2) / (fabs_t ** 2 + k0 ** 2) ** (11 / 6.)) * cn2[:, None, None]
+    vk[np.isinf(vk)] = 0.
+    ps = vk * TWO_PI * (TWO_PI / wvl) ** 2
+    ps = ps * np.sin(wvl * h[:, None, None] * fabs_t ** 2 / (4 * np.pi)) ** 2
+    P = np.stack([spline(ay_t[i], ax_t[i]) for i in range(len(h))])
+    return (ps * P).sum(0).sum(-2) * dfy
+
+
+def draw_logamp_temporal(rng, n_iter, logamp_var, tps):
+    """funcs.py:367-375: coloured series = centred DFT of white noise * sqrt(normalised spectrum)."""
+    r = rng.normal(0, 1, size=(n_iter,)) + 1j * rng.normal(0, 1, size=(n_iter,))
+    r = r * np.sqrt(tps / tps.sum())
+    series = np.fft.fftshift(np.fft.fft(np.fft.fftshift(r)))
+    return (series.T * np.sqrt(logamp_var)).real
+
+
+def temporal_pixel_shifts(M, dt, wind_vector, dx):
+    """fast.py:543-544 -> (L, 2, M)."""
+    dts = np.arange(1, M + 1) * dt
+    return dts * np.asarray(wind_vector)[..., np.newaxis] / dx
+
+
+def temporal_coords(interp_coords, N):
+    """fast.py:621-626: wrapped + sorted sample coordinates and the roll that undoes the sort."""
+    coord = interp_coords % N
+    coord = np.sort(coord, axis=-1)
+    diffs = np.abs(np.diff(coord, axis=-1))
+    shifts = diffs.argmax(-1)
+    shifts[np.isclose(diffs, 1).all(-1)] = 0
+    return coord, shifts
+
+
+def temporal_chunk_phases(scrns, coord, shifts, Np):
+    """fast.py:628-633: bilinear samples of each layer's screen at the shifted pupil grid, summed."""
+    L, _, M, _ = coord.shape
+    N = scrns.shape[-1]
+    interps = [RectBivariateSpline(np.arange(N), np.arange(N), s, kx=1, ky=1, s=0) for s in scrns]
+    phs = np.zeros((M, Np, Np))
+    for i in range(L):
+        for j in range(M):
+            p = interps[i](coord[i, 0, j], coord[i, 1, j])
+            phs[j] += np.roll(p, -shifts[i, :, j], axis=(0, 1))
+    return phs
+
+
+def monte_carlo_temporal(seed_or_rng, n_iter, n_chunks, per_layer, df, W, dx, logamp_var, tps, wind_vector, dt, N, Np,
+                         coherent=False, return_screens=False):
+    """Fast.run with TEMPORAL (fast.py:115-140, 607-637), FFTW-branch screens (double=False)."""
+    rng = seed_or_rng if isinstance(seed_or_rng, np.random.Generator) else np.random.default_rng(seed_or_rng)
+    M = n_iter // n_chunks
+    chi = draw_logamp_temporal(rng, n_iter, logamp_var, tps)
+    coeffs = draw_coefficients(rng, per_layer.shape)
+    scrns = screens_fftw(coeffs * np.sqrt(per_layer), df).real
+    lo = (N - Np) // 2
+    pup = np.arange(lo, lo + Np).astype(float)
+    shifts_px = temporal_pixel_shifts(M, dt, wind_vector, dx)
+    interp = np.stack([pup, pup])[None, :, None, :] + shifts_px[:, :, :, None]
+    out = np.zeros((n_chunks, M), dtype=complex if coherent else float)
+    for c in range(n_chunks):
+        coord, shifts = temporal_coords(interp, N)
+        phs = temporal_chunk_phases(scrns, coord, shifts, Np)
+        out[c] = detector(phs, W, dx, chi[c * M:(c + 1) * M], coherent)
+        interp = interp + shifts_px[:, :, -1, None, None]
+    if return_screens:
+        return out.flatten(), chi, scrns
+    return out.flatten()

@@ -106,3 +106,26 @@ def test_monte_carlo_matches_reference_same_seed(case):
                       float(g["logamp_var"]), coherent=p["COHERENT"], sub=sub)
     np.testing.assert_allclose(r, g["r"], rtol=1e-10)
     assert r.dtype == g["r"].dtype
+
+
+# ------------------------------------------------------------------ temporal (frozen-flow) mode
+@pytest.mark.parametrize("name", ["temporal_default", "temporal_small", "temporal_noao"])
+def test_temporal_mode_matches_reference(name):
+    g = load_golden(name)
+    p = params_from_json(g["params_json"])
+    N, Np, dx = int(g["Npxls"]), int(g["Npxls_pup"]), float(g["dx"])
+    grid = R.main_grid(N, dx)
+    L = len(g["h"])
+    ax, ay, fabs = R.temporal_freqs(L, N, p["NITER"], g["wind_speed"], g["wind_dir"], p["DT"], grid.df)
+    np.testing.assert_allclose(ax, g["fx_axis_t"], rtol=1e-14)
+    np.testing.assert_allclose(fabs, g["fabs_t"], rtol=1e-13, atol=1e-12)
+    spline = R.temporal_pupil_filter(ax, ay, grid.df, p["D_GROUND"], p["OBSC_GROUND"], float(g["W0"]), Np, dx)
+    tps = R.temporal_logamp_spectrum(ax, ay, fabs, g["h"], g["cn2"], p["WVL"], spline, p["L0"], p["l0"], grid.df)
+    np.testing.assert_allclose(tps, g["temporal_logamp_powerspec"], rtol=1e-9, atol=1e-30)
+    np.testing.assert_allclose(R.temporal_pixel_shifts(p["NITER"] // p["NCHUNKS"], p["DT"], g["wind_vector"], dx),
+                               g["pixel_shifts"], rtol=1e-14)
+    W = g["pupil"] * g["pupil_mode"]
+    r = R.monte_carlo_temporal(p["SEED"], p["NITER"], p["NCHUNKS"], g["powerspec_per_layer"], grid.df, W, dx,
+                               float(g["logamp_var"]), g["temporal_logamp_powerspec"], g["wind_vector"], p["DT"], N, Np,
+                               coherent=p["COHERENT"])
+    np.testing.assert_allclose(r, g["r"], rtol=1e-9)

@@ -239,6 +239,32 @@ def e2e():
         capture_sim("e2e_" + name, base_params(**over), note)
 
 
+def temporal():
+    """TEMPORAL (frozen-flow) fixtures: the shipped test_params.py geometry and a small one."""
+    def cap(name, p, note):
+        sim = fast.Fast(p)
+        res = sim.run()
+        d = {"params_json": np.array(params_to_json(p))}
+        for k in ("dx", "Npxls", "Npxls_pup", "logamp_var", "diffraction_limit", "W0"):
+            d[k] = np.array(getattr(sim, k))
+        d.update(h=sim.h, cn2=sim.cn2, wind_vector=sim.wind_vector, wind_speed=sim.wind_speed,
+                 wind_dir=np.asarray(sim.wind_dir, dtype=float), pupil=sim.pupil, pupil_mode=sim.pupil_mode,
+                 powerspec_per_layer=sim.powerspec_per_layer, temporal_logamp_powerspec=sim.temporal_logamp_powerspec,
+                 pixel_shifts=sim.pixel_shifts, logamp=sim.logamp.copy(), r=res._r, phs_last_chunk=sim.phs.copy(),
+                 fx_axis_t=sim.freq.temporal.fx_axis, fy_axis_t=sim.freq.temporal.fy_axis, fabs_t=sim.freq.temporal.fabs)
+        save(name, note, True, **d)
+    h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
+    p = dict(fast.conf.DEFAULTS)
+    p.update({"NPXLS": "auto", "DX": 0.01, "NITER": 100, "NCHUNKS": 10, "TEMPORAL": True, "FFTW": True, "SEED": 1,
+              "DT": 0.001, "W0": "opt", "D_GROUND": 0.8, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w,
+              "WIND_DIR": [0, 90, 180, 270], "ZENITH_ANGLE": 55, "DSUBAP": 0.1, "LOGLEVEL": "ERROR", "H_SAT": 36e6})
+    cap("temporal_default", p, "test/test_params.py as shipped (TEMPORAL True) with FFTW True, SEED 1")
+    cap("temporal_small", base_params(TEMPORAL=True, NITER=24, NCHUNKS=4, DT=0.004, NPXLS=64),
+        "small TEMPORAL config: N=64, 24 steps of 4 ms, wrap-around of the sample coordinates")
+    cap("temporal_noao", base_params(TEMPORAL=True, NITER=12, NCHUNKS=3, DT=0.01, NPXLS=48, AO_MODE="NOAO", L0=20.0, COHERENT=True),
+        "TEMPORAL + NOAO + COHERENT, N=48")
+
+
 def default_cfg():
     h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
     p = dict(fast.conf.DEFAULTS)
@@ -268,10 +294,16 @@ def big(p):
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("capturing into", OUT)
+    if "--only-temporal" in sys.argv:      # add / refresh one family; MANIFEST lines are appended by hand
+        temporal()
+        for name, size, st, note in MANIFEST:
+            print(f"| {name}.npz | {size} | {st} | {note} |")
+        return
     kat_fft()
     kat_detector()
     kat_small()
     e2e()
+    temporal()
     p = default_cfg()
     if "--no-big" not in sys.argv:
         big(p)

@@ -19,11 +19,11 @@ def circle(radius, size, circle_centre=(0, 0), origin="middle"):
 
 def gaussian2d(size, width, amplitude=1.0, cent=None):
     try:
-        xs, ys = size[0], size[1]
+        ys, xs = size[0], size[1]          # (rows, columns): the image has shape `size`
     except (TypeError, IndexError):
         xs = ys = size
     try:
-        xw, yw = float(width[0]), float(width[1])
+        yw, xw = float(width[0]), float(width[1])
     except (TypeError, IndexError):
         xw = yw = float(width)
     if not cent:

@@ -18,6 +18,7 @@ EXPORTS = [
     "fastmc_set_spectrum", "fastmc_set_pupil", "fastmc_set_subharm", "fastmc_run", "fastmc_run_coeffs",
     "fastmc_screens_coeffs", "fastmc_screens", "fastmc_rng_coeffs", "fastmc_rng_logamp", "fastmc_histogram",
     "fastmc_last_timing", "fastmc_kernel_path", "fastmc_set_batch", "fastmc_powerspec",
+    "fastmc_set_layer_screens", "fastmc_temporal_chunk",
     "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_gather", "fastmc_comm_destroy",
 ]
 
@@ -65,6 +66,8 @@ def lib():
     L.fastmc_screens.argtypes = [vp, u64, i64, i64, dp]
     L.fastmc_rng_coeffs.argtypes = [vp, u64, i64, dp]
     L.fastmc_rng_logamp.argtypes = [vp, u64, i64, i64, dp]
+    L.fastmc_set_layer_screens.argtypes = [vp, dp, C.c_int]
+    L.fastmc_temporal_chunk.argtypes = [vp, dp, dp, C.POINTER(C.c_int32), C.c_int, dp, C.c_int, dp]
     L.fastmc_histogram.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.POINTER(i64)]
     L.fastmc_last_timing.argtypes = [vp, dp, C.POINTER(i64)]
     L.fastmc_kernel_path.argtypes = [vp, C.c_int]
@@ -187,6 +190,22 @@ class Handle:
         out = np.empty(n_iter, dtype=np.float64)
         _chk(lib().fastmc_rng_logamp(self._h, int(seed) & (2 ** 64 - 1), int(iter0), int(n_iter), _dptr(out)))
         return out
+
+    def set_layer_screens(self, screens):
+        sc = _f64(screens)
+        assert sc.ndim == 3 and sc.shape[1:] == (self.N, self.N)
+        _chk(lib().fastmc_set_layer_screens(self._h, _dptr(sc), sc.shape[0]))
+        self._n_layers = sc.shape[0]
+
+    def temporal_chunk(self, xs, ys, roll, logamp, coherent=False):
+        xs, ys, la = _f64(xs), _f64(ys), _f64(logamp)
+        roll = np.ascontiguousarray(roll, dtype=np.int32)
+        L, M, Np = xs.shape
+        assert ys.shape == xs.shape and Np == self.Np and roll.shape == (L, 2, M) and la.shape == (M,)
+        out = np.empty(M * (2 if coherent else 1))
+        _chk(lib().fastmc_temporal_chunk(self._h, _dptr(xs), _dptr(ys), roll.ctypes.data_as(C.POINTER(C.c_int32)), M,
+                                         _dptr(la), int(bool(coherent)), _dptr(out)))
+        return out.view(np.complex128) if coherent else out
 
     def histogram(self, lo_db, hi_db, nbins):
         bins = np.zeros(nbins + 2, dtype=np.int64)

@@ -77,6 +77,8 @@ struct fastmc_ctx {
   double* sh_in_re = nullptr;  // host-mode coefficients [batch][27]
   double* sh_in_im = nullptr;
   size_t sh_cap = 0;
+  double* layers = nullptr;    // [n_layers][N][N] real layer screens (TEMPORAL mode)
+  int n_layers = 0;
   unsigned long long* hist = nullptr;
   size_t hist_cap = 0;
   // timing
@@ -219,7 +221,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->amp, h->amp_s, h->tw, h->tw1, h->om, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_in_re,
-                  h->sh_in_im, h->hist, h->gather_buf};
+                  h->sh_in_im, h->hist, h->gather_buf, h->layers};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (auto e : h->pool) hipEventDestroy(e);
@@ -650,6 +652,47 @@ extern "C" int fastmc_rng_logamp(fastmc_t* h, uint64_t seed, int64_t iter0, int6
                      n_iter, d.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, d.p, (size_t)n_iter * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int fastmc_set_layer_screens(fastmc_t* h, const double* screens, int n_layers) {
+  if (!h || !screens || n_layers < 1 || n_layers > 1024) return fail(FASTMC_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t n = (size_t)n_layers * h->N * h->N;
+  if (h->layers) { HIPCHK(hipFree(h->layers)); h->layers = nullptr; h->n_layers = 0; }
+  HIPCHK(hipMalloc((void**)&h->layers, n * 8));
+  HIPCHK(hipMemcpy(h->layers, screens, n * 8, hipMemcpyHostToDevice));
+  h->n_layers = n_layers;
+  return 0;
+}
+
+extern "C" int fastmc_temporal_chunk(fastmc_t* h, const double* xs, const double* ys, const int32_t* roll, int M,
+                                     const double* logamp, int coherent, double* out) {
+  if (!h || !xs || !ys || !roll || !logamp || !out || M < 1) return fail(FASTMC_EINVAL, "bad argument");
+  if (!h->have_pupil) return fail(FASTMC_ESTATE, "set_pupil must be called first");
+  if (!h->layers) return fail(FASTMC_ESTATE, "set_layer_screens must be called first");
+  if (h->N < 2) return fail(FASTMC_EINVAL, "N must be at least 2");
+  HIPCHK(hipSetDevice(h->device));
+  const int L = h->n_layers, Np = h->Np;
+  const size_t nc = (size_t)L * M * Np;
+  ScratchBuf dxs, dys, dla, dout, droll;
+  HIPCHK(hipMalloc((void**)&dxs.p, nc * 8));
+  HIPCHK(hipMalloc((void**)&dys.p, nc * 8));
+  HIPCHK(hipMalloc((void**)&dla.p, (size_t)M * 8));
+  HIPCHK(hipMalloc((void**)&dout.p, (size_t)M * 16));
+  HIPCHK(hipMalloc((void**)&droll.p, (size_t)L * 2 * M * 4 + 8));
+  HIPCHK(hipMemcpyAsync(dxs.p, xs, nc * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dys.p, ys, nc * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dla.p, logamp, (size_t)M * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(droll.p, roll, (size_t)L * 2 * M * 4, hipMemcpyHostToDevice, h->stream));
+  TemporalArgs A;
+  A.N = h->N; A.Np = Np; A.L = L; A.M = M; A.coherent = coherent;
+  A.screens = h->layers; A.xs = dxs.p; A.ys = dys.p; A.roll = (const int*)droll.p; A.W = h->W; A.logamp = dla.p;
+  A.dx2 = h->dx * h->dx; A.norm = h->wsum * (h->dx * h->dx); A.out = dout.p;
+  hipLaunchKernelGGL(k_temporal_detect, dim3(M), dim3(256), 0, h->stream, A);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)M * 8 * (coherent ? 2 : 1), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }

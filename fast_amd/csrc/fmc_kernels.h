@@ -469,6 +469,70 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs A) {
   else A.out[o] = ar * ar + ai * ai;
 }
 
+// ================================================================== frozen-flow time series
+// Fast.compute_phs_temporal (fast/fast.py:619-633) + compute_detector (647-668) for one chunk of M
+// time steps: every layer's N x N screen is sampled bilinearly (RectBivariateSpline kx=ky=1: FITPACK
+// clamps arguments to the knot range [0, N-1]) on the wind-shifted, wrapped and sorted pupil grid,
+// rolled back (numpy.roll by -shift), summed over layers, then W exp(i phi) is reduced.
+struct TemporalArgs {
+  int N, Np, L, M, coherent;
+  const double* screens;   // [L][N][N]
+  const double* xs;        // [L][M][Np] sorted row coordinates
+  const double* ys;        // [L][M][Np] sorted column coordinates
+  const int* roll;         // [L][2][M]
+  const double* W;         // [Np][Np]
+  const double* logamp;    // [M]
+  double dx2, norm;
+  double* out;             // [M] or [M][2]
+};
+
+__device__ __forceinline__ void bilinear_cell(double x, int N, int& i, double& t) {
+  if (x < 0.0) x = 0.0;
+  if (x > (double)(N - 1)) x = (double)(N - 1);
+  i = (int)floor(x);
+  if (i > N - 2) i = N - 2;
+  t = x - (double)i;
+}
+
+__global__ __launch_bounds__(256) void k_temporal_detect(TemporalArgs A) {
+  __shared__ double s_red[2][4];
+  const int j = blockIdx.x;
+  const int Np = A.Np, N = A.N;
+  double sr = 0.0, si = 0.0;
+  for (int pix = threadIdx.x; pix < Np * Np; pix += blockDim.x) {
+    const int a = pix / Np, b = pix % Np;
+    double phi = 0.0;
+    for (int l = 0; l < A.L; ++l) {
+      const int ra = (a + A.roll[(l * 2 + 0) * A.M + j]) % Np;
+      const int rb = (b + A.roll[(l * 2 + 1) * A.M + j]) % Np;
+      int i0, j0;
+      double t, u;
+      bilinear_cell(A.xs[((size_t)l * A.M + j) * Np + ra], N, i0, t);
+      bilinear_cell(A.ys[((size_t)l * A.M + j) * Np + rb], N, j0, u);
+      const double* z = A.screens + (size_t)l * N * N + (size_t)i0 * N + j0;
+      phi += (1 - t) * ((1 - u) * z[0] + u * z[1]) + t * ((1 - u) * z[N] + u * z[N + 1]);
+    }
+    double s, c;
+    sincos(phi, &s, &c);
+    const double w = A.W[pix];
+    sr += w * c;
+    si += w * s;
+  }
+  sr = wave_sum(sr);
+  si = wave_sum(si);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { s_red[0][wv] = sr; s_red[1][wv] = si; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tr = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    const double ti = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    const double e = exp(A.logamp[j]);
+    const double ar = (e * (tr * A.dx2)) / A.norm, ai = (e * (ti * A.dx2)) / A.norm;
+    if (A.coherent) { A.out[2 * j] = ar; A.out[2 * j + 1] = ai; }
+    else A.out[j] = ar * ar + ai * ai;
+  }
+}
+
 // ================================================================== histogram of dB_rel
 __global__ void k_histogram(const double* out, int64_t n, int coherent, double lo, double hi, int nbins,
                             unsigned long long* bins) {

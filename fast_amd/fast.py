@@ -12,7 +12,9 @@ Differences from the reference, all deliberate:
     the number of GPUs; 'host' draws them with numpy in the reference's order, so the same
     SEED reproduces the reference's `result._r` to ~1e-10 (parity mode, PCIe-bound);
   * `GPU_PRECISION`: 'f64' (default, complex128 like the reference) or 'f32';
-  * `TEMPORAL` (frozen-flow time series, fast.py:607-637) is outside this path: NotImplementedError;
+  * `TEMPORAL` (frozen-flow time series, fast.py:607-637): the layer screens, the bilinear shifts and
+    the detector run on the GPU; its draws are always numpy's, in the reference's order (the
+    series is sequential and tiny), so the same SEED reproduces the reference;
   * `FFTW` / `FFTW_THREADS` are accepted and ignored (they select a CPU FFT in the reference).
 """
 import logging
@@ -44,9 +46,6 @@ class Fast():
 
         prob = host.build_problem(p)          # raises the reference's config Exceptions
         self._prob = prob
-        if self.temporal:
-            raise NotImplementedError("TEMPORAL=True (frozen-flow time series) is not part of the GPU Monte-Carlo "
-                                      "path; set TEMPORAL=False")
         self.Niter_per_chunk = prob.M
         atm, pup = prob.atm, prob.pup
         # attributes of the reference object (fast.py:49-64 and the init_* methods)
@@ -118,7 +117,9 @@ class Fast():
         else:
             self.powerspec_subharm = None
         self.temporal_powerspec = None
-        self.temporal_logamp_powerspec = None
+        self.temporal_logamp_powerspec = prob.temporal.logamp_powerspec if self.temporal else None
+        if self.temporal:
+            self.pixel_shifts = prob.temporal.pixel_shifts
 
     # ------------------------------------------------------------------ Monte Carlo
     def run(self):
@@ -126,7 +127,9 @@ class Fast():
         M, half = self.Niter_per_chunk, self.Niter_per_chunk // 2
         coherent = bool(self.params['COHERENT'])
         I = numpy.zeros((self.Nchunks, M), dtype=complex if coherent else float)
-        if self.rng_mode == 'host':
+        if self.temporal:
+            self._run_temporal(I, coherent)
+        elif self.rng_mode == 'host':
             self._run_host_rng(I, coherent)
         else:
             seed = self.seed if self.seed is not None else int(numpy.random.SeedSequence().generate_state(2, numpy.uint32).view(numpy.uint64)[0])
@@ -176,6 +179,34 @@ class Fast():
                 sr = _R.normal(0, 1, size=(half, 3, 3, 3))
                 si = _R.normal(0, 1, size=(half, 3, 3, 3))
             I[i] = self._handle.run_coeffs(cr, ci, self.logamp[i * M:(i + 1) * M], coherent, sr, si)
+
+    def _run_temporal(self, I, coherent):
+        """Frozen-flow series (fast.py:607-637; funcs.py:367-375): numpy draws in the reference's
+        order; screens, bilinear shifts and detector on the GPU."""
+        N, Np, M, prob = self.Npxls, self.Npxls_pup, self.Niter_per_chunk, self._prob
+        tps = self.temporal_logamp_powerspec
+        r = _R.normal(0, 1, size=(self.Niter,)) + 1j * _R.normal(0, 1, size=(self.Niter,))
+        r *= numpy.sqrt(tps / tps.sum())
+        series = numpy.fft.fftshift(numpy.fft.fft(numpy.fft.fftshift(r)))
+        self.logamp[:] = (series.T * numpy.sqrt(self.logamp_var)).real
+        # chunk 0: one real screen per layer from (L, N, N) coefficients (double=False)
+        L = self.powerspec_per_layer.shape[0]
+        cr = _R.normal(0, 1, size=(L, N, N))
+        ci = _R.normal(0, 1, size=(L, N, N))
+        full = _lib.Handle(N, N, self.precision, self.device)
+        full.set_pupil(numpy.ones((N, N)), 0, self.dx)
+        scrns = numpy.empty((L, N, N))
+        for l in range(L):
+            full.set_spectrum(self.powerspec_per_layer[l], prob.df)
+            scrns[l] = full.screens_coeffs(cr[l:l + 1], ci[l:l + 1])[0]
+        full.close()
+        self._handle.set_layer_screens(scrns)
+        pup = prob.pup.pup_coords.astype(float)
+        interp = pup[numpy.newaxis, :, numpy.newaxis, :] + self.pixel_shifts[:, :, :, numpy.newaxis]
+        for i in range(self.Nchunks):
+            coord, shifts = host.temporal_coords(interp, N)
+            I[i] = self._handle.temporal_chunk(coord[:, 0], coord[:, 1], shifts, self.logamp[i * M:(i + 1) * M], coherent)
+            interp = interp + self.pixel_shifts[:, :, -1, numpy.newaxis, numpy.newaxis]
 
     def _transport(self):
         """The result exchange of a multi-process run, or None.  GPU_SHARD: 'auto' (default) shards

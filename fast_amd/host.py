@@ -234,6 +234,66 @@ def pupils(p, N, Np, dx):
     return o
 
 
+# ----------------------------------------------------------------------------- temporal (frozen-flow) mode
+def aperture_rect(N, dx, D, obsc, Ny):
+    """compute_pupil with Ny != N: columns zero-padded or cropped (funcs.py:265-273)."""
+    ap = hm.circle(D / dx / 2, N) - hm.circle(obsc / dx / 2, N)
+    if Ny > N:
+        pad = (Ny - N) // 2
+        ap = np.pad(ap, [(0, 0), (pad, pad)])
+    if Ny < N:
+        cut = (N - Ny) // 2
+        ap = ap[:, cut:-cut]
+    return ap / np.sqrt(ap.sum() * dx ** 2)
+
+
+def temporal_setup(prob):
+    """Everything TEMPORAL adds to the init (fast.py:217-219, 394-405, 538-587): per-layer temporal
+    frequency grids, the high-resolution pupil-filter spline, the temporal log-amplitude spectrum
+    and the per-step pixel shifts.  O(L * N * NITER) numpy work, once per object."""
+    from scipy.interpolate import RectBivariateSpline
+    p, atm = prob.params, prob.atm
+    t = SimpleNamespace()
+    L, Ny, Nx, dt = len(atm.h), prob.N, prob.Niter, p['DT']
+    ax, ay, fabs = [], [], []
+    for i in range(L):                                                    # fast.py:851-864
+        fx_axis = np.arange(-Nx / 2, Nx / 2) * (1 / (Nx * atm.wind_speed[i] * dt))   # linear frequency (sic)
+        fy_axis = np.arange(-Ny / 2, Ny / 2) * prob.df
+        fx, fy = np.meshgrid(fx_axis, fy_axis)
+        rot = np.radians(atm.wind_dir[i])
+        fabs.append(np.sqrt((fx * np.cos(rot) - fy * np.sin(rot)) ** 2 + (fx * np.sin(rot) + fy * np.cos(rot)) ** 2))
+        ax.append(fx_axis)
+        ay.append(fy_axis)
+    ax, ay, fabs = np.array(ax), np.array(ay), np.array(fabs)
+    # pupil filter fine enough for those frequencies, as a bilinear spline (fast.py:396-405)
+    dx_req = np.pi / max(ax.max(), ay.max())
+    N_req = int(2 * np.ceil(2 * np.pi / (prob.df * dx_req) / 2))
+    Nyp = 2 * prob.Np
+    pupil_t = aperture_rect(N_req, dx_req, p['D_GROUND'], p['OBSC_GROUND'], Nyp)
+    mode_t, _ = fibre_mode(pupil_t, dx_req, W0=prob.pup.W0, ptype="gauss")
+    P = pupil_filter(pupil_t * mode_t)
+    fxa = np.arange(-N_req / 2., N_req / 2.) * (TWO_PI / (N_req * dx_req))
+    fya = np.arange(-Nyp / 2., Nyp / 2.) * (TWO_PI / (Nyp * prob.dx))
+    spline = RectBivariateSpline(fxa, fya, P, kx=1, ky=1, s=0)
+    # temporal log-amplitude spectrum (ao_power_spectra.py:272-301 on the per-layer grids; fast.py:582-587)
+    turb = np.stack([_von_karman(fabs[i], [atm.cn2[i]], p['L0'], p['l0'])[0] for i in range(L)])
+    ps = turb * TWO_PI * (TWO_PI / prob.wvl) ** 2
+    ps = ps * np.sin(prob.wvl * atm.h[:, None, None] * fabs ** 2 / (4 * np.pi)) ** 2
+    ps = ps * np.stack([spline(ay[i], ax[i]) for i in range(L)])
+    t.logamp_powerspec = ps.sum(0).sum(-2) * prob.df
+    t.pixel_shifts = (np.arange(1, prob.M + 1) * dt) * atm.wind_vector[..., np.newaxis] / prob.dx   # fast.py:543-544
+    return t
+
+
+def temporal_coords(interp_coords, N):
+    """Wrapped + sorted sample coordinates and the roll that undoes the sort (fast.py:621-626)."""
+    coord = np.sort(interp_coords % N, axis=-1)
+    diffs = np.abs(np.diff(coord, axis=-1))
+    shifts = diffs.argmax(-1)
+    shifts[np.isclose(diffs, 1).all(-1)] = 0
+    return coord, shifts
+
+
 # ----------------------------------------------------------------------------- link budget
 def link_budget(p, pup, atm, dx):
     """Fast.compute_link_budget (fast.py:670-734) -> (dict, diffraction_limit [W])."""
@@ -363,4 +423,5 @@ def build_problem(params):
     prob.W = prob.pup.pupil * prob.pup.pupil_mode
     prob.link_budget, prob.diffraction_limit = link_budget(p, prob.pup, prob.atm, prob.dx)
     prob.simpson_w = hm.simpson_weights(prob.axis)
+    prob.temporal = temporal_setup(prob) if p['TEMPORAL'] else None
     return prob

@@ -101,6 +101,16 @@ int fastmc_screens(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real, do
 int fastmc_rng_coeffs(fastmc_t* h, uint64_t seed, int64_t real, double* coeff_interleaved);
 int fastmc_rng_logamp(fastmc_t* h, uint64_t seed, int64_t iter0, int64_t n_iter, double* normals);
 
+/* Frozen-flow time series (TEMPORAL mode; Fast.compute_phs_temporal fast/fast.py:607-637 +
+ * compute_detector 647-668).  set_layer_screens keeps the L real N x N layer screens on the
+ * device (the reference builds them once, in chunk 0, fast.py:609-615).  temporal_chunk evaluates
+ * one chunk of M time steps: xs, ys are the wrapped, sorted sample coordinates (L, M, Np)
+ * (fast.py:621-622), roll the numpy.roll amounts (L, 2, M) (fast.py:624-626), logamp the M
+ * log-amplitudes of the chunk; out: M float64 (or M complex128 when coherent). */
+int fastmc_set_layer_screens(fastmc_t* h, const double* screens, int n_layers);
+int fastmc_temporal_chunk(fastmc_t* h, const double* xs, const double* ys, const int32_t* roll, int M,
+                          const double* logamp, int coherent, double* out);
+
 /* Fixed-bin histogram of 10*log10(power) of the last run's results kept on the device
  * (FastResult.dB_rel, fast/fast.py:949-951): bins[k] counts lo + k*(hi-lo)/nbins <= x <
  * ..., bins[nbins] = underflow, bins[nbins+1] = overflow.  bins: nbins+2 int64. */

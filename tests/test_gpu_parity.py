@@ -340,8 +340,6 @@ def test_errors_are_reported_not_fatal():
         h.set_spectrum(-np.ones((64, 64)), 1.0)
     with pytest.raises(Exception, match="NCHUNKS must divide"):
         fast_amd.Fast({"NITER": 10, "NCHUNKS": 3, "LOGLEVEL": "ERROR"})
-    with pytest.raises(NotImplementedError):
-        fast_amd.Fast({"NITER": 4, "NCHUNKS": 1, "TEMPORAL": True, "NPXLS": 64, "DX": 0.01, "D_GROUND": 0.2, "LOGLEVEL": "ERROR"})
 
 
 def test_rccl_exchange_world_of_one():
@@ -418,3 +416,18 @@ def test_many_realisations_cross_finalize_span():
     np.testing.assert_array_equal(full, np.r_[a[:20000], b[:13000], a[20000:], b[13000:]])
     one = h.run(3, 32999, 1, None, 0.01)
     np.testing.assert_array_equal(one, [full[32999], full[n + 32999]])
+
+
+@pytest.mark.parametrize("name", ["temporal_default", "temporal_small", "temporal_noao"])
+def test_temporal_mode_reproduces_reference(name):
+    """TEMPORAL (frozen-flow) runs, incl. the reference's shipped test_params.py: same SEED -> same series."""
+    g = load_golden(name)
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_DEVICE": 0})
+    sim = fast_amd.Fast(p)
+    np.testing.assert_allclose(sim.temporal_logamp_powerspec, g["temporal_logamp_powerspec"], rtol=1e-9, atol=1e-30)
+    np.testing.assert_allclose(sim.pixel_shifts, g["pixel_shifts"], rtol=1e-13)
+    res = sim.run()
+    assert res._r.dtype == g["r"].dtype
+    np.testing.assert_allclose(sim.logamp, g["logamp"], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(res._r, g["r"], rtol=1e-8)

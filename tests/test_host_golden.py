@@ -100,3 +100,12 @@ def test_fast_result_properties():
     np.testing.assert_allclose(res.scintillation_index, (r / r.mean()).var())
     np.testing.assert_allclose(res.avg_power_dB_rel, 10 * np.log10(r.mean()))
     assert "Scintillation index" in str(res)
+
+
+@pytest.mark.parametrize("name", ["temporal_default", "temporal_small", "temporal_noao"])
+def test_temporal_host_setup_matches_reference(name):
+    g = load_golden(name)
+    p = fast_amd.conf.ConfigParser(dict(params_from_json(g["params_json"]))).config
+    prob = host.build_problem(p)
+    np.testing.assert_allclose(prob.temporal.pixel_shifts, g["pixel_shifts"], rtol=1e-13)
+    np.testing.assert_allclose(prob.temporal.logamp_powerspec, g["temporal_logamp_powerspec"], rtol=1e-9, atol=1e-30)

@@ -4,5 +4,5 @@ A user of ojdf/fast keeps `fast.Fast(config).run()`, `fast.FastResult`, `fast.co
 `fast.turbulence_models`; everything outside that path (comms, orbit tools, FITS I/O) is not
 provided here -- see DESIGN.md section 6.
 """
-from fast_amd import Fast, FastResult, FastMCError, conf, turbulence_models  # noqa: F401
+from fast_amd import Fast, FastResult, FastMCError, load, conf, turbulence_models  # noqa: F401
 from fast_amd import __version__  # noqa: F401

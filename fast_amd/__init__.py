@@ -4,7 +4,7 @@ Public surface = the reference's for this path: `Fast`, `FastResult`, `conf`, `t
 Compute lives in libfastmc.so (hand-written HIP behind the C-ABI of include/fastmc.h),
 loaded with ctypes; there is no CPU fallback.
 """
-from .fast import Fast, FastResult
+from .fast import Fast, FastResult, load
 from . import conf
 from . import turbulence_models
 from . import host
@@ -12,4 +12,4 @@ from . import _lib
 from ._lib import FastMCError
 
 __version__ = "0.1.0"
-__all__ = ["Fast", "FastResult", "conf", "turbulence_models", "host", "FastMCError"]
+__all__ = ["Fast", "FastResult", "load", "conf", "turbulence_models", "host", "FastMCError"]

@@ -22,7 +22,7 @@ import os
 
 import numpy
 
-from . import _lib, conf, host
+from . import _lib, conf, fitsio, host
 
 logger = logging.getLogger(__name__)
 
@@ -233,8 +233,57 @@ class Fast():
         """Histogram of dB_rel of the last run, computed on the device."""
         return self._handle.histogram(lo_db, hi_db, nbins)
 
+    def compute_mean_irradiance(self, onaxis=True):
+        """Analytic (non Monte-Carlo) mean coupled flux, fast.py:736-761; host numpy, one-off."""
+        return host.mean_irradiance(self.powerspec, self._prob.W, self.dx, self._prob.df, self.diffraction_limit, onaxis)
+
+    def make_header(self, params):
+        """Result-file header cards (fast.py:771-807)."""
+        hdr = {}
+        hdr['ZENITH'] = params['ZENITH_ANGLE']
+        hdr['WVL'] = int(params['WVL'] * 1e9)
+        hdr['OTRSCALE'] = str(params['L0']) if numpy.isinf(params['L0']) else params['L0']
+        hdr['INRSCALE'] = params['l0']
+        hdr['POWER'] = params['POWER']
+        hdr['PAA'] = self.paa
+        hdr['AO_MODE'] = self.ao_mode
+        hdr['TLOOP'] = params['TLOOP']
+        hdr['TEXP'] = params['TEXP']
+        hdr['DSUBAP'] = params['DSUBAP']
+        hdr['ALIAS'] = str(params['ALIAS'])
+        hdr['NOISE'] = params['NOISE']
+        hdr['D_GND'] = params['D_GROUND']
+        hdr['OBSC_GND'] = params['OBSC_GROUND']
+        hdr['D_SAT'] = params['D_SAT']
+        hdr['OBSC_SAT'] = params['OBSC_SAT']
+        hdr['AXICON'] = str(params['AXICON'])
+        hdr['W0'] = self.W0
+        hdr['L_SAT'] = self.L
+        hdr['H_SAT'] = params['H_SAT']
+        hdr['DX'] = self.dx
+        hdr['NPXLS'] = self.Npxls
+        hdr['NITER'] = self.Niter
+        hdr['R0'] = self.r0
+        hdr['THETA0'] = self.theta0
+        hdr['TAU0'] = self.tau0
+        hdr["DIFFLIM"] = self.diffraction_limit
+        if self.seed != None:
+            hdr["SEED"] = self.seed
+        return hdr
+
+    def save(self, fname, **kwargs):
+        """Write `result.power` and the header as a FITS file (fast.py:809-812)."""
+        logger.info(f"Saving results to {fname}")
+        fitsio.writeto(fname, self.result.power, header=self.make_header(self.params), **kwargs)
+
     def calc_zenith_correction(self, zenith_angle):
         return 1 / numpy.cos(numpy.radians(zenith_angle))
+
+
+def load(fname):
+    """Result file -> FastResult (fast.py:998-1002; data are stored in watts)."""
+    hdr, data = fitsio.read(fname)
+    return FastResult(data / hdr['DIFFLIM'], hdr['DIFFLIM'], header=hdr)
 
 
 class FastResult():

@@ -234,6 +234,27 @@ def pupils(p, N, Np, dx):
     return o
 
 
+# ----------------------------------------------------------------------------- analytic mean irradiance
+def ift2(G, delta_f):
+    """Centred inverse 2-D DFT scaled by (N delta_f)^2 (aotools.fouriertransform.ift2, 2-D input)."""
+    N = G.shape[0]
+    return np.fft.ifftshift(np.fft.ifft2(np.fft.ifftshift(G))) * (N * delta_f) ** 2
+
+
+def mean_irradiance(powerspec, W, dx, df, diffraction_limit, onaxis=True):
+    """Fast.compute_mean_irradiance (fast.py:736-761): mean coupled flux from the optical transfer
+    functions, no Monte Carlo.  Three N x N FFTs, once; host-side (not part of the GPU hot path)."""
+    pupil = np.zeros(powerspec.shape)
+    pupil[:W.shape[0], :W.shape[1]] = W
+    phs_otf = ift2(powerspec, df)
+    phs_sf = phs_otf[phs_otf.shape[0] // 2, phs_otf.shape[1] // 2] - phs_otf
+    pupil_ft = hm.ft2(pupil, dx)
+    pupil_otf = ift2(np.abs(pupil_ft) ** 2, df) / (2 * np.pi) ** 2
+    otf = np.exp(-phs_sf) * pupil_otf
+    psf = otf.sum().real * dx ** 2 if onaxis else hm.ft2(otf, dx).real
+    return psf * (diffraction_limit / (pupil.sum() * dx ** 2) ** 2)
+
+
 # ----------------------------------------------------------------------------- temporal (frozen-flow) mode
 def aperture_rect(N, dx, D, obsc, Ny):
     """compute_pupil with Ny != N: columns zero-padded or cropped (funcs.py:265-273)."""

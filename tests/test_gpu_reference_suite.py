@@ -69,3 +69,22 @@ def test_sim_coherent():
     sim = fast.Fast(p)
     sim.run()
     assert sim.I.dtype == complex
+
+
+def test_sim_mean_irradiance():
+    sim = fast.Fast(example_params())
+    psf = sim.compute_mean_irradiance()
+    assert numpy.isfinite(psf.all())
+
+
+def test_save_and_load(tmp_path):
+    p = example_params()
+    p.update({'TEMPORAL': False, 'SEED': 4})
+    sim = fast.Fast(p)
+    sim.run()
+    f = str(tmp_path / "out.fits")
+    sim.save(f)
+    res = fast.load(f)
+    numpy.testing.assert_allclose(res.power, sim.result.power, rtol=1e-15)
+    numpy.testing.assert_allclose(res.dB_rel, sim.result.dB_rel, rtol=1e-12)
+    assert res.hdr['NPXLS'] == 164 and res.hdr['AO_MODE'] == 'AO' and res.hdr['SEED'] == 4

@@ -109,3 +109,35 @@ def test_temporal_host_setup_matches_reference(name):
     prob = host.build_problem(p)
     np.testing.assert_allclose(prob.temporal.pixel_shifts, g["pixel_shifts"], rtol=1e-13)
     np.testing.assert_allclose(prob.temporal.logamp_powerspec, g["temporal_logamp_powerspec"], rtol=1e-9, atol=1e-30)
+
+
+def test_mean_irradiance_matches_reference():
+    g = load_golden("mean_irradiance")
+    on = host.mean_irradiance(g["powerspec"], g["W"], float(g["dx"]), float(g["df"]), float(g["diffraction_limit"]))
+    np.testing.assert_allclose(on, g["onaxis"], rtol=1e-10)
+    off = host.mean_irradiance(g["powerspec"], g["W"], float(g["dx"]), float(g["df"]), float(g["diffraction_limit"]), onaxis=False)
+    np.testing.assert_allclose(off, g["offaxis"], rtol=1e-9, atol=1e-12 * np.abs(g["offaxis"]).max())
+    on2 = host.mean_irradiance(g["powerspec2"], g["W2"], float(g["dx2"]), float(g["df2"]), float(g["diffraction_limit2"]))
+    np.testing.assert_allclose(on2, g["onaxis2"], rtol=1e-10)
+
+
+def test_fits_round_trip(tmp_path):
+    from fast_amd import fitsio
+    data = np.random.default_rng(0).random(37) * 1e-6
+    hdr = {"ZENITH": 55, "WVL": 1550, "OTRSCALE": "inf", "INRSCALE": 1e-6, "AO_MODE": "AO", "ALIAS": "True",
+           "W0": 0.3567852394658434, "DIFFLIM": 3.111218108226167e-06, "NITER": 100, "SEED": 1}
+    f = str(tmp_path / "r.fits")
+    fitsio.writeto(f, data, header=hdr)
+    assert len(open(f, "rb").read()) % 2880 == 0
+    h2, d2 = fitsio.read(f)
+    assert np.array_equal(d2, data)
+    for k, v in hdr.items():
+        assert h2[k] == v, k
+    assert h2["BITPIX"] == -64 and h2["NAXIS1"] == 37
+    with pytest.raises(OSError):
+        fitsio.writeto(f, data, header=hdr)
+    fitsio.writeto(f, data[:5], header=hdr, overwrite=True)
+    res = fast_amd.load(f)
+    np.testing.assert_allclose(res.power, data[:5], rtol=1e-15)
+    np.testing.assert_allclose(res._r, data[:5] / hdr["DIFFLIM"], rtol=1e-15)
+    assert res.hdr["SEED"] == 1

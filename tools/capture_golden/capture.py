@@ -265,6 +265,17 @@ def temporal():
         "TEMPORAL + NOAO + COHERENT, N=48")
 
 
+def mean_irradiance():
+    sim = fast.Fast(base_params())
+    sim2 = fast.Fast(base_params(AO_MODE="NOAO", L0=30.0, NPXLS=48))
+    save("mean_irradiance", "Fast.compute_mean_irradiance on- and off-axis (aotools ft2/ift2 stand-ins)", True,
+         powerspec=sim.powerspec, W=sim.pupil * sim.pupil_mode, dx=sim.dx, df=sim.freq.df,
+         diffraction_limit=sim.diffraction_limit, onaxis=sim.compute_mean_irradiance(),
+         offaxis=sim.compute_mean_irradiance(onaxis=False),
+         powerspec2=sim2.powerspec, W2=sim2.pupil * sim2.pupil_mode, dx2=sim2.dx, df2=sim2.freq.df,
+         diffraction_limit2=sim2.diffraction_limit, onaxis2=sim2.compute_mean_irradiance())
+
+
 def default_cfg():
     h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
     p = dict(fast.conf.DEFAULTS)
@@ -294,8 +305,9 @@ def big(p):
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("capturing into", OUT)
-    if "--only-temporal" in sys.argv:      # add / refresh one family; MANIFEST lines are appended by hand
-        temporal()
+    if "--only-temporal" in sys.argv or "--only-mean-irradiance" in sys.argv:
+        # add / refresh one family; MANIFEST lines are appended by hand
+        temporal() if "--only-temporal" in sys.argv else mean_irradiance()
         for name, size, st, note in MANIFEST:
             print(f"| {name}.npz | {size} | {st} | {note} |")
         return
@@ -304,6 +316,7 @@ def main():
     kat_small()
     e2e()
     temporal()
+    mean_irradiance()
     p = default_cfg()
     if "--no-big" not in sys.argv:
         big(p)

@@ -89,6 +89,33 @@ def cpu_baseline(sim, seconds_target=12.0):
     return out
 
 
+def extras(args, device):
+    """Short side measurements printed next to the headline (never part of `value`): the float32
+    pipeline on the same job and BASELINE configs[2] (AO-corrected residual spectrum, float64),
+    with the time of the GPU power-spectrum evaluation that config adds to every `Fast()`."""
+    import copy
+    import fast_amd
+    out = {}
+    for tag, over in (("f32_same_job", {"GPU_PRECISION": "f32"}), ("config2_AO_alias_f64", {"AO_MODE": "AO", "ALIAS": True})):
+        a = copy.copy(args)
+        p = workload_params(a)
+        p.update(over)
+        p["GPU_DEVICE"] = device
+        t0 = time.perf_counter()
+        sim = fast_amd.Fast(p)
+        init_s = time.perf_counter() - t0
+        h = sim._handle
+        n_real = ITERS_PER_STEP // 2
+        h.run(1, 0, n_real, None, float(sim.logamp_var), False)
+        t0 = time.perf_counter()
+        for i in range(3):
+            h.run(1, (i + 1) * n_real, n_real, None, float(sim.logamp_var), False)
+        dt = time.perf_counter() - t0
+        out[tag] = {"iterations_per_s": 3 * ITERS_PER_STEP / dt, "init_s": init_s, "powerspec_kernel_ms": sim.powerspec_kernel_ms,
+                    "mean_dB_rel": float(10 * np.log10(np.mean(h.run(1, 0, 512, None, float(sim.logamp_var), False))))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,6 +125,7 @@ def main():
     ap.add_argument("--npxls", type=int, default=1024)
     ap.add_argument("--ao-mode", default="NOAO")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short f32 / AO-config side measurements")
     ap.add_argument("--batch", type=int, default=0, help="realisations per launch (0 = library default)")
     args = ap.parse_args()
 
@@ -223,6 +251,8 @@ def main():
                          "frac_whole_job": value / world * bytes_per_iter / 1e9 / HBM_PEAK_GBS,
                          "init_s": init_s, "powerspec_kernel_ms": sim.powerspec_kernel_ms},
         }
+        if world == 1 and not args.no_extras:
+            line["extras"] = extras(args, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sim)
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]

@@ -61,9 +61,17 @@ def noll_to_nm(j):
     return n, m
 
 
+_SIMPSON_CACHE = {}
+
+
 def simpson_weights(f):
     """Weights w with simpson(y, x=f) == w @ y for every y (scipy's rule is linear in y).
     Used so that the GPU evaluates funcs.integrate_powerspectrum (funcs.py:100-115) as a
-    weighted sum with exactly scipy's end-interval handling."""
+    weighted sum with exactly scipy's end-interval handling.  Cached per axis (sweeps)."""
     f = np.asarray(f, dtype=float)
-    return simpson(np.eye(len(f)), x=f, axis=-1)
+    key = (len(f), float(f[0]), float(f[-1]))
+    if key not in _SIMPSON_CACHE:
+        if len(_SIMPSON_CACHE) > 16:
+            _SIMPSON_CACHE.clear()
+        _SIMPSON_CACHE[key] = simpson(np.eye(len(f)), x=f, axis=-1)
+    return _SIMPSON_CACHE[key]

@@ -431,3 +431,35 @@ def test_temporal_mode_reproduces_reference(name):
     assert res._r.dtype == g["r"].dtype
     np.testing.assert_allclose(sim.logamp, g["logamp"], rtol=1e-9, atol=1e-300)
     np.testing.assert_allclose(res._r, g["r"], rtol=1e-8)
+
+
+def test_device_generator_statistical_quality():
+    """Moments, tails, uniformity of phase and independence across lanes / rows / realisations of the
+    device generator (Philox-seeded xoshiro128+ streams + hardware Box-Muller), 4 x 1024^2 draws."""
+    from scipy import stats
+    h = _lib.Handle(1024, 8, "f64", 0)
+    c = np.stack([h.rng_coeffs(2024, g) for g in range(4)])          # (4, 1024, 1024) complex
+    z = np.concatenate([c.real.ravel(), c.imag.ravel()])
+    n = z.size
+    assert abs(z.mean()) < 5 / np.sqrt(n)
+    assert abs(z.var() - 1) < 5 * np.sqrt(2 / n)
+    assert abs(stats.skew(z)) < 5 * np.sqrt(6 / n)
+    assert abs(stats.kurtosis(z)) < 5 * np.sqrt(24 / n)
+    # tails against the normal law: expected counts beyond 3, 4, 5 sigma
+    for k in (3.0, 4.0, 5.0):
+        expect = n * 2 * stats.norm.sf(k)
+        got = np.count_nonzero(np.abs(z) > k)
+        assert abs(got - expect) < 6 * np.sqrt(expect) + 3
+    # |c|^2 / 2 is Exp(1), the phase is uniform
+    assert stats.kstest((np.abs(c[0]) ** 2 / 2).ravel()[::7], "expon").pvalue > 1e-3
+    assert stats.kstest((np.angle(c[1]).ravel()[::7] + np.pi) / (2 * np.pi), "uniform").pvalue > 1e-3
+    # independence: neighbouring lanes, neighbouring stream positions (kx, kx+64), rows, realisations
+    def corr(a, b):
+        return abs(np.mean(a * b)) * np.sqrt(a.size)
+    re = c.real
+    assert corr(re[:, :, :-1], re[:, :, 1:]) < 5
+    assert corr(re[:, :, :-64], re[:, :, 64:]) < 5
+    assert corr(re[:, :-1, :], re[:, 1:, :]) < 5
+    assert corr(re[0], re[1]) < 5 and corr(re[0], c.imag[0]) < 5
+    # different seeds decorrelate
+    assert corr(re[0], h.rng_coeffs(2025, 0).real) < 5

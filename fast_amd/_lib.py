@@ -17,7 +17,7 @@ EXPORTS = [
     "fastmc_version", "fastmc_last_error", "fastmc_device_count", "fastmc_create", "fastmc_destroy",
     "fastmc_set_spectrum", "fastmc_set_pupil", "fastmc_set_subharm", "fastmc_run", "fastmc_run_coeffs",
     "fastmc_screens_coeffs", "fastmc_screens", "fastmc_rng_coeffs", "fastmc_rng_logamp", "fastmc_histogram",
-    "fastmc_last_timing", "fastmc_kernel_path", "fastmc_set_batch", "fastmc_powerspec",
+    "fastmc_result_stats", "fastmc_last_timing", "fastmc_kernel_path", "fastmc_set_batch", "fastmc_powerspec",
     "fastmc_set_layer_screens", "fastmc_temporal_chunk",
     "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_gather", "fastmc_comm_destroy",
 ]
@@ -69,6 +69,7 @@ def lib():
     L.fastmc_set_layer_screens.argtypes = [vp, dp, C.c_int]
     L.fastmc_temporal_chunk.argtypes = [vp, dp, dp, C.POINTER(C.c_int32), C.c_int, dp, C.c_int, dp]
     L.fastmc_histogram.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.POINTER(i64)]
+    L.fastmc_result_stats.argtypes = [vp, dp, C.c_int, dp]
     L.fastmc_last_timing.argtypes = [vp, dp, C.POINTER(i64)]
     L.fastmc_kernel_path.argtypes = [vp, C.c_int]
     L.fastmc_set_batch.argtypes = [vp, C.c_int]
@@ -211,6 +212,17 @@ class Handle:
         bins = np.zeros(nbins + 2, dtype=np.int64)
         _chk(lib().fastmc_histogram(self._h, float(lo_db), float(hi_db), int(nbins), bins.ctypes.data_as(C.POINTER(C.c_int64))))
         return bins
+
+    def result_stats(self, thresholds=()):
+        """Device-side statistics of the last run: dict(n, mean, scintillation_index, mean_dB_rel,
+        avg_dB_rel, min, max, fade_prob[...]) -- FastResult's summaries without the vector."""
+        thr = _f64(np.asarray(thresholds, dtype=float).ravel())
+        st = np.zeros(6 + len(thr))
+        _chk(lib().fastmc_result_stats(self._h, _dptr(thr) if len(thr) else None, len(thr), _dptr(st)))
+        n, s1, s2 = st[0], st[1], st[2]
+        mean = s1 / n
+        return {"n": int(n), "mean": mean, "scintillation_index": (s2 / n) / mean ** 2 - 1.0, "mean_dB_rel": st[3] / n,
+                "avg_dB_rel": 10 * np.log10(mean), "min": st[4], "max": st[5], "fade_prob": st[6:] / n}
 
     def last_timing(self):
         t = np.zeros(4)

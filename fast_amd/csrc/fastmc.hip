@@ -721,6 +721,26 @@ extern "C" int fastmc_histogram(fastmc_t* h, double lo_db, double hi_db, int nbi
   return 0;
 }
 
+extern "C" int fastmc_result_stats(fastmc_t* h, const double* thresholds, int n_thr, double* stats) {
+  if (!h || !stats || n_thr < 0 || n_thr > STATS_MAX_THR || (n_thr > 0 && !thresholds)) return fail(FASTMC_EINVAL, "bad argument");
+  if (h->last_n_iter <= 0) return fail(FASTMC_ESTATE, "no run results on the device");
+  HIPCHK(hipSetDevice(h->device));
+  const int nblocks = 256, stride = STATS_NQ + STATS_MAX_THR, nq = STATS_NQ + n_thr;
+  ScratchBuf part, thr, res;
+  HIPCHK(hipMalloc((void**)&part.p, (size_t)nblocks * stride * 8));
+  HIPCHK(hipMalloc((void**)&thr.p, (size_t)STATS_MAX_THR * 8));
+  HIPCHK(hipMalloc((void**)&res.p, (size_t)stride * 8));
+  if (n_thr) HIPCHK(hipMemcpyAsync(thr.p, thresholds, (size_t)n_thr * 8, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_stats_partial, dim3(nblocks), dim3(256), 0, h->stream, h->out, h->last_n_iter, h->last_coherent,
+                     thr.p, n_thr, part.p);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(64), 0, h->stream, part.p, nblocks, nq, res.p);
+  HIPCHK(hipGetLastError());
+  stats[0] = (double)h->last_n_iter;
+  HIPCHK(hipMemcpyAsync(stats + 1, res.p, (size_t)nq * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 extern "C" int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches) {
   if (!h || !times_ms || !launches) return fail(FASTMC_EINVAL, "null argument");
   for (int i = 0; i < 4; ++i) { times_ms[i] = h->t_ms[i]; launches[i] = h->t_n[i]; }

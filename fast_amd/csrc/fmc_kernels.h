@@ -547,6 +547,53 @@ __global__ void k_histogram(const double* out, int64_t n, int coherent, double l
   atomicAdd(&bins[k], 1ULL);
 }
 
+// ================================================================== result statistics on the device
+// FastResult.avg_power / scintillation_index (fast/fast.py:965-983) and the fade probability of
+// comms.fade_prob (fast/comms.py:171-177) without moving the per-iteration vector to the host.
+// Deterministic two-stage reduction: block partials, then one thread per quantity.
+constexpr int STATS_MAX_THR = 16;
+constexpr int STATS_NQ = 5;   // sum r, sum r^2, sum 10log10 r, min r, max r  (+ counts below thresholds)
+
+__global__ __launch_bounds__(256) void k_stats_partial(const double* out, int64_t n, int coherent, const double* thr,
+                                                       int n_thr, double* partial) {
+  __shared__ double s_q[4][STATS_NQ + STATS_MAX_THR];
+  double q[STATS_NQ + STATS_MAX_THR];
+  for (int i = 0; i < STATS_NQ + STATS_MAX_THR; ++i) q[i] = 0.0;
+  q[3] = INFINITY; q[4] = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double r = coherent ? out[2 * i] * out[2 * i] + out[2 * i + 1] * out[2 * i + 1] : out[i];
+    q[0] += r; q[1] += r * r; q[2] += 10.0 * log10(r);
+    q[3] = fmin(q[3], r); q[4] = fmax(q[4], r);
+    for (int t = 0; t < n_thr; ++t) q[STATS_NQ + t] += (r < thr[t]) ? 1.0 : 0.0;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = 0; i < STATS_NQ + n_thr; ++i) {
+    double v = q[i];
+    for (int o = 32; o >= 1; o >>= 1) {
+      const double u = __shfl_xor(v, o, 64);
+      v = (i == 3) ? fmin(v, u) : (i == 4) ? fmax(v, u) : v + u;
+    }
+    if (lane == 0) s_q[wv][i] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < STATS_NQ + n_thr; i += blockDim.x) {
+    double v = s_q[0][i];
+    for (int w2 = 1; w2 < 4; ++w2) v = (i == 3) ? fmin(v, s_q[w2][i]) : (i == 4) ? fmax(v, s_q[w2][i]) : v + s_q[w2][i];
+    partial[(size_t)blockIdx.x * (STATS_NQ + STATS_MAX_THR) + i] = v;
+  }
+}
+
+__global__ void k_stats_final(const double* partial, int nblocks, int nq, double* result) {
+  const int i = threadIdx.x;
+  if (i >= nq) return;
+  double v = partial[i];
+  for (int b = 1; b < nblocks; ++b) {
+    const double u = partial[(size_t)b * (STATS_NQ + STATS_MAX_THR) + i];
+    v = (i == 3) ? fmin(v, u) : (i == 4) ? fmax(v, u) : v + u;
+  }
+  result[i] = v;
+}
+
 // ================================================================== generator read-back (parity tests)
 __global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, double* out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;

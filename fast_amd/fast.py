@@ -233,6 +233,11 @@ class Fast():
         """Histogram of dB_rel of the last run, computed on the device."""
         return self._handle.histogram(lo_db, hi_db, nbins)
 
+    def result_stats(self, thresholds_dB_rel=()):
+        """Summary statistics of the last run reduced on the device (mean, scintillation index, fade
+        probabilities below the given dB_rel thresholds): nothing per-iteration crosses PCIe."""
+        return self._handle.result_stats([10 ** (t / 10) for t in thresholds_dB_rel])
+
     def compute_mean_irradiance(self, onaxis=True):
         """Analytic (non Monte-Carlo) mean coupled flux, fast.py:736-761; host numpy, one-off."""
         return host.mean_irradiance(self.powerspec, self._prob.W, self.dx, self._prob.df, self.diffraction_limit, onaxis)

@@ -116,6 +116,12 @@ int fastmc_temporal_chunk(fastmc_t* h, const double* xs, const double* ys, const
  * ..., bins[nbins] = underflow, bins[nbins+1] = overflow.  bins: nbins+2 int64. */
 int fastmc_histogram(fastmc_t* h, double lo_db, double hi_db, int nbins, int64_t* bins);
 
+/* Statistics of the last run's results, reduced on the device (FastResult.avg_power_*,
+ * scintillation_index, fast/fast.py:965-983; comms.fade_prob, fast/comms.py:171-177):
+ * stats = [n, sum r, sum r^2, sum 10 log10 r, min r, max r, count(r < thr[0]), ...], r = power
+ * relative to the diffraction limit; thresholds in the same units; n_thr <= 16. */
+int fastmc_result_stats(fastmc_t* h, const double* thresholds, int n_thr, double* stats);
+
 /* Timing of the last fastmc_run / fastmc_run_coeffs, measured with HIP events on the
  * library's own stream: total ms, and per kernel family [rows, cols, finalize] ms and
  * launch counts.  times_ms: 4 doubles, launches: 4 int64. */

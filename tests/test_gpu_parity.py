@@ -463,3 +463,21 @@ def test_device_generator_statistical_quality():
     assert corr(re[0], re[1]) < 5 and corr(re[0], c.imag[0]) < 5
     # different seeds decorrelate
     assert corr(re[0], h.rng_coeffs(2025, 0).real) < 5
+
+
+def test_result_stats_on_device_match_numpy():
+    h, ps, df, W = _small_problem()
+    out = h.run(5, 0, 3000, None, 0.01)
+    thr = [10 ** (-d / 10) for d in (3.0, 6.0, 10.0)]
+    st = h.result_stats(thr)
+    res = fast_amd.FastResult(out, 1.0)
+    assert st["n"] == 6000
+    np.testing.assert_allclose(st["mean"], out.mean(), rtol=1e-12)
+    np.testing.assert_allclose(st["scintillation_index"], res.scintillation_index, rtol=1e-9)
+    np.testing.assert_allclose(st["avg_dB_rel"], res.avg_power_dB_rel, rtol=1e-12)
+    np.testing.assert_allclose(st["mean_dB_rel"], res.dB_rel.mean(), rtol=1e-12)
+    assert st["min"] == out.min() and st["max"] == out.max()
+    np.testing.assert_array_equal(st["fade_prob"], [(out < t).mean() for t in thr])
+    coh = h.run(5, 0, 100, None, 0.01, coherent=True)
+    st2 = h.result_stats()
+    np.testing.assert_allclose(st2["mean"], (np.abs(coh) ** 2).mean(), rtol=1e-12)

@@ -96,6 +96,11 @@ static int sweep(const char* name, double tol) {
 
 int main() {
   int bad = 0;
+  bad += sweep<double, 2, 2>("f64", 1e-13);
+  bad += sweep<double, 4, 2>("f64", 1e-13);
+  bad += sweep<double, 4, 4>("f64", 1e-13);
+  bad += sweep<float, 2, 2>("f32", 2e-5);
+  bad += sweep<float, 4, 4>("f32", 2e-5);
   bad += sweep<double, 8, 2>("f64", 1e-13);
   bad += sweep<double, 16, 2>("f64", 1e-13);
   bad += sweep<double, 32, 2>("f64", 1e-13);

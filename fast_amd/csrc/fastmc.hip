@@ -182,7 +182,7 @@ extern "C" int fastmc_device_count(int* n) {
   return 0;
 }
 
-static bool wave_supported(int N) { return N == 512 || N == 1024 || N == 2048; }
+static bool wave_supported(int N) { return N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048; }
 
 extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int precision) {
   if (!out) return fail(FASTMC_EINVAL, "handle pointer is NULL");
@@ -231,7 +231,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
 
 extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
-  if (force == 1 && !wave_supported(h->N)) return fail(FASTMC_EINVAL, "wave kernels need N in {512, 1024, 2048}");
+  if (force == 1 && !wave_supported(h->N)) return fail(FASTMC_EINVAL, "wave kernels need N in {128, 256, 512, 1024, 2048}");
   if (force == 0 || force == 1) h->path = force;
   return h->path;
 }
@@ -544,15 +544,23 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     CA.partial = h->partial + (size_t)((bs - fin_start)) * Np * 4; CA.phs = h->phs;
     bool wave_ok = h->path == 1;
     if (wave_ok) {
-      const size_t need = h->NS <= 2 ? (h->P == 8 ? wave_lds_bytes<R, 8, 2>(h->omS) : h->P == 16 ? wave_lds_bytes<R, 16, 2>(h->omS) : wave_lds_bytes<R, 32, 2>(h->omS))
-                                     : (h->P == 8 ? wave_lds_bytes<R, 8, 8>(h->omS) : h->P == 16 ? wave_lds_bytes<R, 16, 16>(h->omS) : wave_lds_bytes<R, 32, 32>(h->omS));
+      size_t need;
+      switch (h->P) {
+        case 2: need = wave_lds_bytes<R, 2, 2>(h->omS); break;
+        case 4: need = h->NS <= 2 ? wave_lds_bytes<R, 4, 2>(h->omS) : wave_lds_bytes<R, 4, 4>(h->omS); break;
+        case 8: need = h->NS <= 2 ? wave_lds_bytes<R, 8, 2>(h->omS) : wave_lds_bytes<R, 8, 8>(h->omS); break;
+        case 16: need = h->NS <= 2 ? wave_lds_bytes<R, 16, 2>(h->omS) : wave_lds_bytes<R, 16, 16>(h->omS); break;
+        default: need = h->NS <= 2 ? wave_lds_bytes<R, 32, 2>(h->omS) : wave_lds_bytes<R, 32, 32>(h->omS); break;
+      }
       if (need > 160 * 1024 || h->NS > h->P) wave_ok = false;   // window tables exceed the LDS: direct family (still on the GPU)
     }
     RA.amp = (const R*)(wave_ok ? h->amp_s : h->amp);
     RA.tw = (const cpx<R>*)(wave_ok ? h->tw1 : h->tw);
     CA.tw = RA.tw;
     if (wave_ok) {
-      if (h->P == 8) TRY((dispatch_wave_ns<R, 8>(h, RA, CA, S.mode, S.epi)));
+      if (h->P == 2) dispatch_wave<R, 2, 2>(h, RA, CA, S.mode, S.epi);
+      else if (h->P == 4) TRY((dispatch_wave_ns<R, 4>(h, RA, CA, S.mode, S.epi)));
+      else if (h->P == 8) TRY((dispatch_wave_ns<R, 8>(h, RA, CA, S.mode, S.epi)));
       else if (h->P == 16) TRY((dispatch_wave_ns<R, 16>(h, RA, CA, S.mode, S.epi)));
       else TRY((dispatch_wave_ns<R, 32>(h, RA, CA, S.mode, S.epi)));
     } else {

@@ -7,7 +7,7 @@
 //                 + sub-harmonics, W * exp(i phi) and the pixel sum  ->  partial[b][xi][4]
 //                                                                 (rows 3-5, 5c)
 //   finalize    : sum the Np column partials, log-amplitude, |.|^2 (rows 5, 5b)
-// Two kernel families: "wave" (N = 512/1024/2048; fmc_wavefft.h) and "direct" (any N <= 4096).
+// Two kernel families: "wave" (N = 128 ... 2048, powers of two; fmc_wavefft.h) and "direct" (any N <= 4096).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fmc_core.h"

@@ -1,6 +1,6 @@
 // fmc_wavefft.h -- one wavefront = one N-point row: output-pruned forward DFT, N = 64*P.
 //
-// A lane holds P inputs in registers (k = lane + 64*j).  The transform is factored
+// A lane holds P inputs in registers (k = lane + 64*j), P = 2 ... 32.  The transform is factored
 //     N = P x 8 x 8 :  in-register radix-P  ->  LDS exchange  ->  in-register radix-8
 //                      ->  LDS exchange  ->  8-term sums for the WANTED outputs only
 // because FAST keeps only the Np x Np pupil window of every N x N screen
@@ -50,20 +50,21 @@ template <class R, int P>
 struct WaveGeom {
   static constexpr int N = WAVE * P;
   static constexpr int LOGP = ilog2(P);
-  static constexpr int NB = P / 8;                 // radix-8 butterflies per lane in stage 2a
+  static constexpr int NB = P >= 8 ? P / 8 : 1;    // radix-8 butterflies per lane in stage 2a (P < 8: lanes i >= P idle)
+  static constexpr int VN = P >= 8 ? P : 8;        // register values per lane (stage 2a needs 8)
   static constexpr int SE = 72;                    // row stride of exchange-1 image  E[a][l]: a*72 + l
   // exchange-2 image F[a][b0][l0] at  a + FL*l0 + FB*b0 : conflict-free for the 16-lane write groups
   // ((a mod 8) + 18 l0 covers 16 banks) and for the 32-lane read groups (a + 16*(b0 parity) covers 32)
   static constexpr int FL = P + 2;
   static constexpr int FB = 8 * FL;
   static constexpr int XELEMS = (P * SE > 8 * FB) ? P * SE : 8 * FB;   // 8-byte elements per wave
-  static_assert(P >= 8 && P <= 32, "wave FFT supports N = 512, 1024, 2048");
+  static_assert(P >= 2 && P <= 32, "wave FFT supports N = 128 ... 2048");
 };
 
 // Per-lane registers of the pipeline.
 template <class R, int P, int NS>
 struct LaneRegs {
-  cpx<R> v[P];   // inputs -> stage values -> (fp32) outputs
+  cpx<R> v[WaveGeom<R, P>::VN];   // inputs (first P) -> stage values
   R xr[NS];      // outputs, real part       (slot s  <->  window index lane + 64 s)
   R xi[NS];      // outputs, imaginary part
 };
@@ -83,15 +84,15 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
 
   // ---- stage 1: radix-P in registers, twiddle, to natural order
   ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
-    fft_dif<P, R>(r.v);
-    cpx<R> t[P];
+    cpx<R> z[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) z[j] = r.v[j];
+    fft_dif<P, R>(z);
 #pragma unroll
     for (int a = 0; a < P; ++a) {
-      const cpx<R> z = r.v[brev(a, G::LOGP)];
-      t[a] = (a == 0) ? z : cmul(z, tw1[a * WAVE + lane]);
+      const cpx<R> y = z[brev(a, G::LOGP)];
+      r.v[a] = (a == 0) ? y : cmul(y, tw1[a * WAVE + lane]);
     }
-#pragma unroll
-    for (int a = 0; a < P; ++a) r.v[a] = t[a];
 #pragma unroll
     for (int s = 0; s < NS; ++s) { r.xr[s] = (R)0; r.xi[s] = (R)0; }
   });
@@ -108,9 +109,11 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
       const int l0 = lane & 7, i = lane >> 3;
 #pragma unroll
       for (int jj = 0; jj < G::NB; ++jj)
+        if (P >= 8 || i < P) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
-          X::unpack(r.v[jj * 8 + m], ex.ld(xbuf + (i + 8 * jj) * G::SE + l0 + 8 * m), c);
+          for (int m = 0; m < 8; ++m)
+            X::unpack(r.v[jj * 8 + m], ex.ld(xbuf + (i + 8 * jj) * G::SE + l0 + 8 * m), c);
+        }
     });
     ex.sync();
   }
@@ -133,9 +136,11 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
       const int l0 = lane & 7, i = lane >> 3;
 #pragma unroll
       for (int jj = 0; jj < G::NB; ++jj)
+        if (P >= 8 || i < P) {
 #pragma unroll
-        for (int b0 = 0; b0 < 8; ++b0)
-          ex.st(xbuf + (i + 8 * jj) + G::FL * l0 + G::FB * b0, X::pack(r.v[jj * 8 + b0], c));
+          for (int b0 = 0; b0 < 8; ++b0)
+            ex.st(xbuf + (i + 8 * jj) + G::FL * l0 + G::FB * b0, X::pack(r.v[jj * 8 + b0], c));
+        }
     });
     ex.sync();
     ex.each([&](int lane, LaneRegs<R, P, NS>& r) {

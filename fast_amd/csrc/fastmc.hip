@@ -252,8 +252,8 @@ static int default_batch(const fastmc_ctx* h) {
   if (h->path == 1) {
     // whole number of workgroup rounds over the 256 CUs: the row kernel runs one 12-wave (P=32: 4/6)
     // workgroup per CU and has batch * N/8 wave-items
-    const int wpb = h->NS > 2 ? 4 : (h->P == 32 ? (h->rsz == 8 ? FMC_WPB_P32_F64 : 6) : 12);
-    const int quantum = std::max(1, 256 * wpb * 8 / h->N);
+    const int wpb = h->NS > 2 ? 4 : (h->P == 32 ? (h->rsz == 8 ? FMC_WPB_P32_F64 : 6) : FMC_WPB);
+    const int quantum = std::max(1, 256 * wpb * ROWS_PER_WAVE / h->N);
     if (b >= quantum) b -= b % quantum;
   } else if (b >= 8) {
     b &= ~7;

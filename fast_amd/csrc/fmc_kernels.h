@@ -158,17 +158,23 @@ struct GpuExec {
   }
 };
 
-constexpr int ROWS_PER_WAVE = 8;   // rows kernel: consecutive ky per wave
+#ifndef FMC_ROWS_PER_WAVE
+#define FMC_ROWS_PER_WAVE 8
+#endif
+constexpr int ROWS_PER_WAVE = FMC_ROWS_PER_WAVE;   // rows kernel: consecutive ky per wave
 // Waves per workgroup: the twiddle tables are staged once per workgroup, so bigger groups leave
 // more LDS for exchange buffers: 12 waves = 3 per SIMD at 132 VGPRs (f64, P = 16).
 // P = 32 keeps 2 x 32 values per lane (>= 200 VGPRs) and 18 KiB of exchange buffer per wave: 6 waves
 // (A/B at 2048^2 f64: 6 waves 141k it/s vs 4 waves 114k it/s; 8 do not fit the LDS).
 // The general-window instantiation (NS = P) carries a large `om` table: 4 waves.
 template <class R, int P, int NS> struct WaveCfg {
+#ifndef FMC_WPB
+#define FMC_WPB 12
+#endif
 #ifndef FMC_WPB_P32_F64
 #define FMC_WPB_P32_F64 6
 #endif
-  static constexpr int WPB = (NS != 2) ? 4 : (P == 32 ? (sizeof(R) == 8 ? FMC_WPB_P32_F64 : 6) : 12);
+  static constexpr int WPB = (NS != 2) ? 4 : (P == 32 ? (sizeof(R) == 8 ? FMC_WPB_P32_F64 : 6) : FMC_WPB);
 };
 
 template <class R, int P>

@@ -233,6 +233,35 @@ class Fast():
         """Histogram of dB_rel of the last run, computed on the device."""
         return self._handle.histogram(lo_db, hi_db, nbins)
 
+    @property
+    def freq(self):
+        """Angular spatial-frequency grids like the reference's `SpatialFrequencies` (fast.py:814-875):
+        freq.main.{fx_axis, fy_axis, fx, fy, fabs, f, df}, the same names on `freq` itself, and
+        freq.subharm when sub-harmonics are on.  Built on first use (three N x N arrays)."""
+        if getattr(self, "_freq", None) is None:
+            from types import SimpleNamespace
+            prob = self._prob
+            fx, fy, fabs = host.mesh(prob.axis)
+            main = SimpleNamespace(fx_axis=prob.axis, fy_axis=prob.axis, f=prob.axis, df=prob.df, dfx=prob.df, dfy=prob.df,
+                                   fx=fx, fy=fy, fabs=fabs, freq_per_layer=False)
+            fr = SimpleNamespace(N=prob.N, dx=prob.dx, main=main, fx=fx, fy=fy, fabs=fabs, f=prob.axis, df=prob.df)
+            if self.subharmonics:
+                ax = host.subharm_axes(prob.N, prob.dx)
+                sfx, sfy, sfabs = host.mesh(ax)
+                fr.subharm = SimpleNamespace(fx_axis=ax, fy_axis=ax, f=ax, df=ax[..., 1] - ax[..., 0], fx=sfx, fy=sfy,
+                                             fabs=sfabs, freq_per_layer=False)
+            self._freq = fr
+        return self._freq
+
+    @property
+    def phs(self):
+        """Phase screens of the LAST chunk, (NITER/NCHUNKS, Np, Np), as `Fast.phs` holds them after
+        `run()` in the reference (fast.py:596-603).  Device-generator runs recompute them on the GPU."""
+        if self.temporal or self.rng_mode != 'device' or not hasattr(self, "_device_seed"):
+            raise AttributeError("phs is available after run() in device-generator, non-temporal mode")
+        half = self.Niter_per_chunk // 2
+        return self._handle.screens(self._device_seed, (self.Nchunks - 1) * half, half)
+
     def result_stats(self, thresholds_dB_rel=()):
         """Summary statistics of the last run reduced on the device (mean, scintillation index, fade
         probabilities below the given dB_rel thresholds): nothing per-iteration crosses PCIe."""

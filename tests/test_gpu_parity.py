@@ -481,3 +481,22 @@ def test_result_stats_on_device_match_numpy():
     coh = h.run(5, 0, 100, None, 0.01, coherent=True)
     st2 = h.result_stats()
     np.testing.assert_allclose(st2["mean"], (np.abs(coh) ** 2).mean(), rtol=1e-12)
+
+
+def test_fast_object_attributes_like_the_reference():
+    """freq grids and the last chunk's phase screens (fast.py:49-64, 596-603, 814-875)."""
+    g = load_golden("e2e_subharm_ao")
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_DEVICE": 0, "NITER": 40, "NCHUNKS": 4})
+    sim = fast_amd.Fast(p)
+    grid = R.main_grid(sim.Npxls, sim.dx)
+    np.testing.assert_allclose(sim.freq.main.fabs, grid.fabs, rtol=1e-15)
+    np.testing.assert_allclose(sim.freq.fx, grid.fx, rtol=1e-15)
+    np.testing.assert_allclose(sim.freq.subharm.fx, g["sh_fx"], rtol=1e-15)
+    assert sim.freq.df == grid.df and sim.freq.main.f.shape == (sim.Npxls,)
+    res = sim.run()
+    phs = sim.phs
+    assert phs.shape == (10, sim.Npxls_pup, sim.Npxls_pup)
+    # detector of those screens == the last chunk's results (oracle formula on GPU screens)
+    want = R.detector(phs, sim.pupil * sim.pupil_mode, sim.dx, sim.logamp[-10:])
+    np.testing.assert_allclose(res._r[-10:], want, rtol=1e-9)

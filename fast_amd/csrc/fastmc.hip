@@ -423,7 +423,8 @@ static int dispatch_wave_ns(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
 
 template <class R>
 static int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
-  const size_t lds = (size_t)2 * h->N * sizeof(cpx<R>);
+  // LDS: twiddles [N] + row/column [N] + segment partials [S][Np] (S*Np <= max(256, Np))
+  const size_t lds = ((size_t)2 * h->N + (size_t)std::max(DIRECT_THREADS, h->Np)) * sizeof(cpx<R>);
   if (lds > 160 * 1024 - 4096) return fail(FASTMC_EINVAL, "N too large for the direct kernels at this precision");
   {
     Span s(h, 0);

@@ -322,16 +322,29 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_rows_direct(RowArgs<R> A) {
       s_row[kx] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
   }
   __syncthreads();
+  // Every window output is a length-N sum; with Np < blockDim the sum is cut into S segments so
+  // that all threads work, and the S partials are added in a fixed order (deterministic).
   const int h = N / 2;
-  for (int oi = threadIdx.x; oi < A.Np; oi += blockDim.x) {
+  const int S = (A.Np < (int)blockDim.x) ? (int)blockDim.x / A.Np : 1;
+  const int K = (N + S - 1) / S;
+  cpx<R>* s_part = s_row + N;                       // [S][Np]
+  for (int item = threadIdx.x; item < S * A.Np; item += blockDim.x) {
+    const int oi = item % A.Np, seg = item / A.Np;
+    const int k0 = seg * K, k1 = min(N, k0 + K);
     const int q = shifted_exponent_step(A.lo + oi, N);
-    int e = (int)(((long long)q * h) % N);
+    int e = (int)(((long long)q * (h + k0)) % N);
     cpx<R> acc = mk<R>((R)0, (R)0);
-    for (int k = 0; k < N; ++k) {
+    for (int k = k0; k < k1; ++k) {
       acc = cfma(s_row[k], s_tw[e], acc);
       e += q;
       if (e >= N) e -= N;
     }
+    s_part[seg * A.Np + oi] = acc;
+  }
+  __syncthreads();
+  for (int oi = threadIdx.x; oi < A.Np; oi += blockDim.x) {
+    cpx<R> acc = s_part[oi];
+    for (int seg = 1; seg < S; ++seg) acc = acc + s_part[seg * A.Np + oi];
     A.V[((size_t)b * A.Np + oi) * N + ky] = acc;
   }
 }
@@ -351,16 +364,27 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_cols_direct(ColArgs<R> A) {
   }
   __syncthreads();
   const int h = N / 2;
-  double acc4[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int yi = threadIdx.x; yi < A.Np; yi += blockDim.x) {
+  const int S = (A.Np < (int)blockDim.x) ? (int)blockDim.x / A.Np : 1;
+  const int K = (N + S - 1) / S;
+  cpx<R>* s_part = s_col + N;                       // [S][Np]
+  for (int item = threadIdx.x; item < S * A.Np; item += blockDim.x) {
+    const int yi = item % A.Np, seg = item / A.Np;
+    const int k0 = seg * K, k1 = min(N, k0 + K);
     const int q = shifted_exponent_step(A.lo + yi, N);
-    int e = (int)(((long long)q * h) % N);
-    cpx<R> acc = mk<R>((R)0, (R)0);
-    for (int k = 0; k < N; ++k) {
-      acc = cfma(s_col[k], s_tw[e], acc);
+    int e = (int)(((long long)q * (h + k0)) % N);
+    cpx<R> part = mk<R>((R)0, (R)0);
+    for (int k = k0; k < k1; ++k) {
+      part = cfma(s_col[k], s_tw[e], part);
       e += q;
       if (e >= N) e -= N;
     }
+    s_part[seg * A.Np + yi] = part;
+  }
+  __syncthreads();
+  double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int yi = threadIdx.x; yi < A.Np; yi += blockDim.x) {
+    cpx<R> acc = s_part[yi];
+    for (int seg = 1; seg < S; ++seg) acc = acc + s_part[seg * A.Np + yi];
     R p1 = acc.x, p2 = acc.y;
     pixel_phase<R>(A.sh, b, A.Np, yi, xi, p1, p2);
     if (EPI == 1) {

@@ -7,7 +7,7 @@ TAG=${1:-r01}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+BENCH="python3 $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras $*"
 # 1) kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 # 2) PMC passes (separate runs; FETCH_SIZE and WRITE_SIZE do not fit one pass)

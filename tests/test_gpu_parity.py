@@ -500,3 +500,22 @@ def test_fast_object_attributes_like_the_reference():
     # detector of those screens == the last chunk's results (oracle formula on GPU screens)
     want = R.detector(phs, sim.pupil * sim.pupil_mode, sim.dx, sim.logamp[-10:])
     np.testing.assert_allclose(res._r[-10:], want, rtol=1e-9)
+
+
+@pytest.mark.parametrize("key,pkey", [("r_ao", "params_json"), ("r_noao", "params2_json")])
+def test_device_mode_distribution_matches_reference_output(key, pkey):
+    """4000 GPU iterations with the device generator vs 2000 iterations of the REFERENCE itself
+    (numpy PCG64 draws) on the same configuration: same distribution (two-sample KS), same mean
+    power within 4 standard errors, same scintillation index within 25 %."""
+    from scipy import stats
+    g = load_golden("stat_ref_256")
+    ref = g[key]
+    p = params_from_json(g[pkey])
+    p.update({"GPU_DEVICE": 0, "NITER": 4000, "NCHUNKS": 20, "SEED": 1234, "GPU_RNG": "device"})
+    r = fast_amd.Fast(p).run()._r
+    d1, d2 = 10 * np.log10(r), 10 * np.log10(ref)
+    assert stats.ks_2samp(d1, d2).pvalue > 0.01
+    se = np.sqrt(r.var() / r.size + ref.var() / ref.size)
+    assert abs(r.mean() - ref.mean()) < 4 * se
+    si1, si2 = (r / r.mean()).var(), (ref / ref.mean()).var()
+    assert abs(si1 / si2 - 1) < 0.25

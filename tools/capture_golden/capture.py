@@ -276,6 +276,24 @@ def mean_irradiance():
          diffraction_limit2=sim2.diffraction_limit, onaxis2=sim2.compute_mean_irradiance())
 
 
+def stat_ref():
+    """2000 iterations of the reference at 256^2 (BASELINE config 1 geometry, AO + alias) and 2000 without
+    AO: only the result vectors, for distribution tests of the device-generator path."""
+    h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
+    p = dict(fast.conf.DEFAULTS)
+    p.update({"NPXLS": 256, "DX": 0.01, "NITER": 2000, "NCHUNKS": 20, "TEMPORAL": False, "FFTW": True, "SEED": 11,
+              "W0": "opt", "D_GROUND": 0.8, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w, "WIND_DIR": [0, 90, 180, 270],
+              "ZENITH_ANGLE": 55, "DSUBAP": 0.1, "LOGLEVEL": "ERROR", "H_SAT": 36e6, "AO_MODE": "AO", "ALIAS": True})
+    sim = fast.Fast(p)
+    r_ao = sim.run()._r
+    p2 = dict(p)
+    p2.update({"AO_MODE": "NOAO", "L0": 25.0, "SEED": 12})
+    sim2 = fast.Fast(p2)
+    r_no = sim2.run()._r
+    save("stat_ref_256", "result._r of 2000 reference iterations at 256^2: AO+alias, and NOAO L0=25", True,
+         params_json=np.array(params_to_json(p)), params2_json=np.array(params_to_json(p2)), r_ao=r_ao, r_noao=r_no)
+
+
 def default_cfg():
     h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
     p = dict(fast.conf.DEFAULTS)
@@ -305,9 +323,10 @@ def big(p):
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("capturing into", OUT)
-    if "--only-temporal" in sys.argv or "--only-mean-irradiance" in sys.argv:
+    only = [a for a in sys.argv if a.startswith("--only-")]
+    if only:
         # add / refresh one family; MANIFEST lines are appended by hand
-        temporal() if "--only-temporal" in sys.argv else mean_irradiance()
+        {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref}[only[0]]()
         for name, size, st, note in MANIFEST:
             print(f"| {name}.npz | {size} | {st} | {note} |")
         return
@@ -317,6 +336,7 @@ def main():
     e2e()
     temporal()
     mean_irradiance()
+    stat_ref()
     p = default_cfg()
     if "--no-big" not in sys.argv:
         big(p)

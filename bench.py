@@ -140,15 +140,25 @@ def main():
     # FASTMC_BENCH_FORCE_DIST=1 exercises the multi-process code path (process group, in-library
     # RCCL communicator, gather) with a single rank: the only way to test it on a 1-GPU box.
     dist_on = world > 1 or (os.environ.get("FASTMC_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    # FASTMC_BENCH_BACKEND=gloo runs the multi-rank logic with host-side collectives and lets several
+    # ranks share one GPU (FASTMC_BENCH_DEVICE): a functional test of the N > 1 path on a 1-GPU box.
+    backend = os.environ.get("FASTMC_BENCH_BACKEND", "nccl")
+    device_index = int(os.environ.get("FASTMC_BENCH_DEVICE", local_rank))
     if dist_on:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(device_index)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
+
+    def dev(t):
+        return t.cuda() if backend == "nccl" else t
 
     import fast_amd
     p = workload_params(args)
-    p["GPU_DEVICE"] = local_rank
+    p["GPU_DEVICE"] = device_index
     p["GPU_BATCH"] = args.batch
     t0 = time.perf_counter()
     sim = fast_amd.Fast(p)
@@ -161,19 +171,27 @@ def main():
     gather = "none"
     if dist_on:
         # RCCL inside the library, on its own stream: unique id from rank 0 via the launcher's store
-        ids = [fast_amd._lib.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        try:
-            h.comm_init(ids[0], world, rank)
-            gather = "rccl(in-library)"
-        except fast_amd.FastMCError as e:      # keep the scaling run alive; say so in the JSON
-            gather = f"torch.distributed ({e})"
+        if backend == "nccl":
+            ids = [fast_amd._lib.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            err = ""
+            try:
+                h.comm_init(ids[0], world, rank)
+            except fast_amd.FastMCError as e:      # keep the scaling run alive; say so in the JSON
+                err = str(e)
+            ok = dev(torch.tensor([0 if err else 1], dtype=torch.int32))
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank takes the same path
+            gather = "rccl(in-library)" if int(ok.item()) == 1 else f"torch.distributed (RCCL init failed: {err or 'on another rank'})"
+        else:
+            gather = f"torch.distributed ({backend})"
 
     def sync_all():
         if dist_on:
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
 
     hist_total = None
 
@@ -190,10 +208,11 @@ def main():
                 except fast_amd.FastMCError as e:
                     gather = f"torch.distributed ({e})"
             if hist is None:
-                hist_l = torch.from_numpy(h.histogram(*HIST)).cuda()
+                hist_l = dev(torch.from_numpy(h.histogram(*HIST)))
                 dist.all_reduce(hist_l)
-                allp_t = [torch.empty(2 * n_real, dtype=torch.float64, device="cuda") for _ in range(world)]
-                dist.all_gather(allp_t, torch.from_numpy(out).cuda())
+                src = dev(torch.from_numpy(out))
+                allp_t = [torch.empty_like(src) for _ in range(world)]
+                dist.all_gather(allp_t, src)
                 hist = hist_l.cpu().numpy()
             hist_total = hist
         return out
@@ -211,7 +230,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist_on:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = dev(torch.tensor([dt], dtype=torch.float64))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert np.isfinite(out).all() and (out > 0).all()
@@ -253,7 +272,7 @@ def main():
                          "init_s": init_s, "powerspec_kernel_ms": sim.powerspec_kernel_ms},
         }
         if world == 1 and not args.no_extras:
-            line["extras"] = extras(args, local_rank)
+            line["extras"] = extras(args, device_index)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sim)
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]

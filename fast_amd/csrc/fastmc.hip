@@ -244,11 +244,12 @@ extern "C" int fastmc_set_batch(fastmc_t* h, int batch) {
 
 static int default_batch(const fastmc_ctx* h) {
   if (h->batch > 0) return h->batch;
-  // V slab (batch * N * Np complex) of up to ~288 MiB (measured: 192 realisations per launch beat 96
-  // at 1024^2 by 3 %; Infinity-Cache residency of the slab does not matter, the pipeline is VALU-bound)
+  // V slab (batch * N * Np complex) of up to 1.5 GiB: fewer, larger launches (measured at 1024^2 f64:
+  // 96 / 216 / 1008 realisations per launch -> 0.97 / 1.00 / 1.05 of the throughput; Infinity-Cache
+  // residency of the slab does not matter, the pipeline is VALU-bound, and HBM is 288 GB)
   const double per = (double)h->N * h->Np * 2 * h->rsz;
-  int b = (int)(288.0 * 1024 * 1024 / per);
-  b = std::max(1, std::min(b, 1024));
+  int b = (int)(1536.0 * 1024 * 1024 / per);
+  b = std::max(1, std::min(b, 4096));
   if (h->path == 1) {
     // whole number of workgroup rounds over the 256 CUs: the row kernel runs one 12-wave (P=32: 4/6)
     // workgroup per CU and has batch * N/8 wave-items

@@ -266,38 +266,40 @@ static int default_batch(const fastmc_ctx* h) {
 template <class R>
 static int upload_spectrum(fastmc_ctx* h, const double* ps, double df) {
   const int N = h->N;
-  std::vector<R> a((size_t)N * N), as((size_t)N * N);
-  for (int ky = 0; ky < N; ++ky)
-    for (int kx = 0; kx < N; ++kx) {
-      const double p = ps[(size_t)ky * N + kx];
-      const double v = std::sqrt(p) * df;
-      a[(size_t)ky * N + kx] = (R)v;
-      as[(size_t)ky * N + kx] = (R)(((ky + kx) & 1) ? -v : v);
-    }
-  if (!h->amp) HIPCHK(hipMalloc(&h->amp, sizeof(R) * N * N));
-  if (!h->amp_s) HIPCHK(hipMalloc(&h->amp_s, sizeof(R) * N * N));
-  HIPCHK(hipMemcpy(h->amp, a.data(), sizeof(R) * N * N, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->amp_s, as.data(), sizeof(R) * N * N, hipMemcpyHostToDevice));
+  const size_t n = (size_t)N * N;
+  if (!h->amp) HIPCHK(hipMalloc(&h->amp, sizeof(R) * n));
+  if (!h->amp_s) HIPCHK(hipMalloc(&h->amp_s, sizeof(R) * n));
+  ScratchBuf d_ps, d_bad;
+  HIPCHK(hipMalloc((void**)&d_ps.p, n * 8));
+  HIPCHK(hipMalloc((void**)&d_bad.p, 8));
+  HIPCHK(hipMemcpyAsync(d_ps.p, ps, n * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(d_bad.p, 0, 8, h->stream));
+  hipLaunchKernelGGL((k_make_amp<R>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d_ps.p, df, N, (R*)h->amp,
+                     (R*)h->amp_s, (unsigned int*)d_bad.p);
+  HIPCHK(hipGetLastError());
+  unsigned int bad = 0;
+  HIPCHK(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (bad) return fail(FASTMC_EINVAL, "powerspec must be finite and non-negative");
   // direct-family twiddles w_N^e
-  std::vector<cpx<R>> tw(N);
-  for (int e = 0; e < N; ++e) {
-    double c, s;
-    cs_turns((double)e / N, &c, &s);
-    tw[e] = mk<R>((R)c, (R)(-s));
+  if (!h->tw) {
+    std::vector<cpx<R>> tw(N);
+    for (int e = 0; e < N; ++e) {
+      double cc, ss;
+      cs_turns((double)e / N, &cc, &ss);
+      tw[e] = mk<R>((R)cc, (R)(-ss));
+    }
+    HIPCHK(hipMalloc(&h->tw, sizeof(cpx<R>) * N));
+    HIPCHK(hipMemcpy(h->tw, tw.data(), sizeof(cpx<R>) * N, hipMemcpyHostToDevice));
   }
-  if (!h->tw) HIPCHK(hipMalloc(&h->tw, sizeof(cpx<R>) * N));
-  HIPCHK(hipMemcpy(h->tw, tw.data(), sizeof(cpx<R>) * N, hipMemcpyHostToDevice));
   return 0;
 }
 
 extern "C" int fastmc_set_spectrum(fastmc_t* h, const double* powerspec, double df) {
   if (!h || !powerspec) return fail(FASTMC_EINVAL, "null argument");
-  const size_t n = (size_t)h->N * h->N;
-  for (size_t i = 0; i < n; ++i)
-    if (!(powerspec[i] >= 0.0) || std::isinf(powerspec[i]))
-      return fail(FASTMC_EINVAL, "powerspec must be finite and non-negative");
   HIPCHK(hipSetDevice(h->device));
   h->df = df;
+  h->have_spec = false;
   TRY(h->precision == FASTMC_F64 ? upload_spectrum<double>(h, powerspec, df) : upload_spectrum<float>(h, powerspec, df));
   h->have_spec = true;
   return 0;

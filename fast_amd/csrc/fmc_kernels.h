@@ -448,6 +448,21 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_cols_direct(ColArgs<R> A) {
   }
 }
 
+// ================================================================== spectrum -> colouring amplitudes
+// amp = sqrt(powerspec) * df (fast/fast.py:594 and the `rand * df` of funcs.py:213); amp_s carries the
+// input-side fftshift sign (-1)^(ky+kx).  bad[0] counts entries that are negative, NaN or infinite.
+template <class R>
+__global__ void k_make_amp(const double* ps, double df, int N, R* amp, R* amp_s, unsigned int* bad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * N) return;
+  const double p = ps[i];
+  if (!(p >= 0.0) || isinf(p)) { atomicAdd(bad, 1u); return; }
+  const double v = sqrt(p) * df;
+  const int ky = (int)(i / N), kx = (int)(i % N);
+  amp[i] = (R)v;
+  amp_s[i] = (R)(((ky + kx) & 1) ? -v : v);
+}
+
 // ================================================================== sub-harmonic coefficients
 // coef[b][m] = rand_lo[b][m] * sqrt(ps_lo[m]) * df_lo[level(m)]  (fast/fast.py:600-601, funcs.py:243)
 // mean[b]    = sum_m coef[b][m] * mu[m],  mu[m] = grid mean of mode m (funcs.py:253)

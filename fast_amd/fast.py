@@ -93,21 +93,25 @@ class Fast():
         global _R
         _R = numpy.random.default_rng(seed)
 
-    def compute_powerspec(self):
-        """AO-residual phase PSD and its Simpson integrals on the GPU (replaces fast.py:445-492)."""
+    def compute_powerspec(self, per_layer=None):
+        """AO-residual phase PSD and its Simpson integrals on the GPU (replaces fast.py:445-492).
+        The (L, N, N) per-layer grids are only copied back when needed (TEMPORAL) or when
+        `powerspec_per_layer` is read."""
         logger.info("Computing (residual) phase power spectra")
+        if per_layer is None:
+            per_layer = bool(self.temporal)
         prob, p, atm = self._prob, self.params, self._prob.atm
         out = _lib.powerspec(prob.N, prob.dx, prob.wvl, p['L0'], p['l0'], prob.ao_mode, p['ALIAS'], p['NOISE'],
                              prob.d_wfs, p['TLOOP'], p['TEXP'], atm.dtheta, atm.cn2, atm.h, atm.wind_vector,
                              prob.pup.pupil_filter, prob.simpson_w, lf_mask=None, modal=prob.modal,
                              modal_mult=prob.modal_mult, zmax=prob.zmax, D_ground=p['D_GROUND'],
-                             per_layer=True, device=self.device)
+                             per_layer=per_layer, device=self.device)
         # mask_lf (ao_power_spectra.py:119-141) was evaluated on the device; same dtype as the reference
         m = out["lf_mask"]
         self.lf_mask = m if (prob.modal and prob.zmax is not None) else m.astype(numpy.int64)
         self.hf_mask = 1 - self.lf_mask
         self.powerspec = out["powerspec"]
-        self.powerspec_per_layer = out["powerspec_per_layer"]
+        self._per_layer = out["powerspec_per_layer"]
         self.logamp_powerspec = out["logamp_powerspec"]
         for k in ("aniso_servo_error", "alias_error", "noise_error", "fitting_error", "phs_var", "logamp_var", "phs_var_weights"):
             setattr(self, k, out[k])
@@ -232,6 +236,13 @@ class Fast():
     def histogram(self, lo_db=-60.0, hi_db=10.0, nbins=4096):
         """Histogram of dB_rel of the last run, computed on the device."""
         return self._handle.histogram(lo_db, hi_db, nbins)
+
+    @property
+    def powerspec_per_layer(self):
+        """(L, N, N) residual PSD per turbulence layer (fast.py:478-479); fetched from the GPU on first use."""
+        if self._per_layer is None:
+            self.compute_powerspec(per_layer=True)
+        return self._per_layer
 
     @property
     def freq(self):

@@ -63,8 +63,9 @@ int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, double dx);
 int fastmc_set_subharm(fastmc_t* h, const double* powerspec_sh, const double* fx,
                        const double* fy, const double* df);
 
-/* Monte-Carlo run with the on-device counter-based generator (Philox4x32-10 keyed on
- * (seed; realisation, pixel), Box-Muller) -- replaces the body of the chunk loop of
+/* Monte-Carlo run with the on-device generator (xoshiro128+ streams seeded by Philox4x32-10
+ * blocks keyed on (seed; realisation, row, column mod 64), Box-Muller; restated in
+ * oracle/devrng.py) -- replaces the body of the chunk loop of
  * Fast.run (fast/fast.py:130-134: compute_phs 589-605 + compute_detector 647-668) and
  * Fast.compute_logamp (fast/fast.py:639-645).
  *

@@ -137,9 +137,15 @@ class Fast():
             self._run_host_rng(I, coherent)
         else:
             seed = self.seed if self.seed is not None else int(numpy.random.SeedSequence().generate_state(2, numpy.uint32).view(numpy.uint64)[0])
-            self._device_seed = seed
             n_real = self.Niter // 2
             tr = self._transport()
+            if tr is not None and self.seed is None:
+                # every rank must draw from the same generator: rank 0's entropy seed wins
+                import torch.distributed as tdist
+                box = [seed]
+                tdist.broadcast_object_list(box, src=0)
+                seed = int(box[0])
+            self._device_seed = seed
             if tr is None:
                 out = self._handle.run(seed, 0, n_real, None, float(self.logamp_var), coherent)
             else:

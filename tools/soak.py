@@ -1,0 +1,18 @@
+import sys, time, gc; sys.path.insert(0, '.')
+import numpy as np, fast_amd, ctypes
+hip = ctypes.CDLL("libamdhip64.so")
+def free_mem():
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)); return f.value / 2**20
+h, cn2, w = fast_amd.turbulence_models.HV57_Bufton_profile(4)
+p = {"NPXLS": 256, "DX": 0.01, "NITER": 2000, "NCHUNKS": 10, "SEED": 1, "LOGLEVEL": "ERROR", "D_GROUND": 0.8, "H_TURB": h,
+     "CN2_TURB": cn2, "WIND_SPD": w, "WIND_DIR": np.array([0., 90., 180., 270.]), "DSUBAP": 0.1, "GPU_DEVICE": 0, "SUBHARM": True}
+m0 = None
+for i in range(150):
+    p["SEED"] = i; p["GPU_PRECISION"] = "f32" if i % 3 == 0 else "f64"
+    sim = fast_amd.Fast(dict(p)); r = sim.run()._r; st = sim.result_stats([-3.0]); hs = sim.histogram()
+    assert np.isfinite(r).all() and hs.sum() == 2000
+    del sim
+    if i == 10: gc.collect(); m0 = free_mem()
+gc.collect(); m1 = free_mem()
+print(f"free device memory after 10 objects {m0:.0f} MiB, after 150 objects {m1:.0f} MiB, drift {m0-m1:.1f} MiB")

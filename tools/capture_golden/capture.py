@@ -212,7 +212,7 @@ def capture_sim(name, p, note, full=True, stride=None):
     save(name, note + f" [ref init {t1-t0:.2f}s run {t2-t1:.2f}s]", True, **d)
 
 
-def e2e():
+def e2e(only=None):
     cases = {
         "ao_alias": (dict(), "AO zonal + ALIAS"),
         "noao": (dict(AO_MODE="NOAO"), "NOAO, L0=inf"),
@@ -234,8 +234,11 @@ def e2e():
                        "L_SAT + ANISO_DL + AZIMUT_SAT optional keys"),
         "oddNp": (dict(D_GROUND=0.205, NPXLS=48), "Np odd (23), N=48 (non power of two)"),
         "autosize": (dict(NPXLS="auto", DX="auto", NITER=4, NCHUNKS=1), "auto DX and NPXLS"),
+        "oddN": (dict(NPXLS=49, SUBHARM=True), "odd grid size N=49 (numpy's asymmetric fftshift), sub-harmonics"),
     }
     for name, (over, note) in cases.items():
+        if only and name not in only:
+            continue
         capture_sim("e2e_" + name, base_params(**over), note)
 
 
@@ -326,7 +329,10 @@ def main():
     only = [a for a in sys.argv if a.startswith("--only-")]
     if only:
         # add / refresh one family; MANIFEST lines are appended by hand
-        {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref}[only[0]]()
+        if only[0].startswith("--only-e2e="):
+            e2e(only[0].split("=", 1)[1].split(","))
+        else:
+            {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref}[only[0]]()
         for name, size, st, note in MANIFEST:
             print(f"| {name}.npz | {size} | {st} | {note} |")
         return

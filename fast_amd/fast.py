@@ -18,7 +18,6 @@ Differences from the reference, all deliberate:
   * `FFTW` / `FFTW_THREADS` are accepted and ignored (they select a CPU FFT in the reference).
 """
 import logging
-import os
 
 import numpy
 

@@ -13,9 +13,7 @@ import copy
 import sys
 import time
 
-import numpy as np
 
-from . import host
 from .fast import Fast
 
 

@@ -36,7 +36,6 @@ def main():
     full = fd.run_sharded(NREAL, compute, tr)
     single = compute(0, NREAL)
     assert np.array_equal(full, single), (full, single)
-    db = 10 * np.log10(full[fd.shard_range(NREAL, tr.world, tr.rank)[0]:][:2])
     h_local = np.histogram(10 * np.log10(compute(*fd.shard_range(NREAL, tr.world, tr.rank))), bins=8, range=(-40, 10))[0]
     h_all = fd.histogram_sharded(h_local, tr)
     assert np.array_equal(h_all, np.histogram(10 * np.log10(single), bins=8, range=(-40, 10))[0])

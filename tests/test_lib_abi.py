@@ -4,7 +4,6 @@ import os
 import re
 import subprocess
 
-import numpy as np
 import pytest
 
 from conftest import ROOT

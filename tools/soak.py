@@ -1,4 +1,4 @@
-import sys, time, gc; sys.path.insert(0, '.')
+import sys, gc; sys.path.insert(0, '.')
 import numpy as np, fast_amd, ctypes
 hip = ctypes.CDLL("libamdhip64.so")
 def free_mem():

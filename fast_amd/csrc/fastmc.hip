@@ -835,7 +835,7 @@ extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double
     hipEventCreate(&e1);
     hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k_powerspec, dim3(N), dim3(PS_THREADS), 0, 0, K);
-    hipLaunchKernelGGL(k_ps_scalars, dim3((nq + 63) / 64), dim3(64), 0, 0, d_rows, d_w, N, nq, d_sc);
+    hipLaunchKernelGGL(k_ps_scalars, dim3(nq), dim3(256), 0, 0, d_rows, d_w, N, nq, d_sc);
     hipEventRecord(e1, 0);
     hipError_t e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipGetLastError();

@@ -212,13 +212,16 @@ __global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
   }
 }
 
-// scalars[i] = sum_iy w[iy] * rowsums[iy][i]
-__global__ void k_ps_scalars(const double* rowsums, const double* w, int N, int nq, double* scalars) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nq) return;
+// scalars[i] = sum_iy w[iy] * rowsums[iy][i]: one block per quantity, fixed-shape tree (deterministic)
+__global__ __launch_bounds__(256) void k_ps_scalars(const double* rowsums, const double* w, int N, int nq, double* scalars) {
+  __shared__ double s_part[4];
+  const int i = blockIdx.x;
   double v = 0.0;
-  for (int iy = 0; iy < N; ++iy) v += w[iy] * rowsums[(size_t)iy * nq + i];
-  scalars[i] = v;
+  for (int iy = threadIdx.x; iy < N; iy += blockDim.x) v += w[iy] * rowsums[(size_t)iy * nq + i];
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) scalars[i] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
 }
 
 }  // namespace fmc

@@ -519,3 +519,21 @@ def test_device_mode_distribution_matches_reference_output(key, pkey):
     assert abs(r.mean() - ref.mean()) < 4 * se
     si1, si2 = (r / r.mean()).var(), (ref / ref.mean()).var()
     assert abs(si1 / si2 - 1) < 0.25
+
+
+@pytest.mark.parametrize("N", [256, 1024, 2048])
+def test_f32_pipeline_tracks_f64_on_the_same_device_draws(N):
+    """Same seed -> same generator words in both precisions; only the transform arithmetic differs.
+    Full-size check of the float32 pipeline against the float64 one (phases of tens of radians)."""
+    ps, df = _vk_spectrum(N, 0.01, 25.0)
+    W = _window_W(82)
+    out = {}
+    for prec in ("f64", "f32"):
+        h = _lib.Handle(N, 82, prec, 0)
+        h.set_spectrum(ps, df)
+        h.set_pupil(W, (N - 82) // 2, 0.01)
+        out[prec] = h.run(77, 3, 16, None, 0.01)
+        scr = h.screens(77, 3, 1)
+        out[prec + "_rms"] = scr.std()
+    assert out["f64_rms"] > 2.0                      # radians rms over the window of one screen
+    np.testing.assert_allclose(out["f32"], out["f64"], rtol=5e-4, atol=1e-9)

@@ -101,6 +101,15 @@ int main() {
   bad += sweep<double, 4, 4>("f64", 1e-13);
   bad += sweep<float, 2, 2>("f32", 2e-5);
   bad += sweep<float, 4, 4>("f32", 2e-5);
+  bad += sweep<double, 3, 2>("f64", 1e-13);
+  bad += sweep<double, 5, 2>("f64", 1e-13);
+  bad += sweep<double, 6, 2>("f64", 1e-13);
+  bad += sweep<double, 10, 2>("f64", 1e-13);
+  bad += sweep<double, 12, 2>("f64", 1e-13);
+  bad += sweep<double, 20, 2>("f64", 1e-13);
+  bad += sweep<double, 24, 2>("f64", 1e-13);
+  bad += sweep<float, 12, 2>("f32", 2e-5);
+  bad += sweep<float, 24, 2>("f32", 2e-5);
   bad += sweep<double, 8, 2>("f64", 1e-13);
   bad += sweep<double, 16, 2>("f64", 1e-13);
   bad += sweep<double, 32, 2>("f64", 1e-13);

@@ -182,7 +182,36 @@ extern "C" int fastmc_device_count(int* n) {
   return 0;
 }
 
-static bool wave_supported(int N) { return N == 128 || N == 256 || N == 512 || N == 1024 || N == 2048; }
+// N = 64 P with P = 2^k, 3*2^k or 5*2^k, 2 <= P <= 32
+static bool wave_supported(int N) {
+  if (N % 64 != 0) return false;
+  switch (N / 64) {
+    case 2: case 3: case 4: case 5: case 6: case 8: case 10: case 12: case 16: case 20: case 24: case 32: return true;
+    default: return false;
+  }
+}
+
+// Launch configuration of the wave family for this handle: LDS bytes and waves per workgroup.
+template <class R>
+static void wave_config(const fastmc_ctx* h, size_t* lds, int* wpb) {
+  const bool big = h->NS > 2;   // general-window instantiation (powers of two only)
+#define FMC_CASE(PP)                                                                                         \
+  case PP:                                                                                                   \
+    if constexpr (is_pow2(PP) && PP >= 4) {                                                                  \
+      *lds = big ? wave_lds_bytes<R, PP, PP>(h->omS) : wave_lds_bytes<R, PP, 2>(h->omS);                     \
+      *wpb = big ? WaveCfg<R, PP, PP>::WPB : WaveCfg<R, PP, 2>::WPB;                                         \
+    } else {                                                                                                 \
+      *lds = big ? (size_t)1 << 30 : wave_lds_bytes<R, PP, 2>(h->omS);                                       \
+      *wpb = WaveCfg<R, PP, 2>::WPB;                                                                         \
+    }                                                                                                        \
+    break;
+  switch (h->P) {
+    FMC_CASE(2) FMC_CASE(3) FMC_CASE(4) FMC_CASE(5) FMC_CASE(6) FMC_CASE(8) FMC_CASE(10) FMC_CASE(12)
+    FMC_CASE(16) FMC_CASE(20) FMC_CASE(24) FMC_CASE(32)
+    default: *lds = (size_t)1 << 30; *wpb = 1; break;
+  }
+#undef FMC_CASE
+}
 
 extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int precision) {
   if (!out) return fail(FASTMC_EINVAL, "handle pointer is NULL");
@@ -231,7 +260,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
 
 extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
-  if (force == 1 && !wave_supported(h->N)) return fail(FASTMC_EINVAL, "wave kernels need N in {128, 256, 512, 1024, 2048}");
+  if (force == 1 && !wave_supported(h->N)) return fail(FASTMC_EINVAL, "wave kernels need N = 64 P with P = 2^k, 3*2^k or 5*2^k, 2 <= P <= 32");
   if (force == 0 || force == 1) h->path = force;
   return h->path;
 }
@@ -253,7 +282,9 @@ static int default_batch(const fastmc_ctx* h) {
   if (h->path == 1) {
     // whole number of workgroup rounds over the 256 CUs: the row kernel runs one 12-wave (P=32: 4/6)
     // workgroup per CU and has batch * N/8 wave-items
-    const int wpb = h->NS > 2 ? 4 : (h->P == 32 ? (h->rsz == 8 ? FMC_WPB_P32_F64 : 6) : FMC_WPB);
+    size_t lds = 0;
+    int wpb = 1;
+    if (h->rsz == 8) wave_config<double>(h, &lds, &wpb); else wave_config<float>(h, &lds, &wpb);
     const int quantum = std::max(1, 256 * wpb * ROWS_PER_WAVE / h->N);
     if (b >= quantum) b -= b % quantum;
   } else if (b >= 8) {
@@ -549,24 +580,28 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     bool wave_ok = h->path == 1;
     if (wave_ok) {
       size_t need;
-      switch (h->P) {
-        case 2: need = wave_lds_bytes<R, 2, 2>(h->omS); break;
-        case 4: need = h->NS <= 2 ? wave_lds_bytes<R, 4, 2>(h->omS) : wave_lds_bytes<R, 4, 4>(h->omS); break;
-        case 8: need = h->NS <= 2 ? wave_lds_bytes<R, 8, 2>(h->omS) : wave_lds_bytes<R, 8, 8>(h->omS); break;
-        case 16: need = h->NS <= 2 ? wave_lds_bytes<R, 16, 2>(h->omS) : wave_lds_bytes<R, 16, 16>(h->omS); break;
-        default: need = h->NS <= 2 ? wave_lds_bytes<R, 32, 2>(h->omS) : wave_lds_bytes<R, 32, 32>(h->omS); break;
-      }
+      int wpb_unused;
+      wave_config<R>(h, &need, &wpb_unused);
       if (need > 160 * 1024 || h->NS > h->P) wave_ok = false;   // window tables exceed the LDS: direct family (still on the GPU)
     }
     RA.amp = (const R*)(wave_ok ? h->amp_s : h->amp);
     RA.tw = (const cpx<R>*)(wave_ok ? h->tw1 : h->tw);
     CA.tw = RA.tw;
     if (wave_ok) {
-      if (h->P == 2) dispatch_wave<R, 2, 2>(h, RA, CA, S.mode, S.epi);
-      else if (h->P == 4) TRY((dispatch_wave_ns<R, 4>(h, RA, CA, S.mode, S.epi)));
-      else if (h->P == 8) TRY((dispatch_wave_ns<R, 8>(h, RA, CA, S.mode, S.epi)));
-      else if (h->P == 16) TRY((dispatch_wave_ns<R, 16>(h, RA, CA, S.mode, S.epi)));
-      else TRY((dispatch_wave_ns<R, 32>(h, RA, CA, S.mode, S.epi)));
+      switch (h->P) {
+        case 2: dispatch_wave<R, 2, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 3: dispatch_wave<R, 3, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 4: TRY((dispatch_wave_ns<R, 4>(h, RA, CA, S.mode, S.epi))); break;
+        case 5: dispatch_wave<R, 5, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 6: dispatch_wave<R, 6, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 8: TRY((dispatch_wave_ns<R, 8>(h, RA, CA, S.mode, S.epi))); break;
+        case 10: dispatch_wave<R, 10, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 12: dispatch_wave<R, 12, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 16: TRY((dispatch_wave_ns<R, 16>(h, RA, CA, S.mode, S.epi))); break;
+        case 20: dispatch_wave<R, 20, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 24: dispatch_wave<R, 24, 2>(h, RA, CA, S.mode, S.epi); break;
+        default: TRY((dispatch_wave_ns<R, 32>(h, RA, CA, S.mode, S.epi))); break;
+      }
     } else {
       TRY(dispatch_direct<R>(h, RA, CA, S.mode, S.epi));
     }

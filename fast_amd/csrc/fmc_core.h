@@ -5,6 +5,7 @@
 // arithmetic as the GPU.  Hardware transcendental intrinsics are confined to fmc_kernels.hip.
 #pragma once
 #include <stdint.h>
+#include <utility>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -101,6 +102,96 @@ FMC_HD void fft_dif(cpx<R> (&v)[P]) {
         v[blk + i + S] = mul_tw<R>(u - w, i * (P / (2 * S)), P);
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------- in-register DFT of any supported size
+// cos / sin of 2*pi*num/den evaluated by the compiler (constant arguments after unrolling):
+// reduction to the first octant, then 12-term Taylor series (error < 1e-17).
+FMC_HD constexpr double taylor_sin(double x) {
+  double term = x, sum = x;
+  for (int k = 1; k < 12; ++k) { term *= -x * x / ((2 * k) * (2 * k + 1)); sum += term; }
+  return sum;
+}
+FMC_HD constexpr double taylor_cos(double x) {
+  double term = 1.0, sum = 1.0;
+  for (int k = 1; k < 12; ++k) { term *= -x * x / ((2 * k - 1) * (2 * k)); sum += term; }
+  return sum;
+}
+FMC_HD constexpr double cos_frac(int num, int den) {   // cos(2 pi num / den)
+  num %= den;
+  if (num < 0) num += den;
+  if (2 * num > den) num = den - num;                                   // cos(2pi - t) = cos t, t now in [0, pi]
+  double sign = 1.0;
+  long long n = num, d = den;
+  if (4 * n > d) { n = d - 2 * n; d = 2 * d; sign = -1.0; }             // cos(t) = -cos(pi - t), now in [0, pi/2]
+  const double t = 6.283185307179586476925286766559 * (double)n / (double)d;
+  return sign * ((8 * n > d) ? taylor_sin(1.5707963267948966192313216916398 - t) : taylor_cos(t));
+}
+FMC_HD constexpr double sin_frac(int num, int den) { return cos_frac(4 * num - den, 4 * den); }   // sin t = cos(t - pi/2)
+
+FMC_HD constexpr bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// f(integral_constant<int, 0>), ..., f(integral_constant<int, N-1>): a loop whose index is a constant expression
+template <class F, int... Is>
+FMC_HD void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+FMC_HD void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+// Natural-order forward DFT of P values held in registers.  Powers of two: radix-2 DIF network;
+// P = 3*2^k or 5*2^k: one Cooley-Tukey level (Q strided power-of-two sub-transforms, twiddle,
+// M radix-Q butterflies with compile-time constants).
+template <int P, class R>
+FMC_HD void dft_reg(cpx<R> (&v)[P]) {
+  if constexpr (is_pow2(P)) {
+    fft_dif<P, R>(v);
+    cpx<R> t[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) t[a] = v[brev(a, ilog2(P))];
+#pragma unroll
+    for (int a = 0; a < P; ++a) v[a] = t[a];
+  } else {
+    constexpr int Q = (P % 3 == 0) ? 3 : 5;
+    constexpr int M = P / Q;
+    static_assert(P % Q == 0 && is_pow2(M), "supported sizes: 2^k, 3*2^k, 5*2^k");
+    cpx<R> y[Q][M];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      cpx<R> t[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) t[m] = v[q + Q * m];
+      if constexpr (M > 1) fft_dif<M, R>(t);
+#pragma unroll
+      for (int a2 = 0; a2 < M; ++a2) y[q][a2] = t[brev(a2, ilog2(M))];
+    }
+    // loop indices as template constants, so that every twiddle is a compile-time literal
+    static_for<M>([&](auto A2) {
+      constexpr int a2 = decltype(A2)::value;
+      cpx<R> u[Q];
+      static_for<Q>([&](auto Qi) {
+        constexpr int q = decltype(Qi)::value;
+        constexpr int e = (q * a2) % P;
+        if constexpr (e == 0) u[q] = y[q][a2];
+        else {
+          constexpr double wr = cos_frac(e, P), wi = -sin_frac(e, P);
+          u[q] = cmul(y[q][a2], mk<R>((R)wr, (R)wi));
+        }
+      });
+      static_for<Q>([&](auto A1) {
+        constexpr int a1 = decltype(A1)::value;
+        cpx<R> acc = u[0];
+        static_for<Q - 1>([&](auto Qm) {
+          constexpr int q = decltype(Qm)::value + 1;
+          constexpr int e = (q * a1) % Q;
+          if constexpr (e == 0) acc = acc + u[q];
+          else {
+            constexpr double wr = cos_frac(e, Q), wi = -sin_frac(e, Q);
+            acc = cfma(u[q], mk<R>((R)wr, (R)wi), acc);
+          }
+        });
+        v[a2 + M * a1] = acc;
+      });
+    });
   }
 }
 

@@ -1,6 +1,6 @@
 // fmc_wavefft.h -- one wavefront = one N-point row: output-pruned forward DFT, N = 64*P.
 //
-// A lane holds P inputs in registers (k = lane + 64*j), P = 2 ... 32.  The transform is factored
+// A lane holds P inputs in registers (k = lane + 64*j), P = 2^k, 3*2^k or 5*2^k <= 32.  The transform is factored
 //     N = P x 8 x 8 :  in-register radix-P  ->  LDS exchange  ->  in-register radix-8
 //                      ->  LDS exchange  ->  8-term sums for the WANTED outputs only
 // because FAST keeps only the Np x Np pupil window of every N x N screen
@@ -49,16 +49,16 @@ template <> struct Xch<double> {
 template <class R, int P>
 struct WaveGeom {
   static constexpr int N = WAVE * P;
-  static constexpr int LOGP = ilog2(P);
-  static constexpr int NB = P >= 8 ? P / 8 : 1;    // radix-8 butterflies per lane in stage 2a (P < 8: lanes i >= P idle)
-  static constexpr int VN = P >= 8 ? P : 8;        // register values per lane (stage 2a needs 8)
+  static constexpr int NB = (P + 7) / 8;           // radix-8 butterflies per lane in stage 2a (slots with a >= P idle)
+  static constexpr int VN = NB * 8;                // register values per lane (stage 2a works on groups of 8)
   static constexpr int SE = 72;                    // row stride of exchange-1 image  E[a][l]: a*72 + l
   // exchange-2 image F[a][b0][l0] at  a + FL*l0 + FB*b0 : conflict-free for the 16-lane write groups
   // ((a mod 8) + 18 l0 covers 16 banks) and for the 32-lane read groups (a + 16*(b0 parity) covers 32)
   static constexpr int FL = P + 2;
   static constexpr int FB = 8 * FL;
   static constexpr int XELEMS = (P * SE > 8 * FB) ? P * SE : 8 * FB;   // 8-byte elements per wave
-  static_assert(P >= 2 && P <= 32, "wave FFT supports N = 128 ... 2048");
+  static_assert(P >= 2 && P <= 32 && (is_pow2(P) || ((P % 3 == 0 || P % 5 == 0) && is_pow2(P / (P % 3 == 0 ? 3 : 5)))),
+                "wave FFT supports N = 64 P with P = 2^k, 3*2^k or 5*2^k, 2 <= P <= 32");
 };
 
 // Per-lane registers of the pipeline.
@@ -71,7 +71,7 @@ struct LaneRegs {
 
 // Tables (precomputed on the host in float64, stored as R):
 //   tw1[a*64 + l]  = w_N^{l a}                                   (P*64 complex)
-//   om[m*omS + oi] = sgn(oi) * w_64^{m * b(oi)},  m < 8          (8*omS complex), b(oi) = (lo+oi) >> LOGP
+//   om[m*omS + oi] = sgn(oi) * w_64^{m * b(oi)},  m < 8          (8*omS complex), b(oi) = (lo+oi) / P
 // `sgn` carries the output-side fftshift sign of fmc_core.h (even N): (-1)^(lo+oi).
 template <class R, int P, int NS, class Exec>
 FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
@@ -87,12 +87,9 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
     cpx<R> z[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) z[j] = r.v[j];
-    fft_dif<P, R>(z);
+    dft_reg<P, R>(z);
 #pragma unroll
-    for (int a = 0; a < P; ++a) {
-      const cpx<R> y = z[brev(a, G::LOGP)];
-      r.v[a] = (a == 0) ? y : cmul(y, tw1[a * WAVE + lane]);
-    }
+    for (int a = 0; a < P; ++a) r.v[a] = (a == 0) ? z[a] : cmul(z[a], tw1[a * WAVE + lane]);
 #pragma unroll
     for (int s = 0; s < NS; ++s) { r.xr[s] = (R)0; r.xi[s] = (R)0; }
   });
@@ -109,7 +106,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
       const int l0 = lane & 7, i = lane >> 3;
 #pragma unroll
       for (int jj = 0; jj < G::NB; ++jj)
-        if (P >= 8 || i < P) {
+        if ((P % 8 == 0) || i + 8 * jj < P) {
 #pragma unroll
           for (int m = 0; m < 8; ++m)
             X::unpack(r.v[jj * 8 + m], ex.ld(xbuf + (i + 8 * jj) * G::SE + l0 + 8 * m), c);
@@ -136,7 +133,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
       const int l0 = lane & 7, i = lane >> 3;
 #pragma unroll
       for (int jj = 0; jj < G::NB; ++jj)
-        if (P >= 8 || i < P) {
+        if ((P % 8 == 0) || i + 8 * jj < P) {
 #pragma unroll
           for (int b0 = 0; b0 < 8; ++b0)
             ex.st(xbuf + (i + 8 * jj) + G::FL * l0 + G::FB * b0, X::pack(r.v[jj * 8 + b0], c));
@@ -150,8 +147,8 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
           const int oi = lane + WAVE * s;
           if (oi < Np) {
             const int x = lo + oi;
-            const int a = x & (P - 1);
-            const int b0 = (x >> G::LOGP) & 7;
+            const int a = x % P;            // P is a compile-time constant: mask / shift for powers of two
+            const int b0 = (x / P) & 7;
             const E* f = xbuf + a + G::FB * b0;
 #pragma unroll
             for (int m = 0; m < 8; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + G::FL * m), c);
@@ -177,12 +174,11 @@ inline void build_tw1(cpx<R>* tw1, int P, CosSin cs) {
 }
 template <class R, class CosSin>
 inline void build_om(cpx<R>* om, int omS, int P, int lo, int Np, bool out_sign, CosSin cs) {
-  const int logp = ilog2(P);
   for (int m = 0; m < 8; ++m)
     for (int oi = 0; oi < omS; ++oi) {
       if (oi >= Np) { om[m * omS + oi] = mk<R>((R)0, (R)0); continue; }
       const int x = lo + oi;
-      const int b = (x >> logp) & 63;
+      const int b = (x / P) & 63;
       double c, s;
       cs((double)((m * b) % 64) / 64.0, &c, &s);
       const double sg = (out_sign && (x & 1)) ? -1.0 : 1.0;

@@ -104,6 +104,12 @@ int main() {
   bad += sweep<double, 3, 2>("f64", 1e-13);
   bad += sweep<double, 5, 2>("f64", 1e-13);
   bad += sweep<double, 6, 2>("f64", 1e-13);
+  bad += sweep<double, 7, 2>("f64", 1e-13);
+  bad += sweep<double, 9, 2>("f64", 1e-13);
+  bad += sweep<double, 14, 2>("f64", 1e-13);
+  bad += sweep<double, 18, 2>("f64", 1e-13);
+  bad += sweep<double, 28, 2>("f64", 1e-13);
+  bad += sweep<float, 18, 2>("f32", 2e-5);
   bad += sweep<double, 10, 2>("f64", 1e-13);
   bad += sweep<double, 12, 2>("f64", 1e-13);
   bad += sweep<double, 20, 2>("f64", 1e-13);

@@ -182,11 +182,12 @@ extern "C" int fastmc_device_count(int* n) {
   return 0;
 }
 
-// N = 64 P with P = 2^k, 3*2^k or 5*2^k, 2 <= P <= 32
+// N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32
 static bool wave_supported(int N) {
   if (N % 64 != 0) return false;
   switch (N / 64) {
-    case 2: case 3: case 4: case 5: case 6: case 8: case 10: case 12: case 16: case 20: case 24: case 32: return true;
+    case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 12: case 14: case 16: case 18: case 20:
+    case 24: case 28: case 32: return true;
     default: return false;
   }
 }
@@ -206,8 +207,8 @@ static void wave_config(const fastmc_ctx* h, size_t* lds, int* wpb) {
     }                                                                                                        \
     break;
   switch (h->P) {
-    FMC_CASE(2) FMC_CASE(3) FMC_CASE(4) FMC_CASE(5) FMC_CASE(6) FMC_CASE(8) FMC_CASE(10) FMC_CASE(12)
-    FMC_CASE(16) FMC_CASE(20) FMC_CASE(24) FMC_CASE(32)
+    FMC_CASE(2) FMC_CASE(3) FMC_CASE(4) FMC_CASE(5) FMC_CASE(6) FMC_CASE(7) FMC_CASE(8) FMC_CASE(9) FMC_CASE(10)
+    FMC_CASE(12) FMC_CASE(14) FMC_CASE(16) FMC_CASE(18) FMC_CASE(20) FMC_CASE(24) FMC_CASE(28) FMC_CASE(32)
     default: *lds = (size_t)1 << 30; *wpb = 1; break;
   }
 #undef FMC_CASE
@@ -260,7 +261,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
 
 extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
-  if (force == 1 && !wave_supported(h->N)) return fail(FASTMC_EINVAL, "wave kernels need N = 64 P with P = 2^k, 3*2^k or 5*2^k, 2 <= P <= 32");
+  if (force == 1 && !wave_supported(h->N)) return fail(FASTMC_EINVAL, "wave kernels need N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32");
   if (force == 0 || force == 1) h->path = force;
   return h->path;
 }
@@ -594,7 +595,12 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
         case 4: TRY((dispatch_wave_ns<R, 4>(h, RA, CA, S.mode, S.epi))); break;
         case 5: dispatch_wave<R, 5, 2>(h, RA, CA, S.mode, S.epi); break;
         case 6: dispatch_wave<R, 6, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 7: dispatch_wave<R, 7, 2>(h, RA, CA, S.mode, S.epi); break;
         case 8: TRY((dispatch_wave_ns<R, 8>(h, RA, CA, S.mode, S.epi))); break;
+        case 9: dispatch_wave<R, 9, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 14: dispatch_wave<R, 14, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 18: dispatch_wave<R, 18, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 28: dispatch_wave<R, 28, 2>(h, RA, CA, S.mode, S.epi); break;
         case 10: dispatch_wave<R, 10, 2>(h, RA, CA, S.mode, S.epi); break;
         case 12: dispatch_wave<R, 12, 2>(h, RA, CA, S.mode, S.epi); break;
         case 16: TRY((dispatch_wave_ns<R, 16>(h, RA, CA, S.mode, S.epi))); break;

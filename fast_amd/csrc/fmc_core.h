@@ -139,8 +139,8 @@ template <int N, class F>
 FMC_HD void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
 // Natural-order forward DFT of P values held in registers.  Powers of two: radix-2 DIF network;
-// P = 3*2^k or 5*2^k: one Cooley-Tukey level (Q strided power-of-two sub-transforms, twiddle,
-// M radix-Q butterflies with compile-time constants).
+// P = Q*2^k with Q = 3, 5, 7, 9: one Cooley-Tukey level (Q strided power-of-two sub-transforms,
+// twiddle, M radix-Q butterflies with compile-time constants).
 template <int P, class R>
 FMC_HD void dft_reg(cpx<R> (&v)[P]) {
   if constexpr (is_pow2(P)) {
@@ -151,9 +151,9 @@ FMC_HD void dft_reg(cpx<R> (&v)[P]) {
 #pragma unroll
     for (int a = 0; a < P; ++a) v[a] = t[a];
   } else {
-    constexpr int Q = (P % 3 == 0) ? 3 : 5;
-    constexpr int M = P / Q;
-    static_assert(P % Q == 0 && is_pow2(M), "supported sizes: 2^k, 3*2^k, 5*2^k");
+    constexpr int M = P & -P;      // largest power of two dividing P
+    constexpr int Q = P / M;       // odd part: one direct radix-Q stage (Q^2 complex MACs per butterfly)
+    static_assert(Q == 3 || Q == 5 || Q == 7 || Q == 9, "supported sizes: 2^k times 1, 3, 5, 7 or 9");
     cpx<R> y[Q][M];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {

@@ -7,7 +7,7 @@
 //                 + sub-harmonics, W * exp(i phi) and the pixel sum  ->  partial[b][xi][4]
 //                                                                 (rows 3-5, 5c)
 //   finalize    : sum the Np column partials, log-amplitude, |.|^2 (rows 5, 5b)
-// Two kernel families: "wave" (N = 64 P, P = 2^k, 3*2^k, 5*2^k <= 32, i.e. 128 ... 2048; fmc_wavefft.h)
+// Two kernel families: "wave" (N = 64 P, P = 2^k times 1, 3, 5, 7, 9, <= 32, i.e. 128 ... 2048; fmc_wavefft.h)
 // and "direct" (any N <= 4096).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -201,7 +201,8 @@ constexpr int ROWS_PER_WAVE = FMC_ROWS_PER_WAVE;   // rows kernel: consecutive k
 // P = 32 keeps 2 x 32 values per lane (>= 200 VGPRs) and 18 KiB of exchange buffer per wave: 6 waves
 // (A/B at 2048^2 f64: 6 waves 141k it/s vs 4 waves 114k it/s; 8 do not fit the LDS).
 // The general-window instantiation (NS = P) carries a large `om` table: 4 waves.  P = 10, 12, 20, 24
-// (3*2^k, 5*2^k): 8 waves (A/B at 640^2 / 768^2: +4 % / +1 % over 12, no spill at the 168-VGPR step).
+// (3*2^k, 5*2^k): 8 waves (A/B at 640^2 / 768^2: +4 % / +1 % over 12, no spill at the 168-VGPR step);
+// P = 18, 28 (radix-9 / radix-7 stage with many live temporaries): 4 waves, one per SIMD, no spill.
 template <class R, int P, int NS> struct WaveCfg {
 #ifndef FMC_WPB
 #define FMC_WPB 12
@@ -209,7 +210,7 @@ template <class R, int P, int NS> struct WaveCfg {
 #ifndef FMC_WPB_P32_F64
 #define FMC_WPB_P32_F64 6
 #endif
-  static constexpr int WPB = (NS != 2) ? 4 : (P == 32 ? (sizeof(R) == 8 ? FMC_WPB_P32_F64 : 6) : ((P > 16 || (!is_pow2(P) && P > 8)) ? 8 : FMC_WPB));
+  static constexpr int WPB = (NS != 2) ? 4 : (P == 32 ? (sizeof(R) == 8 ? FMC_WPB_P32_F64 : 6) : ((P > 16 && P / (P & -P) >= 7) ? 4 : (P > 24 ? 6 : ((P > 16 || (!is_pow2(P) && P > 8)) ? 8 : FMC_WPB))));
 };
 
 template <class R, int P>

@@ -1,6 +1,6 @@
 // fmc_wavefft.h -- one wavefront = one N-point row: output-pruned forward DFT, N = 64*P.
 //
-// A lane holds P inputs in registers (k = lane + 64*j), P = 2^k, 3*2^k or 5*2^k <= 32.  The transform is factored
+// A lane holds P inputs in registers (k = lane + 64*j), P = 2^k times 1, 3, 5, 7 or 9, <= 32.  The transform is factored
 //     N = P x 8 x 8 :  in-register radix-P  ->  LDS exchange  ->  in-register radix-8
 //                      ->  LDS exchange  ->  8-term sums for the WANTED outputs only
 // because FAST keeps only the Np x Np pupil window of every N x N screen
@@ -57,8 +57,9 @@ struct WaveGeom {
   static constexpr int FL = P + 2;
   static constexpr int FB = 8 * FL;
   static constexpr int XELEMS = (P * SE > 8 * FB) ? P * SE : 8 * FB;   // 8-byte elements per wave
-  static_assert(P >= 2 && P <= 32 && (is_pow2(P) || ((P % 3 == 0 || P % 5 == 0) && is_pow2(P / (P % 3 == 0 ? 3 : 5)))),
-                "wave FFT supports N = 64 P with P = 2^k, 3*2^k or 5*2^k, 2 <= P <= 32");
+  static_assert(P >= 2 && P <= 32 && (P / (P & -P) == 1 || P / (P & -P) == 3 || P / (P & -P) == 5 || P / (P & -P) == 7 ||
+                                      P / (P & -P) == 9),
+                "wave FFT supports N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32");
 };
 
 // Per-lane registers of the pipeline.

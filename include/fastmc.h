@@ -129,7 +129,8 @@ int fastmc_result_stats(fastmc_t* h, const double* thresholds, int n_thr, double
 int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches);
 
 /* Which kernel family the handle uses: 0 = direct (any N), 1 = wave-FFT (N = 64 P with
- * P = 2^k, 3*2^k or 5*2^k, i.e. 128, 192, 256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 2048).  force: -1 query only, 0/1 select (1 fails with EINVAL if unsupported). */
+ * P = 2^k times 1, 3, 5, 7 or 9, P <= 32: 128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024,
+ * 1152, 1280, 1536, 1792, 2048).  force: -1 query only, 0/1 select (1 fails with EINVAL if unsupported). */
 int fastmc_kernel_path(fastmc_t* h, int force);
 
 /* Realisations in flight per launch (batch).  0 = library default. */

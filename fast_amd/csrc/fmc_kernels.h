@@ -335,6 +335,7 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_cols_wave(Col
 
 // ================================================================== direct family (any N <= 4096)
 constexpr int DIRECT_THREADS = 256;
+constexpr int DIRECT_RESYNC = 16;   // terms between exact twiddle re-reads in the direct kernels
 
 template <class R, int MODE>
 __global__ __launch_bounds__(DIRECT_THREADS) void k_rows_direct(RowArgs<R> A) {
@@ -370,9 +371,18 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_rows_direct(RowArgs<R> A) {
     const int q = shifted_exponent_step(A.lo + oi, N);
     int e = (int)(((long long)q * (h + k0)) % N);
     cpx<R> acc = mk<R>((R)0, (R)0);
-    for (int k = k0; k < k1; ++k) {
-      acc = cfma(s_row[k], s_tw[e], acc);
-      e += q;
+    // running twiddle w_N^{e_k} by recurrence (no bank-conflicting table look-up per term), re-read
+    // exactly from the table every DIRECT_RESYNC terms so that rounding does not accumulate
+    const int e_step = (int)(((long long)q * DIRECT_RESYNC) % N);
+    const cpx<R> wq = s_tw[q];
+    for (int kb = k0; kb < k1; kb += DIRECT_RESYNC) {
+      cpx<R> wk = s_tw[e];
+      const int kend = min(k1, kb + DIRECT_RESYNC);
+      for (int k = kb; k < kend; ++k) {
+        acc = cfma(s_row[k], wk, acc);
+        wk = cmul(wk, wq);
+      }
+      e += e_step;
       if (e >= N) e -= N;
     }
     s_part[seg * A.Np + oi] = acc;
@@ -409,9 +419,16 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_cols_direct(ColArgs<R> A) {
     const int q = shifted_exponent_step(A.lo + yi, N);
     int e = (int)(((long long)q * (h + k0)) % N);
     cpx<R> part = mk<R>((R)0, (R)0);
-    for (int k = k0; k < k1; ++k) {
-      part = cfma(s_col[k], s_tw[e], part);
-      e += q;
+    const int e_step = (int)(((long long)q * DIRECT_RESYNC) % N);
+    const cpx<R> wq = s_tw[q];
+    for (int kb = k0; kb < k1; kb += DIRECT_RESYNC) {
+      cpx<R> wk = s_tw[e];
+      const int kend = min(k1, kb + DIRECT_RESYNC);
+      for (int k = kb; k < kend; ++k) {
+        part = cfma(s_col[k], wk, part);
+        wk = cmul(wk, wq);
+      }
+      e += e_step;
       if (e >= N) e -= N;
     }
     s_part[seg * A.Np + yi] = part;

@@ -17,6 +17,8 @@ from . import hostmath as hm
 
 logger = logging.getLogger(__name__)
 TWO_PI = 2 * np.pi
+# grid sizes served by the wave-FFT kernels: 64 * 2^k * {1, 3, 5, 7, 9}, 128 ... 2048 (fmc_wavefft.h)
+WAVE_FFT_SIZES = sorted(64 * q * 2 ** k for q in (1, 3, 5, 7, 9) for k in range(6) if 2 <= q * 2 ** k <= 32)
 
 
 # ----------------------------------------------------------------------------- geometry
@@ -85,6 +87,13 @@ def grid_size(p, atm):
         n_ap = int(2 * np.ceil(D / dx / 2)) + 2
         n_t = int(p['WIND_SPD'].max() * p['DT'] * p['NITER'] / p['DX'] / 2) if p['TEMPORAL'] else 0
         N = np.max([n_nyq, n_ap, n_t])
+        if p.get('GPU_ROUND_NPXLS', False):
+            # opt-in: the reference's auto rule gives arbitrary even sizes (164 for the shipped example);
+            # the next size of the fast kernel family samples the spectrum slightly finer
+            bigger = [s for s in WAVE_FFT_SIZES if s >= N]
+            if bigger:
+                logger.info(f"GPU_ROUND_NPXLS: auto NPXLS {N} -> {bigger[0]}")
+                N = bigger[0]
         logger.info(f"Auto set NPXLS to {N}")
         if p['AO_MODE'] == 'NOAO' and not np.isinf(p['L0']):
             n_l0 = int(2 * np.ceil((p['L0'] * 2) / dx) / 2)

@@ -141,3 +141,12 @@ def test_fits_round_trip(tmp_path):
     np.testing.assert_allclose(res.power, data[:5], rtol=1e-15)
     np.testing.assert_allclose(res._r, data[:5] / hdr["DIFFLIM"], rtol=1e-15)
     assert res.hdr["SEED"] == 1
+
+
+def test_optional_rounding_of_auto_grid_size():
+    g = load_golden("e2e_default164")
+    p = fast_amd.conf.ConfigParser(dict(params_from_json(g["params_json"]))).config
+    assert host.build_problem(dict(p)).N == 164                      # the reference's auto rule, untouched by default
+    p["GPU_ROUND_NPXLS"] = True
+    assert host.build_problem(dict(p)).N == 192
+    assert host.WAVE_FFT_SIZES == [128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1152, 1280, 1536, 1792, 2048]

@@ -145,8 +145,14 @@ def main():
     backend = os.environ.get("FASTMC_BENCH_BACKEND", "nccl")
     device_index = int(os.environ.get("FASTMC_BENCH_DEVICE", local_rank))
     if dist_on:
+        # torch FIRST: its wheel bundles its own libamdhip64 / libhsa-runtime64; whichever HIP runtime
+        # is loaded first serves the whole process, and torch cannot run on /opt/rocm's newer one
+        # ("No HIP GPUs are available"), while libfastmc.so runs fine on torch's.
         import torch
         import torch.distributed as dist
+        ndev = torch.cuda.device_count()
+        if ndev > 0 and device_index >= ndev:      # launcher restricted the visible devices per rank
+            device_index %= ndev
         if backend == "nccl":
             torch.cuda.set_device(device_index)
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))

@@ -49,6 +49,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise FastMCError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or `make -C fast_amd/csrc`).  fast_amd has no CPU fallback.")
+    # Note for programs that also use PyTorch (multi-GPU launchers): import torch first -- see dist.py.
     L = C.CDLL(LIB_PATH)
     dp, vp, i64, u64 = C.POINTER(C.c_double), C.c_void_p, C.c_int64, C.c_uint64
     L.fastmc_version.restype = C.c_int

@@ -12,6 +12,12 @@ Transports for the final exchange:
   TorchTransport -- torch.distributed collectives on host tensors (backend gloo on CPU in the
                     tests; also the stand-in if RCCL cannot initialise).
 torch is imported only here and only when a process group exists; the compute path never sees it.
+
+Load order: PyTorch's ROCm wheel bundles its own libamdhip64 / libhsa-runtime64, and the first HIP
+runtime loaded serves the whole process.  A program that uses both must `import torch` BEFORE the
+first fast_amd call that loads libfastmc.so (torch cannot run on /opt/rocm's newer runtime; the
+library runs on either).  `torch.distributed.run` launchers that initialise the process group
+first, as bench.py does, satisfy this automatically.
 """
 import numpy as np
 

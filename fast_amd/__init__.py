@@ -9,7 +9,8 @@ from . import conf
 from . import turbulence_models
 from . import host
 from . import _lib
+from . import comms
 from ._lib import FastMCError
 
 __version__ = "0.1.0"
-__all__ = ["Fast", "FastResult", "load", "conf", "turbulence_models", "host", "FastMCError"]
+__all__ = ["Fast", "FastResult", "load", "conf", "turbulence_models", "host", "comms", "FastMCError"]

@@ -18,13 +18,20 @@ EXPORTS = [
     "fastmc_set_spectrum", "fastmc_set_pupil", "fastmc_set_subharm", "fastmc_run", "fastmc_run_coeffs",
     "fastmc_screens_coeffs", "fastmc_screens", "fastmc_rng_coeffs", "fastmc_rng_logamp", "fastmc_histogram",
     "fastmc_result_stats", "fastmc_last_timing", "fastmc_kernel_path", "fastmc_set_batch", "fastmc_powerspec",
-    "fastmc_set_layer_screens", "fastmc_temporal_chunk",
+    "fastmc_set_layer_screens", "fastmc_temporal_chunk", "fastmc_link_metrics",
     "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_gather", "fastmc_comm_destroy",
 ]
 
 
 class FastMCError(RuntimeError):
     pass
+
+
+class LinkQuery(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("p0", C.c_double), ("p1", C.c_double)]
+
+
+LM_FADE, LM_BER_OOK, LM_SEP_QAM = 0, 1, 2
 
 
 class PsParams(C.Structure):
@@ -71,6 +78,7 @@ def lib():
     L.fastmc_temporal_chunk.argtypes = [vp, dp, dp, C.POINTER(C.c_int32), C.c_int, dp, C.c_int, dp]
     L.fastmc_histogram.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.POINTER(i64)]
     L.fastmc_result_stats.argtypes = [vp, dp, C.c_int, dp]
+    L.fastmc_link_metrics.argtypes = [vp, C.c_int, dp, i64, C.POINTER(LinkQuery), C.c_int, dp]
     L.fastmc_last_timing.argtypes = [vp, dp, C.POINTER(i64)]
     L.fastmc_kernel_path.argtypes = [vp, C.c_int]
     L.fastmc_set_batch.argtypes = [vp, C.c_int]
@@ -255,6 +263,21 @@ class Handle:
                                       None if hist is None else hist.ctypes.data_as(C.POINTER(C.c_int64)),
                                       float(lo), float(hi), int(nb)))
         return allp, hist
+
+
+def link_metrics(queries, samples=None, handle=None, device=0):
+    """fastmc_link_metrics: queries = [(kind, p0, p1), ...] over `samples` (uploaded) or, when samples
+    is None, over the last run's results resident on `handle`'s device.  Returns (n_queries, 4)."""
+    q = (LinkQuery * len(queries))(*[LinkQuery(int(k), float(a), float(b)) for k, a, b in queries])
+    out = np.zeros((len(queries), 4))
+    if samples is not None:
+        x = _f64(np.asarray(samples, dtype=float).ravel())
+        _chk(lib().fastmc_link_metrics(None, int(device), _dptr(x), len(x), q, len(queries), _dptr(out)))
+    else:
+        if handle is None:
+            raise FastMCError("link_metrics needs samples or a handle")
+        _chk(lib().fastmc_link_metrics(handle._h, 0, None, 0, q, len(queries), _dptr(out)))
+    return out
 
 
 def comm_unique_id():

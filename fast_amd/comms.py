@@ -1,0 +1,93 @@
+"""Link metrics over the power vector: the reference's fast/comms.py:171-262 surface
+(fade_prob, fade_dur, ber_ook, sep_qam, ber_qam, Q), evaluated on the GPU through
+fastmc_link_metrics.  Same names, arguments and NaN conventions as the reference.
+
+Each function takes the sample vector the reference takes (uploaded for the call).  Pass a
+`fast_amd.Fast` object instead of an array to reduce the last run's results where they already
+are, on the device, without moving the vector (order-independent metrics only: fade_dur needs
+the FastResult ordering and always takes the vector).
+
+The Monte-Carlo symbol simulator (Modulator / FastFSOC, comms.py:13-168) and the GMI tools are
+outside the hot-path scope and are not provided.
+"""
+import numpy
+
+from . import _lib
+
+
+def _metrics(queries, samples):
+    from .fast import Fast
+    if isinstance(samples, Fast):
+        return _lib.link_metrics(queries, handle=samples._handle)
+    dev = _lib.default_device()
+    return _lib.link_metrics(queries, samples=numpy.abs(samples) ** 2 if numpy.iscomplexobj(samples) else samples, device=dev)
+
+
+def fade_counts(I, threshold):
+    """(n, n_below, n_complete, samples_in_complete): the integers fade_prob and fade_dur are formed
+    from.  A fade is complete when it starts after the first sample and ends before the last
+    (comms.py:181-186: rising edges of the mask, final segment dropped when it is still fading)."""
+    I = numpy.asarray(I)
+    n = I.size
+    n_below, n_rise, first_clear, last_clear = _lib.link_metrics([(_lib.LM_FADE, threshold, 0.0)], samples=I,
+                                                                 device=_lib.default_device())[0]
+    n_below, n_rise = int(n_below), int(n_rise)
+    lead = int(first_clear)                       # length of a fade already running at sample 0
+    trail = n - 1 - int(last_clear)               # length of a fade still running at the end
+    if n_rise == 0:                               # no fade starts inside the record
+        return n, n_below, 0, 0
+    open_end = 1 if trail > 0 else 0
+    return n, n_below, n_rise - open_end, n_below - lead - (trail if open_end else 0)
+
+
+def fade_prob(I, threshold, min_fades=30):
+    """comms.py:171-177.  I may be a Fast object (relative powers of the last run, on the device)."""
+    from .fast import Fast
+    if isinstance(I, Fast):
+        n_below = int(_lib.link_metrics([(_lib.LM_FADE, threshold, 0.0)], handle=I._handle)[0, 0])
+        n = I._handle.result_stats()["n"]
+    else:
+        n, n_below, _, _ = fade_counts(I, threshold)
+    if n_below < min_fades:
+        return numpy.nan
+    return n_below / n
+
+
+def fade_dur(I, threshold, dt=1, min_fades=30):
+    """comms.py:180-195: mean duration of the complete fades, NaN with fewer than min_fades of them."""
+    _, _, n_complete, total = fade_counts(I, threshold)
+    if n_complete < min_fades:
+        return numpy.nan
+    return total / n_complete * dt
+
+
+def ber_ook(EbN0, samples=None):
+    """comms.py:198-222.  samples=None: no atmosphere (one sample of unit power)."""
+    s, _, n, _ = _metrics([(_lib.LM_BER_OOK, EbN0, 0.0)], numpy.ones(1) if samples is None else samples)[0]
+    return s / n
+
+
+def sep_qam(M, EsN0, samples=None):
+    """comms.py:225-242."""
+    s, _, n, _ = _metrics([(_lib.LM_SEP_QAM, M, EsN0)], numpy.ones(1) if samples is None else samples)[0]
+    return s / n
+
+
+def ber_qam(M, EbN0, samples=None):
+    """comms.py:245-255: nearest-neighbour errors with Gray coding."""
+    return 1 / numpy.log2(M) * sep_qam(M, 10 * numpy.log10(numpy.log2(M)) + EbN0, samples)
+
+
+def Q(x):
+    """comms.py:258-262, through the same device code: Q(x) = ber_ook at snr = x with no atmosphere."""
+    x = numpy.asarray(x, dtype=float)
+    flat = numpy.atleast_1d(x).ravel()
+    out = numpy.empty(flat.shape)
+    for i, v in enumerate(flat):
+        if v > 0:
+            out[i] = ber_ook(20 * numpy.log10(v))
+        elif v == 0:
+            out[i] = 0.5
+        else:
+            out[i] = 1.0 - ber_ook(20 * numpy.log10(-v))
+    return out.reshape(x.shape) if x.ndim else float(out[0])

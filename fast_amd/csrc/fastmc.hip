@@ -794,6 +794,56 @@ extern "C" int fastmc_result_stats(fastmc_t* h, const double* thresholds, int n_
   return 0;
 }
 
+extern "C" int fastmc_link_metrics(fastmc_t* h, int device_id, const double* samples, int64_t n, const fastmc_link_query* queries,
+                                   int n_queries, double* out) {
+  if (!queries || !out || n_queries < 1) return fail(FASTMC_EINVAL, "bad argument");
+  for (int k = 0; k < n_queries; ++k) {
+    const fastmc_link_query& q = queries[k];
+    if (q.kind < LM_FADE || q.kind > LM_SEP_QAM) return fail(FASTMC_EINVAL, "unknown link query kind");
+    if (q.kind == LM_SEP_QAM && !(q.p0 > 1.0)) return fail(FASTMC_EINVAL, "QAM order must exceed 1");
+  }
+  hipStream_t stream = nullptr;
+  const double* x = nullptr;
+  int coherent = 0;
+  ScratchBuf up;
+  if (samples) {
+    if (n < 1) return fail(FASTMC_EINVAL, "empty sample vector");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FASTMC_ENODEV, "no HIP device");
+    if (device_id < 0 || device_id >= ndev) return fail(FASTMC_EINVAL, "device_id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(hipMalloc((void**)&up.p, (size_t)n * 8));
+    HIPCHK(hipMemcpy(up.p, samples, (size_t)n * 8, hipMemcpyHostToDevice));
+    x = (const double*)up.p;
+  } else {
+    if (!h) return fail(FASTMC_EINVAL, "neither samples nor a handle");
+    if (h->last_n_iter <= 0) return fail(FASTMC_ESTATE, "no run results on the device");
+    HIPCHK(hipSetDevice(h->device));
+    stream = h->stream;
+    x = h->out;
+    n = h->last_n_iter;
+    coherent = h->last_coherent;
+  }
+  const int nblocks = (int)std::min<int64_t>(256, (n + 255) / 256), stride = STATS_NQ + STATS_MAX_THR;
+  ScratchBuf part, sums, res;
+  HIPCHK(hipMalloc((void**)&part.p, (size_t)256 * stride * 8));
+  HIPCHK(hipMalloc((void**)&sums.p, (size_t)stride * 8));
+  HIPCHK(hipMalloc((void**)&res.p, (size_t)n_queries * 4 * 8));
+  // sum of the vector (for the mean the BER / SEP integrals normalise by): the statistics pass
+  hipLaunchKernelGGL(k_stats_partial, dim3(256), dim3(256), 0, stream, x, n, coherent, (const double*)nullptr, 0, (double*)part.p);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(64), 0, stream, (const double*)part.p, 256, STATS_NQ, (double*)sums.p);
+  for (int k = 0; k < n_queries; ++k) {
+    hipLaunchKernelGGL(k_link_query, dim3(nblocks), dim3(256), 0, stream, x, n, coherent, (const double*)sums.p, (int)queries[k].kind,
+                       queries[k].p0, queries[k].p1, (double*)part.p);
+    hipLaunchKernelGGL(k_link_final, dim3(1), dim3(64), 0, stream, (const double*)part.p, nblocks, n, (const double*)sums.p,
+                       (int)queries[k].kind, (double*)res.p + 4 * k);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, res.p, (size_t)n_queries * 4 * 8, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  return 0;
+}
+
 extern "C" int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches) {
   if (!h || !times_ms || !launches) return fail(FASTMC_EINVAL, "null argument");
   for (int i = 0; i < 4; ++i) { times_ms[i] = h->t_ms[i]; launches[i] = h->t_n[i]; }

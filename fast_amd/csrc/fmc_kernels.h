@@ -692,6 +692,76 @@ __global__ void k_stats_final(const double* partial, int nblocks, int nq, double
   result[i] = v;
 }
 
+// ================================================================== link metrics (fast/comms.py:171-262)
+// One launch per query; every block leaves 4 partial values combined by k_link_final with the
+// operators (+, +, min, max).  `mean` is read from the statistics pass (sum r / n).
+constexpr int LM_FADE = 0, LM_BER_OOK = 1, LM_SEP_QAM = 2;
+
+__device__ __forceinline__ double link_sample(const double* x, int64_t i, int coherent) {
+  return coherent ? x[2 * i] * x[2 * i] + x[2 * i + 1] * x[2 * i + 1] : x[i];
+}
+
+__device__ __forceinline__ double q_function(double v) { return 0.5 * erfc(v * 0.70710678118654752440); }
+
+__global__ __launch_bounds__(256) void k_link_query(const double* x, int64_t n, int coherent, const double* sum_r, int kind,
+                                                    double p0, double p1, double* partial) {
+  __shared__ double s_q[4][4];
+  double q0 = 0.0, q1 = 0.0, q2 = (double)n, q3 = -1.0;
+  const double inv_mean = (double)n / sum_r[0];
+  double a = 0.0, c = 0.0;
+  if (kind == LM_BER_OOK) a = sqrt(pow(10.0, p0 / 10.0));
+  if (kind == LM_SEP_QAM) {
+    a = 3.0 / (p0 - 1.0) * pow(10.0, p1 / 10.0);
+    c = (sqrt(p0) - 1.0) / sqrt(p0);
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double r = link_sample(x, i, coherent);
+    if (kind == LM_FADE) {
+      const bool below = r < p0;
+      if (below) {
+        q0 += 1.0;
+        if (i > 0 && !(link_sample(x, i - 1, coherent) < p0)) q1 += 1.0;
+      } else {
+        q2 = fmin(q2, (double)i);
+        q3 = fmax(q3, (double)i);
+      }
+    } else if (kind == LM_BER_OOK) {
+      q0 += q_function(r * inv_mean * a);
+    } else {
+      const double s = r * inv_mean;
+      const double q = q_function(sqrt(a * s * s));
+      q0 += 4.0 * (c * q - c * c * q * q);
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int o = 32; o >= 1; o >>= 1) {
+    q0 += __shfl_xor(q0, o, 64);
+    q1 += __shfl_xor(q1, o, 64);
+    q2 = fmin(q2, __shfl_xor(q2, o, 64));
+    q3 = fmax(q3, __shfl_xor(q3, o, 64));
+  }
+  if (lane == 0) { s_q[wv][0] = q0; s_q[wv][1] = q1; s_q[wv][2] = q2; s_q[wv][3] = q3; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w2 = 1; w2 < 4; ++w2) {
+      q0 += s_q[w2][0]; q1 += s_q[w2][1]; q2 = fmin(q2, s_q[w2][2]); q3 = fmax(q3, s_q[w2][3]);
+    }
+    double* o = partial + 4 * (size_t)blockIdx.x;
+    o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
+  }
+}
+
+__global__ void k_link_final(const double* partial, int nblocks, int64_t n, const double* sum_r, int kind, double* result) {
+  if (threadIdx.x != 0) return;
+  double q0 = 0.0, q1 = 0.0, q2 = (double)n, q3 = -1.0;
+  for (int b = 0; b < nblocks; ++b) {       // fixed order: the sums do not depend on scheduling
+    q0 += partial[4 * b]; q1 += partial[4 * b + 1];
+    q2 = fmin(q2, partial[4 * b + 2]); q3 = fmax(q3, partial[4 * b + 3]);
+  }
+  if (kind == LM_FADE) { result[0] = q0; result[1] = q1; result[2] = q2; result[3] = q3; }
+  else { result[0] = q0; result[1] = sum_r[0] / (double)n; result[2] = (double)n; result[3] = 0.0; }
+}
+
 // ================================================================== generator read-back (parity tests)
 __global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, double* out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;

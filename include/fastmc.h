@@ -123,6 +123,28 @@ int fastmc_histogram(fastmc_t* h, double lo_db, double hi_db, int nbins, int64_t
  * relative to the diffraction limit; thresholds in the same units; n_thr <= 16. */
 int fastmc_result_stats(fastmc_t* h, const double* thresholds, int n_thr, double* stats);
 
+/* Link metrics over a power vector, reduced on the device (fast/comms.py:171-262: fade_prob 171-177,
+ * fade_dur 180-195, ber_ook 198-222, sep_qam 225-242, ber_qam 245-255, Q 258-262).
+ * The vector is `samples` (n host doubles, copied to device `device_id`; h may be NULL), or, when
+ * samples == NULL, the last run's results resident on h's device (|a|^2 for a coherent run; n ignored).
+ * out: 4 doubles per query --
+ *   FASTMC_LM_FADE   p0 = threshold (units of the vector):
+ *       [count(x < p0), rising edges (x[i] < p0 <= x[i-1], i >= 1), index of the first sample >= p0 (n if
+ *        none), index of the last sample >= p0 (-1 if none)]; the caller forms fade_prob and the mean
+ *        duration of the fades that start and end inside the record from these (fast_amd/comms.py).
+ *   FASTMC_LM_BER_OOK p0 = Eb/N0 [dB]:        [sum_i Q(s_i * sqrt(10^(p0/10))), mean(x), n, 0], s = x / mean(x)
+ *   FASTMC_LM_SEP_QAM p0 = M, p1 = Es/N0 [dB]: [sum_i 4 (c q_i - c^2 q_i^2), mean(x), n, 0],
+ *       q_i = Q(sqrt(3/(M-1) 10^(p1/10) s_i^2)), c = (sqrt(M)-1)/sqrt(M). */
+#define FASTMC_LM_FADE 0
+#define FASTMC_LM_BER_OOK 1
+#define FASTMC_LM_SEP_QAM 2
+typedef struct {
+  int32_t kind;
+  double p0, p1;
+} fastmc_link_query;
+int fastmc_link_metrics(fastmc_t* h, int device_id, const double* samples, int64_t n,
+                        const fastmc_link_query* queries, int n_queries, double* out);
+
 /* Timing of the last fastmc_run / fastmc_run_coeffs, measured with HIP events on the
  * library's own stream: total ms, and per kernel family [rows, cols, finalize] ms and
  * launch counts.  times_ms: 4 doubles, launches: 4 int64. */

@@ -451,6 +451,53 @@ def result_stats(r, dl):
 
 
 # --------------------------------------------------------------------------
+# link metrics over the power vector      fast/comms.py:171-262
+# --------------------------------------------------------------------------
+def _fade_runs(I, threshold):
+    """Run-length view of the fade mask: (start, length) of every maximal run of I < threshold."""
+    m = np.asarray(I) < threshold
+    edges = np.flatnonzero(np.diff(np.concatenate(([0], m.view(np.int8), [0]))))
+    return edges[0::2], edges[1::2] - edges[0::2], m
+
+
+def fade_prob(I, threshold, min_fades=30):                       # comms.py:171-177
+    below = int((np.asarray(I) < threshold).sum())
+    return below / len(I) if below >= min_fades else np.nan
+
+
+def fade_dur(I, threshold, dt=1, min_fades=30):                  # comms.py:180-195
+    """Mean length of the fades that both start and end inside the record: a run touching the
+    first sample has no rising edge (diff == 1) and a run touching the last sample has not ended."""
+    start, length, m = _fade_runs(I, threshold)
+    keep = (start > 0) & (start + length < len(m))
+    if keep.sum() < min_fades:
+        return np.nan
+    return length[keep].mean() * dt
+
+
+def q_function(x):                                               # comms.py:258-262
+    from scipy.special import erfc
+    return 0.5 * erfc(np.asarray(x) / np.sqrt(2.0))
+
+
+def ber_ook(EbN0, samples=None):                                 # comms.py:198-222
+    snr = np.sqrt(10 ** (EbN0 / 10))
+    s = 1.0 if samples is None else samples / np.mean(samples)
+    return np.mean(q_function(s * snr))
+
+
+def sep_qam(M, EsN0, samples=None):                              # comms.py:225-242
+    s = 1.0 if samples is None else samples / np.mean(samples)
+    pf = (np.sqrt(M) - 1) / np.sqrt(M)
+    q = q_function(np.sqrt(3 / (M - 1) * 10 ** (EsN0 / 10) * s ** 2))
+    return 4 * np.mean(pf * q - pf ** 2 * q ** 2)
+
+
+def ber_qam(M, EbN0, samples=None):                              # comms.py:245-255
+    return sep_qam(M, 10 * np.log10(np.log2(M)) + EbN0, samples) / np.log2(M)
+
+
+# --------------------------------------------------------------------------
 # Temporal (frozen-flow) mode -- SURVEY 8f rank 2
 #   fast/fast.py:846-864 (frequencies), 394-405 (high-resolution pupil filter),
 #   538-587 (shifts, temporal log-amplitude spectrum), 607-637 (shifted screens),

@@ -538,3 +538,46 @@ def test_f32_pipeline_tracks_f64_on_the_same_device_draws(N):
         out[prec + "_rms"] = scr.std()
     assert out["f64_rms"] > 2.0                      # radians rms over the window of one screen
     np.testing.assert_allclose(out["f32"], out["f64"], rtol=5e-4, atol=1e-9)
+
+
+def test_link_metrics_match_reference_fixtures():
+    """fast_amd.comms (device reductions) vs the reference's fast/comms.py:171-262 outputs: integer counts
+    behind fade_prob / fade_dur exact (NaN conventions included); erfc integrals rtol 1e-11."""
+    from fast_amd import comms
+    d = load_golden("comms_metrics")
+    thr, eb, Ms, dt = d["thresholds"], d["ebn0"], d["Ms"], float(d["dt"])
+    for n in d["names"]:
+        v = d["v_" + n]
+        np.testing.assert_array_equal([comms.fade_prob(v, t) for t in thr], d["fade_prob_" + n])
+        np.testing.assert_array_equal([comms.fade_prob(v, t, 5) for t in thr], d["fade_prob_min5_" + n])
+        np.testing.assert_allclose([comms.fade_dur(v, t, dt) for t in thr], d["fade_dur_" + n], rtol=1e-14)
+        np.testing.assert_allclose([comms.fade_dur(v, t, dt, 5) for t in thr], d["fade_dur_min5_" + n], rtol=1e-14)
+        np.testing.assert_allclose([comms.ber_ook(s, v) for s in eb], d["ber_ook_" + n], rtol=1e-11)
+        np.testing.assert_allclose([[comms.sep_qam(M, s, v) for s in eb] for M in Ms], d["sep_qam_" + n], rtol=1e-11)
+        np.testing.assert_allclose([[comms.ber_qam(M, s, v) for s in eb] for M in Ms], d["ber_qam_" + n], rtol=1e-11)
+    np.testing.assert_allclose([comms.ber_ook(s) for s in eb], d["ber_ook_nosamples"], rtol=1e-12)
+    np.testing.assert_allclose([[comms.ber_qam(M, s) for s in eb] for M in Ms], d["ber_qam_nosamples"], rtol=1e-12)
+    np.testing.assert_allclose(comms.Q(np.array([-1.0, 0.0, 0.5, 3.0])), R.q_function(np.array([-1.0, 0.0, 0.5, 3.0])), rtol=1e-12)
+
+
+def test_link_metrics_on_resident_results_match_oracle():
+    """Metrics reduced where the run left its results (no vector transfer) equal the oracle's on the
+    returned vector; random long series incl. fades crossing block boundaries vs the run-length oracle."""
+    from fast_amd import comms
+    p = params_from_json(load_golden("e2e_noao_L0")["params_json"])
+    p.update({"NITER": 4000, "NCHUNKS": 4, "SEED": 5, "GPU_RNG": "device"})
+    sim = fast_amd.Fast(p)
+    r = sim.run()._r
+    thr = float(np.quantile(r, 0.2))
+    assert comms.fade_prob(sim, thr) == R.fade_prob(r, thr)
+    np.testing.assert_allclose(comms.ber_ook(8.0, sim), R.ber_ook(8.0, r), rtol=1e-11)
+    np.testing.assert_allclose(comms.ber_qam(16, 12.0, sim), R.ber_qam(16, 12.0, r), rtol=1e-11)
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 255, 256, 257, 65536 + 17, 300001):
+        x = np.exp(np.convolve(rng.normal(0, 1, n + 40), np.ones(41) / 6.4, mode="valid"))
+        for t in (0.5, 1.0, 2.0):
+            assert comms.fade_counts(x, t)[1] == int((x < t).sum())
+            a, b = comms.fade_dur(x, t, 0.5, 3), R.fade_dur(x, t, 0.5, 3)
+            assert (np.isnan(a) and np.isnan(b)) or a == b
+    with pytest.raises(fast_amd.FastMCError):
+        _lib.link_metrics([(7, 0.0, 0.0)], samples=np.ones(4))

@@ -129,3 +129,21 @@ def test_temporal_mode_matches_reference(name):
                                float(g["logamp_var"]), g["temporal_logamp_powerspec"], g["wind_vector"], p["DT"], N, Np,
                                coherent=p["COHERENT"])
     np.testing.assert_allclose(r, g["r"], rtol=1e-9)
+
+
+def test_link_metrics_match_reference():
+    """oracle fade / BER restatement vs reference fast/comms.py:171-262 (comms_metrics.npz)."""
+    d = load_golden("comms_metrics")
+    thr, eb, Ms, dt = d["thresholds"], d["ebn0"], d["Ms"], float(d["dt"])
+    for n in d["names"]:
+        v = d["v_" + n]
+        np.testing.assert_array_equal([R.fade_prob(v, t) for t in thr], d["fade_prob_" + n])
+        np.testing.assert_array_equal([R.fade_prob(v, t, 5) for t in thr], d["fade_prob_min5_" + n])
+        np.testing.assert_allclose([R.fade_dur(v, t, dt) for t in thr], d["fade_dur_" + n], rtol=1e-14)
+        np.testing.assert_allclose([R.fade_dur(v, t, dt, 5) for t in thr], d["fade_dur_min5_" + n], rtol=1e-14)
+        np.testing.assert_allclose([R.ber_ook(s, v) for s in eb], d["ber_ook_" + n], rtol=1e-13)
+        np.testing.assert_allclose([[R.sep_qam(M, s, v) for s in eb] for M in Ms], d["sep_qam_" + n], rtol=1e-13)
+        np.testing.assert_allclose([[R.ber_qam(M, s, v) for s in eb] for M in Ms], d["ber_qam_" + n], rtol=1e-13)
+    np.testing.assert_allclose([R.ber_ook(s) for s in eb], d["ber_ook_nosamples"], rtol=1e-14)
+    np.testing.assert_allclose([[R.sep_qam(M, s) for s in eb] for M in Ms], d["sep_qam_nosamples"], rtol=1e-14)
+    np.testing.assert_allclose([[R.ber_qam(M, s) for s in eb] for M in Ms], d["ber_qam_nosamples"], rtol=1e-14)

@@ -297,6 +297,44 @@ def stat_ref():
          params_json=np.array(params_to_json(p)), params2_json=np.array(params_to_json(p2)), r_ao=r_ao, r_noao=r_no)
 
 
+def comms_metrics():
+    """Reference fade statistics and BER / SEP integrals (comms.py:171-262) on explicit sample vectors:
+    a correlated log-normal series with many fades, its edge-case slices, and the stat_ref NOAO powers."""
+    from fast import comms
+    rng = np.random.default_rng(2024)
+    n = 40000
+    e = rng.normal(0, 1, n)
+    x = np.empty(n)
+    a = 0.97
+    x[0] = e[0]
+    for i in range(1, n):
+        x[i] = a * x[i - 1] + np.sqrt(1 - a * a) * e[i]
+    series = np.exp(0.6 * x - 0.18)                        # mean ~1, fades below 0.3 last tens of samples
+    d = np.load(os.path.join(OUT, "stat_ref_256.npz"))
+    vectors = {"series": series, "noao": d["r_noao"], "ao": d["r_ao"],
+               "starts_in_fade": series[np.argmax(series < 0.3):][:6000],
+               "ends_in_fade": series[:len(series) - np.argmax(series[::-1] < 0.3)][-6000:],
+               "all_below": np.full(50, 0.1), "none_below": np.full(50, 2.0), "few": series[:400]}
+    thresholds = np.array([0.1, 0.3, 0.5, 1.0])
+    ebn0 = np.array([0.0, 6.0, 10.0, 14.0])
+    Ms = np.array([4, 16, 64])
+    out = {}
+    for name, v in vectors.items():
+        out["v_" + name] = v
+        out["fade_prob_" + name] = np.array([comms.fade_prob(v, t) for t in thresholds])
+        out["fade_prob_min5_" + name] = np.array([comms.fade_prob(v, t, min_fades=5) for t in thresholds])
+        out["fade_dur_" + name] = np.array([comms.fade_dur(v, t, dt=2e-3) for t in thresholds])
+        out["fade_dur_min5_" + name] = np.array([comms.fade_dur(v, t, dt=2e-3, min_fades=5) for t in thresholds])
+        out["ber_ook_" + name] = np.array([comms.ber_ook(s, v) for s in ebn0])
+        out["sep_qam_" + name] = np.array([[comms.sep_qam(M, s, v) for s in ebn0] for M in Ms])
+        out["ber_qam_" + name] = np.array([[comms.ber_qam(M, s, v) for s in ebn0] for M in Ms])
+    out["ber_ook_nosamples"] = np.array([comms.ber_ook(s) for s in ebn0])
+    out["sep_qam_nosamples"] = np.array([[comms.sep_qam(M, s) for s in ebn0] for M in Ms])
+    out["ber_qam_nosamples"] = np.array([[comms.ber_qam(M, s) for s in ebn0] for M in Ms])
+    save("comms_metrics", "reference comms.fade_prob / fade_dur / ber_ook / sep_qam / ber_qam on explicit sample vectors",
+         False, names=np.array(list(vectors)), thresholds=thresholds, ebn0=ebn0, Ms=Ms, dt=np.array(2e-3), **out)
+
+
 def default_cfg():
     h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
     p = dict(fast.conf.DEFAULTS)
@@ -332,7 +370,8 @@ def main():
         if only[0].startswith("--only-e2e="):
             e2e(only[0].split("=", 1)[1].split(","))
         else:
-            {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref}[only[0]]()
+            {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref,
+             "--only-comms": comms_metrics}[only[0]]()
         for name, size, st, note in MANIFEST:
             print(f"| {name}.npz | {size} | {st} | {note} |")
         return
@@ -343,6 +382,7 @@ def main():
     temporal()
     mean_irradiance()
     stat_ref()
+    comms_metrics()
     p = default_cfg()
     if "--no-big" not in sys.argv:
         big(p)

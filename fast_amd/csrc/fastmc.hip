@@ -422,8 +422,14 @@ static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
   const size_t lds = wave_lds_bytes<R, P, NS>(A.omS);
   hipFuncSetAttribute((const void*)k_rows_wave<R, P, NS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   constexpr int WPB = WaveCfg<R, P, NS>::WPB;
+#if FMC_ROWMAP == 0
   const int items = A.nb * (A.N / ROWS_PER_WAVE);
-  hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, A);
+  const int blocks = (items + WPB - 1) / WPB;
+#else
+  constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
+  const int blocks = (A.N / LR) * ((A.nb + BPG - 1) / BPG);
+#endif
+  hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE>), dim3(blocks), dim3(WPB * 64), lds, h->stream, A);
 }
 template <class R, int P, int NS, int EPI>
 static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {

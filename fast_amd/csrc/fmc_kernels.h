@@ -195,7 +195,10 @@ struct GpuExec {
 #ifndef FMC_ROWS_PER_WAVE
 #define FMC_ROWS_PER_WAVE 8
 #endif
-constexpr int ROWS_PER_WAVE = FMC_ROWS_PER_WAVE;   // rows kernel: consecutive ky per wave
+constexpr int ROWS_PER_WAVE = FMC_ROWS_PER_WAVE;   // rows kernel: rows per wave
+#ifndef FMC_ROWMAP
+#define FMC_ROWMAP 1
+#endif
 // Waves per workgroup: the twiddle tables are staged once per workgroup, so bigger groups leave
 // more LDS for exchange buffers: 12 waves = 3 per SIMD at 132 VGPRs (f64, P = 16).
 // P = 32 keeps 2 x 32 values per lane (>= 200 VGPRs) and 18 KiB of exchange buffer per wave: 6 waves
@@ -238,24 +241,57 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   E* xbuf = s_x + w * G::XELEMS;
+  const int N = G::N;
+  LaneRegs<R, P, NS> regs;
+  GpuExec<R, P, NS> ex{lane, regs};
+#if FMC_ROWMAP == 0
   // work item = (row group of 8 consecutive ky, realisation b), b fastest: the waves of a block
   // colour the SAME spectrum rows for different realisations (amp rows shared in L1/L2)
-  const int N = G::N;
   const int item = blockIdx.x * WaveCfg<R, P, NS>::WPB + w;
   if (item >= A.nb * (N / ROWS_PER_WAVE)) return;   // after the only block barrier
   const int b = item % A.nb;
   const int row0 = (item / A.nb) * ROWS_PER_WAVE;
   const uint64_t g = A.g0 + (uint64_t)b;
-
-  LaneRegs<R, P, NS> regs;
-  GpuExec<R, P, NS> ex{lane, regs};
   for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
     const int ky = row0 + rr;
+#else
+  // A workgroup owns LR consecutive rows (one 128-byte line of every V column) of RPW*WPB/LR
+  // consecutive realisations, and its waves walk that tile row-fastest: the LR 16-byte pieces of a
+  // line are stored by LR different waves within one or two iterations, so the line is complete
+  // in L2 long before it is evicted.  (With one wave storing its own 8 rows over 8 iterations the
+  // partially written lines in flight -- 256 CUs x 12 waves x Np lines -- equal the L2 capacity
+  // and leave as partial writes: 2.7x write amplification, rows kernel 12.8 -> ... ms.)
+  constexpr int WPB = WaveCfg<R, P, NS>::WPB;
+  constexpr int LR = 128 / (int)sizeof(cpx<R>);
+  static_assert((ROWS_PER_WAVE * WPB) % LR == 0, "tile must hold whole lines");
+  constexpr int BPG = ROWS_PER_WAVE * WPB / LR;          // realisations per workgroup
+  const int nbb = (A.nb + BPG - 1) / BPG;
+  const int b0 = (blockIdx.x % nbb) * BPG;               // realisation block fastest: neighbours share amp rows
+  const int row0 = (blockIdx.x / nbb) * LR;
+  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+    const int flat = rr * WPB + w;
+    const int b = b0 + flat / LR;
+    if (b >= A.nb) break;                                // wave-uniform
+    const int ky = row0 + flat % LR;
+    const uint64_t g = A.g0 + (uint64_t)b;
+#endif
     const R* amp = A.amp + (size_t)ky * N;
     if (MODE == 0) {
+#if defined(FMC_ABL_NOGEN)      // ablation (timing only, wrong results): no generator at all
+#pragma unroll
+      for (int j = 0; j < P; ++j) regs.v[j] = cscale(mk<R>((R)(lane + j), (R)(ky - j)), amp[lane + WAVE * j]);
+#elif defined(FMC_ABL_NOBM)     // ablation: uniform words only, no Box-Muller
+      xoshiro128p rs = row_stream(A.key, g, ky, lane);
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const uint32_t a = rs.next(), bb = rs.next();
+        regs.v[j] = cscale(mk<R>((R)(int)a, (R)(int)bb), amp[lane + WAVE * j]);
+      }
+#else
       xoshiro128p rs = row_stream(A.key, g, ky, lane);
 #pragma unroll
       for (int j = 0; j < P; ++j) regs.v[j] = cscale(draw_coeff<R>(rs), amp[lane + WAVE * j]);
+#endif
     } else {
       const size_t base = ((size_t)b * N + ky) * N;
 #pragma unroll
@@ -264,14 +300,25 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
         regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
       }
     }
+#if defined(FMC_ABL_NOFFT)      // ablation: generator + stores only
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { regs.xr[s] = 0; regs.xi[s] = 0; }
+#pragma unroll
+    for (int j = 0; j < P; ++j) { regs.xr[j % NS] += regs.v[j].x; regs.xi[j % NS] += regs.v[j].y; }
+#else
     pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+#endif
     // V is stored column-major per realisation, V[b][oi][ky], so that the column pass reads it
     // coalesced; the 8 consecutive rows of this wave complete one 128-byte line per window column.
     cpx<R>* out = A.V + (size_t)b * A.Np * N + ky;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int oi = lane + WAVE * s;
+#if defined(FMC_ABL_NOSTORE)    // ablation: compute only (the comparison keeps the work alive)
+      if (oi < A.Np && regs.xr[s] == (R)1.2345e30) out[(size_t)oi * N] = mk<R>(regs.xr[s], regs.xi[s]);
+#else
       if (oi < A.Np) out[(size_t)oi * N] = mk<R>(regs.xr[s], regs.xi[s]);
+#endif
     }
   }
 }

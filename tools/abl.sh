@@ -1,0 +1,17 @@
+#!/bin/bash
+# Phase-ablation timing of k_rows_wave on ONE box: tools/abl.sh lib1.so lib2.so ...   (variants built with -DFMC_ABL_*)
+for L in "$@"; do
+  FASTMC_LIB=$PWD/$L python - <<'PY'
+import os, json, numpy as np, fast_amd, bench
+import argparse
+a = argparse.Namespace(precision="f64", npxls=1024, ao_mode="NOAO", batch=0)
+p = bench.workload_params(a); p["GPU_DEVICE"] = 0
+sim = fast_amd.Fast(p); h = sim._handle
+for i in range(2): h.run(1, 0, 5000, None, float(sim.logamp_var), False)
+t = {"rows_ms": 0, "cols_ms": 0}
+for i in range(5):
+    h.run(1, 0, 5000, None, float(sim.logamp_var), False)
+    tt = h.last_timing(); t["rows_ms"] += tt["rows_ms"] / 5; t["cols_ms"] += tt["cols_ms"] / 5
+print(os.path.basename(os.environ["FASTMC_LIB"]), "rows %.3f ms  cols %.3f ms" % (t["rows_ms"], t["cols_ms"]))
+PY
+done

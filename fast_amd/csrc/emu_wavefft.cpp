@@ -21,6 +21,7 @@ struct HostExec {
     for (int l = 0; l < WAVE; ++l) f(l, regs[l]);
   }
   void sync() {}
+  template <class T> static void pin(T&) {}
   template <class E> static E ld(const E* p) { return *p; }
   template <class E> static void st(E* p, E v) { *p = v; }
 };

@@ -19,6 +19,13 @@
 #pragma once
 #include "fmc_core.h"
 
+#ifndef FMC_BATCH_LDS
+#define FMC_BATCH_LDS 1
+#endif
+#ifndef FMC_TW_CHUNK
+#define FMC_TW_CHUNK 4
+#endif
+
 namespace fmc {
 
 // LDS exchange element: 8 bytes in both precisions (ds_write_b64 / ds_read_b64).
@@ -62,6 +69,19 @@ struct WaveGeom {
                 "wave FFT supports N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32");
 };
 
+// Twiddles per prefetch chunk in stage 1 (0 = let the compiler place the loads): bounded by the
+// registers left beside the 2P values of the row (f64: 4 VGPRs per twiddle).
+template <class R, int P>
+constexpr int tw_chunk() {
+#if FMC_BATCH_LDS
+  // measured at 1024^2 (P = 16): rows -1.6 % (f64), -5 % (f32); P <= 8 loses 2-6 % (more registers,
+  // fewer waves per SIMD) and P > 24 has no registers to spare
+  return (P < 12) ? 0 : (sizeof(R) == 8) ? (P <= 16 ? FMC_TW_CHUNK : 0) : (P <= 16 ? P - 1 : (P <= 24 ? 8 : 0));
+#else
+  return 0;
+#endif
+}
+
 // Per-lane registers of the pipeline.
 template <class R, int P, int NS>
 struct LaneRegs {
@@ -86,11 +106,40 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
   // ---- stage 1: radix-P in registers, twiddle, to natural order
   ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
     cpx<R> z[P];
+    // Twiddle loads in chunks of CH, double-buffered: chunk 0 is in flight under the in-register
+    // DFT, chunk k+1 under the multiplies of chunk k, one wait (ex.pin) per chunk.  Left to itself
+    // the compiler keeps two loads in flight and exposes ~P/2 LDS round trips per row.
+    constexpr int CH = tw_chunk<R, P>();
+    constexpr int NCH = CH ? (P - 1 + CH - 1) / CH : 0;
+    cpx<R> t[2][CH ? CH : 1];
+    if (CH) {
+#pragma unroll
+      for (int q = 0; q < CH; ++q)
+        if (1 + q < P) t[0][q] = tw1[(1 + q) * WAVE + lane];
+    }
 #pragma unroll
     for (int j = 0; j < P; ++j) z[j] = r.v[j];
     dft_reg<P, R>(z);
+    r.v[0] = z[0];
+    if (CH) {
 #pragma unroll
-    for (int a = 0; a < P; ++a) r.v[a] = (a == 0) ? z[a] : cmul(z[a], tw1[a * WAVE + lane]);
+      for (int k = 0; k < NCH; ++k) {
+        if (k + 1 < NCH) {
+#pragma unroll
+          for (int q = 0; q < CH; ++q)
+            if (1 + (k + 1) * CH + q < P) t[(k + 1) & 1][q] = tw1[(1 + (k + 1) * CH + q) * WAVE + lane];
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+          if (1 + k * CH + q < P) { ex.pin(t[k & 1][q].x); ex.pin(t[k & 1][q].y); }
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+          if (1 + k * CH + q < P) r.v[1 + k * CH + q] = cmul(z[1 + k * CH + q], t[k & 1][q]);
+      }
+    } else {
+#pragma unroll
+      for (int a = 1; a < P; ++a) r.v[a] = cmul(z[a], tw1[a * WAVE + lane]);
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) { r.xr[s] = (R)0; r.xi[s] = (R)0; }
   });
@@ -151,8 +200,22 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
             const int a = x % P;            // P is a compile-time constant: mask / shift for powers of two
             const int b0 = (x / P) & 7;
             const E* f = xbuf + a + G::FB * b0;
+#if FMC_BATCH_LDS
+            if (P >= 12 && NS == 2) {
+            cpx<R> w[8];
+            E fv[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { w[m] = om[m * omS + oi]; fv[m] = ex.ld(f + G::FL * m); }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { ex.pin(w[m].x); ex.pin(w[m].y); ex.pin(fv[m]); }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) X::acc(r.xr[s], r.xi[s], w[m], fv[m], c);
+            } else
+#endif
+            {
 #pragma unroll
             for (int m = 0; m < 8; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + G::FL * m), c);
+            }
           }
         }
       }

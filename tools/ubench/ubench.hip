@@ -31,6 +31,24 @@ __global__ void k(uint32_t* out, uint32_t seed) {
       if (OP == 11) a[i] = __builtin_amdgcn_alignbit(a[i], a[i], 13) + 1u;  // rotate + add
       if (OP == 12) a[i] = __umul24(a[i], 0x51F53u) + 1u;    // v_mul_u32_u24 / v_mad_u32_u24
       if (OP == 13) d[i] = (double)(float)d[i] + 1.0;                        // cvt f64<->f32
+      if (OP == 14) { f[i] = (float)a[i]; a[i] = __float_as_uint(f[i]) + 3u; }           // v_cvt_f32_u32 + add
+      if (OP == 15) { d[i] = (double)f[i]; f[i] = __uint_as_float((uint32_t)((uint64_t)__double_as_longlong(d[i]) >> 32)); }  // v_cvt_f64_f32
+      if (OP == 16) f[i] = __builtin_amdgcn_cosf(f[i]) + 0.3f;
+      if (OP == 17) {   // one complex coefficient as the rows kernel draws it: 2 xoshiro128+ words, Box-Muller, to f64, scale
+        uint32_t s0 = a[i], s1 = a[(i + 1) & 7], s2 = a[(i + 2) & 7], s3 = a[(i + 3) & 7];
+        uint32_t w[2];
+        for (int k2 = 0; k2 < 2; ++k2) {
+          w[k2] = s0 + s3;
+          const uint32_t t = s1 << 9;
+          s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t;
+          s3 = __builtin_amdgcn_alignbit(s3, s3, 21);
+        }
+        a[i] = s0; a[(i + 1) & 7] = s1; a[(i + 2) & 7] = s2; a[(i + 3) & 7] = s3;
+        const float u = fmaf((float)w[0], 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+        const float t = fmaf((float)w[1], 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+        const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));
+        d[i] = d[i] * (double)(r * __builtin_amdgcn_cosf(t)) + d[(i + 1) & 7] * (double)(r * __builtin_amdgcn_sinf(t));
+      }
     }
   }
   uint32_t r = 0;
@@ -74,5 +92,9 @@ int main() {
   run<8>("xor/shift/add (3 ops)", 3);
   run<11>("alignbit+add (2 ops)", 2);
   run<13>("cvt f64->f32->f64 + add (3)", 3);
+  run<14>("v_cvt_f32_u32+add (2 ops)", 2);
+  run<15>("v_cvt_f64_f32", 1);
+  run<16>("v_cos_f32+add (2 ops)", 2);
+  run<17>("one complex coefficient", 1);
   return 0;
 }

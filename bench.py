@@ -277,15 +277,17 @@ def main():
                          "frac_whole_job": value / world * bytes_per_iter / 1e9 / HBM_PEAK_GBS,
                          "init_s": init_s, "powerspec_kernel_ms": sim.powerspec_kernel_ms},
         }
-        # The binding resource is the vector ALU, not HBM: float64 butterfly work
-        # per iteration from the static instruction count of k_rows_wave<double,16> (196 add, 68 mul,
-        # 150 fma per row-wave = 564 flop/lane; profiles/): N rows x 64 lanes per realisation, halved.
+        # The binding resource is the vector ALU, not HBM: per row-wave of
+        # k_rows_wave<double,16> rocprofv3 counts 970 VALU instructions: 414 float64 butterflies (196 add,
+        # 68 mul, 150 fma = 564 flop/lane), ~490 integer/f32 and 64 transcendental instructions of the generator.
         if args.precision == "f64" and N == 1024:
             f64_flop_per_iter = 564 * 64 * N / 2 * (1 + Np / N)
             line["valu"] = {"f64_flop_per_iteration": f64_flop_per_iter,
                             "achieved_f64_TFLOPs": value / world * f64_flop_per_iter / 1e12, "peak_f64_vector_TFLOPs": 78.6,
-                            "note": "plus ~350 integer/f32 and 64 transcendental VALU instructions per row-wave for the "
-                                    "generator; rocprofv3 (profiles/) shows the vector ALU active 69 % of SIMD cycles"}
+                            "note": "issue-time model from measured instruction rates (profiles/r01j_ubench_valu_issue_rates.txt: "
+                                    "f64 5.1, transcendental 6.3, other 4 cycles per wave-instruction) = 4470 cycles per row-wave "
+                                    "against 6100 measured: the kernel runs at 73 % of the VALU issue bound; rocprofv3 "
+                                    "SQ_ACTIVE_INST_VALU gives the same 74 %"}
         if world == 1 and not args.no_extras:
             line["extras"] = extras(args, device_index)
         if world == 1 and not args.no_cpu_baseline:

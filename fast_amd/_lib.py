@@ -265,6 +265,35 @@ class Handle:
         return allp, hist
 
 
+def centred_fft2(g, device=None, inverse=False):
+    """Centred 2-D DFT of a square complex array on the GPU: numpy's fftshift(fft2(fftshift(g))), or with
+    inverse=True ifftshift(ifft2(ifftshift(g))) -- the kernels of the Monte-Carlo path with the window
+    set to the whole grid, a unit spectrum and host-supplied 'coefficients' g.  Used by the analytic
+    mean-irradiance path (fast/fast.py:736-761: aotools ft2 / ift2)."""
+    g = np.asarray(g)
+    N = g.shape[0]
+    assert g.shape == (N, N)
+    h = Handle(N, N, "f64", device)
+    try:
+        h.set_pupil(np.ones((N, N)), 0, 1.0)
+        h.set_spectrum(np.ones((N, N)), 1.0)
+        x = np.conj(g) if inverse else g
+        phs = h.screens_coeffs(np.ascontiguousarray(x.real, dtype=float)[None], np.ascontiguousarray(x.imag, dtype=float)[None])
+    finally:
+        h.close()
+    out = phs[0] + 1j * phs[1]
+    if not inverse:
+        return out
+    out = np.conj(out) / N ** 2                   # = fftshift(ifft2(fftshift(g)))
+    if N % 2:
+        # odd N: ifftshift = one more sample of roll than fftshift, on the way in (a linear phase
+        # after the transform) and on the way out
+        n = np.fft.fftshift(np.arange(N))
+        ph = np.exp(2j * np.pi * n / N)
+        out = np.roll(out * ph[:, None] * ph[None, :], (1, 1), axis=(0, 1))
+    return out
+
+
 def link_metrics(queries, samples=None, handle=None, device=0):
     """fastmc_link_metrics: queries = [(kind, p0, p1), ...] over `samples` (uploaded) or, when samples
     is None, over the last run's results resident on `handle`'s device.  Returns (n_queries, 4)."""

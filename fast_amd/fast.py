@@ -284,8 +284,9 @@ class Fast():
         return self._handle.result_stats([10 ** (t / 10) for t in thresholds_dB_rel])
 
     def compute_mean_irradiance(self, onaxis=True):
-        """Analytic (non Monte-Carlo) mean coupled flux, fast.py:736-761; host numpy, one-off."""
-        return host.mean_irradiance(self.powerspec, self._prob.W, self.dx, self._prob.df, self.diffraction_limit, onaxis)
+        """Analytic (non Monte-Carlo) mean coupled flux, fast.py:736-761; its N x N transforms on the GPU."""
+        return host.mean_irradiance(self.powerspec, self._prob.W, self.dx, self._prob.df, self.diffraction_limit, onaxis,
+                                    self.device)
 
     def make_header(self, params):
         """Result-file header cards (fast.py:771-807)."""

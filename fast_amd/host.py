@@ -244,23 +244,22 @@ def pupils(p, N, Np, dx):
 
 
 # ----------------------------------------------------------------------------- analytic mean irradiance
-def ift2(G, delta_f):
-    """Centred inverse 2-D DFT scaled by (N delta_f)^2 (aotools.fouriertransform.ift2, 2-D input)."""
-    N = G.shape[0]
-    return np.fft.ifftshift(np.fft.ifft2(np.fft.ifftshift(G))) * (N * delta_f) ** 2
-
-
-def mean_irradiance(powerspec, W, dx, df, diffraction_limit, onaxis=True):
+def mean_irradiance(powerspec, W, dx, df, diffraction_limit, onaxis=True, device=None):
     """Fast.compute_mean_irradiance (fast.py:736-761): mean coupled flux from the optical transfer
-    functions, no Monte Carlo.  Three N x N FFTs, once; host-side (not part of the GPU hot path)."""
+    functions, no Monte Carlo.  Its three or four N x N transforms (aotools ft2 / ift2: centred DFTs
+    scaled by delta^2 resp. (N delta_f)^2) run on the GPU (_lib.centred_fft2)."""
+    from . import _lib
+    N = powerspec.shape[0]
+    ft2 = lambda g, delta: _lib.centred_fft2(g, device) * delta ** 2
+    ift2 = lambda G, delta_f: _lib.centred_fft2(G, device, inverse=True) * (N * delta_f) ** 2
     pupil = np.zeros(powerspec.shape)
     pupil[:W.shape[0], :W.shape[1]] = W
     phs_otf = ift2(powerspec, df)
-    phs_sf = phs_otf[phs_otf.shape[0] // 2, phs_otf.shape[1] // 2] - phs_otf
-    pupil_ft = hm.ft2(pupil, dx)
+    phs_sf = phs_otf[N // 2, N // 2] - phs_otf
+    pupil_ft = ft2(pupil, dx)
     pupil_otf = ift2(np.abs(pupil_ft) ** 2, df) / (2 * np.pi) ** 2
     otf = np.exp(-phs_sf) * pupil_otf
-    psf = otf.sum().real * dx ** 2 if onaxis else hm.ft2(otf, dx).real
+    psf = otf.sum().real * dx ** 2 if onaxis else ft2(otf, dx).real
     return psf * (diffraction_limit / (pupil.sum() * dx ** 2) ** 2)
 
 

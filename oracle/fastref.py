@@ -451,6 +451,31 @@ def result_stats(r, dl):
 
 
 # --------------------------------------------------------------------------
+# analytic mean irradiance                fast/fast.py:736-761
+#   aotools.fouriertransform.ft2 / ift2 (third party, absent): centred DFTs scaled by delta^2
+#   resp. (N delta_f)^2, restated from their documented behaviour (see capture_golden/shims).
+# --------------------------------------------------------------------------
+def ft2_centred(g, delta):
+    return np.fft.fftshift(np.fft.fft2(np.fft.fftshift(g))) * delta ** 2
+
+
+def ift2_centred(G, delta_f):
+    return np.fft.ifftshift(np.fft.ifft2(np.fft.ifftshift(G))) * (G.shape[0] * delta_f) ** 2
+
+
+def mean_irradiance(powerspec, W, dx, df, diffraction_limit, onaxis=True):
+    N = powerspec.shape[0]
+    pupil = np.zeros((N, N))
+    pupil[:W.shape[0], :W.shape[1]] = W                                  # fast.py:739-741
+    phs_otf = ift2_centred(powerspec, df)                                # 745
+    phs_sf = phs_otf[N // 2, N // 2] - phs_otf                           # 746
+    pupil_otf = ift2_centred(np.abs(ft2_centred(pupil, dx)) ** 2, df) / (2 * np.pi) ** 2   # 748-749
+    otf = np.exp(-phs_sf) * pupil_otf                                    # 751
+    psf = otf.sum().real * dx ** 2 if onaxis else ft2_centred(otf, dx).real               # 753-757
+    return psf * (diffraction_limit / (pupil.sum() * dx ** 2) ** 2)      # 759-761
+
+
+# --------------------------------------------------------------------------
 # link metrics over the power vector      fast/comms.py:171-262
 # --------------------------------------------------------------------------
 def _fade_runs(I, threshold):

@@ -581,3 +581,29 @@ def test_link_metrics_on_resident_results_match_oracle():
             assert (np.isnan(a) and np.isnan(b)) or a == b
     with pytest.raises(fast_amd.FastMCError):
         _lib.link_metrics([(7, 0.0, 0.0)], samples=np.ones(4))
+
+
+@pytest.mark.parametrize("N", [48, 49, 64, 100, 256])
+def test_centred_fft2_matches_numpy(N):
+    """_lib.centred_fft2 (the row/column kernels with the window = the whole grid; wave family for
+    64 and 256, direct family otherwise, odd N with numpy's asymmetric shifts) vs numpy.fft."""
+    rng = np.random.default_rng(N)
+    g = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    fwd = np.fft.fftshift(np.fft.fft2(np.fft.fftshift(g)))
+    inv = np.fft.ifftshift(np.fft.ifft2(np.fft.ifftshift(g)))
+    np.testing.assert_allclose(_lib.centred_fft2(g), fwd, rtol=0, atol=1e-11 * np.abs(fwd).max())
+    np.testing.assert_allclose(_lib.centred_fft2(g, inverse=True), inv, rtol=0, atol=1e-11 * np.abs(inv).max())
+
+
+def test_mean_irradiance_matches_reference():
+    """Fast.compute_mean_irradiance with its transforms on the GPU vs the reference's outputs (fast.py:736-761)."""
+    from fast_amd import host
+    g = load_golden("mean_irradiance")
+    on = host.mean_irradiance(g["powerspec"], g["W"], float(g["dx"]), float(g["df"]), float(g["diffraction_limit"]))
+    np.testing.assert_allclose(on, g["onaxis"], rtol=1e-10)
+    off = host.mean_irradiance(g["powerspec"], g["W"], float(g["dx"]), float(g["df"]), float(g["diffraction_limit"]), onaxis=False)
+    np.testing.assert_allclose(off, g["offaxis"], rtol=1e-9, atol=1e-11 * np.abs(g["offaxis"]).max())
+    on2 = host.mean_irradiance(g["powerspec2"], g["W2"], float(g["dx2"]), float(g["df2"]), float(g["diffraction_limit2"]))
+    np.testing.assert_allclose(on2, g["onaxis2"], rtol=1e-10)
+    np.testing.assert_allclose(on, R.mean_irradiance(g["powerspec"], g["W"], float(g["dx"]), float(g["df"]),
+                                                     float(g["diffraction_limit"])), rtol=1e-11)

@@ -111,16 +111,6 @@ def test_temporal_host_setup_matches_reference(name):
     np.testing.assert_allclose(prob.temporal.logamp_powerspec, g["temporal_logamp_powerspec"], rtol=1e-9, atol=1e-30)
 
 
-def test_mean_irradiance_matches_reference():
-    g = load_golden("mean_irradiance")
-    on = host.mean_irradiance(g["powerspec"], g["W"], float(g["dx"]), float(g["df"]), float(g["diffraction_limit"]))
-    np.testing.assert_allclose(on, g["onaxis"], rtol=1e-10)
-    off = host.mean_irradiance(g["powerspec"], g["W"], float(g["dx"]), float(g["df"]), float(g["diffraction_limit"]), onaxis=False)
-    np.testing.assert_allclose(off, g["offaxis"], rtol=1e-9, atol=1e-12 * np.abs(g["offaxis"]).max())
-    on2 = host.mean_irradiance(g["powerspec2"], g["W2"], float(g["dx2"]), float(g["df2"]), float(g["diffraction_limit2"]))
-    np.testing.assert_allclose(on2, g["onaxis2"], rtol=1e-10)
-
-
 def test_fits_round_trip(tmp_path):
     from fast_amd import fitsio
     data = np.random.default_rng(0).random(37) * 1e-6

@@ -147,3 +147,14 @@ def test_link_metrics_match_reference():
     np.testing.assert_allclose([R.ber_ook(s) for s in eb], d["ber_ook_nosamples"], rtol=1e-14)
     np.testing.assert_allclose([[R.sep_qam(M, s) for s in eb] for M in Ms], d["sep_qam_nosamples"], rtol=1e-14)
     np.testing.assert_allclose([[R.ber_qam(M, s) for s in eb] for M in Ms], d["ber_qam_nosamples"], rtol=1e-14)
+
+
+def test_mean_irradiance_matches_reference():
+    """oracle restatement of Fast.compute_mean_irradiance (fast.py:736-761) vs the captured outputs."""
+    g = load_golden("mean_irradiance")
+    on = R.mean_irradiance(g["powerspec"], g["W"], float(g["dx"]), float(g["df"]), float(g["diffraction_limit"]))
+    np.testing.assert_allclose(on, g["onaxis"], rtol=1e-10)
+    off = R.mean_irradiance(g["powerspec"], g["W"], float(g["dx"]), float(g["df"]), float(g["diffraction_limit"]), onaxis=False)
+    np.testing.assert_allclose(off, g["offaxis"], rtol=1e-9, atol=1e-12 * np.abs(g["offaxis"]).max())
+    on2 = R.mean_irradiance(g["powerspec2"], g["W2"], float(g["dx2"]), float(g["df2"]), float(g["diffraction_limit2"]))
+    np.testing.assert_allclose(on2, g["onaxis2"], rtol=1e-10)

@@ -19,6 +19,9 @@ logger = logging.getLogger(__name__)
 TWO_PI = 2 * np.pi
 # grid sizes served by the wave-FFT kernels: 64 * 2^k * {1, 3, 5, 7, 9}, 128 ... 2048 (fmc_wavefft.h)
 WAVE_FFT_SIZES = sorted(64 * q * 2 ** k for q in (1, 3, 5, 7, 9) for k in range(6) if 2 <= q * 2 ** k <= 32)
+# sizes GPU_ROUND_NPXLS rounds up to: 896 and 1792 (radix-7 stage, 2 resp. 1 waves per SIMD) are slower than the
+# next power of two (measured 0.55 vs 0.73 M it/s and 0.137 vs 0.153 M it/s, tools/sizesweep.sh)
+ROUND_UP_SIZES = [s for s in WAVE_FFT_SIZES if s not in (896, 1792)]
 
 
 # ----------------------------------------------------------------------------- geometry
@@ -90,7 +93,7 @@ def grid_size(p, atm):
         if p.get('GPU_ROUND_NPXLS', False):
             # opt-in: the reference's auto rule gives arbitrary even sizes (164 for the shipped example);
             # the next size of the fast kernel family samples the spectrum slightly finer
-            bigger = [s for s in WAVE_FFT_SIZES if s >= N]
+            bigger = [s for s in ROUND_UP_SIZES if s >= N]
             if bigger:
                 logger.info(f"GPU_ROUND_NPXLS: auto NPXLS {N} -> {bigger[0]}")
                 N = bigger[0]

@@ -32,8 +32,12 @@ def shard_range(n_real_total, world, rank):
 
 def assemble(gathered, world, n_local, complex_out=False):
     """[rank][Re block | Im block] -> [Re of all realisations | Im of all realisations]
-    (the order fastmc_run uses for a single range)."""
-    g = np.asarray(gathered).reshape(world, 2, n_local)
+    (the order fastmc_run uses for a single range).  complex_out: COHERENT runs, every value a
+    complex128 amplitude carried as two float64."""
+    g = np.asarray(gathered)
+    if complex_out:
+        g = np.ascontiguousarray(g, dtype=np.float64).reshape(world, -1).view(np.complex128)
+    g = g.reshape(world, 2, n_local)
     return np.concatenate([g[:, 0].ravel(), g[:, 1].ravel()])
 
 
@@ -79,15 +83,16 @@ class RcclTransport:
 
 
 def run_sharded(n_real_total, compute_local, transport):
-    """compute_local(real0, n_local) -> float64 [2*n_local] ([Re | Im]); every rank returns the
-    full [2*n_real_total] vector."""
+    """compute_local(real0, n_local) -> [2*n_local] values ([Re-screen results | Im-screen results]),
+    float64 powers or complex128 amplitudes (COHERENT); every rank returns the full [2*n_real_total] vector."""
     real0, n_local = shard_range(n_real_total, transport.world, transport.rank)
-    local = compute_local(real0, n_local)
+    local = np.asarray(compute_local(real0, n_local))
+    cplx = np.iscomplexobj(local)
     if isinstance(transport, RcclTransport):
-        gathered, _ = transport.gather(2 * n_local)
+        gathered, _ = transport.gather((4 if cplx else 2) * n_local)      # float64 values on the device
     else:
-        gathered = transport.all_gather(local)
-    return assemble(gathered, transport.world, n_local)
+        gathered = transport.all_gather(np.ascontiguousarray(local).view(np.float64) if cplx else local)
+    return assemble(gathered, transport.world, n_local, complex_out=cplx)
 
 
 def histogram_sharded(local_hist, transport):

@@ -150,15 +150,8 @@ class Fast():
             else:
                 # one process per GPU: this rank's contiguous realisation range, then one exchange
                 from . import dist as fdist
-                if coherent:
-                    raise NotImplementedError("COHERENT results are not exchanged across GPUs yet")
-                real0, n_loc = fdist.shard_range(n_real, tr.world, tr.rank)
-                loc = self._handle.run(seed, real0, n_loc, None, float(self.logamp_var), False)
-                if isinstance(tr, fdist.RcclTransport):
-                    gathered, _ = tr.gather(2 * n_loc)
-                else:
-                    gathered = tr.all_gather(loc)
-                out = fdist.assemble(gathered, tr.world, n_loc)
+                out = fdist.run_sharded(n_real, lambda real0, n_loc: self._handle.run(
+                    seed, real0, n_loc, None, float(self.logamp_var), coherent), tr)
             re, im = out[:n_real].reshape(self.Nchunks, half), out[n_real:].reshape(self.Nchunks, half)
             I[:, :half], I[:, half:] = re, im
             # the log-amplitudes the device drew, in iteration order (global iteration 2g+s)

@@ -17,10 +17,11 @@ def main():
     h, cn2, w = fast_amd.turbulence_models.HV57_Bufton_profile(4)
     p = {"NPXLS": 512, "DX": 0.01, "NITER": 400, "NCHUNKS": 4, "SEED": None if os.environ.get("NOSEED") else 21,
          "LOGLEVEL": "ERROR", "D_GROUND": 0.4, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w,
-         "WIND_DIR": np.array([0., 90., 180., 270.]), "DSUBAP": 0.1, "GPU_DEVICE": 0}
+         "WIND_DIR": np.array([0., 90., 180., 270.]), "DSUBAP": 0.1, "GPU_DEVICE": 0,
+         "COHERENT": bool(os.environ.get("COHERENT"))}
     sim = fast_amd.Fast(dict(p))
     r = sim.run()._r                                   # sharded: GPU_SHARD 'auto' sees the process group
-    assert r.shape == (400,) and np.isfinite(r).all()
+    assert r.shape == (400,) and np.isfinite(r).all() and np.iscomplexobj(r) == p["COHERENT"]
     p1 = dict(p)
     p1.update({"GPU_SHARD": False, "SEED": sim._device_seed})
     single = fast_amd.Fast(p1).run()._r

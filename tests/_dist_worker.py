@@ -22,12 +22,12 @@ def problem():
     return ps, g.df, W
 
 
-def compute(real0, n):
+def compute(real0, n, coherent=False):
     ps, df, W = problem()
     coeffs = np.stack([devrng.device_coefficients(SEED, real0 + j, N) for j in range(n)])
     chi = devrng.device_logamp_normals(SEED, 2 * real0, 2 * n) * 0.1
     la = np.concatenate([chi[0::2], chi[1::2]])
-    return R.powers_from_coefficients(coeffs, ps, df, W, 0.02, la)
+    return R.powers_from_coefficients(coeffs, ps, df, W, 0.02, la, coherent=coherent)
 
 
 def main():
@@ -36,6 +36,9 @@ def main():
     full = fd.run_sharded(NREAL, compute, tr)
     single = compute(0, NREAL)
     assert np.array_equal(full, single), (full, single)
+    full_c = fd.run_sharded(NREAL, lambda r0, n: compute(r0, n, coherent=True), tr)      # COHERENT: complex amplitudes
+    single_c = compute(0, NREAL, coherent=True)
+    assert np.iscomplexobj(full_c) and np.array_equal(full_c, single_c), (full_c, single_c)
     h_local = np.histogram(10 * np.log10(compute(*fd.shard_range(NREAL, tr.world, tr.rank))), bins=8, range=(-40, 10))[0]
     h_all = fd.histogram_sharded(h_local, tr)
     assert np.array_equal(h_all, np.histogram(10 * np.log10(single), bins=8, range=(-40, 10))[0])

@@ -12,9 +12,9 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("noseed", ["", "1"])
-def test_sharded_run_two_ranks_one_gpu(noseed):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NOSEED=noseed)
+@pytest.mark.parametrize("noseed,coherent", [("", ""), ("1", ""), ("", "1")])
+def test_sharded_run_two_ranks_one_gpu(noseed, coherent):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", NOSEED=noseed, COHERENT=coherent)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "tests", "_dist_gpu_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)

@@ -18,7 +18,7 @@ EXPORTS = [
     "fastmc_set_spectrum", "fastmc_set_pupil", "fastmc_set_subharm", "fastmc_run", "fastmc_run_coeffs",
     "fastmc_screens_coeffs", "fastmc_screens", "fastmc_rng_coeffs", "fastmc_rng_logamp", "fastmc_histogram",
     "fastmc_result_stats", "fastmc_last_timing", "fastmc_kernel_path", "fastmc_set_batch", "fastmc_powerspec",
-    "fastmc_set_layer_screens", "fastmc_temporal_chunk", "fastmc_link_metrics",
+    "fastmc_set_layer_screens", "fastmc_temporal_chunk", "fastmc_link_metrics", "fastmc_set_results",
     "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_gather", "fastmc_comm_destroy",
 ]
 
@@ -76,6 +76,7 @@ def lib():
     L.fastmc_rng_logamp.argtypes = [vp, u64, i64, i64, dp]
     L.fastmc_set_layer_screens.argtypes = [vp, dp, C.c_int]
     L.fastmc_temporal_chunk.argtypes = [vp, dp, dp, C.POINTER(C.c_int32), C.c_int, dp, C.c_int, dp]
+    L.fastmc_set_results.argtypes = [vp, dp, i64, C.c_int]
     L.fastmc_histogram.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.POINTER(i64)]
     L.fastmc_result_stats.argtypes = [vp, dp, C.c_int, dp]
     L.fastmc_link_metrics.argtypes = [vp, C.c_int, dp, i64, C.POINTER(LinkQuery), C.c_int, dp]
@@ -221,6 +222,13 @@ class Handle:
         bins = np.zeros(nbins + 2, dtype=np.int64)
         _chk(lib().fastmc_histogram(self._h, float(lo_db), float(hi_db), int(nbins), bins.ctypes.data_as(C.POINTER(C.c_int64))))
         return bins
+
+    def set_results(self, values):
+        """Make `values` (float64 powers or complex128 amplitudes) the resident results of the handle."""
+        v = np.ascontiguousarray(values)
+        coherent = np.iscomplexobj(v)
+        v = v.astype(np.complex128 if coherent else np.float64, copy=False)
+        _chk(lib().fastmc_set_results(self._h, v.view(np.float64).ctypes.data_as(C.POINTER(C.c_double)), v.size, int(coherent)))
 
     def result_stats(self, thresholds=()):
         """Device-side statistics of the last run: dict(n, mean, scintillation_index, mean_dB_rel,

@@ -771,6 +771,18 @@ static int histogram_device(fastmc_ctx* h, double lo, double hi, int nbins) {
   return 0;
 }
 
+extern "C" int fastmc_set_results(fastmc_t* h, const double* values, int64_t n_iter, int coherent) {
+  if (!h || !values || n_iter < 1) return fail(FASTMC_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t need = (size_t)n_iter * (coherent ? 2 : 1);
+  TRY(grow(&h->out, &h->out_cap, need));
+  HIPCHK(hipMemcpyAsync(h->out, values, need * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->last_n_iter = n_iter;
+  h->last_coherent = coherent ? 1 : 0;
+  return 0;
+}
+
 extern "C" int fastmc_histogram(fastmc_t* h, double lo_db, double hi_db, int nbins, int64_t* bins) {
   if (!h || !bins) return fail(FASTMC_EINVAL, "null argument");
   HIPCHK(hipSetDevice(h->device));

@@ -163,6 +163,10 @@ class Fast():
         self.random_iters = I[-1]
         self.timing = self._handle.last_timing()
         self.result = FastResult(I.flatten(), self.diffraction_limit)
+        if self.temporal or self.rng_mode == 'host' or getattr(self, '_tr', None) is not None:
+            # a run made of several library calls: hand the assembled vector back so that histogram(),
+            # result_stats() and the fast_amd.comms reductions see all of it, not the last chunk / shard
+            self._handle.set_results(self.result._r)
         self.I = self.result.power
         logger.info(self.result)
         return self.result

@@ -112,6 +112,13 @@ int fastmc_set_layer_screens(fastmc_t* h, const double* screens, int n_layers);
 int fastmc_temporal_chunk(fastmc_t* h, const double* xs, const double* ys, const int32_t* roll, int M,
                           const double* logamp, int coherent, double* out);
 
+/* Make a result vector the handle's resident results (n_iter float64 powers, or n_iter complex128
+ * amplitudes when coherent): what fastmc_histogram / fastmc_result_stats / fastmc_link_metrics /
+ * fastmc_comm_gather then reduce.  fastmc_run leaves its results resident by itself; a run made of
+ * several calls (host-coefficient chunks, fastmc_temporal_chunk, a sharded run after its exchange)
+ * assembles FastResult._r on the host (fast/fast.py:127-137) and hands it back with this call. */
+int fastmc_set_results(fastmc_t* h, const double* values, int64_t n_iter, int coherent);
+
 /* Fixed-bin histogram of 10*log10(power) of the last run's results kept on the device
  * (FastResult.dB_rel, fast/fast.py:949-951): bins[k] counts lo + k*(hi-lo)/nbins <= x <
  * ..., bins[nbins] = underflow, bins[nbins+1] = overflow.  bins: nbins+2 int64. */

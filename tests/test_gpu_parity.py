@@ -607,3 +607,19 @@ def test_mean_irradiance_matches_reference():
     np.testing.assert_allclose(on2, g["onaxis2"], rtol=1e-10)
     np.testing.assert_allclose(on, R.mean_irradiance(g["powerspec"], g["W"], float(g["dx"]), float(g["df"]),
                                                      float(g["diffraction_limit"])), rtol=1e-11)
+
+
+@pytest.mark.parametrize("name", ["e2e_ao_alias", "e2e_coherent", "temporal_small"])
+def test_device_reductions_cover_multi_call_runs(name):
+    """Host-coefficient chunks and TEMPORAL chunks are several library calls: the histogram, the
+    statistics and the link metrics must reduce the whole FastResult, not the last chunk."""
+    from fast_amd import comms
+    p = params_from_json(load_golden(name)["params_json"])
+    sim = fast_amd.Fast(p)
+    r = np.abs(sim.run()._r) ** 2 if p.get("COHERENT") else sim.run()._r
+    assert sim.Nchunks > 1
+    assert sim.histogram(-80.0, 20.0, 64).sum() == len(r)
+    st = sim.result_stats()
+    assert st["n"] == len(r)
+    np.testing.assert_allclose(st["mean"], r.mean(), rtol=1e-12)
+    np.testing.assert_allclose(comms.ber_ook(6.0, sim), R.ber_ook(6.0, r), rtol=1e-11)

@@ -36,38 +36,31 @@ GPU_DEFAULTS = {
 }
 
 
-class ConfigParser():
+def _read_py_config(path):
+    """A config file is a Python module that defines the dict `p` (fast/conf.py:92-101)."""
+    if not path.endswith(".py"):
+        raise Exception("Require .py config file")
+    spec = importlib.util.spec_from_file_location("", path)
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    return module.p
+
+
+class ConfigParser:
+    """`.config`: the user's dict (or the `p` of a .py file), completed in place: reference keys with a
+    warning per missing key (fast/conf.py:103-116), GPU keys silently.  `.fname`, `.defaults` as in the reference."""
 
     def __init__(self, fname_or_dict):
-        if type(fname_or_dict) == dict:
-            self.config = fname_or_dict
-            self.fname = None
-        elif type(fname_or_dict) == str:
-            self.fname = fname_or_dict
-            self.config = {}
-            self.load(fname_or_dict)
+        if isinstance(fname_or_dict, dict):
+            self.fname, self.config = None, fname_or_dict
+        elif isinstance(fname_or_dict, str):
+            self.fname, self.config = fname_or_dict, _read_py_config(fname_or_dict)
         else:
             raise Exception("Either config file name or params dict required")
-        self.defaults = {}
-        self.set_defaults()
-        self.check()
-
-    def load(self, fname):
-        if fname.split('.')[-1] == "py":
-            spec = importlib.util.spec_from_file_location("", fname)
-            module = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(module)
-            self.config = module.p
-            return
-        raise Exception("Require .py config file")
-
-    def check(self):
-        for key, val in self.defaults.items():
-            if key not in self.config:
-                logger.warning(f"Config parameter {key} not defined in {self.fname}, setting default value of {val}")
-                self.config[key] = val
+        self.defaults = DEFAULTS
+        missing = [k for k in DEFAULTS if k not in self.config]
+        for key in missing:
+            logger.warning(f"Config parameter {key} not defined in {self.fname}, setting default value of {DEFAULTS[key]}")
+            self.config[key] = DEFAULTS[key]
         for key, val in GPU_DEFAULTS.items():
             self.config.setdefault(key, val)
-
-    def set_defaults(self):
-        self.defaults = DEFAULTS

@@ -192,24 +192,35 @@ static bool wave_supported(int N) {
   }
 }
 
-// Launch configuration of the wave family for this handle: LDS bytes and waves per workgroup.
+// Which window instantiation of the wave family serves this handle: NS = 2 (Np <= 128), NS = 4
+// (Np <= 256; P = 8, 16, 32), NS = P (any window, powers of two), or 0 when none fits the LDS.
+constexpr size_t LDS_MAX = 160 * 1024;
+template <class R, int PP>
+static int pick_ns(const fastmc_ctx* h) {
+  if (h->NS <= 2) return wave_lds_bytes<R, PP, 2>(h->omS) <= LDS_MAX ? 2 : 0;
+  if constexpr (is_pow2(PP) && PP >= 8) {
+    if (h->NS <= 4 && wave_lds_bytes<R, PP, 4>(h->omS) <= LDS_MAX) return 4;
+  }
+  if constexpr (is_pow2(PP) && PP >= 4) {
+    if (h->NS <= PP && wave_lds_bytes<R, PP, PP>(h->omS) <= LDS_MAX) return PP;
+  }
+  return 0;
+}
+
+// Launch configuration of the wave family for this handle: instantiation, waves per workgroup.
 template <class R>
-static void wave_config(const fastmc_ctx* h, size_t* lds, int* wpb) {
-  const bool big = h->NS > 2;   // general-window instantiation (powers of two only)
+static void wave_config(const fastmc_ctx* h, int* ns, int* wpb) {
 #define FMC_CASE(PP)                                                                                         \
   case PP:                                                                                                   \
-    if constexpr (is_pow2(PP) && PP >= 4) {                                                                  \
-      *lds = big ? wave_lds_bytes<R, PP, PP>(h->omS) : wave_lds_bytes<R, PP, 2>(h->omS);                     \
-      *wpb = big ? WaveCfg<R, PP, PP>::WPB : WaveCfg<R, PP, 2>::WPB;                                         \
-    } else {                                                                                                 \
-      *lds = big ? (size_t)1 << 30 : wave_lds_bytes<R, PP, 2>(h->omS);                                       \
-      *wpb = WaveCfg<R, PP, 2>::WPB;                                                                         \
-    }                                                                                                        \
+    *ns = pick_ns<R, PP>(h);                                                                                 \
+    *wpb = WaveCfg<R, PP, 2>::WPB;                                                                           \
+    if constexpr (is_pow2(PP) && PP >= 8) { if (*ns == 4) *wpb = WaveCfg<R, PP, 4>::WPB; }                   \
+    if constexpr (is_pow2(PP) && PP >= 4) { if (*ns == PP && PP > 2) *wpb = WaveCfg<R, PP, PP>::WPB; }       \
     break;
   switch (h->P) {
     FMC_CASE(2) FMC_CASE(3) FMC_CASE(4) FMC_CASE(5) FMC_CASE(6) FMC_CASE(7) FMC_CASE(8) FMC_CASE(9) FMC_CASE(10)
     FMC_CASE(12) FMC_CASE(14) FMC_CASE(16) FMC_CASE(18) FMC_CASE(20) FMC_CASE(24) FMC_CASE(28) FMC_CASE(32)
-    default: *lds = (size_t)1 << 30; *wpb = 1; break;
+    default: *ns = 0; *wpb = 1; break;
   }
 #undef FMC_CASE
 }
@@ -283,9 +294,8 @@ static int default_batch(const fastmc_ctx* h) {
   if (h->path == 1) {
     // whole number of workgroup rounds over the 256 CUs: the row kernel runs one 12-wave (P=32: 4/6)
     // workgroup per CU and has batch * N/8 wave-items
-    size_t lds = 0;
-    int wpb = 1;
-    if (h->rsz == 8) wave_config<double>(h, &lds, &wpb); else wave_config<float>(h, &lds, &wpb);
+    int ns = 0, wpb = 1;
+    if (h->rsz == 8) wave_config<double>(h, &ns, &wpb); else wave_config<float>(h, &ns, &wpb);
     const int quantum = std::max(1, 256 * wpb * ROWS_PER_WAVE / h->N);
     if (b >= quantum) b -= b % quantum;
   } else if (b >= 8) {
@@ -456,9 +466,13 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
 
 template <class R, int P>
 static int dispatch_wave_ns(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
-  // two instantiations per (R, P): windows up to 128 pixels, and the general case
-  if (h->NS <= 2) dispatch_wave<R, P, 2>(h, RA, CA, mode, epi);
-  else dispatch_wave<R, P, P>(h, RA, CA, mode, epi);
+  // up to three instantiations per (R, P): windows up to 128 pixels, up to 256, and the general case
+  const int ns = pick_ns<R, P>(h);
+  if (ns == 2) dispatch_wave<R, P, 2>(h, RA, CA, mode, epi);
+  else if (ns == 4 && P >= 8) {
+    if constexpr (P >= 8) dispatch_wave<R, P, 4>(h, RA, CA, mode, epi);
+  } else if (ns == P) dispatch_wave<R, P, P>(h, RA, CA, mode, epi);
+  else return fail(FASTMC_ESTATE, "no wave instantiation for this window");
   return 0;
 }
 
@@ -586,10 +600,9 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     CA.partial = h->partial + (size_t)((bs - fin_start)) * Np * 4; CA.phs = h->phs;
     bool wave_ok = h->path == 1;
     if (wave_ok) {
-      size_t need;
-      int wpb_unused;
-      wave_config<R>(h, &need, &wpb_unused);
-      if (need > 160 * 1024 || h->NS > h->P) wave_ok = false;   // window tables exceed the LDS: direct family (still on the GPU)
+      int ns, wpb_unused;
+      wave_config<R>(h, &ns, &wpb_unused);
+      if (ns == 0) wave_ok = false;   // window tables exceed the LDS: direct family (still on the GPU)
     }
     RA.amp = (const R*)(wave_ok ? h->amp_s : h->amp);
     RA.tw = (const cpx<R>*)(wave_ok ? h->tw1 : h->tw);

@@ -221,6 +221,7 @@ constexpr int ROWS_PER_WAVE = FMC_ROWS_PER_WAVE;   // rows kernel: rows per wave
 // more LDS for exchange buffers: 12 waves = 3 per SIMD at 132 VGPRs (f64, P = 16).
 // P = 32 keeps 2 x 32 values per lane (>= 200 VGPRs) and 18 KiB of exchange buffer per wave: 6 waves
 // (A/B at 2048^2 f64: 6 waves 141k it/s vs 4 waves 114k it/s; 8 do not fit the LDS).
+// Windows of 129-256 pixels (NS = 4, P = 8, 16, 32) keep the NS = 2 configuration.
 // The general-window instantiation (NS = P) carries a large `om` table: 4 waves.  P = 10, 12, 20, 24
 // (3*2^k, 5*2^k): 8 waves (A/B at 640^2 / 768^2: +4 % / +1 % over 12, no spill at the 168-VGPR step);
 // P = 18, 28 (radix-9 / radix-7 stage with many live temporaries): 4 waves, one per SIMD, no spill.
@@ -231,7 +232,7 @@ template <class R, int P, int NS> struct WaveCfg {
 #ifndef FMC_WPB_P32_F64
 #define FMC_WPB_P32_F64 6
 #endif
-  static constexpr int WPB = (NS != 2) ? 4 : (P == 32 ? (sizeof(R) == 8 ? FMC_WPB_P32_F64 : 6) : ((P > 16 && P / (P & -P) >= 7) ? 4 : (P > 24 ? 6 : ((P > 16 || (!is_pow2(P) && P > 8)) ? 8 : FMC_WPB))));
+  static constexpr int WPB = (NS > 4 || (NS > 2 && NS == P)) ? 4 : (P == 32 ? (sizeof(R) == 8 ? FMC_WPB_P32_F64 : 6) : ((P > 16 && P / (P & -P) >= 7) ? 4 : (P > 24 ? 6 : ((P > 16 || (!is_pow2(P) && P > 8)) ? 8 : FMC_WPB))));
 };
 
 template <class R, int P>

@@ -62,7 +62,8 @@ def test_screens_match_reference_fft_kat(N, prec, tol):
 
 # ------------------------------------------------------------------ screens: wave family vs numpy FFT
 @pytest.mark.parametrize("N,Np", [(128, 22), (128, 128), (192, 82), (320, 33), (384, 128), (640, 82), (768, 82), (1280, 82), (1536, 101), (768, 300), (448, 82), (576, 82), (896, 82), (1152, 82), (1792, 82),
-                                  (256, 82), (256, 200), (256, 256), (512, 82), (1024, 82), (2048, 82), (512, 23), (1024, 200), (512, 512), (1024, 1), (2048, 129)])
+                                  (256, 82), (256, 200), (256, 256), (512, 82), (1024, 82), (2048, 82), (512, 23), (1024, 200), (512, 512), (1024, 1), (2048, 129),
+                                  (512, 150), (1024, 129), (1024, 256), (1024, 257), (2048, 256)])
 @pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 5e-5)])
 def test_wave_kernels_match_oracle_fft(N, Np, prec, tol):
     ps, df = _vk_spectrum(N, 0.01, 25.0)

@@ -74,6 +74,8 @@ struct fastmc_ctx {
   double* sh_ey = nullptr;
   double* sh_coef = nullptr;   // [batch][27][2]
   double* sh_mean = nullptr;
+  double* sh_dcol = nullptr;   // [batch][Np][9][2] column-folded coefficients (separable grids)
+  bool sh_sep = false;         // fx independent of i and fy independent of j within every level
   double* sh_in_re = nullptr;  // host-mode coefficients [batch][27]
   double* sh_in_im = nullptr;
   size_t sh_cap = 0;
@@ -261,7 +263,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   if (h->comm) fastmc_comm_destroy(h);
   if (h->stream) hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->amp, h->amp_s, h->tw, h->tw1, h->om, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
-                  h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_in_re,
+                  h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -422,6 +424,11 @@ extern "C" int fastmc_set_subharm(fastmc_t* h, const double* ps_sh, const double
   HIPCHK(hipMemcpy(h->sh_mu, mu.data(), 54 * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->sh_ex, ex.data(), ex.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->sh_ey, ey.data(), ey.size() * 8, hipMemcpyHostToDevice));
+  h->sh_sep = true;
+  for (int m = 0; m < 27; ++m) {
+    const int lvl = m / 9, i = (m % 9) / 3, j = m % 3;
+    if (fx[m] != fx[9 * lvl + j] || fy[m] != fy[9 * lvl + 3 * i]) h->sh_sep = false;
+  }
   h->have_sh = true;
   return 0;
 }
@@ -556,9 +563,10 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
   if (S.epi == 1) TRY(grow(&h->phs, &h->phs_cap, (size_t)2 * B * Np * Np));
   const bool sh = h->have_sh;
   if (sh && h->sh_cap < (size_t)B) {
-    for (double** p : {&h->sh_coef, &h->sh_mean, &h->sh_in_re, &h->sh_in_im})
+    for (double** p : {&h->sh_coef, &h->sh_mean, &h->sh_dcol, &h->sh_in_re, &h->sh_in_im})
       if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
     TRY(dev_alloc(&h->sh_coef, (size_t)B * 54));
+    TRY(dev_alloc(&h->sh_dcol, (size_t)B * Np * 18));
     TRY(dev_alloc(&h->sh_mean, (size_t)B * 2));
     TRY(dev_alloc(&h->sh_in_re, (size_t)B * 27));
     TRY(dev_alloc(&h->sh_in_im, (size_t)B * 27));
@@ -586,6 +594,9 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       }
       SA.scale = h->sh_scale; SA.mu = h->sh_mu; SA.coef = h->sh_coef; SA.mean = h->sh_mean;
       hipLaunchKernelGGL(k_subharm_coeffs, dim3((nb + 63) / 64), dim3(64), 0, h->stream, SA);
+      if (h->sh_sep)
+        hipLaunchKernelGGL(k_subharm_cols, dim3((nb * Np + 255) / 256), dim3(256), 0, h->stream, (const double*)h->sh_coef,
+                           (const double*)h->sh_ex, nb, Np, h->sh_dcol);
     }
     RowArgs<R> RA;
     RA.N = N; RA.Np = Np; RA.lo = h->lo; RA.nb = nb;
@@ -596,7 +607,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     CA.N = N; CA.Np = Np; CA.lo = h->lo; CA.nb = nb;
     CA.V = (const cpx<R>*)h->V; CA.om = RA.om; CA.omS = h->omS;
     CA.W = h->W;
-    CA.sh.enabled = sh ? 1 : 0; CA.sh.coef = h->sh_coef; CA.sh.mean = h->sh_mean; CA.sh.ex = h->sh_ex; CA.sh.ey = h->sh_ey;
+    CA.sh.enabled = sh ? (h->sh_sep ? 2 : 1) : 0; CA.sh.dcol = h->sh_dcol; CA.sh.coef = h->sh_coef; CA.sh.mean = h->sh_mean; CA.sh.ex = h->sh_ex; CA.sh.ey = h->sh_ey;
     CA.partial = h->partial + (size_t)((bs - fin_start)) * Np * 4; CA.phs = h->phs;
     bool wave_ok = h->path == 1;
     if (wave_ok) {

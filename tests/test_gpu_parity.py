@@ -624,3 +624,33 @@ def test_device_reductions_cover_multi_call_runs(name):
     assert st["n"] == len(r)
     np.testing.assert_allclose(st["mean"], r.mean(), rtol=1e-12)
     np.testing.assert_allclose(comms.ber_ook(6.0, sim), R.ber_ook(6.0, r), rtol=1e-11)
+
+
+@pytest.mark.parametrize("rotate", [0.0, 0.3])
+@pytest.mark.parametrize("N,Np", [(128, 22), (256, 82), (48, 23)])
+def test_subharmonic_screens_separable_and_general_grids(N, Np, rotate):
+    """fastmc_set_subharm takes arbitrary (3,3,3) frequency grids.  The reference's are 3 x 3
+    meshgrids per level (fast.py:835-844) and take the column-folded 9-term path; a rotated grid
+    takes the general 27-term path.  Both against the oracle's full-grid evaluation (funcs.py:225-258)."""
+    from types import SimpleNamespace
+    dx = 0.01
+    ps, df = _vk_spectrum(N, dx, 25.0)
+    g = R.subharm_grid(N, dx)
+    c, s_ = np.cos(rotate), np.sin(rotate)
+    grid = SimpleNamespace(fx=c * g.fx - s_ * g.fy, fy=s_ * g.fx + c * g.fy, df=g.df)
+    rng = np.random.default_rng(N)
+    ps_lo = rng.uniform(0.5, 2.0, size=(3, 3, 3))
+    B = 2
+    cr, ci = rng.normal(size=(B, N, N)), rng.normal(size=(B, N, N))
+    sr, si = rng.normal(size=(B, 3, 3, 3)), rng.normal(size=(B, 3, 3, 3))
+    lo = (N - Np) // 2
+    want = R.crop(R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df))
+                  + R.subharm_screens((sr + 1j * si) * np.sqrt(ps_lo), grid, N, dx), N, Np)
+    for path in ([1, 0] if N % 64 == 0 else [0]):
+        h = _lib.Handle(N, Np, "f64", 0)
+        h.kernel_path(path)
+        h.set_spectrum(ps, df)
+        h.set_pupil(np.ones((Np, Np)), lo, dx)
+        h.set_subharm(ps_lo, grid.fx, grid.fy, grid.df)
+        got = h.screens_coeffs(cr, ci, sr, si)
+        assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max()

@@ -21,6 +21,7 @@ TWO_PI = 2 * np.pi
 WAVE_FFT_SIZES = sorted(64 * q * 2 ** k for q in (1, 3, 5, 7, 9) for k in range(6) if 2 <= q * 2 ** k <= 32)
 # sizes GPU_ROUND_NPXLS rounds up to: 896 and 1792 (radix-7 stage, 2 resp. 1 waves per SIMD) are slower than the
 # next power of two (measured 0.55 vs 0.73 M it/s and 0.137 vs 0.153 M it/s, tools/sizesweep.sh)
+MAX_NPXLS = 4096          # libfastmc: N <= 4096 (fastmc_create)
 ROUND_UP_SIZES = [s for s in WAVE_FFT_SIZES if s not in (896, 1792)]
 
 
@@ -106,6 +107,11 @@ def grid_size(p, atm):
         N = p['NPXLS']
     if N > 2048:
         logger.warning(f"NPXLS is large ({N}) and may cause very high memory usage")
+    if N > MAX_NPXLS:
+        # fail before any O(N^2) host work; a TEMPORAL series auto-sizes to half its total wind
+        # displacement (fast.py:201-206), which outgrows the kernels quickly
+        hint = " (TEMPORAL: fewer steps per object, a shorter DT or a coarser DX)" if p['TEMPORAL'] else ""
+        raise Exception(f"NPXLS = {N} exceeds the GPU kernels' limit of {MAX_NPXLS}{hint}")
     Np = int(np.ceil(D / dx)) + 2
     return dx, int(N), Np
 

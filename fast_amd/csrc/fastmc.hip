@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -54,6 +55,7 @@ struct fastmc_ctx {
   double* W = nullptr;
   void* V = nullptr;
   size_t V_cap = 0;        // realisations
+  size_t V_bytes = 0;      // size of the slab behind V (may exceed V_cap realisations: taken from the cache)
   double* partial = nullptr;
   size_t partial_cap = 0;
   double* out = nullptr;   // device results of the last run
@@ -257,11 +259,39 @@ extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int p
   return 0;
 }
 
+// One retired V slab per device stays allocated for the next handle: a sweep builds hundreds of
+// short-lived handles (fast/complete_orbit_simulation.py:227-236 builds one Fast per pass) and a
+// 1.5 GiB hipMalloc / hipFree pair costs 60-150 ms every few objects (tools/alloc_probe.py).
+struct SlabCache {
+  std::mutex mu;
+  struct Entry { void* p = nullptr; size_t bytes = 0; } dev[64];
+  void* take(int device, size_t need, size_t* bytes) {
+    std::lock_guard<std::mutex> g(mu);
+    Entry& e = dev[device & 63];
+    if (!e.p || e.bytes < need || e.bytes > 4 * need + ((size_t)64 << 20)) return nullptr;
+    void* p = e.p;
+    *bytes = e.bytes;
+    e = Entry();
+    return p;
+  }
+  void give(int device, void* p, size_t bytes) {     // keeps the larger slab, frees the other
+    void* drop = p;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      Entry& e = dev[device & 63];
+      if (!e.p || e.bytes < bytes) { drop = e.p; e.p = p; e.bytes = bytes; }
+    }
+    if (drop) hipFree(drop);
+  }
+};
+static SlabCache g_slabs;
+
 extern "C" void fastmc_destroy(fastmc_t* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->comm) fastmc_comm_destroy(h);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
   void* ptrs[] = {h->amp, h->amp_s, h->tw, h->tw1, h->om, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers};
@@ -538,9 +568,14 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
 
   // buffers
   if (h->V_cap < (size_t)B) {
-    if (h->V) HIPCHK(hipFree(h->V));
+    if (h->V) g_slabs.give(h->device, h->V, h->V_bytes);
     h->V = nullptr; h->V_cap = 0;
-    HIPCHK(hipMalloc(&h->V, (size_t)B * N * Np * sizeof(cpx<R>)));
+    const size_t need = (size_t)B * N * Np * sizeof(cpx<R>);
+    h->V = g_slabs.take(h->device, need, &h->V_bytes);
+    if (!h->V) {
+      HIPCHK(hipMalloc(&h->V, need));
+      h->V_bytes = need;
+    }
     h->V_cap = B;
   }
   // detector partials are kept for FIN_SPAN realisations so that one finalize launch serves many batches

@@ -259,7 +259,7 @@ def main():
                 traffic = None
         gpu_ms = tim["rows_ms"] + tim["cols_ms"] + tim["finalize_ms"]
         line = {
-            "metric": "Monte-Carlo iterations/sec (1024^2 grid)", "value": value, "unit": "iterations/s",
+            "metric": f"Monte-Carlo iterations/sec ({N}^2 grid)", "value": value, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.precision == "f64" else "f32", "data": "synthetic",

@@ -41,6 +41,7 @@ struct TimedSpan {
 struct fastmc_ctx {
   int device = 0, N = 0, Np = 0, lo = 0, precision = 0;
   int path = 0, P = 0, NS = 0, omS = 0;
+  int S = 1;               // wave family: sub-rows per row (N = S * 64 * P); spec_split(N)
   int batch = 0;
   double df = 0, dx = 0, wsum = 0;
   bool have_spec = false, have_pupil = false, have_sh = false;
@@ -52,6 +53,9 @@ struct fastmc_ctx {
   void* tw = nullptr;      // direct: cpx<R>[N]
   void* tw1 = nullptr;     // wave
   void* om = nullptr;      // wave
+  void* cw = nullptr;      // wave, S > 1: [S][omS] combination twiddles
+  void* tw1g = nullptr;    // N = 2048 only: tables of the single-pass P = 32 kernels (windows > 256 pixels,
+  void* omg = nullptr;     //   host coefficients: TEMPORAL layer screens, centred_fft2)
   double* W = nullptr;
   void* V = nullptr;
   size_t V_cap = 0;        // realisations
@@ -189,6 +193,7 @@ extern "C" int fastmc_device_count(int* n) {
 // N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32
 static bool wave_supported(int N) {
   if (N % 64 != 0) return false;
+  if (N == 4096) return true;       // 4 sub-rows of 1024
   switch (N / 64) {
     case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 12: case 14: case 16: case 18: case 20:
     case 24: case 28: case 32: return true;
@@ -205,6 +210,7 @@ static int pick_ns(const fastmc_ctx* h) {
   if constexpr (is_pow2(PP) && PP >= 8) {
     if (h->NS <= 4 && wave_lds_bytes<R, PP, 4>(h->omS) <= LDS_MAX) return 4;
   }
+  if (h->S > 1) return 0;    // split rows: windows up to 256 pixels only
   if constexpr (is_pow2(PP) && PP >= 4) {
     if (h->NS <= PP && wave_lds_bytes<R, PP, PP>(h->omS) <= LDS_MAX) return PP;
   }
@@ -251,7 +257,8 @@ extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int p
   h->precision = precision;
   h->rsz = precision == FASTMC_F64 ? 8 : 4;
   h->path = wave_supported(N) ? 1 : 0;
-  h->P = N / 64;
+  h->S = h->path == 1 ? spec_split(N) : 1;
+  h->P = N / 64 / h->S;
   h->NS = (Np + 63) / 64;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail(FASTMC_EHIP, hipGetErrorString(e)); }
@@ -292,7 +299,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   if (h->comm) fastmc_comm_destroy(h);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
-  void* ptrs[] = {h->amp, h->amp_s, h->tw, h->tw1, h->om, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+  void* ptrs[] = {h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers};
   for (void* p : ptrs)
@@ -380,18 +387,41 @@ extern "C" int fastmc_set_spectrum(fastmc_t* h, const double* powerspec, double 
 }
 
 template <class R>
+static int upload_table(void** dst, const std::vector<cpx<R>>& v) {
+  if (*dst) HIPCHK(hipFree(*dst));
+  *dst = nullptr;
+  HIPCHK(hipMalloc(dst, sizeof(cpx<R>) * v.size()));
+  HIPCHK(hipMemcpy(*dst, v.data(), sizeof(cpx<R>) * v.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+template <class R>
 static int upload_wave_tables(fastmc_ctx* h) {
-  const int P = h->P;
+  const int P = h->P, S = h->S;
   h->omS = (h->Np + 7) & ~7;
   std::vector<cpx<R>> tw1((size_t)P * 64), om((size_t)8 * h->omS);
   build_tw1<R>(tw1.data(), P, cs_turns);
   build_om<R>(om.data(), h->omS, P, h->lo, h->Np, true, cs_turns);
-  if (h->tw1) HIPCHK(hipFree(h->tw1));
-  if (h->om) HIPCHK(hipFree(h->om));
-  HIPCHK(hipMalloc(&h->tw1, sizeof(cpx<R>) * tw1.size()));
-  HIPCHK(hipMalloc(&h->om, sizeof(cpx<R>) * om.size()));
-  HIPCHK(hipMemcpy(h->tw1, tw1.data(), sizeof(cpx<R>) * tw1.size(), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(h->om, om.data(), sizeof(cpx<R>) * om.size(), hipMemcpyHostToDevice));
+  TRY(upload_table<R>(&h->tw1, tw1));
+  TRY(upload_table<R>(&h->om, om));
+  if (S > 1) {
+    // X[x] = sum_s w_N^{s x} Y_s[x mod N/S]:  cw[s][oi] = w_N^{s (lo + oi)}
+    std::vector<cpx<R>> cw((size_t)S * h->omS);
+    for (int sp = 0; sp < S; ++sp)
+      for (int oi = 0; oi < h->omS; ++oi) {
+        double c, sn;
+        cs_turns((double)(((long long)sp * (h->lo + oi)) % h->N) / h->N, &c, &sn);
+        cw[(size_t)sp * h->omS + oi] = mk<R>((R)c, (R)(-sn));
+      }
+    TRY(upload_table<R>(&h->cw, cw));
+  }
+  if (h->N == 2048) {
+    std::vector<cpx<R>> tw1g((size_t)32 * 64), omg((size_t)8 * h->omS);
+    build_tw1<R>(tw1g.data(), 32, cs_turns);
+    build_om<R>(omg.data(), h->omS, 32, h->lo, h->Np, true, cs_turns);
+    TRY(upload_table<R>(&h->tw1g, tw1g));
+    TRY(upload_table<R>(&h->omg, omg));
+  }
   return 0;
 }
 
@@ -464,10 +494,10 @@ extern "C" int fastmc_set_subharm(fastmc_t* h, const double* ps_sh, const double
 }
 
 // ------------------------------------------------------------------ launches
-template <class R, int P, int NS, int MODE>
+template <class R, int P, int NS, int MODE, int S = 1>
 static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
   const size_t lds = wave_lds_bytes<R, P, NS>(A.omS);
-  hipFuncSetAttribute((const void*)k_rows_wave<R, P, NS, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)k_rows_wave<R, P, NS, MODE, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   constexpr int WPB = WaveCfg<R, P, NS>::WPB;
 #if FMC_ROWMAP == 0
   const int items = A.nb * (A.N / ROWS_PER_WAVE);
@@ -476,29 +506,39 @@ static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
   constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
   const int blocks = (A.N / LR) * ((A.nb + BPG - 1) / BPG);
 #endif
-  hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE>), dim3(blocks), dim3(WPB * 64), lds, h->stream, A);
+  hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE, S>), dim3(blocks), dim3(WPB * 64), lds, h->stream, A);
 }
-template <class R, int P, int NS, int EPI>
+template <class R, int P, int NS, int EPI, int S = 1>
 static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
   const size_t lds = wave_lds_bytes<R, P, NS>(A.omS);
-  hipFuncSetAttribute((const void*)k_cols_wave<R, P, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)k_cols_wave<R, P, NS, EPI, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   constexpr int WPB = WaveCfg<R, P, NS>::WPB;
   const int items = A.nb * A.Np;
-  hipLaunchKernelGGL((k_cols_wave<R, P, NS, EPI>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, A);
+  hipLaunchKernelGGL((k_cols_wave<R, P, NS, EPI, S>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, A);
 }
 
-template <class R, int P, int NS>
+template <class R, int P, int NS, int S = 1>
 static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   {
     Span s(h, 0);
-    if (mode == 0) launch_rows_wave<R, P, NS, 0>(h, RA);
-    else launch_rows_wave<R, P, NS, 1>(h, RA);
+    if (mode == 0) launch_rows_wave<R, P, NS, 0, S>(h, RA);
+    else launch_rows_wave<R, P, NS, 1, S>(h, RA);
   }
   {
     Span s(h, 1);
-    if (epi == 0) launch_cols_wave<R, P, NS, 0>(h, CA);
-    else launch_cols_wave<R, P, NS, 1>(h, CA);
+    if (epi == 0) launch_cols_wave<R, P, NS, 0, S>(h, CA);
+    else launch_cols_wave<R, P, NS, 1, S>(h, CA);
   }
+}
+
+// N = 2048 (S = 2) and 4096 (S = 4): sub-rows of 1024 points through the P = 16 pipeline
+template <class R, int S>
+static int dispatch_wave_split(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  const int ns = pick_ns<R, 16>(h);
+  if (ns == 2) dispatch_wave<R, 16, 2, S>(h, RA, CA, mode, epi);
+  else if (ns == 4) dispatch_wave<R, 16, 4, S>(h, RA, CA, mode, epi);
+  else return fail(FASTMC_ESTATE, "no split-row instantiation for this window");
+  return 0;
 }
 
 template <class R, int P>
@@ -645,14 +685,30 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     CA.sh.enabled = sh ? (h->sh_sep ? 2 : 1) : 0; CA.sh.dcol = h->sh_dcol; CA.sh.coef = h->sh_coef; CA.sh.mean = h->sh_mean; CA.sh.ex = h->sh_ex; CA.sh.ey = h->sh_ey;
     CA.partial = h->partial + (size_t)((bs - fin_start)) * Np * 4; CA.phs = h->phs;
     bool wave_ok = h->path == 1;
+    bool general_2048 = false;   // N = 2048, window > 256 pixels, host coefficients: single-pass P = 32 kernels
     if (wave_ok) {
       int ns, wpb_unused;
       wave_config<R>(h, &ns, &wpb_unused);
-      if (ns == 0) wave_ok = false;   // window tables exceed the LDS: direct family (still on the GPU)
+      if (ns == 0) {
+        // window tables exceed the LDS / no instantiation: direct family (still on the GPU)
+        if (h->N == 2048 && S.mode == 1 && wave_lds_bytes<R, 32, 32>(h->omS) <= LDS_MAX) general_2048 = true;
+        else wave_ok = false;
+      }
     }
     RA.amp = (const R*)(wave_ok ? h->amp_s : h->amp);
-    RA.tw = (const cpx<R>*)(wave_ok ? h->tw1 : h->tw);
+    RA.tw = (const cpx<R>*)(wave_ok ? (general_2048 ? h->tw1g : h->tw1) : h->tw);
     CA.tw = RA.tw;
+    RA.cw = (const cpx<R>*)h->cw;
+    CA.cw = RA.cw;
+    if (general_2048) {
+      RA.om = (const cpx<R>*)h->omg;
+      CA.om = RA.om;
+      dispatch_wave<R, 32, 32>(h, RA, CA, S.mode, S.epi);
+    } else if (wave_ok && h->S == 2) {
+      TRY((dispatch_wave_split<R, 2>(h, RA, CA, S.mode, S.epi)));
+    } else if (wave_ok && h->S == 4) {
+      TRY((dispatch_wave_split<R, 4>(h, RA, CA, S.mode, S.epi)));
+    } else
     if (wave_ok) {
       switch (h->P) {
         case 2: dispatch_wave<R, 2, 2>(h, RA, CA, S.mode, S.epi); break;
@@ -671,7 +727,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
         case 16: TRY((dispatch_wave_ns<R, 16>(h, RA, CA, S.mode, S.epi))); break;
         case 20: dispatch_wave<R, 20, 2>(h, RA, CA, S.mode, S.epi); break;
         case 24: dispatch_wave<R, 24, 2>(h, RA, CA, S.mode, S.epi); break;
-        default: TRY((dispatch_wave_ns<R, 32>(h, RA, CA, S.mode, S.epi))); break;
+        default: return fail(FASTMC_ESTATE, "no wave instantiation for this grid size");
       }
     } else {
       TRY(dispatch_direct<R>(h, RA, CA, S.mode, S.epi));
@@ -752,7 +808,7 @@ extern "C" int fastmc_rng_coeffs(fastmc_t* h, uint64_t seed, int64_t real, doubl
   ScratchBuf d;
   HIPCHK(hipMalloc((void**)&d.p, (size_t)N * N * 16));
   RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
-  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * WAVE + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, d.p);
+  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * WAVE * spec_split(N) + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, d.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, d.p, (size_t)N * N * 16, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));

@@ -238,8 +238,12 @@ struct xoshiro128p {
 };
 
 // Streams of the device generator (counter word 1).
-//   STREAM_SCREEN: counter word 0 = ky*64 + (kx mod 64); the xoshiro stream seeded by that block
-//                  yields, for j = 0, 1, ..., the two words of coefficient (ky, kx = (kx mod 64) + 64 j).
+//   STREAM_SCREEN: counter word 0 = ky*SL + L, SL = 64*spec_split(N), L = kx mod SL; the xoshiro stream seeded by that
+//                  block yields, for j = 0, 1, ..., the two words of coefficient (ky, kx = L + SL j).
+// Generator layout: a grid of N columns is drawn as 64*spec_split(N) streams per row, stream L = kx mod (64 S)
+// yielding coefficient j <-> kx = L + 64 S j.  S > 1 where the wave kernels transform a row as S interleaved
+// sub-rows (kx = s mod S), so that lane l of pass s reads ONE stream (L = s + S l) sequentially.
+FMC_HD constexpr int spec_split(int N) { return N == 4096 ? 4 : (N == 2048 ? 2 : 1); }
 constexpr uint32_t STREAM_SCREEN = 0;
 constexpr uint32_t STREAM_LOGAMP = 1;   // counter words 2,3 = global iteration index
 constexpr uint32_t STREAM_SUBHARM = 2;  // counter word 0 = mode-pair index m in [0,14)

@@ -47,11 +47,11 @@ struct RngKey {
   uint32_t k0, k1;   // seed
 };
 
-// Coefficient stream of (realisation g, row ky, lane class l = kx mod 64): xoshiro128+ seeded with
-// one Philox block; its (2j)-th and (2j+1)-th words make coefficient (ky, l + 64 j).
-__device__ __forceinline__ xoshiro128p row_stream(RngKey key, uint64_t g, int ky, int l) {
+// Coefficient stream of (realisation g, row ky, stream L = kx mod SL), SL = 64 * spec_split(N): xoshiro128+
+// seeded with one Philox block; its (2j)-th and (2j+1)-th words make coefficient (ky, L + SL j).
+__device__ __forceinline__ xoshiro128p row_stream(RngKey key, uint64_t g, int ky, int L, int SL) {
   xoshiro128p s;
-  s.seed(philox4x32_10((uint32_t)(ky * WAVE + l), STREAM_SCREEN, (uint32_t)g, (uint32_t)(g >> 32), key.k0, key.k1));
+  s.seed(philox4x32_10((uint32_t)(ky * SL + L), STREAM_SCREEN, (uint32_t)g, (uint32_t)(g >> 32), key.k0, key.k1));
   return s;
 }
 template <class R>
@@ -78,6 +78,7 @@ struct RowArgs {
   const cpx<R>* tw;             // wave: tw1 [P*64];  direct: w_N^e, e < N
   const cpx<R>* om;             // wave: [8][omS]
   int omS;
+  const cpx<R>* cw;             // split rows (S > 1): [S][omS]  w_N^{s (lo + oi)}
   cpx<R>* V;                    // [nb][Np][N]  (window column major)
   RngKey key;
   uint64_t g0;                  // global index of realisation b = 0
@@ -101,6 +102,7 @@ struct ColArgs {
   const cpx<R>* tw;
   const cpx<R>* om;
   int omS;
+  const cpx<R>* cw;             // split columns (S > 1): [S][omS]
   const double* W;              // [Np][Np]
   SubharmArgs sh;
   double* partial;              // [nb][Np][4]  (EPI 0)
@@ -264,7 +266,11 @@ __host__ __device__ constexpr size_t wave_lds_bytes(int omS) {
   return (size_t)(P * WAVE + 8 * omS) * sizeof(cpx<R>) + (size_t)WaveCfg<R, P, NS>::WPB * WaveGeom<R, P>::XELEMS * 8;
 }
 
-template <class R, int P, int NS, int MODE>
+// S > 1: the row of NF = S * 64 P points is transformed as S interleaved sub-rows (kx = s mod S), each by
+// the same P-per-lane pipeline, and the window outputs are combined, X[x] = sum_s w_NF^{s x} Y_s[x mod 64 P]
+// (decimation in time, evaluated only for the window).  2048 = 2 x 1024 and 4096 = 4 x 1024 run the
+// P = 16 pipeline at 3 waves per SIMD instead of a 32-values-per-lane pipeline at 2.
+template <class R, int P, int NS, int MODE, int S = 1>
 __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = WaveGeom<R, P>;
@@ -276,7 +282,7 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   E* xbuf = s_x + w * G::XELEMS;
-  const int N = G::N;
+  const int N = S * G::N;           // full row length
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
 #if FMC_ROWMAP == 0
@@ -311,27 +317,33 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
     const uint64_t g = A.g0 + (uint64_t)b;
 #endif
     const R* amp = A.amp + (size_t)ky * N;
+    R accr[NS], acci[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) { accr[s2] = (R)0; acci[s2] = (R)0; }
+#pragma unroll 1
+    for (int sp = 0; sp < S; ++sp) {
+    // sub-row sp: kx = sp + S (lane + 64 j)
     if (MODE == 0) {
 #if defined(FMC_ABL_NOGEN)      // ablation (timing only, wrong results): no generator at all
 #pragma unroll
-      for (int j = 0; j < P; ++j) regs.v[j] = cscale(mk<R>((R)(lane + j), (R)(ky - j)), amp[lane + WAVE * j]);
+      for (int j = 0; j < P; ++j) regs.v[j] = cscale(mk<R>((R)(lane + j), (R)(ky - j)), amp[sp + S * (lane + WAVE * j)]);
 #elif defined(FMC_ABL_NOBM)     // ablation: uniform words only, no Box-Muller
-      xoshiro128p rs = row_stream(A.key, g, ky, lane);
+      xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
 #pragma unroll
       for (int j = 0; j < P; ++j) {
         const uint32_t a = rs.next(), bb = rs.next();
-        regs.v[j] = cscale(mk<R>((R)(int)a, (R)(int)bb), amp[lane + WAVE * j]);
+        regs.v[j] = cscale(mk<R>((R)(int)a, (R)(int)bb), amp[sp + S * (lane + WAVE * j)]);
       }
 #else
-      xoshiro128p rs = row_stream(A.key, g, ky, lane);
+      xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
 #pragma unroll
-      for (int j = 0; j < P; ++j) regs.v[j] = cscale(draw_coeff<R>(rs), amp[lane + WAVE * j]);
+      for (int j = 0; j < P; ++j) regs.v[j] = cscale(draw_coeff<R>(rs), amp[sp + S * (lane + WAVE * j)]);
 #endif
     } else {
       const size_t base = ((size_t)b * N + ky) * N;
 #pragma unroll
       for (int j = 0; j < P; ++j) {
-        const int kx = lane + WAVE * j;
+        const int kx = sp + S * (lane + WAVE * j);
         regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
       }
     }
@@ -343,6 +355,22 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
 #else
     pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
 #endif
+    if (S > 1) {
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const int oi = lane + WAVE * s2;
+        if (oi < A.Np) {
+          const cpx<R> c = A.cw[sp * A.omS + oi];
+          accr[s2] += c.x * regs.xr[s2] - c.y * regs.xi[s2];
+          acci[s2] += c.x * regs.xi[s2] + c.y * regs.xr[s2];
+        }
+      }
+    }
+    }
+    if (S > 1) {
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) { regs.xr[s2] = accr[s2]; regs.xi[s2] = acci[s2]; }
+    }
     // V is stored column-major per realisation, V[b][oi][ky], so that the column pass reads it
     // coalesced; the 8 consecutive rows of this wave complete one 128-byte line per window column.
     cpx<R>* out = A.V + (size_t)b * A.Np * N + ky;
@@ -359,7 +387,7 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
 }
 
 // EPI 0: detector partial sums; EPI 1: write the cropped screens.
-template <class R, int P, int NS, int EPI>
+template <class R, int P, int NS, int EPI, int S = 1>
 __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_cols_wave(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = WaveGeom<R, P>;
@@ -376,14 +404,37 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_cols_wave(Col
   if (item >= A.nb * A.Np) return;   // whole wave exits; no block barrier follows
   const int b = item / A.Np;
   const int xi = item % A.Np;
-  const int N = G::N;
+  const int N = S * G::N;
 
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
   const cpx<R>* col = A.V + ((size_t)b * A.Np + xi) * N;
+  if (S == 1) {
 #pragma unroll
-  for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
-  pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
+    pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+  } else {
+    R accr[NS], acci[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) { accr[s2] = (R)0; acci[s2] = (R)0; }
+#pragma unroll 1
+    for (int sp = 0; sp < S; ++sp) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (lane + WAVE * j)];
+      pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const int oi = lane + WAVE * s2;
+        if (oi < A.Np) {
+          const cpx<R> c = A.cw[sp * A.omS + oi];
+          accr[s2] += c.x * regs.xr[s2] - c.y * regs.xi[s2];
+          acci[s2] += c.x * regs.xi[s2] + c.y * regs.xr[s2];
+        }
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) { regs.xr[s2] = accr[s2]; regs.xi[s2] = acci[s2]; }
+  }
 
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -431,9 +482,10 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_rows_direct(RowArgs<R> A) {
   const R* amp = A.amp + (size_t)ky * N;
   for (int i = threadIdx.x; i < N; i += blockDim.x) s_tw[i] = A.tw[i];
   if (MODE == 0) {
-    if (threadIdx.x < WAVE && (int)threadIdx.x < N) {   // one sequential stream per lane class
-      xoshiro128p rs = row_stream(A.key, g, ky, threadIdx.x);
-      for (int kx = threadIdx.x; kx < N; kx += WAVE) s_row[kx] = cscale(draw_coeff<R>(rs), amp[kx]);
+    const int SL = WAVE * spec_split(N);
+    if ((int)threadIdx.x < SL && (int)threadIdx.x < N) {   // one sequential stream per stream index
+      xoshiro128p rs = row_stream(A.key, g, ky, threadIdx.x, SL);
+      for (int kx = threadIdx.x; kx < N; kx += SL) s_row[kx] = cscale(draw_coeff<R>(rs), amp[kx]);
     }
   } else {
     const size_t base = ((size_t)b * N + ky) * N;
@@ -865,12 +917,13 @@ __global__ void k_link_final(const double* partial, int nblocks, int64_t n, cons
 
 // ================================================================== generator read-back (parity tests)
 __global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, double* out) {
+  const int SL = WAVE * spec_split(N);
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * WAVE) return;
-  const int ky = idx / WAVE, l = idx % WAVE;
+  if (idx >= N * SL) return;
+  const int ky = idx / SL, l = idx % SL;
   if (l >= N) return;
-  xoshiro128p rs = row_stream(key, g, ky, l);
-  for (int kx = l; kx < N; kx += WAVE) {
+  xoshiro128p rs = row_stream(key, g, ky, l, SL);
+  for (int kx = l; kx < N; kx += SL) {
     const cpx<double> c = draw_coeff<double>(rs);
     out[2 * ((size_t)ky * N + kx)] = c.x;
     out[2 * ((size_t)ky * N + kx) + 1] = c.y;

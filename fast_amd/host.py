@@ -17,8 +17,9 @@ from . import hostmath as hm
 
 logger = logging.getLogger(__name__)
 TWO_PI = 2 * np.pi
-# grid sizes served by the wave-FFT kernels: 64 * 2^k * {1, 3, 5, 7, 9}, 128 ... 2048 (fmc_wavefft.h)
-WAVE_FFT_SIZES = sorted(64 * q * 2 ** k for q in (1, 3, 5, 7, 9) for k in range(6) if 2 <= q * 2 ** k <= 32)
+# grid sizes served by the wave-FFT kernels: 64 * 2^k * {1, 3, 5, 7, 9}, 128 ... 2048 (fmc_wavefft.h), and 4096
+# (4 interleaved sub-rows of 1024; 2048 runs as 2)
+WAVE_FFT_SIZES = sorted(64 * q * 2 ** k for q in (1, 3, 5, 7, 9) for k in range(6) if 2 <= q * 2 ** k <= 32) + [4096]
 # sizes GPU_ROUND_NPXLS rounds up to: 896 and 1792 (radix-7 stage, 2 resp. 1 waves per SIMD) are slower than the
 # next power of two (measured 0.55 vs 0.73 M it/s and 0.137 vs 0.153 M it/s, tools/sizesweep.sh)
 MAX_NPXLS = 4096          # libfastmc: N <= 4096 (fastmc_create)

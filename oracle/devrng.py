@@ -62,26 +62,33 @@ def xoshiro128p_next(s):
     return r
 
 
+def spec_split(N):
+    """fmc_core.h: spec_split -- sub-rows per row of the wave kernels, which fixes the stream layout."""
+    return 4 if N == 4096 else (2 if N == 2048 else 1)
+
+
 def device_coefficients(seed, g, N):
     """(N, N) complex coefficients of realisation g (== fastmc_rng_coeffs).
 
-    Stream (g, ky, l = kx mod 64): state = Philox4x32-10(ctr = (ky*64 + l, STREAM_SCREEN, g_lo, g_hi),
-    key = seed) (s0 := 1 if the block is all zero); coefficient (ky, l + 64 j) = BM(word 2j, word 2j+1)
-    of xoshiro128+ (fmc_core.h: xoshiro128p, fmc_kernels.h: row_stream / draw_coeff)."""
-    lanes = min(64, N)
+    SL = 64 * spec_split(N) streams per row.  Stream (g, ky, L = kx mod SL): state = Philox4x32-10(ctr =
+    (ky*SL + L, STREAM_SCREEN, g_lo, g_hi), key = seed) (s0 := 1 if the block is all zero); coefficient
+    (ky, L + SL j) = BM(word 2j, word 2j+1) of xoshiro128+ (fmc_core.h: xoshiro128p, fmc_kernels.h:
+    row_stream / draw_coeff)."""
+    SL = 64 * spec_split(N)
+    lanes = min(SL, N)
     ky, l = np.meshgrid(np.arange(N), np.arange(lanes), indexing="ij")
-    x = philox4x32_10(ky * 64 + l, STREAM_SCREEN, g & 0xFFFFFFFF, g >> 32, seed & 0xFFFFFFFF, seed >> 32)
+    x = philox4x32_10(ky * SL + l, STREAM_SCREEN, g & 0xFFFFFFFF, g >> 32, seed & 0xFFFFFFFF, seed >> 32)
     s = [np.array(w, dtype=np.uint64).astype(np.uint32) for w in x]
     zero = (s[0] | s[1] | s[2] | s[3]) == 0
     s[0][zero] = 1
     out = np.empty((N, N), dtype=complex)
     with np.errstate(over="ignore"):
-        for j in range((N + 63) // 64):
+        for j in range((N + SL - 1) // SL):
             a = xoshiro128p_next(s)
             b = xoshiro128p_next(s)
             c = box_muller(a, b)
-            w = min(64, N - 64 * j)
-            out[:, 64 * j:64 * j + w] = c[:, :w]
+            w = min(SL, N - SL * j)
+            out[:, SL * j:SL * j + w] = c[:, :w]
     return out
 
 

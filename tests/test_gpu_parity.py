@@ -30,13 +30,16 @@ def _window_W(Np, seed=0):
 
 
 # ------------------------------------------------------------------ generator
-@pytest.mark.parametrize("N", [16, 33, 512])
+@pytest.mark.parametrize("N", [16, 33, 512, 2048, 4096])
 def test_device_generator_matches_oracle_restatement(N):
     h = _lib.Handle(N, max(1, N // 4), "f64", 0)
     for seed, g in ((1, 0), (0xDEADBEEFCAFE, 5), (7, 2 ** 33 + 3)):
         got = h.rng_coeffs(seed, g)
         want = devrng.device_coefficients(seed, g, N)
-        assert np.abs(got - want).max() < 1e-4
+        err = np.abs(got - want)
+        # float32 hardware log / sqrt / sin / cos against float64: ~1e-7 typically; the radius loses relative
+        # accuracy where u -> 1 (|ln u| tiny), which 16.8 M draws at 4096^2 do reach
+        assert err.max() < 1e-3 and np.quantile(err, 0.9999) < 1e-5
     la = h.rng_logamp(9, 2 ** 32 - 4, 16)
     assert np.abs(la - devrng.device_logamp_normals(9, 2 ** 32 - 4, 16)).max() < 1e-4
     big = h.rng_coeffs(3, 1)
@@ -63,12 +66,14 @@ def test_screens_match_reference_fft_kat(N, prec, tol):
 # ------------------------------------------------------------------ screens: wave family vs numpy FFT
 @pytest.mark.parametrize("N,Np", [(128, 22), (128, 128), (192, 82), (320, 33), (384, 128), (640, 82), (768, 82), (1280, 82), (1536, 101), (768, 300), (448, 82), (576, 82), (896, 82), (1152, 82), (1792, 82),
                                   (256, 82), (256, 200), (256, 256), (512, 82), (1024, 82), (2048, 82), (512, 23), (1024, 200), (512, 512), (1024, 1), (2048, 129),
-                                  (512, 150), (1024, 129), (1024, 256), (1024, 257), (2048, 256)])
+                                  (512, 150), (1024, 129), (1024, 256), (1024, 257), (2048, 256), (2048, 300), (4096, 82), (4096, 200)])
 @pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 5e-5)])
 def test_wave_kernels_match_oracle_fft(N, Np, prec, tol):
     ps, df = _vk_spectrum(N, 0.01, 25.0)
     rng = np.random.default_rng(N + Np)
     B = 2 if N < 2048 else 1
+    if N == 4096 and prec == "f32":
+        pytest.skip("4096^2 oracle transform once is enough")
     cr, ci = rng.normal(size=(B, N, N)), rng.normal(size=(B, N, N))
     lo = (N - Np) // 2
     want = R.crop(R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df)), N, Np)
@@ -225,11 +230,13 @@ def _small_problem(N=512, Np=82, prec="f64", scale=0.02):
     return h, ps * scale, df, W
 
 
-@pytest.mark.parametrize("N", [64, 512])
+@pytest.mark.parametrize("N", [64, 512, 2048, 4096])
 def test_device_rng_run_matches_oracle_with_restated_generator(N):
+    """2048 and 4096 run as 2 resp. 4 interleaved sub-rows of 1024 (split wave kernels), with 128 resp. 256
+    generator streams per row; the device result must follow the restated generator there too."""
     Np = 22 if N == 64 else 82
     h, ps, df, W = _small_problem(N, Np)
-    seed, real0, n = 42, 5, 4
+    seed, real0, n = 42, 5, (4 if N <= 512 else 2)
     got = h.run(seed, real0, n, None, 0.01)
     coeffs = np.stack([devrng.device_coefficients(seed, real0 + j, N) for j in range(n)])
     it = 2 * real0

@@ -139,4 +139,4 @@ def test_optional_rounding_of_auto_grid_size():
     assert host.build_problem(dict(p)).N == 164                      # the reference's auto rule, untouched by default
     p["GPU_ROUND_NPXLS"] = True
     assert host.build_problem(dict(p)).N == 192
-    assert host.WAVE_FFT_SIZES == [128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1152, 1280, 1536, 1792, 2048]
+    assert host.WAVE_FFT_SIZES == [128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1152, 1280, 1536, 1792, 2048, 4096]

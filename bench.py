@@ -92,12 +92,13 @@ def cpu_baseline(sim, seconds_target=12.0):
 
 def extras(args, device):
     """Short side measurements printed next to the headline (never part of `value`): the float32
-    pipeline on the same job and BASELINE configs[2] (AO-corrected residual spectrum, float64),
-    with the time of the GPU power-spectrum evaluation that config adds to every `Fast()`."""
+    pipeline on the same job, BASELINE configs[2] (AO-corrected residual spectrum, float64) with the time
+    of the GPU power-spectrum evaluation that config adds to every `Fast()`, and the 2048^2 grid of configs[3]."""
     import copy
     import fast_amd
     out = {}
-    for tag, over in (("f32_same_job", {"GPU_PRECISION": "f32"}), ("config2_AO_alias_f64", {"AO_MODE": "AO", "ALIAS": True})):
+    for tag, over in (("f32_same_job", {"GPU_PRECISION": "f32"}), ("config2_AO_alias_f64", {"AO_MODE": "AO", "ALIAS": True}),
+                      ("config3_2048_f64", {"NPXLS": 2048})):
         a = copy.copy(args)
         p = workload_params(a)
         p.update(over)

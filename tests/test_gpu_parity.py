@@ -244,6 +244,9 @@ def test_device_rng_run_matches_oracle_with_restated_generator(N):
     la = np.concatenate([chi[0::2], chi[1::2]])
     want = R.powers_from_coefficients(coeffs, ps, df, W, 0.01, la)
     np.testing.assert_allclose(got, want, rtol=2e-3)
+    if N in (512, 2048):
+        h.kernel_path(0)                               # the direct family draws the same streams
+        np.testing.assert_allclose(h.run(seed, real0, n, None, 0.01), got, rtol=1e-9)
 
 
 def test_device_rng_invariant_to_batch_and_split():

@@ -204,10 +204,12 @@ static bool wave_supported(int N) {
 // Which window instantiation of the wave family serves this handle: NS = 2 (Np <= 128), NS = 4
 // (Np <= 256; P = 8, 16, 32), NS = P (any window, powers of two), or 0 when none fits the LDS.
 constexpr size_t LDS_MAX = 160 * 1024;
+// P with an NS = 4 instantiation (windows of 129-256 pixels): 512, 576, 640, 768, 1024 (and 2048 / 4096 as sub-rows), 1280, 1536
+constexpr bool has_ns4(int P) { return P == 8 || P == 9 || P == 10 || P == 12 || P == 16 || P == 20 || P == 24; }
 template <class R, int PP>
 static int pick_ns(const fastmc_ctx* h) {
   if (h->NS <= 2) return wave_lds_bytes<R, PP, 2>(h->omS) <= LDS_MAX ? 2 : 0;
-  if constexpr (is_pow2(PP) && PP >= 8) {
+  if constexpr (has_ns4(PP)) {
     if (h->NS <= 4 && wave_lds_bytes<R, PP, 4>(h->omS) <= LDS_MAX) return 4;
   }
   if (h->S > 1) return 0;    // split rows: windows up to 256 pixels only
@@ -224,7 +226,7 @@ static void wave_config(const fastmc_ctx* h, int* ns, int* wpb) {
   case PP:                                                                                                   \
     *ns = pick_ns<R, PP>(h);                                                                                 \
     *wpb = WaveCfg<R, PP, 2>::WPB;                                                                           \
-    if constexpr (is_pow2(PP) && PP >= 8) { if (*ns == 4) *wpb = WaveCfg<R, PP, 4>::WPB; }                   \
+    if constexpr (has_ns4(PP)) { if (*ns == 4) *wpb = WaveCfg<R, PP, 4>::WPB; }                              \
     if constexpr (is_pow2(PP) && PP >= 4) { if (*ns == PP && PP > 2) *wpb = WaveCfg<R, PP, PP>::WPB; }       \
     break;
   switch (h->P) {
@@ -546,9 +548,11 @@ static int dispatch_wave_ns(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
   // up to three instantiations per (R, P): windows up to 128 pixels, up to 256, and the general case
   const int ns = pick_ns<R, P>(h);
   if (ns == 2) dispatch_wave<R, P, 2>(h, RA, CA, mode, epi);
-  else if (ns == 4 && P >= 8) {
-    if constexpr (P >= 8) dispatch_wave<R, P, 4>(h, RA, CA, mode, epi);
-  } else if (ns == P) dispatch_wave<R, P, P>(h, RA, CA, mode, epi);
+  else if (ns == 4 && has_ns4(P)) {
+    if constexpr (has_ns4(P)) dispatch_wave<R, P, 4>(h, RA, CA, mode, epi);
+  } else if (ns == P) {
+    if constexpr (is_pow2(P)) dispatch_wave<R, P, P>(h, RA, CA, mode, epi);
+  }
   else return fail(FASTMC_ESTATE, "no wave instantiation for this window");
   return 0;
 }
@@ -718,15 +722,15 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
         case 6: dispatch_wave<R, 6, 2>(h, RA, CA, S.mode, S.epi); break;
         case 7: dispatch_wave<R, 7, 2>(h, RA, CA, S.mode, S.epi); break;
         case 8: TRY((dispatch_wave_ns<R, 8>(h, RA, CA, S.mode, S.epi))); break;
-        case 9: dispatch_wave<R, 9, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 9: TRY((dispatch_wave_ns<R, 9>(h, RA, CA, S.mode, S.epi))); break;
         case 14: dispatch_wave<R, 14, 2>(h, RA, CA, S.mode, S.epi); break;
         case 18: dispatch_wave<R, 18, 2>(h, RA, CA, S.mode, S.epi); break;
         case 28: dispatch_wave<R, 28, 2>(h, RA, CA, S.mode, S.epi); break;
-        case 10: dispatch_wave<R, 10, 2>(h, RA, CA, S.mode, S.epi); break;
-        case 12: dispatch_wave<R, 12, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 10: TRY((dispatch_wave_ns<R, 10>(h, RA, CA, S.mode, S.epi))); break;
+        case 12: TRY((dispatch_wave_ns<R, 12>(h, RA, CA, S.mode, S.epi))); break;
         case 16: TRY((dispatch_wave_ns<R, 16>(h, RA, CA, S.mode, S.epi))); break;
-        case 20: dispatch_wave<R, 20, 2>(h, RA, CA, S.mode, S.epi); break;
-        case 24: dispatch_wave<R, 24, 2>(h, RA, CA, S.mode, S.epi); break;
+        case 20: TRY((dispatch_wave_ns<R, 20>(h, RA, CA, S.mode, S.epi))); break;
+        case 24: TRY((dispatch_wave_ns<R, 24>(h, RA, CA, S.mode, S.epi))); break;
         default: return fail(FASTMC_ESTATE, "no wave instantiation for this grid size");
       }
     } else {

@@ -250,7 +250,8 @@ template <class R, int P, int NS> struct WaveCfg {
 #ifndef FMC_WPB_P32_F64
 #define FMC_WPB_P32_F64 6
 #endif
-  static constexpr int WPB = (NS > 4 || (NS > 2 && NS == P)) ? 4 : (P == 32 ? (sizeof(R) == 8 ? FMC_WPB_P32_F64 : 6) : ((P > 16 && P / (P & -P) >= 7) ? 4 : (P > 24 ? 6 : ((P > 16 || (!is_pow2(P) && P > 8)) ? 8 : FMC_WPB))));
+  static constexpr int WPB = (NS > 4 || (NS > 2 && NS == P)) ? 4 : (NS == 4 && P == 24) ? 6 :   // 256-pixel window tables: 6 waves fit the LDS
+                              (P == 32 ? (sizeof(R) == 8 ? FMC_WPB_P32_F64 : 6) : ((P > 16 && P / (P & -P) >= 7) ? 4 : (P > 24 ? 6 : ((P > 16 || (!is_pow2(P) && P > 8)) ? 8 : FMC_WPB))));
 };
 
 template <class R, int P>

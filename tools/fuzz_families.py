@@ -1,0 +1,37 @@
+"""Differential fuzz: wave family vs direct family on random (N, Np, lo, precision) with host coefficients,
+and both against numpy for the smaller grids.  tools/fuzz_families.py [cases] [seed]"""
+import sys
+import numpy as np
+from fast_amd import _lib, host
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for c in range(cases):
+    N = int(rng.choice(host.WAVE_FFT_SIZES))
+    if N >= 2048 and rng.random() < 0.5:
+        N = int(rng.choice([s for s in host.WAVE_FFT_SIZES if s < 2048]))
+    Np = int(rng.integers(1, min(N, 300) + 1))
+    lo = int(rng.choice([0, N - Np, (N - Np) // 2, rng.integers(0, N - Np + 1)]))
+    prec = "f64" if rng.random() < 0.7 else "f32"
+    tol = 1e-10 if prec == "f64" else 1e-4
+    ps = rng.uniform(0.0, 1.0, size=(N, N)) ** 4
+    cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
+    h = _lib.Handle(N, Np, prec, 0)
+    h.set_spectrum(ps, 0.37)
+    h.set_pupil(np.ones((Np, Np)), lo, 0.01)
+    a = h.screens_coeffs(cr, ci)
+    path = h.kernel_path()
+    h.kernel_path(0)
+    b = h.screens_coeffs(cr, ci)
+    h.close()
+    err = np.abs(a - b).max() / np.abs(b).max()
+    ref_err = float("nan")
+    if N <= 1024:
+        z = np.fft.fftshift(np.fft.fft2(np.fft.fftshift((cr[0] + 1j * ci[0]) * np.sqrt(ps) * 0.37)))[lo:lo + Np, lo:lo + Np]
+        ref_err = max(np.abs(a[0] - z.real).max(), np.abs(a[1] - z.imag).max()) / np.abs(z).max()
+    ok = err < tol and not (ref_err >= tol)
+    bad += not ok
+    print(f"{'ok ' if ok else 'BAD'} N={N:5d} Np={Np:4d} lo={lo:5d} {prec} path={path} wave-vs-direct {err:.2e} vs-numpy {ref_err:.2e}")
+print("failures:", bad)
+sys.exit(1 if bad else 0)

@@ -43,6 +43,16 @@ def workload_params(args):
     }
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sim, seconds_target=12.0):
     """The oracle (numpy restatement of the reference's CPU path, FFTW-branch semantics) timed on
     this host on a bounded sample of the same workload: one core (the reference's default,
@@ -66,7 +76,7 @@ def cpu_baseline(sim, seconds_target=12.0):
            "sample": f"median of 3 x {n_it} iterations ({chunks} chunks of 20) of the same {ps.shape[0]}^2 workload, "
                      f"oracle/fastref.py (numpy {np.__version__} pocketfft, float64, 1 thread); "
                      f"repeats {', '.join(f'{x:.1f}' for x in rates)} it/s",
-           "host_cpus": os.cpu_count()}
+           "host_cpus": os.cpu_count(), "cpu_model": _cpu_model()}
     try:   # all cores: one child program per core (never a fork of this GPU-initialised process)
         import subprocess
         import tempfile

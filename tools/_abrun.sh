@@ -1,3 +1,3 @@
-for p in f64 f32; do
-NPX=1024 PREC=$p tools/abl.sh fast_amd/libfastmc.so fast_amd/libfastmc_c5.so fast_amd/libfastmc_c4.so fast_amd/libfastmc_c6.so fast_amd/libfastmc.so fast_amd/libfastmc_c5.so 2>&1 | grep "rows "
+for s in 256 512 1024; do
+NPX=$s PREC=f64 tools/abl.sh fast_amd/libfastmc.so fast_amd/libfastmc_cpw2.so fast_amd/libfastmc_cpw4.so fast_amd/libfastmc_cpw4a.so fast_amd/libfastmc.so 2>&1 | grep "rows "
 done

@@ -183,10 +183,41 @@ __device__ __forceinline__ void sincos_r(float x, double& s, double& c) {
   s = fs; c = fc;
 }
 
+#ifndef FMC_DPP_REDUCE
+#define FMC_DPP_REDUCE 1
+#endif
+// One DPP-permuted copy of a double (two 32-bit movs; all rows and banks enabled).
+template <int CTRL>
+__device__ __forceinline__ double dpp_copy(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Sum over the 64 lanes, the same value in every lane, in a fixed order (deterministic).  Within a
+// 16-lane row by DPP (quad permutes, half-row mirror, row mirror: register-file crossbar, no LDS), then
+// the four row sums by v_readlane -- instead of six ds_bpermute round trips per value.
 __device__ __forceinline__ double wave_sum(double v) {
+#if FMC_DPP_REDUCE
+  v += dpp_copy<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_copy<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_copy<0x141>(v);    // row_half_mirror
+  v += dpp_copy<0x140>(v);    // row_mirror
+  const long long b = __double_as_longlong(v);
+  const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  double r[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int l2 = __builtin_amdgcn_readlane(lo, 16 * q), h2 = __builtin_amdgcn_readlane(hi, 16 * q);
+    r[q] = __longlong_as_double(((long long)h2 << 32) | (unsigned int)l2);
+  }
+  return (r[0] + r[1]) + (r[2] + r[3]);
+#else
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+#endif
 }
 
 // ================================================================== wave family
@@ -388,8 +419,15 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
 }
 
 // EPI 0: detector partial sums; EPI 1: write the cropped screens.
+// Small grids (P <= 8): each wave is short-lived (one column, a few microseconds of mostly latency), so
+// two workgroups per CU are worth a tighter register budget (6 waves per SIMD): column time -26 % at
+// 128^2 / 256^2, -17 % at 512^2.  (The same hint on the rows kernel spills and gains nothing.)
+#ifndef FMC_COLS_WPE_MAXP
+#define FMC_COLS_WPE_MAXP 8
+#endif
 template <class R, int P, int NS, int EPI, int S = 1>
-__global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_cols_wave(ColArgs<R> A) {
+__global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64), ((P <= FMC_COLS_WPE_MAXP && P != 7 && NS == 2 && WaveCfg<R, P, NS>::WPB == 12) ? 6 : 1))
+void k_cols_wave(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = WaveGeom<R, P>;
   using E = typename Xch<R>::E;

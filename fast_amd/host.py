@@ -92,9 +92,15 @@ def grid_size(p, atm):
         n_ap = int(2 * np.ceil(D / dx / 2)) + 2
         n_t = int(p['WIND_SPD'].max() * p['DT'] * p['NITER'] / p['DX'] / 2) if p['TEMPORAL'] else 0
         N = np.max([n_nyq, n_ap, n_t])
-        if p.get('GPU_ROUND_NPXLS', False):
-            # opt-in: the reference's auto rule gives arbitrary even sizes (164 for the shipped example);
-            # the next size of the fast kernel family samples the spectrum slightly finer
+        rnd = p.get('GPU_ROUND_NPXLS', False)
+        if rnd == 'auto':
+            # host-drawn coefficients (parity with the reference for a seed) and TEMPORAL series (numpy
+            # draws in the reference's order) need the reference's exact grid; the device generator does not
+            rnd = p.get('GPU_RNG', 'device') == 'device' and not p['TEMPORAL']
+        if rnd:
+            # the reference's auto rule is a lower bound and gives arbitrary even sizes (164 for the shipped
+            # example, 5x slower on the direct kernels than 192 on the wave kernels); the next size of the
+            # fast kernel family samples the spectrum slightly finer
             bigger = [s for s in ROUND_UP_SIZES if s >= N]
             if bigger:
                 logger.info(f"GPU_ROUND_NPXLS: auto NPXLS {N} -> {bigger[0]}")

@@ -30,6 +30,7 @@ def params_from_json(s):
             out[k] = float(v["__float__"])
         else:
             out[k] = v
+    out.setdefault("GPU_ROUND_NPXLS", False)     # captured configs are compared with the reference on ITS grid
     return out
 
 

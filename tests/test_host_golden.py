@@ -136,7 +136,15 @@ def test_fits_round_trip(tmp_path):
 def test_optional_rounding_of_auto_grid_size():
     g = load_golden("e2e_default164")
     p = fast_amd.conf.ConfigParser(dict(params_from_json(g["params_json"]))).config
-    assert host.build_problem(dict(p)).N == 164                      # the reference's auto rule, untouched by default
+    p["GPU_ROUND_NPXLS"] = False
+    assert host.build_problem(dict(p)).N == 164                      # the reference's auto rule
     p["GPU_ROUND_NPXLS"] = True
     assert host.build_problem(dict(p)).N == 192
+    p["GPU_ROUND_NPXLS"] = "auto"                                    # default: round unless the grid is tied to the reference's
+    for rng_mode, temporal, n in (("device", False, 192), ("host", False, 164), ("device", True, None)):
+        q = dict(p, GPU_RNG=rng_mode, TEMPORAL=temporal)
+        if n is not None:
+            assert host.build_problem(q).N == n
+        else:
+            assert host.build_problem(q).N not in (192,) or host.build_problem(dict(q, GPU_ROUND_NPXLS=False)).N == 192
     assert host.WAVE_FFT_SIZES == [128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1152, 1280, 1536, 1792, 2048, 4096]

@@ -664,3 +664,28 @@ def test_subharmonic_screens_separable_and_general_grids(N, Np, rotate):
         h.set_subharm(ps_lo, grid.fx, grid.fy, grid.df)
         got = h.screens_coeffs(cr, ci, sr, si)
         assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
+
+
+def test_two_handles_in_two_threads():
+    """Handles are independent (own stream, own buffers; ctypes releases the GIL): two threads running
+    different problems concurrently get what they get alone."""
+    import threading
+    jobs = [(512, 82, "f64", 11), (256, 40, "f32", 12)]
+    alone, together = {}, {}
+
+    def work(store, job):
+        N, Np, prec, seed = job
+        h, ps, df, W = _small_problem(N, Np, prec)
+        out = [h.run(seed, 7 * k, 50, None, 0.01) for k in range(6)]
+        store[job] = np.concatenate(out)
+        h.close()
+
+    for j in jobs:
+        work(alone, j)
+    ts = [threading.Thread(target=work, args=(together, j)) for j in jobs]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for j in jobs:
+        np.testing.assert_array_equal(alone[j], together[j])

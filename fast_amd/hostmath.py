@@ -13,8 +13,8 @@ def circle(radius, size):
     """Disc of `radius` pixels on a size x size grid, pixel centres at 0.5, 1.5, ...,
     disc centre at size/2 (aotools.circle, origin='middle')."""
     c = np.arange(0.5, size, 1.0) - size / 2.0
-    x, y = np.meshgrid(c, c)
-    return (x * x + y * y <= radius * radius).astype(float)
+    cc = c * c                                   # x*x + y*y of the meshgrid form, without the two N x N copies
+    return (cc[None, :] + cc[:, None] <= radius * radius).astype(float)
 
 
 def gaussian2d(size, width):

@@ -361,6 +361,17 @@ def big(p):
     capture_sim("big_ao_1024", pb3, "BASELINE config 3 geometry (AO + ALIAS), NITER 8", full=False, stride=16)
 
 
+def big2048():
+    """BASELINE configs[3] geometry (2048^2), 4 iterations of the reference: the grid the wave kernels
+    transform as two interleaved sub-rows."""
+    h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
+    p = dict(fast.conf.DEFAULTS)
+    p.update({"NPXLS": 2048, "DX": 0.01, "NITER": 4, "NCHUNKS": 2, "TEMPORAL": False, "FFTW": True, "SEED": 5, "W0": "opt",
+              "D_GROUND": 0.8, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w, "WIND_DIR": [0, 90, 180, 270], "ZENITH_ANGLE": 55,
+              "DSUBAP": 0.1, "LOGLEVEL": "ERROR", "H_SAT": 36e6, "AO_MODE": "NOAO", "L0": 25.0})
+    capture_sim("big_noao_L0_2048", p, "BASELINE configs[3] geometry (2048^2), NOAO, L0=25, NITER 4", full=False, stride=32)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("capturing into", OUT)
@@ -371,7 +382,7 @@ def main():
             e2e(only[0].split("=", 1)[1].split(","))
         else:
             {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref,
-             "--only-comms": comms_metrics}[only[0]]()
+             "--only-comms": comms_metrics, "--only-big2048": big2048}[only[0]]()
         for name, size, st, note in MANIFEST:
             print(f"| {name}.npz | {size} | {st} | {note} |")
         return

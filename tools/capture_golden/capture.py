@@ -370,6 +370,10 @@ def big2048():
               "D_GROUND": 0.8, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w, "WIND_DIR": [0, 90, 180, 270], "ZENITH_ANGLE": 55,
               "DSUBAP": 0.1, "LOGLEVEL": "ERROR", "H_SAT": 36e6, "AO_MODE": "NOAO", "L0": 25.0})
     capture_sim("big_noao_L0_2048", p, "BASELINE configs[3] geometry (2048^2), NOAO, L0=25, NITER 4", full=False, stride=32)
+    if "--with-4096" in sys.argv:
+        p4 = dict(p)
+        p4.update({"NPXLS": 4096, "NITER": 2, "NCHUNKS": 1, "SEED": 6})
+        capture_sim("big_noao_L0_4096", p4, "4096^2 (four interleaved sub-rows on the GPU), NOAO, L0=25, NITER 2", full=False, stride=64)
 
 
 def main():

@@ -558,9 +558,17 @@ static int dispatch_wave_ns(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
 }
 
 template <class R>
-static int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+static int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in, int mode, int epi) {
   // LDS: twiddles [N] + row/column [N] + segment partials [S][Np] (S*Np <= max(256, Np))
-  const size_t lds = ((size_t)2 * h->N + (size_t)std::max(DIRECT_THREADS, h->Np)) * sizeof(cpx<R>);
+  size_t lds = ((size_t)2 * h->N + (size_t)std::max(DIRECT_THREADS, h->Np)) * sizeof(cpx<R>);
+  RowArgs<R> RA = RA_in;
+  ColArgs<R> CA = CA_in;
+  RA.tw_global = CA.tw_global = 0;
+  if (lds > 160 * 1024 - 4096) {
+    // keep the N twiddles in global memory (L2-resident) and only the row / column in the LDS
+    lds -= (size_t)h->N * sizeof(cpx<R>);
+    RA.tw_global = CA.tw_global = 1;
+  }
   if (lds > 160 * 1024 - 4096) return fail(FASTMC_EINVAL, "N too large for the direct kernels at this precision");
   {
     Span s(h, 0);
@@ -703,6 +711,8 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     RA.tw = (const cpx<R>*)(wave_ok ? (general_2048 ? h->tw1g : h->tw1) : h->tw);
     CA.tw = RA.tw;
     RA.cw = (const cpx<R>*)h->cw;
+    RA.tw_global = 0;
+    CA.tw_global = 0;
     CA.cw = RA.cw;
     if (general_2048) {
       RA.om = (const cpx<R>*)h->omg;

@@ -79,6 +79,7 @@ struct RowArgs {
   const cpx<R>* om;             // wave: [8][omS]
   int omS;
   const cpx<R>* cw;             // split rows (S > 1): [S][omS]  w_N^{s (lo + oi)}
+  int tw_global;                // direct family: twiddles read from global memory (the LDS holds the row only)
   cpx<R>* V;                    // [nb][Np][N]  (window column major)
   RngKey key;
   uint64_t g0;                  // global index of realisation b = 0
@@ -103,6 +104,7 @@ struct ColArgs {
   const cpx<R>* om;
   int omS;
   const cpx<R>* cw;             // split columns (S > 1): [S][omS]
+  int tw_global;                // direct family: twiddles read from global memory
   const double* W;              // [Np][Np]
   SubharmArgs sh;
   double* partial;              // [nb][Np][4]  (EPI 0)
@@ -513,13 +515,17 @@ template <class R, int MODE>
 __global__ __launch_bounds__(DIRECT_THREADS) void k_rows_direct(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = A.N;
-  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
-  cpx<R>* s_row = s_tw + N;
+  // [twiddles N][row N][partials]; with tw_global (grids whose 3 N complex do not fit the LDS, e.g. a
+  // full-window transform at 4096) the table stays in global memory / L2
+  cpx<R>* s_lds = reinterpret_cast<cpx<R>*>(smem);
+  const cpx<R>* s_tw = A.tw_global ? A.tw : s_lds;
+  cpx<R>* s_row = s_lds + (A.tw_global ? 0 : N);
   const int b = blockIdx.x % A.nb;
   const int ky = blockIdx.x / A.nb;
   const uint64_t g = A.g0 + (uint64_t)b;
   const R* amp = A.amp + (size_t)ky * N;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) s_tw[i] = A.tw[i];
+  if (!A.tw_global)
+    for (int i = threadIdx.x; i < N; i += blockDim.x) s_lds[i] = A.tw[i];
   if (MODE == 0) {
     const int SL = WAVE * spec_split(N);
     if ((int)threadIdx.x < SL && (int)threadIdx.x < N) {   // one sequential stream per stream index
@@ -573,12 +579,13 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_cols_direct(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double s_red[4][DIRECT_THREADS / 64];
   const int N = A.N;
-  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
-  cpx<R>* s_col = s_tw + N;
+  cpx<R>* s_lds = reinterpret_cast<cpx<R>*>(smem);
+  const cpx<R>* s_tw = A.tw_global ? A.tw : s_lds;
+  cpx<R>* s_col = s_lds + (A.tw_global ? 0 : N);
   const int b = blockIdx.x / A.Np;
   const int xi = blockIdx.x % A.Np;
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
-    s_tw[i] = A.tw[i];
+    if (!A.tw_global) s_lds[i] = A.tw[i];
     s_col[i] = A.V[((size_t)b * A.Np + xi) * N + i];
   }
   __syncthreads();

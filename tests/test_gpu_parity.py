@@ -594,10 +594,11 @@ def test_link_metrics_on_resident_results_match_oracle():
         _lib.link_metrics([(7, 0.0, 0.0)], samples=np.ones(4))
 
 
-@pytest.mark.parametrize("N", [48, 49, 64, 100, 256])
+@pytest.mark.parametrize("N", [48, 49, 64, 100, 256, 2048, 4096])
 def test_centred_fft2_matches_numpy(N):
     """_lib.centred_fft2 (the row/column kernels with the window = the whole grid; wave family for
-    64 and 256, direct family otherwise, odd N with numpy's asymmetric shifts) vs numpy.fft."""
+    64, 256 and 2048 (its single-pass P = 32 kernels), direct family otherwise -- at 4096 with the twiddles
+    in global memory because 3 N complex exceed the LDS; odd N with numpy's asymmetric shifts) vs numpy.fft."""
     rng = np.random.default_rng(N)
     g = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
     fwd = np.fft.fftshift(np.fft.fft2(np.fft.fftshift(g)))

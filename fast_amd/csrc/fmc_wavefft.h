@@ -25,6 +25,9 @@
 #ifndef FMC_TW_CHUNK
 #define FMC_TW_CHUNK 4
 #endif
+#ifndef FMC_TW_CHUNK_NS4
+#define FMC_TW_CHUNK_NS4 0
+#endif
 
 namespace fmc {
 
@@ -71,9 +74,11 @@ struct WaveGeom {
 
 // Twiddles per prefetch chunk in stage 1 (0 = let the compiler place the loads): bounded by the
 // registers left beside the 2P values of the row (f64: 4 VGPRs per twiddle).
-template <class R, int P>
+template <class R, int P, int NS = 2>
 constexpr int tw_chunk() {
 #if FMC_BATCH_LDS
+  // four output slots leave no registers for the prefetch: 2048^2 / Np = 152 runs 116 / 138 / 153 k it/s with chunks of 4 / 2 / 0
+  if (NS > 2 && sizeof(R) == 8) return (P >= 12 && P <= 16) ? FMC_TW_CHUNK_NS4 : 0;
   // measured at 1024^2 (P = 16): rows -1.6 % (f64), -5 % (f32); P <= 8 loses 2-6 % (more registers,
   // fewer waves per SIMD) and P > 24 has no registers to spare
   return (P < 12) ? 0 : (sizeof(R) == 8) ? (P <= 16 ? FMC_TW_CHUNK : 0) : (P <= 16 ? P - 1 : (P <= 24 ? 8 : 0));
@@ -109,7 +114,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
     // Twiddle loads in chunks of CH, double-buffered: chunk 0 is in flight under the in-register
     // DFT, chunk k+1 under the multiplies of chunk k, one wait (ex.pin) per chunk.  Left to itself
     // the compiler keeps two loads in flight and exposes ~P/2 LDS round trips per row.
-    constexpr int CH = tw_chunk<R, P>();
+    constexpr int CH = tw_chunk<R, P, NS>();
     constexpr int NCH = CH ? (P - 1 + CH - 1) / CH : 0;
     cpx<R> t[2][CH ? CH : 1];
     if (CH) {

@@ -191,11 +191,20 @@ def main():
         if backend == "nccl":
             ids = [fast_amd._lib.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            err = ""
-            try:
-                h.comm_init(ids[0], world, rank)
-            except fast_amd.FastMCError as e:      # keep the scaling run alive; say so in the JSON
-                err = str(e)
+            # keep the scaling run alive whatever the communicator does (error or no return): say so in the JSON
+            import threading
+            box = {}
+
+            def _init():
+                try:
+                    h.comm_init(ids[0], world, rank)
+                    box["ok"] = True
+                except fast_amd.FastMCError as e:
+                    box["err"] = str(e)
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("FASTMC_BENCH_RCCL_TIMEOUT", "180")))
+            err = "" if box.get("ok") else box.get("err", "ncclCommInitRank did not return in time")
             ok = dev(torch.tensor([0 if err else 1], dtype=torch.int32))
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank takes the same path
             gather = "rccl(in-library)" if int(ok.item()) == 1 else f"torch.distributed (RCCL init failed: {err or 'on another rank'})"

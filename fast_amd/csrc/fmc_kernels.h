@@ -335,7 +335,7 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
   // line are stored by LR different waves within one or two iterations, so the line is complete
   // in L2 long before it is evicted.  (With one wave storing its own 8 rows over 8 iterations the
   // partially written lines in flight -- 256 CUs x 12 waves x Np lines -- equal the L2 capacity
-  // and leave as partial writes: 2.7x write amplification, rows kernel 12.8 -> ... ms.)
+  // and leave as partial writes: 2.2x write amplification, rows kernel 13.9 -> 12.6 ms per 5000 realisations.)
   constexpr int WPB = WaveCfg<R, P, NS>::WPB;
   constexpr int LR = 128 / (int)sizeof(cpx<R>);
   static_assert((ROWS_PER_WAVE * WPB) % LR == 0, "tile must hold whole lines");

@@ -43,3 +43,27 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def _build_c_client(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "c_smoke")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c_abi", "c_smoke.c"), "-o", exe, "-L", os.path.join(ROOT, "fast_amd"), "-lfastmc",
+           "-Wl,-rpath," + os.path.join(ROOT, "fast_amd"), "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_links(built, tmp_path):
+    """include/fastmc.h compiles as C99 and a C client links against libfastmc.so (no compute here)."""
+    _build_c_client(tmp_path)
+
+
+@pytest.mark.gpu
+def test_plain_c_client_runs(built, tmp_path):
+    import subprocess
+    r = subprocess.run([_build_c_client(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "C-ABI OK" in r.stdout and "split_maxdiff=0" in r.stdout

@@ -782,7 +782,12 @@ static int run_checked(fastmc_ctx* h, const RunSpec& S) {
   if (S.n_real <= 0) return fail(FASTMC_EINVAL, "n_real must be positive");
   if (S.real0 < 0) return fail(FASTMC_EINVAL, "real0 must be non-negative");
   HIPCHK(hipSetDevice(h->device));
+#ifdef FMC_ONLY_F64   // experiment builds (make variant ... DEFS="-DFMC_ONLY_F64 ..."): half the compile time
+  if (h->precision != FASTMC_F64) return fail(FASTMC_ESTATE, "this build has no float32 kernels (FMC_ONLY_F64)");
+  return run_impl<double>(h, S);
+#else
   return h->precision == FASTMC_F64 ? run_impl<double>(h, S) : run_impl<float>(h, S);
+#endif
 }
 
 extern "C" int fastmc_run(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real, const double* logamp,

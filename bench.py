@@ -85,14 +85,16 @@ def cpu_baseline(sim, seconds_target=12.0):
             npz = os.path.join(tmp, "inputs.npz")
             np.savez(npz, ps=ps, df=df, W=W, dx=dx, lv=lv)
             t0 = time.perf_counter()
-            procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", npz, str(1000 + i), "2"], cwd=ROOT,
+            procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", npz, str(1000 + i), "4"], cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(ncore)]
             outs = [p.communicate(timeout=600)[0] for p in procs]
             wall = time.perf_counter() - t0
         if all(p.returncode == 0 for p in procs):
             n_done = sum(int(o.split()[0]) for o in outs)
-            out["all_cores"] = {"value": n_done / wall, "unit": "iterations/s", "cores": ncore,
-                                "sample": f"{ncore} child processes x 40 iterations, wall {wall:.1f} s (includes interpreter start)"}
+            t_comp = max(float(o.split()[1]) for o in outs)          # slowest child's compute loop (no interpreter start)
+            out["all_cores"] = {"value": n_done / t_comp, "unit": "iterations/s", "cores": ncore,
+                                "sample": f"{ncore} concurrent child processes x 80 iterations; slowest compute loop {t_comp:.1f} s, "
+                                          f"wall incl. interpreter start {wall:.1f} s"}
         else:
             out["all_cores"] = {"error": "a worker failed"}
     except Exception as e:   # the baseline of record is the single-core figure above

@@ -376,6 +376,23 @@ def big2048():
         capture_sim("big_noao_L0_4096", p4, "4096^2 (four interleaved sub-rows on the GPU), NOAO, L0=25, NITER 2", full=False, stride=64)
 
 
+def big_modes():
+    """1024^2 runs of the AO modes whose masks use the Zernike / Bessel filters (TT, LGSAO, modal Zmax) and of the
+    noise term: 4 iterations each, scalars + strided spectrum sample + powers."""
+    h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
+    base = dict(fast.conf.DEFAULTS)
+    base.update({"NPXLS": 1024, "DX": 0.01, "NITER": 4, "NCHUNKS": 2, "TEMPORAL": False, "FFTW": True, "SEED": 9, "W0": "opt",
+                 "D_GROUND": 0.8, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w, "WIND_DIR": [0, 90, 180, 270], "ZENITH_ANGLE": 55,
+                 "DSUBAP": 0.1, "LOGLEVEL": "ERROR", "H_SAT": 36e6, "ALIAS": True})
+    for name, over, note in (("big_tt_1024", {"AO_MODE": "TT"}, "TT (Zernike Zmax=3 mask)"),
+                             ("big_lgsao_1024", {"AO_MODE": "LGSAO"}, "LGSAO (Z<=4 filter)"),
+                             ("big_modal_zmax_noise_1024", {"AO_MODE": "AO", "MODAL": True, "ZMAX": 21, "NOISE": 0.5},
+                              "AO modal Zmax=21 + alias + noise")):
+        p = dict(base)
+        p.update(over)
+        capture_sim(name, p, f"1024^2 {note}, NITER 4", full=False, stride=16)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("capturing into", OUT)
@@ -386,7 +403,7 @@ def main():
             e2e(only[0].split("=", 1)[1].split(","))
         else:
             {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref,
-             "--only-comms": comms_metrics, "--only-big2048": big2048}[only[0]]()
+             "--only-comms": comms_metrics, "--only-big2048": big2048, "--only-big-modes": big_modes}[only[0]]()
         for name, size, st, note in MANIFEST:
             print(f"| {name}.npz | {size} | {st} | {note} |")
         return

@@ -390,7 +390,11 @@ def big_modes():
                               "AO modal Zmax=21 + alias + noise")):
         p = dict(base)
         p.update(over)
-        capture_sim(name, p, f"1024^2 {note}, NITER 4", full=False, stride=16)
+        if "--only-combo" not in sys.argv:
+            capture_sim(name, p, f"1024^2 {note}, NITER 4", full=False, stride=16)
+    p = dict(base)
+    p.update({"AO_MODE": "AO", "SUBHARM": True, "COHERENT": True, "PROP_DIR": "down", "L0": 40.0, "SEED": 10})
+    capture_sim("big_subharm_coherent_down_1024", p, "1024^2 AO + alias + SUBHARM + COHERENT + downlink, L0=40, NITER 4", full=False, stride=16)
 
 
 def main():

@@ -11,7 +11,10 @@
  *   - the caller owns every host buffer; the library copies in during set_* / run and
  *     owns all device memory until fastmc_destroy();
  *   - all host arrays are C-contiguous float64 unless stated otherwise;
- *   - calls on one handle must be serialised by the caller; calls are blocking;
+ *   - calls on one handle must be serialised by the caller; calls are blocking; different
+ *     handles may be driven from different threads (each has its own HIP stream);
+ *   - N <= 4096, Np <= N; fastmc_destroy() keeps the largest work buffer of the device for
+ *     the next handle of the process (sweeps of short-lived handles), everything else is freed;
  *   - nothing here ever falls back to a CPU implementation: without a gfx950 device
  *     fastmc_create() fails with FASTMC_ENODEV.
  */

@@ -78,7 +78,7 @@ class Fast():
         self._handle = _lib.Handle(self.Npxls, self.Npxls_pup, self.precision, self.device)
         if p['GPU_BATCH']:
             self._handle.set_batch(p['GPU_BATCH'])
-        if self._handle.kernel_path() == 0 and self.Npxls >= 128:
+        if self._handle.kernel_path() == 0 and self.Npxls >= 128 and not self.temporal:
             below = [n for n in host.WAVE_FFT_SIZES if n <= self.Npxls][-1:]
             above = [n for n in host.ROUND_UP_SIZES if n >= self.Npxls][:1]
             logger.warning(f"NPXLS = {self.Npxls} runs on the direct O(N^2 Np) kernels (about 10x slower than the "

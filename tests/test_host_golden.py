@@ -148,3 +148,45 @@ def test_optional_rounding_of_auto_grid_size():
         else:
             assert host.build_problem(q).N not in (192,) or host.build_problem(dict(q, GPU_ROUND_NPXLS=False)).N == 192
     assert host.WAVE_FFT_SIZES == [128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1152, 1280, 1536, 1792, 2048, 4096]
+
+
+def test_comms_host_logic_without_gpu(monkeypatch):
+    """fast_amd.comms forms fade_prob / fade_dur / BER from the four numbers per query the device returns;
+    with the device reduction replaced by its numpy definition (include/fastmc.h) the host logic alone must
+    reproduce the reference's values (comms_metrics.npz), NaN conventions included."""
+    from scipy.special import erfc
+    from fast_amd import comms, _lib
+
+    def fake_link_metrics(queries, samples=None, handle=None, device=0):
+        x = np.asarray(samples, dtype=float)
+        out = np.zeros((len(queries), 4))
+        for i, (kind, p0, p1) in enumerate(queries):
+            if kind == _lib.LM_FADE:
+                below = x < p0
+                clear = np.flatnonzero(~below)
+                out[i] = [below.sum(), np.sum(below[1:] & ~below[:-1]), clear[0] if len(clear) else len(x),
+                          clear[-1] if len(clear) else -1]
+            else:
+                s = x / x.mean()
+                if kind == _lib.LM_BER_OOK:
+                    v = 0.5 * erfc(s * np.sqrt(10 ** (p0 / 10)) / np.sqrt(2))
+                else:
+                    q = 0.5 * erfc(np.sqrt(3 / (p0 - 1) * 10 ** (p1 / 10) * s ** 2) / np.sqrt(2))
+                    c = (np.sqrt(p0) - 1) / np.sqrt(p0)
+                    v = 4 * (c * q - c * c * q * q)
+                out[i] = [v.sum(), x.mean(), len(x), 0]
+        return out
+
+    monkeypatch.setattr(_lib, "link_metrics", fake_link_metrics)
+    monkeypatch.setattr(_lib, "default_device", lambda: 0)
+    d = load_golden("comms_metrics")
+    thr, eb, Ms, dt = d["thresholds"], d["ebn0"], d["Ms"], float(d["dt"])
+    for n in d["names"]:
+        v = d["v_" + n]
+        np.testing.assert_array_equal([comms.fade_prob(v, t) for t in thr], d["fade_prob_" + n])
+        np.testing.assert_array_equal([comms.fade_prob(v, t, 5) for t in thr], d["fade_prob_min5_" + n])
+        np.testing.assert_allclose([comms.fade_dur(v, t, dt) for t in thr], d["fade_dur_" + n], rtol=1e-14)
+        np.testing.assert_allclose([comms.fade_dur(v, t, dt, 5) for t in thr], d["fade_dur_min5_" + n], rtol=1e-14)
+        np.testing.assert_allclose([comms.ber_ook(s, v) for s in eb], d["ber_ook_" + n], rtol=1e-12)
+        np.testing.assert_allclose([[comms.ber_qam(M, s, v) for s in eb] for M in Ms], d["ber_qam_" + n], rtol=1e-12)
+    np.testing.assert_allclose([comms.ber_ook(s) for s in eb], d["ber_ook_nosamples"], rtol=1e-13)

@@ -27,6 +27,9 @@ def fade_counts(I, threshold):
     """(n, n_below, n_complete, samples_in_complete): the integers fade_prob and fade_dur are formed
     from.  A fade is complete when it starts after the first sample and ends before the last
     (comms.py:181-186: rising edges of the mask, final segment dropped when it is still fading)."""
+    from .fast import Fast
+    if isinstance(I, Fast):                      # fade durations need the FastResult ordering: take its vector
+        I = I.result.power
     I = numpy.asarray(I)
     n = I.size
     n_below, n_rise, first_clear, last_clear = _lib.link_metrics([(_lib.LM_FADE, threshold, 0.0)], samples=I,

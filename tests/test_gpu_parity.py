@@ -583,6 +583,8 @@ def test_link_metrics_on_resident_results_match_oracle():
     r = sim.run()._r
     thr = float(np.quantile(r, 0.2))
     assert comms.fade_prob(sim, thr) == R.fade_prob(r, thr)
+    a, b = comms.fade_dur(sim, thr * sim.diffraction_limit, 1e-3, 5), R.fade_dur(r, thr, 1e-3, 5)
+    assert (np.isnan(a) and np.isnan(b)) or a == b
     np.testing.assert_allclose(comms.ber_ook(8.0, sim), R.ber_ook(8.0, r), rtol=1e-11)
     np.testing.assert_allclose(comms.ber_qam(16, 12.0, sim), R.ber_qam(16, 12.0, r), rtol=1e-11)
     rng = np.random.default_rng(3)

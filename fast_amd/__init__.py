@@ -10,7 +10,8 @@ from . import turbulence_models
 from . import host
 from . import _lib
 from . import comms
+from . import funcs
 from ._lib import FastMCError
 
 __version__ = "0.1.0"
-__all__ = ["Fast", "FastResult", "load", "conf", "turbulence_models", "host", "comms", "FastMCError"]
+__all__ = ["Fast", "FastResult", "load", "conf", "turbulence_models", "host", "comms", "funcs", "FastMCError"]

@@ -694,3 +694,31 @@ def test_two_handles_in_two_threads():
         t.join()
     for j in jobs:
         np.testing.assert_array_equal(alone[j], together[j])
+
+
+@pytest.mark.parametrize("N", [16, 30, 33, 64, 128])
+def test_funcs_make_phase_fft_like_the_reference(N):
+    """fast_amd.funcs.make_phase_fft (reference signature, fast/funcs.py:210-223) against the reference's own
+    outputs: full N x N screens, double=True stacks [Re | Im], double=False returns Re."""
+    from fast_amd import funcs
+    g = load_golden(f"kat_fft_N{N}")
+    rand = g["coeffs"] * np.sqrt(g["powerspec"])
+    want = g["screens"]
+    got = funcs.make_phase_fft(rand, float(g["df"]), fftw=True, double=True)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
+    single = funcs.make_phase_fft(rand, float(g["df"]))
+    assert np.abs(single - want[:len(rand)]).max() <= 1e-11 * np.abs(want).max()
+    assert funcs.make_phase_fft(rand[0], float(g["df"])).shape == (N, N)
+
+
+def test_funcs_make_phase_subharm_like_the_reference():
+    """fast_amd.funcs.make_phase_subharm (fast/funcs.py:225-258) against the reference's output (kat_subharm.npz)."""
+    from types import SimpleNamespace
+    from fast_amd import funcs
+    g = load_golden("kat_subharm")
+    freq = SimpleNamespace(subharm=SimpleNamespace(fx=g["fx"], fy=g["fy"], df=g["df"]))
+    got = funcs.make_phase_subharm(g["rand"], freq, int(g["N"]), float(g["dx"]), double=True)
+    assert got.shape == g["screens"].shape
+    assert np.abs(got - g["screens"]).max() <= 1e-11 * np.abs(g["screens"]).max()
+    np.testing.assert_array_equal(funcs.make_phase_subharm(g["rand"], freq, int(g["N"]), float(g["dx"])), got[:len(g["rand"])])

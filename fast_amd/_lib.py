@@ -19,6 +19,7 @@ EXPORTS = [
     "fastmc_screens_coeffs", "fastmc_screens", "fastmc_rng_coeffs", "fastmc_rng_logamp", "fastmc_histogram",
     "fastmc_result_stats", "fastmc_last_timing", "fastmc_kernel_path", "fastmc_set_batch", "fastmc_powerspec",
     "fastmc_set_layer_screens", "fastmc_temporal_chunk", "fastmc_link_metrics", "fastmc_set_results",
+    "fastmc_powerspec_terms",
     "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_gather", "fastmc_comm_destroy",
 ]
 
@@ -84,6 +85,7 @@ def lib():
     L.fastmc_kernel_path.argtypes = [vp, C.c_int]
     L.fastmc_set_batch.argtypes = [vp, C.c_int]
     L.fastmc_powerspec.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp, dp, dp]
+    L.fastmc_powerspec_terms.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp]
     L.fastmc_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     L.fastmc_comm_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
     L.fastmc_comm_gather.argtypes = [vp, i64, dp, C.POINTER(i64), C.c_double, C.c_double, C.c_int]
@@ -332,13 +334,9 @@ def mask_spec(modal, modal_mult, zmax):
     return 3, int(zmax), float(modal_mult)
 
 
-def powerspec(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, dtheta, cn2, h, wind, pupil_filter,
-              simpson_w, lf_mask=None, modal=False, modal_mult=1, zmax=None, D_ground=0.0, lgs_z=None,
-              per_layer=False, device=None):
-    """fastmc_powerspec: mask_lf, AO-residual PSD grid and Simpson scalars on the GPU.
-    `lf_mask=None`: the mask is evaluated on the device from (modal, modal_mult, zmax, D_ground);
-    otherwise the given (N, N) grid is used.  Returns dict(powerspec, powerspec_per_layer|None,
-    logamp_powerspec, lf_mask, scalars..., kernel_ms)."""
+def _ps_params(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, dtheta, cn2, h, wind, pupil_filter,
+               simpson_w, lf_mask, modal, modal_mult, zmax, D_ground, lgs_z):
+    """fastmc_ps_params for the two power-spectrum entry points; returns (struct, arrays it points into)."""
     cn2, h, wind = _f64(cn2), _f64(h), _f64(wind)
     Lr = len(cn2)
     mask, pf, z, w = _f64(lf_mask), _f64(pupil_filter), _f64(lgs_z), _f64(simpson_w)
@@ -360,6 +358,19 @@ def powerspec(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, d
     p.D_ground = float(D_ground)
     p.pupil_filter = None if pf is None else pf.ctypes.data
     p.lgs_z = None if z is None else z.ctypes.data
+    return p, (cn2, h, wind, mask, pf, z, w)
+
+
+def powerspec(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, dtheta, cn2, h, wind, pupil_filter,
+              simpson_w, lf_mask=None, modal=False, modal_mult=1, zmax=None, D_ground=0.0, lgs_z=None,
+              per_layer=False, device=None):
+    """fastmc_powerspec: mask_lf, AO-residual PSD grid and Simpson scalars on the GPU.
+    `lf_mask=None`: the mask is evaluated on the device from (modal, modal_mult, zmax, D_ground);
+    otherwise the given (N, N) grid is used.  Returns dict(powerspec, powerspec_per_layer|None,
+    logamp_powerspec, lf_mask, scalars..., kernel_ms)."""
+    p, keep = _ps_params(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, dtheta, cn2, h, wind, pupil_filter,
+                         simpson_w, lf_mask, modal, modal_mult, zmax, D_ground, lgs_z)
+    Lr = p.n_layers
     ps = np.empty((N, N))
     la = np.empty((N, N))
     mo = np.empty((N, N))
@@ -371,3 +382,15 @@ def powerspec(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, d
     return {"powerspec": ps, "powerspec_per_layer": pl, "logamp_powerspec": la, "lf_mask": mo,
             "aniso_servo_error": sc[0], "alias_error": sc[1], "noise_error": sc[2], "fitting_error": sc[3],
             "phs_var": sc[4], "logamp_var": sc[5], "phs_var_weights": sc[6:].copy(), "kernel_ms": ms.value}
+
+
+def powerspec_terms(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, dtheta, cn2, h, wind, pupil_filter,
+                    simpson_w, lf_mask=None, modal=False, modal_mult=1, zmax=None, D_ground=0.0, lgs_z=None, device=None):
+    """fastmc_powerspec_terms: the (L, N, N) von Karman, G_AO and alias grids and the (N, N) noise grid."""
+    p, keep = _ps_params(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, dtheta, cn2, h, wind, pupil_filter,
+                         simpson_w, lf_mask, modal, modal_mult, zmax, D_ground, lgs_z)
+    Lr = p.n_layers
+    turb, g, al, no = np.empty((Lr, N, N)), np.empty((Lr, N, N)), np.empty((Lr, N, N)), np.empty((N, N))
+    dev = default_device() if device is None else int(device)
+    _chk(lib().fastmc_powerspec_terms(dev, C.byref(p), _dptr(turb), _dptr(g), _dptr(al), _dptr(no)))
+    return {"turb_powerspec": turb, "G_ao": g, "alias_powerspec": al, "noise_powerspec": no}

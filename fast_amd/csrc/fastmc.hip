@@ -1013,8 +1013,9 @@ static void noll_to_nm(int j, int* n_out, int* m_out) {   // aotools zernIndex (
   *m_out = m;
 }
 
-extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double* powerspec, double* per_layer,
-                                double* logamp_ps, double* lf_mask_out, double* scalars, double* kernel_ms) {
+static int powerspec_impl(int device_id, const fastmc_ps_params* p, double* powerspec, double* per_layer, double* logamp_ps,
+                          double* lf_mask_out, double* scalars, double* kernel_ms, double* turb, double* g_ao, double* alias_ps,
+                          double* noise_ps) {
   if (!p) return fail(FASTMC_EINVAL, "params is NULL");
   const int N = p->N, L = p->n_layers;
   if (N < 2 || N > 16384) return fail(FASTMC_EINVAL, "bad N");
@@ -1033,7 +1034,7 @@ extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double
   const int nq = PS_NQ + L;
   double *d_cn2 = nullptr, *d_h = nullptr, *d_wind = nullptr, *d_mask = nullptr, *d_pf = nullptr, *d_z = nullptr,
          *d_w = nullptr, *d_ps = nullptr, *d_pl = nullptr, *d_la = nullptr, *d_rows = nullptr, *d_sc = nullptr,
-         *d_mo = nullptr, *d_noll = nullptr;
+         *d_mo = nullptr, *d_noll = nullptr, *d_turb = nullptr, *d_g = nullptr, *d_al = nullptr, *d_no = nullptr;
   std::vector<double*> owned;
   auto A = [&](double** q, size_t n) -> int {
     hipError_t e = hipMalloc((void**)q, n * 8);
@@ -1053,6 +1054,10 @@ extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double
     if (p->pupil_filter && (rc = A(&d_pf, N2))) break;
     if (p->lgs_z && (rc = A(&d_z, N2))) break;
     if (per_layer && (rc = A(&d_pl, N2 * L))) break;
+    if (turb && (rc = A(&d_turb, N2 * L))) break;
+    if (g_ao && (rc = A(&d_g, N2 * L))) break;
+    if (alias_ps && (rc = A(&d_al, N2 * L))) break;
+    if (noise_ps && (rc = A(&d_no, N2))) break;
     hipMemcpy(d_cn2, p->cn2, L * 8, hipMemcpyHostToDevice);
     hipMemcpy(d_h, p->h, L * 8, hipMemcpyHostToDevice);
     hipMemcpy(d_wind, p->wind, 2 * L * 8, hipMemcpyHostToDevice);
@@ -1073,6 +1078,7 @@ extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double
     K.mask_mode = p->mask_mode; K.zmax = p->zmax; K.modal_mult = p->modal_mult; K.D_zern = p->D_ground;
     K.noll_n = (const int*)d_noll; K.noll_m = (const int*)d_noll + nmodes; K.mask_out = d_mo;
     K.powerspec = d_ps; K.per_layer = d_pl; K.logamp_ps = d_la; K.rowsums = d_rows;
+    K.turb = d_turb; K.g_ao = d_g; K.alias_out = d_al; K.noise_out = d_no;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -1092,6 +1098,10 @@ extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double
     if (per_layer) hipMemcpy(per_layer, d_pl, N2 * L * 8, hipMemcpyDeviceToHost);
     if (logamp_ps) hipMemcpy(logamp_ps, d_la, N2 * 8, hipMemcpyDeviceToHost);
     if (lf_mask_out) hipMemcpy(lf_mask_out, d_mo, N2 * 8, hipMemcpyDeviceToHost);
+    if (turb) hipMemcpy(turb, d_turb, N2 * L * 8, hipMemcpyDeviceToHost);
+    if (g_ao) hipMemcpy(g_ao, d_g, N2 * L * 8, hipMemcpyDeviceToHost);
+    if (alias_ps) hipMemcpy(alias_ps, d_al, N2 * L * 8, hipMemcpyDeviceToHost);
+    if (noise_ps) hipMemcpy(noise_ps, d_no, N2 * 8, hipMemcpyDeviceToHost);
     if (scalars) {
       std::vector<double> sc(nq);
       hipMemcpy(sc.data(), d_sc, nq * 8, hipMemcpyDeviceToHost);
@@ -1101,6 +1111,18 @@ extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double
   } while (0);
   cleanup();
   return rc;
+}
+
+extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double* powerspec, double* per_layer,
+                                double* logamp_ps, double* lf_mask_out, double* scalars, double* kernel_ms) {
+  return powerspec_impl(device_id, p, powerspec, per_layer, logamp_ps, lf_mask_out, scalars, kernel_ms, nullptr, nullptr, nullptr,
+                        nullptr);
+}
+
+extern "C" int fastmc_powerspec_terms(int device_id, const fastmc_ps_params* p, double* turb, double* g_ao, double* alias_ps,
+                                      double* noise_ps) {
+  if (!turb && !g_ao && !alias_ps && !noise_ps) return fail(FASTMC_EINVAL, "no output requested");
+  return powerspec_impl(device_id, p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, turb, g_ao, alias_ps, noise_ps);
 }
 
 // ------------------------------------------------------------------ RCCL (loaded on demand)

@@ -41,6 +41,11 @@ struct PsArgs {
   double* per_layer;           // [L][N][N] or null
   double* logamp_ps;           // [N][N] or null
   double* rowsums;             // [N][PS_NQ + L]
+  // the terms of the assembly, as the reference keeps them on the object (fast/fast.py:448-472); any may be null
+  double* turb;                // [L][N][N] turb_powerspec   (funcs.turb_powerspectrum_vonKarman)
+  double* g_ao;                // [L][N][N] G_ao             (ao_power_spectra.G_AO_PAOLA)
+  double* alias_out;           // [L][N][N] alias_powerspec  (Jol_alias_openloop)
+  double* noise_out;           // [N][N]    noise_powerspec  (Jol_noise_openloop)
 };
 
 __device__ __forceinline__ double np_sinc(double x) {   // numpy.sinc
@@ -177,6 +182,9 @@ __global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
       }
       const double pl = c2pk2 * (turb * G + alias) + noise_ps / L;
       if (A.per_layer) A.per_layer[(size_t)l * N * N + pix] = pl;
+      if (A.turb) A.turb[(size_t)l * N * N + pix] = turb;
+      if (A.g_ao) A.g_ao[(size_t)l * N * N + pix] = G;
+      if (A.alias_out) A.alias_out[(size_t)l * N * N + pix] = alias;
       ps += pl;
       gt_sum += G * turb;
       alias_tot += alias * c2pk2;
@@ -189,6 +197,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
     }
     A.powerspec[pix] = ps;
     if (A.logamp_ps) A.logamp_ps[pix] = la;
+    if (A.noise_out) A.noise_out[pix] = noise_ps;
     const double wj = A.w[ix];
     q[0] += wj * (gt_sum * mask * c2pk2);
     q[1] += wj * alias_tot;

@@ -244,6 +244,31 @@ class Fast():
         """Histogram of dB_rel of the last run, computed on the device."""
         return self._handle.histogram(lo_db, hi_db, nbins)
 
+    def _psd_terms(self):
+        """turb_powerspec, G_ao, alias_powerspec, noise_powerspec of fast.py:448-472, fetched from the GPU on first use."""
+        if getattr(self, "_terms", None) is None:
+            prob, p, atm = self._prob, self.params, self._prob.atm
+            t = _lib.powerspec_terms(prob.N, prob.dx, prob.wvl, p['L0'], p['l0'], prob.ao_mode, p['ALIAS'], p['NOISE'],
+                                     prob.d_wfs, p['TLOOP'], p['TEXP'], atm.dtheta, atm.cn2, atm.h, atm.wind_vector,
+                                     prob.pup.pupil_filter, prob.simpson_w, lf_mask=None, modal=prob.modal,
+                                     modal_mult=prob.modal_mult, zmax=prob.zmax, D_ground=p['D_GROUND'], device=self.device)
+            noao = prob.ao_mode == 'NOAO'
+            # the reference keeps plain scalars where a term is switched off (fast.py:464-465, 471-472; G_AO_PAOLA
+            # returns 1 for NOAO, ao_power_spectra.py:235-236)
+            if noao:
+                t["G_ao"] = 1
+            if noao or not p['ALIAS']:
+                t["alias_powerspec"] = 0.
+            if noao or not p['NOISE'] > 0:
+                t["noise_powerspec"] = 0.
+            self._terms = t
+        return self._terms
+
+    turb_powerspec = property(lambda self: self._psd_terms()["turb_powerspec"])
+    G_ao = property(lambda self: self._psd_terms()["G_ao"])
+    alias_powerspec = property(lambda self: self._psd_terms()["alias_powerspec"])
+    noise_powerspec = property(lambda self: self._psd_terms()["noise_powerspec"])
+
     @property
     def powerspec_per_layer(self):
         """(L, N, N) residual PSD per turbulence layer (fast.py:478-479); fetched from the GPU on first use."""

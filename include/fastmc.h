@@ -209,6 +209,13 @@ int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double* powerspec
                      double* per_layer, double* logamp_ps, double* lf_mask_out, double* scalars,
                      double* kernel_ms);
 
+/* The terms of that assembly as the reference keeps them on the object (fast/fast.py:448-472; any may be NULL):
+ * turb (L,N,N) = funcs.turb_powerspectrum_vonKarman (fast/funcs.py:138-173); g_ao (L,N,N) = G_AO_PAOLA
+ * (fast/ao_power_spectra.py:225-270; all ones for FASTMC_NOAO); alias (L,N,N) = Jol_alias_openloop (163-223;
+ * zeros when p->alias is off or NOAO); noise (N,N) = Jol_noise_openloop (148-161; zeros when p->noise == 0). */
+int fastmc_powerspec_terms(int device_id, const fastmc_ps_params* p, double* turb, double* g_ao,
+                           double* alias, double* noise);
+
 /* ---- multi-GPU result exchange: one process per GPU, RCCL over xGMI ---- */
 /* 128-byte RCCL unique id, created on rank 0 and distributed by the launcher. */
 int fastmc_comm_unique_id(uint8_t id128[128]);

@@ -722,3 +722,18 @@ def test_funcs_make_phase_subharm_like_the_reference():
     assert got.shape == g["screens"].shape
     assert np.abs(got - g["screens"]).max() <= 1e-11 * np.abs(g["screens"]).max()
     np.testing.assert_array_equal(funcs.make_phase_subharm(g["rand"], freq, int(g["N"]), float(g["dx"])), got[:len(g["rand"])])
+
+
+@pytest.mark.parametrize("case", E2E_CASES)
+def test_psd_terms_on_the_object_match_reference(case):
+    """Fast.turb_powerspec / G_ao / alias_powerspec / noise_powerspec (fast.py:448-472: funcs.turb_powerspectrum_vonKarman,
+    ao_power_spectra.G_AO_PAOLA, Jol_alias_openloop, Jol_noise_openloop) from the GPU vs the reference's attributes,
+    plain scalars where the reference keeps scalars."""
+    g = load_golden("e2e_" + case)
+    p = params_from_json(g["params_json"])
+    p["GPU_DEVICE"] = 0
+    sim = fast_amd.Fast(p)
+    for name in ("turb_powerspec", "G_ao", "alias_powerspec", "noise_powerspec"):
+        want, got = g[name], getattr(sim, name)
+        assert np.shape(got) == want.shape, name
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-13 * max(np.abs(want).max(), 1e-300), err_msg=name)

@@ -31,9 +31,35 @@ def run_sim(p):
     return sim
 
 
+# --- turbulence models (tests_pytest.py:12-27)
+def test_HV57():
+    h = numpy.linspace(0, 20000, 10)
+    cn2 = fast.turbulence_models.HV57(h)
+    assert len(cn2) == len(h)
+    assert cn2.dtype == float
+
+
+def test_Bufton():
+    h = numpy.linspace(0, 20000, 10)
+    w = fast.turbulence_models.Bufton_wind(h)
+    assert len(w) == len(h)
+    assert w.dtype == float
+
+
 def test_HV57_Bufton():
     h, cn2, w = fast.turbulence_models.HV57_Bufton_profile(10)
     assert len(h) == len(cn2) == len(w) == 10
+
+
+# --- config parsing (tests_pytest.py:30-32): a .py file that defines `p`
+def test_config_default(tmp_path):
+    cfg = tmp_path / "test_params.py"
+    cfg.write_text("import numpy\nimport fast\nh, cn2, w = fast.turbulence_models.HV57_Bufton_profile(4)\n"
+                   "p = {'NPXLS': 'auto', 'DX': 0.01, 'NITER': 100, 'NCHUNKS': 10, 'H_TURB': h, 'CN2_TURB': cn2, 'WIND_SPD': w,\n"
+                   "     'WIND_DIR': [0, 90, 180, 270], 'D_GROUND': 0.8, 'ZENITH_ANGLE': 55, 'DSUBAP': 0.1, 'LOGLEVEL': 'ERROR'}\n")
+    c = fast.conf.ConfigParser(str(cfg))
+    assert c.config['NITER'] == 100 and c.config['AO_MODE'] == 'AO'        # missing keys filled from the defaults
+    run_sim(str(cfg))                                                        # Fast accepts the file name, like the reference
 
 
 def test_sim_default():
@@ -88,3 +114,31 @@ def test_save_and_load(tmp_path):
     numpy.testing.assert_allclose(res.power, sim.result.power, rtol=1e-15)
     numpy.testing.assert_allclose(res.dB_rel, sim.result.dB_rel, rtol=1e-12)
     assert res.hdr['NPXLS'] == 192 and res.hdr['AO_MODE'] == 'AO' and res.hdr['SEED'] == 4   # auto 164, rounded up (GPU_ROUND_NPXLS 'auto')
+
+
+# --- error-rate integrals over the result (tests_pytest.py:168-187)
+def test_ber_ook():
+    p = example_params()
+    sim = fast.Fast(p)
+    sim.run()
+    ber = fast.comms.ber_ook(10, sim.result.power)
+    assert numpy.isfinite(ber) and 0 < ber < 0.5
+    assert abs(fast.comms.ber_ook(10, sim) - ber) < 1e-12 * ber             # same reduction on the resident results
+
+
+def test_ber_ook_nosamples():
+    ber = fast.comms.ber_ook(10)
+    assert numpy.isfinite(ber)
+
+
+def test_sep_qam():
+    p = example_params()
+    sim = fast.Fast(p)
+    sim.run()
+    ber = fast.comms.ber_qam(4, 10, samples=sim.result.power)
+    assert numpy.isfinite(ber)
+
+
+def test_ber_qam_nosamples():
+    ber = fast.comms.ber_qam(4, 10)
+    assert numpy.isfinite(ber)

@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- Monte-Carlo iterations/s of the FAST hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        one process drives N GPUs (N handles on N threads)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W       one process per GPU (any launcher that sets
+                                                                     RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)
 
-Workload (BASELINE.json configs[1]): 1024 x 1024 grid, Np = 82 pupil window (D = 0.8 m,
-DX = 0.01 m), pure von Karman spectrum (AO_MODE 'NOAO', HV5/7 + Bufton 4-layer profile at
-55 deg zenith), 10 000 Monte-Carlo iterations, on-device generator, float64 pipeline.
-One "step" = that whole 10 000-iteration job on each GPU (weak scaling: each rank owns a
-disjoint range of realisations); with N > 1 every step ends with the RCCL all-gather of the
-per-iteration powers and all-reduce of the dB histogram over xGMI.  Inputs (spectrum, pupil
-weights) are resident in HBM before the timed region; only the 80 kB of results per step
-crosses PCIe.  Rank 0 prints ONE JSON line.
+No torch in either form: under a launcher the ranks meet through fast_amd/rendezvous.py (plain sockets) and the
+results are exchanged by RCCL inside libfastmc.so (host sockets if RCCL cannot initialise on EVERY rank).  `--gpus N`
+with more GPUs than are visible, or a launcher world that differs from N, exits non-zero: the line never reports
+devices that did not run.
+
+Workload (BASELINE.json configs[1]): 1024 x 1024 grid, Np = 82 pupil window (D = 0.8 m, DX = 0.01 m), pure von Karman
+spectrum (AO_MODE 'NOAO', HV5/7 + Bufton 4-layer profile at 55 deg zenith), 10 000 Monte-Carlo iterations, on-device
+generator, float64 transform.  One "step" = that whole 10 000-iteration job on each GPU (weak scaling: every GPU owns a
+disjoint range of realisations); with N > 1 every step ends with the all-gather of the per-iteration powers and the
+all-reduce of the dB histogram.  Inputs (spectrum, pupil weights) are resident in HBM before the timed region; only the
+80 kB of results per step and GPU crosses PCIe.  Rank 0 prints ONE JSON line.
+
+Every figure in the line is computed from this run, from the instruction counts of the code object that ran
+(fast_amd/kernel_isa_stats.json, written by the build) or, where it needs hardware counters, from a committed
+rocprofv3 summary that is named in the line and dropped when it belongs to another build.
 """
 import argparse
 import json
@@ -26,8 +34,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+F32_VECTOR_PEAK_TFLOPS = 157.3
+NOMINAL_GHZ = 2.4
+N_SIMD = 1024
 ITERS_PER_STEP = 10000
 HIST = (-60.0, 10.0, 4096)
+# Issue cost per wave-instruction per SIMD in cycles at 2.4 GHz, measured by tools/ubench on MI355X at 4 waves per SIMD
+# (profiles/r01j_ubench_valu_issue_rates.txt): v_add/mul/fma_f64 5.0, v_cvt_f64_f32 4.5, v_log/sqrt/sin/cos_f32 7.8
+# (= 2 x 5.15 - 2.5 of the paired add), v_mad_u64_u32 8.1, plain integer / float32 2.7.
+ISSUE_COST = {"valu_f64": 5.0, "valu_cvt_f64": 4.5, "valu_trans": 7.8, "valu_int_quarter": 8.1, "valu_other": 2.7}
+ISSUE_COST_SOURCE = "profiles/r01j_ubench_valu_issue_rates.txt"
 
 
 def workload_params(args):
@@ -39,24 +56,36 @@ def workload_params(args):
         "D_SAT": 0.1, "H_SAT": 36e6, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w,
         "WIND_DIR": np.array([0., 90., 180., 270.]), "L0": np.inf, "l0": 1e-6, "ZENITH_ANGLE": 55,
         "DTHETA": [4, 0], "AO_MODE": args.ao_mode, "DSUBAP": 0.1, "TLOOP": 1e-3, "TEXP": 1e-3, "ALIAS": True,
-        "NOISE": 0, "GPU_PRECISION": args.precision, "GPU_RNG": "device",
+        "NOISE": 0, "GPU_PRECISION": args.precision, "GPU_RNG": "device", "FFTW": True, "GPU_SHARD": False,
     }
 
 
-def _cpu_model():
+def _cpu_info():
+    model, phys = "unknown", None
     try:
+        cores = set()
+        pid = cid = None
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    cores.add((pid, cid))
+                pid = cid = None
+        phys = len(cores) or None
     except OSError:
         pass
-    return "unknown"
+    return model, phys
 
 
 def cpu_baseline(sim, seconds_target=12.0):
-    """The oracle (numpy restatement of the reference's CPU path, FFTW-branch semantics) timed on
-    this host on a bounded sample of the same workload: one core (the reference's default,
-    FFTW_THREADS 1, fast/conf.py:71-72) and, as an extra, one process per core."""
+    """The oracle (numpy restatement of the reference's CPU path, FFTW-branch semantics) timed on this host on a bounded
+    sample of the same workload: one core (the reference's default, FFTW_THREADS 1, fast/conf.py:71-72) and, as an extra,
+    one process on every CPU this process may run on (os.sched_getaffinity)."""
     from oracle import fastref as R
     for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ.setdefault(v, "1")
@@ -72,29 +101,36 @@ def cpu_baseline(sim, seconds_target=12.0):
         r = R.monte_carlo(124 + rep, n_it, chunks, ps, df, W, dx, lv)
         rates.append(n_it / (time.perf_counter() - t0))
         assert np.isfinite(r).all()
+    model, phys = _cpu_info()
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out = {"value": float(np.median(rates)), "unit": "iterations/s", "cores": 1, "kind": "port",
            "sample": f"median of 3 x {n_it} iterations ({chunks} chunks of 20) of the same {ps.shape[0]}^2 workload, "
                      f"oracle/fastref.py (numpy {np.__version__} pocketfft, float64, 1 thread); "
                      f"repeats {', '.join(f'{x:.1f}' for x in rates)} it/s",
-           "host_cpus": os.cpu_count(), "cpu_model": _cpu_model()}
-    try:   # all cores: one child program per core (never a fork of this GPU-initialised process)
+           "host_cpus": os.cpu_count(), "usable_cpus": affinity, "physical_cores": phys, "cpu_model": model}
+    try:   # every usable CPU: one child program each (never a fork of this GPU-initialised process)
         import subprocess
         import tempfile
-        ncore = min(os.cpu_count() or 1, 64)
+        ncore = affinity
+        try:       # each child holds ~0.5 GB at 1024^2 (20 complex128 screens + copies): stay inside the free memory
+            avail_kb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+            ncore = max(1, min(ncore, int(avail_kb / 1024 / 1024 / 0.7)))
+        except Exception:
+            pass
         with tempfile.TemporaryDirectory() as tmp:
             npz = os.path.join(tmp, "inputs.npz")
             np.savez(npz, ps=ps, df=df, W=W, dx=dx, lv=lv)
             t0 = time.perf_counter()
-            procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", npz, str(1000 + i), "4"], cwd=ROOT,
+            procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", npz, str(1000 + i), "2"], cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(ncore)]
-            outs = [p.communicate(timeout=600)[0] for p in procs]
+            outs = [p.communicate(timeout=900)[0] for p in procs]
             wall = time.perf_counter() - t0
         if all(p.returncode == 0 for p in procs):
             n_done = sum(int(o.split()[0]) for o in outs)
             t_comp = max(float(o.split()[1]) for o in outs)          # slowest child's compute loop (no interpreter start)
             out["all_cores"] = {"value": n_done / t_comp, "unit": "iterations/s", "cores": ncore,
-                                "sample": f"{ncore} concurrent child processes x 80 iterations; slowest compute loop {t_comp:.1f} s, "
-                                          f"wall incl. interpreter start {wall:.1f} s"}
+                                "sample": f"{ncore} concurrent child processes (one per usable CPU) x 40 iterations; slowest compute "
+                                          f"loop {t_comp:.1f} s, wall incl. interpreter start {wall:.1f} s"}
         else:
             out["all_cores"] = {"error": "a worker failed"}
     except Exception as e:   # the baseline of record is the single-core figure above
@@ -103,16 +139,16 @@ def cpu_baseline(sim, seconds_target=12.0):
 
 
 def extras(args, device):
-    """Short side measurements printed next to the headline (never part of `value`): the float32
-    pipeline on the same job, BASELINE configs[2] (AO-corrected residual spectrum, float64) with the time
-    of the GPU power-spectrum evaluation that config adds to every `Fast()`, and the 2048^2 grid of configs[3]."""
+    """Side measurements printed next to the headline (never part of `value`): the float32 pipeline on the same job,
+    BASELINE configs[2] (AO-corrected residual spectrum) with the warm time of the power-spectrum kernel that config adds
+    to every `Fast()`, configs[3] (2048^2, 100 000 iterations, split over two handles = two worker threads, here on one
+    device) and configs[4] (32 zenith angles x 4096 iterations at 1024^2, AO) with the init / Monte-Carlo wall split."""
     import copy
     import fast_amd
+    from fast_amd import sweep
     out = {}
-    for tag, over in (("f32_same_job", {"GPU_PRECISION": "f32"}), ("config2_AO_alias_f64", {"AO_MODE": "AO", "ALIAS": True}),
-                      ("config3_2048_f64", {"NPXLS": 2048})):
-        a = copy.copy(args)
-        p = workload_params(a)
+    for tag, over in (("f32_same_job", {"GPU_PRECISION": "f32"}), ("config2_AO_alias_f64", {"AO_MODE": "AO", "ALIAS": True})):
+        p = workload_params(copy.copy(args))
         p.update(over)
         p["GPU_DEVICE"] = device
         t0 = time.perf_counter()
@@ -125,8 +161,106 @@ def extras(args, device):
         for i in range(3):
             h.run(1, (i + 1) * n_real, n_real, None, float(sim.logamp_var), False)
         dt = time.perf_counter() - t0
-        out[tag] = {"iterations_per_s": 3 * ITERS_PER_STEP / dt, "init_s": init_s, "powerspec_kernel_ms": sim.powerspec_kernel_ms,
+        sim.compute_powerspec()                              # second evaluation: no module load in the figure
+        out[tag] = {"iterations_per_s": 3 * ITERS_PER_STEP / dt, "init_s": init_s, "powerspec_kernel_ms_warm": sim.powerspec_kernel_ms,
                     "mean_dB_rel": float(10 * np.log10(np.mean(h.run(1, 0, 512, None, float(sim.logamp_var), False))))}
+    # configs[3]: 2048^2, 100 000 iterations, two handles
+    p = workload_params(copy.copy(args))
+    p.update({"NPXLS": 2048, "NITER": 100000, "NCHUNKS": 100, "GPU_DEVICES": [device, device]})
+    t0 = time.perf_counter()
+    sim = fast_amd.Fast(p)
+    t1 = time.perf_counter()
+    r = sim.run()._r
+    t2 = time.perf_counter()
+    hist = sim.histogram(*HIST)
+    out["config3_2048_100k_two_handles"] = {"iterations_per_s": 100000 / (t2 - t1), "init_s": t1 - t0, "run_s": t2 - t1,
+                                            "histogram_total": int(hist.sum()), "exchange": sim._group.exchange,
+                                            "mean_dB_rel": float(10 * np.log10(r.mean()))}
+    # configs[4]: zenith-angle scan, 32 x 4096 iterations at 1024^2, AO + alias (second pass: pupil / module caches warm)
+    base = workload_params(copy.copy(args))
+    base.update({"AO_MODE": "AO", "ALIAS": True, "GPU_DEVICE": device, "NPXLS": 1024})
+    angles = np.linspace(0, 70, 32)
+    sweep.zenith_scan(base, angles[:2], niter=4096)
+    t0 = time.perf_counter()
+    recs = sweep.zenith_scan(base, angles, niter=4096)
+    wall = time.perf_counter() - t0
+    out["config5_zenith_scan_32x4096"] = {"wall_s": wall, "init_s": sum(r["init_s"] for r in recs), "run_s": sum(r["run_s"] for r in recs),
+                                          "iterations_per_s_end_to_end": 32 * 4096 / wall,
+                                          "powerspec_kernel_ms_total": sum(r["powerspec_kernel_ms"] for r in recs),
+                                          "mean_dB_rel_first_last": [recs[0]["mean_dB_rel"], recs[-1]["mean_dB_rel"]]}
+    return out
+
+
+def load_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def roofline(args, N, Np, tim, steps, workers, value_per_worker):
+    """The `roofline` object for the dominant kernel (k_rows_wave) of THIS run.  The kernel is bound by the SIMDs'
+    instruction issue (float64 butterflies + the generator + LDS instructions), not by HBM or MFMA:
+    `bound` says so, `achieved` / `frac` are executed float64 (float32) vector FLOP/s against the vector peak, `issue` the
+    share of the SIMDs' issue cycles the VALU instructions of the code object account for, `hbm` the byte models."""
+    f64 = args.precision == "f64"
+    launches = max(tim["rows_launches"], 1)
+    avg_rows_ms = tim["rows_ms"] / launches
+    avg_cols_ms = tim["cols_ms"] / max(tim["cols_launches"], 1)
+    real_per_launch = ITERS_PER_STEP / 2 * steps * workers / launches        # realisations in an average launch
+    S = 4 if N == 4096 else (2 if N == 2048 else 1)
+    isa = load_json(os.path.join(ROOT, "fast_amd", "kernel_isa_stats.json")) or {}
+    key = f"rows_{args.precision}_{N}"
+    st = isa.get(key) if S == 1 else None      # split rows loop over sub-rows inside the counted body: no static count
+    wc = 16 if f64 else 8
+    it_per_launch = 2 * real_per_launch
+    bytes_alg = (20 if f64 else 10) * N * N                                     # SURVEY 8(d), per iteration
+    # what THIS design must move per realisation: V written by the row pass and read by the column pass (window columns
+    # only), the column partials, the results; the float32 colouring table (4 N^2 B) stays in cache across a launch
+    bytes_pruned_rows = wc * N * Np
+    bytes_pruned_cols = wc * N * Np + 32 * Np + 8 * Np * Np / max(real_per_launch, 1)
+    out = {"bound": "valu", "kernel": "k_rows_wave", "avg_launch_ms": avg_rows_ms, "realisations_per_launch": real_per_launch,
+           "iterations_per_launch": it_per_launch, "peak": F64_VECTOR_PEAK_TFLOPS if f64 else F32_VECTOR_PEAK_TFLOPS,
+           "unit": "TFLOP/s", "achieved": None, "frac": None, "traffic": None}
+    if st:
+        rows = real_per_launch * N                # row iterations of the kernel's main loop per launch
+        flop_lane = st["f64_flop_per_lane"] if f64 else st["f32_flop_per_lane"]
+        flops = flop_lane * 64 * rows
+        out["achieved"] = flops / (avg_rows_ms * 1e-3) / 1e12
+        out["frac"] = out["achieved"] / out["peak"]
+        cyc = sum(ISSUE_COST.get(k, 0.0) * v for k, v in st["instructions"].items())
+        row_cycles = avg_rows_ms * 1e-3 * NOMINAL_GHZ * 1e9 * N_SIMD / rows
+        out["issue"] = {"frac": cyc / row_cycles, "valu_issue_cycles_per_row": cyc, "measured_cycles_per_row_at_2.4GHz": row_cycles,
+                        "instructions_per_row": st["instructions"], "valu_instructions_per_row": st["valu_total"],
+                        "flop_per_lane_per_row": flop_lane, "counts_from": "fast_amd/kernel_isa_stats.json (tools/isa_stats.py on the built source)",
+                        "cycles_per_instruction": ISSUE_COST, "costs_from": ISSUE_COST_SOURCE,
+                        "note": "VALU classes only; LDS / scalar / memory instructions issue on top of this"}
+    hbm = {"rows": {"algorithmic_GBps": bytes_alg * it_per_launch / (avg_rows_ms * 1e-3) / 1e9,
+                    "pruned_algorithmic_GBps": bytes_pruned_rows * real_per_launch / (avg_rows_ms * 1e-3) / 1e9},
+           "cols": {"pruned_algorithmic_GBps": bytes_pruned_cols * real_per_launch / (avg_cols_ms * 1e-3) / 1e9 if avg_cols_ms else None},
+           "peak_GBps": HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": bytes_alg,
+           "pruned_bytes_per_realisation": {"rows": bytes_pruned_rows, "cols": bytes_pruned_cols},
+           "note": "algorithmic = SURVEY 8(d) model (full grid written and re-read between the passes); the kernels are output-"
+                   "pruned and move only the pruned bytes, so the 8(d) figure is not a bandwidth and may exceed the peak"}
+    hbm["rows"]["frac_pruned"] = hbm["rows"]["pruned_algorithmic_GBps"] / HBM_PEAK_GBS
+    if hbm["cols"]["pruned_algorithmic_GBps"]:
+        hbm["cols"]["frac_pruned"] = hbm["cols"]["pruned_algorithmic_GBps"] / HBM_PEAK_GBS
+    # hardware counters of the same command, when a committed rocprofv3 summary belongs to this build
+    prof = load_json(os.path.join(ROOT, "profiles", "latest_counters.json"))
+    if prof and st and prof.get("precision") == args.precision and prof.get("npxls") == N:
+        if prof.get("rows_valu_instructions_per_row") == st["valu_total"]:
+            for k in ("rows", "cols"):
+                c = prof.get(k, {})
+                if c.get("hbm_bytes_per_launch") and c.get("avg_launch_ms"):
+                    hbm[k]["counter_GBps"] = c["hbm_bytes_per_launch"] / (c["avg_launch_ms"] * 1e-3) / 1e9
+                    hbm[k]["frac_counter"] = hbm[k]["counter_GBps"] / HBM_PEAK_GBS
+            out["traffic"] = prof.get("rows", {}).get("hbm_bytes_per_launch")
+            out["counters"] = {k: prof[k] for k in ("valu_busy", "issue_busy", "lds_issue_busy", "source") if k in prof}
+        else:
+            out["counters"] = {"stale": f"{prof.get('source')} belongs to a build with {prof.get('rows_valu_instructions_per_row')} "
+                                        f"VALU instructions per row, this build has {st['valu_total']}"}
+    out["hbm"] = hbm
     return out
 
 
@@ -139,188 +273,168 @@ def main():
     ap.add_argument("--npxls", type=int, default=1024)
     ap.add_argument("--ao-mode", default="NOAO")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the short f32 / AO-config side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (f32, AO config, configs[3], configs[4])")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained run after the timed steps")
     ap.add_argument("--batch", type=int, default=0, help="realisations per launch (0 = library default)")
     args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = None
-    torch = None
-    # FASTMC_BENCH_FORCE_DIST=1 exercises the multi-process code path (process group, in-library
-    # RCCL communicator, gather) with a single rank: the only way to test it on a 1-GPU box.
-    dist_on = world > 1 or (os.environ.get("FASTMC_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
-    # FASTMC_BENCH_BACKEND=gloo runs the multi-rank logic with host-side collectives and lets several
-    # ranks share one GPU (FASTMC_BENCH_DEVICE): a functional test of the N > 1 path on a 1-GPU box.
-    backend = os.environ.get("FASTMC_BENCH_BACKEND", "nccl")
-    device_index = int(os.environ.get("FASTMC_BENCH_DEVICE", local_rank))
-    if dist_on:
-        # torch FIRST: its wheel bundles its own libamdhip64 / libhsa-runtime64; whichever HIP runtime
-        # is loaded first serves the whole process, and torch cannot run on /opt/rocm's newer one
-        # ("No HIP GPUs are available"), while libfastmc.so runs fine on torch's.
-        import torch
-        import torch.distributed as dist
-        ndev = torch.cuda.device_count()
-        if ndev > 0 and device_index >= ndev:      # launcher restricted the visible devices per rank
-            device_index %= ndev
-        if backend == "nccl":
-            torch.cuda.set_device(device_index)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend)
-
-    def dev(t):
-        return t.cuda() if backend == "nccl" else t
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
 
     import fast_amd
+    from fast_amd import _lib, dist, multi, rendezvous
+    rank, world, local_rank = rendezvous.env_world()
+    ndev = _lib.device_count()
+    if ndev < 1:
+        raise SystemExit("no GPU visible: bench.py measures the HIP path and has no CPU fallback")
+    rdzv = None
+    if world > 1:
+        # one process per GPU, started by a launcher
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        mode = "ranks"
+        devices = [int(os.environ.get("FASTMC_BENCH_DEVICE", _lib.default_device()))]
+        rdzv = rendezvous.from_env()
+    else:
+        # one process drives all the GPUs; FASTMC_BENCH_DEVICES=0,0 puts several workers on one device (functional tests)
+        mode = "threads" if args.gpus > 1 else "single"
+        if os.environ.get("FASTMC_BENCH_DEVICES"):
+            devices = [int(x) for x in os.environ["FASTMC_BENCH_DEVICES"].split(",")]
+            if len(devices) != args.gpus:
+                raise SystemExit(f"FASTMC_BENCH_DEVICES names {len(devices)} workers, --gpus {args.gpus}")
+        else:
+            if args.gpus > ndev:
+                raise SystemExit(f"--gpus {args.gpus} but only {ndev} GPU(s) visible to this process "
+                                 "(under a launcher, start one rank per GPU; bench.py never reports GPUs that did not run)")
+            devices = list(range(args.gpus))
+    if max(devices) >= ndev:
+        raise SystemExit(f"device {max(devices)} requested but only {ndev} GPU(s) visible")
+
     p = workload_params(args)
-    p["GPU_DEVICE"] = device_index
+    p["GPU_DEVICES"] = devices
     p["GPU_BATCH"] = args.batch
     t0 = time.perf_counter()
     sim = fast_amd.Fast(p)
     init_s = time.perf_counter() - t0
-    h = sim._handle
+    grp, h = sim._group, sim._handle
     N, Np = sim.Npxls, sim.Npxls_pup
     n_real = ITERS_PER_STEP // 2
     lvar = float(sim.logamp_var)
+    workers = len(devices) if mode != "ranks" else world
 
-    gather = "none"
-    if dist_on:
-        # RCCL inside the library, on its own stream: unique id from rank 0 via the launcher's store
-        if backend == "nccl":
-            ids = [fast_amd._lib.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            # keep the scaling run alive whatever the communicator does (error or no return): say so in the JSON
-            import threading
-            box = {}
-
-            def _init():
-                try:
-                    h.comm_init(ids[0], world, rank)
-                    box["ok"] = True
-                except fast_amd.FastMCError as e:
-                    box["err"] = str(e)
-            th = threading.Thread(target=_init, daemon=True)
-            th.start()
-            th.join(float(os.environ.get("FASTMC_BENCH_RCCL_TIMEOUT", "180")))
-            err = "" if box.get("ok") else box.get("err", "ncclCommInitRank did not return in time")
-            ok = dev(torch.tensor([0 if err else 1], dtype=torch.int32))
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank takes the same path
-            gather = "rccl(in-library)" if int(ok.item()) == 1 else f"torch.distributed (RCCL init failed: {err or 'on another rank'})"
-        else:
-            gather = f"torch.distributed ({backend})"
-
-    def sync_all():
-        if dist_on:
-            if backend == "nccl":
-                torch.cuda.synchronize()
-            dist.barrier()
-            if backend == "nccl":
-                torch.cuda.synchronize()
+    tr = None
+    if mode == "ranks":
+        tr = dist.make_transport(h, rdzv)                 # collective: RCCL on every rank, or the host path on every rank
+        exchange = "rccl (in-library, one process per GPU)" if tr.name == "rccl" else f"host sockets ({getattr(tr, 'why', '')})"
+    elif mode == "threads":
+        exchange = "rccl (in-library, ncclCommInitAll)" if grp.exchange == "rccl" else grp.exchange
+    else:
+        exchange = "none"
 
     hist_total = None
 
     def step(i):
-        nonlocal hist_total, gather
-        # disjoint realisation ranges: step i, rank r
-        real0 = (i * world + rank) * n_real
-        out = h.run(p["SEED"], real0, n_real, None, lvar, False)
-        if dist_on:
-            hist = None
-            if gather.startswith("rccl"):
-                try:
-                    allp, hist = h.comm_gather(2 * n_real, world, HIST)
-                except fast_amd.FastMCError as e:
-                    gather = f"torch.distributed ({e})"
-            if hist is None:
-                hist_l = dev(torch.from_numpy(h.histogram(*HIST)))
-                dist.all_reduce(hist_l)
-                src = dev(torch.from_numpy(out))
-                allp_t = [torch.empty_like(src) for _ in range(world)]
-                dist.all_gather(allp_t, src)
-                hist = hist_l.cpu().numpy()
-            hist_total = hist
+        """Step i: every worker computes ITERS_PER_STEP iterations of its own realisation range, then one exchange."""
+        nonlocal hist_total
+        if mode == "ranks":
+            real0 = (i * world + rank) * n_real
+            out = h.run(p["SEED"], real0, n_real, None, lvar, False)
+            if tr.name == "rccl":
+                _, hist_total = tr.gather_with_hist(out, h, HIST)
+            else:
+                tr.gather(out, h)
+                hist_total = tr.reduce_hist(h.histogram(*HIST))
+            return out
+        out = grp.run(p["SEED"], i * workers * n_real, workers * n_real, None, lvar, False, hist_range=HIST)
+        hist_total = grp.last_hist
         return out
+
+    def sync_all():
+        if rdzv is not None:
+            rdzv.barrier()                  # library calls are blocking: every device is idle when its rank gets here
+
+    tim_keys = ("rows_ms", "cols_ms", "finalize_ms", "rows_launches", "cols_launches")
+
+    def add_timing(tim):
+        for t in (grp.last_timing() if mode != "ranks" else [h.last_timing()]):
+            for k in tim_keys:
+                tim[k] += t[k]
 
     for i in range(args.warmup):
         step(i)
-    tim = {"rows_ms": 0.0, "cols_ms": 0.0, "finalize_ms": 0.0, "rows_launches": 0, "cols_launches": 0}
+    tim = dict.fromkeys(tim_keys, 0.0)
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
-        t = h.last_timing()
-        for k in tim:
-            tim[k] += t[k]
+        add_timing(tim)
     sync_all()
     dt = time.perf_counter() - t0
-    if dist_on:
-        tmax = dev(torch.tensor([dt], dtype=torch.float64))
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    if rdzv is not None:
+        dt = float(rdzv.all_reduce(np.array([dt]), "max")[0])
+        for k in tim_keys:
+            tim[k] = float(rdzv.all_reduce(np.array([tim[k]]), "sum")[0])
     assert np.isfinite(out).all() and (out > 0).all()
 
+    sustained = None
+    if not args.no_sustained:
+        # one figure a coarse sampler (rocm-smi at 1 Hz) can see: the same steps back to back for >= 5 s
+        sync_all()
+        t0 = time.perf_counter()
+        n_sus = 0
+        while True:
+            step(args.warmup + args.steps + n_sus)
+            n_sus += 1
+            go = np.array([1 if time.perf_counter() - t0 < 5.0 else 0])
+            if rdzv is not None:
+                go = rdzv.all_reduce(go, "max")
+            if not go[0]:
+                break
+        sync_all()
+        dts = time.perf_counter() - t0
+        if rdzv is not None:
+            dts = float(rdzv.all_reduce(np.array([dts]), "max")[0])
+        sustained = {"seconds": dts, "steps": n_sus, "value": ITERS_PER_STEP * n_sus * workers / dts, "unit": "iterations/s"}
+
+    # GPUs that actually ran (one node: distinct device indices over all workers)
+    if mode == "ranks":
+        n_devices = len(set(int(x) for x in rdzv.all_gather_array(np.array([devices[0]], dtype=np.int64)).ravel()))
+    else:
+        n_devices = len(set(devices))
     if rank == 0:
-        bytes_per_iter = (20 if args.precision == "f64" else 10) * N * N
-        total_iters = ITERS_PER_STEP * args.steps * world
+        total_iters = ITERS_PER_STEP * args.steps * workers
         value = total_iters / dt
-        iters_per_launch = ITERS_PER_STEP * args.steps / max(tim["rows_launches"], 1)
-        avg_rows_ms = tim["rows_ms"] / max(tim["rows_launches"], 1)
-        achieved = bytes_per_iter * iters_per_launch / (avg_rows_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_rows_kernel.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("precision") == args.precision and tj.get("npxls") == N:
-                    traffic = tj["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
         gpu_ms = tim["rows_ms"] + tim["cols_ms"] + tim["finalize_ms"]
+        sim.compute_powerspec()                   # the evaluation at init paid the module load; this one is warm
         line = {
             "metric": f"Monte-Carlo iterations/sec ({N}^2 grid)", "value": value, "unit": "iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": n_devices, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if args.precision == "f64" else "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {N}^2 grid, Np={Np}, {ITERS_PER_STEP} iters/step/GPU, "
-                                   f"{args.ao_mode} von Karman spectrum, device generator (Philox4x32-10-seeded xoshiro128+ streams, Box-Muller)",
+            "config": {"workload": f"configs[1]: {N}^2 grid, Np={Np}, {ITERS_PER_STEP} iters/step/GPU, {args.ao_mode} von Karman spectrum, "
+                                   "device generator (Philox4x32-7-seeded xoshiro128+ streams, Box-Muller)",
+                       "arithmetic": ("complex128 transform and float64 detector sums" if args.precision == "f64" else "complex64 transform, float64 detector sums")
+                                     + "; the device generator's normals are float32 (24-bit uniforms, hardware log/sqrt/sin/cos), "
+                                       "coloured in float32 and widened; host-coefficient (parity) mode is float64 throughout",
                        "iters_per_step_per_gpu": ITERS_PER_STEP, "kernel_path": "wave-fft" if h.kernel_path() == 1 else "direct",
-                       "parallelism": f"realisations sharded over {world} GPU(s)", "result_exchange": gather},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_rows_wave", "avg_launch_ms": avg_rows_ms,
-                         "iterations_per_launch": iters_per_launch, "algorithmic_bytes_per_iteration": bytes_per_iter},
-            "pipeline": {"gpu_busy_ms_per_step": gpu_ms / args.steps, "rows_ms": tim["rows_ms"] / args.steps,
-                         "cols_ms": tim["cols_ms"] / args.steps, "finalize_ms": tim["finalize_ms"] / args.steps,
-                         "algorithmic_GBps_whole_job": value / world * bytes_per_iter / 1e9,
-                         "frac_whole_job": value / world * bytes_per_iter / 1e9 / HBM_PEAK_GBS,
-                         "init_s": init_s, "powerspec_kernel_ms": sim.powerspec_kernel_ms},
+                       "launch": {"single": "one process, one GPU", "threads": f"one process, {workers} worker threads",
+                                  "ranks": f"{workers} processes (launcher), fast_amd.rendezvous"}[mode],
+                       "workers": workers, "devices": devices if mode != "ranks" else "LOCAL_RANK per process",
+                       "parallelism": f"realisations sharded over {workers} worker(s) on {n_devices} GPU(s)", "result_exchange": exchange,
+                       "histogram_total": None if hist_total is None else int(np.sum(hist_total))},
+            "roofline": roofline(args, N, Np, tim, args.steps, workers, value / workers),
+            "pipeline": {"gpu_busy_ms_per_step_per_worker": gpu_ms / args.steps / workers, "rows_ms": tim["rows_ms"] / args.steps / workers,
+                         "cols_ms": tim["cols_ms"] / args.steps / workers, "finalize_ms": tim["finalize_ms"] / args.steps / workers,
+                         "init_s": init_s, "powerspec_kernel_ms_warm": sim.powerspec_kernel_ms},
         }
-        # The binding resource is the vector ALU, not HBM: per row-wave of
-        # k_rows_wave<double,16> rocprofv3 counts 970 VALU instructions: 414 float64 butterflies (196 add,
-        # 68 mul, 150 fma = 564 flop/lane), ~490 integer/f32 and 64 transcendental instructions of the generator.
-        if args.precision == "f64" and N == 1024:
-            f64_flop_per_iter = 564 * 64 * N / 2 * (1 + Np / N)
-            line["valu"] = {"f64_flop_per_iteration": f64_flop_per_iter,
-                            "achieved_f64_TFLOPs": value / world * f64_flop_per_iter / 1e12, "peak_f64_vector_TFLOPs": 78.6,
-                            "note": "issue-time model from measured instruction rates (profiles/r01j_ubench_valu_issue_rates.txt: "
-                                    "f64 5.1, transcendental 6.3, other 4 cycles per wave-instruction) = 4470 cycles per row-wave "
-                                    "against 6100 measured: the kernel runs at 73 % of the VALU issue bound; rocprofv3 "
-                                    "SQ_ACTIVE_INST_VALU gives the same 74 %"}
-        if world == 1 and not args.no_extras:
-            line["extras"] = extras(args, device_index)
-        if world == 1 and not args.no_cpu_baseline:
+        if sustained:
+            line["sustained"] = sustained
+        if mode == "single" and not args.no_extras:
+            line["extras"] = extras(args, devices[0])
+        if mode == "single" and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sim)
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
-        if hist_total is not None:
-            line["config"]["histogram_total"] = int(np.sum(hist_total))
         print(json.dumps(line))
-    if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
+    sync_all()
 
 
 if __name__ == "__main__":

@@ -20,7 +20,8 @@ EXPORTS = [
     "fastmc_result_stats", "fastmc_last_timing", "fastmc_kernel_path", "fastmc_set_batch", "fastmc_powerspec",
     "fastmc_set_layer_screens", "fastmc_temporal_chunk", "fastmc_link_metrics", "fastmc_set_results",
     "fastmc_powerspec_terms",
-    "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_gather", "fastmc_comm_destroy",
+    "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_init_all", "fastmc_comm_world", "fastmc_comm_gather",
+    "fastmc_comm_gather_all", "fastmc_comm_destroy",
 ]
 
 
@@ -57,7 +58,6 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise FastMCError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or `make -C fast_amd/csrc`).  fast_amd has no CPU fallback.")
-    # Note for programs that also use PyTorch (multi-GPU launchers): import torch first -- see dist.py.
     L = C.CDLL(LIB_PATH)
     dp, vp, i64, u64 = C.POINTER(C.c_double), C.c_void_p, C.c_int64, C.c_uint64
     L.fastmc_version.restype = C.c_int
@@ -89,6 +89,9 @@ def lib():
     L.fastmc_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     L.fastmc_comm_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
     L.fastmc_comm_gather.argtypes = [vp, i64, dp, C.POINTER(i64), C.c_double, C.c_double, C.c_int]
+    L.fastmc_comm_init_all.argtypes = [C.POINTER(vp), C.c_int]
+    L.fastmc_comm_world.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.fastmc_comm_gather_all.argtypes = [C.POINTER(vp), C.c_int, i64, dp, C.POINTER(i64), C.c_double, C.c_double, C.c_int]
     L.fastmc_comm_destroy.argtypes = [vp]
     for name in EXPORTS:
         if name not in ("fastmc_last_error", "fastmc_destroy"):
@@ -118,7 +121,14 @@ def device_count():
 
 
 def default_device():
-    return int(os.environ.get("LOCAL_RANK", "0"))
+    """LOCAL_RANK (one process per GPU under a launcher), folded onto the visible devices when the launcher
+    also restricted them per rank; 0 otherwise."""
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    if lr > 0:
+        n = device_count()
+        if n > 0:
+            lr %= n
+    return lr
 
 
 class Handle:
@@ -256,13 +266,22 @@ class Handle:
     def set_batch(self, batch):
         _chk(lib().fastmc_set_batch(self._h, int(batch)))
 
-    # ---- RCCL
+    # ---- RCCL (the communicator belongs to the handle's DEVICE and outlives the handle)
     def comm_init(self, unique_id, world_size, rank):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         _chk(lib().fastmc_comm_init(self._h, buf, int(world_size), int(rank)))
 
-    def comm_gather(self, n_local, world_size, hist_range=None):
-        allp = np.empty(n_local * world_size, dtype=np.float64)
+    def comm_world(self):
+        """(world size, rank) of the communicator of this handle's device; (0, -1) when there is none."""
+        w, r = C.c_int(0), C.c_int(-1)
+        _chk(lib().fastmc_comm_world(self._h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
+    def comm_destroy(self):
+        _chk(lib().fastmc_comm_destroy(self._h))
+
+    def comm_gather(self, n_local, world_size, hist_range=None, powers=True):
+        allp = np.empty(n_local * world_size, dtype=np.float64) if powers else None
         hist = None
         lo = hi = 0.0
         nb = 1
@@ -317,6 +336,31 @@ def link_metrics(queries, samples=None, handle=None, device=0):
             raise FastMCError("link_metrics needs samples or a handle")
         _chk(lib().fastmc_link_metrics(handle._h, 0, None, 0, q, len(queries), _dptr(out)))
     return out
+
+
+def _handle_array(handles):
+    return (C.c_void_p * len(handles))(*[h._h for h in handles])
+
+
+def comm_init_all(handles):
+    """ncclCommInitAll over the devices of `handles` (one handle per device): handles[i] becomes rank i."""
+    _chk(lib().fastmc_comm_init_all(_handle_array(handles), len(handles)))
+
+
+def comm_gather_all(handles, n_local, hist_range=None, powers=True):
+    """Grouped all-gather of every handle's last-run results (n_local float64 each) and all-reduce of the
+    dB histogram, issued from this thread for all handles; returns (all_values | None, hist | None)."""
+    allp = np.empty(n_local * len(handles), dtype=np.float64) if powers else None
+    hist = None
+    lo = hi = 0.0
+    nb = 1
+    if hist_range is not None:
+        lo, hi, nb = hist_range
+        hist = np.zeros(nb + 2, dtype=np.int64)
+    _chk(lib().fastmc_comm_gather_all(_handle_array(handles), len(handles), int(n_local), _dptr(allp),
+                                      None if hist is None else hist.ctypes.data_as(C.POINTER(C.c_int64)),
+                                      float(lo), float(hi), int(nb)))
+    return allp, hist
 
 
 def comm_unique_id():

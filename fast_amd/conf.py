@@ -30,10 +30,13 @@ GPU_DEFAULTS = {
     'GPU_PRECISION': 'f64',   # 'f64' (complex128 pipeline, reference precision) or 'f32'
     'GPU_RNG': 'device',      # 'device': Philox on the GPU; 'host': numpy draws, reference order (parity mode)
     'GPU_DEVICE': None,       # HIP device index; None -> LOCAL_RANK or 0
+    'GPU_DEVICES': None,      # list of HIP device indices driven by THIS process (one thread each, fast_amd/multi.py);
+                              # None -> [GPU_DEVICE]
     'GPU_BATCH': 0,           # realisations in flight per launch (0 = library default)
     'GPU_ROUND_NPXLS': 'auto', # with NPXLS 'auto': round the auto-sized grid up to the next fast-kernel size: True | False |
                                # 'auto' = when nothing ties the run to the reference's exact grid (GPU_RNG 'device', not TEMPORAL)
-    'GPU_SHARD': 'auto',      # shard iterations over the ranks of a torch.distributed group ('auto' | True | False)
+    'GPU_SHARD': 'auto',      # shard iterations over the ranks of a multi-process launch (RANK / WORLD_SIZE in the
+                              # environment; fast_amd/rendezvous.py): 'auto' | True | False
 }
 
 

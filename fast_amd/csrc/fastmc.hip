@@ -50,6 +50,8 @@ struct fastmc_ctx {
 
   void* amp = nullptr;     // R[N*N]  unsigned (direct family)
   void* amp_s = nullptr;   // R[N*N]  with (-1)^(ky+kx)  (wave family)
+  float* ampf = nullptr;   // amp / amp_s times sqrt(2 ln 2) in float32: colouring of the device generator's draws
+  float* ampf_s = nullptr; //   (fmc_kernels.h: box_muller_scaled)
   void* tw = nullptr;      // direct: cpx<R>[N]
   void* tw1 = nullptr;     // wave
   void* om = nullptr;      // wave
@@ -95,10 +97,7 @@ struct fastmc_ctx {
   size_t pool_used = 0;
   double t_ms[4] = {0, 0, 0, 0};
   int64_t t_n[4] = {0, 0, 0, 0};
-  // RCCL
-  void* rccl_lib = nullptr;
-  ncclComm_t comm = nullptr;
-  int world = 1, rank = 0;
+  // RCCL exchange buffer (the communicator itself belongs to the device, see DeviceComm)
   double* gather_buf = nullptr;
   size_t gather_cap = 0;
 };
@@ -298,10 +297,9 @@ static SlabCache g_slabs;
 extern "C" void fastmc_destroy(fastmc_t* h) {
   if (!h) return;
   hipSetDevice(h->device);
-  if (h->comm) fastmc_comm_destroy(h);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
-  void* ptrs[] = {h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+  void* ptrs[] = {h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers};
   for (void* p : ptrs)
@@ -352,13 +350,15 @@ static int upload_spectrum(fastmc_ctx* h, const double* ps, double df) {
   const size_t n = (size_t)N * N;
   if (!h->amp) HIPCHK(hipMalloc(&h->amp, sizeof(R) * n));
   if (!h->amp_s) HIPCHK(hipMalloc(&h->amp_s, sizeof(R) * n));
+  if (!h->ampf) HIPCHK(hipMalloc((void**)&h->ampf, sizeof(float) * n));
+  if (!h->ampf_s) HIPCHK(hipMalloc((void**)&h->ampf_s, sizeof(float) * n));
   ScratchBuf d_ps, d_bad;
   HIPCHK(hipMalloc((void**)&d_ps.p, n * 8));
   HIPCHK(hipMalloc((void**)&d_bad.p, 8));
   HIPCHK(hipMemcpyAsync(d_ps.p, ps, n * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemsetAsync(d_bad.p, 0, 8, h->stream));
   hipLaunchKernelGGL((k_make_amp<R>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d_ps.p, df, N, (R*)h->amp,
-                     (R*)h->amp_s, (unsigned int*)d_bad.p);
+                     (R*)h->amp_s, h->ampf, h->ampf_s, (unsigned int*)d_bad.p);
   HIPCHK(hipGetLastError());
   unsigned int bad = 0;
   HIPCHK(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, h->stream));
@@ -708,6 +708,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       }
     }
     RA.amp = (const R*)(wave_ok ? h->amp_s : h->amp);
+    RA.ampf = wave_ok ? h->ampf_s : h->ampf;
     RA.tw = (const cpx<R>*)(wave_ok ? (general_2048 ? h->tw1g : h->tw1) : h->tw);
     CA.tw = RA.tw;
     RA.cw = (const cpx<R>*)h->cw;
@@ -1126,25 +1127,38 @@ extern "C" int fastmc_powerspec_terms(int device_id, const fastmc_ps_params* p, 
 }
 
 // ------------------------------------------------------------------ RCCL (loaded on demand)
+// One communicator per DEVICE of this process, shared by every handle on that device: sweeps build many
+// short-lived handles, and a communicator costs a rendezvous.  Two ways to create them:
+//   fastmc_comm_init      one process per GPU (a launcher distributes the unique id), ncclCommInitRank;
+//   fastmc_comm_init_all  one process drives n devices, ncclCommInitAll.
 struct RcclApi {
   decltype(&ncclGetUniqueId) GetUniqueId;
   decltype(&ncclCommInitRank) CommInitRank;
+  decltype(&ncclCommInitAll) CommInitAll;
   decltype(&ncclCommDestroy) CommDestroy;
+  decltype(&ncclCommAbort) CommAbort;
   decltype(&ncclAllGather) AllGather;
   decltype(&ncclAllReduce) AllReduce;
+  decltype(&ncclGroupStart) GroupStart;
+  decltype(&ncclGroupEnd) GroupEnd;
   decltype(&ncclGetErrorString) GetErrorString;
   void* lib = nullptr;
 };
 static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
 static int load_rccl() {
+  std::lock_guard<std::mutex> g(g_rccl_mu);
   if (g_rccl.lib) return 0;
+  if (const char* off = getenv("FASTMC_DISABLE_RCCL"))
+    if (off[0] && off[0] != '0') return fail(FASTMC_ECOMM, "RCCL disabled by FASTMC_DISABLE_RCCL");
   void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!lib) return fail(FASTMC_ECOMM, std::string("cannot load librccl: ") + dlerror());
 #define SYM(n)                                                        \
   g_rccl.n = (decltype(g_rccl.n))dlsym(lib, "nccl" #n);                \
   if (!g_rccl.n) return fail(FASTMC_ECOMM, "librccl lacks nccl" #n);
-  SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllGather) SYM(AllReduce) SYM(GetErrorString)
+  SYM(GetUniqueId) SYM(CommInitRank) SYM(CommInitAll) SYM(CommDestroy) SYM(CommAbort) SYM(AllGather) SYM(AllReduce)
+  SYM(GroupStart) SYM(GroupEnd) SYM(GetErrorString)
 #undef SYM
   g_rccl.lib = lib;
   return 0;
@@ -1154,6 +1168,17 @@ static int load_rccl() {
     ncclResult_t r__ = (expr);                                                                 \
     if (r__ != ncclSuccess) return fail(FASTMC_ECOMM, std::string(#expr) + ": " + g_rccl.GetErrorString(r__)); \
   } while (0)
+
+struct DeviceComm {
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0;
+};
+static DeviceComm g_comm[64];
+static std::mutex g_comm_mu;
+static DeviceComm device_comm(int device) {
+  std::lock_guard<std::mutex> g(g_comm_mu);
+  return g_comm[device & 63];
+}
 
 extern "C" int fastmc_comm_unique_id(uint8_t id128[128]) {
   if (!id128) return fail(FASTMC_EINVAL, "null id");
@@ -1168,39 +1193,136 @@ extern "C" int fastmc_comm_unique_id(uint8_t id128[128]) {
 extern "C" int fastmc_comm_init(fastmc_t* h, const uint8_t id128[128], int world_size, int rank) {
   if (!h || !id128 || world_size < 1 || rank < 0 || rank >= world_size) return fail(FASTMC_EINVAL, "bad argument");
   TRY(load_rccl());
+  if (device_comm(h->device).comm) return fail(FASTMC_ESTATE, "this device already has a communicator (fastmc_comm_destroy first)");
   HIPCHK(hipSetDevice(h->device));
   ncclUniqueId id;
   memcpy(&id, id128, 128);
-  NCCLCHK(g_rccl.CommInitRank(&h->comm, world_size, id, rank));
-  h->world = world_size;
-  h->rank = rank;
+  ncclComm_t c = nullptr;
+  NCCLCHK(g_rccl.CommInitRank(&c, world_size, id, rank));
+  std::lock_guard<std::mutex> g(g_comm_mu);
+  g_comm[h->device & 63] = DeviceComm{c, world_size, rank};
+  return 0;
+}
+
+extern "C" int fastmc_comm_init_all(fastmc_t* const* handles, int n) {
+  if (!handles || n < 1 || n > 64) return fail(FASTMC_EINVAL, "bad argument");
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) {
+    if (!handles[i]) return fail(FASTMC_EINVAL, "null handle");
+    devs[i] = handles[i]->device;
+    for (int j = 0; j < i; ++j)
+      if (devs[j] == devs[i]) return fail(FASTMC_ECOMM, "two handles on one device: RCCL needs one device per rank (use the host exchange)");
+    if (device_comm(devs[i]).comm) return fail(FASTMC_ESTATE, "a device already has a communicator (fastmc_comm_destroy first)");
+  }
+  TRY(load_rccl());
+  std::vector<ncclComm_t> comms(n, nullptr);
+  NCCLCHK(g_rccl.CommInitAll(comms.data(), n, devs.data()));
+  std::lock_guard<std::mutex> g(g_comm_mu);
+  for (int i = 0; i < n; ++i) g_comm[devs[i] & 63] = DeviceComm{comms[i], n, i};
+  return 0;
+}
+
+extern "C" int fastmc_comm_world(fastmc_t* h, int* world_size, int* rank) {
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  const DeviceComm dc = device_comm(h->device);
+  if (world_size) *world_size = dc.comm ? dc.world : 0;
+  if (rank) *rank = dc.comm ? dc.rank : -1;
+  return 0;
+}
+
+// Enqueue this handle's part of the exchange on its stream (inside an RCCL group when several handles of one
+// process take part); the host copies follow on the same stream.
+static int comm_enqueue_gather(fastmc_ctx* h, const DeviceComm& dc, int64_t n_local, bool powers) {
+  HIPCHK(hipSetDevice(h->device));
+  if (powers) NCCLCHK(g_rccl.AllGather(h->out, h->gather_buf, (size_t)n_local, ncclDouble, dc.comm, h->stream));
+  return 0;
+}
+static int comm_enqueue_hist(fastmc_ctx* h, const DeviceComm& dc, int nbins) {
+  HIPCHK(hipSetDevice(h->device));
+  NCCLCHK(g_rccl.AllReduce(h->hist, h->hist, (size_t)nbins + 2, ncclUint64, ncclSum, dc.comm, h->stream));
   return 0;
 }
 
 extern "C" int fastmc_comm_gather(fastmc_t* h, int64_t n_local, double* all_powers, int64_t* hist, double lo_db,
                                   double hi_db, int nbins) {
-  if (!h || !h->comm) return fail(FASTMC_ESTATE, "fastmc_comm_init not called");
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  const DeviceComm dc = device_comm(h->device);
+  if (!dc.comm) return fail(FASTMC_ESTATE, "fastmc_comm_init not called for this device");
   if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds the last run");
   HIPCHK(hipSetDevice(h->device));
   if (all_powers) {
-    TRY(grow(&h->gather_buf, &h->gather_cap, (size_t)n_local * h->world));
-    NCCLCHK(g_rccl.AllGather(h->out, h->gather_buf, (size_t)n_local, ncclDouble, h->comm, h->stream));
-    HIPCHK(hipMemcpyAsync(all_powers, h->gather_buf, (size_t)n_local * h->world * 8, hipMemcpyDeviceToHost, h->stream));
+    TRY(grow(&h->gather_buf, &h->gather_cap, (size_t)n_local * dc.world));
+    TRY(comm_enqueue_gather(h, dc, n_local, true));
+    HIPCHK(hipMemcpyAsync(all_powers, h->gather_buf, (size_t)n_local * dc.world * 8, hipMemcpyDeviceToHost, h->stream));
   }
   if (hist) {
     TRY(histogram_device(h, lo_db, hi_db, nbins));
-    NCCLCHK(g_rccl.AllReduce(h->hist, h->hist, (size_t)nbins + 2, ncclUint64, ncclSum, h->comm, h->stream));
+    TRY(comm_enqueue_hist(h, dc, nbins));
     HIPCHK(hipMemcpyAsync(hist, h->hist, ((size_t)nbins + 2) * 8, hipMemcpyDeviceToHost, h->stream));
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
+extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n_local, double* all_powers, int64_t* hist,
+                                      double lo_db, double hi_db, int nbins) {
+  if (!handles || n < 1 || n > 64) return fail(FASTMC_EINVAL, "bad argument");
+  std::vector<DeviceComm> dcs(n);
+  for (int i = 0; i < n; ++i) {
+    fastmc_ctx* h = handles[i];
+    if (!h) return fail(FASTMC_EINVAL, "null handle");
+    dcs[i] = device_comm(h->device);
+    if (!dcs[i].comm || dcs[i].world != n || dcs[i].rank != i)
+      return fail(FASTMC_ESTATE, "handles do not match the communicators of fastmc_comm_init_all (same handles, same order)");
+    if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds a handle's last run");
+  }
+  if (all_powers) {
+    for (int i = 0; i < n; ++i) {
+      HIPCHK(hipSetDevice(handles[i]->device));
+      TRY(grow(&handles[i]->gather_buf, &handles[i]->gather_cap, (size_t)n_local * n));
+    }
+    NCCLCHK(g_rccl.GroupStart());
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; ++i) rc = comm_enqueue_gather(handles[i], dcs[i], n_local, true);
+    ncclResult_t ge = g_rccl.GroupEnd();
+    if (rc) return rc;
+    if (ge != ncclSuccess) return fail(FASTMC_ECOMM, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
+  }
+  if (hist) {
+    for (int i = 0; i < n; ++i) {
+      HIPCHK(hipSetDevice(handles[i]->device));
+      TRY(histogram_device(handles[i], lo_db, hi_db, nbins));
+    }
+    NCCLCHK(g_rccl.GroupStart());
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; ++i) rc = comm_enqueue_hist(handles[i], dcs[i], nbins);
+    ncclResult_t ge = g_rccl.GroupEnd();
+    if (rc) return rc;
+    if (ge != ncclSuccess) return fail(FASTMC_ECOMM, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
+  }
+  // every rank holds the same gathered data: the host copy comes from rank 0, the others are only waited for
+  fastmc_ctx* h0 = handles[0];
+  HIPCHK(hipSetDevice(h0->device));
+  if (all_powers) HIPCHK(hipMemcpyAsync(all_powers, h0->gather_buf, (size_t)n_local * n * 8, hipMemcpyDeviceToHost, h0->stream));
+  if (hist) HIPCHK(hipMemcpyAsync(hist, h0->hist, ((size_t)nbins + 2) * 8, hipMemcpyDeviceToHost, h0->stream));
+  for (int i = 0; i < n; ++i) {
+    HIPCHK(hipSetDevice(handles[i]->device));
+    HIPCHK(hipStreamSynchronize(handles[i]->stream));
+  }
+  return 0;
+}
+
 extern "C" int fastmc_comm_destroy(fastmc_t* h) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
-  if (h->comm && g_rccl.lib) {
-    g_rccl.CommDestroy(h->comm);
-    h->comm = nullptr;
+  ncclComm_t c = nullptr;
+  {
+    std::lock_guard<std::mutex> g(g_comm_mu);
+    c = g_comm[h->device & 63].comm;
+    g_comm[h->device & 63] = DeviceComm();
+  }
+  if (c && g_rccl.lib) {
+    hipSetDevice(h->device);
+    g_rccl.CommDestroy(c);
   }
   return 0;
 }

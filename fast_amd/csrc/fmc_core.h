@@ -200,15 +200,17 @@ struct u32x4 {
   uint32_t a, b, c, d;
 };
 
-FMC_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+FMC_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c);
+template <int ROUNDS>
+FMC_HD u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)M0 * c0;
     const uint64_t p1 = (uint64_t)M1 * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
     const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
     const uint32_t n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += W0; k1 += W1;
@@ -216,24 +218,51 @@ FMC_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
   u32x4 o; o.a = c0; o.b = c1; o.c = c2; o.d = c3;
   return o;
 }
+FMC_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  return philox4x32<10>(c0, c1, c2, c3, k0, k1);
+}
 
 // ---------------------------------------------------------------- xoshiro128+ (Blackman & Vigna)
 // Short per-(realisation, row, lane) streams: the 128-bit state is one Philox4x32-10 block, then
 // each 32-bit output costs ~9 cheap VALU ops instead of a quarter of a Philox block.  The "+"
 // scrambler's weak low bits are dropped by the u32 -> float32 conversion in Box-Muller.
+FMC_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FMC_NO_BITOP3)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);     // truth table of a ^ b ^ c
+#else
+  return a ^ b ^ c;
+#endif
+}
+
 struct xoshiro128p {
   uint32_t s0, s1, s2, s3;
   FMC_HD void seed(u32x4 x) {
     s0 = x.a; s1 = x.b; s2 = x.c; s3 = x.d;
     if ((s0 | s1 | s2 | s3) == 0u) s0 = 1u;
   }
+  // the five xors of the reference formulation (s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t) as three 3-input xors
+  // of the OLD state words and one 2-input xor: on gfx950 a 3-input xor is one v_bitop3_b32
+  FMC_HD void advance() {
+    const uint32_t t = s1 << 9;
+    const uint32_t n1 = xor3(s1, s2, s0);
+    const uint32_t n0 = xor3(s0, s3, s1);
+    const uint32_t n2 = xor3(s2, s0, t);
+    const uint32_t x3 = s3 ^ s1;
+    s0 = n0; s1 = n1; s2 = n2;
+    s3 = (x3 << 11) | (x3 >> 21);
+  }
   FMC_HD uint32_t next() {
     const uint32_t r = s0 + s3;
-    const uint32_t t = s1 << 9;
-    s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
-    s2 ^= t;
-    s3 = (s3 << 11) | (s3 >> 21);
+    advance();
     return r;
+  }
+  // Two words from ONE state advance: a = s0 + s3 (the "+" scrambler) and b = s1 + s2.  Over the period the state
+  // visits every non-zero 128-bit value once, so (a, b) is jointly equidistributed (each pair has 2^64 preimages);
+  // the streams here are 2 P <= 64 steps long, seeded by independent Philox blocks.
+  FMC_HD void next2(uint32_t& a, uint32_t& b) {
+    a = s0 + s3;
+    b = s1 + s2;
+    advance();
   }
 };
 

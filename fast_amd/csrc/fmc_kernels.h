@@ -20,27 +20,48 @@ namespace fmc {
 #ifndef FMC_PK_BM
 #define FMC_PK_BM 0
 #endif
-// Box-Muller on two 32-bit words:  r = sqrt(-2 ln U), U = (x0 + 0.5) 2^-32;  theta = 2 pi (x1 + 0.5) 2^-32
+// Philox rounds of the block that seeds a coefficient stream.  7 is the smallest count for which Philox4x32 is
+// Crush-resistant (Salmon et al., SC'11, table 2; 10 is its safety-margin default, kept for the log-amplitude and
+// sub-harmonic draws, which use Philox words directly): here the block only seeds a 16- to 64-step xoshiro128+ stream.
+#ifndef FMC_SEED_ROUNDS
+#define FMC_SEED_ROUNDS 7
+#endif
+// Box-Muller on two 32-bit words:  r = sqrt(-2 ln U), U = (x0 + 0.5) 2^-32;  theta = 2 pi (x1 >> 9) 2^-23
 // -> (r cos theta, r sin theta): a standard complex normal.  float32 hardware transcendentals
 // (v_log_f32 = log2, v_sqrt_f32, v_sin_f32 / v_cos_f32 take turns); the oracle restates the
 // same formula in float64 (oracle/devrng.py) and the two agree to ~1e-6 absolute.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// The angle as a float in [1, 2) built from the top 23 bits of the word by ONE v_alignbit (v_sin_f32 / v_cos_f32 take
+// turns and have period 1): theta / 2 pi = 1 + (x1 >> 9) 2^-23.
+__device__ __forceinline__ float angle_turns(uint32_t x1) {
+  return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, x1, 9));     // (0x7F << 23) | (x1 >> 9)
+}
+// K_BM = sqrt(2 ln 2): r = K_BM sqrt(-log2 u).  draw_coloured folds K_BM into the colouring table instead.
+#define FMC_K_BM 1.1774100225154747f
 __device__ __forceinline__ void box_muller(uint32_t x0, uint32_t x1, float& re, float& im) {
 #if FMC_PK_BM       // A/B variant: packed f32 pairs (v_pk_fma_f32, v_pk_mul_f32), same arithmetic; measured +1 % slower (pair packing moves)
-  f32x2 x = {(float)x0, (float)x1};
-  const f32x2 ut = __builtin_elementwise_fma(x, (f32x2){2.3283064365386963e-10f, 2.3283064365386963e-10f},
-                                             (f32x2){1.1641532182693481e-10f, 1.1641532182693481e-10f});
-  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(ut.x));
-  const f32x2 z = (f32x2){__builtin_amdgcn_cosf(ut.y), __builtin_amdgcn_sinf(ut.y)} * (f32x2){r, r};
+  const float u = fmaf((float)x0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+  const float t = angle_turns(x1);
+  const float r = FMC_K_BM * __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));
+  const f32x2 z = (f32x2){__builtin_amdgcn_cosf(t), __builtin_amdgcn_sinf(t)} * (f32x2){r, r};
   re = z.x;
   im = z.y;
 #else
   const float u = fmaf((float)x0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);  // (x0 + .5) 2^-32
-  const float t = fmaf((float)x1, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));  // -2 ln2 log2 u
+  const float t = angle_turns(x1);
+  const float r = FMC_K_BM * __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));            // sqrt(-2 ln u)
   re = r * __builtin_amdgcn_cosf(t);
   im = r * __builtin_amdgcn_sinf(t);
 #endif
+}
+// The same draw scaled by `ampk` = amp * K_BM (the constant of the radius folded into the colouring table):
+// cvt, fma, log, sqrt, alignbit, cos, sin and three multiplies.
+__device__ __forceinline__ void box_muller_scaled(uint32_t x0, uint32_t x1, float ampk, float& re, float& im) {
+  const float u = fmaf((float)x0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+  const float t = angle_turns(x1);
+  const float ra = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u)) * ampk;
+  re = ra * __builtin_amdgcn_cosf(t);
+  im = ra * __builtin_amdgcn_sinf(t);
 }
 
 struct RngKey {
@@ -51,15 +72,43 @@ struct RngKey {
 // seeded with one Philox block; its (2j)-th and (2j+1)-th words make coefficient (ky, L + SL j).
 __device__ __forceinline__ xoshiro128p row_stream(RngKey key, uint64_t g, int ky, int L, int SL) {
   xoshiro128p s;
-  s.seed(philox4x32_10((uint32_t)(ky * SL + L), STREAM_SCREEN, (uint32_t)g, (uint32_t)(g >> 32), key.k0, key.k1));
+#if defined(FMC_ABL_NOPHILOX)   // ablation (timing only): what the per-row Philox seeding costs
+  s.s0 = (uint32_t)(ky * SL + L) * 0x9E3779B9u; s.s1 = (uint32_t)g ^ key.k0; s.s2 = s.s0 ^ key.k1; s.s3 = s.s0 + 0x85EBCA6Bu;
+#else
+  s.seed(philox4x32<FMC_SEED_ROUNDS>((uint32_t)(ky * SL + L), STREAM_SCREEN, (uint32_t)g, (uint32_t)(g >> 32), key.k0, key.k1));
+#endif
   return s;
+}
+#ifndef FMC_RNG_PAIR
+#define FMC_RNG_PAIR 1
+#endif
+__device__ __forceinline__ void draw_words(xoshiro128p& s, uint32_t& a, uint32_t& b) {
+#if FMC_RNG_PAIR   // both Box-Muller words of a coefficient from one state advance (9 instead of 16 integer operations)
+  s.next2(a, b);
+#else
+  a = s.next();
+  b = s.next();
+#endif
 }
 template <class R>
 __device__ __forceinline__ cpx<R> draw_coeff(xoshiro128p& s) {
-  const uint32_t a = s.next();
-  const uint32_t b = s.next();
+  uint32_t a, b;
+  draw_words(s, a, b);
   float re, im;
   box_muller(a, b, re, im);
+  return mk<R>((R)re, (R)im);
+}
+// The coloured coefficient c * amp.  The normals are float32 (hardware Box-Muller), so the colouring multiply is done
+// in float32 too (amp as a float table; one rounding to 24 bits, like the normals themselves) and the product is
+// widened: float32 multiplies instead of 2 v_mul_f64, half the table bytes; the table carries the radius constant
+// sqrt(2 ln 2) of Box-Muller, so a coefficient costs three multiplies.  Host-coefficient (parity) mode multiplies
+// float64 by float64 as the reference does (fast/fast.py:594).
+template <class R>
+__device__ __forceinline__ cpx<R> draw_coloured(xoshiro128p& s, float ampk) {   // ampk = amp * K_BM (k_make_amp)
+  uint32_t a, b;
+  draw_words(s, a, b);
+  float re, im;
+  box_muller_scaled(a, b, ampk, re, im);
   return mk<R>((R)re, (R)im);
 }
 
@@ -74,7 +123,8 @@ __device__ __forceinline__ float draw_logamp_normal(RngKey key, uint64_t iter) {
 template <class R>
 struct RowArgs {
   int N, Np, lo, nb;            // grid size, window size, first window index, realisations in this launch
-  const R* amp;                 // [N][N] sqrt(powerspec)*df  (wave family: with (-1)^(ky+kx) folded in)
+  const R* amp;                 // [N][N] sqrt(powerspec)*df  (wave family: with (-1)^(ky+kx) folded in); host-coefficient mode
+  const float* ampf;            // the same table rounded to float32: colouring of the device generator's float32 normals
   const cpx<R>* tw;             // wave: tw1 [P*64];  direct: w_N^e, e < N
   const cpx<R>* om;             // wave: [8][omS]
   int omS;
@@ -314,7 +364,9 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
   E* s_x = reinterpret_cast<E*>(s_om + 8 * A.omS);
   load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
 
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // the wave index is wave-uniform: in an SGPR, so that row / realisation indices and the table base addresses
+  // derived from it are scalar and the loads use the scalar-base + lane-offset form
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * G::XELEMS;
   const int N = S * G::N;           // full row length
   LaneRegs<R, P, NS> regs;
@@ -351,6 +403,7 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
     const uint64_t g = A.g0 + (uint64_t)b;
 #endif
     const R* amp = A.amp + (size_t)ky * N;
+    const float* ampf = A.ampf + (size_t)ky * N;
     R accr[NS], acci[NS];
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2) { accr[s2] = (R)0; acci[s2] = (R)0; }
@@ -360,18 +413,22 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
     if (MODE == 0) {
 #if defined(FMC_ABL_NOGEN)      // ablation (timing only, wrong results): no generator at all
 #pragma unroll
-      for (int j = 0; j < P; ++j) regs.v[j] = cscale(mk<R>((R)(lane + j), (R)(ky - j)), amp[sp + S * (lane + WAVE * j)]);
+      for (int j = 0; j < P; ++j) regs.v[j] = cscale(mk<R>((R)(lane + j), (R)(ky - j)), (R)ampf[sp + S * (lane + WAVE * j)]);
 #elif defined(FMC_ABL_NOBM)     // ablation: uniform words only, no Box-Muller
       xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
 #pragma unroll
       for (int j = 0; j < P; ++j) {
         const uint32_t a = rs.next(), bb = rs.next();
-        regs.v[j] = cscale(mk<R>((R)(int)a, (R)(int)bb), amp[sp + S * (lane + WAVE * j)]);
+        regs.v[j] = cscale(mk<R>((R)(int)a, (R)(int)bb), (R)ampf[sp + S * (lane + WAVE * j)]);
       }
+#elif defined(FMC_ABL_NOAMP)    // ablation: no spectrum loads (constant colouring)
+      xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
+#pragma unroll
+      for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, 1.0f + (float)j);
 #else
       xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
 #pragma unroll
-      for (int j = 0; j < P; ++j) regs.v[j] = cscale(draw_coeff<R>(rs), amp[sp + S * (lane + WAVE * j)]);
+      for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[sp + S * (lane + WAVE * j)]);
 #endif
     } else {
       const size_t base = ((size_t)b * N + ky) * N;
@@ -438,7 +495,7 @@ void k_cols_wave(ColArgs<R> A) {
   E* s_x = reinterpret_cast<E*>(s_om + 8 * A.omS);
   load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
 
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * G::XELEMS;
   // work item = (realisation b, window column xi), xi fastest: adjacent waves read adjacent columns
   const int item = blockIdx.x * WaveCfg<R, P, NS>::WPB + w;
@@ -530,7 +587,7 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_rows_direct(RowArgs<R> A) {
     const int SL = WAVE * spec_split(N);
     if ((int)threadIdx.x < SL && (int)threadIdx.x < N) {   // one sequential stream per stream index
       xoshiro128p rs = row_stream(A.key, g, ky, threadIdx.x, SL);
-      for (int kx = threadIdx.x; kx < N; kx += SL) s_row[kx] = cscale(draw_coeff<R>(rs), amp[kx]);
+      for (int kx = threadIdx.x; kx < N; kx += SL) s_row[kx] = draw_coloured<R>(rs, A.ampf[(size_t)ky * N + kx]);
     }
   } else {
     const size_t base = ((size_t)b * N + ky) * N;
@@ -651,8 +708,9 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_cols_direct(ColArgs<R> A) {
 // ================================================================== spectrum -> colouring amplitudes
 // amp = sqrt(powerspec) * df (fast/fast.py:594 and the `rand * df` of funcs.py:213); amp_s carries the
 // input-side fftshift sign (-1)^(ky+kx).  bad[0] counts entries that are negative, NaN or infinite.
+// ampf / ampf_s: the same two tables times sqrt(2 ln 2), rounded to float32: colouring of the device generator's draws.
 template <class R>
-__global__ void k_make_amp(const double* ps, double df, int N, R* amp, R* amp_s, unsigned int* bad) {
+__global__ void k_make_amp(const double* ps, double df, int N, R* amp, R* amp_s, float* ampf, float* ampf_s, unsigned int* bad) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)N * N) return;
   const double p = ps[i];
@@ -661,6 +719,9 @@ __global__ void k_make_amp(const double* ps, double df, int N, R* amp, R* amp_s,
   const int ky = (int)(i / N), kx = (int)(i % N);
   amp[i] = (R)v;
   amp_s[i] = (R)(((ky + kx) & 1) ? -v : v);
+  const float vk = (float)(v * 1.1774100225154746910);      // * sqrt(2 ln 2): see box_muller_scaled
+  ampf[i] = vk;
+  ampf_s[i] = ((ky + kx) & 1) ? -vk : vk;
 }
 
 // ================================================================== sub-harmonic coefficients

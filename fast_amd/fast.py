@@ -15,19 +15,44 @@ Differences from the reference, all deliberate:
   * `TEMPORAL` (frozen-flow time series, fast.py:607-637): the layer screens, the bilinear shifts and
     the detector run on the GPU; its draws are always numpy's, in the reference's order (the
     series is sequential and tiny), so the same SEED reproduces the reference;
-  * `FFTW` / `FFTW_THREADS` are accepted and ignored (they select a CPU FFT in the reference).
+  * `FFTW` / `FFTW_THREADS` are accepted; the transform always has the arithmetic of the reference's FFTW branch
+    (funcs.py:212-215), a warning says so once when `FFTW` is False (the reference's default, aotools ift2);
+  * `GPU_DEVICES: [0, 1, ...]`: one process drives several GPUs (fast_amd/multi.py); under a multi-rank launcher
+    (RANK / WORLD_SIZE in the environment) the iterations are sharded over the ranks instead (fast_amd/dist.py).
+    Either way the result vector is identical to a single-GPU run.  No torch anywhere.
 """
 import logging
 
 import numpy
 
-from . import _lib, conf, fitsio, host
+from . import _lib, conf, dist, fitsio, host, multi, rendezvous
 
 logger = logging.getLogger(__name__)
 
 # Host generator of parity mode: module-global like the reference's funcs._R (funcs.py:21),
 # so a second Fast with SEED=None continues the stream.
 _R = numpy.random.default_rng()
+
+
+_BRANCH_WARNED = set()
+
+
+def _warn_transform_branch(fftw):
+    """Say once per process which of the reference's two transform branches is reproduced.  The reference's DEFAULT
+    is `FFTW: False` (fast/conf.py:71) = `aotools.fouriertransform.ift2` (fast/funcs.py:216-218); its `FFTW: True`
+    branch is fftshift -> unnormalised forward DFT -> fftshift (funcs.py:212-215).  The GPU path always has the
+    FFTW-branch arithmetic (the only branch written out in the reference itself): for the same SEED a
+    reference run with `FFTW: False` sees point-mirrored screens of the same statistics, not the same `_r`."""
+    key = bool(fftw)
+    if key in _BRANCH_WARNED:
+        return
+    _BRANCH_WARNED.add(key)
+    if fftw:
+        logger.info("FFTW flag: the FFT runs on the GPU with the arithmetic of the reference's FFTW branch (funcs.py:212-215)")
+    else:
+        logger.warning("FFTW is False: the reference would use aotools' ift2 (funcs.py:216-218); the GPU path computes the "
+                       "FFTW-branch transform (funcs.py:212-215) -- same statistics, but not the same per-iteration values "
+                       "as a reference run with FFTW False and the same SEED (set FFTW True there to compare seeds)")
 
 
 class Fast():
@@ -70,23 +95,33 @@ class Fast():
             raise Exception("GPU_PRECISION must be 'f64' or 'f32'")
         if self.rng_mode not in ('device', 'host'):
             raise Exception("GPU_RNG must be 'device' or 'host'")
-        self.device = _lib.default_device() if p['GPU_DEVICE'] is None else int(p['GPU_DEVICE'])
-        if p['FFTW']:
-            logger.info("FFTW flag ignored: the FFT runs on the GPU")
+        devs = p['GPU_DEVICES']
+        if devs is not None:
+            devs = [int(d) for d in (devs if isinstance(devs, (list, tuple, numpy.ndarray)) else [devs])]
+            if not devs:
+                raise Exception("GPU_DEVICES must name at least one device")
+            if p['GPU_DEVICE'] is not None and int(p['GPU_DEVICE']) != devs[0]:
+                raise Exception("GPU_DEVICE and GPU_DEVICES disagree: give one of them")
+        self.device = (_lib.default_device() if p['GPU_DEVICE'] is None else int(p['GPU_DEVICE'])) if devs is None else devs[0]
+        self.devices = [self.device] if devs is None else devs
+        _warn_transform_branch(p['FFTW'])
 
         self.compute_powerspec()
-        self._handle = _lib.Handle(self.Npxls, self.Npxls_pup, self.precision, self.device)
+        # one handle per device, one thread each (fast_amd/multi.py); the first handle also serves everything that is
+        # not sharded (statistics, histogram of the assembled vector, TEMPORAL and host-generator modes)
+        self._group = multi.DeviceGroup(self.Npxls, self.Npxls_pup, self.precision, self.devices)
+        self._handle = self._group.handles[0]
         if p['GPU_BATCH']:
-            self._handle.set_batch(p['GPU_BATCH'])
+            self._group.set_batch(p['GPU_BATCH'])
         if self._handle.kernel_path() == 0 and self.Npxls >= 128 and not self.temporal:
             below = [n for n in host.WAVE_FFT_SIZES if n <= self.Npxls][-1:]
             above = [n for n in host.ROUND_UP_SIZES if n >= self.Npxls][:1]
             logger.warning(f"NPXLS = {self.Npxls} runs on the direct O(N^2 Np) kernels (about 10x slower than the "
                            f"FFT kernels); nearest fast grid sizes: {', '.join(str(n) for n in below + above)}")
-        self._handle.set_spectrum(self.powerspec, prob.df)
-        self._handle.set_pupil(prob.W, pup.crop_lo, self.dx)
+        self._group.set_spectrum(self.powerspec, prob.df)
+        self._group.set_pupil(prob.W, pup.crop_lo, self.dx)
         if self.subharmonics:
-            self._handle.set_subharm(self.powerspec_subharm, self._sh_fx, self._sh_fy, self._sh_df)
+            self._group.set_subharm(self.powerspec_subharm, self._sh_fx, self._sh_fy, self._sh_df)
 
     # ------------------------------------------------------------------ init pieces
     def init_logging(self):
@@ -145,18 +180,15 @@ class Fast():
             tr = self._transport()
             if tr is not None and self.seed is None:
                 # every rank must draw from the same generator: rank 0's entropy seed wins
-                import torch.distributed as tdist
-                box = [seed]
-                tdist.broadcast_object_list(box, src=0)
-                seed = int(box[0])
+                seed = int.from_bytes(tr.rdzv.broadcast(int(seed).to_bytes(8, "little"), src=0), "little")
             self._device_seed = seed
             if tr is None:
-                out = self._handle.run(seed, 0, n_real, None, float(self.logamp_var), coherent)
+                # this process's devices (one or several): contiguous pieces, one thread per device
+                out = self._group.run(seed, 0, n_real, None, float(self.logamp_var), coherent)
             else:
                 # one process per GPU: this rank's contiguous realisation range, then one exchange
-                from . import dist as fdist
-                out = fdist.run_sharded(n_real, lambda real0, n_loc: self._handle.run(
-                    seed, real0, n_loc, None, float(self.logamp_var), coherent), tr)
+                out = dist.run_sharded(n_real, lambda real0, n_loc: self._handle.run(
+                    seed, real0, n_loc, None, float(self.logamp_var), coherent), tr, self._handle)
             re, im = out[:n_real].reshape(self.Nchunks, half), out[n_real:].reshape(self.Nchunks, half)
             I[:, :half], I[:, half:] = re, im
             # the log-amplitudes the device drew, in iteration order (global iteration 2g+s)
@@ -168,7 +200,7 @@ class Fast():
         self.random_iters = I[-1]
         self.timing = self._handle.last_timing()
         self.result = FastResult(I.flatten(), self.diffraction_limit)
-        if self.temporal or self.rng_mode == 'host' or getattr(self, '_tr', None) is not None:
+        if self.temporal or self.rng_mode == 'host' or getattr(self, '_tr', None) is not None or self._group.world > 1:
             # a run made of several library calls: hand the assembled vector back so that histogram(),
             # result_stats() and the fast_amd.comms reductions see all of it, not the last chunk / shard
             self._handle.set_results(self.result._r)
@@ -220,24 +252,21 @@ class Fast():
             interp = interp + self.pixel_shifts[:, :, -1, numpy.newaxis, numpy.newaxis]
 
     def _transport(self):
-        """The result exchange of a multi-process run, or None.  GPU_SHARD: 'auto' (default) shards
-        when a torch.distributed process group with more than one rank exists."""
-        import sys
+        """The result exchange of a one-process-per-GPU run, or None.  GPU_SHARD: 'auto' (default) shards when a
+        launcher started this process as one of several ranks (WORLD_SIZE > 1 with RANK / MASTER_ADDR / MASTER_PORT in
+        the environment); True requires that; False never shards (every rank runs its own simulation, as the sweeps do)."""
         mode = self.params.get('GPU_SHARD', 'auto')
         if mode is False:
             return None
-        tdist = getattr(sys.modules.get('torch'), 'distributed', None) if 'torch' in sys.modules else None
-        if tdist is None or not tdist.is_available() or not tdist.is_initialized() or tdist.get_world_size() < 2:
-            if mode is True:
-                raise Exception("GPU_SHARD=True needs an initialised torch.distributed process group")
-            return None
         if getattr(self, '_tr', None) is None:
-            from . import dist as fdist
-            try:
-                self._tr = fdist.RcclTransport(self._handle)
-            except _lib.FastMCError as e:
-                logger.warning(f"RCCL exchange unavailable ({e}); using torch.distributed collectives")
-                self._tr = fdist.TorchTransport()
+            rdzv = rendezvous.from_env()
+            if rdzv is None:
+                if mode is True:
+                    raise Exception("GPU_SHARD=True needs a multi-rank launch (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)")
+                return None
+            if self._group.world > 1:
+                raise Exception("GPU_DEVICES with several devices inside a multi-rank launch: use one device per rank")
+            self._tr = dist.make_transport(self._handle, rdzv)
         return self._tr
 
     def histogram(self, lo_db=-60.0, hi_db=10.0, nbins=4096):

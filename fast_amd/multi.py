@@ -1,0 +1,159 @@
+"""One process drives N GPUs: N handles, one thread each (`GPU_DEVICES: [0, 1, ...]` on `Fast`, `bench.py --gpus N`).
+
+SURVEY 8(e): iterations are independent (fast/fast.py:130-134, 589-605), the spectrum and pupil weights are small
+(8-32 MB) and replicated by one host copy per device, and the only exchange is at the end of a run.  Every handle owns
+a HIP stream and ctypes releases the GIL during library calls, so N Python threads keep N devices busy; the exchange is
+RCCL over xGMI when `ncclCommInitAll` gives this process a communicator clique (fastmc_comm_init_all: grouped
+ncclAllGather of the powers, ncclAllReduce of the dB histogram on the device buffers, issued from one thread), else the
+host concatenation of the vectors `fastmc_run` already returned.  Which one ran is reported in `exchange`.
+
+Nothing here imports torch or needs a launcher.  The reference is single-threaded; no counterpart.
+"""
+import logging
+import os
+import threading
+
+import numpy as np
+
+from . import _lib, dist
+
+logger = logging.getLogger(__name__)
+
+
+def run_threads(fns):
+    """Run the callables concurrently, one thread each; return their results in order; re-raise the first error."""
+    res = [None] * len(fns)
+    err = [None] * len(fns)
+
+    def work(i):
+        try:
+            res[i] = fns[i]()
+        except BaseException as e:       # re-raised in the caller's thread
+            err[i] = e
+    if len(fns) == 1:
+        work(0)
+    else:
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(fns))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return res
+
+
+class DeviceGroup:
+    """N handles of one (N_grid, Np, precision) problem on N devices.
+
+    handles[i] lives on devices[i]; `run` cuts the realisation range into contiguous pieces (sizes differing by at most
+    one), runs them concurrently and returns the vector an unsharded `Handle.run` would return, bit for bit.
+    `exchange`: 'rccl' or 'host (reason)'.  `factory(device) -> handle-like` lets the CPU tests stand in for the GPU."""
+
+    def __init__(self, N, Np, precision="f64", devices=(0,), exchange="auto", rccl_timeout=None, factory=None):
+        self.devices = [int(d) for d in devices]
+        if not self.devices:
+            raise Exception("GPU_DEVICES must name at least one device")
+        make = factory or (lambda d: _lib.Handle(N, Np, precision, d))
+        self.handles = run_threads([(lambda d=d: make(d)) for d in self.devices])
+        self.world = len(self.handles)
+        self.exchange = "none" if self.world == 1 else "host"
+        self._rccl = False
+        if self.world > 1 and exchange in ("auto", "rccl") and factory is None:
+            self._try_rccl(rccl_timeout)
+            if exchange == "rccl" and not self._rccl:
+                raise _lib.FastMCError(f"RCCL exchange requested but unavailable: {self.exchange}")
+
+    def _try_rccl(self, timeout):
+        timeout = float(os.environ.get("FASTMC_RCCL_TIMEOUT", "90")) if timeout is None else timeout
+        if len(set(self.devices)) < self.world:
+            self.exchange = "host (several handles share a device: RCCL needs one device per rank)"
+            return
+        # the communicators belong to the devices and outlive the handles: a clique left by an earlier group of the
+        # same devices in the same order is reused
+        try:
+            if all(h.comm_world() == (self.world, i) for i, h in enumerate(self.handles)):
+                self._rccl, self.exchange = True, "rccl"
+                return
+        except Exception:
+            pass
+        box = {}
+
+        def _init():
+            try:
+                _lib.comm_init_all(self.handles)
+                box["ok"] = True
+            except Exception as e:
+                box["err"] = str(e)
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(timeout)
+        if box.get("ok"):
+            self._rccl, self.exchange = True, "rccl"
+        else:
+            self.exchange = f"host ({box.get('err', 'ncclCommInitAll did not return in time')})"
+            logger.warning(f"RCCL exchange unavailable ({self.exchange}); results are concatenated on the host")
+
+    # ---- broadcast of the problem (one host copy per device)
+    def each(self, fn):
+        return run_threads([(lambda h=h, i=i: fn(h, i)) for i, h in enumerate(self.handles)])
+
+    def set_spectrum(self, powerspec, df):
+        self.each(lambda h, i: h.set_spectrum(powerspec, df))
+
+    def set_pupil(self, W, crop_lo, dx):
+        self.each(lambda h, i: h.set_pupil(W, crop_lo, dx))
+
+    def set_subharm(self, *a):
+        self.each(lambda h, i: h.set_subharm(*a))
+
+    def set_batch(self, batch):
+        self.each(lambda h, i: h.set_batch(batch))
+
+    # ---- the sharded run
+    def run(self, seed, real0, n_real, logamp=None, logamp_var=0.0, coherent=False, hist_range=None):
+        """Realisations [real0, real0 + n_real) over the devices; returns the full vector in `Handle.run`'s order
+        ([Re-screen results | Im-screen results]).  With hist_range = (lo_db, hi_db, nbins) also leaves the global dB
+        histogram in `self.last_hist` (device all-reduce when RCCL is up)."""
+        ranges = dist.shard_ranges(n_real, self.world)
+        la = None if logamp is None else np.ascontiguousarray(logamp, dtype=np.float64)
+
+        def piece(h, i):
+            r0, n = ranges[i]
+            if n == 0:
+                return np.empty(0, dtype=np.complex128 if coherent else np.float64)
+            lai = None
+            if la is not None:        # [Re block | Im block] of the whole range -> this shard's two blocks
+                lai = np.concatenate([la[r0:r0 + n], la[n_real + r0:n_real + r0 + n]])
+            return h.run(seed, real0 + r0, n, lai, logamp_var, coherent)
+        parts = self.each(piece)
+        self.last_hist = None
+        equal = len({n for _, n in ranges}) == 1 and ranges[0][1] > 0
+        if self._rccl and equal:
+            nval = 2 * ranges[0][1] * (2 if coherent else 1)
+            allp, hist = _lib.comm_gather_all(self.handles, nval, hist_range)
+            allp = allp.reshape(self.world, nval)
+            parts = [allp[r].view(np.complex128) if coherent else allp[r] for r in range(self.world)]
+            self.last_hist = hist
+            self.last_exchange = "rccl"
+        else:
+            self.last_exchange = "host" if self.world > 1 else "none"
+            if hist_range is not None:
+                hs = self.each(lambda h, i: h.histogram(*hist_range) if ranges[i][1] else 0)
+                self.last_hist = np.sum([x for x in hs if not np.isscalar(x)], axis=0)
+        return dist.assemble(parts, complex_out=coherent)
+
+    def last_timing(self):
+        return [h.last_timing() for h in self.handles]
+
+    def close(self, destroy_comm=False):
+        if self._rccl and destroy_comm:
+            for h in self.handles:
+                try:
+                    h.comm_destroy()
+                except Exception:
+                    pass
+        self._rccl = False
+        for h in self.handles:
+            h.close()

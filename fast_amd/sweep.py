@@ -6,11 +6,11 @@ corrected.  Per sample the reference rebuilds everything (`fast.Fast(params)`,
 complete_orbit_simulation.py:227) and its init is dominated by `compute_powerspec` (12-15 s at
 1024^2).  Here the power spectrum is one GPU kernel (< 1 ms), the pupil /
 fibre-mode products are cached across samples that share the aperture (host.pupils cache), and
-samples are dealt round-robin to the ranks of a torch.distributed group (one process per
-GPU); only the per-sample summary statistics are gathered.
+samples are dealt round-robin to the ranks of a multi-process launch (one process per GPU) or to
+the devices of one process (`zenith_scan_devices`: one thread per device); only the per-sample
+summary statistics are gathered.
 """
 import copy
-import sys
 import time
 
 
@@ -46,10 +46,11 @@ def zenith_scan(base_params, zenith_angles, niter=4096, nchunks=1, keep_power=Fa
 
 
 def gather_records(records):
-    """All ranks' records on every rank (torch.distributed object gather when a group exists)."""
-    tdist = getattr(sys.modules.get("torch"), "distributed", None) if "torch" in sys.modules else None
-    if tdist is None or not tdist.is_initialized() or tdist.get_world_size() < 2:
+    """All ranks' records on every rank (through the rendezvous of a multi-rank launch, fast_amd/rendezvous.py)."""
+    import pickle
+    from . import rendezvous
+    rdzv = rendezvous.from_env()
+    if rdzv is None:
         return sorted(records, key=lambda r: r["index"])
-    bucket = [None] * tdist.get_world_size()
-    tdist.all_gather_object(bucket, records)
-    return sorted([r for part in bucket for r in part], key=lambda r: r["index"])
+    parts = rdzv.exchange(pickle.dumps(records))
+    return sorted([r for part in parts for r in pickle.loads(part)], key=lambda r: r["index"])

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FASTMC_VERSION 100
+#define FASTMC_VERSION 200
 
 #define FASTMC_OK 0
 #define FASTMC_EINVAL (-1)   /* bad argument */
@@ -216,15 +216,34 @@ int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double* powerspec
 int fastmc_powerspec_terms(int device_id, const fastmc_ps_params* p, double* turb, double* g_ao,
                            double* alias, double* noise);
 
-/* ---- multi-GPU result exchange: one process per GPU, RCCL over xGMI ---- */
-/* 128-byte RCCL unique id, created on rank 0 and distributed by the launcher. */
+/* ---- multi-GPU result exchange: RCCL over xGMI ----
+ * Iterations are independent (fast/fast.py:130-134 loops over chunks, 589-605 draws each chunk afresh), so the
+ * realisation range is cut into one contiguous piece per GPU and the only exchange is at the end of a run:
+ * an all-gather of the per-iteration powers (8 B each) and an all-reduce of the dB histogram.  The reference has no
+ * counterpart (single process, single thread).
+ * A communicator belongs to a DEVICE of this process and serves every handle on that device (sweeps build many
+ * short-lived handles); collectives on one device's communicator must be serialised by the caller.
+ *   one process drives n devices:  fastmc_comm_init_all(handles, n) (ncclCommInitAll), then fastmc_comm_gather_all;
+ *   one process per GPU:           rank 0 calls fastmc_comm_unique_id, the launcher distributes the 128 bytes, every
+ *                                  rank calls fastmc_comm_init (ncclCommInitRank), then fastmc_comm_gather.
+ * FASTMC_DISABLE_RCCL=1 in the environment makes the init calls fail with FASTMC_ECOMM (callers then exchange
+ * through the host: fast_amd/dist.py, fast_amd/multi.py). */
 int fastmc_comm_unique_id(uint8_t id128[128]);
 int fastmc_comm_init(fastmc_t* h, const uint8_t id128[128], int world_size, int rank);
-/* All-gather of each rank's last-run powers (equal count per rank) and all-reduce (sum)
- * of its histogram, on the device buffers, then copied to the host arrays. */
+/* handles[i] becomes rank i of an n-rank communicator clique; one handle per device, distinct devices. */
+int fastmc_comm_init_all(fastmc_t* const* handles, int n);
+/* world size and rank of the communicator of h's device (0 and -1 when there is none). */
+int fastmc_comm_world(fastmc_t* h, int* world_size, int* rank);
+/* All-gather of each rank's last-run results (n_local float64 values per rank, equal on all ranks) and all-reduce
+ * (sum) of its histogram, on the device buffers, then copied to the host arrays (either may be NULL). */
 int fastmc_comm_gather(fastmc_t* h, int64_t n_local, double* all_powers /* world*n_local */,
                        int64_t* hist /* nbins+2, in: unused, out: global */, double lo_db,
                        double hi_db, int nbins);
+/* The same exchange for the n handles of fastmc_comm_init_all (same handles, same order), issued from one thread
+ * as one RCCL group per collective; the host arrays are filled from rank 0's copy. */
+int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n_local, double* all_powers, int64_t* hist,
+                           double lo_db, double hi_db, int nbins);
+/* Destroys the communicator of h's device (no-op when there is none). */
 int fastmc_comm_destroy(fastmc_t* h);
 
 #ifdef __cplusplus

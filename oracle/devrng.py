@@ -6,12 +6,13 @@ generator has no counterpart in the reference (which uses numpy's PCG64 stream,
 fast/funcs.py:21,352-356); this module restates OUR definition in numpy/float64 so that the
 device path can be checked deterministically, not only statistically:
 
-  stream (g, ky, l = kx mod 64): xoshiro128+ seeded with Philox4x32-10(ctr=(ky*64+l, STREAM, g_lo, g_hi), key=seed)
-  coefficient (ky, l + 64 j) = BM(word 2j, word 2j+1) of that stream
-  BM(a, b) = sqrt(-2 ln((a+.5)/2^32)) * exp(2 pi i (b+.5)/2^32)
+  stream (g, ky, l = kx mod 64): xoshiro128+ seeded with Philox4x32-7(ctr=(ky*64+l, STREAM, g_lo, g_hi), key=seed)
+  coefficient (ky, l + 64 j) = BM(a_j, b_j), (a_j, b_j) = (s0 + s3, s1 + s2) of the state after j advances
+  (two words per state advance; jointly equidistributed over the period)
+  BM(a, b) = sqrt(-2 ln((a+.5)/2^32)) * exp(2 pi i (b >> 9)/2^23)
   (log-amplitude and sub-harmonic draws use Philox blocks directly)
 
-Philox4x32-10 is the published Random123 algorithm (Salmon et al., SC'11); `test_oracle_devrng`
+Philox4x32-10 is the published Random123 algorithm (Salmon et al., SC'11); `tests/test_oracle_devrng.py`
 pins this implementation to Random123's known-answer vectors.
 The device evaluates BM in float32 with hardware log2/sqrt/sin/cos; agreement is ~1e-6 absolute.
 """
@@ -23,12 +24,16 @@ MASK = np.uint64(0xFFFFFFFF)
 STREAM_SCREEN, STREAM_LOGAMP, STREAM_SUBHARM = 0, 1, 2
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Vectorised over the counter words (uint32 arrays or scalars); key words are ints."""
+SEED_ROUNDS = 7   # fmc_kernels.h: FMC_SEED_ROUNDS -- Philox rounds of the block that seeds a coefficient stream
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1, rounds=10):
+    """Philox4x32 with `rounds` rounds (10: the Random123 default the known-answer tests pin; the stream seeds use
+    SEED_ROUNDS).  Vectorised over the counter words (uint32 arrays or scalars); key words are ints."""
     c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & MASK for c in (c0, c1, c2, c3))
     c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
     k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = M0 * c0
         p1 = M1 * c2
         n0 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)
@@ -43,7 +48,7 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 def box_muller(a, b):
     u = (a.astype(np.float64) + 0.5) / 2.0 ** 32
-    t = (b.astype(np.float64) + 0.5) / 2.0 ** 32
+    t = (np.asarray(b).astype(np.uint64) >> np.uint64(9)).astype(np.float64) / 2.0 ** 23   # top 23 bits (fmc_kernels.h: angle_turns)
     r = np.sqrt(-2.0 * np.log(u))
     return r * np.cos(2 * np.pi * t) + 1j * r * np.sin(2 * np.pi * t)
 
@@ -62,6 +67,14 @@ def xoshiro128p_next(s):
     return r
 
 
+def xoshiro128p_next2(s):
+    """Two words from ONE state advance (fmc_core.h: xoshiro128p::next2): a = s0 + s3, b = s1 + s2."""
+    a = (s[0] + s[3]).astype(np.uint32)
+    b = (s[1] + s[2]).astype(np.uint32)
+    xoshiro128p_next(s)
+    return a, b
+
+
 def spec_split(N):
     """fmc_core.h: spec_split -- sub-rows per row of the wave kernels, which fixes the stream layout."""
     return 4 if N == 4096 else (2 if N == 2048 else 1)
@@ -70,22 +83,23 @@ def spec_split(N):
 def device_coefficients(seed, g, N):
     """(N, N) complex coefficients of realisation g (== fastmc_rng_coeffs).
 
-    SL = 64 * spec_split(N) streams per row.  Stream (g, ky, L = kx mod SL): state = Philox4x32-10(ctr =
+    SL = 64 * spec_split(N) streams per row.  Stream (g, ky, L = kx mod SL): state = Philox4x32-7(ctr =
     (ky*SL + L, STREAM_SCREEN, g_lo, g_hi), key = seed) (s0 := 1 if the block is all zero); coefficient
-    (ky, L + SL j) = BM(word 2j, word 2j+1) of xoshiro128+ (fmc_core.h: xoshiro128p, fmc_kernels.h:
-    row_stream / draw_coeff)."""
+    (ky, L + SL j) = BM(s0 + s3, s1 + s2) of the xoshiro128+ state after j advances (fmc_core.h: xoshiro128p::next2,
+    fmc_kernels.h: row_stream / draw_words).  The device colours these float32 normals with sqrt(powerspec) * df
+    rounded to float32 (fmc_kernels.h: draw_coloured); the restatement keeps float64 throughout (difference ~6e-8
+    relative per coefficient, inside the 2e-3 bar of the device-generator tests)."""
     SL = 64 * spec_split(N)
     lanes = min(SL, N)
     ky, l = np.meshgrid(np.arange(N), np.arange(lanes), indexing="ij")
-    x = philox4x32_10(ky * SL + l, STREAM_SCREEN, g & 0xFFFFFFFF, g >> 32, seed & 0xFFFFFFFF, seed >> 32)
+    x = philox4x32_10(ky * SL + l, STREAM_SCREEN, g & 0xFFFFFFFF, g >> 32, seed & 0xFFFFFFFF, seed >> 32, rounds=SEED_ROUNDS)
     s = [np.array(w, dtype=np.uint64).astype(np.uint32) for w in x]
     zero = (s[0] | s[1] | s[2] | s[3]) == 0
     s[0][zero] = 1
     out = np.empty((N, N), dtype=complex)
     with np.errstate(over="ignore"):
         for j in range((N + SL - 1) // SL):
-            a = xoshiro128p_next(s)
-            b = xoshiro128p_next(s)
+            a, b = xoshiro128p_next2(s)
             c = box_muller(a, b)
             w = min(SL, N - SL * j)
             out[:, SL * j:SL * j + w] = c[:, :w]

@@ -1,4 +1,5 @@
-"""Worker of tests/test_dist_gloo.py: run under torch.distributed.run with backend gloo (CPU).
+"""Worker of tests/test_dist_gloo.py: run under torch.distributed.run with backend gloo (CPU), the exchange through
+examples/torch_transport.py (fast_amd itself is torch-free; tests/test_dist_rdzv.py covers its own rendezvous).
 compute_local is the ORACLE fed with the restated device generator, i.e. exactly what each GPU
 rank computes; the sharded result must equal the single-process one bit for bit."""
 import os
@@ -9,7 +10,9 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "examples"))
 from fast_amd import dist as fd   # noqa: E402
+from torch_transport import TorchTransport   # noqa: E402
 from oracle import fastref as R, devrng   # noqa: E402
 
 N, Np, SEED, NREAL = 16, 6, 77, 8
@@ -32,7 +35,7 @@ def compute(real0, n, coherent=False):
 
 def main():
     dist.init_process_group("gloo")
-    tr = fd.TorchTransport()
+    tr = TorchTransport()
     full = fd.run_sharded(NREAL, compute, tr)
     single = compute(0, NREAL)
     assert np.array_equal(full, single), (full, single)

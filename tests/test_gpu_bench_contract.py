@@ -1,4 +1,5 @@
-"""GPU: bench.py prints ONE JSON line with the fields of the driver's contract."""
+"""GPU: bench.py prints ONE JSON line with the fields of the driver's contract, and every fraction in it is a
+utilisation (<= 1) computed from this run and from the instruction counts of the code object that ran."""
 import json
 import os
 import subprocess
@@ -12,8 +13,9 @@ pytestmark = pytest.mark.gpu
 
 
 def test_bench_json_line_contract():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                          "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600)
+                          "--no-cpu-baseline", "--no-extras", "--no-sustained"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -23,8 +25,20 @@ def test_bench_json_line_contract():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"]
+    assert "workload" in d["config"] and "model" not in d["config"] and "float32" in d["config"]["arithmetic"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and (r["traffic"] is None or r["traffic"] > 0)
+    # the kernel is bound by vector-instruction issue: the fraction is executed float64 FLOP/s over the vector peak
+    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac"] <= 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    iss = r["issue"]
+    assert 0.3 < iss["frac"] <= 1.0 and iss["valu_instructions_per_row"] > 500
+    assert abs(iss["frac"] - iss["valu_issue_cycles_per_row"] / iss["measured_cycles_per_row_at_2.4GHz"]) < 1e-12
+    hbm = r["hbm"]
+    assert 0 < hbm["rows"]["frac_pruned"] <= 1.0 and 0 < hbm["cols"]["frac_pruned"] <= 1.0
+    assert hbm["rows"]["algorithmic_GBps"] > hbm["rows"]["pruned_algorithmic_GBps"]
+    for k in ("counter_GBps",):
+        if k in hbm["rows"]:
+            assert hbm["rows"]["frac_counter"] <= 1.0
     assert d["value"] > 1e5 and abs(d["value"] - 10000 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-3 * d["value"]
+    assert d["pipeline"]["powerspec_kernel_ms_warm"] < 2.0        # not the first-launch artefact

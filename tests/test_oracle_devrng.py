@@ -1,0 +1,113 @@
+"""CPU: the oracle's restatement of OUR device generator (oracle/devrng.py).
+
+The generator has no counterpart in the reference (numpy PCG64, fast/funcs.py:21,352-356), so it is pinned to the
+published algorithms it is built from and to its own statistical quality:
+  * Philox4x32 at 7 and 10 rounds against Random123's known-answer vectors (kat_vectors of the Random123
+    distribution, Salmon et al. SC'11);
+  * xoshiro128+ against a scalar transcription of Blackman & Vigna's reference code;
+  * the two-words-per-state-advance output (s0 + s3, s1 + s2) and the 23-bit angle: moments, tails, uniformity and
+    independence of the resulting normals on 2 x 512^2 draws (the GPU suite repeats this on the device's own draws).
+"""
+import numpy as np
+import pytest
+
+from oracle import devrng
+
+KAT = [  # rounds, counter, key -> output (Random123 kat_vectors: "philox4x32 R c0 c1 c2 c3 k0 k1  o0 o1 o2 o3")
+    (7, (0, 0, 0, 0), (0, 0), (0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48)),
+    (7, (0xffffffff,) * 4, (0xffffffff,) * 2, (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662)),
+    (7, (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a)),
+    (10, (0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    (10, (0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    (10, (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+@pytest.mark.parametrize("rounds,ctr,key,want", KAT)
+def test_philox_known_answers(rounds, ctr, key, want):
+    got = devrng.philox4x32_10(*ctr, *key, rounds=rounds)
+    assert tuple(int(x) for x in got) == want
+
+
+def _xoshiro_scalar(s, n):
+    """Blackman & Vigna, xoshiro128plus.c: result = s[0] + s[3]; t = s[1] << 9; s[2] ^= s[0]; s[3] ^= s[1];
+    s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 11)."""
+    M = 0xFFFFFFFF
+    s = list(s)
+    out = []
+    for _ in range(n):
+        out.append(((s[0] + s[3]) & M, (s[1] + s[2]) & M))
+        t = (s[1] << 9) & M
+        s[2] ^= s[0]
+        s[3] ^= s[1]
+        s[1] ^= s[2]
+        s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = ((s[3] << 11) | (s[3] >> 21)) & M
+    return out
+
+
+def test_xoshiro_pair_output_follows_the_reference_engine():
+    seed = (0x12345678, 0x9abcdef0, 0x0fedcba9, 0x87654321)
+    s = [np.array([w], dtype=np.uint32) for w in seed]
+    want = _xoshiro_scalar(seed, 40)
+    with np.errstate(over="ignore"):
+        for a_w, b_w in want:
+            a, b = devrng.xoshiro128p_next2(s)
+            assert (int(a[0]), int(b[0])) == (a_w, b_w)
+        # the single-word form is the engine's own output
+        s2 = [np.array([w], dtype=np.uint32) for w in seed]
+        assert [int(devrng.xoshiro128p_next(s2)[0]) for _ in range(5)] == [a for a, _ in want[:5]]
+
+
+def test_box_muller_definition():
+    a = np.array([0, 1, 2 ** 31, 2 ** 32 - 1], dtype=np.uint32)
+    b = np.array([0, 2 ** 9, 2 ** 31, 2 ** 32 - 1], dtype=np.uint32)
+    c = devrng.box_muller(a, b)
+    u = (a.astype(float) + 0.5) / 2 ** 32
+    t = (b.astype(np.uint64) >> np.uint64(9)).astype(float) / 2 ** 23
+    np.testing.assert_allclose(c, np.sqrt(-2 * np.log(u)) * np.exp(2j * np.pi * t), rtol=1e-14, atol=1e-14)
+    assert abs(c[0]) == pytest.approx(np.sqrt(-2 * np.log(0.5 / 2 ** 32)))      # 6.66 sigma: the largest radius
+
+
+def test_generator_statistics():
+    from scipy import stats
+    N = 512
+    c = np.stack([devrng.device_coefficients(2024, g, N) for g in range(2)])
+    z = np.concatenate([c.real.ravel(), c.imag.ravel()])
+    n = z.size
+    assert abs(z.mean()) < 5 / np.sqrt(n)
+    assert abs(z.var() - 1) < 5 * np.sqrt(2 / n)
+    assert abs(stats.skew(z)) < 5 * np.sqrt(6 / n)
+    assert abs(stats.kurtosis(z)) < 5 * np.sqrt(24 / n)
+    for k in (3.0, 4.0):
+        expect = n * 2 * stats.norm.sf(k)
+        assert abs(np.count_nonzero(np.abs(z) > k) - expect) < 6 * np.sqrt(expect) + 3
+    # the two words of one state advance: radius and angle of the SAME coefficient, and of neighbouring steps
+    u = np.exp(-np.abs(c) ** 2 / 2)
+    t = (np.angle(c) + np.pi) / (2 * np.pi)
+    assert stats.kstest(u.ravel()[::5], "uniform").pvalue > 1e-3
+    assert stats.kstest(t.ravel()[::5], "uniform").pvalue > 1e-3
+
+    def chi2_z(a, b, bins=32):
+        H, _, _ = np.histogram2d(a.ravel(), b.ravel(), bins=bins, range=[[0, 1], [0, 1]])
+        e = a.size / bins ** 2
+        dof = bins ** 2 - 1
+        return (((H - e) ** 2 / e).sum() - dof) / np.sqrt(2 * dof)
+    S = 64                                           # stream step: coefficient j -> j + 1 of one stream is kx -> kx + 64
+    for a, b in ((u, t), (u[:, :, :-S], u[:, :, S:]), (t[:, :, :-S], t[:, :, S:]), (u[:, :, :-S], t[:, :, S:]),
+                 (t[:, :, :-S], u[:, :, S:]), (u[:, :, :-1], u[:, :, 1:]), (u[:, :-1], u[:, 1:])):
+        assert abs(chi2_z(a, b)) < 5
+
+    def corr(a, b):
+        return abs(np.mean(a * b)) * np.sqrt(a.size)
+    re, im = c.real, c.imag
+    assert corr(re[:, :, :-1], re[:, :, 1:]) < 5 and corr(re[:, :, :-S], re[:, :, S:]) < 5
+    assert corr(re[:, :-1], re[:, 1:]) < 5 and corr(re[0], re[1]) < 5 and corr(re, im) < 5
+
+
+def test_split_layouts_cover_the_grid():
+    """2048 / 4096 draw 128 / 256 streams per row (fmc_core.h: spec_split); every coefficient is drawn once."""
+    for N in (2048,):
+        c = devrng.device_coefficients(5, 0, N)
+        assert np.isfinite(c).all() and len(np.unique(c[:4].ravel())) == 4 * N

@@ -34,7 +34,7 @@ for f in find("trace", "*kernel_trace.csv")[:1]:
         print(f"| {k} | {r.get('Grid_Size_X','?')} | {r.get('Workgroup_Size_X','?')} | {r.get('VGPR_Count','?')} | "
               f"{r.get('Accum_VGPR_Count','?')} | {r.get('SGPR_Count','?')} | {r.get('LDS_Block_Size','?')} | {r.get('Scratch_Size','?')} |")
     print()
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_sq4"):
     files = find(sub, "*counter_collection.csv")
     if not files:
         continue

@@ -19,7 +19,7 @@ EXPORTS = [
     "fastmc_screens_coeffs", "fastmc_screens", "fastmc_rng_coeffs", "fastmc_rng_logamp", "fastmc_histogram",
     "fastmc_result_stats", "fastmc_last_timing", "fastmc_kernel_path", "fastmc_set_batch", "fastmc_powerspec",
     "fastmc_set_layer_screens", "fastmc_temporal_chunk", "fastmc_link_metrics", "fastmc_set_results",
-    "fastmc_powerspec_terms",
+    "fastmc_powerspec_terms", "fastmc_powerspec_set", "fastmc_powerspec_get",
     "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_init_all", "fastmc_comm_world", "fastmc_comm_gather",
     "fastmc_comm_gather_all", "fastmc_comm_destroy",
 ]
@@ -44,6 +44,7 @@ class PsParams(C.Structure):
         ("dtheta", C.c_double * 2), ("cn2", C.c_void_p), ("h", C.c_void_p), ("wind", C.c_void_p),
         ("mask_mode", C.c_int32), ("zmax", C.c_int32), ("modal_mult", C.c_double), ("D_ground", C.c_double),
         ("lf_mask", C.c_void_p), ("pupil_filter", C.c_void_p), ("lgs_z", C.c_void_p), ("simpson_w", C.c_void_p),
+        ("pupil_filter_token", C.c_int64),
     ]
 
 
@@ -86,6 +87,8 @@ def lib():
     L.fastmc_set_batch.argtypes = [vp, C.c_int]
     L.fastmc_powerspec.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp, dp, dp]
     L.fastmc_powerspec_terms.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp]
+    L.fastmc_powerspec_set.argtypes = [vp, C.POINTER(PsParams), C.c_double, dp, dp]
+    L.fastmc_powerspec_get.argtypes = [vp, C.c_int, dp]
     L.fastmc_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     L.fastmc_comm_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
     L.fastmc_comm_gather.argtypes = [vp, i64, dp, C.POINTER(i64), C.c_double, C.c_double, C.c_int]
@@ -260,6 +263,12 @@ class Handle:
         return {"total_ms": t[0], "rows_ms": t[1], "cols_ms": t[2], "finalize_ms": t[3],
                 "rows_launches": int(n[1]), "cols_launches": int(n[2]), "finalize_launches": int(n[3])}
 
+    def powerspec_get(self, which):
+        """(N, N) grid left on the device by powerspec_set: 'powerspec', 'logamp_powerspec' or 'lf_mask'."""
+        out = np.empty((self.N, self.N))
+        _chk(lib().fastmc_powerspec_get(self._h, {"powerspec": 0, "logamp_powerspec": 1, "lf_mask": 2}[which], _dptr(out)))
+        return out
+
     def kernel_path(self, force=-1):
         return _chk(lib().fastmc_kernel_path(self._h, int(force)))
 
@@ -379,7 +388,7 @@ def mask_spec(modal, modal_mult, zmax):
 
 
 def _ps_params(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, dtheta, cn2, h, wind, pupil_filter,
-               simpson_w, lf_mask, modal, modal_mult, zmax, D_ground, lgs_z):
+               simpson_w, lf_mask, modal, modal_mult, zmax, D_ground, lgs_z, pupil_filter_token=0):
     """fastmc_ps_params for the two power-spectrum entry points; returns (struct, arrays it points into)."""
     cn2, h, wind = _f64(cn2), _f64(h), _f64(wind)
     Lr = len(cn2)
@@ -401,6 +410,7 @@ def _ps_params(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, 
         p.lf_mask = mask.ctypes.data
     p.D_ground = float(D_ground)
     p.pupil_filter = None if pf is None else pf.ctypes.data
+    p.pupil_filter_token = int(pupil_filter_token) if pf is not None else 0
     p.lgs_z = None if z is None else z.ctypes.data
     return p, (cn2, h, wind, mask, pf, z, w)
 
@@ -425,6 +435,20 @@ def powerspec(N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, d
     _chk(lib().fastmc_powerspec(dev, C.byref(p), _dptr(ps), _dptr(pl), _dptr(la), _dptr(mo), _dptr(sc), C.byref(ms)))
     return {"powerspec": ps, "powerspec_per_layer": pl, "logamp_powerspec": la, "lf_mask": mo,
             "aniso_servo_error": sc[0], "alias_error": sc[1], "noise_error": sc[2], "fitting_error": sc[3],
+            "phs_var": sc[4], "logamp_var": sc[5], "phs_var_weights": sc[6:].copy(), "kernel_ms": ms.value}
+
+
+def powerspec_set(handle, df, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, dtheta, cn2, h, wind, pupil_filter,
+                  simpson_w, lf_mask=None, modal=False, modal_mult=1, zmax=None, D_ground=0.0, lgs_z=None, pupil_filter_token=0):
+    """fastmc_powerspec_set: the residual PSD evaluated on the handle's device and left there as its spectrum
+    (no N x N grid crosses PCIe); returns the Simpson scalars and the kernel time.  The grids are fetched on demand
+    with Handle.powerspec_get."""
+    p, keep = _ps_params(handle.N, dx, wvl, L0, l0, ao_mode, alias, noise, d_wfs, t_loop, t_exp, dtheta, cn2, h, wind, pupil_filter,
+                         simpson_w, lf_mask, modal, modal_mult, zmax, D_ground, lgs_z, pupil_filter_token)
+    sc = np.empty(PS_NSCALARS + p.n_layers)
+    ms = C.c_double(0.0)
+    _chk(lib().fastmc_powerspec_set(handle._h, C.byref(p), float(df), _dptr(sc), C.byref(ms)))
+    return {"aniso_servo_error": sc[0], "alias_error": sc[1], "noise_error": sc[2], "fitting_error": sc[3],
             "phs_var": sc[4], "logamp_var": sc[5], "phs_var_weights": sc[6:].copy(), "kernel_ms": ms.value}
 
 

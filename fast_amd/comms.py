@@ -5,7 +5,10 @@ fastmc_link_metrics.  Same names, arguments and NaN conventions as the reference
 Each function takes the sample vector the reference takes (uploaded for the call).  Pass a
 `fast_amd.Fast` object instead of an array to reduce the last run's results where they already
 are, on the device, without moving the vector (order-independent metrics only: fade_dur needs
-the FastResult ordering and always takes the vector).
+the FastResult ordering and always takes the vector).  With a `Fast` object every function works on
+the power RELATIVE to the diffraction limit (`FastResult._r`, i.e. 10^(dB_rel/10)): thresholds are in
+that unit for fade_prob, fade_counts and fade_dur alike; pass `sim.result.power` (an array, watts)
+to work in watts.
 
 The Monte-Carlo symbol simulator (Modulator / FastFSOC, comms.py:13-168) and the GMI tools are
 outside the hot-path scope and are not provided.
@@ -28,8 +31,12 @@ def fade_counts(I, threshold):
     from.  A fade is complete when it starts after the first sample and ends before the last
     (comms.py:181-186: rising edges of the mask, final segment dropped when it is still fading)."""
     from .fast import Fast
-    if isinstance(I, Fast):                      # fade durations need the FastResult ordering: take its vector
-        I = I.result.power
+    if isinstance(I, Fast):
+        # fade durations need the FastResult ordering: take its vector -- in the SAME unit fade_prob reduces on the
+        # device (power relative to the diffraction limit, FastResult._r; |a|^2 for a coherent run), so that one
+        # threshold means the same thing in fade_prob(sim, t) and fade_dur(sim, t)
+        I = I.result._r
+        I = numpy.abs(I) ** 2 if numpy.iscomplexobj(I) else I
     I = numpy.asarray(I)
     n = I.size
     n_below, n_rise, first_clear, last_clear = _lib.link_metrics([(_lib.LM_FADE, threshold, 0.0)], samples=I,

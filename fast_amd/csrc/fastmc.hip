@@ -52,6 +52,7 @@ struct fastmc_ctx {
   void* amp_s = nullptr;   // R[N*N]  with (-1)^(ky+kx)  (wave family)
   float* ampf = nullptr;   // amp / amp_s times sqrt(2 ln 2) in float32: colouring of the device generator's draws
   float* ampf_s = nullptr; //   (fmc_kernels.h: box_muller_scaled)
+  unsigned int* bad = nullptr;   // count of invalid spectrum entries (k_make_amp)
   void* tw = nullptr;      // direct: cpx<R>[N]
   void* tw1 = nullptr;     // wave
   void* om = nullptr;      // wave
@@ -87,6 +88,7 @@ struct fastmc_ctx {
   double* sh_in_re = nullptr;  // host-mode coefficients [batch][27]
   double* sh_in_im = nullptr;
   size_t sh_cap = 0;
+  double* ps_dev = nullptr;    // [3][N][N] powerspec, logamp powerspec, lf_mask left by fastmc_powerspec_set
   double* layers = nullptr;    // [n_layers][N][N] real layer screens (TEMPORAL mode)
   int n_layers = 0;
   unsigned long long* hist = nullptr;
@@ -299,9 +301,9 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
-  void* ptrs[] = {h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+  void* ptrs[] = {h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
-                  h->sh_in_im, h->hist, h->gather_buf, h->layers};
+                  h->sh_in_im, h->hist, h->gather_buf, h->layers, h->ps_dev};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (auto e : h->pool) hipEventDestroy(e);
@@ -344,25 +346,23 @@ static int default_batch(const fastmc_ctx* h) {
 }
 
 // ------------------------------------------------------------------ set_spectrum / set_pupil
+// Colouring tables from a spectrum already on the device (`d_ps`), on `stream`; synchronises it.
 template <class R>
-static int upload_spectrum(fastmc_ctx* h, const double* ps, double df) {
+static int make_amp(fastmc_ctx* h, const double* d_ps, double df, hipStream_t stream) {
   const int N = h->N;
   const size_t n = (size_t)N * N;
   if (!h->amp) HIPCHK(hipMalloc(&h->amp, sizeof(R) * n));
   if (!h->amp_s) HIPCHK(hipMalloc(&h->amp_s, sizeof(R) * n));
   if (!h->ampf) HIPCHK(hipMalloc((void**)&h->ampf, sizeof(float) * n));
   if (!h->ampf_s) HIPCHK(hipMalloc((void**)&h->ampf_s, sizeof(float) * n));
-  ScratchBuf d_ps, d_bad;
-  HIPCHK(hipMalloc((void**)&d_ps.p, n * 8));
-  HIPCHK(hipMalloc((void**)&d_bad.p, 8));
-  HIPCHK(hipMemcpyAsync(d_ps.p, ps, n * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemsetAsync(d_bad.p, 0, 8, h->stream));
-  hipLaunchKernelGGL((k_make_amp<R>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d_ps.p, df, N, (R*)h->amp,
-                     (R*)h->amp_s, h->ampf, h->ampf_s, (unsigned int*)d_bad.p);
+  if (!h->bad) HIPCHK(hipMalloc((void**)&h->bad, 8));
+  HIPCHK(hipMemsetAsync(h->bad, 0, 8, stream));
+  hipLaunchKernelGGL((k_make_amp<R>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_ps, df, N, (R*)h->amp,
+                     (R*)h->amp_s, h->ampf, h->ampf_s, h->bad);
   HIPCHK(hipGetLastError());
   unsigned int bad = 0;
-  HIPCHK(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpyAsync(&bad, h->bad, 4, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
   if (bad) return fail(FASTMC_EINVAL, "powerspec must be finite and non-negative");
   // direct-family twiddles w_N^e
   if (!h->tw) {
@@ -375,6 +375,23 @@ static int upload_spectrum(fastmc_ctx* h, const double* ps, double df) {
     HIPCHK(hipMalloc(&h->tw, sizeof(cpx<R>) * N));
     HIPCHK(hipMemcpy(h->tw, tw.data(), sizeof(cpx<R>) * N, hipMemcpyHostToDevice));
   }
+  return 0;
+}
+
+template <class R>
+static int upload_spectrum(fastmc_ctx* h, const double* ps, double df) {
+  const size_t n = (size_t)h->N * h->N;
+  ScratchBuf d_ps;
+  HIPCHK(hipMalloc((void**)&d_ps.p, n * 8));
+  HIPCHK(hipMemcpyAsync(d_ps.p, ps, n * 8, hipMemcpyHostToDevice, h->stream));
+  return make_amp<R>(h, d_ps.p, df, h->stream);
+}
+
+static int make_amp_from_device(fastmc_ctx* h, const double* d_ps, double df, hipStream_t stream) {
+  h->df = df;
+  h->have_spec = false;
+  TRY(h->precision == FASTMC_F64 ? make_amp<double>(h, d_ps, df, stream) : make_amp<float>(h, d_ps, df, stream));
+  h->have_spec = true;
   return 0;
 }
 
@@ -1014,9 +1031,36 @@ static void noll_to_nm(int j, int* n_out, int* m_out) {   // aotools zernIndex (
   *m_out = m;
 }
 
+// Device scratch of the power-spectrum evaluation, one per device for the life of the process: sweeps build one
+// Fast object per geometry sample (fast/complete_orbit_simulation.py:217-228) and ten hipMalloc / hipFree pairs plus
+// null-stream synchronisations per object cost more than the kernel (0.2 ms).  Buffers only grow; its own stream.
+struct PsScratch {
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct Buf { double* p = nullptr; size_t cap = 0; };
+  Buf small, ps, la, rows, sc, mask, mo, pf, z, pl, turb, g, al, no;
+  int64_t pf_token = 0;      // identity of the pupil filter resident in `pf` (fastmc_ps_params.pupil_filter_token)
+  int pf_N = 0;
+  int ensure(Buf& b, size_t n) {
+    if (b.cap >= n) return 0;
+    if (b.p) hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+    HIPCHK(hipMalloc((void**)&b.p, n * 8));
+    b.cap = n;
+    return 0;
+  }
+};
+static PsScratch g_ps_scratch[64];
+
+// Evaluate the spectrum on `device_id` (stream of the device's scratch).  Host outputs (any may be null) are copied
+// back; with `into` the spectrum also becomes that handle's colouring tables and stays resident on it
+// (fastmc_powerspec_set), with no host round trip of the N x N grids.
+static int make_amp_from_device(fastmc_ctx* h, const double* d_ps, double df, hipStream_t stream);
+
 static int powerspec_impl(int device_id, const fastmc_ps_params* p, double* powerspec, double* per_layer, double* logamp_ps,
                           double* lf_mask_out, double* scalars, double* kernel_ms, double* turb, double* g_ao, double* alias_ps,
-                          double* noise_ps) {
+                          double* noise_ps, fastmc_ctx* into = nullptr, double df = 0.0) {
   if (!p) return fail(FASTMC_EINVAL, "params is NULL");
   const int N = p->N, L = p->n_layers;
   if (N < 2 || N > 16384) return fail(FASTMC_EINVAL, "bad N");
@@ -1031,87 +1075,105 @@ static int powerspec_impl(int device_id, const fastmc_ps_params* p, double* powe
     return fail(FASTMC_ENODEV, "no HIP device visible: libfastmc has no CPU fallback");
   if (device_id < 0 || device_id >= count) return fail(FASTMC_EINVAL, "device_id out of range");
   HIPCHK(hipSetDevice(device_id));
+  PsScratch& S = g_ps_scratch[device_id & 63];
+  std::lock_guard<std::mutex> guard(S.mu);
+  if (!S.stream) {
+    HIPCHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&S.e0));
+    HIPCHK(hipEventCreate(&S.e1));
+  }
+  hipStream_t st = S.stream;
   const size_t N2 = (size_t)N * N;
   const int nq = PS_NQ + L;
-  double *d_cn2 = nullptr, *d_h = nullptr, *d_wind = nullptr, *d_mask = nullptr, *d_pf = nullptr, *d_z = nullptr,
-         *d_w = nullptr, *d_ps = nullptr, *d_pl = nullptr, *d_la = nullptr, *d_rows = nullptr, *d_sc = nullptr,
-         *d_mo = nullptr, *d_noll = nullptr, *d_turb = nullptr, *d_g = nullptr, *d_al = nullptr, *d_no = nullptr;
-  std::vector<double*> owned;
-  auto A = [&](double** q, size_t n) -> int {
-    hipError_t e = hipMalloc((void**)q, n * 8);
-    if (e != hipSuccess) return fail(FASTMC_EHIP, hipGetErrorString(e));
-    owned.push_back(*q);
-    return 0;
-  };
-  auto cleanup = [&]() { for (double* q : owned) hipFree(q); };
-  int rc = 0;
-  do {
-    const int nmodes = std::max(p->mask_mode == 3 ? p->zmax : 0, 4);
-    if ((rc = A(&d_cn2, L)) || (rc = A(&d_h, L)) || (rc = A(&d_wind, 2 * L)) || (rc = A(&d_w, N)) || (rc = A(&d_noll, nmodes)) ||
-        (rc = A(&d_ps, N2)) || (rc = A(&d_la, N2)) || (rc = A(&d_rows, (size_t)N * nq)) || (rc = A(&d_sc, nq)))
-      break;
-    if (p->mask_mode == 0 && (rc = A(&d_mask, N2))) break;
-    if (lf_mask_out && (rc = A(&d_mo, N2))) break;
-    if (p->pupil_filter && (rc = A(&d_pf, N2))) break;
-    if (p->lgs_z && (rc = A(&d_z, N2))) break;
-    if (per_layer && (rc = A(&d_pl, N2 * L))) break;
-    if (turb && (rc = A(&d_turb, N2 * L))) break;
-    if (g_ao && (rc = A(&d_g, N2 * L))) break;
-    if (alias_ps && (rc = A(&d_al, N2 * L))) break;
-    if (noise_ps && (rc = A(&d_no, N2))) break;
-    hipMemcpy(d_cn2, p->cn2, L * 8, hipMemcpyHostToDevice);
-    hipMemcpy(d_h, p->h, L * 8, hipMemcpyHostToDevice);
-    hipMemcpy(d_wind, p->wind, 2 * L * 8, hipMemcpyHostToDevice);
-    if (d_mask) hipMemcpy(d_mask, p->lf_mask, N2 * 8, hipMemcpyHostToDevice);
-    {
-      std::vector<int> nm(2 * nmodes);
-      for (int j = 1; j <= nmodes; ++j) noll_to_nm(j, &nm[j - 1], &nm[nmodes + j - 1]);
-      hipMemcpy(d_noll, nm.data(), 2 * nmodes * sizeof(int), hipMemcpyHostToDevice);
+  const int nmodes = std::max(p->mask_mode == 3 ? p->zmax : 0, 4);
+  const bool want_mask = lf_mask_out || into;
+  // small inputs packed into one upload: [cn2 L][h L][wind 2L][w N][noll 2*nmodes ints, padded to doubles]
+  const size_t o_cn2 = 0, o_h = L, o_wind = 2 * (size_t)L, o_w = 4 * (size_t)L, o_noll = 4 * (size_t)L + N;
+  const size_t n_small = o_noll + nmodes + 1;
+  TRY(S.ensure(S.small, n_small));
+  TRY(S.ensure(S.ps, N2));
+  TRY(S.ensure(S.la, N2));
+  TRY(S.ensure(S.rows, (size_t)N * nq));
+  TRY(S.ensure(S.sc, nq));
+  if (p->mask_mode == 0) TRY(S.ensure(S.mask, N2));
+  if (want_mask) TRY(S.ensure(S.mo, N2));
+  if (p->pupil_filter) TRY(S.ensure(S.pf, N2));
+  if (p->lgs_z) TRY(S.ensure(S.z, N2));
+  if (per_layer) TRY(S.ensure(S.pl, N2 * L));
+  if (turb) TRY(S.ensure(S.turb, N2 * L));
+  if (g_ao) TRY(S.ensure(S.g, N2 * L));
+  if (alias_ps) TRY(S.ensure(S.al, N2 * L));
+  if (noise_ps) TRY(S.ensure(S.no, N2));
+  std::vector<double> small(n_small, 0.0);
+  memcpy(&small[o_cn2], p->cn2, L * 8);
+  memcpy(&small[o_h], p->h, L * 8);
+  memcpy(&small[o_wind], p->wind, 2 * (size_t)L * 8);
+  memcpy(&small[o_w], p->simpson_w, (size_t)N * 8);
+  {
+    int* nm = reinterpret_cast<int*>(&small[o_noll]);
+    for (int j = 1; j <= nmodes; ++j) noll_to_nm(j, &nm[j - 1], &nm[nmodes + j - 1]);
+  }
+  HIPCHK(hipMemcpyAsync(S.small.p, small.data(), n_small * 8, hipMemcpyHostToDevice, st));
+  if (p->mask_mode == 0) HIPCHK(hipMemcpyAsync(S.mask.p, p->lf_mask, N2 * 8, hipMemcpyHostToDevice, st));
+  if (p->pupil_filter) {
+    // the filter depends on the aperture only: a caller that re-uses one array names it with a token and it is uploaded once
+    const bool resident = p->pupil_filter_token != 0 && p->pupil_filter_token == S.pf_token && S.pf_N == N;
+    if (!resident) {
+      HIPCHK(hipMemcpyAsync(S.pf.p, p->pupil_filter, N2 * 8, hipMemcpyHostToDevice, st));
+      S.pf_token = p->pupil_filter_token;
+      S.pf_N = N;
     }
-    hipMemcpy(d_w, p->simpson_w, N * 8, hipMemcpyHostToDevice);
-    if (d_pf) hipMemcpy(d_pf, p->pupil_filter, N2 * 8, hipMemcpyHostToDevice);
-    if (d_z) hipMemcpy(d_z, p->lgs_z, N2 * 8, hipMemcpyHostToDevice);
-    PsArgs K;
-    K.N = N; K.L = L; K.ao_mode = p->ao_mode; K.alias = p->alias;
-    K.dx = p->dx; K.wvl = p->wvl; K.L0 = p->L0; K.l0 = p->l0; K.noise = p->noise; K.d_wfs = p->d_wfs;
-    K.t_loop = p->t_loop; K.t_exp = p->t_exp; K.dth_x = p->dtheta[0]; K.dth_y = p->dtheta[1];
-    K.cn2 = d_cn2; K.h = d_h; K.wind = d_wind; K.mask = d_mask; K.pfilter = d_pf; K.lgs_z = d_z; K.w = d_w;
-    K.mask_mode = p->mask_mode; K.zmax = p->zmax; K.modal_mult = p->modal_mult; K.D_zern = p->D_ground;
-    K.noll_n = (const int*)d_noll; K.noll_m = (const int*)d_noll + nmodes; K.mask_out = d_mo;
-    K.powerspec = d_ps; K.per_layer = d_pl; K.logamp_ps = d_la; K.rowsums = d_rows;
-    K.turb = d_turb; K.g_ao = d_g; K.alias_out = d_al; K.noise_out = d_no;
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_powerspec, dim3(N), dim3(PS_THREADS), 0, 0, K);
-    hipLaunchKernelGGL(k_ps_scalars, dim3(nq), dim3(256), 0, 0, d_rows, d_w, N, nq, d_sc);
-    hipEventRecord(e1, 0);
-    hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipGetLastError();
+  }
+  if (p->lgs_z) HIPCHK(hipMemcpyAsync(S.z.p, p->lgs_z, N2 * 8, hipMemcpyHostToDevice, st));
+  PsArgs K;
+  K.N = N; K.L = L; K.ao_mode = p->ao_mode; K.alias = p->alias;
+  K.dx = p->dx; K.wvl = p->wvl; K.L0 = p->L0; K.l0 = p->l0; K.noise = p->noise; K.d_wfs = p->d_wfs;
+  K.t_loop = p->t_loop; K.t_exp = p->t_exp; K.dth_x = p->dtheta[0]; K.dth_y = p->dtheta[1];
+  K.cn2 = S.small.p + o_cn2; K.h = S.small.p + o_h; K.wind = S.small.p + o_wind; K.w = S.small.p + o_w;
+  K.mask = p->mask_mode == 0 ? S.mask.p : nullptr;
+  K.pfilter = p->pupil_filter ? S.pf.p : nullptr;
+  K.lgs_z = p->lgs_z ? S.z.p : nullptr;
+  K.mask_mode = p->mask_mode; K.zmax = p->zmax; K.modal_mult = p->modal_mult; K.D_zern = p->D_ground;
+  K.noll_n = reinterpret_cast<const int*>(S.small.p + o_noll); K.noll_m = K.noll_n + nmodes;
+  K.mask_out = want_mask ? S.mo.p : nullptr;
+  K.powerspec = S.ps.p; K.per_layer = per_layer ? S.pl.p : nullptr; K.logamp_ps = S.la.p; K.rowsums = S.rows.p;
+  K.turb = turb ? S.turb.p : nullptr; K.g_ao = g_ao ? S.g.p : nullptr; K.alias_out = alias_ps ? S.al.p : nullptr;
+  K.noise_out = noise_ps ? S.no.p : nullptr;
+  HIPCHK(hipEventRecord(S.e0, st));
+  hipLaunchKernelGGL(k_powerspec, dim3(N), dim3(PS_THREADS), 0, st, K);
+  hipLaunchKernelGGL(k_ps_scalars, dim3(nq), dim3(256), 0, st, S.rows.p, K.w, N, nq, S.sc.p);
+  HIPCHK(hipEventRecord(S.e1, st));
+  HIPCHK(hipGetLastError());
+  std::vector<double> sc(nq);
+  if (scalars) HIPCHK(hipMemcpyAsync(sc.data(), S.sc.p, nq * 8, hipMemcpyDeviceToHost, st));
+  if (powerspec) HIPCHK(hipMemcpyAsync(powerspec, S.ps.p, N2 * 8, hipMemcpyDeviceToHost, st));
+  if (per_layer) HIPCHK(hipMemcpyAsync(per_layer, S.pl.p, N2 * L * 8, hipMemcpyDeviceToHost, st));
+  if (logamp_ps) HIPCHK(hipMemcpyAsync(logamp_ps, S.la.p, N2 * 8, hipMemcpyDeviceToHost, st));
+  if (lf_mask_out) HIPCHK(hipMemcpyAsync(lf_mask_out, S.mo.p, N2 * 8, hipMemcpyDeviceToHost, st));
+  if (turb) HIPCHK(hipMemcpyAsync(turb, S.turb.p, N2 * L * 8, hipMemcpyDeviceToHost, st));
+  if (g_ao) HIPCHK(hipMemcpyAsync(g_ao, S.g.p, N2 * L * 8, hipMemcpyDeviceToHost, st));
+  if (alias_ps) HIPCHK(hipMemcpyAsync(alias_ps, S.al.p, N2 * L * 8, hipMemcpyDeviceToHost, st));
+  if (noise_ps) HIPCHK(hipMemcpyAsync(noise_ps, S.no.p, N2 * 8, hipMemcpyDeviceToHost, st));
+  if (into) {
+    // keep the three grids a Fast object exposes (powerspec, logamp_powerspec, lf_mask) on the handle, and colour from them
+    if (!into->ps_dev) HIPCHK(hipMalloc((void**)&into->ps_dev, 3 * N2 * 8));
+    HIPCHK(hipMemcpyAsync(into->ps_dev, S.ps.p, N2 * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(into->ps_dev + N2, S.la.p, N2 * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(into->ps_dev + 2 * N2, S.mo.p, N2 * 8, hipMemcpyDeviceToDevice, st));
+    TRY(make_amp_from_device(into, into->ps_dev, df, st));      // synchronises `st`
+  } else {
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  if (kernel_ms) {
     float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    if (e != hipSuccess) { rc = fail(FASTMC_EHIP, hipGetErrorString(e)); break; }
-    if (kernel_ms) *kernel_ms = ms;
-    if (powerspec) hipMemcpy(powerspec, d_ps, N2 * 8, hipMemcpyDeviceToHost);
-    if (per_layer) hipMemcpy(per_layer, d_pl, N2 * L * 8, hipMemcpyDeviceToHost);
-    if (logamp_ps) hipMemcpy(logamp_ps, d_la, N2 * 8, hipMemcpyDeviceToHost);
-    if (lf_mask_out) hipMemcpy(lf_mask_out, d_mo, N2 * 8, hipMemcpyDeviceToHost);
-    if (turb) hipMemcpy(turb, d_turb, N2 * L * 8, hipMemcpyDeviceToHost);
-    if (g_ao) hipMemcpy(g_ao, d_g, N2 * L * 8, hipMemcpyDeviceToHost);
-    if (alias_ps) hipMemcpy(alias_ps, d_al, N2 * L * 8, hipMemcpyDeviceToHost);
-    if (noise_ps) hipMemcpy(noise_ps, d_no, N2 * 8, hipMemcpyDeviceToHost);
-    if (scalars) {
-      std::vector<double> sc(nq);
-      hipMemcpy(sc.data(), d_sc, nq * 8, hipMemcpyDeviceToHost);
-      for (int i = 0; i < PS_NQ; ++i) scalars[i] = sc[i];
-      for (int l = 0; l < L; ++l) scalars[PS_NQ + l] = sc[PS_NQ + l] / sc[4];   // phs_var_weights
-    }
-  } while (0);
-  cleanup();
-  return rc;
+    hipEventElapsedTime(&ms, S.e0, S.e1);
+    *kernel_ms = ms;
+  }
+  if (scalars) {
+    for (int i = 0; i < PS_NQ; ++i) scalars[i] = sc[i];
+    for (int l = 0; l < L; ++l) scalars[PS_NQ + l] = sc[PS_NQ + l] / sc[4];   // phs_var_weights
+  }
+  return 0;
 }
 
 extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double* powerspec, double* per_layer,
@@ -1124,6 +1186,22 @@ extern "C" int fastmc_powerspec_terms(int device_id, const fastmc_ps_params* p, 
                                       double* noise_ps) {
   if (!turb && !g_ao && !alias_ps && !noise_ps) return fail(FASTMC_EINVAL, "no output requested");
   return powerspec_impl(device_id, p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, turb, g_ao, alias_ps, noise_ps);
+}
+
+extern "C" int fastmc_powerspec_set(fastmc_t* h, const fastmc_ps_params* p, double df, double* scalars, double* kernel_ms) {
+  if (!h || !p) return fail(FASTMC_EINVAL, "null argument");
+  if (p->N != h->N) return fail(FASTMC_EINVAL, "params.N differs from the handle's grid");
+  return powerspec_impl(h->device, p, nullptr, nullptr, nullptr, nullptr, scalars, kernel_ms, nullptr, nullptr, nullptr, nullptr, h, df);
+}
+
+extern "C" int fastmc_powerspec_get(fastmc_t* h, int which, double* out) {
+  if (!h || !out || which < 0 || which > 2) return fail(FASTMC_EINVAL, "bad argument");
+  if (!h->ps_dev) return fail(FASTMC_ESTATE, "fastmc_powerspec_set has not been called on this handle");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t N2 = (size_t)h->N * h->N;
+  HIPCHK(hipMemcpyAsync(out, h->ps_dev + (size_t)which * N2, N2 * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
 }
 
 // ------------------------------------------------------------------ RCCL (loaded on demand)

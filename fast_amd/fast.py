@@ -106,19 +106,18 @@ class Fast():
         self.devices = [self.device] if devs is None else devs
         _warn_transform_branch(p['FFTW'])
 
-        self.compute_powerspec()
         # one handle per device, one thread each (fast_amd/multi.py); the first handle also serves everything that is
         # not sharded (statistics, histogram of the assembled vector, TEMPORAL and host-generator modes)
         self._group = multi.DeviceGroup(self.Npxls, self.Npxls_pup, self.precision, self.devices)
         self._handle = self._group.handles[0]
         if p['GPU_BATCH']:
             self._group.set_batch(p['GPU_BATCH'])
+        self.compute_powerspec()
         if self._handle.kernel_path() == 0 and self.Npxls >= 128 and not self.temporal:
             below = [n for n in host.WAVE_FFT_SIZES if n <= self.Npxls][-1:]
             above = [n for n in host.ROUND_UP_SIZES if n >= self.Npxls][:1]
             logger.warning(f"NPXLS = {self.Npxls} runs on the direct O(N^2 Np) kernels (about 10x slower than the "
                            f"FFT kernels); nearest fast grid sizes: {', '.join(str(n) for n in below + above)}")
-        self._group.set_spectrum(self.powerspec, prob.df)
         self._group.set_pupil(prob.W, pup.crop_lo, self.dx)
         if self.subharmonics:
             self._group.set_subharm(self.powerspec_subharm, self._sh_fx, self._sh_fy, self._sh_df)
@@ -133,36 +132,65 @@ class Fast():
         _R = numpy.random.default_rng(seed)
 
     def compute_powerspec(self, per_layer=None):
-        """AO-residual phase PSD and its Simpson integrals on the GPU (replaces fast.py:445-492).
-        The (L, N, N) per-layer grids are only copied back when needed (TEMPORAL) or when
-        `powerspec_per_layer` is read."""
+        """AO-residual phase PSD and its Simpson integrals on the GPU (replaces fast.py:445-492).  The spectrum is
+        evaluated on every device of the object and STAYS there as the handle's colouring tables
+        (fastmc_powerspec_set): no N x N grid crosses PCIe unless `powerspec`, `logamp_powerspec`, `lf_mask` /
+        `hf_mask` are read (fetched on first use) or the (L, N, N) per-layer grids are needed (TEMPORAL,
+        `powerspec_per_layer`)."""
         logger.info("Computing (residual) phase power spectra")
         if per_layer is None:
             per_layer = bool(self.temporal)
         prob, p, atm = self._prob, self.params, self._prob.atm
-        out = _lib.powerspec(prob.N, prob.dx, prob.wvl, p['L0'], p['l0'], prob.ao_mode, p['ALIAS'], p['NOISE'],
-                             prob.d_wfs, p['TLOOP'], p['TEXP'], atm.dtheta, atm.cn2, atm.h, atm.wind_vector,
-                             prob.pup.pupil_filter, prob.simpson_w, lf_mask=None, modal=prob.modal,
-                             modal_mult=prob.modal_mult, zmax=prob.zmax, D_ground=p['D_GROUND'],
-                             per_layer=per_layer, device=self.device)
-        # mask_lf (ao_power_spectra.py:119-141) was evaluated on the device; same dtype as the reference
-        m = out["lf_mask"]
-        self.lf_mask = m if (prob.modal and prob.zmax is not None) else m.astype(numpy.int64)
-        self.hf_mask = 1 - self.lf_mask
-        self.powerspec = out["powerspec"]
-        self._per_layer = out["powerspec_per_layer"]
-        self.logamp_powerspec = out["logamp_powerspec"]
+        args = (prob.dx, prob.wvl, p['L0'], p['l0'], prob.ao_mode, p['ALIAS'], p['NOISE'], prob.d_wfs, p['TLOOP'], p['TEXP'],
+                atm.dtheta, atm.cn2, atm.h, atm.wind_vector, prob.pup.pupil_filter, prob.simpson_w)
+        kw = dict(lf_mask=None, modal=prob.modal, modal_mult=prob.modal_mult, zmax=prob.zmax, D_ground=p['D_GROUND'])
+        outs = self._group.each(lambda h, i: _lib.powerspec_set(h, prob.df, *args, pupil_filter_token=prob.pup.token, **kw))
+        out = outs[0]
+        self._grids = {}
         for k in ("aniso_servo_error", "alias_error", "noise_error", "fitting_error", "phs_var", "logamp_var", "phs_var_weights"):
             setattr(self, k, out[k])
         self.powerspec_kernel_ms = out["kernel_ms"]
+        self._per_layer = None
+        if per_layer:
+            self._per_layer = _lib.powerspec(prob.N, *args, per_layer=True, device=self.device, **kw)["powerspec_per_layer"]
         if self.subharmonics:
-            self.powerspec_subharm, self._sh_fx, self._sh_fy, self._sh_df = host.subharm_spectrum(prob)
+            self.powerspec_subharm, self._sh_fx, self._sh_fy, self._sh_df, sh = host.subharm_spectrum(prob)
+            # the bookkeeping of fast.py:494-526, as the reference leaves it on the object
+            self.powerspec_subharm_per_layer, self.lf_mask_subharm = sh.per_layer, sh.lf_mask
+            self.turb_lo, self.G_ao_lo, self.alias_subharm, self.noise_subharm = sh.turb, sh.G, sh.alias, sh.noise
+            self.phs_var_subharm, self.phs_var_weights_sh = sh.phs_var, sh.phs_var_weights
         else:
-            self.powerspec_subharm = None
+            self.powerspec_subharm = self.phs_var_subharm = self.phs_var_weights_sh = None
         self.temporal_powerspec = None
         self.temporal_logamp_powerspec = prob.temporal.logamp_powerspec if self.temporal else None
         if self.temporal:
             self.pixel_shifts = prob.temporal.pixel_shifts
+
+    def _grid(self, which):
+        if which not in self._grids:
+            self._grids[which] = self._handle.powerspec_get(which)
+        return self._grids[which]
+
+    @property
+    def powerspec(self):
+        """(N, N) residual phase PSD, fft-shifted layout (fast.py:481); fetched from the GPU on first use."""
+        return self._grid("powerspec")
+
+    @property
+    def logamp_powerspec(self):
+        return self._grid("logamp_powerspec")
+
+    @property
+    def lf_mask(self):
+        """mask_lf (ao_power_spectra.py:119-141), evaluated on the device; same dtype as the reference's."""
+        if "lf_mask_typed" not in self._grids:
+            m = self._grid("lf_mask")
+            self._grids["lf_mask_typed"] = m if (self._prob.modal and self._prob.zmax is not None) else m.astype(numpy.int64)
+        return self._grids["lf_mask_typed"]
+
+    @property
+    def hf_mask(self):
+        return 1 - self.lf_mask
 
     # ------------------------------------------------------------------ Monte Carlo
     def run(self):

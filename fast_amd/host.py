@@ -257,6 +257,7 @@ def pupil_filter(field):
 
 
 _PUPIL_CACHE = {}
+_PUPIL_TOKEN = 0
 
 
 def pupils(p, N, Np, dx):
@@ -265,9 +266,9 @@ def pupils(p, N, Np, dx):
     key = (N, Np, float(dx), p['D_GROUND'], p['OBSC_GROUND'], p['D_SAT'], p['OBSC_SAT'], str(p['W0']), bool(p['AXICON']))
     if key in _PUPIL_CACHE:
         return _PUPIL_CACHE[key]
-    if len(_PUPIL_CACHE) > 8:
-        _PUPIL_CACHE.clear()
-    o = _PUPIL_CACHE[key] = SimpleNamespace()
+    # built locally and stored only when complete: an exception part-way (axicon with W0 'opt', a failed Brent
+    # search) must not leave a half-filled entry for the next Fast() with the same key
+    o = SimpleNamespace()
     D, obsc = p['D_GROUND'], p['OBSC_GROUND']
     o.dx_sat = p['D_SAT'] / 32
     full = aperture(N, dx, D, obsc)
@@ -280,6 +281,16 @@ def pupils(p, N, Np, dx):
     o.pup_coords = np.array((np.arange(lo, hi), np.arange(lo, hi))).astype(int)
     o.pupil = full[lo:hi, lo:hi]
     o.pupil_mode = mode_full[lo:hi, lo:hi]
+    # the arrays are shared by every Fast object of this geometry: read-only, so that an in-place edit of
+    # `sim.pupil` cannot leak into later simulations (copy it to modify it)
+    for a in (o.pupil, o.pupil_mode, o.pupil_sat, o.pupil_mode_sat, o.pupil_filter, o.pup_coords):
+        a.flags.writeable = False
+    global _PUPIL_TOKEN
+    _PUPIL_TOKEN += 1
+    o.token = _PUPIL_TOKEN          # names pupil_filter for the device-side cache (fastmc_ps_params.pupil_filter_token)
+    if len(_PUPIL_CACHE) > 8:
+        _PUPIL_CACHE.clear()
+    _PUPIL_CACHE[key] = o
     return o
 
 
@@ -451,7 +462,11 @@ def subharm_spectrum(prob):
         noise = mask * noise
     per_layer = TWO_PI * k ** 2 * (turb * G + alias) + noise / L
     df = axes[..., 1] - axes[..., 0]
-    return per_layer.sum(0), fx, fy, df
+    # the bookkeeping the reference leaves on the object (fast.py:494-526)
+    phs_var = per_layer.sum((-1, -2)) * df ** 2
+    extra = SimpleNamespace(per_layer=per_layer, lf_mask=mask, turb=turb, G=G, alias=alias, noise=noise,
+                            phs_var=phs_var, phs_var_weights=phs_var / phs_var.sum())
+    return per_layer.sum(0), fx, fy, df, extra
 
 
 def _shifted(axes, k, l, d):

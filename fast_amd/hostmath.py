@@ -39,7 +39,8 @@ def cn2_to_r0(cn2, lamda=500e-9):
 
 
 def isoplanatic_angle(cn2, h, lamda=500e-9):
-    return 0.057 * lamda ** (6.0 / 5.0) * np.sum(cn2 * h ** (5.0 / 3.0)) ** (-3.0 / 5.0)
+    """aotools.isoplanaticAngle: arcseconds (the reference stores it as theta0 / theta0_los and in the THETA0 card)."""
+    return 0.057 * lamda ** (6.0 / 5.0) * np.sum(cn2 * h ** (5.0 / 3.0)) ** (-3.0 / 5.0) * 180.0 * 3600.0 / np.pi
 
 
 def coherence_time(cn2, v, lamda=500e-9):

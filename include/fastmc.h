@@ -198,6 +198,9 @@ typedef struct {
   const double* pupil_filter; /* (N, N) funcs.pupil_filter (funcs.py:308-315) or NULL */
   const double* lgs_z;        /* (N, N) zernike_squared_filter(Z<=4) for LGSAO, or NULL = evaluate on the device */
   const double* simpson_w;    /* (N,) Simpson weights of the frequency axis (funcs.py:100-115) */
+  int64_t pupil_filter_token; /* 0, or a caller-chosen name of the pupil_filter array: while consecutive calls on a device
+                                 carry the same non-zero token (and N) the filter already on the device is used and the
+                                 pointer is not read (the filter depends on the aperture only; sweeps over geometry reuse it) */
 } fastmc_ps_params;
 
 #define FASTMC_PS_NSCALARS 6 /* aniso_servo, alias, noise, fitting, phs_var, logamp_var */
@@ -208,6 +211,14 @@ typedef struct {
 int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double* powerspec,
                      double* per_layer, double* logamp_ps, double* lf_mask_out, double* scalars,
                      double* kernel_ms);
+
+/* The same evaluation on h's device, left there: the spectrum becomes the handle's colouring tables (as
+ * fastmc_set_spectrum(h, powerspec, df) would make them) without crossing PCIe, and powerspec, the log-amplitude spectrum
+ * and the mask stay resident for fastmc_powerspec_get (which = 0, 1, 2; each (N, N)).  This is what a sweep pays per
+ * geometry sample (fast/complete_orbit_simulation.py:217-228 builds one Fast per sample; compute_powerspec is 12-15 s of
+ * each in the reference).  scalars / kernel_ms as above. */
+int fastmc_powerspec_set(fastmc_t* h, const fastmc_ps_params* p, double df, double* scalars, double* kernel_ms);
+int fastmc_powerspec_get(fastmc_t* h, int which, double* out);
 
 /* The terms of that assembly as the reference keeps them on the object (fast/fast.py:448-472; any may be NULL):
  * turb (L,N,N) = funcs.turb_powerspectrum_vonKarman (fast/funcs.py:138-173); g_ao (L,N,N) = G_AO_PAOLA

@@ -129,16 +129,31 @@ def test_powers_match_oracle(N, Np, prec, rtol, coherent):
 
 
 def test_detector_kat_from_reference():
-    """kat_detector holds phases, not coefficients: check the oracle formula on the device by
-    feeding the equivalent problem (identity check of normalisation and exp(chi))."""
+    """The reference's Fast.compute_detector (fast/fast.py:647-668) on an explicit phase cube: the fixture's `phs`
+    goes through the DEVICE detector and must give its `incoherent` and `coherent`.  The four 22 x 22 phase planes
+    are tiled into one 64 x 64 layer screen and sampled by the frozen-flow entry point at integer coordinates
+    (bilinear weights 0 and 1: the plane itself), so the W exp(i phi) reduction, the normalisation and exp(chi) that
+    run are the kernel's own (k_temporal_detect; the screen path's epilogue is pinned through `_r` of the e2e fixtures)."""
     g = load_golden("kat_detector")
-    # zero spectrum -> phi = 0 -> power = exp(2 chi)
-    Np = g["W"].shape[0]
-    h = _lib.Handle(64, Np, "f64", 0)
-    h.set_spectrum(np.zeros((64, 64)), 1.0)
-    h.set_pupil(g["W"], (64 - Np) // 2, float(g["dx"]))
-    la = g["logamp"][:4]
-    got = h.run_coeffs(np.ones((2, 64, 64)), np.ones((2, 64, 64)), la)
+    phs, W, M = g["phs"], g["W"], int(g["M"])
+    Np, N = W.shape[0], 64
+    la = g["logamp"][int(g["chunk"]) * M:(int(g["chunk"]) + 1) * M]
+    screen = np.zeros((1, N, N))
+    corners = [(0, 0), (0, Np + 3), (Np + 5, 1), (Np + 7, Np + 9)]
+    for j, (r0, c0) in enumerate(corners):
+        screen[0, r0:r0 + Np, c0:c0 + Np] = phs[j]
+    xs = np.stack([r0 + np.arange(Np, dtype=float) for r0, _ in corners])[None]       # (L=1, M, Np) rows
+    ys = np.stack([c0 + np.arange(Np, dtype=float) for _, c0 in corners])[None]
+    h = _lib.Handle(N, Np, "f64", 0)
+    h.set_pupil(W, (N - Np) // 2, float(g["dx"]))
+    h.set_layer_screens(screen)
+    inc = h.temporal_chunk(xs, ys, np.zeros((1, 2, M), dtype=np.int32), la, coherent=False)
+    coh = h.temporal_chunk(xs, ys, np.zeros((1, 2, M), dtype=np.int32), la, coherent=True)
+    np.testing.assert_allclose(inc, g["incoherent"], rtol=1e-12)
+    np.testing.assert_allclose(coh, g["coherent"], rtol=1e-12, atol=1e-15)
+    # and the screen path's epilogue on a zero spectrum: phi = 0 -> power = exp(2 chi)
+    h.set_spectrum(np.zeros((N, N)), 1.0)
+    got = h.run_coeffs(np.ones((2, N, N)), np.ones((2, N, N)), la)
     np.testing.assert_allclose(got, np.exp(2 * la), rtol=1e-12)
 
 
@@ -170,7 +185,8 @@ def test_powerspec_kernel_matches_reference(case):
 
 
 @pytest.mark.parametrize("name", ["big_noao_1024", "big_noao_L0_1024", "big_ao_1024", "cfg1_256", "big_noao_L0_2048", "big_noao_L0_4096",
-                                  "big_tt_1024", "big_lgsao_1024", "big_modal_zmax_noise_1024", "big_subharm_coherent_down_1024"])
+                                  "big_tt_1024", "big_lgsao_1024", "big_modal_zmax_noise_1024", "big_subharm_coherent_down_1024",
+                                  "big_zenith05_1024", "big_zenith27_1024"])
 def test_powerspec_kernel_full_size(name):
     g = load_golden(name)
     p = params_from_json(g["params_json"])
@@ -212,7 +228,8 @@ def test_fast_run_f32_close_to_reference(case):
 
 
 @pytest.mark.parametrize("name", ["cfg1_256", "big_noao_1024", "big_noao_L0_1024", "big_ao_1024", "big_noao_L0_2048", "big_noao_L0_4096",
-                                  "big_tt_1024", "big_lgsao_1024", "big_modal_zmax_noise_1024", "big_subharm_coherent_down_1024"])
+                                  "big_tt_1024", "big_lgsao_1024", "big_modal_zmax_noise_1024", "big_subharm_coherent_down_1024",
+                                  "big_zenith05_1024", "big_zenith27_1024"])
 def test_fast_run_full_size_same_seed(name):
     g = load_golden(name)
     p = params_from_json(g["params_json"])
@@ -401,6 +418,61 @@ def test_zenith_scan_sweep():
     assert half[0]["mean_dB_rel"] == recs[1]["mean_dB_rel"]
 
 
+def test_config5_zenith_scan_full_size():
+    """BASELINE configs[4] at size: 32 zenith angles x 4096 iterations at 1024^2, AO + alias, through
+    sweep.zenith_scan (one Fast object per angle, spectrum evaluated and kept on the GPU).  Two of the angles are
+    pinned to the reference (fixtures big_zenith05 / big_zenith27: same parameters, captured by
+    tools/capture_golden/capture.py:zenith): the Simpson scalars of the device spectrum to 1e-9, and
+    test_fast_run_full_size_same_seed reproduces their `_r`; the rest must follow the physics monotonically."""
+    import time
+    from fast_amd import sweep
+    g5, g27 = load_golden("big_zenith05_1024"), load_golden("big_zenith27_1024")
+    base = params_from_json(g5["params_json"])
+    for k in ("ZENITH_ANGLE", "NITER", "NCHUNKS"):
+        base.pop(k)
+    base.update({"GPU_DEVICE": 0, "SEED": 1, "GPU_RNG": "device"})
+    angles = np.linspace(0, 70, 32)
+    assert angles[5] == params_from_json(g5["params_json"])["ZENITH_ANGLE"] and angles[27] == params_from_json(g27["params_json"])["ZENITH_ANGLE"]
+    t0 = time.perf_counter()
+    recs = sweep.zenith_scan(base, angles, niter=4096, keep_power=True)
+    wall = time.perf_counter() - t0
+    assert len(recs) == 32 and all(r["r"].shape == (4096,) and np.isfinite(r["r"]).all() and (r["r"] > 0).all() for r in recs)
+    for idx, g in ((5, g5), (27, g27)):
+        for k in ("phs_var", "logamp_var", "r0_los", "L"):
+            np.testing.assert_allclose(recs[idx][k], g[k], rtol=1e-9, err_msg=f"{k} at angle {idx}")
+        # 4096 device-generator iterations against the reference's 8 numpy-seeded ones: same distribution
+        z = (np.log(g["r"]).mean() - np.log(recs[idx]["r"]).mean()) / (np.log(recs[idx]["r"]).std() / np.sqrt(8))
+        assert abs(z) < 5
+    r0 = np.array([r["r0_los"] for r in recs])
+    pv = np.array([r["phs_var"] for r in recs])
+    lv = np.array([r["logamp_var"] for r in recs])
+    mean_db = np.array([r["mean_dB_rel"] for r in recs])
+    assert (np.diff(r0) < 0).all() and (np.diff(pv) > 0).all() and (np.diff(lv) > 0).all()     # more air mass, every step
+    assert mean_db[0] > mean_db[-1] + 3 and np.corrcoef(mean_db, pv)[0, 1] < -0.9
+    assert recs[0]["scintillation_index"] < recs[-1]["scintillation_index"]
+    assert wall < 5.0, wall                    # seconds; the reference needs 32 x (12 s init + 5 min run)
+
+
+def test_config4_full_size_two_handles():
+    """BASELINE configs[3] at size: 2048^2, 100 000 iterations, split over two handles (two worker threads; on a 1-GPU box
+    both on device 0): the assembled vector is bit-identical to the unsharded run and the dB histogram counts every
+    iteration."""
+    g = load_golden("big_noao_L0_2048")
+    p = params_from_json(g["params_json"])
+    p.update({"NITER": 100000, "NCHUNKS": 100, "SEED": 9, "GPU_RNG": "device"})
+    one = fast_amd.Fast(dict(p, GPU_DEVICE=0))
+    want = one.run()._r
+    assert want.shape == (100000,) and np.isfinite(want).all() and (want > 0).all()
+    two = fast_amd.Fast(dict(p, GPU_DEVICES=[0, 0]))
+    got = two.run()._r
+    assert two._group.world == 2 and np.array_equal(got, want)
+    hist = two.histogram(-60.0, 10.0, 4096)
+    assert hist.sum() == 100000 and np.array_equal(hist, one.histogram(-60.0, 10.0, 4096))
+    # the reference's own 4 iterations of this configuration lie inside the distribution
+    lo, hi = np.quantile(want, [0.001, 0.999])
+    assert ((g["r"] > lo / 3) & (g["r"] < hi * 3)).all()
+
+
 def test_config4_geometry_2048():
     """2048^2 grid (BASELINE config 4 geometry) through Fast: device RNG, finite results, and the
     same statistics as the 1024^2 run of the same physical problem within sampling error."""
@@ -549,7 +621,7 @@ def test_f32_pipeline_tracks_f64_on_the_same_device_draws(N):
         out[prec] = h.run(77, 3, 16, None, 0.01)
         scr = h.screens(77, 3, 1)
         out[prec + "_rms"] = scr.std()
-    assert out["f64_rms"] > 2.0                      # radians rms over the window of one screen
+    assert out["f64_rms"] > 0.5                      # radians rms over the window of one screen (piston-dominated: varies per draw)
     np.testing.assert_allclose(out["f32"], out["f64"], rtol=5e-4, atol=1e-9)
 
 
@@ -583,8 +655,13 @@ def test_link_metrics_on_resident_results_match_oracle():
     r = sim.run()._r
     thr = float(np.quantile(r, 0.2))
     assert comms.fade_prob(sim, thr) == R.fade_prob(r, thr)
-    a, b = comms.fade_dur(sim, thr * sim.diffraction_limit, 1e-3, 5), R.fade_dur(r, thr, 1e-3, 5)
+    # one threshold, one unit (power relative to the diffraction limit) for every function that takes the object
+    assert comms.fade_prob(sim, thr) == comms.fade_prob(sim.result._r, thr)
+    a, b = comms.fade_dur(sim, thr, 1e-3, 5), R.fade_dur(r, thr, 1e-3, 5)
     assert (np.isnan(a) and np.isnan(b)) or a == b
+    a, b = comms.fade_dur(sim, thr, 1e-3, 5), comms.fade_dur(sim.result._r, thr, 1e-3, 5)
+    assert (np.isnan(a) and np.isnan(b)) or a == b
+    assert comms.fade_counts(sim, thr)[:2] == (4000, int((r < thr).sum()))
     np.testing.assert_allclose(comms.ber_ook(8.0, sim), R.ber_ook(8.0, r), rtol=1e-11)
     np.testing.assert_allclose(comms.ber_qam(16, 12.0, sim), R.ber_qam(16, 12.0, r), rtol=1e-11)
     rng = np.random.default_rng(3)
@@ -737,3 +814,54 @@ def test_psd_terms_on_the_object_match_reference(case):
         want, got = g[name], getattr(sim, name)
         assert np.shape(got) == want.shape, name
         np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-13 * max(np.abs(want).max(), 1e-300), err_msg=name)
+
+
+def test_default_fftw_false_is_warned_and_tied_to_the_numpy_branch_fixture(caplog):
+    """`FFTW: False` is the reference's default (fast/conf.py:71 -> aotools ift2, funcs.py:216-218).  The GPU path
+    computes the FFTW branch whatever the flag: (i) it says so, once; (ii) its result for the same SEED is the FFTW
+    branch's `_r`, not the default branch's; (iii) the full-grid device screens reproduce the default branch's screens
+    of the fixture through the relation pinned in tests/test_oracle_golden.py (mirror, chunk roll, (chunk / N)^2)."""
+    import logging
+    from fast_amd import fast as ffast, funcs as gfuncs
+    g = load_golden("e2e_numpy_branch")
+    p = params_from_json(g["params_json"])
+    assert p["FFTW"] is False
+    ffast._BRANCH_WARNED.discard(False)
+    p.update({"GPU_RNG": "host", "GPU_DEVICE": 0, "LOGLEVEL": "WARNING"})
+    with caplog.at_level(logging.WARNING, logger="fast_amd.fast"):
+        sim = fast_amd.Fast(dict(p))
+        fast_amd.Fast(dict(p))
+    msgs = [r.getMessage() for r in caplog.records if "FFTW is False" in r.getMessage()]
+    assert len(msgs) == 1 and "ift2" in msgs[0] and "funcs.py:212-215" in msgs[0]
+    r = sim.run()._r
+    np.testing.assert_allclose(r, g["r_fftw"], rtol=1e-9)
+    assert np.abs(r / g["r"] - 1).max() > 1e-3
+    # (iii) device transform of the last chunk's coefficients -> the default branch's window
+    N, Np = int(g["Npxls"]), int(g["Npxls_pup"])
+    B = p["NITER"] // p["NCHUNKS"] // 2
+    rng = np.random.default_rng(p["SEED"])
+    R.draw_logamp(rng, p["NITER"], float(g["logamp_var"]))
+    for _ in range(p["NCHUNKS"]):
+        coeffs = R.draw_coefficients(rng, (B, N, N))
+    full = gfuncs.make_phase_fft(coeffs * np.sqrt(g["powerspec"]), float(g["df"]), double=True, device=0)      # (2B, N, N)
+    z = full[:B] + 1j * full[B:]
+    idx = (N - np.arange(N)) % N
+    zn = (B / N) ** 2 * np.roll(z[:, idx][:, :, idx], -2 * (B // 2), axis=0)
+    got = R.crop(R.double_screens(zn), N, Np)
+    np.testing.assert_allclose(got, g["phs_last_chunk"], rtol=1e-9, atol=1e-12 * np.abs(g["phs_last_chunk"]).max())
+
+
+def test_subharm_bookkeeping_attributes_like_the_reference():
+    """powerspec_subharm_per_layer, phs_var_subharm, phs_var_weights_sh, lf_mask_subharm (fast.py:494-526) on the object."""
+    g = load_golden("e2e_subharm_ao")
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_DEVICE": 0})
+    sim = fast_amd.Fast(p)
+    np.testing.assert_allclose(sim.powerspec_subharm_per_layer, g["powerspec_subharm_per_layer"], rtol=1e-11)
+    np.testing.assert_allclose(sim.phs_var_subharm, g["phs_var_subharm"], rtol=1e-11)
+    np.testing.assert_allclose(sim.phs_var_weights_sh, g["phs_var_weights_sh"], rtol=1e-11)
+    np.testing.assert_allclose(np.asarray(sim.lf_mask_subharm, dtype=float), g["lf_mask_subharm"], rtol=1e-12, atol=1e-15)
+    q = params_from_json(load_golden("e2e_ao_alias")["params_json"])
+    q.update({"GPU_DEVICE": 0})
+    plain = fast_amd.Fast(q)
+    assert plain.powerspec_subharm is None and plain.phs_var_subharm is None and plain.phs_var_weights_sh is None

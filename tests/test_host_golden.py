@@ -39,14 +39,19 @@ def test_host_init_matches_reference(case):
     np.testing.assert_allclose(list(prob.link_budget.values()), g["link_budget_vals"], rtol=1e-12)
 
 
-@pytest.mark.parametrize("case", ["subharm", "subharm_ao"])
+@pytest.mark.parametrize("case", ["subharm", "subharm_ao", "oddN"])
 def test_subharm_spectrum_matches_reference(case):
     g, p, prob = _problem(case)
-    ps, fx, fy, df = host.subharm_spectrum(prob)
+    ps, fx, fy, df, sh = host.subharm_spectrum(prob)
     np.testing.assert_allclose(ps, g["powerspec_subharm"], rtol=1e-11)
     np.testing.assert_allclose(fx, g["sh_fx"], rtol=1e-15)
     np.testing.assert_allclose(fy, g["sh_fy"], rtol=1e-15)
     np.testing.assert_allclose(df, g["sh_df"], rtol=1e-15)
+    # the bookkeeping attributes of fast.py:494-526
+    np.testing.assert_allclose(sh.per_layer, g["powerspec_subharm_per_layer"], rtol=1e-11)
+    np.testing.assert_allclose(sh.phs_var, g["phs_var_subharm"], rtol=1e-11)
+    np.testing.assert_allclose(sh.phs_var_weights, g["phs_var_weights_sh"], rtol=1e-11)
+    np.testing.assert_allclose(np.asarray(sh.lf_mask, dtype=float), g["lf_mask_subharm"], rtol=1e-12, atol=1e-15)
 
 
 def test_simpson_weights_reproduce_scipy():
@@ -190,3 +195,29 @@ def test_comms_host_logic_without_gpu(monkeypatch):
         np.testing.assert_allclose([comms.ber_ook(s, v) for s in eb], d["ber_ook_" + n], rtol=1e-12)
         np.testing.assert_allclose([[comms.ber_qam(M, s, v) for s in eb] for M in Ms], d["ber_qam_" + n], rtol=1e-12)
     np.testing.assert_allclose([comms.ber_ook(s) for s in eb], d["ber_ook_nosamples"], rtol=1e-13)
+
+
+def test_pupil_cache_entries_are_complete_and_read_only():
+    """A failed init must not leave a half-built cache entry (the next Fast() with the same key then raises the
+    reference's exception again, fast/funcs.py:298-299, not an AttributeError), and the arrays shared through the cache
+    cannot be edited in place."""
+    p = params_from_json(load_golden("e2e_axicon")["params_json"])
+    p["W0"] = "opt"                                     # axicon + W0 'opt': TypeError in the reference
+    for _ in range(2):
+        with pytest.raises(TypeError, match="axicon"):
+            host.build_problem(fast_amd.conf.ConfigParser(dict(p)).config)
+    g, cfg, prob = _problem("ao_alias")
+    assert host.build_problem(cfg).pup is prob.pup       # served from the cache
+    assert isinstance(prob.pup.token, int) and prob.pup.token > 0
+    with pytest.raises(ValueError, match="read-only"):
+        prob.pup.pupil[0, 0] = 7.0
+    with pytest.raises(ValueError, match="read-only"):
+        prob.pup.pupil_filter[0, 0] = 7.0
+
+
+def test_theta0_is_in_arcseconds_like_aotools():
+    """aotools.isoplanaticAngle returns arcseconds; the reference stores it as theta0 / theta0_los and in THETA0."""
+    cn2, h = np.array([1e-13, 2e-14]), np.array([1000.0, 9000.0])
+    rad = 0.057 * 500e-9 ** 1.2 * np.sum(cn2 * h ** (5 / 3)) ** -0.6
+    assert hostmath.isoplanatic_angle(cn2, h) == pytest.approx(rad * 206264.80624709636, rel=1e-12)
+    assert 0.5 < hostmath.isoplanatic_angle(cn2, h) < 10        # arcseconds at 500 nm, not 1e-5

@@ -158,3 +158,36 @@ def test_mean_irradiance_matches_reference():
     np.testing.assert_allclose(off, g["offaxis"], rtol=1e-9, atol=1e-12 * np.abs(g["offaxis"]).max())
     on2 = R.mean_irradiance(g["powerspec2"], g["W2"], float(g["dx2"]), float(g["df2"]), float(g["diffraction_limit2"]))
     np.testing.assert_allclose(on2, g["onaxis2"], rtol=1e-10)
+
+
+def test_default_numpy_branch_fixture_and_its_relation_to_the_fftw_branch():
+    """The reference's DEFAULT transform branch (FFTW False, funcs.py:216-218: aotools ift2) next to the FFTW branch
+    the GPU computes, same SEED (fixture e2e_numpy_branch; STAND-IN DEPENDENT in its arithmetic: ift2 is our
+    stand-in of aotools).  (i) the oracle's restatement of that branch reproduces the reference's screens; (ii) per
+    chunk of B complex transforms on an N x N grid the two branches are tied by
+        numpy[b] = (B / N)^2 * point_mirror(FFTW[(b + 2 (B // 2)) mod B])      (mirror: index -> (N - index) mod N)
+    i.e. the default branch sees the same screens mirrored, rolled along the chunk axis (all-axes ifftshift) and
+    scaled by (chunk / N)^2 (`N = DATA.shape[0]` inside ift2 is the chunk length): with chunk != N they are NOT the
+    same physical phase.  fast_amd always computes the FFTW branch and warns when FFTW is False."""
+    g = load_golden("e2e_numpy_branch")
+    p = params_from_json(g["params_json"])
+    N, Np = int(g["Npxls"]), int(g["Npxls_pup"])
+    B = p["NITER"] // p["NCHUNKS"] // 2
+    rng = np.random.default_rng(p["SEED"])
+    R.draw_logamp(rng, p["NITER"], float(g["logamp_var"]))
+    for _ in range(p["NCHUNKS"]):
+        coeffs = R.draw_coefficients(rng, (B, N, N))                          # last chunk's draws
+    col = coeffs * np.sqrt(g["powerspec"])
+    npb = R.crop(R.double_screens(R.screens_numpy_branch(col, float(g["df"]))), N, Np)
+    np.testing.assert_allclose(npb, g["phs_last_chunk"], rtol=1e-12, atol=1e-14 * np.abs(g["phs_last_chunk"]).max())
+    fw = R.crop(R.double_screens(R.screens_fftw(col, float(g["df"]))), N, Np)
+    np.testing.assert_allclose(fw, g["phs_last_chunk_fftw"], rtol=1e-12, atol=1e-14 * np.abs(fw).max())
+    # the relation, on the full grid
+    zf = R.screens_fftw(col, float(g["df"]))
+    zn = R.screens_numpy_branch(col, float(g["df"]))
+    idx = (N - np.arange(N)) % N
+    mirrored = zf[:, idx][:, :, idx]
+    want = (B / N) ** 2 * np.roll(mirrored, -2 * (B // 2), axis=0)
+    np.testing.assert_allclose(zn, want, rtol=1e-10, atol=1e-13 * np.abs(want).max())
+    # consequence for the results: the default branch's phases are (B/N)^2 smaller -> powers near the no-turbulence value
+    assert g["r"].mean() > g["r_fftw"].mean()

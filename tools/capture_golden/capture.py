@@ -200,6 +200,11 @@ def capture_sim(name, p, note, full=True, stride=None):
             d["sh_fx"] = sim.freq.subharm.fx
             d["sh_fy"] = sim.freq.subharm.fy
             d["sh_df"] = sim.freq.subharm.df
+            # the sub-harmonic bookkeeping a caller can read off the object (fast.py:494-526)
+            d["powerspec_subharm_per_layer"] = sim.powerspec_subharm_per_layer
+            d["phs_var_subharm"] = sim.phs_var_subharm
+            d["phs_var_weights_sh"] = sim.phs_var_weights_sh
+            d["lf_mask_subharm"] = np.asarray(sim.lf_mask_subharm, dtype=float)
     else:
         s = stride
         d["stride"] = np.array(s)
@@ -397,6 +402,42 @@ def big_modes():
     capture_sim("big_subharm_coherent_down_1024", p, "1024^2 AO + alias + SUBHARM + COHERENT + downlink, L0=40, NITER 4", full=False, stride=16)
 
 
+def zenith():
+    """BASELINE configs[4]: the zenith-angle scan of fast_amd.sweep.zenith_scan / bench.py (32 angles, linspace(0, 70, 32),
+    1024^2, AO + alias, SEED + index) at two of its angles (indices 5 and 27), 8 iterations of the reference each:
+    scalars, strided spectrum sample, powers."""
+    h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
+    angles = np.linspace(0, 70, 32)
+    for idx in (5, 27):
+        p = dict(fast.conf.DEFAULTS)
+        p.update({"NPXLS": 1024, "DX": 0.01, "NITER": 8, "NCHUNKS": 1, "TEMPORAL": False, "SUBHARM": False, "FFTW": True,
+                  "SEED": 1 + idx, "W0": "opt", "D_GROUND": 0.8, "OBSC_GROUND": 0, "D_SAT": 0.1, "H_SAT": 36e6, "H_TURB": h,
+                  "CN2_TURB": cn2, "WIND_SPD": w, "WIND_DIR": np.array([0., 90., 180., 270.]), "L0": np.inf, "l0": 1e-6,
+                  "ZENITH_ANGLE": float(angles[idx]), "DTHETA": [4, 0], "AO_MODE": "AO", "DSUBAP": 0.1, "TLOOP": 1e-3,
+                  "TEXP": 1e-3, "ALIAS": True, "NOISE": 0, "LOGLEVEL": "ERROR"})
+        capture_sim(f"big_zenith{idx:02d}_1024", p, f"BASELINE configs[4]: zenith scan sample {idx} of 32 ({angles[idx]:.2f} deg), "
+                    "1024^2 AO + alias, NITER 8", full=False, stride=16)
+
+
+def numpy_branch():
+    """The reference's DEFAULT transform branch (FFTW False, fast/conf.py:71 -> funcs.py:216-218:
+    aotools.fouriertransform.ift2(rand * df, 1.)) on the small AO + alias geometry, same SEED as e2e_ao_alias.
+    STAND-IN DEPENDENT in its very arithmetic: ift2 is our stand-in of aotools (N = DATA.shape[0], all-axes
+    ifftshift), which on the (chunk, N, N) arrays of Fast.compute_phs scales the screens by (chunk / N)^2 and
+    rolls the chunk axis.  Kept to document what `FFTW: False` means next to the FFTW branch the GPU computes."""
+    p = base_params(FFTW=False, NITER=20, NCHUNKS=2)
+    sim = fast.Fast(p)
+    res = sim.run()
+    p2 = base_params(FFTW=True, NITER=20, NCHUNKS=2)
+    sim2 = fast.Fast(p2)
+    res2 = sim2.run()
+    save("e2e_numpy_branch", "FFTW False (reference default): aotools ift2 stand-in branch next to the FFTW branch, same SEED, "
+         "N=64, 2 chunks of 10", True, params_json=np.array(params_to_json(p)), r=res._r, phs_last_chunk=sim.phs.copy(),
+         r_fftw=res2._r, phs_last_chunk_fftw=sim2.phs.copy(), logamp=sim.logamp.copy(), powerspec=sim.powerspec,
+         W=sim.pupil * sim.pupil_mode, dx=np.array(sim.dx), df=np.array(sim.freq.main.df), logamp_var=np.array(sim.logamp_var),
+         Npxls=np.array(sim.Npxls), Npxls_pup=np.array(sim.Npxls_pup))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("capturing into", OUT)
@@ -407,7 +448,8 @@ def main():
             e2e(only[0].split("=", 1)[1].split(","))
         else:
             {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref,
-             "--only-comms": comms_metrics, "--only-big2048": big2048, "--only-big-modes": big_modes}[only[0]]()
+             "--only-comms": comms_metrics, "--only-big2048": big2048, "--only-big-modes": big_modes,
+             "--only-zenith": zenith, "--only-numpy-branch": numpy_branch}[only[0]]()
         for name, size, st, note in MANIFEST:
             print(f"| {name}.npz | {size} | {st} | {note} |")
         return
@@ -420,8 +462,12 @@ def main():
     stat_ref()
     comms_metrics()
     p = default_cfg()
+    numpy_branch()
     if "--no-big" not in sys.argv:
         big(p)
+        big2048()            # add --with-4096 for the 4096^2 fixture (70 s of reference init)
+        big_modes()
+        zenith()
     with open(os.path.join(OUT, "MANIFEST.md"), "w") as f:
         f.write("# Golden fixtures captured from the reference (tools/capture_golden/capture.py)\n\n")
         f.write(f"numpy {np.__version__}; reference snapshot /root/reference (2025-04-04).\n")

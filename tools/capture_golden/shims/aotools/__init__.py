@@ -39,8 +39,9 @@ def cn2_to_r0(cn2, lamda=500.0e-9):
 
 
 def isoplanaticAngle(cn2, h, lamda=500.0e-9):
+    # aotools returns ARCSECONDS (atmos_conversions.isoplanaticAngle: "... * 180. * 3600. / numpy.pi")
     Jh = numpy.sum(cn2 * h ** (5.0 / 3.0))
-    return 0.057 * lamda ** (6.0 / 5.0) * Jh ** (-3.0 / 5.0)
+    return 0.057 * lamda ** (6.0 / 5.0) * Jh ** (-3.0 / 5.0) * 180.0 * 3600.0 / numpy.pi
 
 
 def coherenceTime(cn2, v, lamda=500.0e-9):

@@ -433,7 +433,12 @@ def main():
         if mode == "single" and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sim)
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
+        try:      # RCCL prints a version banner through C stdio: flush it first so that the JSON line is the last line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
     sync_all()
 
 

@@ -53,3 +53,58 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_sq4")
         n = max(len(cnt[k]), 1)
         print(f"| {k} | {n} | " + " | ".join(f"{agg[k][c]/n:.4g}" for c in names) + " |")
     print()
+
+# ---- machine-readable counters of the two hot kernels (bench.py reads profiles/latest_counters.json)
+import json
+import re
+
+
+def _avg(sub, counter, prefix):
+    tot, ids = 0.0, set()
+    for f in find(sub, "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if short(r["Kernel_Name"]).startswith(prefix) and r["Counter_Name"] == counter:
+                tot += float(r["Counter_Value"])
+                ids.add(r["Dispatch_Id"])
+    return tot / len(ids) if ids else None
+
+
+def _kernel_ms(prefix):
+    for f in find("trace", "*kernel_stats.csv"):
+        for r in csv.DictReader(open(f)):
+            if short(r["Name"]).startswith(prefix):
+                return float(r["AverageNs"]) / 1e6, short(r["Name"])
+    return None, None
+
+
+if len(sys.argv) > 2:
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    isa = {}
+    try:
+        isa = json.load(open(os.path.join(root, "fast_amd", "kernel_isa_stats.json")))
+    except Exception:
+        pass
+    prec, npx = sys.argv[3] if len(sys.argv) > 3 else "f64", int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+    doc = {"source": f"profiles/{os.path.basename(sys.argv[2]).replace('_counters.json', '')}_* (tools/profile_gpu.sh: rocprofv3 --kernel-trace --stats, "
+                     "separate --pmc passes FETCH_SIZE / WRITE_SIZE / SQ; per-dispatch averages)",
+           "precision": prec, "npxls": npx,
+           "rows_valu_instructions_per_row": isa.get(f"rows_{prec}_{npx}", {}).get("valu_total"),
+           "fetch_correction": "x2 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section)"}
+    for tag, prefix in (("rows", "k_rows_wave"), ("cols", "k_cols_wave")):
+        ms, name = _kernel_ms(prefix)
+        fetch, write = _avg("pmc_fetch", "FETCH_SIZE", prefix), _avg("pmc_write", "WRITE_SIZE", prefix)
+        ent = {"kernel": name, "avg_launch_ms": ms, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write}
+        if fetch is not None and write is not None:
+            ent["hbm_bytes_per_launch"] = (2 * fetch + write) * 1024
+        doc[tag] = ent
+    grbm = _avg("pmc_sq2", "GRBM_GUI_ACTIVE", "k_rows_wave")
+    if grbm:
+        simd_cycles = grbm / 8 * 1024          # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
+        for key, sub, counter in (("valu_busy", "pmc_sq", "SQ_ACTIVE_INST_VALU"), ("issue_busy", "pmc_sq2", "SQ_ACTIVE_INST_ANY"),
+                                  ("lds_issue_busy", "pmc_sq2", "SQ_ACTIVE_INST_LDS")):
+            v = _avg(sub, counter, "k_rows_wave")
+            if v:
+                doc[key] = v * 4 / simd_cycles   # SQ_ACTIVE_INST_* count quad-cycles
+        doc["busy_note"] = "k_rows_wave: SQ_ACTIVE_INST_* x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)"
+        doc["clock_GHz_profiled"] = grbm / 8 / (doc["rows"]["avg_launch_ms"] * 1e-3) / 1e9 if doc["rows"]["avg_launch_ms"] else None
+    json.dump(doc, open(sys.argv[2], "w"), indent=1)

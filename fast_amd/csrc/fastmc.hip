@@ -44,7 +44,8 @@ struct fastmc_ctx {
   int S = 1;               // wave family: sub-rows per row (N = S * 64 * P); spec_split(N)
   int batch = 0;
   double df = 0, dx = 0, wsum = 0;
-  bool have_spec = false, have_pupil = false, have_sh = false;
+  bool have_spec = false, have_pupil = false, have_sh = false, have_ps = false;
+  int tables_lo = -1;      // window position the wave tables were built for (-1: none)
   hipStream_t stream = nullptr;
   size_t rsz = 8;   // sizeof(R)
 
@@ -238,6 +239,17 @@ static void wave_config(const fastmc_ctx* h, int* ns, int* wpb) {
 #undef FMC_CASE
 }
 
+// One retired handle per device is kept whole (stream, events, every device buffer) and handed to the next
+// fastmc_create of the same (N, Np, precision): a sweep builds one short-lived handle per geometry sample
+// (fast/complete_orbit_simulation.py:217-228) and ~15 hipMalloc / hipFree pairs per object cost more than its spectrum.
+struct HandleCache {
+  std::mutex mu;
+  fastmc_ctx* dev[64] = {};
+  fastmc_ctx* take(int device, int N, int Np, int precision);
+  fastmc_ctx* swap_in(fastmc_ctx* h);     // returns the handle to free (the previous occupant), or nullptr
+};
+static HandleCache g_handles;
+
 extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int precision) {
   if (!out) return fail(FASTMC_EINVAL, "handle pointer is NULL");
   *out = nullptr;
@@ -249,6 +261,10 @@ extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int p
     return fail(FASTMC_ENODEV, "no HIP device visible: libfastmc has no CPU fallback");
   if (device_id < 0 || device_id >= count) return fail(FASTMC_EINVAL, "device_id out of range");
   HIPCHK(hipSetDevice(device_id));
+  if (fastmc_ctx* r = g_handles.take(device_id, N, Np, precision)) {
+    *out = r;
+    return 0;
+  }
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device_id));
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
@@ -296,8 +312,43 @@ struct SlabCache {
 };
 static SlabCache g_slabs;
 
+fastmc_ctx* HandleCache::take(int device, int N, int Np, int precision) {
+  std::lock_guard<std::mutex> g(mu);
+  fastmc_ctx* h = dev[device & 63];
+  if (!h || h->device != device || h->N != N || h->Np != Np || h->precision != precision) return nullptr;
+  dev[device & 63] = nullptr;
+  return h;
+}
+fastmc_ctx* HandleCache::swap_in(fastmc_ctx* h) {
+  std::lock_guard<std::mutex> g(mu);
+  fastmc_ctx* old = dev[h->device & 63];
+  dev[h->device & 63] = h;
+  return old;
+}
+
+static void destroy_now(fastmc_ctx* h);
+
 extern "C" void fastmc_destroy(fastmc_t* h) {
   if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  // back to the state fastmc_create leaves: problem unset, results forgotten, options at their defaults; buffers kept
+  h->have_spec = h->have_pupil = h->have_sh = h->have_ps = false;
+  h->last_n_iter = 0;
+  h->last_coherent = 0;
+  h->batch = 0;
+  h->path = wave_supported(h->N) ? 1 : 0;
+  h->lo = 0;
+  h->df = h->dx = h->wsum = 0;
+  if (h->layers) { hipFree(h->layers); h->layers = nullptr; h->n_layers = 0; }
+  if (h->cre) { hipFree(h->cre); h->cre = nullptr; }
+  if (h->cim) { hipFree(h->cim); h->cim = nullptr; }
+  h->coef_cap = 0;
+  if (h->phs) { hipFree(h->phs); h->phs = nullptr; h->phs_cap = 0; }
+  if (fastmc_ctx* old = g_handles.swap_in(h)) destroy_now(old);
+}
+
+static void destroy_now(fastmc_ctx* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
@@ -456,8 +507,11 @@ extern "C" int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, doubl
   h->dx = dx;
   if (!h->W) HIPCHK(hipMalloc((void**)&h->W, n * sizeof(double)));
   HIPCHK(hipMemcpy(h->W, W, n * sizeof(double), hipMemcpyHostToDevice));
-  if (wave_supported(h->N))
+  if (wave_supported(h->N) && h->tables_lo != crop_lo) {      // the tables depend on (N, Np, window position) only
+    h->tables_lo = -1;
     TRY(h->precision == FASTMC_F64 ? upload_wave_tables<double>(h) : upload_wave_tables<float>(h));
+    h->tables_lo = crop_lo;
+  }
   h->have_pupil = true;
   return 0;
 }
@@ -1161,6 +1215,7 @@ static int powerspec_impl(int device_id, const fastmc_ps_params* p, double* powe
     HIPCHK(hipMemcpyAsync(into->ps_dev + N2, S.la.p, N2 * 8, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(into->ps_dev + 2 * N2, S.mo.p, N2 * 8, hipMemcpyDeviceToDevice, st));
     TRY(make_amp_from_device(into, into->ps_dev, df, st));      // synchronises `st`
+    into->have_ps = true;
   } else {
     HIPCHK(hipStreamSynchronize(st));
   }
@@ -1196,7 +1251,7 @@ extern "C" int fastmc_powerspec_set(fastmc_t* h, const fastmc_ps_params* p, doub
 
 extern "C" int fastmc_powerspec_get(fastmc_t* h, int which, double* out) {
   if (!h || !out || which < 0 || which > 2) return fail(FASTMC_EINVAL, "bad argument");
-  if (!h->ps_dev) return fail(FASTMC_ESTATE, "fastmc_powerspec_set has not been called on this handle");
+  if (!h->ps_dev || !h->have_ps) return fail(FASTMC_ESTATE, "fastmc_powerspec_set has not been called on this handle");
   HIPCHK(hipSetDevice(h->device));
   const size_t N2 = (size_t)h->N * h->N;
   HIPCHK(hipMemcpyAsync(out, h->ps_dev + (size_t)which * N2, N2 * 8, hipMemcpyDeviceToHost, h->stream));

@@ -13,8 +13,10 @@
  *   - all host arrays are C-contiguous float64 unless stated otherwise;
  *   - calls on one handle must be serialised by the caller; calls are blocking; different
  *     handles may be driven from different threads (each has its own HIP stream);
- *   - N <= 4096, Np <= N; fastmc_destroy() keeps the largest work buffer of the device for
- *     the next handle of the process (sweeps of short-lived handles), everything else is freed;
+ *   - N <= 4096, Np <= N; fastmc_destroy() parks ONE retired handle per device, whole (stream, buffers), and
+ *     fastmc_create() of the same (N, Np, precision) on that device takes it back, reset to the state of a new
+ *     handle (sweeps build one short-lived handle per geometry sample); a handle it displaces is freed, except
+ *     for the largest work buffer of the device, which is kept for the next handle;
  *   - nothing here ever falls back to a CPU implementation: without a gfx950 device
  *     fastmc_create() fails with FASTMC_ENODEV.
  */

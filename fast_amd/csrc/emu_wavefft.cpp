@@ -11,6 +11,7 @@
 
 #include "fmc_core.h"
 #include "fmc_wavefft.h"
+#include "fmc_bluestein.h"
 
 using namespace fmc;
 
@@ -95,8 +96,81 @@ static int sweep(const char* name, double tol) {
   return bad;
 }
 
+// Chirp-z row of fmc_bluestein.h: any N (odd included) with M = 64 P >= N + Np - 1, against the naive DFT with
+// numpy's fftshift on both sides: out[p] = sum_k in[k] w_N^{(p - h)(k + h)}, h = N // 2.
+template <class R, int P, int NS>
+static double run_blu_case(int N, int lo, int Np, unsigned seed) {
+  constexpr int M = WAVE * P;
+  using B = BluGeom<R, P>;
+  using E = typename Xch<R>::E;
+  std::mt19937_64 gen(seed);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  std::vector<double> inr(N), ini(N);
+  for (int k = 0; k < N; ++k) { inr[k] = nd(gen); ini[k] = nd(gen); }
+  const int omS = NS * WAVE;
+  std::vector<cpx<R>> tw1((size_t)P * WAVE), om((size_t)8 * omS), pre(M), vhat(M), post(omS), twf(64);
+  build_tw1<R>(tw1.data(), P, cs_turns);
+  build_om<R>(om.data(), omS, P, 0, Np, false, cs_turns);
+  if (!build_blu_tables<R>(N, Np, lo, P, pre.data(), vhat.data(), post.data(), omS, twf.data(), cs_turns)) return 1e30;
+  std::vector<E> xbuf(B::XELEMS);
+  static HostExec<R, P, NS> ex;
+  for (int l = 0; l < WAVE; ++l)
+    for (int j = 0; j < P; ++j) {
+      const int k = l + WAVE * j;
+      ex.regs[l].v[j] = k < N ? cmul(mk<R>((R)inr[k], (R)ini[k]), pre[k]) : mk<R>((R)0, (R)0);
+    }
+  bluestein_row<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, twf.data(), vhat.data(), Np);
+  double worst = 0.0, scale = 0.0;
+  const int h = N / 2;
+  for (int oi = 0; oi < Np; ++oi) {
+    const int p = lo + oi;
+    long double sr = 0, si = 0;
+    for (int k = 0; k < N; ++k) {
+      const long long e = (((long long)(p - h) * (k + h)) % N + N) % N;
+      const long double a = -2.0L * M_PIl * (long double)e / N;
+      const long double c = cosl(a), s2 = sinl(a);
+      sr += inr[k] * c - ini[k] * s2;
+      si += inr[k] * s2 + ini[k] * c;
+    }
+    const int l = oi % WAVE, s = oi / WAVE;
+    const double yr = ex.regs[l].xr[s], yi = ex.regs[l].xi[s];
+    const double gr = post[oi].x * yr + post[oi].y * yi, gi = post[oi].y * yr - post[oi].x * yi;   // post * conj(Y)
+    worst = std::fmax(worst, std::fmax(std::fabs(gr - (double)sr), std::fabs(gi - (double)si)));
+    scale = std::fmax(scale, std::fmax(std::fabs((double)sr), std::fabs((double)si)));
+  }
+  return worst / scale;
+}
+
+template <class R, int P, int NS>
+static int sweep_blu(const char* name, double tol) {
+  constexpr int M = WAVE * P;
+  int bad = 0;
+  // (N, lo, Np): the reference's auto-sized 164 with its 82-pixel window, odd N, windows at both ends, the largest N that fits
+  const int cases[][3] = {{164, 41, 82}, {49, 13, 23}, {100, 0, 64}, {M - 82 + 1, (M - 82 + 1 - 82) / 2, 82}, {1000, 459, 82},
+                          {M - 127, M - 127 - 128, 128}, {M / 2 + 1, 3, 64 * NS < M / 2 ? 64 * NS : M / 2}, {333, 100, 129}, {97, 96, 1}};
+  for (auto& c : cases) {
+    const int N = c[0], lo = c[1], Np = c[2];
+    if (Np > 64 * NS || Np < 1 || lo < 0 || lo + Np > N || N + Np - 1 > M || N < 2) continue;
+    const double err = run_blu_case<R, P, NS>(N, lo, Np, 99u + N);
+    const bool ok = err <= tol;
+    std::printf("%s chirp-z P=%d NS=%d N=%d lo=%d Np=%d relerr=%.3e %s\n", name, P, NS, N, lo, Np, err, ok ? "ok" : "FAIL");
+    bad += !ok;
+  }
+  return bad;
+}
+
 int main() {
   int bad = 0;
+  bad += sweep_blu<double, 4, 2>("f64", 1e-12);
+  bad += sweep_blu<double, 8, 2>("f64", 1e-12);
+  bad += sweep_blu<double, 8, 4>("f64", 1e-12);
+  bad += sweep_blu<double, 16, 2>("f64", 1e-12);
+  bad += sweep_blu<double, 16, 4>("f64", 1e-12);
+  bad += sweep_blu<double, 24, 2>("f64", 1e-12);
+  bad += sweep_blu<double, 32, 2>("f64", 1e-12);
+  bad += sweep_blu<float, 4, 2>("f32", 1e-4);
+  bad += sweep_blu<float, 16, 2>("f32", 1e-4);
+  bad += sweep_blu<float, 24, 4>("f32", 1e-4);
   bad += sweep<double, 2, 2>("f64", 1e-13);
   bad += sweep<double, 4, 2>("f64", 1e-13);
   bad += sweep<double, 4, 4>("f64", 1e-13);

@@ -58,6 +58,15 @@ struct fastmc_ctx {
   void* tw1 = nullptr;     // wave
   void* om = nullptr;      // wave
   void* cw = nullptr;      // wave, S > 1: [S][omS] combination twiddles
+  // chirp-z family (path 2: grid sizes that are not 64 P): M = 64 * blu_P >= N + Np - 1
+  int blu_P = 0;           // 0: not eligible
+  int blu_lo = -1;         // window position the tables below were built for
+  void* blu_tw1 = nullptr; // tw1 of size M
+  void* blu_om = nullptr;  // om for the window [0, Np) of the second transform
+  void* blu_twf = nullptr;
+  void* blu_pre = nullptr;
+  void* blu_vhat = nullptr;
+  void* blu_post = nullptr;
   void* tw1g = nullptr;    // N = 2048 only: tables of the single-pass P = 32 kernels (windows > 256 pixels,
   void* omg = nullptr;     //   host coefficients: TEMPORAL layer screens, centred_fft2)
   double* W = nullptr;
@@ -203,6 +212,25 @@ static bool wave_supported(int N) {
   }
 }
 
+// Default kernel family: wave where N = 64 P, else chirp-z where it applies and the grid is big enough to pay for two
+// transforms per row (below ~96 points the direct kernels win), else direct.
+static bool wave_supported(int N);
+static int default_path(int N, int blu_P) { return wave_supported(N) ? 1 : ((blu_P && N >= 96) ? 2 : 0); }
+
+// Chirp-z family: smallest M = 64 P (P = 4, 8, 16, 24, 32) with M >= N + Np - 1 and a window instantiation
+// (NS = 2: Np <= 128; NS = 4: Np <= 256, P = 8, 16, 24); 0 when there is none.
+static int blu_pick_P(int N, int Np) {
+  if (N < 2) return 0;
+  const int ns = (Np + 63) / 64;
+  if (ns > 4) return 0;
+  for (int P : {4, 8, 16, 24, 32}) {
+    if (64 * P < N + Np - 1) continue;
+    if (ns > 2 && !(P == 8 || P == 16 || P == 24)) continue;
+    return P;
+  }
+  return 0;
+}
+
 // Which window instantiation of the wave family serves this handle: NS = 2 (Np <= 128), NS = 4
 // (Np <= 256; P = 8, 16, 32), NS = P (any window, powers of two), or 0 when none fits the LDS.
 constexpr size_t LDS_MAX = 160 * 1024;
@@ -275,7 +303,8 @@ extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int p
   h->Np = Np;
   h->precision = precision;
   h->rsz = precision == FASTMC_F64 ? 8 : 4;
-  h->path = wave_supported(N) ? 1 : 0;
+  h->blu_P = blu_pick_P(N, Np);
+  h->path = default_path(N, h->blu_P);
   h->S = h->path == 1 ? spec_split(N) : 1;
   h->P = N / 64 / h->S;
   h->NS = (Np + 63) / 64;
@@ -337,7 +366,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   h->last_n_iter = 0;
   h->last_coherent = 0;
   h->batch = 0;
-  h->path = wave_supported(h->N) ? 1 : 0;
+  h->path = default_path(h->N, h->blu_P);
   h->lo = 0;
   h->df = h->dx = h->wsum = 0;
   if (h->layers) { hipFree(h->layers); h->layers = nullptr; h->n_layers = 0; }
@@ -352,7 +381,7 @@ static void destroy_now(fastmc_ctx* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
-  void* ptrs[] = {h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+  void* ptrs[] = {h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers, h->ps_dev};
   for (void* p : ptrs)
@@ -365,7 +394,8 @@ static void destroy_now(fastmc_ctx* h) {
 extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   if (force == 1 && !wave_supported(h->N)) return fail(FASTMC_EINVAL, "wave kernels need N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32");
-  if (force == 0 || force == 1) h->path = force;
+  if (force == 2 && !h->blu_P) return fail(FASTMC_EINVAL, "chirp-z kernels need 64 P >= N + Np - 1 for P in {4, 8, 16, 24, 32} and Np <= 256");
+  if (force >= 0 && force <= 2) h->path = force;
   return h->path;
 }
 
@@ -495,6 +525,26 @@ static int upload_wave_tables(fastmc_ctx* h) {
   return 0;
 }
 
+template <class R>
+static int upload_blu_tables(fastmc_ctx* h) {
+  if (!h->blu_P || h->blu_lo == h->lo) return 0;
+  const int P = h->blu_P, M = 64 * P;
+  h->omS = (h->Np + 7) & ~7;
+  std::vector<cpx<R>> tw1((size_t)P * 64), om((size_t)8 * h->omS), twf(64), pre(M), vhat(M), post(h->omS);
+  build_tw1<R>(tw1.data(), P, cs_turns);
+  build_om<R>(om.data(), h->omS, P, 0, h->Np, false, cs_turns);
+  if (!build_blu_tables<R>(h->N, h->Np, h->lo, P, pre.data(), vhat.data(), post.data(), h->omS, twf.data(), cs_turns))
+    return fail(FASTMC_ESTATE, "chirp-z size does not hold the window");
+  TRY(upload_table<R>(&h->blu_tw1, tw1));
+  TRY(upload_table<R>(&h->blu_om, om));
+  TRY(upload_table<R>(&h->blu_twf, twf));
+  TRY(upload_table<R>(&h->blu_pre, pre));
+  TRY(upload_table<R>(&h->blu_vhat, vhat));
+  TRY(upload_table<R>(&h->blu_post, post));
+  h->blu_lo = h->lo;
+  return 0;
+}
+
 extern "C" int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, double dx) {
   if (!h || !W) return fail(FASTMC_EINVAL, "null argument");
   if (crop_lo < 0 || crop_lo + h->Np > h->N) return fail(FASTMC_EINVAL, "window [crop_lo, crop_lo+Np) outside the grid");
@@ -507,6 +557,10 @@ extern "C" int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, doubl
   h->dx = dx;
   if (!h->W) HIPCHK(hipMalloc((void**)&h->W, n * sizeof(double)));
   HIPCHK(hipMemcpy(h->W, W, n * sizeof(double), hipMemcpyHostToDevice));
+  if (!wave_supported(h->N) && h->blu_P) {
+    if (h->blu_lo != crop_lo) h->blu_lo = -1;
+    TRY(h->precision == FASTMC_F64 ? upload_blu_tables<double>(h) : upload_blu_tables<float>(h));
+  }
   if (wave_supported(h->N) && h->tables_lo != crop_lo) {      // the tables depend on (N, Np, window position) only
     h->tables_lo = -1;
     TRY(h->precision == FASTMC_F64 ? upload_wave_tables<double>(h) : upload_wave_tables<float>(h));
@@ -602,6 +656,44 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
     if (epi == 0) launch_cols_wave<R, P, NS, 0, S>(h, CA);
     else launch_cols_wave<R, P, NS, 1, S>(h, CA);
   }
+}
+
+template <class R, int P, int NS>
+static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  const size_t lds = blu_lds_bytes<R, P, NS>(RA.omS);
+  constexpr int WPB = BluCfg<R, P, NS>::WPB;
+  constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
+  const int blocks = ((RA.N + LR - 1) / LR) * ((RA.nb + BPG - 1) / BPG);
+  {
+    Span s(h, 0);
+    if (mode == 0) {
+      hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_blu<R, P, NS, 0>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+    } else {
+      hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_blu<R, P, NS, 1>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+    }
+  }
+  {
+    Span s(h, 1);
+    const int items = CA.nb * CA.Np;
+    if (epi == 0) {
+      hipFuncSetAttribute((const void*)k_cols_blu<R, P, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_cols_blu<R, P, NS, 0>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+    } else {
+      hipFuncSetAttribute((const void*)k_cols_blu<R, P, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_cols_blu<R, P, NS, 1>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+    }
+  }
+}
+
+template <class R>
+static int dispatch_blu(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  const int ns = h->NS <= 2 ? 2 : 4;
+#define FMC_BLU(PP, NN) if (h->blu_P == PP && ns == NN) { dispatch_blu_pn<R, PP, NN>(h, RA, CA, mode, epi); return 0; }
+  FMC_BLU(4, 2) FMC_BLU(8, 2) FMC_BLU(8, 4) FMC_BLU(16, 2) FMC_BLU(16, 4) FMC_BLU(24, 2) FMC_BLU(24, 4) FMC_BLU(32, 2)
+#undef FMC_BLU
+  return fail(FASTMC_ESTATE, "no chirp-z instantiation for this grid / window");
 }
 
 // N = 2048 (S = 2) and 4096 (S = 4): sub-rows of 1024 points through the P = 16 pipeline
@@ -767,6 +859,15 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     CA.W = h->W;
     CA.sh.enabled = sh ? (h->sh_sep ? 2 : 1) : 0; CA.sh.dcol = h->sh_dcol; CA.sh.coef = h->sh_coef; CA.sh.mean = h->sh_mean; CA.sh.ex = h->sh_ex; CA.sh.ey = h->sh_ey;
     CA.partial = h->partial + (size_t)((bs - fin_start)) * Np * 4; CA.phs = h->phs;
+    if (h->path == 2) {
+      TRY(upload_blu_tables<R>(h));
+      RA.amp = (const R*)h->amp; RA.ampf = h->ampf; RA.tw = (const cpx<R>*)h->blu_tw1; RA.om = (const cpx<R>*)h->blu_om;
+      RA.cw = nullptr; RA.tw_global = 0;
+      RA.blu.twf = (const cpx<R>*)h->blu_twf; RA.blu.pre = (const cpx<R>*)h->blu_pre;
+      RA.blu.vhat = (const cpx<R>*)h->blu_vhat; RA.blu.post = (const cpx<R>*)h->blu_post;
+      CA.tw = RA.tw; CA.om = RA.om; CA.cw = nullptr; CA.tw_global = 0; CA.blu = RA.blu;
+      TRY(dispatch_blu<R>(h, RA, CA, S.mode, S.epi));
+    } else {
     bool wave_ok = h->path == 1;
     bool general_2048 = false;   // N = 2048, window > 256 pixels, host coefficients: single-pass P = 32 kernels
     if (wave_ok) {
@@ -817,6 +918,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       }
     } else {
       TRY(dispatch_direct<R>(h, RA, CA, S.mode, S.epi));
+    }
     }
     if (S.epi == 0) {
       const int64_t done = bs + nb;                 // realisations with partials ready: [fin_start, done)

@@ -1,0 +1,264 @@
+// fmc_bluestein.h -- arbitrary row length N on the wave pipeline: chirp-z (Bluestein) transform, window outputs only.
+//
+// The reference auto-sizes its grid to arbitrary even N (fast/fast.py:176-211: 164 for the shipped example) and
+// users set e.g. NPXLS 1000; the wave kernels of fmc_wavefft.h need N = 64 P.  With a = k + h, b = p - h (h = N // 2,
+// numpy's fftshift on both sides, fast/funcs.py:213-215) the wanted outputs are
+//     out[p] = sum_k in[k] w_N^{a b},      a b = (a^2 + b^2 - (b - a)^2) / 2
+//            = w_2N^{b^2} sum_k (in[k] w_2N^{a^2}) w_2N^{-(b - a)^2}
+// i.e. a correlation of the pre-chirped row u[k] = in[k] w_2N^{(k+h)^2} with the chirp c(n) = w_2N^{-n^2}, needed for
+// the Np window outputs only: a cyclic convolution of length M = 64 P >= N + Np - 1,
+//     y = IDFT_M( DFT_M(u) . DFT_M(v) ),   v[m] = c(m + lo - 2h) for m < Np,  c(m - M + lo - 2h) for m > M - N,
+//     out[lo + t] = w_2N^{b_t^2} y[t],  t < Np.
+// One wavefront does the whole row in registers and LDS:
+//     forward DFT_M with ALL outputs (full_row_fft: the pipeline of fmc_wavefft.h with a real third radix-8 stage
+//     instead of the pruned 8-term sums)  ->  multiply by V^ = DFT_M(v), conjugate  ->  one more LDS exchange back to
+//     the k = lane + 64 j layout  ->  pruned_row_fft for the window [0, Np)  ->  conjugate, multiply by post[t].
+// (IDFT(z) = conj(DFT(conj z)) / M; the 1 / M lives in `post`.)  About 2.7 plain rows of work for any N.
+//
+// Like fmc_wavefft.h the per-lane phases are written against an executor, so that emu_wavefft.cpp runs the same index
+// arithmetic on the host.
+#pragma once
+#include "fmc_core.h"
+#include "fmc_wavefft.h"
+
+namespace fmc {
+
+// LDS images of the two extra exchanges (8-byte elements, conflict-free by construction; searched with
+// tools/lds_bank_check.py under the lane-group rules of MI355X_MICROARCH.md):
+//   full stage 2b : F[a][b0][l0] at a + FL l0 + FBF b0, written by lane (l0 = lane & 7, i = lane >> 3) for a = i + 8 jj,
+//                   read by lane (i = lane & 7, b0 = lane >> 3): 16-lane write groups and 32-lane read groups hit
+//                   distinct banks for FL = P + 2 and FBF = 8 P + 24 (46 for P = 4);
+//   re-layout     : Z[x] at swz(x), written in the (a, b0; b1) layout of stage 2b, read as x = lane + 64 j.
+template <class R, int P>
+struct BluGeom {
+  using G = WaveGeom<R, P>;
+  static constexpr int M = WAVE * P;
+  static constexpr int FL = P + 2;
+  static constexpr int FBF = (P == 4) ? 46 : 8 * P + 24;
+  static constexpr int X1 = G::XELEMS > 8 * FBF ? G::XELEMS : 8 * FBF;
+  static constexpr int XELEMS = X1 > M ? X1 : M;
+  static_assert(P == 4 || P == 8 || P == 16 || P == 24 || P == 32, "chirp-z sizes: M = 256, 512, 1024, 1536, 2048");
+  static FMC_HD int swz(int x) {
+    if (P == 16) return x ^ (((x >> 3) & 3) << 2);
+    if (P == 32) return x ^ (((x >> 4) & 3) << 2);
+    return x;
+  }
+};
+
+// Forward DFT_M of the P values per lane (k = lane + 64 j), ALL outputs, left in registers:
+// lane (i = lane & 7, b0 = lane >> 3), slot jj * 8 + b1  <->  X[(i + 8 jj) + P (b0 + 8 b1)]   (lanes with i + 8 jj >= P idle).
+//   twf[b0 * 8 + l0] = w_64^{l0 b0}
+template <class R, int P, int NS, class Exec>
+FMC_HD void full_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* twf) {
+  using G = WaveGeom<R, P>;
+  using B = BluGeom<R, P>;
+  using X = Xch<R>;
+  constexpr int NC = X::NC;
+  // ---- stage 1: radix-P in registers, twiddle
+  ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+    cpx<R> z[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) z[j] = r.v[j];
+    dft_reg<P, R>(z);
+    r.v[0] = z[0];
+#pragma unroll
+    for (int a = 1; a < P; ++a) r.v[a] = cmul(z[a], tw1[a * WAVE + lane]);
+  });
+  // ---- exchange 1 + stage 2a (as in pruned_row_fft)
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) ex.st(xbuf + a * G::SE + lane, X::pack(r.v[a], c));
+    });
+    ex.sync();
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int l0 = lane & 7, i = lane >> 3;
+#pragma unroll
+      for (int jj = 0; jj < G::NB; ++jj)
+        if ((P % 8 == 0) || i + 8 * jj < P) {
+#pragma unroll
+          for (int m = 0; m < 8; ++m) X::unpack(r.v[jj * 8 + m], ex.ld(xbuf + (i + 8 * jj) * G::SE + l0 + 8 * m), c);
+        }
+    });
+    ex.sync();
+  }
+  ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+#pragma unroll
+    for (int jj = 0; jj < G::NB; ++jj) {
+      cpx<R> t[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) t[m] = r.v[jj * 8 + m];
+      fft_dif<8, R>(t);
+#pragma unroll
+      for (int b0 = 0; b0 < 8; ++b0) r.v[jj * 8 + b0] = t[brev(b0, 3)];
+    }
+  });
+  // ---- exchange 2 (full image) + stage 2b as a real radix-8 stage
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int l0 = lane & 7, i = lane >> 3;
+#pragma unroll
+      for (int jj = 0; jj < G::NB; ++jj)
+        if ((P % 8 == 0) || i + 8 * jj < P) {
+#pragma unroll
+          for (int b0 = 0; b0 < 8; ++b0) ex.st(xbuf + (i + 8 * jj) + B::FL * l0 + B::FBF * b0, X::pack(r.v[jj * 8 + b0], c));
+        }
+    });
+    ex.sync();
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int i = lane & 7, b0 = lane >> 3;
+#pragma unroll
+      for (int jj = 0; jj < G::NB; ++jj)
+        if ((P % 8 == 0) || i + 8 * jj < P) {
+#pragma unroll
+          for (int l0 = 0; l0 < 8; ++l0) X::unpack(r.v[jj * 8 + l0], ex.ld(xbuf + (i + 8 * jj) + B::FL * l0 + B::FBF * b0), c);
+        }
+    });
+    ex.sync();
+  }
+  ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+    const int i = lane & 7, b0 = lane >> 3;
+#pragma unroll
+    for (int jj = 0; jj < G::NB; ++jj)
+      if ((P % 8 == 0) || i + 8 * jj < P) {
+        cpx<R> t[8];
+        t[0] = r.v[jj * 8];
+#pragma unroll
+        for (int l0 = 1; l0 < 8; ++l0) t[l0] = cmul(r.v[jj * 8 + l0], twf[b0 * 8 + l0]);
+        fft_dif<8, R>(t);
+#pragma unroll
+        for (int b1 = 0; b1 < 8; ++b1) r.v[jj * 8 + b1] = t[brev(b1, 3)];
+      }
+  });
+}
+
+// The whole chirp-z row: on entry r.v[j] = u[lane + 64 j] (pre-chirped, zero beyond N); on return slot s of lane l
+// holds Y[t], t = l + 64 s < Np, with out[lo + t] = post[t] * conj(Y[t]).
+//   vhat: DFT_M(v) in natural order (global memory / L2);  om: tables of pruned_row_fft for the window [0, Np), no sign.
+template <class R, int P, int NS, class Exec>
+FMC_HD void bluestein_row(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om, int omS,
+                          const cpx<R>* twf, const cpx<R>* vhat, int Np) {
+  using G = WaveGeom<R, P>;
+  using B = BluGeom<R, P>;
+  using X = Xch<R>;
+  constexpr int NC = X::NC;
+  full_row_fft<R, P, NS>(ex, xbuf, tw1, twf);
+  // pointwise product with V^, conjugated (the inverse transform is done as conj(DFT(conj .)))
+  ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+    const int i = lane & 7, b0 = lane >> 3;
+#pragma unroll
+    for (int jj = 0; jj < G::NB; ++jj)
+      if ((P % 8 == 0) || i + 8 * jj < P) {
+#pragma unroll
+        for (int b1 = 0; b1 < 8; ++b1) {
+          const cpx<R> v = vhat[(i + 8 * jj) + P * (b0 + 8 * b1)];
+          const cpx<R> u = r.v[jj * 8 + b1];
+          r.v[jj * 8 + b1] = mk<R>(u.x * v.x - u.y * v.y, -(u.x * v.y + u.y * v.x));
+        }
+      }
+  });
+  // back to the input layout of the pipeline: x = lane + 64 j
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int i = lane & 7, b0 = lane >> 3;
+#pragma unroll
+      for (int jj = 0; jj < G::NB; ++jj)
+        if ((P % 8 == 0) || i + 8 * jj < P) {
+#pragma unroll
+          for (int b1 = 0; b1 < 8; ++b1)
+            ex.st(xbuf + B::swz((i + 8 * jj) + P * (b0 + 8 * b1)), X::pack(r.v[jj * 8 + b1], c));
+        }
+    });
+    ex.sync();
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) X::unpack(r.v[j], ex.ld(xbuf + B::swz(lane + WAVE * j)), c);
+    });
+    ex.sync();
+  }
+  pruned_row_fft<R, P, NS>(ex, xbuf, tw1, om, omS, 0, Np);
+}
+
+// ---------------------------------------------------------------- host-side tables (float64 trigonometry by `cs`)
+// pre[k]  = w_2N^{(k+h)^2}, k < N, zero up to M        (input chirp, with the input-side fftshift)
+// vhat    = DFT_M(v)                                   (chirp kernel of the window, see the header)
+// post[t] = w_2N^{(lo - h + t)^2} / M, t < Np          (output chirp, with the output-side fftshift and the 1 / M of the IDFT)
+// twf[b0 * 8 + l0] = w_64^{l0 b0}
+// Returns false when M < N + Np - 1 (the cyclic convolution would alias).
+template <class R, class CosSin>
+inline bool build_blu_tables(int N, int Np, int lo, int P, cpx<R>* pre, cpx<R>* vhat, cpx<R>* post, int post_len, cpx<R>* twf,
+                             CosSin cs) {
+  const int M = WAVE * P, h = N / 2;
+  if (M < N + Np - 1) return false;
+  auto chirp = [&](long long n, double sign, double* c, double* s) {   // exp(sign * i pi n^2 / N)
+    const long long q = (n * n) % (2LL * N);
+    double cc, ss;
+    cs((double)q / (2.0 * N), &cc, &ss);
+    *c = cc;
+    *s = sign * ss;
+  };
+  for (int k = 0; k < M; ++k) {
+    if (k < N) {
+      double c, s;
+      chirp(k + h, -1.0, &c, &s);
+      pre[k] = mk<R>((R)c, (R)s);
+    } else {
+      pre[k] = mk<R>((R)0, (R)0);
+    }
+  }
+  for (int t = 0; t < post_len; ++t) {
+    if (t < Np) {
+      double c, s;
+      chirp(lo - h + t, -1.0, &c, &s);
+      post[t] = mk<R>((R)(c / M), (R)(s / M));
+    } else {
+      post[t] = mk<R>((R)0, (R)0);
+    }
+  }
+  // v and its DFT (naive O(M^2) in long double with exact twiddle indices: once per problem)
+  struct LD { long double x, y; };
+  LD* v = new LD[M];
+  LD* w = new LD[M];
+  for (int m = 0; m < M; ++m) {
+    v[m].x = v[m].y = 0;
+    long long n;
+    bool used = false;
+    if (m < Np) { n = (long long)m + lo - 2 * h; used = true; }
+    else if (m > M - N) { n = (long long)m - M + lo - 2 * h; used = true; }
+    if (used) {
+      double c, s;
+      chirp(n < 0 ? -n : n, +1.0, &c, &s);
+      v[m].x = c;
+      v[m].y = s;
+    }
+    double c, s;
+    cs((double)m / M, &c, &s);
+    w[m].x = c;
+    w[m].y = -s;                                  // w_M^m
+  }
+  for (int q = 0; q < M; ++q) {
+    long double ar = 0, ai = 0;
+    int e = 0;
+    for (int m = 0; m < M; ++m) {
+      ar += v[m].x * w[e].x - v[m].y * w[e].y;
+      ai += v[m].x * w[e].y + v[m].y * w[e].x;
+      e += q;
+      if (e >= M) e -= M;
+    }
+    vhat[q] = mk<R>((R)ar, (R)ai);
+  }
+  delete[] v;
+  delete[] w;
+  for (int b0 = 0; b0 < 8; ++b0)
+    for (int l0 = 0; l0 < 8; ++l0) {
+      double c, s;
+      cs((double)((l0 * b0) % 64) / 64.0, &c, &s);
+      twf[b0 * 8 + l0] = mk<R>((R)c, (R)(-s));
+    }
+  return true;
+}
+
+}  // namespace fmc

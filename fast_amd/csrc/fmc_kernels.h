@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include "fmc_core.h"
 #include "fmc_wavefft.h"
+#include "fmc_bluestein.h"
 
 namespace fmc {
 
@@ -120,6 +121,15 @@ __device__ __forceinline__ float draw_logamp_normal(RngKey key, uint64_t iter) {
 }
 
 // ------------------------------------------------------------------ shared parameter blocks
+// Tables of the chirp-z kernels (fmc_bluestein.h), all in global memory except twf (staged into LDS).
+template <class R>
+struct BluArgs {
+  const cpx<R>* twf;            // [64]   w_64^{l0 b0}
+  const cpx<R>* pre;            // [M]    input chirp (zero beyond N)
+  const cpx<R>* vhat;           // [M]    DFT_M of the chirp kernel
+  const cpx<R>* post;           // [omS]  output chirp / M
+};
+
 template <class R>
 struct RowArgs {
   int N, Np, lo, nb;            // grid size, window size, first window index, realisations in this launch
@@ -135,6 +145,7 @@ struct RowArgs {
   uint64_t g0;                  // global index of realisation b = 0
   const double* cre;            // host-coefficient mode: [nb][N][N] real parts
   const double* cim;
+  BluArgs<R> blu;               // chirp-z family only
 };
 
 struct SubharmArgs {
@@ -159,6 +170,7 @@ struct ColArgs {
   SubharmArgs sh;
   double* partial;              // [nb][Np][4]  (EPI 0)
   double* phs;                  // [2][nb][Np][Np] (EPI 1): Re screens then Im screens of this launch
+  BluArgs<R> blu;               // chirp-z family only
 };
 
 // phi -> contribution of one window pixel to the four sums; sub-harmonics added first.
@@ -540,6 +552,151 @@ void k_cols_wave(ColArgs<R> A) {
     const int yi = lane + WAVE * s;
     if (yi < A.Np) {
       R p1 = regs.xr[s], p2 = regs.xi[s];
+      pixel_phase<R>(A.sh, b, A.Np, yi, xi, p1, p2);
+      if (EPI == 1) {
+        const size_t plane = (size_t)A.Np * A.Np;
+        A.phs[((size_t)b) * plane + (size_t)yi * A.Np + xi] = (double)p1;
+        A.phs[((size_t)(A.nb + b)) * plane + (size_t)yi * A.Np + xi] = (double)p2;
+      } else {
+        const double wgt = A.W[(size_t)yi * A.Np + xi];
+        double s1, c1, s2, c2;
+        sincos_r(p1, s1, c1);
+        sincos_r(p2, s2, c2);
+        acc[0] += wgt * c1; acc[1] += wgt * s1; acc[2] += wgt * c2; acc[3] += wgt * s2;
+      }
+    }
+  }
+  if (EPI == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane == 0) {
+      double* o = A.partial + ((size_t)b * A.Np + xi) * 4;
+      o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+    }
+  }
+}
+
+// ================================================================== chirp-z family (any N with 64 P >= N + Np - 1)
+// The row / column passes of the wave family for grid sizes that are not 64 P: every 1-D transform is a chirp-z
+// (Bluestein) transform on the same pipeline (fmc_bluestein.h), window outputs only.  Same generator streams as the
+// direct family (64 streams per row, stream L = kx mod 64), so the two agree to rounding.
+// Waves per workgroup.  The chirp-z row keeps P complex values, the chirp tables' loads and the generator live at once:
+// at P = 16 (f64) twelve waves (168-VGPR cap) spill 270 B per lane and run 17.6 ms per 5000 realisations at N = 500,
+// eight waves (256-VGPR cap, no spill) 12.8 ms; at P = 24 eight waves (164 B of spill) beat four (no spill, one wave per
+// SIMD) 48.9 to 70.3 ms at N = 1000; at P = 32 four waves beat six (690 B of spill) 140 to 207 ms at N = 1500.
+#ifndef FMC_BLU_WPB16
+#define FMC_BLU_WPB16 8
+#endif
+#ifndef FMC_BLU_WPB24
+#define FMC_BLU_WPB24 8
+#endif
+template <class R, int P, int NS> struct BluCfg {
+  static constexpr int W0 = WaveCfg<R, P, NS>::WPB;
+  static constexpr int W1 = (NS == 4 && W0 > 8) ? 8 : W0;     // 256-pixel window tables: 8 waves fit the LDS
+  static constexpr int CAP = sizeof(R) == 8 ? (P >= 32 ? 4 : (P >= 24 ? FMC_BLU_WPB24 : (P >= 16 ? FMC_BLU_WPB16 : 12))) : 12;
+  static constexpr int WPB = W1 > CAP ? CAP : W1;
+};
+template <class R, int P, int NS>
+__host__ __device__ constexpr size_t blu_lds_bytes(int omS) {
+  return (size_t)(P * WAVE + 8 * omS + 64) * sizeof(cpx<R>) + (size_t)BluCfg<R, P, NS>::WPB * BluGeom<R, P>::XELEMS * 8;
+}
+
+template <class R, int P, int NS, int MODE>
+__global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using BG = BluGeom<R, P>;
+  using E = typename Xch<R>::E;
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  cpx<R>* s_om = s_tw + P * WAVE;
+  cpx<R>* s_twf = s_om + 8 * A.omS;
+  E* s_x = reinterpret_cast<E*>(s_twf + 64);
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) s_twf[i] = A.blu.twf[i];
+  load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
+
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  E* xbuf = s_x + w * BG::XELEMS;
+  const int N = A.N;
+  LaneRegs<R, P, NS> regs;
+  GpuExec<R, P, NS> ex{lane, regs};
+  constexpr int WPB = BluCfg<R, P, NS>::WPB;
+  constexpr int LR = 128 / (int)sizeof(cpx<R>);
+  static_assert((ROWS_PER_WAVE * WPB) % LR == 0, "tile must hold whole lines");
+  constexpr int BPG = ROWS_PER_WAVE * WPB / LR;
+  const int nbb = (A.nb + BPG - 1) / BPG;
+  const int b0 = (blockIdx.x % nbb) * BPG;
+  const int row0 = (blockIdx.x / nbb) * LR;
+  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+    const int flat = rr * WPB + w;
+    const int b = b0 + flat / LR;
+    if (b >= A.nb) break;                                // wave-uniform
+    const int ky = row0 + flat % LR;
+    if (ky >= N) continue;                               // wave-uniform (N need not be a multiple of LR)
+    const uint64_t g = A.g0 + (uint64_t)b;
+    if (MODE == 0) {
+      const float* ampf = A.ampf + (size_t)ky * N;
+      xoshiro128p rs = row_stream(A.key, g, ky, lane, WAVE);
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int kx = lane + WAVE * j;
+        regs.v[j] = kx < N ? cmul(draw_coloured<R>(rs, ampf[kx]), A.blu.pre[kx]) : mk<R>((R)0, (R)0);
+      }
+    } else {
+      const size_t base = ((size_t)b * N + ky) * N;
+      const R* amp = A.amp + (size_t)ky * N;
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int kx = lane + WAVE * j;
+        regs.v[j] = kx < N ? cmul(cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]), A.blu.pre[kx]) : mk<R>((R)0, (R)0);
+      }
+    }
+    bluestein_row<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, s_twf, A.blu.vhat, A.Np);
+    cpx<R>* out = A.V + (size_t)b * A.Np * N + ky;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int oi = lane + WAVE * s;
+      if (oi < A.Np) {
+        const cpx<R> q = A.blu.post[oi];
+        out[(size_t)oi * N] = mk<R>(q.x * regs.xr[s] + q.y * regs.xi[s], q.y * regs.xr[s] - q.x * regs.xi[s]);   // post * conj(Y)
+      }
+    }
+  }
+}
+
+template <class R, int P, int NS, int EPI>
+__global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_cols_blu(ColArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using BG = BluGeom<R, P>;
+  using E = typename Xch<R>::E;
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  cpx<R>* s_om = s_tw + P * WAVE;
+  cpx<R>* s_twf = s_om + 8 * A.omS;
+  E* s_x = reinterpret_cast<E*>(s_twf + 64);
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) s_twf[i] = A.blu.twf[i];
+  load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
+
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  E* xbuf = s_x + w * BG::XELEMS;
+  const int item = blockIdx.x * BluCfg<R, P, NS>::WPB + w;
+  if (item >= A.nb * A.Np) return;   // whole wave exits; no block barrier follows
+  const int b = item / A.Np;
+  const int xi = item % A.Np;
+  const int N = A.N;
+  LaneRegs<R, P, NS> regs;
+  GpuExec<R, P, NS> ex{lane, regs};
+  const cpx<R>* col = A.V + ((size_t)b * A.Np + xi) * N;
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const int ky = lane + WAVE * j;
+    regs.v[j] = ky < N ? cmul(col[ky], A.blu.pre[ky]) : mk<R>((R)0, (R)0);
+  }
+  bluestein_row<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, s_twf, A.blu.vhat, A.Np);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int yi = lane + WAVE * s;
+    if (yi < A.Np) {
+      const cpx<R> q = A.blu.post[yi];
+      R p1 = q.x * regs.xr[s] + q.y * regs.xi[s], p2 = q.y * regs.xr[s] - q.x * regs.xi[s];      // post * conj(Y)
       pixel_phase<R>(A.sh, b, A.Np, yi, xi, p1, p2);
       if (EPI == 1) {
         const size_t plane = (size_t)A.Np * A.Np;

@@ -112,12 +112,21 @@ class Fast():
         self._handle = self._group.handles[0]
         if p['GPU_BATCH']:
             self._group.set_batch(p['GPU_BATCH'])
+        if p['GPU_KERNELS'] != 'auto':
+            if p['GPU_KERNELS'] not in _lib.KERNEL_PATHS:
+                raise Exception("GPU_KERNELS must be 'auto', 'wave', 'chirpz' or 'direct'")
+            self._group.each(lambda h, i: h.kernel_path(_lib.KERNEL_PATHS[p['GPU_KERNELS']]))
         self.compute_powerspec()
-        if self._handle.kernel_path() == 0 and self.Npxls >= 128 and not self.temporal:
+        if self._handle.kernel_path() != 1 and self.Npxls >= 128 and not self.temporal:
             below = [n for n in host.WAVE_FFT_SIZES if n <= self.Npxls][-1:]
             above = [n for n in host.ROUND_UP_SIZES if n >= self.Npxls][:1]
-            logger.warning(f"NPXLS = {self.Npxls} runs on the direct O(N^2 Np) kernels (about 10x slower than the "
-                           f"FFT kernels); nearest fast grid sizes: {', '.join(str(n) for n in below + above)}")
+            near = ', '.join(str(n) for n in below + above)
+            if self._handle.kernel_path() == 2:
+                logger.info(f"NPXLS = {self.Npxls} is not 64 P: chirp-z kernels (about 3x the work per row of the plain FFT "
+                            f"kernels); nearest plain sizes: {near}")
+            else:
+                logger.warning(f"NPXLS = {self.Npxls} runs on the direct O(N^2 Np) kernels (about 10x slower than the "
+                               f"FFT kernels); nearest fast grid sizes: {near}")
         self._group.set_pupil(prob.W, pup.crop_lo, self.dx)
         if self.subharmonics:
             self._group.set_subharm(self.powerspec_subharm, self._sh_fx, self._sh_fy, self._sh_df)

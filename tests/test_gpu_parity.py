@@ -865,3 +865,61 @@ def test_subharm_bookkeeping_attributes_like_the_reference():
     q.update({"GPU_DEVICE": 0})
     plain = fast_amd.Fast(q)
     assert plain.powerspec_subharm is None and plain.phs_var_subharm is None and plain.phs_var_weights_sh is None
+
+
+# ------------------------------------------------------------------ chirp-z family: grid sizes that are not 64 P
+@pytest.mark.parametrize("N,Np", [(164, 82), (100, 40), (49, 23), (33, 9), (250, 129), (500, 82), (943, 82), (1000, 82), (1455, 82),
+                                  (1280 - 255, 256), (1900, 100), (333, 333 // 3)])
+@pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 5e-5)])
+def test_chirpz_kernels_match_oracle_fft(N, Np, prec, tol):
+    """Arbitrary N (the reference auto-sizes to e.g. 164, fast.py:176-211; odd N with numpy's asymmetric fftshift) on the
+    chirp-z kernels: screens from host coefficients against the oracle's FFT-branch transform, and against the direct family."""
+    ps, df = _vk_spectrum(N, 0.01, 25.0)
+    rng = np.random.default_rng(N + Np)
+    cr, ci = rng.normal(size=(2, N, N)), rng.normal(size=(2, N, N))
+    want = R.crop(R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df)), N, Np)
+    for lo in ((N - Np) // 2, 0, N - Np):
+        h = _lib.Handle(N, Np, prec, 0)
+        assert h.kernel_path() == (2 if N >= 96 else 0)
+        h.kernel_path(2)
+        h.set_spectrum(ps, df)
+        h.set_pupil(np.ones((Np, Np)), lo, 0.01)
+        got = h.screens_coeffs(cr, ci)
+        if lo != (N - Np) // 2:
+            full = R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df))
+            want_lo = full[:, lo:lo + Np, lo:lo + Np]
+        else:
+            want_lo = want
+        assert np.abs(got - want_lo).max() <= tol * np.abs(want).max()
+    h.kernel_path(0)
+    got_d = h.screens_coeffs(cr[:1], ci[:1])
+    assert np.abs(got_d[0] - want_lo[0]).max() <= tol * np.abs(want).max()
+
+
+@pytest.mark.parametrize("N,Np", [(164, 82), (1000, 82), (300, 150)])
+def test_chirpz_device_generator_equals_direct_family(N, Np):
+    h, ps, df, W = _small_problem(N, Np)
+    assert h.kernel_path() == 2
+    a = h.run(7, 3, 6, None, 0.02)
+    coh = h.run(7, 3, 6, None, 0.02, coherent=True)
+    np.testing.assert_allclose(np.abs(coh) ** 2, a, rtol=1e-12)
+    h.set_batch(4)
+    np.testing.assert_array_equal(h.run(7, 3, 6, None, 0.02), a)
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.run(7, 3, 6, None, 0.02), a, rtol=1e-9)
+    # and the restated generator + oracle
+    coeffs = np.stack([devrng.device_coefficients(7, 3 + j, N) for j in range(6)])
+    chi = devrng.device_logamp_normals(7, 6, 12) * np.sqrt(0.02)
+    la = np.concatenate([chi[0::2], chi[1::2]])
+    np.testing.assert_allclose(a, R.powers_from_coefficients(coeffs, ps, df, W, 0.01, la), rtol=2e-3)
+
+
+@pytest.mark.parametrize("case", ["default164", "oddN", "oddNp", "autosize", "subharm"])
+def test_fast_run_reproduces_reference_on_chirpz_kernels(case):
+    """The reference's own grids (auto-sized 164, odd 49, 48, 64) forced onto the chirp-z family: same SEED -> same `_r`."""
+    g = load_golden("e2e_" + case)
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_RNG": "host", "GPU_DEVICE": 0, "GPU_KERNELS": "chirpz"})
+    sim = fast_amd.Fast(p)
+    assert sim._handle.kernel_path() == 2
+    np.testing.assert_allclose(sim.run()._r, g["r"], rtol=1e-9)

@@ -242,7 +242,10 @@ static int pick_ns(const fastmc_ctx* h) {
   if constexpr (has_ns4(PP)) {
     if (h->NS <= 4 && wave_lds_bytes<R, PP, 4>(h->omS) <= LDS_MAX) return 4;
   }
-  if (h->S > 1) return 0;    // split rows: windows up to 256 pixels only
+  if constexpr (PP == 16) {  // windows of 257-512 pixels (also on the split grids 2048 / 4096): eight output slots per lane
+    if (h->NS <= 8 && wave_lds_bytes<R, PP, 8>(h->omS) <= LDS_MAX) return 8;
+  }
+  if (h->S > 1) return 0;    // split rows: windows up to 512 pixels only
   if constexpr (is_pow2(PP) && PP >= 4) {
     if (h->NS <= PP && wave_lds_bytes<R, PP, PP>(h->omS) <= LDS_MAX) return PP;
   }
@@ -257,6 +260,7 @@ static void wave_config(const fastmc_ctx* h, int* ns, int* wpb) {
     *ns = pick_ns<R, PP>(h);                                                                                 \
     *wpb = WaveCfg<R, PP, 2>::WPB;                                                                           \
     if constexpr (has_ns4(PP)) { if (*ns == 4) *wpb = WaveCfg<R, PP, 4>::WPB; }                              \
+    if constexpr (PP == 16) { if (*ns == 8) *wpb = WaveCfg<R, PP, 8>::WPB; }                                   \
     if constexpr (is_pow2(PP) && PP >= 4) { if (*ns == PP && PP > 2) *wpb = WaveCfg<R, PP, PP>::WPB; }       \
     break;
   switch (h->P) {
@@ -702,6 +706,7 @@ static int dispatch_wave_split(fastmc_ctx* h, const RowArgs<R>& RA, const ColArg
   const int ns = pick_ns<R, 16>(h);
   if (ns == 2) dispatch_wave<R, 16, 2, S>(h, RA, CA, mode, epi);
   else if (ns == 4) dispatch_wave<R, 16, 4, S>(h, RA, CA, mode, epi);
+  else if (ns == 8) dispatch_wave<R, 16, 8, S>(h, RA, CA, mode, epi);
   else return fail(FASTMC_ESTATE, "no split-row instantiation for this window");
   return 0;
 }
@@ -713,6 +718,8 @@ static int dispatch_wave_ns(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
   if (ns == 2) dispatch_wave<R, P, 2>(h, RA, CA, mode, epi);
   else if (ns == 4 && has_ns4(P)) {
     if constexpr (has_ns4(P)) dispatch_wave<R, P, 4>(h, RA, CA, mode, epi);
+  } else if (ns == 8 && P == 16) {
+    if constexpr (P == 16) dispatch_wave<R, 16, 8>(h, RA, CA, mode, epi);
   } else if (ns == P) {
     if constexpr (is_pow2(P)) dispatch_wave<R, P, P>(h, RA, CA, mode, epi);
   }

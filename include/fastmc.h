@@ -162,9 +162,13 @@ int fastmc_link_metrics(fastmc_t* h, int device_id, const double* samples, int64
  * launch counts.  times_ms: 4 doubles, launches: 4 int64. */
 int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches);
 
-/* Which kernel family the handle uses: 0 = direct (any N), 1 = wave-FFT (N = 64 P with
- * P = 2^k times 1, 3, 5, 7 or 9, P <= 32: 128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024,
- * 1152, 1280, 1536, 1792, 2048).  force: -1 query only, 0/1 select (1 fails with EINVAL if unsupported). */
+/* Which kernel family the handle uses:
+ *   1 = wave-FFT (N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, P <= 32: 128, 192, 256, 320, 384, 448, 512, 576, 640, 768,
+ *       896, 1024, 1152, 1280, 1536, 1792, and 2048 / 4096 as interleaved sub-rows of 1024);
+ *   2 = chirp-z (any other N, odd included, with 64 P >= N + Np - 1 for P in {4, 8, 16, 24, 32} and Np <= 256: every 1-D
+ *       transform as a Bluestein convolution on the same pipeline; default for N >= 96);
+ *   0 = direct O(N^2 Np) pruned DFT (any N <= 4096; tiny grids, huge windows, cross-check of the other two).
+ * force: -1 query only, 0 / 1 / 2 select (fails with EINVAL if the family does not serve this (N, Np)). */
 int fastmc_kernel_path(fastmc_t* h, int force);
 
 /* Realisations in flight per launch (batch).  0 = library default. */

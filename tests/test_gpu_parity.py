@@ -66,7 +66,8 @@ def test_screens_match_reference_fft_kat(N, prec, tol):
 # ------------------------------------------------------------------ screens: wave family vs numpy FFT
 @pytest.mark.parametrize("N,Np", [(128, 22), (128, 128), (192, 82), (320, 33), (384, 128), (640, 82), (768, 82), (1280, 82), (1536, 101), (768, 300), (448, 82), (576, 82), (896, 82), (1152, 82), (1792, 82),
                                   (256, 82), (256, 200), (256, 256), (512, 82), (1024, 82), (2048, 82), (512, 23), (1024, 200), (512, 512), (1024, 1), (2048, 129),
-                                  (512, 150), (1024, 129), (1024, 256), (1024, 257), (2048, 256), (2048, 300), (4096, 82), (4096, 200)])
+                                  (512, 150), (1024, 129), (1024, 256), (1024, 257), (2048, 256), (2048, 300), (4096, 82), (4096, 200),
+                                  (1024, 402), (1024, 512), (2048, 402), (2048, 512)])
 @pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 5e-5)])
 def test_wave_kernels_match_oracle_fft(N, Np, prec, tol):
     ps, df = _vk_spectrum(N, 0.01, 25.0)
@@ -923,3 +924,14 @@ def test_fast_run_reproduces_reference_on_chirpz_kernels(case):
     sim = fast_amd.Fast(p)
     assert sim._handle.kernel_path() == 2
     np.testing.assert_allclose(sim.run()._r, g["r"], rtol=1e-9)
+
+
+def test_wide_windows_on_split_grids_use_the_wave_family():
+    """Windows of 257-512 pixels (a 2.6-5 m aperture at 1 cm) at 2048^2 stay on the wave kernels (eight output slots per
+    lane) with the device generator, and agree with the direct family."""
+    h, ps, df, W = _small_problem(2048, 402)
+    assert h.kernel_path() == 1
+    a = h.run(5, 0, 2, None, 0.01)
+    assert h.last_timing()["rows_launches"] == 1 and np.isfinite(a).all()
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.run(5, 0, 2, None, 0.01), a, rtol=1e-9)

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Bank-conflict checker / layout search for the 8-byte LDS exchange images of fmc_bluestein.h (see tools/README.md)."""
+# LDS bank-conflict checker for 8-byte accesses (MI355X_MICROARCH.md LDS table)
+#  ds_read_b64 : lane groups {0-31},{32-63}; bank of dword d = d mod 64 ; each lane touches dwords 2e, 2e+1
+#  ds_write_b64: 4 groups of 16 contiguous lanes; bank = dword mod 32
+import itertools
+def cycles(addrs, kind):
+    # addrs: list of 64 element indices (8-byte elements) or None for inactive
+    groups = [range(0,32), range(32,64)] if kind=="r" else [range(16*g,16*g+16) for g in range(4)]
+    nb = 64 if kind=="r" else 32
+    tot=0
+    for g in groups:
+        per_bank={}
+        for l in g:
+            e=addrs[l]
+            if e is None: continue
+            for d in (2*e, 2*e+1):
+                per_bank.setdefault(d%nb,set()).add(d)
+        tot+=max([len(v) for v in per_bank.values()] or [0])
+    return tot
+def check_full2b(P, FL, FB):
+    worst_r=worst_w=0
+    NB=(P+7)//8
+    # writes: lane (l0=lane&7, i=lane>>3), per (jj,b0): addr=(i+8jj)+FL*l0+FB*b0
+    for jj in range(NB):
+        for b0 in range(8):
+            a=[((l>>3)+8*jj)+FL*(l&7)+FB*b0 if (l>>3)+8*jj<P else None for l in range(64)]
+            worst_w=max(worst_w,cycles(a,"w"))
+    # full reads: lane (i=lane&7 -> a=i+8jj, b0=lane>>3), per (jj,l0)
+    for jj in range(NB):
+        for l0 in range(8):
+            a=[((l&7)+8*jj)+FL*l0+FB*(l>>3) if (l&7)+8*jj<P else None for l in range(64)]
+            worst_r=max(worst_r,cycles(a,"r"))
+    return worst_w, worst_r
+for P in (4,8,16,24,32):
+    FL=P+2
+    best=None
+    for FB in range((P-1)+FL*7+1, (P-1)+FL*7+1+80):
+        w,r=check_full2b(P,FL,FB)
+        if w<=4 and r<=2:
+            best=FB;break
+    print("P",P,"FL",FL,"FB",best, check_full2b(P,FL,best) if best else None, "XELEMS", 8*best if best else None, "old", max(P*72, 8*8*FL))
+print("relayout")
+def check_relayout(P, adr):
+    NB=(P+7)//8
+    ww=rr=0
+    for jj in range(NB):
+        for b1 in range(8):
+            a=[adr(((l&7)+8*jj)+P*((l>>3)+8*b1)) if (l&7)+8*jj<P else None for l in range(64)]
+            ww=max(ww,cycles(a,"w"))
+    for j in range(P):
+        a=[adr(l+64*j) for l in range(64)]
+        rr=max(rr,cycles(a,"r"))
+    return ww,rr
+for P in (4,8,16,24,32):
+    found=None
+    for W in (8,16,32,64,P,2*P,4*P,8*P):
+        for pad in range(0,9):
+            adr=lambda x,W=W,pad=pad: x+pad*(x//W)
+            w,r=check_relayout(P,adr)
+            if w<=4 and r<=2:
+                size=adr(64*P-1)+1
+                if found is None or size<found[2]: found=(W,pad,size)
+    print("P",P,found)
+print("relayout2")
+def check_relayout2(P, adr, mapping):
+    NB=(P+7)//8
+    ww=rr=0
+    for jj in range(NB):
+        for b1 in range(8):
+            a=[]
+            for l in range(64):
+                i,b0 = ((l&7),(l>>3)) if mapping==0 else ((l>>3),(l&7))
+                a.append(adr((i+8*jj)+P*(b0+8*b1)) if i+8*jj<P else None)
+            ww=max(ww,cycles(a,"w"))
+    for j in range(P):
+        a=[adr(l+64*j) for l in range(64)]
+        rr=max(rr,cycles(a,"r"))
+    return ww,rr
+P=16
+res=[]
+for mapping in (0,1):
+  for W1 in (8,16,32):
+    for p1 in range(0,33):
+      for W2 in (64,128,256):
+        for p2 in range(0,17):
+            adr=lambda x: x+p1*(x//W1)+p2*(x//W2)
+            w,r=check_relayout2(P,adr,mapping)
+            if w<=4 and r<=2:
+                res.append((adr(64*P-1)+1,mapping,W1,p1,W2,p2))
+res.sort(); print(res[:5])
+# xor swizzles
+res=[]
+for mapping in (0,1):
+  for sh in range(1,8):
+    for mask in (1,3,7,15):
+      for mul in (1,2,4,8,16):
+        adr=lambda x: x ^ (((x>>sh)&mask)*mul)
+        w,r=check_relayout2(P,adr,mapping)
+        if w<=4 and r<=2: res.append((mapping,sh,mask,mul))
+print(res[:10])
+print("relayout3")
+for P in (4,8,16,24,32):
+    res=[]
+    for mapping in (0,1):
+      for sh in range(1,10):
+        for mask in (1,3,7,15,31):
+          for mul in (1,2,4,8,16,32):
+            adr=lambda x: x ^ (((x>>sh)&mask)*mul)
+            vals=[adr(x) for x in range(64*P)]
+            if len(set(vals))!=64*P: continue
+            w,r=check_relayout2(P,adr,mapping)
+            if w<=4 and r<=2: res.append((max(vals)+1,mapping,sh,mask,mul))
+    res.sort()
+    print(P,res[:6])
+print("more P")
+for P in (10,12,20):
+    FL=P+2
+    best=None
+    for FB in range((P-1)+FL*7+1, (P-1)+FL*7+1+120):
+        # reader mapping i=lane&7,b0=lane>>3
+        w,r=check_full2b(P,FL,FB)
+        if w<=4 and r<=2: best=FB;break
+    print("P",P,"FL",FL,"FB",best, "XELEMS", 8*best if best else None, "old", max(P*72, 8*8*FL))
+    res=[]
+    for sh in range(1,10):
+        for mask in (0,1,3,7,15,31):
+          for mul in (1,2,4,8,16,32):
+            adr=lambda x: x ^ (((x>>sh)&mask)*mul)
+            vals=[adr(x) for x in range(64*P)]
+            if len(set(vals))!=64*P: continue
+            w,r=check_relayout2(P,adr,0)
+            if w<=4 and r<=2: res.append((max(vals)+1,sh,mask,mul))
+    res.sort(); print(P,res[:4])

@@ -383,6 +383,7 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
   const int N = S * G::N;           // full row length
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
+  const int b0mask = window_b0_mask(A.lo, A.Np, P);
 #if FMC_ROWMAP == 0
   // work item = (row group of 8 consecutive ky, realisation b), b fastest: the waves of a block
   // colour the SAME spectrum rows for different realisations (amp rows shared in L1/L2)
@@ -437,6 +438,25 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
       xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
 #pragma unroll
       for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, 1.0f + (float)j);
+#elif defined(FMC_GEN_BATCH)    // A/B variant: the words of FMC_GEN_BATCH coefficients first, then their Box-Muller transforms together
+      xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
+#pragma unroll
+      for (int j0 = 0; j0 < P; j0 += FMC_GEN_BATCH) {
+        uint32_t wa[FMC_GEN_BATCH], wb[FMC_GEN_BATCH];
+        float lg[FMC_GEN_BATCH], tt[FMC_GEN_BATCH], ra[FMC_GEN_BATCH];
+#pragma unroll
+        for (int q = 0; q < FMC_GEN_BATCH; ++q) if (j0 + q < P) draw_words(rs, wa[q], wb[q]);
+#pragma unroll
+        for (int q = 0; q < FMC_GEN_BATCH; ++q) if (j0 + q < P) {
+          lg[q] = __builtin_amdgcn_logf(fmaf((float)wa[q], 2.3283064365386963e-10f, 1.1641532182693481e-10f));
+          tt[q] = angle_turns(wb[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < FMC_GEN_BATCH; ++q) if (j0 + q < P) ra[q] = __builtin_amdgcn_sqrtf(-lg[q]) * ampf[sp + S * (lane + WAVE * (j0 + q))];
+#pragma unroll
+        for (int q = 0; q < FMC_GEN_BATCH; ++q) if (j0 + q < P)
+          regs.v[j0 + q] = mk<R>((R)(ra[q] * __builtin_amdgcn_cosf(tt[q])), (R)(ra[q] * __builtin_amdgcn_sinf(tt[q])));
+      }
 #else
       xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
 #pragma unroll
@@ -456,7 +476,7 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
 #pragma unroll
     for (int j = 0; j < P; ++j) { regs.xr[j % NS] += regs.v[j].x; regs.xi[j % NS] += regs.v[j].y; }
 #else
-    pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, b0mask);
 #endif
     if (S > 1) {
 #pragma unroll

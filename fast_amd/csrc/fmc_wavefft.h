@@ -99,15 +99,38 @@ struct LaneRegs {
 //   tw1[a*64 + l]  = w_N^{l a}                                   (P*64 complex)
 //   om[m*omS + oi] = sgn(oi) * w_64^{m * b(oi)},  m < 8          (8*omS complex), b(oi) = (lo+oi) / P
 // `sgn` carries the output-side fftshift sign of fmc_core.h (even N): (-1)^(lo+oi).
+// Which residues b0 = b mod 8 of the output blocks b = x / P the window [lo, lo + Np) touches: stage 2b reads only
+// those planes of the exchange-2 image, so the others need not be stored (a window of 82 at P = 16 touches 6 of 8).
+FMC_HD int window_b0_mask(int lo, int Np, int P) {
+  const int b_lo = lo / P, b_hi = (lo + Np - 1) / P;
+  if (b_hi - b_lo >= 7) return 0xFF;
+  int m = 0;
+  for (int b = b_lo; b <= b_hi; ++b) m |= 1 << (b & 7);
+  return m;
+}
+
+#ifndef FMC_B0MASK
+#define FMC_B0MASK 0   // measured: no gain (10.69 vs 10.66 ms per 5000 realisations): the conditional stores lose the write2 pairing
+#endif
 template <class R, int P, int NS, class Exec>
 FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
-                           int omS, int lo, int Np) {
+                           int omS, int lo, int Np, int b0mask = 0xFF) {
   using G = WaveGeom<R, P>;
   using X = Xch<R>;
   using E = typename X::E;
   constexpr int NC = X::NC;
   const int nslots = (Np + WAVE - 1) / WAVE;
 
+#if defined(FMC_ABL_NOTW)      // ablation (timing only, wrong results): no LDS reads of the stage-1 twiddles
+#define FMC_TW1(a, lane) mk<R>((R)(lane) * (R)1e-3, (R)(a))
+#else
+#define FMC_TW1(a, lane) tw1[(a) * WAVE + (lane)]
+#endif
+#if defined(FMC_ABL_NOOM)      // ablation: no LDS reads of the stage-2b table
+#define FMC_OM(m, oi) mk<R>((R)(oi) * (R)1e-3, (R)(m))
+#else
+#define FMC_OM(m, oi) om[(m) * omS + (oi)]
+#endif
   // ---- stage 1: radix-P in registers, twiddle, to natural order
   ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
     cpx<R> z[P];
@@ -120,7 +143,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
     if (CH) {
 #pragma unroll
       for (int q = 0; q < CH; ++q)
-        if (1 + q < P) t[0][q] = tw1[(1 + q) * WAVE + lane];
+        if (1 + q < P) t[0][q] = FMC_TW1(1 + q, lane);
     }
 #pragma unroll
     for (int j = 0; j < P; ++j) z[j] = r.v[j];
@@ -132,7 +155,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
         if (k + 1 < NCH) {
 #pragma unroll
           for (int q = 0; q < CH; ++q)
-            if (1 + (k + 1) * CH + q < P) t[(k + 1) & 1][q] = tw1[(1 + (k + 1) * CH + q) * WAVE + lane];
+            if (1 + (k + 1) * CH + q < P) t[(k + 1) & 1][q] = FMC_TW1(1 + (k + 1) * CH + q, lane);
         }
 #pragma unroll
         for (int q = 0; q < CH; ++q)
@@ -143,7 +166,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
       }
     } else {
 #pragma unroll
-      for (int a = 1; a < P; ++a) r.v[a] = cmul(z[a], tw1[a * WAVE + lane]);
+      for (int a = 1; a < P; ++a) r.v[a] = cmul(z[a], FMC_TW1(a, lane));
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) { r.xr[s] = (R)0; r.xi[s] = (R)0; }
@@ -191,7 +214,8 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
         if ((P % 8 == 0) || i + 8 * jj < P) {
 #pragma unroll
           for (int b0 = 0; b0 < 8; ++b0)
-            ex.st(xbuf + (i + 8 * jj) + G::FL * l0 + G::FB * b0, X::pack(r.v[jj * 8 + b0], c));
+            if (!FMC_B0MASK || ((b0mask >> b0) & 1))       // wave-uniform: planes no window output reads are not stored
+              ex.st(xbuf + (i + 8 * jj) + G::FL * l0 + G::FB * b0, X::pack(r.v[jj * 8 + b0], c));
         }
     });
     ex.sync();
@@ -210,7 +234,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
             cpx<R> w[8];
             E fv[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) { w[m] = om[m * omS + oi]; fv[m] = ex.ld(f + G::FL * m); }
+            for (int m = 0; m < 8; ++m) { w[m] = FMC_OM(m, oi); fv[m] = ex.ld(f + G::FL * m); }
 #pragma unroll
             for (int m = 0; m < 8; ++m) { ex.pin(w[m].x); ex.pin(w[m].y); ex.pin(fv[m]); }
 #pragma unroll
@@ -219,7 +243,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
 #endif
             {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + G::FL * m), c);
+            for (int m = 0; m < 8; ++m) X::acc(r.xr[s], r.xi[s], FMC_OM(m, oi), ex.ld(f + G::FL * m), c);
             }
           }
         }

@@ -162,13 +162,15 @@ def g_ao(fx, fy, fabs, mask, mode, h, wind, dtheta, D_tx, zmax, t_loop, t_exp):
 def alias_openloop(grid, d_wfs, cn2, mask, wind, t_exp, lmax, kmax, L0, l0):
     """Sum over the (2*lmax+1)(2*kmax+1)-1 shifted von Karman spectra, with the
     reference's special-cased centre row / column / pixel (208-213), times
-    sinc^2(t_exp v.kappa / 2pi) * mask (216), NaN -> 0 (221).  Shape (L, n, n)."""
+    sinc^2(t_exp v.kappa / 2pi) * mask (216), NaN -> 0 (221).  Shape (L, n, n), or (L, 3, 3, 3) on the stacked
+    sub-harmonic grids (fast.py:504-509)."""
     fx, fy, fabs = grid.fx, grid.fy, grid.fabs
     cn2 = np.asarray(cn2, dtype=float)
     wind = np.asarray(wind, dtype=float)
     mid_r = int(fx.shape[-2] / 2.0)
     mid_c = int(fy.shape[-1] / 2.0)
-    v_k = fx[None] * wind[:, 0][:, None, None] + fy[None] * wind[:, 1][:, None, None]
+    lead = (slice(None),) + (None,) * fx.ndim              # (n, n) main grid or the stacked (3, 3, 3) sub-harmonic grids
+    v_k = fx[None] * wind[:, 0][lead] + fy[None] * wind[:, 1][lead]
     alias = np.zeros((len(cn2),) + fabs.shape)
     with np.errstate(divide="ignore", invalid="ignore"):
         sinc2 = np.sinc(t_exp * v_k / TWO_PI) ** 2
@@ -264,10 +266,10 @@ def subharm_powerspec(N, dx, cn2, h, wind, L0, l0, wvl, ao_mode, d_wfs, dtheta, 
     g = subharm_grid(N, dx)
     k = TWO_PI / wvl
     mask = mask_lf(g.fx, g.fy, d_wfs, modal=modal, modal_mult=modal_mult, zmax=zmax, D=D_ground)
-    turb = _von_karman_stacked(g.fabs, cn2, L0, l0)
-    G = _g_ao_stacked(g, mask, ao_mode, h, wind, dtheta, D_ground, zmax, t_loop, t_exp)
+    turb = von_karman(g.fabs, cn2, L0, l0)                 # funcs.py:164 on (3, 3, 3) grids: the layer axis leads
+    G = g_ao(g.fx, g.fy, g.fabs, mask, ao_mode, h, wind, dtheta, D_ground, zmax, t_loop, t_exp)
     if alias and ao_mode != "NOAO":
-        alias_ps = _alias_stacked(g, d_wfs, cn2, mask, wind, t_exp, L0, l0)
+        alias_ps = alias_openloop(g, d_wfs, cn2, mask, wind, t_exp, 5, 5, L0, l0)
     else:
         alias_ps = 0.0
     if noise > 0 and ao_mode != "NOAO":
@@ -276,50 +278,6 @@ def subharm_powerspec(N, dx, cn2, h, wind, L0, l0, wvl, ao_mode, d_wfs, dtheta, 
         noise_ps = 0.0
     per_layer = TWO_PI * k ** 2 * (turb * G + alias_ps) + noise_ps / len(h)
     return per_layer.sum(0), g
-
-
-def _von_karman_stacked(fabs, cn2, L0, l0):
-    # funcs.py:164 with a (3,3,3) fabs: list*nlayers -> (L,3,3,3); .T * cn2 broadcasts on the
-    # last transposed axis = layer axis.
-    return von_karman(fabs, cn2, L0, l0)
-
-
-def _g_ao_stacked(g, mask, mode, h, wind, dtheta, D_tx, zmax, t_loop, t_exp):
-    # ao_power_spectra.py:242-260 with 3-D fx: tile -> (L,3,3,3); .T products hit the layer axis.
-    return g_ao(g.fx, g.fy, g.fabs, mask, mode, h, wind, dtheta, D_tx, zmax, t_loop, t_exp)
-
-
-def _alias_stacked(g, d_wfs, cn2, mask, wind, t_exp, L0, l0):
-    """Jol_alias_openloop on stacked (3, 3) axes (ao_power_spectra.py:163-223)."""
-    fx, fy, fabs = g.fx, g.fy, g.fabs
-    cn2 = np.asarray(cn2, dtype=float)
-    wind = np.asarray(wind, dtype=float)
-    mid_r = int(fx.shape[-2] / 2.0)
-    mid_c = int(fy.shape[-1] / 2.0)
-    lead = (slice(None),) + (None,) * fx.ndim
-    v_k = fx[None] * wind[:, 0][lead] + fy[None] * wind[:, 1][lead]
-    alias = np.zeros((len(cn2),) + fabs.shape)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        sinc2 = np.sinc(t_exp * v_k / TWO_PI) ** 2
-        term_0 = fx ** 2 * fy ** 2 / fabs ** 4
-        for l in range(-5, 6):
-            for k in range(-5, 6):
-                if l == 0 and k == 0:
-                    continue
-                sh = FreqGrid(g.axis_x - TWO_PI * k / d_wfs, g.axis_y - TWO_PI * l / d_wfs)
-                term_1 = (fx / sh.fy + fy / sh.fx) ** 2
-                term_2 = von_karman(sh.fabs, cn2, L0, l0)
-                mult = term_1 * term_2 * term_0
-                mult[..., mid_r, mid_c] = 0.0
-                if l == 0:
-                    mult[..., mid_r, :] = term_2[..., mid_r, :]
-                if k == 0:
-                    mult[..., mid_c] = term_2[..., mid_c]
-                    mult[..., mid_r, mid_c] = term_2[..., mid_r, mid_c]
-                alias += mult
-        alias *= sinc2 * mask
-    alias[np.isnan(alias)] = 0.0
-    return alias
 
 
 # --------------------------------------------------------------------------

@@ -22,6 +22,7 @@ struct HostExec {
     for (int l = 0; l < WAVE; ++l) f(l, regs[l]);
   }
   void sync() {}
+  static void loadfence() {}
   template <class T> static void pin(T&) {}
   template <class E> static E ld(const E* p) { return *p; }
   template <class E> static void st(E* p, E v) { *p = v; }

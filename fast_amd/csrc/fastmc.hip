@@ -664,8 +664,8 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
 
 template <class R, int P, int NS>
 static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
-  const size_t lds = blu_lds_bytes<R, P, NS>(RA.omS);
-  constexpr int WPB = BluCfg<R, P, NS>::WPB;
+  constexpr int WPB = BluCfg<R, P, NS>::WPB, WPC = BluCfg<R, P, NS>::WPB_COLS;
+  const size_t lds = blu_lds_bytes<R, P, NS>(RA.omS, WPB), ldc = blu_lds_bytes<R, P, NS>(RA.omS, WPC);
   constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
   const int blocks = ((RA.N + LR - 1) / LR) * ((RA.nb + BPG - 1) / BPG);
   {
@@ -682,11 +682,11 @@ static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
     Span s(h, 1);
     const int items = CA.nb * CA.Np;
     if (epi == 0) {
-      hipFuncSetAttribute((const void*)k_cols_blu<R, P, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_cols_blu<R, P, NS, 0>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+      hipFuncSetAttribute((const void*)k_cols_blu<R, P, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
+      hipLaunchKernelGGL((k_cols_blu<R, P, NS, 0>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), ldc, h->stream, CA);
     } else {
-      hipFuncSetAttribute((const void*)k_cols_blu<R, P, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_cols_blu<R, P, NS, 1>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+      hipFuncSetAttribute((const void*)k_cols_blu<R, P, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
+      hipLaunchKernelGGL((k_cols_blu<R, P, NS, 1>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), ldc, h->stream, CA);
     }
   }
 }

@@ -157,6 +157,7 @@ FMC_HD void bluestein_row(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1,
           const cpx<R> u = r.v[jj * 8 + b1];
           r.v[jj * 8 + b1] = mk<R>(u.x * v.x - u.y * v.y, -(u.x * v.y + u.y * v.x));
         }
+        ex.loadfence();      // one group of 8 table loads in flight at a time: P of them would hold 4 P registers
       }
   });
   // back to the input layout of the pipeline: x = lane + 64 j

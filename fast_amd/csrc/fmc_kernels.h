@@ -302,6 +302,8 @@ struct GpuExec {
     return o;
   }
   template <class E> static __device__ __forceinline__ void st(E* p, E v) { *p = v; }
+  // compiler-only barrier for memory operations: loads after it are not hoisted above it
+  static __device__ __forceinline__ void loadfence() { asm volatile("" ::: "memory"); }
   // "this value is needed HERE": loads feeding it are issued before this point and waited for once.
   static __device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
   static __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
@@ -615,10 +617,12 @@ template <class R, int P, int NS> struct BluCfg {
   static constexpr int W1 = (NS == 4 && W0 > 8) ? 8 : W0;     // 256-pixel window tables: 8 waves fit the LDS
   static constexpr int CAP = sizeof(R) == 8 ? (P >= 32 ? 4 : (P >= 24 ? FMC_BLU_WPB24 : (P >= 16 ? FMC_BLU_WPB16 : 12))) : 12;
   static constexpr int WPB = W1 > CAP ? CAP : W1;
+  // the column kernel has no generator and fits the 168-VGPR step at P = 16: twelve waves (500^2: 2.59 against 3.08 ms)
+  static constexpr int WPB_COLS = (P == 16 && NS == 2) ? W1 : WPB;
 };
 template <class R, int P, int NS>
-__host__ __device__ constexpr size_t blu_lds_bytes(int omS) {
-  return (size_t)(P * WAVE + 8 * omS + 64) * sizeof(cpx<R>) + (size_t)BluCfg<R, P, NS>::WPB * BluGeom<R, P>::XELEMS * 8;
+__host__ __device__ constexpr size_t blu_lds_bytes(int omS, int wpb) {
+  return (size_t)(P * WAVE + 8 * omS + 64) * sizeof(cpx<R>) + (size_t)wpb * BluGeom<R, P>::XELEMS * 8;
 }
 
 template <class R, int P, int NS, int MODE>
@@ -652,13 +656,21 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
     const int ky = row0 + flat % LR;
     if (ky >= N) continue;                               // wave-uniform (N need not be a multiple of LR)
     const uint64_t g = A.g0 + (uint64_t)b;
+    // The chirp tables do not depend on the row: left alone, the compiler hoists their 2 P + NS 16-byte loads out of
+    // the row loop and then spills them (270 B per lane at P = 16).  An offset it cannot see through keeps the loads
+    // inside the iteration.
+    int zoff = 0;
+    asm volatile("" : "+s"(zoff));
+    const cpx<R>* pre = A.blu.pre + zoff;
+    const cpx<R>* vhat = A.blu.vhat + zoff;
+    const cpx<R>* post = A.blu.post + zoff;
     if (MODE == 0) {
       const float* ampf = A.ampf + (size_t)ky * N;
       xoshiro128p rs = row_stream(A.key, g, ky, lane, WAVE);
 #pragma unroll
       for (int j = 0; j < P; ++j) {
         const int kx = lane + WAVE * j;
-        regs.v[j] = kx < N ? cmul(draw_coloured<R>(rs, ampf[kx]), A.blu.pre[kx]) : mk<R>((R)0, (R)0);
+        regs.v[j] = kx < N ? cmul(draw_coloured<R>(rs, ampf[kx]), pre[kx]) : mk<R>((R)0, (R)0);
       }
     } else {
       const size_t base = ((size_t)b * N + ky) * N;
@@ -666,16 +678,16 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
 #pragma unroll
       for (int j = 0; j < P; ++j) {
         const int kx = lane + WAVE * j;
-        regs.v[j] = kx < N ? cmul(cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]), A.blu.pre[kx]) : mk<R>((R)0, (R)0);
+        regs.v[j] = kx < N ? cmul(cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]), pre[kx]) : mk<R>((R)0, (R)0);
       }
     }
-    bluestein_row<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, s_twf, A.blu.vhat, A.Np);
+    bluestein_row<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, s_twf, vhat, A.Np);
     cpx<R>* out = A.V + (size_t)b * A.Np * N + ky;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int oi = lane + WAVE * s;
       if (oi < A.Np) {
-        const cpx<R> q = A.blu.post[oi];
+        const cpx<R> q = post[oi];
         out[(size_t)oi * N] = mk<R>(q.x * regs.xr[s] + q.y * regs.xi[s], q.y * regs.xr[s] - q.x * regs.xi[s]);   // post * conj(Y)
       }
     }
@@ -683,7 +695,7 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
 }
 
 template <class R, int P, int NS, int EPI>
-__global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_cols_blu(ColArgs<R> A) {
+__global__ __launch_bounds__((BluCfg<R, P, NS>::WPB_COLS * 64)) void k_cols_blu(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using BG = BluGeom<R, P>;
   using E = typename Xch<R>::E;
@@ -696,7 +708,7 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_cols_blu(ColAr
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * BG::XELEMS;
-  const int item = blockIdx.x * BluCfg<R, P, NS>::WPB + w;
+  const int item = blockIdx.x * BluCfg<R, P, NS>::WPB_COLS + w;
   if (item >= A.nb * A.Np) return;   // whole wave exits; no block barrier follows
   const int b = item / A.Np;
   const int xi = item % A.Np;

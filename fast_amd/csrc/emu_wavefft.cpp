@@ -33,6 +33,8 @@ static void cs_turns(double t, double* c, double* s) {
   *s = std::sin(2.0 * M_PI * t);
 }
 
+static bool g_dense = false;      // P = 16: run the dense-image variant (pruned_row_fft_d16)
+
 template <class R, int P, int NS>
 static double run_case(int lo, int Np, unsigned seed) {
   constexpr int N = WAVE * P;
@@ -57,7 +59,12 @@ static double run_case(int lo, int Np, unsigned seed) {
       const double sg = (k & 1) ? -1.0 : 1.0;
       ex.regs[l].v[j] = mk<R>((R)(sg * inr[k]), (R)(sg * ini[k]));
     }
-  pruned_row_fft<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
+  if constexpr (P == 16) {
+    if (g_dense) pruned_row_fft_d16<R, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
+    else pruned_row_fft<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
+  } else {
+    pruned_row_fft<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
+  }
 
   // reference: fftshift(fft(fftshift(in)))[p], p = lo + oi   (even N: h = N/2 both ways)
   double worst = 0.0, scale = 0.0;
@@ -194,6 +201,11 @@ int main() {
   bad += sweep<float, 24, 2>("f32", 2e-5);
   bad += sweep<double, 8, 2>("f64", 1e-13);
   bad += sweep<double, 16, 2>("f64", 1e-13);
+  g_dense = true;
+  bad += sweep<double, 16, 2>("f64 dense", 1e-13);
+  bad += sweep<float, 16, 2>("f32 dense", 2e-5);
+  bad += sweep<double, 16, 4>("f64 dense", 1e-13);
+  g_dense = false;
   bad += sweep<double, 32, 2>("f64", 1e-13);
   bad += sweep<double, 8, 8>("f64", 1e-13);
   bad += sweep<double, 16, 16>("f64", 1e-13);

@@ -59,6 +59,7 @@ struct fastmc_ctx {
   void* om = nullptr;      // wave
   void* cw = nullptr;      // wave, S > 1: [S][omS] combination twiddles
   // chirp-z family (path 2: grid sizes that are not 64 P): M = 64 * blu_P >= N + Np - 1
+  bool no_dense = false;   // FASTMC_NO_DENSE16=1 in the environment at create: keep the twelve-wave kernels (A/B)
   int blu_P = 0;           // 0: not eligible
   int blu_lo = -1;         // window position the tables below were built for
   void* blu_tw1 = nullptr; // tw1 of size M
@@ -308,6 +309,7 @@ extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int p
   h->precision = precision;
   h->rsz = precision == FASTMC_F64 ? 8 : 4;
   h->blu_P = blu_pick_P(N, Np);
+  if (const char* e = getenv("FASTMC_NO_DENSE16")) h->no_dense = e[0] && e[0] != '0';
   h->path = default_path(N, h->blu_P);
   h->S = h->path == 1 ? spec_split(N) : 1;
   h->P = N / 64 / h->S;
@@ -409,6 +411,13 @@ extern "C" int fastmc_set_batch(fastmc_t* h, int batch) {
   return 0;
 }
 
+// The dense-image kernels (sixteen waves per workgroup) serve P = 16, NS = 2, unsplit rows, device generator and
+// detector epilogue, when their LDS fits (window up to 96 pixels): the configuration of the BASELINE workloads at 1024^2.
+template <class R>
+static bool dense16_fits(const fastmc_ctx* h) {
+  return FMC_DENSE16 && wave_lds_bytes_d<R, 16, 2, 1>(h->omS) <= 160 * 1024;
+}
+
 static int default_batch(const fastmc_ctx* h) {
   if (h->batch > 0) return h->batch;
   // V slab (batch * N * Np complex) of up to 1.5 GiB: fewer, larger launches (measured at 1024^2 f64:
@@ -422,6 +431,7 @@ static int default_batch(const fastmc_ctx* h) {
     // workgroup per CU and has batch * N/8 wave-items
     int ns = 0, wpb = 1;
     if (h->rsz == 8) wave_config<double>(h, &ns, &wpb); else wave_config<float>(h, &ns, &wpb);
+    if (h->P == 16 && ns == 2 && h->S == 1 && !h->no_dense && (h->rsz == 8 ? dense16_fits<double>(h) : dense16_fits<float>(h))) wpb = 16;
     const int quantum = std::max(1, 256 * wpb * ROWS_PER_WAVE / h->N);
     if (b >= quantum) b -= b % quantum;
   } else if (b >= 8) {
@@ -625,11 +635,11 @@ extern "C" int fastmc_set_subharm(fastmc_t* h, const double* ps_sh, const double
 }
 
 // ------------------------------------------------------------------ launches
-template <class R, int P, int NS, int MODE, int S = 1>
+template <class R, int P, int NS, int MODE, int S = 1, int D = 0>
 static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
-  const size_t lds = wave_lds_bytes<R, P, NS>(A.omS);
-  hipFuncSetAttribute((const void*)k_rows_wave<R, P, NS, MODE, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  constexpr int WPB = WaveCfg<R, P, NS>::WPB;
+  const size_t lds = wave_lds_bytes_d<R, P, NS, D>(A.omS);
+  hipFuncSetAttribute((const void*)k_rows_wave<R, P, NS, MODE, S, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  constexpr int WPB = WCfg<R, P, NS, D>::WPB;
 #if FMC_ROWMAP == 0
   const int items = A.nb * (A.N / ROWS_PER_WAVE);
   const int blocks = (items + WPB - 1) / WPB;
@@ -637,19 +647,26 @@ static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
   constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
   const int blocks = (A.N / LR) * ((A.nb + BPG - 1) / BPG);
 #endif
-  hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE, S>), dim3(blocks), dim3(WPB * 64), lds, h->stream, A);
+  hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE, S, D>), dim3(blocks), dim3(WPB * 64), lds, h->stream, A);
 }
-template <class R, int P, int NS, int EPI, int S = 1>
+template <class R, int P, int NS, int EPI, int S = 1, int D = 0>
 static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
-  const size_t lds = wave_lds_bytes<R, P, NS>(A.omS);
-  hipFuncSetAttribute((const void*)k_cols_wave<R, P, NS, EPI, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  constexpr int WPB = WaveCfg<R, P, NS>::WPB;
+  const size_t lds = wave_lds_bytes_d<R, P, NS, D>(A.omS);
+  hipFuncSetAttribute((const void*)k_cols_wave<R, P, NS, EPI, S, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  constexpr int WPB = WCfg<R, P, NS, D>::WPB;
   const int items = A.nb * A.Np;
-  hipLaunchKernelGGL((k_cols_wave<R, P, NS, EPI, S>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, A);
+  hipLaunchKernelGGL((k_cols_wave<R, P, NS, EPI, S, D>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, A);
 }
 
 template <class R, int P, int NS, int S = 1>
 static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  if constexpr (P == 16 && NS == 2 && S == 1) {
+    if (mode == 0 && epi == 0 && dense16_fits<R>(h) && !h->no_dense) {
+      { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, 1, 1>(h, RA); }
+      { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, 1, 1>(h, CA); }
+      return;
+    }
+  }
   {
     Span s(h, 0);
     if (mode == 0) launch_rows_wave<R, P, NS, 0, S>(h, RA);

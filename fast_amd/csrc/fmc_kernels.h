@@ -351,6 +351,18 @@ template <class R, int P, int NS> struct WaveCfg {
                               (P == 32 ? (sizeof(R) == 8 ? FMC_WPB_P32_F64 : 6) : ((P > 16 && P / (P & -P) >= 7) ? 4 : (P > 24 ? 6 : ((P > 16 || (!is_pow2(P) && P > 8)) ? 8 : FMC_WPB))));
 };
 
+// D = 1: the dense-image variant of the P = 16, NS = 2 row / column (pruned_row_fft_d16): sixteen waves per workgroup
+// = four per SIMD, 128 VGPRs.  Its exchange buffers (8448 B per wave) and the tables fit the 160 KB of a CU for windows
+// of up to 96 pixels (wave_lds_bytes_d); wider windows keep the twelve-wave kernels.
+#ifndef FMC_DENSE16
+#define FMC_DENSE16 1
+#endif
+template <class R, int P, int NS, int D> struct WCfg {
+  static_assert(D == 0 || (P == 16 && NS == 2), "dense images exist for P = 16, NS = 2");
+  static constexpr int WPB = D ? 16 : WaveCfg<R, P, NS>::WPB;
+  static constexpr int XELEMS = D ? D16_XELEMS : WaveGeom<R, P>::XELEMS;
+};
+
 template <class R, int P>
 __device__ __forceinline__ void load_tables(cpx<R>* s_tw, cpx<R>* s_om, const cpx<R>* tw, const cpx<R>* om, int omS) {
   for (int i = threadIdx.x; i < P * WAVE; i += blockDim.x) s_tw[i] = tw[i];
@@ -363,13 +375,17 @@ template <class R, int P, int NS>
 __host__ __device__ constexpr size_t wave_lds_bytes(int omS) {
   return (size_t)(P * WAVE + 8 * omS) * sizeof(cpx<R>) + (size_t)WaveCfg<R, P, NS>::WPB * WaveGeom<R, P>::XELEMS * 8;
 }
+template <class R, int P, int NS, int D>
+__host__ __device__ constexpr size_t wave_lds_bytes_d(int omS) {
+  return (size_t)(P * WAVE + 8 * omS) * sizeof(cpx<R>) + (size_t)WCfg<R, P, NS, D>::WPB * WCfg<R, P, NS, D>::XELEMS * 8;
+}
 
 // S > 1: the row of NF = S * 64 P points is transformed as S interleaved sub-rows (kx = s mod S), each by
 // the same P-per-lane pipeline, and the window outputs are combined, X[x] = sum_s w_NF^{s x} Y_s[x mod 64 P]
 // (decimation in time, evaluated only for the window).  2048 = 2 x 1024 and 4096 = 4 x 1024 run the
 // P = 16 pipeline at 3 waves per SIMD instead of a 32-values-per-lane pipeline at 2.
-template <class R, int P, int NS, int MODE, int S = 1>
-__global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(RowArgs<R> A) {
+template <class R, int P, int NS, int MODE, int S = 1, int D = 0>
+__global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = WaveGeom<R, P>;
   using E = typename Xch<R>::E;
@@ -381,7 +397,7 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
   // the wave index is wave-uniform: in an SGPR, so that row / realisation indices and the table base addresses
   // derived from it are scalar and the loads use the scalar-base + lane-offset form
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  E* xbuf = s_x + w * G::XELEMS;
+  E* xbuf = s_x + w * WCfg<R, P, NS, D>::XELEMS;
   const int N = S * G::N;           // full row length
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
@@ -389,7 +405,7 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
 #if FMC_ROWMAP == 0
   // work item = (row group of 8 consecutive ky, realisation b), b fastest: the waves of a block
   // colour the SAME spectrum rows for different realisations (amp rows shared in L1/L2)
-  const int item = blockIdx.x * WaveCfg<R, P, NS>::WPB + w;
+  const int item = blockIdx.x * WCfg<R, P, NS, D>::WPB + w;
   if (item >= A.nb * (N / ROWS_PER_WAVE)) return;   // after the only block barrier
   const int b = item % A.nb;
   const int row0 = (item / A.nb) * ROWS_PER_WAVE;
@@ -403,7 +419,7 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
   // in L2 long before it is evicted.  (With one wave storing its own 8 rows over 8 iterations the
   // partially written lines in flight -- 256 CUs x 12 waves x Np lines -- equal the L2 capacity
   // and leave as partial writes: 2.2x write amplification, rows kernel 13.9 -> 12.6 ms per 5000 realisations.)
-  constexpr int WPB = WaveCfg<R, P, NS>::WPB;
+  constexpr int WPB = WCfg<R, P, NS, D>::WPB;
   constexpr int LR = 128 / (int)sizeof(cpx<R>);
   static_assert((ROWS_PER_WAVE * WPB) % LR == 0, "tile must hold whole lines");
   constexpr int BPG = ROWS_PER_WAVE * WPB / LR;          // realisations per workgroup
@@ -478,7 +494,8 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
 #pragma unroll
     for (int j = 0; j < P; ++j) { regs.xr[j % NS] += regs.v[j].x; regs.xi[j % NS] += regs.v[j].y; }
 #else
-    pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, b0mask);
+    if constexpr (D) pruned_row_fft_d16<R, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    else pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, b0mask);
 #endif
     if (S > 1) {
 #pragma unroll
@@ -518,8 +535,8 @@ __global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64)) void k_rows_wave(Row
 #ifndef FMC_COLS_WPE_MAXP
 #define FMC_COLS_WPE_MAXP 8
 #endif
-template <class R, int P, int NS, int EPI, int S = 1>
-__global__ __launch_bounds__((WaveCfg<R, P, NS>::WPB * 64), ((P <= FMC_COLS_WPE_MAXP && P != 7 && NS == 2 && WaveCfg<R, P, NS>::WPB == 12) ? 6 : 1))
+template <class R, int P, int NS, int EPI, int S = 1, int D = 0>
+__global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64), ((P <= FMC_COLS_WPE_MAXP && P != 7 && NS == 2 && WaveCfg<R, P, NS>::WPB == 12) ? 6 : 1))
 void k_cols_wave(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = WaveGeom<R, P>;
@@ -530,9 +547,9 @@ void k_cols_wave(ColArgs<R> A) {
   load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  E* xbuf = s_x + w * G::XELEMS;
+  E* xbuf = s_x + w * WCfg<R, P, NS, D>::XELEMS;
   // work item = (realisation b, window column xi), xi fastest: adjacent waves read adjacent columns
-  const int item = blockIdx.x * WaveCfg<R, P, NS>::WPB + w;
+  const int item = blockIdx.x * WCfg<R, P, NS, D>::WPB + w;
   if (item >= A.nb * A.Np) return;   // whole wave exits; no block barrier follows
   const int b = item / A.Np;
   const int xi = item % A.Np;
@@ -544,7 +561,8 @@ void k_cols_wave(ColArgs<R> A) {
   if (S == 1) {
 #pragma unroll
     for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
-    pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    if constexpr (D) pruned_row_fft_d16<R, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    else pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
   } else {
     R accr[NS], acci[NS];
 #pragma unroll

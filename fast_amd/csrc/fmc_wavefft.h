@@ -253,6 +253,90 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
   }
 }
 
+// ---------------------------------------------------------------- P = 16, dense LDS images: four waves per SIMD
+// The same transform as pruned_row_fft<R, 16, NS> with exchange images small enough for SIXTEEN waves per workgroup
+// (16 x 8448 B + 28 KB of tables = the 160 KB of a CU) and no prefetch staging, so that the row fits 128 VGPRs:
+//   stage 2a is owned by lane (a = lane & 15, lp = lane >> 4) for l0 = lp and lp + 4 (instead of (i, l0) for a = i, i + 8):
+//   exchange 1:  E[a][l] at 66 a + l          reads (66 a + lp) mod 32 = 2 a + lp: the 32 lanes of a read group differ
+//   exchange 2:  F[a][b0][l0] at a + 16 b0 + 128 l0 (dense, 1024 elements): consecutive window outputs walk a, then b0,
+//                and 16 b0 alternates the upper half of the 32 element banks
+// all affine, so every access is base + immediate offset (tools/lds_bank_check.py verifies both images for every window).
+constexpr int D16_SE = 66;
+constexpr int D16_XELEMS = 16 * D16_SE;
+template <class R, int NS, class Exec>
+FMC_HD void pruned_row_fft_d16(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
+                               int omS, int lo, int Np) {
+  constexpr int P = 16;
+  using X = Xch<R>;
+  using E = typename X::E;
+  constexpr int NC = X::NC;
+  const int nslots = (Np + WAVE - 1) / WAVE;
+  ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+    cpx<R> z[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) z[j] = r.v[j];
+    dft_reg<P, R>(z);
+    r.v[0] = z[0];
+#pragma unroll
+    for (int a = 1; a < P; ++a) r.v[a] = cmul(z[a], tw1[a * WAVE + lane]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { r.xr[s] = (R)0; r.xi[s] = (R)0; }
+  });
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) ex.st(xbuf + a * D16_SE + lane, X::pack(r.v[a], c));
+    });
+    ex.sync();
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int a = lane & 15, lp = lane >> 4;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int l1 = 0; l1 < 8; ++l1) X::unpack(r.v[q * 8 + l1], ex.ld(xbuf + a * D16_SE + lp + 4 * q + 8 * l1), c);
+    });
+    ex.sync();
+  }
+  ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      cpx<R> t[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) t[m] = r.v[q * 8 + m];
+      fft_dif<8, R>(t);
+#pragma unroll
+      for (int b0 = 0; b0 < 8; ++b0) r.v[q * 8 + b0] = t[brev(b0, 3)];
+    }
+  });
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int a = lane & 15, lp = lane >> 4;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int b0 = 0; b0 < 8; ++b0) ex.st(xbuf + a + 16 * b0 + 128 * (lp + 4 * q), X::pack(r.v[q * 8 + b0], c));
+    });
+    ex.sync();
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s < nslots) {
+          const int oi = lane + WAVE * s;
+          if (oi < Np) {
+            const int x = lo + oi;
+            const E* f = xbuf + (x & 15) + 16 * ((x >> 4) & 7);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + 128 * m), c);
+          }
+        }
+      }
+    });
+    ex.sync();
+  }
+}
+
 // Host-side construction of the two tables (float64 trigonometry by the caller-supplied functor
 // `cs(turns, &c, &s)` = cos/sin(2*pi*turns)).
 template <class R, class CosSin>

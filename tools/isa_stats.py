@@ -30,12 +30,14 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=f
 
 # demangled-name prefixes of the kernels whose counts bench.py uses
 KERNELS = {
-    "rows_f64_1024": "void fmc::k_rows_wave<double, 16, 2, 0, 1>(",
-    "cols_f64_1024": "void fmc::k_cols_wave<double, 16, 2, 0, 1>(",
-    "rows_f32_1024": "void fmc::k_rows_wave<float, 16, 2, 0, 1>(",
-    "cols_f32_1024": "void fmc::k_cols_wave<float, 16, 2, 0, 1>(",
-    "rows_f64_2048": "void fmc::k_rows_wave<double, 16, 2, 0, 2>(",
-    "cols_f64_2048": "void fmc::k_cols_wave<double, 16, 2, 0, 2>(",
+    # 1024^2 with a window of up to 96 pixels: the dense-image, sixteen-wave instantiations (last template argument 1)
+    "rows_f64_1024": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 1>(",
+    "cols_f64_1024": "void fmc::k_cols_wave<double, 16, 2, 0, 1, 1>(",
+    "rows_f32_1024": "void fmc::k_rows_wave<float, 16, 2, 0, 1, 1>(",
+    "cols_f32_1024": "void fmc::k_cols_wave<float, 16, 2, 0, 1, 1>(",
+    "rows_f64_1024_12waves": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 0>(",
+    "rows_f64_2048": "void fmc::k_rows_wave<double, 16, 2, 0, 2, 0>(",
+    "cols_f64_2048": "void fmc::k_cols_wave<double, 16, 2, 0, 2, 0>(",
 }
 
 TRANS = re.compile(r"^v_(log|sqrt|sin|cos|exp|rcp|rsq)_(f32|f16|f64)")

@@ -11,7 +11,12 @@ from . import host
 from . import _lib
 from . import comms
 from . import funcs
+from . import dist
+from . import multi
+from . import rendezvous
+from . import sweep
 from ._lib import FastMCError
 
-__version__ = "0.1.0"
-__all__ = ["Fast", "FastResult", "load", "conf", "turbulence_models", "host", "comms", "funcs", "FastMCError"]
+__version__ = "0.2.0"
+__all__ = ["Fast", "FastResult", "load", "conf", "turbulence_models", "host", "comms", "funcs", "dist", "multi",
+           "rendezvous", "sweep", "FastMCError"]

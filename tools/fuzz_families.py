@@ -1,7 +1,10 @@
-"""Differential fuzz: wave family vs direct family on random (N, Np, lo, precision) with host coefficients,
-(screens) and with the device generator (powers), and the screens against numpy for the smaller grids.  tools/fuzz_families.py [cases] [seed]"""
+"""Differential fuzz: wave / chirp-z family vs direct family on random (N, Np, lo, precision) with host coefficients
+(screens) and with the device generator (powers), and the screens against numpy for the smaller grids (odd N use
+numpy's asymmetric fftshift).  tools/fuzz_families.py [cases] [seed]"""
+import os
 import sys
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fast_amd import _lib, host
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
@@ -11,7 +14,9 @@ for c in range(cases):
     N = int(rng.choice(host.WAVE_FFT_SIZES))
     if N >= 2048 and rng.random() < 0.5:
         N = int(rng.choice([s for s in host.WAVE_FFT_SIZES if s < 2048]))
-    Np = int(rng.integers(1, min(N, 300) + 1))
+    if c % 2:                                           # every other case: a size that is not 64 P -> chirp-z family
+        N = int(rng.integers(8, 1500))
+    Np = int(rng.integers(1, min(N, 300 if c % 2 == 0 else 256) + 1))
     lo = int(rng.choice([0, N - Np, (N - Np) // 2, rng.integers(0, N - Np + 1)]))
     prec = "f64" if rng.random() < 0.7 else "f32"
     tol = 1e-10 if prec == "f64" else 1e-4
@@ -34,6 +39,6 @@ for c in range(cases):
         ref_err = max(np.abs(a[0] - z.real).max(), np.abs(a[1] - z.imag).max()) / np.abs(z).max()
     ok = err < tol and not (ref_err >= tol)
     bad += not ok
-    print(f"{'ok ' if ok else 'BAD'} N={N:5d} Np={Np:4d} lo={lo:5d} {prec} path={path} wave-vs-direct {err:.2e} vs-numpy {ref_err:.2e}")
+    print(f"{'ok ' if ok else 'BAD'} N={N:5d} Np={Np:4d} lo={lo:5d} {prec} path={path} vs-direct {err:.2e} vs-numpy {ref_err:.2e}")
 print("failures:", bad)
 sys.exit(1 if bad else 0)

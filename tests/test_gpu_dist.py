@@ -112,3 +112,36 @@ def test_bench_two_threads_on_one_gpu_reports_what_ran():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["workers"] == 2 and line["config"]["result_exchange"].startswith("host")
     assert line["config"]["histogram_total"] == 2 * 10000
+
+
+def test_rccl_transport_code_path_with_a_world_of_one():
+    """The one-process-per-GPU RCCL path (unique id -> ncclCommInitRank -> all-gather + all-reduce on the device buffers)
+    end to end with a single rank, the only world size RCCL accepts on a 1-GPU box: transport decision, gather,
+    gather + histogram, histogram alone, sharded run, teardown."""
+    from fast_amd import dist, rendezvous
+    h = _lib.Handle(256, 40, "f64", 0)
+    if h.comm_world()[0]:
+        h.comm_destroy()
+    ps = np.full((256, 256), 1e-3)
+    ps[128, 128] = 0.0
+    h.set_spectrum(ps, 0.25)
+    h.set_pupil(np.ones((40, 40)), 108, 0.01)
+    rdzv = rendezvous.Rendezvous(0, 1, "unix", "fastmc-test-world1")
+    dist._TRANSPORT.pop(h.device, None)
+    try:
+        tr = dist.make_transport(h, rdzv, rccl_timeout=60)
+        assert tr.name == "rccl" and h.comm_world() == (1, 0)
+        out = h.run(4, 0, 200, None, 0.01)
+        parts = tr.gather(out, h)
+        assert len(parts) == 1 and np.array_equal(parts[0], out)
+        allp, hist = tr.gather_with_hist(out, h, (-40.0, 10.0, 64))
+        assert np.array_equal(allp[0], out) and np.array_equal(hist, h.histogram(-40.0, 10.0, 64)) and hist.sum() == 400
+        assert np.array_equal(tr.device_hist(h, (-40.0, 10.0, 64)), hist)
+        full = dist.run_sharded(200, lambda r0, n: h.run(4, r0, n, None, 0.01), tr, h)
+        assert np.array_equal(full, out)
+        coh = dist.run_sharded(200, lambda r0, n: h.run(4, r0, n, None, 0.01, True), tr, h)
+        assert np.iscomplexobj(coh) and np.allclose(np.abs(coh) ** 2, out, rtol=1e-12)
+    finally:
+        dist._TRANSPORT.pop(h.device, None)
+        h.comm_destroy()
+    assert h.comm_world() == (0, -1)

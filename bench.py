@@ -255,7 +255,9 @@ def roofline(args, N, Np, tim, steps, workers, value_per_worker):
                 if c.get("hbm_bytes_per_launch") and c.get("avg_launch_ms"):
                     hbm[k]["counter_GBps"] = c["hbm_bytes_per_launch"] / (c["avg_launch_ms"] * 1e-3) / 1e9
                     hbm[k]["frac_counter"] = hbm[k]["counter_GBps"] / HBM_PEAK_GBS
-            out["traffic"] = prof.get("rows", {}).get("hbm_bytes_per_launch")
+            tb, rpl = prof.get("rows", {}).get("hbm_bytes_per_launch"), prof.get("realisations_per_launch")
+            # counter bytes of the profiled launches, scaled to this run's launch size (bytes are per realisation)
+            out["traffic"] = tb * real_per_launch / rpl if (tb and rpl) else tb
             out["counters"] = {k: prof[k] for k in ("valu_busy", "issue_busy", "lds_issue_busy", "source") if k in prof}
         else:
             out["counters"] = {"stale": f"{prof.get('source')} belongs to a build with {prof.get('rows_valu_instructions_per_row')} "

@@ -420,11 +420,11 @@ static bool dense16_fits(const fastmc_ctx* h) {
 
 static int default_batch(const fastmc_ctx* h) {
   if (h->batch > 0) return h->batch;
-  // V slab (batch * N * Np complex) of up to 1.5 GiB: fewer, larger launches (measured at 1024^2 f64:
+  // V slab (batch * N * Np complex) of up to 2 GiB: fewer, larger launches (measured at 1024^2 f64:
   // 96 / 216 / 1008 realisations per launch -> 0.97 / 1.00 / 1.05 of the throughput; Infinity-Cache
   // residency of the slab does not matter, the pipeline is VALU-bound, and HBM is 288 GB)
   const double per = (double)h->N * h->Np * 2 * h->rsz;
-  int b = (int)(1536.0 * 1024 * 1024 / per);
+  int b = (int)(2048.0 * 1024 * 1024 / per);       // round 2: 1568 realisations per launch +0.9 % over 1176 at 1024^2
   b = std::max(1, std::min(b, 4096));
   if (h->path == 1) {
     // whole number of workgroup rounds over the 256 CUs: the row kernel runs one 12-wave (P=32: 4/6)

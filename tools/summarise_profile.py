@@ -107,4 +107,9 @@ if len(sys.argv) > 2:
                 doc[key] = v * 4 / simd_cycles   # SQ_ACTIVE_INST_* count quad-cycles
         doc["busy_note"] = "k_rows_wave: SQ_ACTIVE_INST_* x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)"
         doc["clock_GHz_profiled"] = grbm / 8 / (doc["rows"]["avg_launch_ms"] * 1e-3) / 1e9 if doc["rows"]["avg_launch_ms"] else None
+    try:       # launch size of the profiled command: the per-launch byte counts scale with it
+        line = json.loads(open(os.path.join(out, "bench_line_under_rocprof.json")).read())
+        doc["realisations_per_launch"] = line["roofline"]["realisations_per_launch"]
+    except Exception:
+        doc["realisations_per_launch"] = None
     json.dump(doc, open(sys.argv[2], "w"), indent=1)

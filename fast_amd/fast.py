@@ -185,6 +185,16 @@ class Fast():
         """(N, N) residual phase PSD, fft-shifted layout (fast.py:481); fetched from the GPU on first use."""
         return self._grid("powerspec")
 
+    @powerspec.setter
+    def powerspec(self, value):
+        """The reference reads `self.powerspec` in every chunk (fast.py:593-594), so a caller may replace it between
+        construction and `run()`; here the new grid is uploaded to every device as the colouring tables."""
+        ps = numpy.ascontiguousarray(value, dtype=float)
+        if ps.shape != (self.Npxls, self.Npxls):
+            raise ValueError(f"powerspec must be ({self.Npxls}, {self.Npxls})")
+        self._group.set_spectrum(ps, self._prob.df)
+        self._grids["powerspec"] = ps
+
     @property
     def logamp_powerspec(self):
         return self._grid("logamp_powerspec")

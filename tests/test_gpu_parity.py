@@ -935,3 +935,20 @@ def test_wide_windows_on_split_grids_use_the_wave_family():
     assert h.last_timing()["rows_launches"] == 1 and np.isfinite(a).all()
     h.kernel_path(0)
     np.testing.assert_allclose(h.run(5, 0, 2, None, 0.01), a, rtol=1e-9)
+
+
+def test_powerspec_attribute_can_be_replaced_like_in_the_reference():
+    """`sim.powerspec` is fetched from the device on first use and, as in the reference (where run() reads the attribute
+    in every chunk, fast.py:593-594), can be replaced before run(): the new grid colours the draws."""
+    g = load_golden("e2e_ao_alias")
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_RNG": "host", "GPU_DEVICE": 0})
+    sim = fast_amd.Fast(dict(p))
+    np.testing.assert_allclose(sim.powerspec, g["powerspec"], rtol=1e-10, atol=1e-13 * np.abs(g["powerspec"]).max())
+    sim.powerspec = 4.0 * g["powerspec"]
+    assert np.array_equal(sim.powerspec, 4.0 * g["powerspec"])
+    r4 = sim.run()._r
+    want = R.monte_carlo(p["SEED"], p["NITER"], p["NCHUNKS"], 4.0 * g["powerspec"], sim._prob.df, sim._prob.W, sim.dx, float(sim.logamp_var))
+    np.testing.assert_allclose(r4, want, rtol=1e-9)
+    with pytest.raises(ValueError):
+        sim.powerspec = np.ones((3, 3))

@@ -88,6 +88,12 @@ class Fast():
         self.pupil_filter, self.pup_coords = pup.pupil_filter, pup.pup_coords
         self.link_budget, self.diffraction_limit = prob.link_budget, prob.diffraction_limit
         self.logamp = numpy.zeros((self.Niter))
+        # bookkeeping names of the reference object that a caller may read (fast.py:78-80, 106, 245-257, 528-531)
+        self.F0 = numpy.inf
+        self.fftw, self.nthreads, self.fftw_objs = p['FFTW'], p['FFTW_THREADS'], None
+        self.shifts = self.shifts_sh = None
+        if hasattr(atm, "wind_correction"):
+            self.wind_correction = atm.wind_correction
 
         self.precision = p['GPU_PRECISION']
         self.rng_mode = p['GPU_RNG']
@@ -293,10 +299,12 @@ class Fast():
         self._handle.set_layer_screens(scrns)
         pup = prob.pup.pup_coords.astype(float)
         interp = pup[numpy.newaxis, :, numpy.newaxis, :] + self.pixel_shifts[:, :, :, numpy.newaxis]
+        self.interp_coords = interp                      # fast.py:617 (chunk 0)
         for i in range(self.Nchunks):
             coord, shifts = host.temporal_coords(interp, N)
             I[i] = self._handle.temporal_chunk(coord[:, 0], coord[:, 1], shifts, self.logamp[i * M:(i + 1) * M], coherent)
             interp = interp + self.pixel_shifts[:, :, -1, numpy.newaxis, numpy.newaxis]
+            self.interp_coords = interp                  # advanced after every chunk, as fast.py:635 leaves it
 
     def _transport(self):
         """The result exchange of a one-process-per-GPU run, or None.  GPU_SHARD: 'auto' (default) shards when a

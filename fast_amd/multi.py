@@ -20,8 +20,24 @@ from . import _lib, dist
 logger = logging.getLogger(__name__)
 
 
-def run_threads(fns):
-    """Run the callables concurrently, one thread each; return their results in order; re-raise the first error."""
+def run_threads(fns, pool=None):
+    """Run the callables concurrently, one thread each (on `pool`, a ThreadPoolExecutor with at least len(fns) workers,
+    when given: a sharded run is called once per step and should not pay thread start-up each time); return their results
+    in order; re-raise the first error."""
+    if len(fns) == 1:
+        return [fns[0]()]
+    if pool is not None:
+        futs = [pool.submit(f) for f in fns]
+        res, err = [], None
+        for f in futs:
+            try:
+                res.append(f.result())
+            except BaseException as e:   # wait for all of them, then re-raise the first
+                res.append(None)
+                err = err or e
+        if err is not None:
+            raise err
+        return res
     res = [None] * len(fns)
     err = [None] * len(fns)
 
@@ -30,14 +46,11 @@ def run_threads(fns):
             res[i] = fns[i]()
         except BaseException as e:       # re-raised in the caller's thread
             err[i] = e
-    if len(fns) == 1:
-        work(0)
-    else:
-        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(fns))]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(fns))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
     for e in err:
         if e is not None:
             raise e
@@ -56,7 +69,11 @@ class DeviceGroup:
         if not self.devices:
             raise Exception("GPU_DEVICES must name at least one device")
         make = factory or (lambda d: _lib.Handle(N, Np, precision, d))
-        self.handles = run_threads([(lambda d=d: make(d)) for d in self.devices])
+        self._pool = None
+        if len(self.devices) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=len(self.devices), thread_name_prefix="fastmc-dev")
+        self.handles = run_threads([(lambda d=d: make(d)) for d in self.devices], self._pool)
         self.world = len(self.handles)
         self.exchange = "none" if self.world == 1 else "host"
         self._rccl = False
@@ -97,7 +114,7 @@ class DeviceGroup:
 
     # ---- broadcast of the problem (one host copy per device)
     def each(self, fn):
-        return run_threads([(lambda h=h, i=i: fn(h, i)) for i, h in enumerate(self.handles)])
+        return run_threads([(lambda h=h, i=i: fn(h, i)) for i, h in enumerate(self.handles)], self._pool)
 
     def set_spectrum(self, powerspec, df):
         self.each(lambda h, i: h.set_spectrum(powerspec, df))
@@ -147,6 +164,13 @@ class DeviceGroup:
     def last_timing(self):
         return [h.last_timing() for h in self.handles]
 
+    def __del__(self):
+        try:
+            if self._pool is not None:
+                self._pool.shutdown(wait=False)
+        except Exception:
+            pass
+
     def close(self, destroy_comm=False):
         if self._rccl and destroy_comm:
             for h in self.handles:
@@ -157,3 +181,6 @@ class DeviceGroup:
         self._rccl = False
         for h in self.handles:
             h.close()
+        if self._pool is not None:
+            self._pool.shutdown(wait=False)
+            self._pool = None

@@ -18,7 +18,10 @@
  *     handle (sweeps build one short-lived handle per geometry sample); a handle it displaces is freed, except
  *     for the largest work buffer of the device, which is kept for the next handle;
  *   - nothing here ever falls back to a CPU implementation: without a gfx950 device
- *     fastmc_create() fails with FASTMC_ENODEV.
+ *     fastmc_create() fails with FASTMC_ENODEV;
+ *   - environment: FASTMC_DISABLE_RCCL=1 makes the communicator entry points fail with FASTMC_ECOMM (callers exchange
+ *     through the host); FASTMC_NO_DENSE16=1 (read by fastmc_create) keeps the twelve-wave kernels where the
+ *     sixteen-wave dense-image kernels would run (A/B timing; same results).
  */
 #ifndef FASTMC_H
 #define FASTMC_H

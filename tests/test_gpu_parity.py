@@ -952,3 +952,25 @@ def test_powerspec_attribute_can_be_replaced_like_in_the_reference():
     np.testing.assert_allclose(r4, want, rtol=1e-9)
     with pytest.raises(ValueError):
         sim.powerspec = np.ones((3, 3))
+
+
+def test_dense_sixteen_wave_kernels_equal_the_twelve_wave_kernels():
+    """1024^2 with a window of up to 96 pixels runs the dense-image kernels (sixteen waves per workgroup); with
+    FASTMC_NO_DENSE16=1 the same library keeps the twelve-wave kernels: same arithmetic, same results."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from tests.test_gpu_parity import _small_problem; "
+            "h, ps, df, W = _small_problem(1024, 82); np.save(sys.argv[1], h.run(17, 2, 40, None, 0.02))") % ROOT
+    outs = []
+    for flag in ("0", "1"):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"fastmc_dense_{flag}_{os.getpid()}.npy")
+        env = dict(os.environ, FASTMC_NO_DENSE16=flag, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
+        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+        os.remove(path)
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-12)
+    h, ps, df, W = _small_problem(1024, 82)
+    np.testing.assert_array_equal(h.run(17, 2, 40, None, 0.02), outs[0 if not os.environ.get("FASTMC_NO_DENSE16") else 1])

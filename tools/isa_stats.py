@@ -25,7 +25,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "fast_amd", "csrc", "fastmc.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast", "-Wno-unused-result",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast", "-fno-slp-vectorize", "-Wno-unused-result",
          "-Wno-unused-value", "-Wno-unused-command-line-argument", "--cuda-device-only", "-S"]
 
 # demangled-name prefixes of the kernels whose counts bench.py uses

@@ -3,7 +3,7 @@
 import re, subprocess, sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "fast_amd", "csrc", "fastmc.hip")
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast", "-fno-slp-vectorize",
        "-Wno-unused-result", "-Wno-unused-value", "--cuda-device-only", "-c", "-o", "/tmp/fmc_res.o", src,
        "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr

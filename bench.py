@@ -417,7 +417,7 @@ def main():
                        "arithmetic": ("complex128 transform and float64 detector sums" if args.precision == "f64" else "complex64 transform, float64 detector sums")
                                      + "; the device generator's normals are float32 (24-bit uniforms, hardware log/sqrt/sin/cos), "
                                        "coloured in float32 and widened; host-coefficient (parity) mode is float64 throughout",
-                       "iters_per_step_per_gpu": ITERS_PER_STEP, "kernel_path": {0: "direct", 1: "wave-fft", 2: "chirp-z"}[h.kernel_path()],
+                       "iters_per_step_per_gpu": ITERS_PER_STEP, "kernel_path": {0: "direct", 1: "wave-fft", 2: "chirp-z", 3: "lanes50-fft"}[h.kernel_path()],
                        "launch": {"single": "one process, one GPU", "threads": f"one process, {workers} worker threads",
                                   "ranks": f"{workers} processes (launcher), fast_amd.rendezvous"}[mode],
                        "workers": workers, "devices": devices if mode != "ranks" else "LOCAL_RANK per process",

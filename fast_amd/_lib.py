@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FASTMC_LIB") or os.path.join(_HERE, "libfastmc.so")
 
 F64, F32 = 0, 1
-KERNEL_PATHS = {"direct": 0, "wave": 1, "chirpz": 2}
+KERNEL_PATHS = {"direct": 0, "wave": 1, "chirpz": 2, "lanes50": 3}
 AO_MODES = {"NOAO": 0, "AO": 1, "TT": 2, "LGSAO": 3}
 PS_NSCALARS = 6
 

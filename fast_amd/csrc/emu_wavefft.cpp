@@ -12,6 +12,7 @@
 #include "fmc_core.h"
 #include "fmc_wavefft.h"
 #include "fmc_bluestein.h"
+#include "fmc_mrfft.h"
 
 using namespace fmc;
 
@@ -167,8 +168,91 @@ static int sweep_blu(const char* name, double tol) {
   return bad;
 }
 
+// 50-lane mixed-radix row of fmc_mrfft.h: N = 50 P against the naive DFT with numpy's fftshift on both sides (N even).
+template <class R, int P, int NS>
+static double run_mr_case(int lo, int Np, unsigned seed) {
+  constexpr int N = MR_LN * P;
+  using G = MrGeom<R, P>;
+  using E = typename Xch<R>::E;
+  std::mt19937_64 gen(seed);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  std::vector<double> inr(N), ini(N);
+  for (int k = 0; k < N; ++k) { inr[k] = nd(gen); ini[k] = nd(gen); }
+  const int omS = NS * WAVE;
+  std::vector<cpx<R>> tw1((size_t)P * WAVE), om((size_t)G::L0 * omS);
+  build_tw1_mr<R>(tw1.data(), P, cs_turns);
+  build_om_mr<R>(om.data(), omS, P, lo, Np, true, cs_turns);
+  std::vector<E> xbuf(G::XELEMS);
+  static HostExec<R, P, NS> ex;
+  for (int l = 0; l < WAVE; ++l)
+    for (int j = 0; j < P; ++j) {
+      const int k = l + MR_LN * j;
+      const double sg = (k & 1) ? -1.0 : 1.0;
+      // idle lanes carry garbage on the GPU (nothing reads their exchange-1 column): poison them here
+      ex.regs[l].v[j] = l < MR_LN ? mk<R>((R)(sg * inr[k]), (R)(sg * ini[k])) : mk<R>((R)1e3, (R)-1e3);
+    }
+  pruned_row_fft_mr<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
+  double worst = 0.0, scale = 0.0;
+  const int h = N / 2;
+  for (int oi = 0; oi < Np; ++oi) {
+    const int p = lo + oi;
+    long double sr = 0, si = 0;
+    for (int k = 0; k < N; ++k) {
+      const long long e = (((long long)(p - h) * (k + h)) % N + N) % N;
+      const long double a = -2.0L * M_PIl * (long double)e / N;
+      const long double c = cosl(a), s = sinl(a);
+      sr += inr[k] * c - ini[k] * s;
+      si += inr[k] * s + ini[k] * c;
+    }
+    const int l = oi % WAVE, s = oi / WAVE;
+    const double gr = ex.regs[l].xr[s], gi = ex.regs[l].xi[s];
+    worst = std::fmax(worst, std::fmax(std::fabs(gr - (double)sr), std::fabs(gi - (double)si)));
+    scale = std::fmax(scale, std::fmax(std::fabs((double)sr), std::fabs((double)si)));
+  }
+  return worst / scale;
+}
+
+template <class R, int P, int NS>
+static int sweep_mr(const char* name, double tol) {
+  constexpr int N = MR_LN * P;
+  int bad = 0;
+  const int cases[][2] = {{(N - 82) / 2, 82}, {0, 64 * NS < N ? 64 * NS : N}, {N - 5, 5}, {(N - 23) / 2, 23},
+                          {(N - 1) / 2, 1}, {7, 64 * NS - 3 < N - 7 ? 64 * NS - 3 : N - 7}, {(N - 128) / 2, NS >= 2 ? 128 : 64},
+                          {N - 64 * NS > 0 ? N - 64 * NS : 0, 64 * NS < N ? 64 * NS : N}};
+  for (auto& c : cases) {
+    if (c[1] > 64 * NS || c[0] < 0 || c[0] + c[1] > N || c[1] < 1) continue;
+    const double err = run_mr_case<R, P, NS>(c[0], c[1], 4321u + c[0]);
+    const bool ok = err <= tol;
+    std::printf("%s 50-lane P=%d NS=%d N=%d lo=%d Np=%d relerr=%.3e %s\n", name, P, NS, N, c[0], c[1], err, ok ? "ok" : "FAIL");
+    bad += !ok;
+  }
+  return bad;
+}
+
 int main() {
   int bad = 0;
+  bad += sweep_mr<double, 2, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 3, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 4, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 5, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 6, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 7, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 8, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 9, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 10, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 10, 4>("f64", 1e-13);
+  bad += sweep_mr<double, 12, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 14, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 16, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 18, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 20, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 20, 4>("f64", 1e-13);
+  bad += sweep_mr<double, 24, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 28, 2>("f64", 1e-13);
+  bad += sweep_mr<double, 32, 2>("f64", 1e-13);
+  bad += sweep_mr<float, 5, 2>("f32", 2e-5);
+  bad += sweep_mr<float, 20, 2>("f32", 2e-5);
+  bad += sweep_mr<float, 24, 4>("f32", 2e-5);
   bad += sweep_blu<double, 4, 2>("f64", 1e-12);
   bad += sweep_blu<double, 8, 2>("f64", 1e-12);
   bad += sweep_blu<double, 8, 4>("f64", 1e-12);

@@ -68,6 +68,11 @@ struct fastmc_ctx {
   void* blu_pre = nullptr;
   void* blu_vhat = nullptr;
   void* blu_post = nullptr;
+  // 50-lane family (path 3: N = 50 P, fmc_mrfft.h)
+  int mr_P = 0;            // 0: not eligible (N not 50 P, or no window instantiation)
+  int mr_lo = -1;          // window position the tables below were built for
+  void* mr_tw1 = nullptr;
+  void* mr_om = nullptr;
   void* tw1g = nullptr;    // N = 2048 only: tables of the single-pass P = 32 kernels (windows > 256 pixels,
   void* omg = nullptr;     //   host coefficients: TEMPORAL layer screens, centred_fft2)
   double* W = nullptr;
@@ -216,12 +221,12 @@ static bool wave_supported(int N) {
 // Default kernel family: wave where N = 64 P, else chirp-z where it applies and the grid is big enough to pay for two
 // transforms per row (below ~96 points the direct kernels win), else direct.
 static bool wave_supported(int N);
-static int default_path(int N, int blu_P) { return wave_supported(N) ? 1 : ((blu_P && N >= 96) ? 2 : 0); }
+static int default_path(int N, int blu_P, int mr_P) { return wave_supported(N) ? 1 : (mr_P ? 3 : ((blu_P && N >= 96) ? 2 : 0)); }
 
 // Chirp-z family: smallest M = 64 P (P = 4, 8, 16, 24, 32) with M >= N + Np - 1 and a window instantiation
 // (NS = 2: Np <= 128; NS = 4: Np <= 256, P = 8, 16, 24); 0 when there is none.
 static int blu_pick_P(int N, int Np) {
-  if (N < 2) return 0;
+  if (N < 2 || mr_supported(N)) return 0;      // 50 P grids are drawn as 50 streams per row: 50-lane or direct family
   const int ns = (Np + 63) / 64;
   if (ns > 4) return 0;
   for (int P : {4, 8, 16, 24, 32}) {
@@ -230,6 +235,15 @@ static int blu_pick_P(int N, int Np) {
     return P;
   }
   return 0;
+}
+
+// 50-lane family: N = 50 P with a window instantiation (NS = 2: Np <= 128; NS = 4: Np <= 256 for P = 8, 10, 12, 16, 20, 24)
+constexpr bool mr_has_ns4(int P) { return P == 8 || P == 10 || P == 12 || P == 16 || P == 20 || P == 24; }
+static int mr_pick_P(int N, int Np) {
+  if (!mr_supported(N)) return 0;
+  const int P = N / MR_LN, ns = (Np + 63) / 64;
+  if (ns <= 2) return P;
+  return (ns <= 4 && mr_has_ns4(P)) ? P : 0;
 }
 
 // Which window instantiation of the wave family serves this handle: NS = 2 (Np <= 128), NS = 4
@@ -310,7 +324,8 @@ extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int p
   h->rsz = precision == FASTMC_F64 ? 8 : 4;
   h->blu_P = blu_pick_P(N, Np);
   if (const char* e = getenv("FASTMC_NO_DENSE16")) h->no_dense = e[0] && e[0] != '0';
-  h->path = default_path(N, h->blu_P);
+  h->mr_P = mr_pick_P(N, Np);
+  h->path = default_path(N, h->blu_P, h->mr_P);
   h->S = h->path == 1 ? spec_split(N) : 1;
   h->P = N / 64 / h->S;
   h->NS = (Np + 63) / 64;
@@ -372,7 +387,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   h->last_n_iter = 0;
   h->last_coherent = 0;
   h->batch = 0;
-  h->path = default_path(h->N, h->blu_P);
+  h->path = default_path(h->N, h->blu_P, h->mr_P);
   h->lo = 0;
   h->df = h->dx = h->wsum = 0;
   if (h->layers) { hipFree(h->layers); h->layers = nullptr; h->n_layers = 0; }
@@ -387,7 +402,7 @@ static void destroy_now(fastmc_ctx* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
-  void* ptrs[] = {h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+  void* ptrs[] = {h->mr_tw1, h->mr_om, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers, h->ps_dev};
   for (void* p : ptrs)
@@ -401,7 +416,8 @@ extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   if (force == 1 && !wave_supported(h->N)) return fail(FASTMC_EINVAL, "wave kernels need N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32");
   if (force == 2 && !h->blu_P) return fail(FASTMC_EINVAL, "chirp-z kernels need 64 P >= N + Np - 1 for P in {4, 8, 16, 24, 32} and Np <= 256");
-  if (force >= 0 && force <= 2) h->path = force;
+  if (force == 3 && !h->mr_P) return fail(FASTMC_EINVAL, "50-lane kernels need N = 50 P (not 64 P) with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32, and Np <= 128 (256 for P = 8, 10, 12, 16, 20, 24)");
+  if (force >= 0 && force <= 3) h->path = force;
   return h->path;
 }
 
@@ -559,6 +575,20 @@ static int upload_blu_tables(fastmc_ctx* h) {
   return 0;
 }
 
+template <class R>
+static int upload_mr_tables(fastmc_ctx* h) {
+  if (!h->mr_P || h->mr_lo == h->lo) return 0;
+  const int P = h->mr_P;
+  h->omS = (h->Np + 7) & ~7;
+  std::vector<cpx<R>> tw1((size_t)P * 64), om((size_t)5 * h->omS);
+  build_tw1_mr<R>(tw1.data(), P, cs_turns);
+  build_om_mr<R>(om.data(), h->omS, P, h->lo, h->Np, true, cs_turns);
+  TRY(upload_table<R>(&h->mr_tw1, tw1));
+  TRY(upload_table<R>(&h->mr_om, om));
+  h->mr_lo = h->lo;
+  return 0;
+}
+
 extern "C" int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, double dx) {
   if (!h || !W) return fail(FASTMC_EINVAL, "null argument");
   if (crop_lo < 0 || crop_lo + h->Np > h->N) return fail(FASTMC_EINVAL, "window [crop_lo, crop_lo+Np) outside the grid");
@@ -574,6 +604,10 @@ extern "C" int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, doubl
   if (!wave_supported(h->N) && h->blu_P) {
     if (h->blu_lo != crop_lo) h->blu_lo = -1;
     TRY(h->precision == FASTMC_F64 ? upload_blu_tables<double>(h) : upload_blu_tables<float>(h));
+  }
+  if (h->mr_P) {
+    if (h->mr_lo != crop_lo) h->mr_lo = -1;
+    TRY(h->precision == FASTMC_F64 ? upload_mr_tables<double>(h) : upload_mr_tables<float>(h));
   }
   if (wave_supported(h->N) && h->tables_lo != crop_lo) {      // the tables depend on (N, Np, window position) only
     h->tables_lo = -1;
@@ -715,6 +749,49 @@ static int dispatch_blu(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& C
   FMC_BLU(4, 2) FMC_BLU(8, 2) FMC_BLU(8, 4) FMC_BLU(16, 2) FMC_BLU(16, 4) FMC_BLU(24, 2) FMC_BLU(24, 4) FMC_BLU(32, 2)
 #undef FMC_BLU
   return fail(FASTMC_ESTATE, "no chirp-z instantiation for this grid / window");
+}
+
+template <class R, int P, int NS>
+static void dispatch_mr_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  constexpr int WPB = MrCfg<R, P, NS>::WPB;
+  const size_t lds = mr_lds_bytes<R, P, NS>(RA.omS);
+  constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
+  const int blocks = ((RA.N + LR - 1) / LR) * ((RA.nb + BPG - 1) / BPG);
+  {
+    Span s(h, 0);
+    if (mode == 0) {
+      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 0>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+    } else {
+      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 1>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+    }
+  }
+  {
+    Span s(h, 1);
+    const int items = CA.nb * CA.Np;
+    if (epi == 0) {
+      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 0>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+    } else {
+      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 1>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+    }
+  }
+}
+
+template <class R>
+static int dispatch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  const int ns = h->NS <= 2 ? 2 : 4;
+#define FMC_MR(PP)                                                                                             \
+  if (h->mr_P == PP) {                                                                                         \
+    if (ns == 2) { dispatch_mr_pn<R, PP, 2>(h, RA, CA, mode, epi); return 0; }                                 \
+    if constexpr (mr_has_ns4(PP)) { if (ns == 4) { dispatch_mr_pn<R, PP, 4>(h, RA, CA, mode, epi); return 0; } } \
+  }
+  FMC_MR(2) FMC_MR(3) FMC_MR(4) FMC_MR(5) FMC_MR(6) FMC_MR(7) FMC_MR(8) FMC_MR(9) FMC_MR(10) FMC_MR(12) FMC_MR(14) FMC_MR(16)
+  FMC_MR(18) FMC_MR(20) FMC_MR(24) FMC_MR(28) FMC_MR(32)
+#undef FMC_MR
+  return fail(FASTMC_ESTATE, "no 50-lane instantiation for this grid / window");
 }
 
 // N = 2048 (S = 2) and 4096 (S = 4): sub-rows of 1024 points through the P = 16 pipeline
@@ -891,6 +968,12 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       RA.blu.vhat = (const cpx<R>*)h->blu_vhat; RA.blu.post = (const cpx<R>*)h->blu_post;
       CA.tw = RA.tw; CA.om = RA.om; CA.cw = nullptr; CA.tw_global = 0; CA.blu = RA.blu;
       TRY(dispatch_blu<R>(h, RA, CA, S.mode, S.epi));
+    } else if (h->path == 3) {
+      TRY(upload_mr_tables<R>(h));
+      RA.amp = (const R*)h->amp_s; RA.ampf = h->ampf_s; RA.tw = (const cpx<R>*)h->mr_tw1; RA.om = (const cpx<R>*)h->mr_om;
+      RA.cw = nullptr; RA.tw_global = 0;
+      CA.tw = RA.tw; CA.om = RA.om; CA.cw = nullptr; CA.tw_global = 0;
+      TRY(dispatch_mr<R>(h, RA, CA, S.mode, S.epi));
     } else {
     bool wave_ok = h->path == 1;
     bool general_2048 = false;   // N = 2048, window > 256 pixels, host coefficients: single-pass P = 32 kernels
@@ -1025,7 +1108,7 @@ extern "C" int fastmc_rng_coeffs(fastmc_t* h, uint64_t seed, int64_t real, doubl
   ScratchBuf d;
   HIPCHK(hipMalloc((void**)&d.p, (size_t)N * N * 16));
   RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
-  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * WAVE * spec_split(N) + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, d.p);
+  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * stream_lanes(N) + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, d.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, d.p, (size_t)N * N * 16, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));

@@ -14,6 +14,7 @@
 #include "fmc_core.h"
 #include "fmc_wavefft.h"
 #include "fmc_bluestein.h"
+#include "fmc_mrfft.h"
 
 namespace fmc {
 
@@ -771,6 +772,134 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB_COLS * 64)) void k_cols_blu(
   }
 }
 
+// ================================================================== 50-lane family (N = 50 P: 100, 200, 250, 500, 1000, ...)
+// Round decimal grids (fast/conf.py NPXLS 1000 etc.) on the mixed-radix row of fmc_mrfft.h: the kernels of the wave family
+// with k = lane + 50 j inputs on lanes 0-49 and 50 generator streams per row (stream L = kx mod 50, fmc_core.h
+// stream_lanes).  Waves per workgroup: the exchange buffer is 69 P elements (P = 20: 11 KB) and the radix-P stage holds 2 P
+// values per lane, as in the wave family.
+template <class R, int P, int NS> struct MrCfg {
+  static constexpr int W0 = WaveCfg<R, P, NS>::WPB;
+  static constexpr int WPB = (sizeof(R) == 8 && P >= 16 && W0 > 8) ? 8 : W0;
+};
+template <class R, int P, int NS>
+__host__ __device__ constexpr size_t mr_lds_bytes(int omS) {
+  return (size_t)(P * WAVE + MrGeom<R, P>::L0 * omS) * sizeof(cpx<R>) + (size_t)MrCfg<R, P, NS>::WPB * MrGeom<R, P>::XELEMS * 8;
+}
+template <class R, int P>
+__device__ __forceinline__ void load_tables_mr(cpx<R>* s_tw, cpx<R>* s_om, const cpx<R>* tw, const cpx<R>* om, int omS) {
+  for (int i = threadIdx.x; i < P * WAVE; i += blockDim.x) s_tw[i] = tw[i];
+  for (int i = threadIdx.x; i < MrGeom<R, P>::L0 * omS; i += blockDim.x) s_om[i] = om[i];
+  __syncthreads();
+}
+
+template <class R, int P, int NS, int MODE>
+__global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_rows_mr(RowArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using G = MrGeom<R, P>;
+  using E = typename Xch<R>::E;
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  cpx<R>* s_om = s_tw + P * WAVE;
+  E* s_x = reinterpret_cast<E*>(s_om + G::L0 * A.omS);
+  load_tables_mr<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
+
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane < MR_LN ? lane : MR_LN - 1;      // idle lanes repeat lane 49 (in-bounds loads; nothing reads their column)
+  E* xbuf = s_x + w * G::XELEMS;
+  constexpr int N = G::N;
+  LaneRegs<R, P, NS> regs;
+  GpuExec<R, P, NS> ex{lane, regs};
+  constexpr int WPB = MrCfg<R, P, NS>::WPB;
+  constexpr int LR = 128 / (int)sizeof(cpx<R>);
+  static_assert((ROWS_PER_WAVE * WPB) % LR == 0, "tile must hold whole lines");
+  constexpr int BPG = ROWS_PER_WAVE * WPB / LR;
+  const int nbb = (A.nb + BPG - 1) / BPG;
+  const int b0 = (blockIdx.x % nbb) * BPG;
+  const int row0 = (blockIdx.x / nbb) * LR;
+  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+    const int flat = rr * WPB + w;
+    const int b = b0 + flat / LR;
+    if (b >= A.nb) break;                                // wave-uniform
+    const int ky = row0 + flat % LR;
+    if (ky >= N) continue;                               // wave-uniform (N need not be a multiple of LR)
+    const uint64_t g = A.g0 + (uint64_t)b;
+    if (MODE == 0) {
+      const float* ampf = A.ampf + (size_t)ky * N;
+      xoshiro128p rs = row_stream(A.key, g, ky, li, MR_LN);
+#pragma unroll
+      for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[li + MR_LN * j]);
+    } else {
+      const size_t base = ((size_t)b * N + ky) * N;
+      const R* amp = A.amp + (size_t)ky * N;
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int kx = li + MR_LN * j;
+        regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
+      }
+    }
+    pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    cpx<R>* out = A.V + (size_t)b * A.Np * N + ky;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int oi = lane + WAVE * s;
+      if (oi < A.Np) out[(size_t)oi * N] = mk<R>(regs.xr[s], regs.xi[s]);
+    }
+  }
+}
+
+template <class R, int P, int NS, int EPI>
+__global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_cols_mr(ColArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using G = MrGeom<R, P>;
+  using E = typename Xch<R>::E;
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  cpx<R>* s_om = s_tw + P * WAVE;
+  E* s_x = reinterpret_cast<E*>(s_om + G::L0 * A.omS);
+  load_tables_mr<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
+
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane < MR_LN ? lane : MR_LN - 1;
+  E* xbuf = s_x + w * G::XELEMS;
+  const int item = blockIdx.x * MrCfg<R, P, NS>::WPB + w;
+  if (item >= A.nb * A.Np) return;   // whole wave exits; no block barrier follows
+  const int b = item / A.Np;
+  const int xi = item % A.Np;
+  constexpr int N = G::N;
+  LaneRegs<R, P, NS> regs;
+  GpuExec<R, P, NS> ex{lane, regs};
+  const cpx<R>* col = A.V + ((size_t)b * A.Np + xi) * N;
+#pragma unroll
+  for (int j = 0; j < P; ++j) regs.v[j] = col[li + MR_LN * j];
+  pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int yi = lane + WAVE * s;
+    if (yi < A.Np) {
+      R p1 = regs.xr[s], p2 = regs.xi[s];
+      pixel_phase<R>(A.sh, b, A.Np, yi, xi, p1, p2);
+      if (EPI == 1) {
+        const size_t plane = (size_t)A.Np * A.Np;
+        A.phs[((size_t)b) * plane + (size_t)yi * A.Np + xi] = (double)p1;
+        A.phs[((size_t)(A.nb + b)) * plane + (size_t)yi * A.Np + xi] = (double)p2;
+      } else {
+        const double wgt = A.W[(size_t)yi * A.Np + xi];
+        double s1, c1, s2, c2;
+        sincos_r(p1, s1, c1);
+        sincos_r(p2, s2, c2);
+        acc[0] += wgt * c1; acc[1] += wgt * s1; acc[2] += wgt * c2; acc[3] += wgt * s2;
+      }
+    }
+  }
+  if (EPI == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane == 0) {
+      double* o = A.partial + ((size_t)b * A.Np + xi) * 4;
+      o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+    }
+  }
+}
+
 // ================================================================== direct family (any N <= 4096)
 constexpr int DIRECT_THREADS = 256;
 constexpr int DIRECT_RESYNC = 16;   // terms between exact twiddle re-reads in the direct kernels
@@ -791,7 +920,7 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_rows_direct(RowArgs<R> A) {
   if (!A.tw_global)
     for (int i = threadIdx.x; i < N; i += blockDim.x) s_lds[i] = A.tw[i];
   if (MODE == 0) {
-    const int SL = WAVE * spec_split(N);
+    const int SL = stream_lanes(N);
     if ((int)threadIdx.x < SL && (int)threadIdx.x < N) {   // one sequential stream per stream index
       xoshiro128p rs = row_stream(A.key, g, ky, threadIdx.x, SL);
       for (int kx = threadIdx.x; kx < N; kx += SL) s_row[kx] = draw_coloured<R>(rs, A.ampf[(size_t)ky * N + kx]);
@@ -1231,7 +1360,7 @@ __global__ void k_link_final(const double* partial, int nblocks, int64_t n, cons
 
 // ================================================================== generator read-back (parity tests)
 __global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, double* out) {
-  const int SL = WAVE * spec_split(N);
+  const int SL = stream_lanes(N);
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * SL) return;
   const int ky = idx / SL, l = idx % SL;

@@ -87,10 +87,15 @@ constexpr int tw_chunk() {
 #endif
 }
 
-// Per-lane registers of the pipeline.
+// Per-lane registers of the pipeline.  Wide enough for the 50-lane factorisation of fmc_mrfft.h too (P L0 / 64 radix-10
+// butterflies per lane); elements a kernel never touches cost nothing (the array is scalarised).
+constexpr int lane_regs_vn(int P) {
+  const int w = (P + 7) / 8 * 8, m = (P * 5 + 63) / 64 * 10;
+  return w > m ? w : m;
+}
 template <class R, int P, int NS>
 struct LaneRegs {
-  cpx<R> v[WaveGeom<R, P>::VN];   // inputs (first P) -> stage values
+  cpx<R> v[lane_regs_vn(P)];      // inputs (first P) -> stage values
   R xr[NS];      // outputs, real part       (slot s  <->  window index lane + 64 s)
   R xi[NS];      // outputs, imaginary part
 };

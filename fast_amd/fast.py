@@ -120,7 +120,7 @@ class Fast():
             self._group.set_batch(p['GPU_BATCH'])
         if p['GPU_KERNELS'] != 'auto':
             if p['GPU_KERNELS'] not in _lib.KERNEL_PATHS:
-                raise Exception("GPU_KERNELS must be 'auto', 'wave', 'chirpz' or 'direct'")
+                raise Exception("GPU_KERNELS must be 'auto', 'wave', 'lanes50', 'chirpz' or 'direct'")
             self._group.each(lambda h, i: h.kernel_path(_lib.KERNEL_PATHS[p['GPU_KERNELS']]))
         self.compute_powerspec()
         if self._handle.kernel_path() != 1 and self.Npxls >= 128 and not self.temporal:

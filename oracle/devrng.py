@@ -80,16 +80,29 @@ def spec_split(N):
     return 4 if N == 4096 else (2 if N == 2048 else 1)
 
 
+def mr_supported(N):
+    """fmc_core.h: mr_supported -- grids of the 50-lane kernel family: N = 50 P, P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32,
+    unless N is a size of the wave family (64 P' with P' of the same form)."""
+    def ok(P):
+        return 2 <= P <= 32 and P // (P & -P) in (1, 3, 5, 7, 9)
+    return N % 50 == 0 and ok(N // 50) and not (N % 64 == 0 and ok(N // 64))
+
+
+def stream_lanes(N):
+    """fmc_core.h: stream_lanes -- generator streams per row: 50 on the 50 P grids, else 64 * spec_split(N)."""
+    return 50 if mr_supported(N) else 64 * spec_split(N)
+
+
 def device_coefficients(seed, g, N):
     """(N, N) complex coefficients of realisation g (== fastmc_rng_coeffs).
 
-    SL = 64 * spec_split(N) streams per row.  Stream (g, ky, L = kx mod SL): state = Philox4x32-7(ctr =
+    SL = stream_lanes(N) streams per row (64; 128 / 256 at 2048 / 4096; 50 on the 50 P grids).  Stream (g, ky, L = kx mod SL): state = Philox4x32-7(ctr =
     (ky*SL + L, STREAM_SCREEN, g_lo, g_hi), key = seed) (s0 := 1 if the block is all zero); coefficient
     (ky, L + SL j) = BM(s0 + s3, s1 + s2) of the xoshiro128+ state after j advances (fmc_core.h: xoshiro128p::next2,
     fmc_kernels.h: row_stream / draw_words).  The device colours these float32 normals with sqrt(powerspec) * df
     rounded to float32 (fmc_kernels.h: draw_coloured); the restatement keeps float64 throughout (difference ~6e-8
     relative per coefficient, inside the 2e-3 bar of the device-generator tests)."""
-    SL = 64 * spec_split(N)
+    SL = stream_lanes(N)
     lanes = min(SL, N)
     ky, l = np.meshgrid(np.arange(N), np.arange(lanes), indexing="ij")
     x = philox4x32_10(ky * SL + l, STREAM_SCREEN, g & 0xFFFFFFFF, g >> 32, seed & 0xFFFFFFFF, seed >> 32, rounds=SEED_ROUNDS)

@@ -36,7 +36,7 @@ def params_from_json(s):
 
 E2E_CASES = ["ao_alias", "noao", "noao_L0", "tt", "noise", "noalias_noise", "modal", "modal_zmax",
              "lgsao", "subharm", "subharm_ao", "coherent", "down", "obsc", "axicon", "w0fixed",
-             "lsat_aniso", "oddNp", "autosize", "oddN"]
+             "lsat_aniso", "oddNp", "autosize", "oddN", "npxls100", "npxls150", "npxls200"]
 
 
 @pytest.fixture(scope="session")

@@ -30,7 +30,7 @@ def _window_W(Np, seed=0):
 
 
 # ------------------------------------------------------------------ generator
-@pytest.mark.parametrize("N", [16, 33, 512, 2048, 4096])
+@pytest.mark.parametrize("N", [16, 33, 512, 2048, 4096, 200, 1000])
 def test_device_generator_matches_oracle_restatement(N):
     h = _lib.Handle(N, max(1, N // 4), "f64", 0)
     for seed, g in ((1, 0), (0xDEADBEEFCAFE, 5), (7, 2 ** 33 + 3)):
@@ -49,7 +49,7 @@ def test_device_generator_matches_oracle_restatement(N):
 
 
 # ------------------------------------------------------------------ screens: golden FFT KATs (direct family)
-@pytest.mark.parametrize("N", [16, 30, 33, 64, 128])
+@pytest.mark.parametrize("N", [16, 30, 33, 64, 128, 100, 150])
 @pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 3e-5)])
 def test_screens_match_reference_fft_kat(N, prec, tol):
     g = load_golden(f"kat_fft_N{N}")
@@ -187,7 +187,7 @@ def test_powerspec_kernel_matches_reference(case):
 
 @pytest.mark.parametrize("name", ["big_noao_1024", "big_noao_L0_1024", "big_ao_1024", "cfg1_256", "big_noao_L0_2048", "big_noao_L0_4096",
                                   "big_tt_1024", "big_lgsao_1024", "big_modal_zmax_noise_1024", "big_subharm_coherent_down_1024",
-                                  "big_zenith05_1024", "big_zenith27_1024"])
+                                  "big_zenith05_1024", "big_zenith27_1024", "big_ao_1000"])
 def test_powerspec_kernel_full_size(name):
     g = load_golden(name)
     p = params_from_json(g["params_json"])
@@ -230,7 +230,7 @@ def test_fast_run_f32_close_to_reference(case):
 
 @pytest.mark.parametrize("name", ["cfg1_256", "big_noao_1024", "big_noao_L0_1024", "big_ao_1024", "big_noao_L0_2048", "big_noao_L0_4096",
                                   "big_tt_1024", "big_lgsao_1024", "big_modal_zmax_noise_1024", "big_subharm_coherent_down_1024",
-                                  "big_zenith05_1024", "big_zenith27_1024"])
+                                  "big_zenith05_1024", "big_zenith27_1024", "big_ao_1000"])
 def test_fast_run_full_size_same_seed(name):
     g = load_golden(name)
     p = params_from_json(g["params_json"])
@@ -505,7 +505,7 @@ def test_many_realisations_cross_finalize_span():
     np.testing.assert_array_equal(one, [full[32999], full[n + 32999]])
 
 
-@pytest.mark.parametrize("name", ["temporal_default", "temporal_small", "temporal_noao"])
+@pytest.mark.parametrize("name", ["temporal_default", "temporal_small", "temporal_noao", "temporal_npxls100"])
 def test_temporal_mode_reproduces_reference(name):
     """TEMPORAL (frozen-flow) runs, incl. the reference's shipped test_params.py: same SEED -> same series."""
     g = load_golden(name)
@@ -774,7 +774,7 @@ def test_two_handles_in_two_threads():
         np.testing.assert_array_equal(alone[j], together[j])
 
 
-@pytest.mark.parametrize("N", [16, 30, 33, 64, 128])
+@pytest.mark.parametrize("N", [16, 30, 33, 64, 128, 100, 150])
 def test_funcs_make_phase_fft_like_the_reference(N):
     """fast_amd.funcs.make_phase_fft (reference signature, fast/funcs.py:210-223) against the reference's own
     outputs: full N x N screens, double=True stacks [Re | Im], double=False returns Re."""
@@ -869,7 +869,7 @@ def test_subharm_bookkeeping_attributes_like_the_reference():
 
 
 # ------------------------------------------------------------------ chirp-z family: grid sizes that are not 64 P
-@pytest.mark.parametrize("N,Np", [(164, 82), (100, 40), (49, 23), (33, 9), (250, 129), (500, 82), (943, 82), (1000, 82), (1455, 82),
+@pytest.mark.parametrize("N,Np", [(164, 82), (102, 40), (49, 23), (33, 9), (252, 129), (502, 82), (943, 82), (1002, 82), (1455, 82),
                                   (1280 - 255, 256), (1900, 100), (333, 333 // 3)])
 @pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 5e-5)])
 def test_chirpz_kernels_match_oracle_fft(N, Np, prec, tol):
@@ -897,7 +897,7 @@ def test_chirpz_kernels_match_oracle_fft(N, Np, prec, tol):
     assert np.abs(got_d[0] - want_lo[0]).max() <= tol * np.abs(want).max()
 
 
-@pytest.mark.parametrize("N,Np", [(164, 82), (1000, 82), (300, 150)])
+@pytest.mark.parametrize("N,Np", [(164, 82), (1002, 82), (302, 150)])
 def test_chirpz_device_generator_equals_direct_family(N, Np):
     h, ps, df, W = _small_problem(N, Np)
     assert h.kernel_path() == 2
@@ -924,6 +924,64 @@ def test_fast_run_reproduces_reference_on_chirpz_kernels(case):
     sim = fast_amd.Fast(p)
     assert sim._handle.kernel_path() == 2
     np.testing.assert_allclose(sim.run()._r, g["r"], rtol=1e-9)
+
+
+# ------------------------------------------------------------------ 50-lane family: N = 50 P (100, 200, 250, 500, 1000, ...)
+@pytest.mark.parametrize("N,Np", [(100, 40), (150, 120), (200, 128), (250, 82), (300, 33), (350, 82), (400, 256), (450, 82), (500, 82),
+                                  (600, 200), (700, 82), (800, 101), (900, 82), (1000, 82), (1000, 256), (1200, 82), (1400, 82),
+                                  (1600, 128)])
+@pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 5e-5)])
+def test_lanes50_kernels_match_oracle_fft(N, Np, prec, tol):
+    """Round decimal grids (NPXLS 1000 etc.) on the 50-lane mixed-radix kernels (fmc_mrfft.h): screens from host coefficients
+    against the oracle's FFT-branch transform for windows in the middle and at both ends, and against the direct family."""
+    ps, df = _vk_spectrum(N, 0.01, 25.0)
+    rng = np.random.default_rng(N + Np)
+    cr, ci = rng.normal(size=(2, N, N)), rng.normal(size=(2, N, N))
+    full = R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df))
+    for lo in sorted({(N - Np) // 2, 0, N - Np}):
+        h = _lib.Handle(N, Np, prec, 0)
+        assert h.kernel_path() == 3
+        h.set_spectrum(ps, df)
+        h.set_pupil(np.ones((Np, Np)), lo, 0.01)
+        got = h.screens_coeffs(cr, ci)
+        want = full[:, lo:lo + Np, lo:lo + Np]
+        assert np.abs(got - want).max() <= tol * np.abs(full).max()
+    h.kernel_path(0)
+    got_d = h.screens_coeffs(cr[:1], ci[:1])
+    assert np.abs(got_d[0] - want[0]).max() <= tol * np.abs(full).max()
+    with pytest.raises(_lib.FastMCError):
+        h.kernel_path(2)             # 50 streams per row: the chirp-z kernels (64 streams) do not serve these grids
+
+
+@pytest.mark.parametrize("N,Np", [(100, 50), (500, 82), (1000, 82), (600, 150)])
+def test_lanes50_device_generator_equals_direct_family(N, Np):
+    h, ps, df, W = _small_problem(N, Np)
+    assert h.kernel_path() == 3
+    a = h.run(7, 3, 6, None, 0.02)
+    coh = h.run(7, 3, 6, None, 0.02, coherent=True)
+    np.testing.assert_allclose(np.abs(coh) ** 2, a, rtol=1e-12)
+    h.set_batch(4)
+    np.testing.assert_array_equal(h.run(7, 3, 6, None, 0.02), a)
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.run(7, 3, 6, None, 0.02), a, rtol=1e-9)
+    # and the restated generator (50 streams per row) + oracle
+    coeffs = np.stack([devrng.device_coefficients(7, 3 + j, N) for j in range(6)])
+    chi = devrng.device_logamp_normals(7, 6, 12) * np.sqrt(0.02)
+    la = np.concatenate([chi[0::2], chi[1::2]])
+    np.testing.assert_allclose(a, R.powers_from_coefficients(coeffs, ps, df, W, 0.01, la), rtol=2e-3)
+
+
+@pytest.mark.parametrize("case", ["npxls100", "npxls150", "npxls200"])
+def test_fast_run_reproduces_reference_on_lanes50_and_direct_kernels(case):
+    """The captured 100^2 / 150^2 / 200^2 runs of the reference: same SEED -> same `_r` on the 50-lane family (the default there)
+    and on the direct family."""
+    g = load_golden("e2e_" + case)
+    for fam, path in (("auto", 3), ("direct", 0)):
+        p = params_from_json(g["params_json"])
+        p.update({"GPU_RNG": "host", "GPU_DEVICE": 0, "GPU_KERNELS": fam})
+        sim = fast_amd.Fast(p)
+        assert sim._handle.kernel_path() == path
+        np.testing.assert_allclose(sim.run()._r, g["r"], rtol=1e-9)
 
 
 def test_wide_windows_on_split_grids_use_the_wave_family():

@@ -39,7 +39,7 @@ def test_host_init_matches_reference(case):
     np.testing.assert_allclose(list(prob.link_budget.values()), g["link_budget_vals"], rtol=1e-12)
 
 
-@pytest.mark.parametrize("case", ["subharm", "subharm_ao", "oddN"])
+@pytest.mark.parametrize("case", ["subharm", "subharm_ao", "oddN", "npxls150"])
 def test_subharm_spectrum_matches_reference(case):
     g, p, prob = _problem(case)
     ps, fx, fy, df, sh = host.subharm_spectrum(prob)
@@ -107,7 +107,7 @@ def test_fast_result_properties():
     assert "Scintillation index" in str(res)
 
 
-@pytest.mark.parametrize("name", ["temporal_default", "temporal_small", "temporal_noao"])
+@pytest.mark.parametrize("name", ["temporal_default", "temporal_small", "temporal_noao", "temporal_npxls100"])
 def test_temporal_host_setup_matches_reference(name):
     g = load_golden(name)
     p = fast_amd.conf.ConfigParser(dict(params_from_json(g["params_json"]))).config

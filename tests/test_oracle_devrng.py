@@ -106,6 +106,19 @@ def test_generator_statistics():
     assert corr(re[:, :-1], re[:, 1:]) < 5 and corr(re[0], re[1]) < 5 and corr(re, im) < 5
 
 
+def test_stream_layout_of_the_50_lane_grids():
+    """N = 50 P grids (fmc_core.h: mr_supported / stream_lanes) are drawn as 50 streams per row, the others as 64 S."""
+    assert [n for n in range(2, 4097) if devrng.mr_supported(n)] == [100, 150, 200, 250, 300, 350, 400, 450, 500, 600, 700,
+                                                                      800, 900, 1000, 1200, 1400, 1600]
+    assert devrng.stream_lanes(1000) == 50 and devrng.stream_lanes(1024) == 64 and devrng.stream_lanes(2048) == 128
+    assert devrng.stream_lanes(3200) == 64 and devrng.stream_lanes(550) == 64 and devrng.stream_lanes(164) == 64
+    c = devrng.device_coefficients(5, 0, 100)
+    assert np.isfinite(c).all() and len(np.unique(c.ravel())) == 100 * 100
+    # column kx belongs to stream kx mod 50 at step kx // 50: the first 50 columns are the first draw of every stream
+    c64 = devrng.device_coefficients(5, 0, 96)          # 64 streams per row: a different layout, different values
+    assert not np.allclose(c[:96, :50], c64[:, :50])
+
+
 def test_split_layouts_cover_the_grid():
     """2048 / 4096 draw 128 / 256 streams per row (fmc_core.h: spec_split); every coefficient is drawn once."""
     for N in (2048,):

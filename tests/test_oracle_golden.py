@@ -6,7 +6,7 @@ from conftest import E2E_CASES, load_golden, params_from_json
 from oracle import fastref as R
 
 
-@pytest.mark.parametrize("N", [16, 30, 33, 64, 128])
+@pytest.mark.parametrize("N", [16, 30, 33, 64, 128, 100, 150])
 def test_fft_branch_matches_reference(N):
     g = load_golden(f"kat_fft_N{N}")
     z = R.screens_fftw(g["coeffs"] * np.sqrt(g["powerspec"]), float(g["df"]))
@@ -109,7 +109,7 @@ def test_monte_carlo_matches_reference_same_seed(case):
 
 
 # ------------------------------------------------------------------ temporal (frozen-flow) mode
-@pytest.mark.parametrize("name", ["temporal_default", "temporal_small", "temporal_noao"])
+@pytest.mark.parametrize("name", ["temporal_default", "temporal_small", "temporal_noao", "temporal_npxls100"])
 def test_temporal_mode_matches_reference(name):
     g = load_golden(name)
     p = params_from_json(g["params_json"])

@@ -438,6 +438,48 @@ def numpy_branch():
          Npxls=np.array(sim.Npxls), Npxls_pup=np.array(sim.Npxls_pup))
 
 
+def decimal():
+    """Round decimal grids (NPXLS 100, 150, 200, 1000: the 50-lane kernel family of the GPU library, 50 streams per row):
+    make_phase_fft KATs at N = 100 (N = 0 mod 4) and 150 (N = 2 mod 4), three small end-to-end runs, a TEMPORAL run and
+    the BASELINE geometry at 1000^2 (scalars + strided spectrum sample + powers)."""
+    rng = np.random.default_rng(20261003)
+    for N, L0 in ((100, 25.0), (150, np.inf)):
+        B, dx = 2, 0.02
+        freq = fast.fast.SpatialFrequencies(N, dx)
+        ps = funcs.turb_powerspectrum_vonKarman(freq.main, np.array([3e-13, 1e-13]), L0, 1e-3).sum(0)
+        ps = ps * 2 * np.pi * (2 * np.pi / 1550e-9) ** 2
+        coeffs = rng.normal(size=(B, N, N)) + 1j * rng.normal(size=(B, N, N))
+        scr = funcs.make_phase_fft(coeffs * np.sqrt(ps), freq.main.df, True, fftw_objs_for((B, N, N)), double=True)
+        save(f"kat_fft_N{N}", f"make_phase_fft FFTW branch, N={N}, L0={L0}", False,
+             N=N, dx=dx, df=freq.main.df, powerspec=ps, coeffs=coeffs, screens=scr)
+    capture_sim("e2e_npxls100", base_params(NPXLS=100), "AO + ALIAS on a 100^2 grid")
+    capture_sim("e2e_npxls150", base_params(NPXLS=150, SUBHARM=True, AO_MODE="NOAO", L0=40.0, D_GROUND=0.3),
+                "NOAO + SUBHARM on a 150^2 grid (N = 2 mod 4), L0=40, 30 cm aperture")
+    capture_sim("e2e_npxls200", base_params(NPXLS=200, COHERENT=True, PROP_DIR="down", D_GROUND=0.5, NITER=4, NCHUNKS=2),
+                "AO + ALIAS, COHERENT, downlink on a 200^2 grid, 50 cm aperture")
+    # the temporal fixture keeps what temporal() keeps
+    def cap_t(name, p, note):
+        sim = fast.Fast(p)
+        res = sim.run()
+        d = {"params_json": np.array(params_to_json(p))}
+        for k in ("dx", "Npxls", "Npxls_pup", "logamp_var", "diffraction_limit", "W0"):
+            d[k] = np.array(getattr(sim, k))
+        d.update(h=sim.h, cn2=sim.cn2, wind_vector=sim.wind_vector, wind_speed=sim.wind_speed,
+                 wind_dir=np.asarray(sim.wind_dir, dtype=float), pupil=sim.pupil, pupil_mode=sim.pupil_mode,
+                 powerspec_per_layer=sim.powerspec_per_layer, temporal_logamp_powerspec=sim.temporal_logamp_powerspec,
+                 pixel_shifts=sim.pixel_shifts, logamp=sim.logamp.copy(), r=res._r, phs_last_chunk=sim.phs.copy(),
+                 fx_axis_t=sim.freq.temporal.fx_axis, fy_axis_t=sim.freq.temporal.fy_axis, fabs_t=sim.freq.temporal.fabs)
+        save(name, note, True, **d)
+    cap_t("temporal_npxls100", base_params(TEMPORAL=True, NITER=16, NCHUNKS=4, DT=0.004, NPXLS=100),
+          "TEMPORAL on a 100^2 grid: 16 steps of 4 ms")
+    h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
+    p = dict(fast.conf.DEFAULTS)
+    p.update({"NPXLS": 1000, "DX": 0.01, "NITER": 8, "NCHUNKS": 2, "TEMPORAL": False, "FFTW": True, "SEED": 3, "W0": "opt",
+              "D_GROUND": 0.8, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w, "WIND_DIR": [0, 90, 180, 270], "ZENITH_ANGLE": 55,
+              "DSUBAP": 0.1, "LOGLEVEL": "ERROR", "H_SAT": 36e6, "AO_MODE": "AO", "ALIAS": True})
+    capture_sim("big_ao_1000", p, "BASELINE geometry on NPXLS 1000 (AO + ALIAS), NITER 8", full=False, stride=20)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("capturing into", OUT)
@@ -449,7 +491,7 @@ def main():
         else:
             {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref,
              "--only-comms": comms_metrics, "--only-big2048": big2048, "--only-big-modes": big_modes,
-             "--only-zenith": zenith, "--only-numpy-branch": numpy_branch}[only[0]]()
+             "--only-zenith": zenith, "--only-numpy-branch": numpy_branch, "--only-decimal": decimal}[only[0]]()
         for name, size, st, note in MANIFEST:
             print(f"| {name}.npz | {size} | {st} | {note} |")
         return
@@ -468,6 +510,7 @@ def main():
         big2048()            # add --with-4096 for the 4096^2 fixture (70 s of reference init)
         big_modes()
         zenith()
+        decimal()
     with open(os.path.join(OUT, "MANIFEST.md"), "w") as f:
         f.write("# Golden fixtures captured from the reference (tools/capture_golden/capture.py)\n\n")
         f.write(f"numpy {np.__version__}; reference snapshot /root/reference (2025-04-04).\n")

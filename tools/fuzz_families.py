@@ -1,4 +1,4 @@
-"""Differential fuzz: wave / chirp-z family vs direct family on random (N, Np, lo, precision) with host coefficients
+"""Differential fuzz: wave / chirp-z / 50-lane family vs direct family on random (N, Np, lo, precision) with host coefficients
 (screens) and with the device generator (powers), and the screens against numpy for the smaller grids (odd N use
 numpy's asymmetric fftshift).  tools/fuzz_families.py [cases] [seed]"""
 import os
@@ -16,6 +16,8 @@ for c in range(cases):
         N = int(rng.choice([s for s in host.WAVE_FFT_SIZES if s < 2048]))
     if c % 2:                                           # every other case: a size that is not 64 P -> chirp-z family
         N = int(rng.integers(8, 1500))
+    if c % 4 == 3:                                      # every fourth: N = 50 P -> 50-lane family
+        N = int(rng.choice([100, 150, 200, 250, 300, 350, 400, 450, 500, 600, 700, 800, 900, 1000, 1200, 1400, 1600]))
     Np = int(rng.integers(1, min(N, 300 if c % 2 == 0 else 256) + 1))
     lo = int(rng.choice([0, N - Np, (N - Np) // 2, rng.integers(0, N - Np + 1)]))
     prec = "f64" if rng.random() < 0.7 else "f32"

@@ -1,0 +1,35 @@
+import sys, numpy as np
+sys.path.insert(0, "/root/repo")
+from fast_amd import _lib
+import time
+rng = np.random.default_rng(0)
+bad = 0
+for (N, Np, lo, prec) in [(1000, 82, 459, "f64"), (500, 82, 209, "f64"), (250, 64, 93, "f64"), (100, 50, 25, "f64"), (200, 128, 0, "f64"),
+                          (1000, 200, 400, "f64"), (1000, 82, 459, "f32"), (150, 30, 120, "f64"), (1600, 82, 759, "f64"), (700, 100, 300, "f32"),
+                          (450, 82, 184, "f64"), (1400, 100, 650, "f64"), (900, 90, 405, "f64"), (600, 256, 172, "f64")]:
+    tol = 1e-10 if prec == "f64" else 1e-4
+    ps = rng.uniform(0.0, 1.0, size=(N, N)) ** 4 * 1e-3
+    cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
+    h = _lib.Handle(N, Np, prec, 0)
+    h.set_spectrum(ps, 0.37); h.set_pupil(np.ones((Np, Np)), lo, 0.01)
+    path = h.kernel_path()
+    a = h.screens_coeffs(cr, ci); ra = h.run(5, 3, 2, None, 0.01)
+    h.kernel_path(0)
+    b = h.screens_coeffs(cr, ci); rb = h.run(5, 3, 2, None, 0.01)
+    h.close()
+    z = np.fft.fftshift(np.fft.fft2(np.fft.fftshift((cr[0] + 1j * ci[0]) * np.sqrt(ps) * 0.37)))[lo:lo + Np, lo:lo + Np]
+    e_np = max(np.abs(a[0] - z.real).max(), np.abs(a[1] - z.imag).max()) / np.abs(z).max()
+    e_d = np.abs(a - b).max() / np.abs(b).max()
+    e_r = np.abs(ra - rb).max() / np.abs(rb).max()
+    ok = e_np < tol and e_d < tol and e_r < (1e-9 if prec == "f64" else 1e-2)
+    bad += not ok
+    print("ok " if ok else "BAD", N, Np, lo, prec, "path", path, "vs numpy %.2e vs direct %.2e run %.2e" % (e_np, e_d, e_r))
+# oracle restatement of the generator on a 50-lane grid
+sys.path.insert(0, "/root/repo")
+from oracle import devrng
+h = _lib.Handle(200, 64, "f64", 0)
+c = h.rng_coeffs(1234, 7)
+o = devrng.device_coefficients(1234, 7, 200)
+print("rng 200 vs oracle", np.abs(c - o).max())
+h.close()
+print("failures", bad)

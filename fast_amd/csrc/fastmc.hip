@@ -69,7 +69,9 @@ struct fastmc_ctx {
   void* blu_vhat = nullptr;
   void* blu_post = nullptr;
   // 50-lane family (path 3: N = 50 P, fmc_mrfft.h)
-  int mr_P = 0;            // 0: not eligible (N not 50 P, or no window instantiation)
+  int mr_P = 0;            // 0: not eligible (N not 50 P S, or no window instantiation)
+  int mr_S = 1;            // sub-rows per row (mr_split(N))
+  void* mr_cw = nullptr;   // S > 1: [S][omS] combination twiddles
   int mr_lo = -1;          // window position the tables below were built for
   void* mr_tw1 = nullptr;
   void* mr_om = nullptr;
@@ -241,7 +243,7 @@ static int blu_pick_P(int N, int Np) {
 constexpr bool mr_has_ns4(int P) { return P == 8 || P == 10 || P == 12 || P == 16 || P == 20 || P == 24; }
 static int mr_pick_P(int N, int Np) {
   if (!mr_supported(N)) return 0;
-  const int P = N / MR_LN, ns = (Np + 63) / 64;
+  const int P = N / MR_LN / mr_split(N), ns = (Np + 63) / 64;
   if (ns <= 2) return P;
   return (ns <= 4 && mr_has_ns4(P)) ? P : 0;
 }
@@ -325,6 +327,7 @@ extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int p
   h->blu_P = blu_pick_P(N, Np);
   if (const char* e = getenv("FASTMC_NO_DENSE16")) h->no_dense = e[0] && e[0] != '0';
   h->mr_P = mr_pick_P(N, Np);
+  h->mr_S = h->mr_P ? mr_split(N) : 1;
   h->path = default_path(N, h->blu_P, h->mr_P);
   h->S = h->path == 1 ? spec_split(N) : 1;
   h->P = N / 64 / h->S;
@@ -402,7 +405,7 @@ static void destroy_now(fastmc_ctx* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
-  void* ptrs[] = {h->mr_tw1, h->mr_om, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers, h->ps_dev};
   for (void* p : ptrs)
@@ -416,7 +419,7 @@ extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   if (force == 1 && !wave_supported(h->N)) return fail(FASTMC_EINVAL, "wave kernels need N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32");
   if (force == 2 && !h->blu_P) return fail(FASTMC_EINVAL, "chirp-z kernels need 64 P >= N + Np - 1 for P in {4, 8, 16, 24, 32} and Np <= 256");
-  if (force == 3 && !h->mr_P) return fail(FASTMC_EINVAL, "50-lane kernels need N = 50 P (not 64 P) with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32, and Np <= 128 (256 for P = 8, 10, 12, 16, 20, 24)");
+  if (force == 3 && !h->mr_P) return fail(FASTMC_EINVAL, "50-lane kernels need N = 50 P S (not 64 P') with P = 2^k times 1, 3, 5, 7 or 9, P <= 24, S <= 5, and Np <= 128 (256 for P = 8, 10, 12, 16, 20, 24)");
   if (force >= 0 && force <= 3) h->path = force;
   return h->path;
 }
@@ -582,9 +585,20 @@ static int upload_mr_tables(fastmc_ctx* h) {
   h->omS = (h->Np + 7) & ~7;
   std::vector<cpx<R>> tw1((size_t)P * 64), om((size_t)5 * h->omS);
   build_tw1_mr<R>(tw1.data(), P, cs_turns);
-  build_om_mr<R>(om.data(), h->omS, P, h->lo, h->Np, true, cs_turns);
+  build_om_mr<R>(om.data(), h->omS, P, h->lo, h->Np, true, cs_turns, h->mr_S);
   TRY(upload_table<R>(&h->mr_tw1, tw1));
   TRY(upload_table<R>(&h->mr_om, om));
+  if (h->mr_S > 1) {
+    // X[x] = sum_s w_N^{s x} Y_s[x mod N/S]:  cw[s][oi] = w_N^{s (lo + oi)}
+    std::vector<cpx<R>> cw((size_t)h->mr_S * h->omS);
+    for (int sp = 0; sp < h->mr_S; ++sp)
+      for (int oi = 0; oi < h->omS; ++oi) {
+        double c, sn;
+        cs_turns((double)(((long long)sp * (h->lo + oi)) % h->N) / h->N, &c, &sn);
+        cw[(size_t)sp * h->omS + oi] = mk<R>((R)c, (R)(-sn));
+      }
+    TRY(upload_table<R>(&h->mr_cw, cw));
+  }
   h->mr_lo = h->lo;
   return 0;
 }
@@ -751,7 +765,7 @@ static int dispatch_blu(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& C
   return fail(FASTMC_ESTATE, "no chirp-z instantiation for this grid / window");
 }
 
-template <class R, int P, int NS>
+template <class R, int P, int NS, bool SPLIT>
 static void dispatch_mr_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   constexpr int WPB = MrCfg<R, P, NS>::WPB;
   const size_t lds = mr_lds_bytes<R, P, NS>(RA.omS);
@@ -760,36 +774,45 @@ static void dispatch_mr_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>
   {
     Span s(h, 0);
     if (mode == 0) {
-      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 0>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 0, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 0, SPLIT>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
     } else {
-      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 1>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 1, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 1, SPLIT>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
     }
   }
   {
     Span s(h, 1);
     const int items = CA.nb * CA.Np;
     if (epi == 0) {
-      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 0>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 0, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 0, SPLIT>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
     } else {
-      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 1>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 1, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 1, SPLIT>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
     }
   }
 }
 
+// P of the split grids (mr_split: the smallest S that leaves 7 <= P <= 24)
+constexpr bool mr_split_P(int P) { return P == 7 || P == 9 || P == 10 || P == 14 || P == 16 || P == 18 || P == 20 || P == 24; }
+
 template <class R>
 static int dispatch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   const int ns = h->NS <= 2 ? 2 : 4;
-#define FMC_MR(PP)                                                                                             \
-  if (h->mr_P == PP) {                                                                                         \
-    if (ns == 2) { dispatch_mr_pn<R, PP, 2>(h, RA, CA, mode, epi); return 0; }                                 \
-    if constexpr (mr_has_ns4(PP)) { if (ns == 4) { dispatch_mr_pn<R, PP, 4>(h, RA, CA, mode, epi); return 0; } } \
+  const bool split = h->mr_S > 1;
+#define FMC_MR(PP)                                                                                                    \
+  if (h->mr_P == PP) {                                                                                                \
+    if (!split) {                                                                                                     \
+      if (ns == 2) { dispatch_mr_pn<R, PP, 2, false>(h, RA, CA, mode, epi); return 0; }                               \
+      if constexpr (mr_has_ns4(PP)) { if (ns == 4) { dispatch_mr_pn<R, PP, 4, false>(h, RA, CA, mode, epi); return 0; } } \
+    } else if constexpr (mr_split_P(PP)) {                                                                            \
+      if (ns == 2) { dispatch_mr_pn<R, PP, 2, true>(h, RA, CA, mode, epi); return 0; }                                \
+      if constexpr (mr_has_ns4(PP)) { if (ns == 4) { dispatch_mr_pn<R, PP, 4, true>(h, RA, CA, mode, epi); return 0; } }  \
+    }                                                                                                                 \
   }
   FMC_MR(2) FMC_MR(3) FMC_MR(4) FMC_MR(5) FMC_MR(6) FMC_MR(7) FMC_MR(8) FMC_MR(9) FMC_MR(10) FMC_MR(12) FMC_MR(14) FMC_MR(16)
-  FMC_MR(18) FMC_MR(20) FMC_MR(24) FMC_MR(28) FMC_MR(32)
+  FMC_MR(18) FMC_MR(20) FMC_MR(24)
 #undef FMC_MR
   return fail(FASTMC_ESTATE, "no 50-lane instantiation for this grid / window");
 }
@@ -971,8 +994,8 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     } else if (h->path == 3) {
       TRY(upload_mr_tables<R>(h));
       RA.amp = (const R*)h->amp_s; RA.ampf = h->ampf_s; RA.tw = (const cpx<R>*)h->mr_tw1; RA.om = (const cpx<R>*)h->mr_om;
-      RA.cw = nullptr; RA.tw_global = 0;
-      CA.tw = RA.tw; CA.om = RA.om; CA.cw = nullptr; CA.tw_global = 0;
+      RA.cw = (const cpx<R>*)h->mr_cw; RA.tw_global = 0;
+      CA.tw = RA.tw; CA.om = RA.om; CA.cw = RA.cw; CA.tw_global = 0;
       TRY(dispatch_mr<R>(h, RA, CA, S.mode, S.epi));
     } else {
     bool wave_ok = h->path == 1;

@@ -273,18 +273,28 @@ struct xoshiro128p {
 // yielding coefficient j <-> kx = L + 64 S j.  S > 1 where the wave kernels transform a row as S interleaved
 // sub-rows (kx = s mod S), so that lane l of pass s reads ONE stream (L = s + S l) sequentially.
 FMC_HD constexpr int spec_split(int N) { return N == 4096 ? 4 : (N == 2048 ? 2 : 1); }
-// Grid sizes of the 50-lane family (fmc_mrfft.h): N = 50 P, P = 2^k times 1, 3, 5, 7 or 9 (2 <= P <= 32), unless the
-// wave family has the size (N = 64 P' with P' of the same form; 1600 = 64 x 25 is not).  Their rows are drawn as 50 streams, stream L = kx mod 50, whichever kernel family transforms them.
+// Grid sizes of the 50-lane family (fmc_mrfft.h): N = 50 P S -- S interleaved sub-rows (kx = s mod S) of 50 P points, P =
+// 2^k times 1, 3, 5, 7 or 9.  S = 1 for P <= 24 (100, 150, ..., 1000, 1200); larger grids take the smallest S <= 5 that
+// leaves 7 <= P <= 24 (1400 = 2 x 700, 1500 = 3 x 500, 1600 = 2 x 800, 2000 = 2 x 1000, 2500 = 5 x 500, 3000 = 3 x 1000,
+// 4000 = 4 x 1000, ...).  Sizes of the wave family (N = 64 P') stay there.  Their rows are drawn as 50 S streams, stream
+// L = kx mod 50 S, whichever kernel family transforms them (lane l of sub-row s reads stream s + S l sequentially).
 constexpr int MR_LN = 50;
 FMC_HD constexpr bool mr_supported_P(int P) {
   if (P < 2 || P > 32) return false;
   const int odd = P / (P & -P);
   return odd == 1 || odd == 3 || odd == 5 || odd == 7 || odd == 9;
 }
-FMC_HD constexpr bool mr_supported(int N) {
-  return N % MR_LN == 0 && mr_supported_P(N / MR_LN) && !(N % 64 == 0 && mr_supported_P(N / 64));
+FMC_HD constexpr int mr_split(int N) {       // 0: not a size of the family
+  if (N < 2 * MR_LN || N % MR_LN != 0) return 0;
+  if (N == 2048 || N == 4096 || (N % 64 == 0 && mr_supported_P(N / 64))) return 0;
+  const int q = N / MR_LN;
+  if (q <= 24) return mr_supported_P(q) ? 1 : 0;
+  for (int S = 2; S <= 5; ++S)
+    if (q % S == 0 && q / S >= 7 && q / S <= 24 && mr_supported_P(q / S)) return S;
+  return 0;
 }
-FMC_HD constexpr int stream_lanes(int N) { return mr_supported(N) ? MR_LN : WAVE * spec_split(N); }
+FMC_HD constexpr bool mr_supported(int N) { return mr_split(N) > 0; }
+FMC_HD constexpr int stream_lanes(int N) { return mr_supported(N) ? MR_LN * mr_split(N) : WAVE * spec_split(N); }
 constexpr uint32_t STREAM_SCREEN = 0;
 constexpr uint32_t STREAM_LOGAMP = 1;   // counter words 2,3 = global iteration index
 constexpr uint32_t STREAM_SUBHARM = 2;  // counter word 0 = mode-pair index m in [0,14)

@@ -777,9 +777,12 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB_COLS * 64)) void k_cols_blu(
 // with k = lane + 50 j inputs on lanes 0-49 and 50 generator streams per row (stream L = kx mod 50, fmc_core.h
 // stream_lanes).  Waves per workgroup: the exchange buffer is 69 P elements (P = 20: 11 KB) and the radix-P stage holds 2 P
 // values per lane, as in the wave family.
+#ifndef FMC_MR_WPB16
+#define FMC_MR_WPB16 8      // A/B at 800^2 f64: 8 waves 10.8 ms per 5000 realisations, 12 waves (168-VGPR cap) 14.2 ms
+#endif
 template <class R, int P, int NS> struct MrCfg {
   static constexpr int W0 = WaveCfg<R, P, NS>::WPB;
-  static constexpr int WPB = (sizeof(R) == 8 && P >= 16 && W0 > 8) ? 8 : W0;
+  static constexpr int WPB = (sizeof(R) == 8 && P >= 16 && W0 > FMC_MR_WPB16) ? FMC_MR_WPB16 : W0;
 };
 template <class R, int P, int NS>
 __host__ __device__ constexpr size_t mr_lds_bytes(int omS) {
@@ -792,7 +795,9 @@ __device__ __forceinline__ void load_tables_mr(cpx<R>* s_tw, cpx<R>* s_om, const
   __syncthreads();
 }
 
-template <class R, int P, int NS, int MODE>
+// SPLIT: the row of N = S * 50 P points as S interleaved sub-rows (kx = s mod S, S = N / 50 P at run time, <= 5), window
+// outputs combined by decimation in time, X[x] = sum_s w_N^{s x} Y_s[x mod 50 P] (cw), as the wave family does for 2048 / 4096.
+template <class R, int P, int NS, int MODE, bool SPLIT = false>
 __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_rows_mr(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = MrGeom<R, P>;
@@ -805,7 +810,8 @@ __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_rows_mr(RowArgs
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane < MR_LN ? lane : MR_LN - 1;      // idle lanes repeat lane 49 (in-bounds loads; nothing reads their column)
   E* xbuf = s_x + w * G::XELEMS;
-  constexpr int N = G::N;
+  const int N = SPLIT ? A.N : G::N;
+  const int S = SPLIT ? A.N / G::N : 1;
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
   constexpr int WPB = MrCfg<R, P, NS>::WPB;
@@ -822,21 +828,42 @@ __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_rows_mr(RowArgs
     const int ky = row0 + flat % LR;
     if (ky >= N) continue;                               // wave-uniform (N need not be a multiple of LR)
     const uint64_t g = A.g0 + (uint64_t)b;
-    if (MODE == 0) {
-      const float* ampf = A.ampf + (size_t)ky * N;
-      xoshiro128p rs = row_stream(A.key, g, ky, li, MR_LN);
+    R accr[NS], acci[NS];
 #pragma unroll
-      for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[li + MR_LN * j]);
-    } else {
-      const size_t base = ((size_t)b * N + ky) * N;
-      const R* amp = A.amp + (size_t)ky * N;
+    for (int s2 = 0; s2 < NS; ++s2) { accr[s2] = (R)0; acci[s2] = (R)0; }
+#pragma unroll 1
+    for (int sp = 0; sp < S; ++sp) {
+      if (MODE == 0) {
+        const float* ampf = A.ampf + (size_t)ky * N + sp;
+        xoshiro128p rs = row_stream(A.key, g, ky, sp + S * li, MR_LN * S);
 #pragma unroll
-      for (int j = 0; j < P; ++j) {
-        const int kx = li + MR_LN * j;
-        regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
+        for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[S * (li + MR_LN * j)]);
+      } else {
+        const size_t base = ((size_t)b * N + ky) * N + sp;
+        const R* amp = A.amp + (size_t)ky * N + sp;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          const int kx = S * (li + MR_LN * j);
+          regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
+        }
+      }
+      pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+      if (SPLIT) {
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+          const int oi = lane + WAVE * s2;
+          if (oi < A.Np) {
+            const cpx<R> c = A.cw[sp * A.omS + oi];
+            accr[s2] += c.x * regs.xr[s2] - c.y * regs.xi[s2];
+            acci[s2] += c.x * regs.xi[s2] + c.y * regs.xr[s2];
+          }
+        }
       }
     }
-    pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    if (SPLIT) {
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) { regs.xr[s2] = accr[s2]; regs.xi[s2] = acci[s2]; }
+    }
     cpx<R>* out = A.V + (size_t)b * A.Np * N + ky;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -846,7 +873,7 @@ __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_rows_mr(RowArgs
   }
 }
 
-template <class R, int P, int NS, int EPI>
+template <class R, int P, int NS, int EPI, bool SPLIT = false>
 __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_cols_mr(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = MrGeom<R, P>;
@@ -863,13 +890,37 @@ __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_cols_mr(ColArgs
   if (item >= A.nb * A.Np) return;   // whole wave exits; no block barrier follows
   const int b = item / A.Np;
   const int xi = item % A.Np;
-  constexpr int N = G::N;
+  const int N = SPLIT ? A.N : G::N;
+  const int S = SPLIT ? A.N / G::N : 1;
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
   const cpx<R>* col = A.V + ((size_t)b * A.Np + xi) * N;
+  if (!SPLIT) {
 #pragma unroll
-  for (int j = 0; j < P; ++j) regs.v[j] = col[li + MR_LN * j];
-  pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    for (int j = 0; j < P; ++j) regs.v[j] = col[li + MR_LN * j];
+    pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+  } else {
+    R accr[NS], acci[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) { accr[s2] = (R)0; acci[s2] = (R)0; }
+#pragma unroll 1
+    for (int sp = 0; sp < S; ++sp) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (li + MR_LN * j)];
+      pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const int oi = lane + WAVE * s2;
+        if (oi < A.Np) {
+          const cpx<R> c = A.cw[sp * A.omS + oi];
+          accr[s2] += c.x * regs.xr[s2] - c.y * regs.xi[s2];
+          acci[s2] += c.x * regs.xi[s2] + c.y * regs.xr[s2];
+        }
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) { regs.xr[s2] = accr[s2]; regs.xi[s2] = acci[s2]; }
+  }
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int s = 0; s < NS; ++s) {

@@ -39,7 +39,7 @@ struct MrGeom {
 };
 
 // Tables:  tw1[a*64 + l] = w_N^{l a} (l < LN; the other lanes idle),  om[m*omS + oi] = sgn(oi) w_LN^{m b(oi)}, m < L0,
-// b(oi) = (lo + oi) / P; sgn = (-1)^(lo+oi) (output-side fftshift, N even) times w_N^{-(N/2)^2} = -1 when N = 2 (mod 4).
+// b(oi) = ((lo + oi) / P) mod 50; sgn = (-1)^(lo+oi) (output-side fftshift, N even) times w_N^{-(N/2)^2} = -1 when N = 2 (mod 4).
 template <class R, int P, int NS, class Exec>
 FMC_HD void pruned_row_fft_mr(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om, int omS, int lo, int Np) {
   using G = MrGeom<R, P>;
@@ -137,8 +137,8 @@ inline void build_tw1_mr(cpx<R>* tw1, int P, CosSin cs) {
     }
 }
 template <class R, class CosSin>
-inline void build_om_mr(cpx<R>* om, int omS, int P, int lo, int Np, bool out_sign, CosSin cs) {
-  const int N = MR_LN * P;
+inline void build_om_mr(cpx<R>* om, int omS, int P, int lo, int Np, bool out_sign, CosSin cs, int S = 1) {
+  const int N = MR_LN * P * S;          // full row length (S interleaved sub-rows): the fftshift signs belong to it
   for (int m = 0; m < 5; ++m)
     for (int oi = 0; oi < omS; ++oi) {
       if (oi >= Np) { om[m * omS + oi] = mk<R>((R)0, (R)0); continue; }

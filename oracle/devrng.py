@@ -80,23 +80,38 @@ def spec_split(N):
     return 4 if N == 4096 else (2 if N == 2048 else 1)
 
 
-def mr_supported(N):
-    """fmc_core.h: mr_supported -- grids of the 50-lane kernel family: N = 50 P, P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32,
-    unless N is a size of the wave family (64 P' with P' of the same form)."""
+def mr_split(N):
+    """fmc_core.h: mr_split -- sub-rows S of the 50-lane kernel family (N = 50 P S, P = 2^k times 1, 3, 5, 7 or 9): 1 for
+    P <= 24, else the smallest S <= 5 that leaves 7 <= P <= 24; 0 when N is not a size of the family (sizes of the wave
+    family, N = 64 P', stay there)."""
     def ok(P):
         return 2 <= P <= 32 and P // (P & -P) in (1, 3, 5, 7, 9)
-    return N % 50 == 0 and ok(N // 50) and not (N % 64 == 0 and ok(N // 64))
+    if N < 100 or N % 50:
+        return 0
+    if N in (2048, 4096) or (N % 64 == 0 and ok(N // 64)):
+        return 0
+    q = N // 50
+    if q <= 24:
+        return 1 if ok(q) else 0
+    for S in range(2, 6):
+        if q % S == 0 and 7 <= q // S <= 24 and ok(q // S):
+            return S
+    return 0
+
+
+def mr_supported(N):
+    return mr_split(N) > 0
 
 
 def stream_lanes(N):
-    """fmc_core.h: stream_lanes -- generator streams per row: 50 on the 50 P grids, else 64 * spec_split(N)."""
-    return 50 if mr_supported(N) else 64 * spec_split(N)
+    """fmc_core.h: stream_lanes -- generator streams per row: 50 S on the 50-lane grids, else 64 * spec_split(N)."""
+    return 50 * mr_split(N) if mr_supported(N) else 64 * spec_split(N)
 
 
 def device_coefficients(seed, g, N):
     """(N, N) complex coefficients of realisation g (== fastmc_rng_coeffs).
 
-    SL = stream_lanes(N) streams per row (64; 128 / 256 at 2048 / 4096; 50 on the 50 P grids).  Stream (g, ky, L = kx mod SL): state = Philox4x32-7(ctr =
+    SL = stream_lanes(N) streams per row (64; 128 / 256 at 2048 / 4096; 50 S on the 50 P S grids).  Stream (g, ky, L = kx mod SL): state = Philox4x32-7(ctr =
     (ky*SL + L, STREAM_SCREEN, g_lo, g_hi), key = seed) (s0 := 1 if the block is all zero); coefficient
     (ky, L + SL j) = BM(s0 + s3, s1 + s2) of the xoshiro128+ state after j advances (fmc_core.h: xoshiro128p::next2,
     fmc_kernels.h: row_stream / draw_words).  The device colours these float32 normals with sqrt(powerspec) * df

@@ -30,7 +30,7 @@ def _window_W(Np, seed=0):
 
 
 # ------------------------------------------------------------------ generator
-@pytest.mark.parametrize("N", [16, 33, 512, 2048, 4096, 200, 1000])
+@pytest.mark.parametrize("N", [16, 33, 512, 2048, 4096, 200, 1000, 1500, 2000])
 def test_device_generator_matches_oracle_restatement(N):
     h = _lib.Handle(N, max(1, N // 4), "f64", 0)
     for seed, g in ((1, 0), (0xDEADBEEFCAFE, 5), (7, 2 ** 33 + 3)):
@@ -929,14 +929,18 @@ def test_fast_run_reproduces_reference_on_chirpz_kernels(case):
 # ------------------------------------------------------------------ 50-lane family: N = 50 P (100, 200, 250, 500, 1000, ...)
 @pytest.mark.parametrize("N,Np", [(100, 40), (150, 120), (200, 128), (250, 82), (300, 33), (350, 82), (400, 256), (450, 82), (500, 82),
                                   (600, 200), (700, 82), (800, 101), (900, 82), (1000, 82), (1000, 256), (1200, 82), (1400, 82),
-                                  (1600, 128)])
+                                  (1600, 128), (1350, 82), (1500, 82), (1750, 60), (2000, 82), (2000, 200), (2500, 82), (3000, 101),
+                                  (4000, 82)])
 @pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 5e-5)])
 def test_lanes50_kernels_match_oracle_fft(N, Np, prec, tol):
     """Round decimal grids (NPXLS 1000 etc.) on the 50-lane mixed-radix kernels (fmc_mrfft.h): screens from host coefficients
     against the oracle's FFT-branch transform for windows in the middle and at both ends, and against the direct family."""
+    if N > 2000 and prec == "f32":
+        pytest.skip("one precision is enough for the largest split grids")
     ps, df = _vk_spectrum(N, 0.01, 25.0)
     rng = np.random.default_rng(N + Np)
-    cr, ci = rng.normal(size=(2, N, N)), rng.normal(size=(2, N, N))
+    nb = 2 if N <= 2000 else 1
+    cr, ci = rng.normal(size=(nb, N, N)), rng.normal(size=(nb, N, N))
     full = R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df))
     for lo in sorted({(N - Np) // 2, 0, N - Np}):
         h = _lib.Handle(N, Np, prec, 0)
@@ -953,7 +957,7 @@ def test_lanes50_kernels_match_oracle_fft(N, Np, prec, tol):
         h.kernel_path(2)             # 50 streams per row: the chirp-z kernels (64 streams) do not serve these grids
 
 
-@pytest.mark.parametrize("N,Np", [(100, 50), (500, 82), (1000, 82), (600, 150)])
+@pytest.mark.parametrize("N,Np", [(100, 50), (500, 82), (1000, 82), (600, 150), (1400, 82), (2500, 82)])
 def test_lanes50_device_generator_equals_direct_family(N, Np):
     h, ps, df, W = _small_problem(N, Np)
     assert h.kernel_path() == 3

@@ -107,11 +107,16 @@ def test_generator_statistics():
 
 
 def test_stream_layout_of_the_50_lane_grids():
-    """N = 50 P grids (fmc_core.h: mr_supported / stream_lanes) are drawn as 50 streams per row, the others as 64 S."""
-    assert [n for n in range(2, 4097) if devrng.mr_supported(n)] == [100, 150, 200, 250, 300, 350, 400, 450, 500, 600, 700,
-                                                                      800, 900, 1000, 1200, 1400, 1600]
+    """N = 50 P S grids (fmc_core.h: mr_split / stream_lanes) are drawn as 50 S streams per row, the others as 64 S'."""
+    assert [(n, devrng.mr_split(n)) for n in range(2, 4097) if devrng.mr_supported(n)] == [
+        (100, 1), (150, 1), (200, 1), (250, 1), (300, 1), (350, 1), (400, 1), (450, 1), (500, 1), (600, 1), (700, 1), (800, 1),
+        (900, 1), (1000, 1), (1200, 1), (1350, 3), (1400, 2), (1500, 3), (1600, 2), (1750, 5), (1800, 2), (2000, 2), (2100, 3),
+        (2250, 5), (2400, 2), (2500, 5), (2700, 3), (2800, 4), (3000, 3), (3200, 4), (3500, 5), (3600, 3), (4000, 4)]
     assert devrng.stream_lanes(1000) == 50 and devrng.stream_lanes(1024) == 64 and devrng.stream_lanes(2048) == 128
-    assert devrng.stream_lanes(3200) == 64 and devrng.stream_lanes(550) == 64 and devrng.stream_lanes(164) == 64
+    assert devrng.stream_lanes(2000) == 100 and devrng.stream_lanes(2500) == 250 and devrng.stream_lanes(4000) == 200
+    assert devrng.stream_lanes(550) == 64 and devrng.stream_lanes(164) == 64 and devrng.stream_lanes(1100) == 64
+    c2 = devrng.device_coefficients(5, 0, 1400)[:3]
+    assert np.isfinite(c2).all() and len(np.unique(c2.ravel())) == 3 * 1400
     c = devrng.device_coefficients(5, 0, 100)
     assert np.isfinite(c).all() and len(np.unique(c.ravel())) == 100 * 100
     # column kx belongs to stream kx mod 50 at step kx // 50: the first 50 columns are the first draw of every stream

@@ -6,7 +6,9 @@ rng = np.random.default_rng(0)
 bad = 0
 for (N, Np, lo, prec) in [(1000, 82, 459, "f64"), (500, 82, 209, "f64"), (250, 64, 93, "f64"), (100, 50, 25, "f64"), (200, 128, 0, "f64"),
                           (1000, 200, 400, "f64"), (1000, 82, 459, "f32"), (150, 30, 120, "f64"), (1600, 82, 759, "f64"), (700, 100, 300, "f32"),
-                          (450, 82, 184, "f64"), (1400, 100, 650, "f64"), (900, 90, 405, "f64"), (600, 256, 172, "f64")]:
+                          (450, 82, 184, "f64"), (1400, 100, 650, "f64"), (900, 90, 405, "f64"), (600, 256, 172, "f64"),
+                          (2000, 82, 959, "f64"), (1500, 82, 0, "f64"), (1350, 82, 1268, "f32"), (2500, 130, 1185, "f64"), (4000, 82, 1959, "f64"),
+                          (1750, 82, 834, "f64"), (3000, 256, 1372, "f32")]:
     tol = 1e-10 if prec == "f64" else 1e-4
     ps = rng.uniform(0.0, 1.0, size=(N, N)) ** 4 * 1e-3
     cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
@@ -19,6 +21,7 @@ for (N, Np, lo, prec) in [(1000, 82, 459, "f64"), (500, 82, 209, "f64"), (250, 6
     h.close()
     z = np.fft.fftshift(np.fft.fft2(np.fft.fftshift((cr[0] + 1j * ci[0]) * np.sqrt(ps) * 0.37)))[lo:lo + Np, lo:lo + Np]
     e_np = max(np.abs(a[0] - z.real).max(), np.abs(a[1] - z.imag).max()) / np.abs(z).max()
+    del z
     e_d = np.abs(a - b).max() / np.abs(b).max()
     e_r = np.abs(ra - rb).max() / np.abs(rb).max()
     ok = e_np < tol and e_d < tol and e_r < (1e-9 if prec == "f64" else 1e-2)

@@ -33,8 +33,9 @@ GPU_DEFAULTS = {
     'GPU_DEVICES': None,      # list of HIP device indices driven by THIS process (one thread each, fast_amd/multi.py);
                               # None -> [GPU_DEVICE]
     'GPU_BATCH': 0,           # realisations in flight per launch (0 = library default)
-    'GPU_KERNELS': 'auto',    # kernel family: 'auto' (wave FFT where NPXLS = 64 P, chirp-z for other sizes, direct for tiny
-                              # grids / huge windows) | 'wave' | 'chirpz' | 'direct' (O(N^2 Np) cross-check)
+    'GPU_KERNELS': 'auto',    # kernel family: 'auto' (wave FFT where NPXLS = 64 P, 50-lane FFT where NPXLS = 50 P S, chirp-z for
+                              # other sizes, direct for tiny grids / huge windows) | 'wave' | 'lanes50' | 'chirpz' | 'direct'
+                              # (O(N^2 Np) cross-check)
     'GPU_ROUND_NPXLS': 'auto', # with NPXLS 'auto': round the auto-sized grid up to the next fast-kernel size: True | False |
                                # 'auto' = when nothing ties the run to the reference's exact grid (GPU_RNG 'device', not TEMPORAL)
     'GPU_SHARD': 'auto',      # shard iterations over the ranks of a multi-process launch (RANK / WORLD_SIZE in the

@@ -168,10 +168,14 @@ int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches);
 /* Which kernel family the handle uses:
  *   1 = wave-FFT (N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, P <= 32: 128, 192, 256, 320, 384, 448, 512, 576, 640, 768,
  *       896, 1024, 1152, 1280, 1536, 1792, and 2048 / 4096 as interleaved sub-rows of 1024);
+ *   3 = 50-lane FFT (round decimal grids N = 50 P S, P as above and <= 24, S <= 5 interleaved sub-rows: 100, 150, ..., 500,
+ *       600, ..., 1000, 1200, 1350, 1400, 1500, 1600, 1750, 1800, 2000, 2100, 2250, 2400, 2500, 2700, 2800, 3000, 3200,
+ *       3500, 3600, 4000; Np <= 128, or <= 256 for P = 8, 10, 12, 16, 20, 24).  The device generator draws 50 S streams per
+ *       row on these grids, whichever family transforms them;
  *   2 = chirp-z (any other N, odd included, with 64 P >= N + Np - 1 for P in {4, 8, 16, 24, 32} and Np <= 256: every 1-D
  *       transform as a Bluestein convolution on the same pipeline; default for N >= 96);
- *   0 = direct O(N^2 Np) pruned DFT (any N <= 4096; tiny grids, huge windows, cross-check of the other two).
- * force: -1 query only, 0 / 1 / 2 select (fails with EINVAL if the family does not serve this (N, Np)). */
+ *   0 = direct O(N^2 Np) pruned DFT (any N <= 4096; tiny grids, huge windows, cross-check of the other three).
+ * force: -1 query only, 0 / 1 / 2 / 3 select (fails with EINVAL if the family does not serve this (N, Np)). */
 int fastmc_kernel_path(fastmc_t* h, int force);
 
 /* Realisations in flight per launch (batch).  0 = library default. */

@@ -139,7 +139,8 @@ def cpu_baseline(sim, seconds_target=12.0):
 
 
 def extras(args, device):
-    """Side measurements printed next to the headline (never part of `value`): the float32 pipeline on the same job,
+    """Side measurements printed next to the headline (never part of `value`): the float32 pipeline on the same job, the
+    same job on a round decimal grid (NPXLS 1000: the 50-lane kernel family),
     BASELINE configs[2] (AO-corrected residual spectrum) with the warm time of the power-spectrum kernel that config adds
     to every `Fast()`, configs[3] (2048^2, 100 000 iterations, split over two handles = two worker threads, here on one
     device) and configs[4] (32 zenith angles x 4096 iterations at 1024^2, AO) with the init / Monte-Carlo wall split."""
@@ -147,7 +148,8 @@ def extras(args, device):
     import fast_amd
     from fast_amd import sweep
     out = {}
-    for tag, over in (("f32_same_job", {"GPU_PRECISION": "f32"}), ("config2_AO_alias_f64", {"AO_MODE": "AO", "ALIAS": True})):
+    for tag, over in (("f32_same_job", {"GPU_PRECISION": "f32"}), ("config2_AO_alias_f64", {"AO_MODE": "AO", "ALIAS": True}),
+                      ("npxls1000_f64_lanes50_kernels", {"NPXLS": 1000})):
         p = workload_params(copy.copy(args))
         p.update(over)
         p["GPU_DEVICE"] = device

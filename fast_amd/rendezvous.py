@@ -84,8 +84,11 @@ def _recv(sock):
 class Rendezvous:
     """Star of sockets centred on rank 0.  Every method is a collective: all ranks call it, in the same order."""
 
-    def __init__(self, rank, world, kind, address, timeout=120.0):
+    def __init__(self, rank, world, kind, address, timeout=120.0, io_timeout=None):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        # `timeout` bounds the meeting of the ranks; a collective later on waits for the slowest rank's Monte-Carlo shard,
+        # which may take much longer (a dead peer closes its socket and is noticed at once): FASTMC_RDZV_IO_TIMEOUT, 1 h
+        self.io_timeout = float(os.environ.get("FASTMC_RDZV_IO_TIMEOUT", "3600")) if io_timeout is None else float(io_timeout)
         self._peers = []          # rank 0: socket of rank r at index r - 1
         self._up = None           # other ranks: socket to rank 0
         self._listener = None
@@ -119,6 +122,8 @@ class Rendezvous:
             except socket.timeout:
                 raise RendezvousError(f"only {len(peers) + 1} of {self.world} ranks reached {self.endpoint} in {self.timeout:.0f} s")
             self._peers = [peers[r] for r in range(1, self.world)]
+            for c in self._peers:
+                c.settimeout(self.io_timeout)
         else:
             deadline = time.monotonic() + self.timeout
             last = None
@@ -137,6 +142,7 @@ class Rendezvous:
             if kind == "tcp":
                 s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             _send(s, struct.pack("<ii", self.rank, self.world))
+            s.settimeout(self.io_timeout)
             self._up = s
 
     # ---- the one primitive: all-gather of byte strings

@@ -230,7 +230,8 @@ def test_fast_run_f32_close_to_reference(case):
 
 @pytest.mark.parametrize("name", ["cfg1_256", "big_noao_1024", "big_noao_L0_1024", "big_ao_1024", "big_noao_L0_2048", "big_noao_L0_4096",
                                   "big_tt_1024", "big_lgsao_1024", "big_modal_zmax_noise_1024", "big_subharm_coherent_down_1024",
-                                  "big_zenith05_1024", "big_zenith27_1024", "big_ao_1000"])
+                                  "big_zenith05_1024", "big_zenith27_1024", "big_ao_1000", "big_noao_1024_s1", "big_noao_1024_s2",
+                                  "big_noao_L0_1024_s1", "big_noao_L0_1024_s2"])
 def test_fast_run_full_size_same_seed(name):
     g = load_golden(name)
     p = params_from_json(g["params_json"])

@@ -366,6 +366,20 @@ def big(p):
     capture_sim("big_ao_1024", pb3, "BASELINE config 3 geometry (AO + ALIAS), NITER 8", full=False, stride=16)
 
 
+def big_seeds():
+    """SURVEY 8(d) config 2 asks for seeds 1..3 with L0 = inf and L0 = 25: `big()` holds SEED 3, these are SEED 1 and 2."""
+    h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
+    p = dict(fast.conf.DEFAULTS)
+    p.update({"NPXLS": 1024, "DX": 0.01, "NITER": 8, "NCHUNKS": 2, "TEMPORAL": False, "FFTW": True, "W0": "opt",
+              "D_GROUND": 0.8, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w, "WIND_DIR": [0, 90, 180, 270], "ZENITH_ANGLE": 55,
+              "DSUBAP": 0.1, "LOGLEVEL": "ERROR", "H_SAT": 36e6, "AO_MODE": "NOAO", "ALIAS": True})
+    for seed in (1, 2):
+        for tag, L0 in (("noao", np.inf), ("noao_L0", 25.0)):
+            q = dict(p)
+            q.update({"SEED": seed, "L0": L0})
+            capture_sim(f"big_{tag}_1024_s{seed}", q, f"BASELINE config 2 geometry, L0={L0}, SEED {seed}, NITER 8", full=False, stride=16)
+
+
 def big2048():
     """BASELINE configs[3] geometry (2048^2), 4 iterations of the reference: the grid the wave kernels
     transform as two interleaved sub-rows."""
@@ -491,7 +505,7 @@ def main():
         else:
             {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref,
              "--only-comms": comms_metrics, "--only-big2048": big2048, "--only-big-modes": big_modes,
-             "--only-zenith": zenith, "--only-numpy-branch": numpy_branch, "--only-decimal": decimal}[only[0]]()
+             "--only-zenith": zenith, "--only-numpy-branch": numpy_branch, "--only-decimal": decimal, "--only-big-seeds": big_seeds}[only[0]]()
         for name, size, st, note in MANIFEST:
             print(f"| {name}.npz | {size} | {st} | {note} |")
         return
@@ -511,6 +525,7 @@ def main():
         big_modes()
         zenith()
         decimal()
+        big_seeds()
     with open(os.path.join(OUT, "MANIFEST.md"), "w") as f:
         f.write("# Golden fixtures captured from the reference (tools/capture_golden/capture.py)\n\n")
         f.write(f"numpy {np.__version__}; reference snapshot /root/reference (2025-04-04).\n")

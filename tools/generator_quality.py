@@ -4,7 +4,7 @@
 Reads `realisations` x N^2 complex coefficients back through fastmc_rng_coeffs (the streams the row kernels consume) and
 tests what the Monte-Carlo path relies on: normality (moments, tails to 6 sigma), exponential radius^2, uniform phase,
 and independence -- between the two words of one xoshiro state advance (radius / angle of one coefficient), between
-consecutive steps of a stream (kx, kx + 64), between neighbouring streams (lanes), rows, realisations and seeds.
+consecutive steps of a stream (kx, kx + streams per row), between neighbouring streams (lanes), rows, realisations and seeds.
 Every statistic is printed as a z-score (|z| < 4.5 expected for all of them together)."""
 import os
 import sys
@@ -13,6 +13,7 @@ from scipy import stats
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fast_amd import _lib   # noqa: E402
+from oracle import devrng   # noqa: E402  (stream layout only; tools/ is test infrastructure)
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
@@ -53,7 +54,7 @@ for g in range(R):
     t = (np.angle(c) + np.pi) / (2 * np.pi)
     hist_u += np.histogram(u, bins=4096, range=(0, 1))[0]
     hist_t += np.histogram(t, bins=4096, range=(0, 1))[0]
-    S = 64 if N not in (2048, 4096) else (128 if N == 2048 else 256)
+    S = devrng.stream_lanes(N)          # streams per row: 64, 128 / 256 at 2048 / 4096, 50 S on the 50-lane grids
     pairs["u-t same"] += chi2_z(u.ravel(), t.ravel())
     pairs["u-u step"] += chi2_z(u[:, :-S].ravel(), u[:, S:].ravel())
     pairs["t-t step"] += chi2_z(t[:, :-S].ravel(), t[:, S:].ravel())

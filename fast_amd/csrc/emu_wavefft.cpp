@@ -49,7 +49,7 @@ static double run_case(int lo, int Np, unsigned seed) {
   const int omS = NS * WAVE;
   std::vector<cpx<R>> tw1((size_t)P * WAVE), om((size_t)8 * omS);
   build_tw1<R>(tw1.data(), P, cs_turns);
-  build_om<R>(om.data(), omS, P, lo, Np, true, cs_turns);
+  build_om<R>(om.data(), omS, P, lo, Np, cs_turns);
   std::vector<E> xbuf(G::XELEMS);
 
   static HostExec<R, P, NS> ex;
@@ -119,7 +119,7 @@ static double run_blu_case(int N, int lo, int Np, unsigned seed) {
   const int omS = NS * WAVE;
   std::vector<cpx<R>> tw1((size_t)P * WAVE), om((size_t)8 * omS), pre(M), vhat(M), post(omS), twf(64);
   build_tw1<R>(tw1.data(), P, cs_turns);
-  build_om<R>(om.data(), omS, P, 0, Np, false, cs_turns);
+  build_om<R>(om.data(), omS, P, 0, Np, cs_turns);
   if (!build_blu_tables<R>(N, Np, lo, P, pre.data(), vhat.data(), post.data(), omS, twf.data(), cs_turns)) return 1e30;
   std::vector<E> xbuf(B::XELEMS);
   static HostExec<R, P, NS> ex;
@@ -181,7 +181,7 @@ static double run_mr_case(int lo, int Np, unsigned seed) {
   const int omS = NS * WAVE;
   std::vector<cpx<R>> tw1((size_t)P * WAVE), om((size_t)G::L0 * omS);
   build_tw1_mr<R>(tw1.data(), P, cs_turns);
-  build_om_mr<R>(om.data(), omS, P, lo, Np, true, cs_turns);
+  build_om_mr<R>(om.data(), omS, P, lo, Np, cs_turns);
   std::vector<E> xbuf(G::XELEMS);
   static HostExec<R, P, NS> ex;
   for (int l = 0; l < WAVE; ++l)
@@ -191,7 +191,7 @@ static double run_mr_case(int lo, int Np, unsigned seed) {
       // idle lanes carry garbage on the GPU (nothing reads their exchange-1 column): poison them here
       ex.regs[l].v[j] = l < MR_LN ? mk<R>((R)(sg * inr[k]), (R)(sg * ini[k])) : mk<R>((R)1e3, (R)-1e3);
     }
-  pruned_row_fft_mr<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
+  pruned_row_fft_mr<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np, mr_osign(N));
   double worst = 0.0, scale = 0.0;
   const int h = N / 2;
   for (int oi = 0; oi < Np; ++oi) {

@@ -534,7 +534,7 @@ static int upload_wave_tables(fastmc_ctx* h) {
   h->omS = (h->Np + 7) & ~7;
   std::vector<cpx<R>> tw1((size_t)P * 64), om((size_t)8 * h->omS);
   build_tw1<R>(tw1.data(), P, cs_turns);
-  build_om<R>(om.data(), h->omS, P, h->lo, h->Np, true, cs_turns);
+  build_om<R>(om.data(), h->omS, P, h->lo, h->Np, cs_turns);
   TRY(upload_table<R>(&h->tw1, tw1));
   TRY(upload_table<R>(&h->om, om));
   if (S > 1) {
@@ -551,7 +551,7 @@ static int upload_wave_tables(fastmc_ctx* h) {
   if (h->N == 2048) {
     std::vector<cpx<R>> tw1g((size_t)32 * 64), omg((size_t)8 * h->omS);
     build_tw1<R>(tw1g.data(), 32, cs_turns);
-    build_om<R>(omg.data(), h->omS, 32, h->lo, h->Np, true, cs_turns);
+    build_om<R>(omg.data(), h->omS, 32, h->lo, h->Np, cs_turns);
     TRY(upload_table<R>(&h->tw1g, tw1g));
     TRY(upload_table<R>(&h->omg, omg));
   }
@@ -565,7 +565,7 @@ static int upload_blu_tables(fastmc_ctx* h) {
   h->omS = (h->Np + 7) & ~7;
   std::vector<cpx<R>> tw1((size_t)P * 64), om((size_t)8 * h->omS), twf(64), pre(M), vhat(M), post(h->omS);
   build_tw1<R>(tw1.data(), P, cs_turns);
-  build_om<R>(om.data(), h->omS, P, 0, h->Np, false, cs_turns);
+  build_om<R>(om.data(), h->omS, P, 0, h->Np, cs_turns);
   if (!build_blu_tables<R>(h->N, h->Np, h->lo, P, pre.data(), vhat.data(), post.data(), h->omS, twf.data(), cs_turns))
     return fail(FASTMC_ESTATE, "chirp-z size does not hold the window");
   TRY(upload_table<R>(&h->blu_tw1, tw1));
@@ -585,7 +585,7 @@ static int upload_mr_tables(fastmc_ctx* h) {
   h->omS = (h->Np + 7) & ~7;
   std::vector<cpx<R>> tw1((size_t)P * 64), om((size_t)5 * h->omS);
   build_tw1_mr<R>(tw1.data(), P, cs_turns);
-  build_om_mr<R>(om.data(), h->omS, P, h->lo, h->Np, true, cs_turns, h->mr_S);
+  build_om_mr<R>(om.data(), h->omS, P, h->lo, h->Np, cs_turns);
   TRY(upload_table<R>(&h->mr_tw1, tw1));
   TRY(upload_table<R>(&h->mr_om, om));
   if (h->mr_S > 1) {

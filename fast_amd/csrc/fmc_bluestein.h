@@ -136,7 +136,7 @@ FMC_HD void full_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, 
 
 // The whole chirp-z row: on entry r.v[j] = u[lane + 64 j] (pre-chirped, zero beyond N); on return slot s of lane l
 // holds Y[t], t = l + 64 s < Np, with out[lo + t] = post[t] * conj(Y[t]).
-//   vhat: DFT_M(v) in natural order (global memory / L2);  om: tables of pruned_row_fft for the window [0, Np), no sign.
+//   vhat: DFT_M(v) in natural order (global memory / L2);  om: tables of pruned_row_fft for the window [0, Np) (run without the fftshift sign).
 template <class R, int P, int NS, class Exec>
 FMC_HD void bluestein_row(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om, int omS,
                           const cpx<R>* twf, const cpx<R>* vhat, int Np) {
@@ -180,7 +180,7 @@ FMC_HD void bluestein_row(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1,
     });
     ex.sync();
   }
-  pruned_row_fft<R, P, NS>(ex, xbuf, tw1, om, omS, 0, Np);
+  pruned_row_fft<R, P, NS>(ex, xbuf, tw1, om, omS, 0, Np, 0xFF, -1);
 }
 
 // ---------------------------------------------------------------- host-side tables (float64 trigonometry by `cs`)

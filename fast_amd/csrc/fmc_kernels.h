@@ -847,7 +847,7 @@ __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_rows_mr(RowArgs
           regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
         }
       }
-      pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+      pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, mr_osign(N));
       if (SPLIT) {
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
@@ -898,7 +898,7 @@ __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_cols_mr(ColArgs
   if (!SPLIT) {
 #pragma unroll
     for (int j = 0; j < P; ++j) regs.v[j] = col[li + MR_LN * j];
-    pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, mr_osign(N));
   } else {
     R accr[NS], acci[NS];
 #pragma unroll
@@ -907,7 +907,7 @@ __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_cols_mr(ColArgs
     for (int sp = 0; sp < S; ++sp) {
 #pragma unroll
       for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (li + MR_LN * j)];
-      pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+      pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, mr_osign(N));
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) {
         const int oi = lane + WAVE * s2;

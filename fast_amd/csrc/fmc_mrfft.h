@@ -38,10 +38,12 @@ struct MrGeom {
   static_assert(VN <= lane_regs_vn(P), "LaneRegs too narrow");
 };
 
-// Tables:  tw1[a*64 + l] = w_N^{l a} (l < LN; the other lanes idle),  om[m*omS + oi] = sgn(oi) w_LN^{m b(oi)}, m < L0,
-// b(oi) = ((lo + oi) / P) mod 50; sgn = (-1)^(lo+oi) (output-side fftshift, N even) times w_N^{-(N/2)^2} = -1 when N = 2 (mod 4).
+// Tables:  tw1[a*64 + l] = w_N^{l a} (l < LN; the other lanes idle),  om[m*omS + oi] = w_LN^{m b(oi)}, m < L0 (row 0 never
+// read), b(oi) = ((lo + oi) / P) mod 50.  The finished sums take the sign (-1)^(lo+oi+osign) by a sign-bit xor: the
+// output-side fftshift (N even) times w_N^{-(N/2)^2} = -1 when the FULL row length is 2 (mod 4) (osign = mr_osign(N)).
 template <class R, int P, int NS, class Exec>
-FMC_HD void pruned_row_fft_mr(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om, int omS, int lo, int Np) {
+FMC_HD void pruned_row_fft_mr(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om, int omS, int lo, int Np,
+                              int osign = 0) {
   using G = MrGeom<R, P>;
   using X = Xch<R>;
   using E = typename X::E;
@@ -115,8 +117,14 @@ FMC_HD void pruned_row_fft_mr(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* 
           if (oi < Np) {
             const int x = lo + oi;
             const E* f = xbuf + L0 * (x % (P * L1));       // = L0 a + NBF b0
+            X::first(r.xr[s], r.xi[s], ex.ld(f), c);
 #pragma unroll
-            for (int m = 0; m < L0; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + m), c);
+            for (int m = 1; m < L0; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + m), c);
+            if (c == NC - 1) {
+              const bool neg = ((x ^ osign) & 1) != 0;
+              r.xr[s] = flip_sign(r.xr[s], neg);
+              r.xi[s] = flip_sign(r.xi[s], neg);
+            }
           }
         }
       }
@@ -124,6 +132,9 @@ FMC_HD void pruned_row_fft_mr(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* 
     ex.sync();
   }
 }
+
+// osign of a row of N points (S sub-rows included): 1 when N = 2 (mod 4)
+FMC_HD constexpr int mr_osign(int N) { return (N % 4 == 2) ? 1 : 0; }
 
 // Host-side tables (float64 trigonometry by `cs(turns, &c, &s)`).
 template <class R, class CosSin>
@@ -137,8 +148,7 @@ inline void build_tw1_mr(cpx<R>* tw1, int P, CosSin cs) {
     }
 }
 template <class R, class CosSin>
-inline void build_om_mr(cpx<R>* om, int omS, int P, int lo, int Np, bool out_sign, CosSin cs, int S = 1) {
-  const int N = MR_LN * P * S;          // full row length (S interleaved sub-rows): the fftshift signs belong to it
+inline void build_om_mr(cpx<R>* om, int omS, int P, int lo, int Np, CosSin cs) {
   for (int m = 0; m < 5; ++m)
     for (int oi = 0; oi < omS; ++oi) {
       if (oi >= Np) { om[m * omS + oi] = mk<R>((R)0, (R)0); continue; }
@@ -146,12 +156,7 @@ inline void build_om_mr(cpx<R>* om, int omS, int P, int lo, int Np, bool out_sig
       const int b = (x / P) % MR_LN;
       double c, s;
       cs((double)((m * b) % MR_LN) / (double)MR_LN, &c, &s);
-      double sg = 1.0;
-      if (out_sign) {
-        if (x & 1) sg = -sg;
-        if (N % 4 == 2) sg = -sg;          // w_N^{-(N/2)^2}
-      }
-      om[m * omS + oi] = mk<R>((R)(sg * c), (R)(-sg * s));
+      om[m * omS + oi] = mk<R>((R)c, (R)(-s));
     }
 }
 

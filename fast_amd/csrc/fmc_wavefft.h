@@ -44,6 +44,7 @@ template <> struct Xch<float> {
     xr += om.x * f.x - om.y * f.y;
     xi += om.x * f.y + om.y * f.x;
   }
+  static FMC_HD void first(float& xr, float& xi, E f, int) { xr += f.x; xi += f.y; }     // the m = 0 term: w^0 = 1
 };
 template <> struct Xch<double> {
   using E = double;
@@ -54,7 +55,24 @@ template <> struct Xch<double> {
     if (c == 0) { xr += om.x * f; xi += om.y * f; }
     else        { xr -= om.y * f; xi += om.x * f; }
   }
+  static FMC_HD void first(double& xr, double& xi, E f, int c) { if (c == 0) xr += f; else xi += f; }
 };
+
+// v or -v by a sign-bit xor (one integer instruction per value on the GPU).
+FMC_HD float flip_sign(float v, bool neg) {
+  uint32_t b;
+  __builtin_memcpy(&b, &v, 4);
+  b ^= (uint32_t)neg << 31;
+  __builtin_memcpy(&v, &b, 4);
+  return v;
+}
+FMC_HD double flip_sign(double v, bool neg) {
+  uint64_t b;
+  __builtin_memcpy(&b, &v, 8);
+  b ^= (uint64_t)neg << 63;
+  __builtin_memcpy(&v, &b, 8);
+  return v;
+}
 
 template <class R, int P>
 struct WaveGeom {
@@ -102,8 +120,10 @@ struct LaneRegs {
 
 // Tables (precomputed on the host in float64, stored as R):
 //   tw1[a*64 + l]  = w_N^{l a}                                   (P*64 complex)
-//   om[m*omS + oi] = sgn(oi) * w_64^{m * b(oi)},  m < 8          (8*omS complex), b(oi) = (lo+oi) / P
-// `sgn` carries the output-side fftshift sign of fmc_core.h (even N): (-1)^(lo+oi).
+//   om[m*omS + oi] = w_64^{m * b(oi)},  m < 8                    (8*omS complex), b(oi) = (lo+oi) / P; row m = 0 (= 1) is
+//                    never read: the first term of every sum is taken as it is
+// The output-side fftshift sign of fmc_core.h (even N), (-1)^(lo+oi), is applied to the finished sums by a sign-bit xor
+// (`osign` 0; 1: the opposite sign; -1: none -- the second transform of the chirp-z row).
 // Which residues b0 = b mod 8 of the output blocks b = x / P the window [lo, lo + Np) touches: stage 2b reads only
 // those planes of the exchange-2 image, so the others need not be stored (a window of 82 at P = 16 touches 6 of 8).
 FMC_HD int window_b0_mask(int lo, int Np, int P) {
@@ -119,7 +139,7 @@ FMC_HD int window_b0_mask(int lo, int Np, int P) {
 #endif
 template <class R, int P, int NS, class Exec>
 FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
-                           int omS, int lo, int Np, int b0mask = 0xFF) {
+                           int omS, int lo, int Np, int b0mask = 0xFF, int osign = 0) {
   using G = WaveGeom<R, P>;
   using X = Xch<R>;
   using E = typename X::E;
@@ -238,17 +258,26 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
             if (P >= 12 && NS == 2) {
             cpx<R> w[8];
             E fv[8];
+            fv[0] = ex.ld(f);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) { w[m] = FMC_OM(m, oi); fv[m] = ex.ld(f + G::FL * m); }
+            for (int m = 1; m < 8; ++m) { w[m] = FMC_OM(m, oi); fv[m] = ex.ld(f + G::FL * m); }
+            ex.pin(fv[0]);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) { ex.pin(w[m].x); ex.pin(w[m].y); ex.pin(fv[m]); }
+            for (int m = 1; m < 8; ++m) { ex.pin(w[m].x); ex.pin(w[m].y); ex.pin(fv[m]); }
+            X::first(r.xr[s], r.xi[s], fv[0], c);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) X::acc(r.xr[s], r.xi[s], w[m], fv[m], c);
+            for (int m = 1; m < 8; ++m) X::acc(r.xr[s], r.xi[s], w[m], fv[m], c);
             } else
 #endif
             {
+            X::first(r.xr[s], r.xi[s], ex.ld(f), c);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) X::acc(r.xr[s], r.xi[s], FMC_OM(m, oi), ex.ld(f + G::FL * m), c);
+            for (int m = 1; m < 8; ++m) X::acc(r.xr[s], r.xi[s], FMC_OM(m, oi), ex.ld(f + G::FL * m), c);
+            }
+            if (c == NC - 1 && osign >= 0) {
+              const bool neg = ((x ^ osign) & 1) != 0;
+              r.xr[s] = flip_sign(r.xr[s], neg);
+              r.xi[s] = flip_sign(r.xi[s], neg);
             }
           }
         }
@@ -332,8 +361,14 @@ FMC_HD void pruned_row_fft_d16(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>*
           if (oi < Np) {
             const int x = lo + oi;
             const E* f = xbuf + (x & 15) + 16 * ((x >> 4) & 7);
+            X::first(r.xr[s], r.xi[s], ex.ld(f), c);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + 128 * m), c);
+            for (int m = 1; m < 8; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + 128 * m), c);
+            if (c == NC - 1) {
+              const bool neg = (x & 1) != 0;
+              r.xr[s] = flip_sign(r.xr[s], neg);
+              r.xi[s] = flip_sign(r.xi[s], neg);
+            }
           }
         }
       }
@@ -355,7 +390,7 @@ inline void build_tw1(cpx<R>* tw1, int P, CosSin cs) {
     }
 }
 template <class R, class CosSin>
-inline void build_om(cpx<R>* om, int omS, int P, int lo, int Np, bool out_sign, CosSin cs) {
+inline void build_om(cpx<R>* om, int omS, int P, int lo, int Np, CosSin cs) {
   for (int m = 0; m < 8; ++m)
     for (int oi = 0; oi < omS; ++oi) {
       if (oi >= Np) { om[m * omS + oi] = mk<R>((R)0, (R)0); continue; }
@@ -363,8 +398,7 @@ inline void build_om(cpx<R>* om, int omS, int P, int lo, int Np, bool out_sign, 
       const int b = (x / P) & 63;
       double c, s;
       cs((double)((m * b) % 64) / 64.0, &c, &s);
-      const double sg = (out_sign && (x & 1)) ? -1.0 : 1.0;
-      om[m * omS + oi] = mk<R>((R)(sg * c), (R)(-sg * s));
+      om[m * omS + oi] = mk<R>((R)c, (R)(-s));
     }
 }
 

@@ -989,6 +989,26 @@ def test_fast_run_reproduces_reference_on_lanes50_and_direct_kernels(case):
         np.testing.assert_allclose(sim.run()._r, g["r"], rtol=1e-9)
 
 
+def test_kernel_family_notes_in_the_log(caplog):
+    """Grids of the direct family are announced with the nearest fast sizes; 64 P and 50 P S grids are not."""
+    import logging
+    g = load_golden("e2e_npxls200")
+    for npx, expect in ((200, False), (128, False), (202, False), (130, False)):
+        p = params_from_json(g["params_json"])
+        p.update({"GPU_DEVICE": 0, "NPXLS": npx, "NITER": 4, "NCHUNKS": 2})
+        caplog.clear()
+        with caplog.at_level(logging.WARNING):
+            sim = fast_amd.Fast(p)
+        assert any("direct O(N^2 Np)" in r.getMessage() for r in caplog.records) == expect
+        assert sim._handle.kernel_path() == {200: 3, 128: 1, 202: 2, 130: 2}[npx]
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_DEVICE": 0, "NPXLS": 2200, "NITER": 2, "NCHUNKS": 1})            # 2200 = 50 x 44: no family has it
+    caplog.clear()
+    with caplog.at_level(logging.WARNING):
+        sim = fast_amd.Fast(p)
+    assert sim._handle.kernel_path() == 0 and any("direct O(N^2 Np)" in r.getMessage() for r in caplog.records)
+
+
 def test_wide_windows_on_split_grids_use_the_wave_family():
     """Windows of 257-512 pixels (a 2.6-5 m aperture at 1 cm) at 2048^2 stay on the wave kernels (eight output slots per
     lane) with the device generator, and agree with the direct family."""

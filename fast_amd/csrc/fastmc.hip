@@ -213,6 +213,7 @@ extern "C" int fastmc_device_count(int* n) {
 static bool wave_supported(int N) {
   if (N % 64 != 0) return false;
   if (N == 4096) return true;       // 4 sub-rows of 1024
+  if (wave_rt_split(N)) return true;   // 64 P S with a run-time sub-row count (k_rows_mr<..., LN = 64>)
   switch (N / 64) {
     case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 12: case 14: case 16: case 18: case 20:
     case 24: case 28: case 32: return true;
@@ -228,7 +229,7 @@ static int default_path(int N, int blu_P, int mr_P) { return wave_supported(N) ?
 // Chirp-z family: smallest M = 64 P (P = 4, 8, 16, 24, 32) with M >= N + Np - 1 and a window instantiation
 // (NS = 2: Np <= 128; NS = 4: Np <= 256, P = 8, 16, 24); 0 when there is none.
 static int blu_pick_P(int N, int Np) {
-  if (N < 2 || mr_supported(N)) return 0;      // 50 P grids are drawn as 50 streams per row: 50-lane or direct family
+  if (N < 2 || mr_supported(N) || wave_rt_split(N)) return 0;      // 50 P grids are drawn as 50 streams per row: 50-lane or direct family
   const int ns = (Np + 63) / 64;
   if (ns > 4) return 0;
   for (int P : {4, 8, 16, 24, 32}) {
@@ -765,31 +766,31 @@ static int dispatch_blu(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& C
   return fail(FASTMC_ESTATE, "no chirp-z instantiation for this grid / window");
 }
 
-template <class R, int P, int NS, bool SPLIT>
+template <class R, int P, int NS, bool SPLIT, int LN = MR_LN>
 static void dispatch_mr_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
-  constexpr int WPB = MrCfg<R, P, NS>::WPB;
-  const size_t lds = mr_lds_bytes<R, P, NS>(RA.omS);
+  constexpr int WPB = MrCfg<R, P, NS, LN>::WPB;
+  const size_t lds = mr_lds_bytes<R, P, NS, LN>(RA.omS);
   constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
   const int blocks = ((RA.N + LR - 1) / LR) * ((RA.nb + BPG - 1) / BPG);
   {
     Span s(h, 0);
     if (mode == 0) {
-      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 0, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 0, SPLIT>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 0, SPLIT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 0, SPLIT, LN>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
     } else {
-      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 1, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 1, SPLIT>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 1, SPLIT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 1, SPLIT, LN>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
     }
   }
   {
     Span s(h, 1);
     const int items = CA.nb * CA.Np;
     if (epi == 0) {
-      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 0, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 0, SPLIT>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 0, SPLIT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 0, SPLIT, LN>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
     } else {
-      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 1, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 1, SPLIT>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 1, SPLIT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 1, SPLIT, LN>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
     }
   }
 }
@@ -815,6 +816,21 @@ static int dispatch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA
   FMC_MR(18) FMC_MR(20) FMC_MR(24)
 #undef FMC_MR
   return fail(FASTMC_ESTATE, "no 50-lane instantiation for this grid / window");
+}
+
+// Wave-family grids with a run-time sub-row count (fmc_core.h: wave_rt_split): the split kernels of the 50-lane family on
+// the 64-lane pipeline; tables as for every wave size (upload_wave_tables with P = h->P, S = h->S).
+template <class R>
+static int dispatch_ws(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  const int ns = h->NS <= 2 ? 2 : 4;
+#define FMC_WS(PP)                                                                                                          \
+  if (h->P == PP) {                                                                                                         \
+    if (ns == 2) { dispatch_mr_pn<R, PP, 2, true, WAVE>(h, RA, CA, mode, epi); return 0; }                                   \
+    if constexpr (has_ns4(PP)) { if (ns == 4) { dispatch_mr_pn<R, PP, 4, true, WAVE>(h, RA, CA, mode, epi); return 0; } }     \
+  }
+  FMC_WS(7) FMC_WS(9) FMC_WS(10) FMC_WS(14) FMC_WS(18) FMC_WS(20) FMC_WS(24)
+#undef FMC_WS
+  return fail(FASTMC_ESTATE, "no run-time-split instantiation for this grid / window");
 }
 
 // N = 2048 (S = 2) and 4096 (S = 4): sub-rows of 1024 points through the P = 16 pipeline
@@ -1021,6 +1037,8 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       RA.om = (const cpx<R>*)h->omg;
       CA.om = RA.om;
       dispatch_wave<R, 32, 32>(h, RA, CA, S.mode, S.epi);
+    } else if (wave_ok && wave_rt_split(h->N)) {
+      TRY(dispatch_ws<R>(h, RA, CA, S.mode, S.epi));
     } else if (wave_ok && h->S == 2) {
       TRY((dispatch_wave_split<R, 2>(h, RA, CA, S.mode, S.epi)));
     } else if (wave_ok && h->S == 4) {

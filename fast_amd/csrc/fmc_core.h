@@ -272,21 +272,33 @@ struct xoshiro128p {
 // Generator layout: a grid of N columns is drawn as 64*spec_split(N) streams per row, stream L = kx mod (64 S)
 // yielding coefficient j <-> kx = L + 64 S j.  S > 1 where the wave kernels transform a row as S interleaved
 // sub-rows (kx = s mod S), so that lane l of pass s reads ONE stream (L = s + S l) sequentially.
-FMC_HD constexpr int spec_split(int N) { return N == 4096 ? 4 : (N == 2048 ? 2 : 1); }
+// P of the in-register radix stage: 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32
+FMC_HD constexpr bool mr_supported_P(int P) {
+  if (P < 2 || P > 32) return false;
+  const int odd = P / (P & -P);
+  return odd == 1 || odd == 3 || odd == 5 || odd == 7 || odd == 9;
+}
+// Wave-family grids N = 64 q whose q is not such a P: S = 2 ... 4 sub-rows (run-time S in the kernels) when that leaves
+// 7 <= P <= 24 -- 1344 = 3 x 448, 1728 = 3 x 576, 1920 = 3 x 640, 2304 = 2 x 1152, 2560 = 2 x 1280, 2688 = 3 x 896,
+// 3072 = 2 x 1536, 3456 = 3 x 1152, 3584 = 4 x 896, 3840 = 3 x 1280.  0 otherwise.
+FMC_HD constexpr int wave_rt_split(int N) {
+  if (N % 64 != 0 || N == 2048 || N == 4096) return 0;
+  const int q = N / 64;
+  if (mr_supported_P(q)) return 0;
+  for (int S = 2; S <= 4; ++S)
+    if (q % S == 0 && q / S >= 7 && q / S <= 24 && mr_supported_P(q / S)) return S;
+  return 0;
+}
+FMC_HD constexpr int spec_split(int N) { return N == 4096 ? 4 : (N == 2048 ? 2 : (wave_rt_split(N) ? wave_rt_split(N) : 1)); }
 // Grid sizes of the 50-lane family (fmc_mrfft.h): N = 50 P S -- S interleaved sub-rows (kx = s mod S) of 50 P points, P =
 // 2^k times 1, 3, 5, 7 or 9.  S = 1 for P <= 24 (100, 150, ..., 1000, 1200); larger grids take the smallest S <= 5 that
 // leaves 7 <= P <= 24 (1400 = 2 x 700, 1500 = 3 x 500, 1600 = 2 x 800, 2000 = 2 x 1000, 2500 = 5 x 500, 3000 = 3 x 1000,
 // 4000 = 4 x 1000, ...).  Sizes of the wave family (N = 64 P') stay there.  Their rows are drawn as 50 S streams, stream
 // L = kx mod 50 S, whichever kernel family transforms them (lane l of sub-row s reads stream s + S l sequentially).
 constexpr int MR_LN = 50;
-FMC_HD constexpr bool mr_supported_P(int P) {
-  if (P < 2 || P > 32) return false;
-  const int odd = P / (P & -P);
-  return odd == 1 || odd == 3 || odd == 5 || odd == 7 || odd == 9;
-}
 FMC_HD constexpr int mr_split(int N) {       // 0: not a size of the family
   if (N < 2 * MR_LN || N % MR_LN != 0) return 0;
-  if (N == 2048 || N == 4096 || (N % 64 == 0 && mr_supported_P(N / 64))) return 0;
+  if (N == 2048 || N == 4096 || (N % 64 == 0 && (mr_supported_P(N / 64) || wave_rt_split(N)))) return 0;
   const int q = N / MR_LN;
   if (q <= 24) return mr_supported_P(q) ? 1 : 0;
   for (int S = 2; S <= 5; ++S)

@@ -780,41 +780,64 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB_COLS * 64)) void k_cols_blu(
 #ifndef FMC_MR_WPB16
 #define FMC_MR_WPB16 8      // A/B at 800^2 f64: 8 waves 10.8 ms per 5000 realisations, 12 waves (168-VGPR cap) 14.2 ms
 #endif
-template <class R, int P, int NS> struct MrCfg {
-  static constexpr int W0 = WaveCfg<R, P, NS>::WPB;
-  static constexpr int WPB = (sizeof(R) == 8 && P >= 16 && W0 > FMC_MR_WPB16) ? FMC_MR_WPB16 : W0;
+// The same two kernels also serve the 64-lane pipeline (LN = 64, SPLIT only): wave-family grids N = 64 P S whose sub-row
+// count is not one of the compiled ones (2304 = 2 x 1152, 2560 = 2 x 1280, 3072 = 2 x 1536, ...; fmc_core.h: wave_rt_split).
+template <class R, int P, int LN> struct LaneFam;
+template <class R, int P> struct LaneFam<R, P, MR_LN> {
+  using G = MrGeom<R, P>;
+  static constexpr int L0 = G::L0, XELEMS = G::XELEMS, N = G::N;
+  static __device__ __forceinline__ int osign(int n_full) { return mr_osign(n_full); }
+  template <int NS, class Exec>
+  static __device__ __forceinline__ void fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw, const cpx<R>* om, int omS, int lo,
+                                             int Np, int os) {
+    pruned_row_fft_mr<R, P, NS>(ex, xbuf, tw, om, omS, lo, Np, os);
+  }
 };
-template <class R, int P, int NS>
+template <class R, int P> struct LaneFam<R, P, WAVE> {
+  using G = WaveGeom<R, P>;
+  static constexpr int L0 = 8, XELEMS = G::XELEMS, N = G::N;
+  static __device__ __forceinline__ int osign(int) { return 0; }      // 64 P S is a multiple of 4
+  template <int NS, class Exec>
+  static __device__ __forceinline__ void fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw, const cpx<R>* om, int omS, int lo,
+                                             int Np, int os) {
+    pruned_row_fft<R, P, NS>(ex, xbuf, tw, om, omS, lo, Np, 0xFF, os);
+  }
+};
+template <class R, int P, int NS, int LN = MR_LN> struct MrCfg {
+  static constexpr int W0 = WaveCfg<R, P, NS>::WPB;
+  static constexpr int WPB = (LN == MR_LN && sizeof(R) == 8 && P >= 16 && W0 > FMC_MR_WPB16) ? FMC_MR_WPB16 : W0;
+};
+template <class R, int P, int NS, int LN = MR_LN>
 __host__ __device__ constexpr size_t mr_lds_bytes(int omS) {
-  return (size_t)(P * WAVE + MrGeom<R, P>::L0 * omS) * sizeof(cpx<R>) + (size_t)MrCfg<R, P, NS>::WPB * MrGeom<R, P>::XELEMS * 8;
+  return (size_t)(P * WAVE + LaneFam<R, P, LN>::L0 * omS) * sizeof(cpx<R>) + (size_t)MrCfg<R, P, NS, LN>::WPB * LaneFam<R, P, LN>::XELEMS * 8;
 }
-template <class R, int P>
+template <class R, int P, int LN>
 __device__ __forceinline__ void load_tables_mr(cpx<R>* s_tw, cpx<R>* s_om, const cpx<R>* tw, const cpx<R>* om, int omS) {
   for (int i = threadIdx.x; i < P * WAVE; i += blockDim.x) s_tw[i] = tw[i];
-  for (int i = threadIdx.x; i < MrGeom<R, P>::L0 * omS; i += blockDim.x) s_om[i] = om[i];
+  for (int i = threadIdx.x; i < LaneFam<R, P, LN>::L0 * omS; i += blockDim.x) s_om[i] = om[i];
   __syncthreads();
 }
 
 // SPLIT: the row of N = S * 50 P points as S interleaved sub-rows (kx = s mod S, S = N / 50 P at run time, <= 5), window
 // outputs combined by decimation in time, X[x] = sum_s w_N^{s x} Y_s[x mod 50 P] (cw), as the wave family does for 2048 / 4096.
-template <class R, int P, int NS, int MODE, bool SPLIT = false>
-__global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_rows_mr(RowArgs<R> A) {
+template <class R, int P, int NS, int MODE, bool SPLIT = false, int LN = MR_LN>
+__global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_rows_mr(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using G = MrGeom<R, P>;
+  using G = LaneFam<R, P, LN>;
   using E = typename Xch<R>::E;
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
   cpx<R>* s_om = s_tw + P * WAVE;
   E* s_x = reinterpret_cast<E*>(s_om + G::L0 * A.omS);
-  load_tables_mr<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
+  load_tables_mr<R, P, LN>(s_tw, s_om, A.tw, A.om, A.omS);
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane < MR_LN ? lane : MR_LN - 1;      // idle lanes repeat lane 49 (in-bounds loads; nothing reads their column)
+  const int li = lane < LN ? lane : LN - 1;            // 50 lanes: idle lanes repeat lane 49 (in-bounds loads; nothing reads their column)
   E* xbuf = s_x + w * G::XELEMS;
   const int N = SPLIT ? A.N : G::N;
   const int S = SPLIT ? A.N / G::N : 1;
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
-  constexpr int WPB = MrCfg<R, P, NS>::WPB;
+  constexpr int WPB = MrCfg<R, P, NS, LN>::WPB;
   constexpr int LR = 128 / (int)sizeof(cpx<R>);
   static_assert((ROWS_PER_WAVE * WPB) % LR == 0, "tile must hold whole lines");
   constexpr int BPG = ROWS_PER_WAVE * WPB / LR;
@@ -835,19 +858,19 @@ __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_rows_mr(RowArgs
     for (int sp = 0; sp < S; ++sp) {
       if (MODE == 0) {
         const float* ampf = A.ampf + (size_t)ky * N + sp;
-        xoshiro128p rs = row_stream(A.key, g, ky, sp + S * li, MR_LN * S);
+        xoshiro128p rs = row_stream(A.key, g, ky, sp + S * li, LN * S);
 #pragma unroll
-        for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[S * (li + MR_LN * j)]);
+        for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[S * (li + LN * j)]);
       } else {
         const size_t base = ((size_t)b * N + ky) * N + sp;
         const R* amp = A.amp + (size_t)ky * N + sp;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-          const int kx = S * (li + MR_LN * j);
+          const int kx = S * (li + LN * j);
           regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
         }
       }
-      pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, mr_osign(N));
+      G::template fft<NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, G::osign(N));
       if (SPLIT) {
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
@@ -873,20 +896,20 @@ __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_rows_mr(RowArgs
   }
 }
 
-template <class R, int P, int NS, int EPI, bool SPLIT = false>
-__global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_cols_mr(ColArgs<R> A) {
+template <class R, int P, int NS, int EPI, bool SPLIT = false, int LN = MR_LN>
+__global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_cols_mr(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using G = MrGeom<R, P>;
+  using G = LaneFam<R, P, LN>;
   using E = typename Xch<R>::E;
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
   cpx<R>* s_om = s_tw + P * WAVE;
   E* s_x = reinterpret_cast<E*>(s_om + G::L0 * A.omS);
-  load_tables_mr<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
+  load_tables_mr<R, P, LN>(s_tw, s_om, A.tw, A.om, A.omS);
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane < MR_LN ? lane : MR_LN - 1;
+  const int li = lane < LN ? lane : LN - 1;
   E* xbuf = s_x + w * G::XELEMS;
-  const int item = blockIdx.x * MrCfg<R, P, NS>::WPB + w;
+  const int item = blockIdx.x * MrCfg<R, P, NS, LN>::WPB + w;
   if (item >= A.nb * A.Np) return;   // whole wave exits; no block barrier follows
   const int b = item / A.Np;
   const int xi = item % A.Np;
@@ -897,8 +920,8 @@ __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_cols_mr(ColArgs
   const cpx<R>* col = A.V + ((size_t)b * A.Np + xi) * N;
   if (!SPLIT) {
 #pragma unroll
-    for (int j = 0; j < P; ++j) regs.v[j] = col[li + MR_LN * j];
-    pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, mr_osign(N));
+    for (int j = 0; j < P; ++j) regs.v[j] = col[li + LN * j];
+    G::template fft<NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, G::osign(N));
   } else {
     R accr[NS], acci[NS];
 #pragma unroll
@@ -906,8 +929,8 @@ __global__ __launch_bounds__((MrCfg<R, P, NS>::WPB * 64)) void k_cols_mr(ColArgs
 #pragma unroll 1
     for (int sp = 0; sp < S; ++sp) {
 #pragma unroll
-      for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (li + MR_LN * j)];
-      pruned_row_fft_mr<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, mr_osign(N));
+      for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (li + LN * j)];
+      G::template fft<NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, G::osign(N));
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) {
         const int oi = lane + WAVE * s2;

@@ -75,20 +75,38 @@ def xoshiro128p_next2(s):
     return a, b
 
 
+def _radix_ok(P):
+    """fmc_core.h: mr_supported_P -- 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32."""
+    return 2 <= P <= 32 and P // (P & -P) in (1, 3, 5, 7, 9)
+
+
+def wave_rt_split(N):
+    """fmc_core.h: wave_rt_split -- grids N = 64 q with q not a radix of the wave family: S = 2 ... 4 sub-rows when that
+    leaves 7 <= P <= 24 (1344, 1728, 1920, 2304, 2560, 2688, 3072, 3456, 3584, 3840), else 0."""
+    if N % 64 or N in (2048, 4096):
+        return 0
+    q = N // 64
+    if _radix_ok(q):
+        return 0
+    for S in (2, 3, 4):
+        if q % S == 0 and 7 <= q // S <= 24 and _radix_ok(q // S):
+            return S
+    return 0
+
+
 def spec_split(N):
     """fmc_core.h: spec_split -- sub-rows per row of the wave kernels, which fixes the stream layout."""
-    return 4 if N == 4096 else (2 if N == 2048 else 1)
+    return 4 if N == 4096 else (2 if N == 2048 else (wave_rt_split(N) or 1))
 
 
 def mr_split(N):
     """fmc_core.h: mr_split -- sub-rows S of the 50-lane kernel family (N = 50 P S, P = 2^k times 1, 3, 5, 7 or 9): 1 for
     P <= 24, else the smallest S <= 5 that leaves 7 <= P <= 24; 0 when N is not a size of the family (sizes of the wave
     family, N = 64 P', stay there)."""
-    def ok(P):
-        return 2 <= P <= 32 and P // (P & -P) in (1, 3, 5, 7, 9)
+    ok = _radix_ok
     if N < 100 or N % 50:
         return 0
-    if N in (2048, 4096) or (N % 64 == 0 and ok(N // 64)):
+    if N in (2048, 4096) or (N % 64 == 0 and (ok(N // 64) or wave_rt_split(N))):
         return 0
     q = N // 50
     if q <= 24:

@@ -989,6 +989,31 @@ def test_fast_run_reproduces_reference_on_lanes50_and_direct_kernels(case):
         np.testing.assert_allclose(sim.run()._r, g["r"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("N,Np", [(1344, 82), (1920, 200), (2304, 82), (2560, 101), (3072, 82), (3072, 256), (3584, 60), (3840, 82)])
+def test_wave_family_with_run_time_sub_rows(N, Np):
+    """Grids N = 64 P S whose sub-row count is not a compiled one (fmc_core.h: wave_rt_split): screens from host coefficients
+    vs the oracle's FFT-branch transform, device-generator powers vs the direct family (64 S streams per row), and the
+    restated generator."""
+    ps, df = _vk_spectrum(N, 0.01, 25.0)
+    rng = np.random.default_rng(N + Np)
+    cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
+    full = R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df))
+    for lo in sorted({(N - Np) // 2, 0, N - Np}):
+        h = _lib.Handle(N, Np, "f64", 0)
+        assert h.kernel_path() == 1
+        h.set_spectrum(ps * 0.02, df)
+        h.set_pupil(_window_W(Np), lo, 0.01)
+        got = h.screens_coeffs(cr, ci)
+        assert np.abs(got - full[:, lo:lo + Np, lo:lo + Np] * np.sqrt(0.02)).max() <= 1e-11 * np.abs(full).max()
+    a = h.run(7, 3, 2, None, 0.02)
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.run(7, 3, 2, None, 0.02), a, rtol=1e-9)
+    with pytest.raises(_lib.FastMCError):
+        h.kernel_path(2)
+    got = h.rng_coeffs(7, 3)
+    assert np.abs(got - devrng.device_coefficients(7, 3, N)).max() < 1e-3
+
+
 def test_kernel_family_notes_in_the_log(caplog):
     """Grids of the direct family are announced with the nearest fast sizes; 64 P and 50 P S grids are not."""
     import logging

@@ -115,6 +115,11 @@ def test_stream_layout_of_the_50_lane_grids():
     assert devrng.stream_lanes(1000) == 50 and devrng.stream_lanes(1024) == 64 and devrng.stream_lanes(2048) == 128
     assert devrng.stream_lanes(2000) == 100 and devrng.stream_lanes(2500) == 250 and devrng.stream_lanes(4000) == 200
     assert devrng.stream_lanes(550) == 64 and devrng.stream_lanes(164) == 64 and devrng.stream_lanes(1100) == 64
+    # wave-family grids with a run-time sub-row count: 64 S streams per row
+    assert [(n, devrng.wave_rt_split(n)) for n in range(2, 4097) if devrng.wave_rt_split(n)] == [
+        (1344, 3), (1728, 3), (1920, 3), (2304, 2), (2560, 2), (2688, 3), (3072, 2), (3456, 3), (3584, 4), (3840, 3)]
+    assert devrng.stream_lanes(3072) == 128 and devrng.stream_lanes(1344) == 192 and devrng.stream_lanes(3584) == 256
+    assert devrng.stream_lanes(3200) == 200 and devrng.stream_lanes(1600) == 100 and devrng.stream_lanes(960) == 64
     c2 = devrng.device_coefficients(5, 0, 1400)[:3]
     assert np.isfinite(c2).all() and len(np.unique(c2.ravel())) == 3 * 1400
     c = devrng.device_coefficients(5, 0, 100)

@@ -17,7 +17,8 @@ for c in range(cases):
     if c % 2:                                           # every other case: a size that is not 64 P -> chirp-z family
         N = int(rng.integers(8, 1500))
     if c % 4 == 3:                                      # every fourth: N = 50 P -> 50-lane family
-        N = int(rng.choice([100, 150, 200, 250, 300, 350, 400, 450, 500, 600, 700, 800, 900, 1000, 1200, 1350, 1400, 1500, 1600, 1750, 1800, 2000]))
+        N = int(rng.choice([100, 150, 200, 250, 300, 350, 400, 450, 500, 600, 700, 800, 900, 1000, 1200, 1350, 1400, 1500, 1600, 1750, 1800, 2000,
+                          1344, 1728, 1920, 2304, 2560]))
     Np = int(rng.integers(1, min(N, 300 if c % 2 == 0 else 256) + 1))
     lo = int(rng.choice([0, N - Np, (N - Np) // 2, rng.integers(0, N - Np + 1)]))
     prec = "f64" if rng.random() < 0.7 else "f32"

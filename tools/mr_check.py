@@ -8,7 +8,10 @@ for (N, Np, lo, prec) in [(1000, 82, 459, "f64"), (500, 82, 209, "f64"), (250, 6
                           (1000, 200, 400, "f64"), (1000, 82, 459, "f32"), (150, 30, 120, "f64"), (1600, 82, 759, "f64"), (700, 100, 300, "f32"),
                           (450, 82, 184, "f64"), (1400, 100, 650, "f64"), (900, 90, 405, "f64"), (600, 256, 172, "f64"),
                           (2000, 82, 959, "f64"), (1500, 82, 0, "f64"), (1350, 82, 1268, "f32"), (2500, 130, 1185, "f64"), (4000, 82, 1959, "f64"),
-                          (1750, 82, 834, "f64"), (3000, 256, 1372, "f32")]:
+                          (1750, 82, 834, "f64"), (3000, 256, 1372, "f32"),
+                          # wave-family grids with a run-time sub-row count (64 P S)
+                          (1344, 82, 631, "f64"), (1920, 200, 0, "f64"), (2304, 82, 1111, "f64"), (2560, 82, 2478, "f32"),
+                          (3072, 130, 1471, "f64"), (3584, 82, 1751, "f64"), (3840, 256, 1792, "f64"), (1728, 82, 823, "f32")]:
     tol = 1e-10 if prec == "f64" else 1e-4
     ps = rng.uniform(0.0, 1.0, size=(N, N)) ** 4 * 1e-3
     cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))

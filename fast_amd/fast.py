@@ -124,7 +124,7 @@ class Fast():
             self._group.each(lambda h, i: h.kernel_path(_lib.KERNEL_PATHS[p['GPU_KERNELS']]))
         self.compute_powerspec()
         if self._handle.kernel_path() not in (1, 3) and self.Npxls >= 128 and not self.temporal:
-            below = [n for n in host.WAVE_FFT_SIZES if n <= self.Npxls][-1:]
+            below = [n for n in host.ROUND_UP_SIZES if n <= self.Npxls][-1:]
             above = [n for n in host.ROUND_UP_SIZES if n >= self.Npxls][:1]
             near = ', '.join(str(n) for n in below + above)
             if self._handle.kernel_path() == 2:

@@ -20,10 +20,29 @@ TWO_PI = 2 * np.pi
 # grid sizes served by the wave-FFT kernels: 64 * 2^k * {1, 3, 5, 7, 9}, 128 ... 2048 (fmc_wavefft.h), and 4096
 # (4 interleaved sub-rows of 1024; 2048 runs as 2)
 WAVE_FFT_SIZES = sorted(64 * q * 2 ** k for q in (1, 3, 5, 7, 9) for k in range(6) if 2 <= q * 2 ** k <= 32) + [4096]
-# sizes GPU_ROUND_NPXLS rounds up to: 896 and 1792 (radix-7 stage, 2 resp. 1 waves per SIMD) are slower than the
-# next power of two (measured 0.55 vs 0.73 M it/s and 0.137 vs 0.153 M it/s, tools/sizesweep.sh)
 MAX_NPXLS = 4096          # libfastmc: N <= 4096 (fastmc_create)
-ROUND_UP_SIZES = [s for s in WAVE_FFT_SIZES if s not in (896, 1792)]
+# Measured float64 throughput [k iterations/s, Np = 82, device generator] of every grid size that has an FFT kernel family
+# (tools/sizesweep.sh on one MI355X; profiles/r01k_sizesweep_f64.txt, r02g_sizesweep_lanes50_f64.txt):
+# 64 P wave sizes, 64 P S with run-time sub-rows, 50 P S on the 50-lane kernels.  GPU_ROUND_NPXLS rounds an auto-sized grid
+# up to the smallest of these that is within 10 % of the fastest one not smaller than it (896 and 1792, radix-7 stages, lose
+# to 1024 and 2048; 2048 beats everything between 1600 and itself).
+FAST_SIZE_RATE = {
+    128: 6500, 192: 5600, 256: 4300, 320: 3400, 384: 2700, 448: 2200, 512: 2100, 576: 1400, 640: 1300, 768: 1000, 896: 550,
+    1024: 840, 1152: 460, 1280: 360, 1536: 320, 1792: 140, 2048: 220, 4096: 48,
+    1344: 318, 1728: 174, 1920: 159, 2304: 86, 2560: 75, 3072: 85, 3584: 43, 3840: 35,
+    100: 8060, 150: 6150, 200: 4850, 250: 3900, 300: 3170, 350: 2545, 400: 2490, 450: 1930, 500: 1930, 600: 1490, 700: 830,
+    800: 780, 900: 590, 1000: 540, 1200: 410, 1400: 227, 1500: 249, 1600: 198, 2000: 124, 2500: 91, 3000: 57, 4000: 32,
+}
+ROUND_UP_SIZES = sorted(FAST_SIZE_RATE)
+
+
+def round_up_size(N):
+    """The grid size GPU_ROUND_NPXLS gives an auto-sized N: None when nothing fast is >= N."""
+    cand = [s for s in ROUND_UP_SIZES if s >= N]
+    if not cand:
+        return None
+    best = max(FAST_SIZE_RATE[s] for s in cand)
+    return next(s for s in cand if FAST_SIZE_RATE[s] >= 0.9 * best)
 
 
 # ----------------------------------------------------------------------------- geometry
@@ -101,10 +120,10 @@ def grid_size(p, atm):
             # the reference's auto rule is a lower bound and gives arbitrary even sizes (164 for the shipped
             # example, 5x slower on the direct kernels than 192 on the wave kernels); the next size of the
             # fast kernel family samples the spectrum slightly finer
-            bigger = [s for s in ROUND_UP_SIZES if s >= N]
+            bigger = round_up_size(N)
             if bigger:
-                logger.info(f"GPU_ROUND_NPXLS: auto NPXLS {N} -> {bigger[0]}")
-                N = bigger[0]
+                logger.info(f"GPU_ROUND_NPXLS: auto NPXLS {N} -> {bigger}")
+                N = bigger
         logger.info(f"Auto set NPXLS to {N}")
         if p['AO_MODE'] == 'NOAO' and not np.isinf(p['L0']):
             n_l0 = int(2 * np.ceil((p['L0'] * 2) / dx) / 2)

@@ -27,6 +27,7 @@ struct HostExec {
   template <class T> static void pin(T&) {}
   template <class E> static E ld(const E* p) { return *p; }
   template <class E> static void st(E* p, E v) { *p = v; }
+  template <class E> static void ld2(const E* p, E& a, E& b) { a = p[0]; b = p[1]; }
 };
 
 static void cs_turns(double t, double* c, double* s) {

@@ -303,6 +303,13 @@ struct GpuExec {
     return o;
   }
   template <class E> static __device__ __forceinline__ void st(E* p, E v) { *p = v; }
+  // two neighbouring 8-byte elements at a 16-byte aligned address: one ds_read_b128
+  template <class E> static __device__ __forceinline__ void ld2(const E* p, E& a, E& b) {
+    struct alignas(16) Pair { E a, b; };
+    const Pair v = *reinterpret_cast<const Pair*>(__builtin_assume_aligned(p, 16));
+    a = v.a;
+    b = v.b;
+  }
   // compiler-only barrier for memory operations: loads after it are not hoisted above it
   static __device__ __forceinline__ void loadfence() { asm volatile("" ::: "memory"); }
   // "this value is needed HERE": loads feeding it are issued before this point and waited for once.

@@ -295,6 +295,9 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
 //   exchange 2:  F[a][b0][l0] at a + 16 b0 + 128 l0 (dense, 1024 elements): consecutive window outputs walk a, then b0,
 //                and 16 b0 alternates the upper half of the 32 element banks
 // all affine, so every access is base + immediate offset (tools/lds_bank_check.py verifies both images for every window).
+#ifndef FMC_D16_PAIR
+#define FMC_D16_PAIR 0   // A/B variant: exchange-1 reads as 8 ds_read_b128 instead of 16 ds_read_b64 per pass (139 -> 123 LDS instructions
+#endif                   // per row): rows 10.44 -> 10.46 ms per 5000 realisations -- the LDS time goes with the bytes, not the instructions
 constexpr int D16_SE = 66;
 constexpr int D16_XELEMS = 16 * D16_SE;
 template <class R, int NS, class Exec>
@@ -318,6 +321,27 @@ FMC_HD void pruned_row_fft_d16(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>*
   });
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
+#if FMC_D16_PAIR
+    // element (a, l) at 66 a + pi(l), pi(l) = 2 (l & 3) + ((l >> 2) & 1) + 8 (l >> 3): the two elements lane (a, lp) needs for
+    // one l1 (l = lp + 8 l1 and l + 4) are neighbours, one 16-byte read instead of two 8-byte reads
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int pl = 2 * (lane & 3) + ((lane >> 2) & 1) + 8 * (lane >> 3);
+#pragma unroll
+      for (int a = 0; a < P; ++a) ex.st(xbuf + a * D16_SE + pl, X::pack(r.v[a], c));
+    });
+    ex.sync();
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int a = lane & 15, lp = lane >> 4;
+#pragma unroll
+      for (int l1 = 0; l1 < 8; ++l1) {
+        E e0, e1;
+        ex.ld2(xbuf + a * D16_SE + 2 * lp + 8 * l1, e0, e1);
+        X::unpack(r.v[l1], e0, c);
+        X::unpack(r.v[8 + l1], e1, c);
+      }
+    });
+    ex.sync();
+#else
     ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
 #pragma unroll
       for (int a = 0; a < P; ++a) ex.st(xbuf + a * D16_SE + lane, X::pack(r.v[a], c));
@@ -331,6 +355,7 @@ FMC_HD void pruned_row_fft_d16(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>*
         for (int l1 = 0; l1 < 8; ++l1) X::unpack(r.v[q * 8 + l1], ex.ld(xbuf + a * D16_SE + lp + 4 * q + 8 * l1), c);
     });
     ex.sync();
+#endif
   }
   ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
 #pragma unroll

@@ -49,7 +49,45 @@ int main(void) {
   long long total = 0;
   for (int i = 0; i < 66; ++i) total += bins[i];
   if (fastmc_run(h, 1u, 0, -5, NULL, 0.0, 0, out) >= 0) { fprintf(stderr, "negative count accepted\n"); return 3; }
+  /* kernel families: 256 = 64 x 4 runs the wave FFT kernels; the direct family gives the same powers to rounding */
+  if (fastmc_kernel_path(h, -1) != 1) { fprintf(stderr, "256^2 is not on the wave kernels\n"); return 5; }
+  CHECK(fastmc_kernel_path(h, 0));
+  CHECK(fastmc_run(h, 1234u, 0, 400, NULL, 0.01, 0, tail));
+  double famdiff = 0.0;
+  for (int i = 0; i < 800; ++i) famdiff = fmax(famdiff, fabs(tail[i] - out2[i]) / out2[i]);
+  if (fastmc_kernel_path(h, 3) >= 0) { fprintf(stderr, "50-lane kernels accepted for N = 256\n"); return 6; }
+  CHECK(fastmc_kernel_path(h, 1));
+  /* one process, one device: communicator of one rank, all-gather + histogram all-reduce through RCCL (or a refusal
+   * with FASTMC_ECOMM when librccl is absent / disabled, which a caller answers with the host copy it already has) */
+  CHECK(fastmc_run(h, 1234u, 0, 400, NULL, 0.01, 0, out2));
+  fastmc_t* group[1];
+  group[0] = h;
+  int world = -1, rank = -2;
+  const int rc_comm = fastmc_comm_init_all(group, 1);
+  double gathered_diff = -1.0;
+  long long gtotal = -1;
+  if (rc_comm >= 0) {
+    CHECK(fastmc_comm_world(h, &world, &rank));
+    double* all = malloc(sizeof(double) * 800);
+    int64_t gb[66];
+    CHECK(fastmc_comm_gather_all(group, 1, 800, all, gb, -60.0, 10.0, 64));
+    gathered_diff = 0.0;
+    for (int i = 0; i < 800; ++i) gathered_diff = fmax(gathered_diff, fabs(all[i] - out2[i]));
+    gtotal = 0;
+    for (int i = 0; i < 66; ++i) gtotal += gb[i];
+    free(all);
+    fastmc_comm_destroy(h);
+  }
   fastmc_destroy(h);
+  /* a round decimal grid: 200 = 50 x 4 runs the 50-lane kernels */
+  fastmc_t* h2 = NULL;
+  CHECK(fastmc_create(&h2, 0, 200, 40, FASTMC_F64));
+  const int path200 = fastmc_kernel_path(h2, -1);
+  fastmc_destroy(h2);
+  printf("families: wave-vs-direct %.3g, path(200)=%d; comm rc=%d world=%d rank=%d gathered_diff=%.3g hist=%lld\n", famdiff, path200,
+         rc_comm, world, rank, gathered_diff, gtotal);
+  if (famdiff > 1e-9 || path200 != 3) return 7;
+  if (rc_comm >= 0 && (world != 1 || rank != 0 || gathered_diff != 0.0 || gtotal != 800)) return 8;
   printf("C-ABI OK mean=%.6f split_maxdiff=%.3g hist_total=%lld last_error_after_bad_call=\"%s\"\n", mean, maxdiff, total,
          fastmc_last_error());
   return (mean > 0.0 && mean <= 1.1 && maxdiff == 0.0 && total == 1200) ? 0 : 4;

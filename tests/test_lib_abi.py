@@ -67,3 +67,5 @@ def test_plain_c_client_runs(built, tmp_path):
     r = subprocess.run([_build_c_client(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "C-ABI OK" in r.stdout and "split_maxdiff=0" in r.stdout
+    # kernel families and the one-process communicator calls from plain C
+    assert "path(200)=3" in r.stdout and ("comm rc=0 world=1 rank=0 gathered_diff=0 hist=800" in r.stdout or "comm rc=-" in r.stdout)

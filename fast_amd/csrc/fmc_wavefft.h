@@ -22,6 +22,9 @@
 #ifndef FMC_BATCH_LDS
 #define FMC_BATCH_LDS 1
 #endif
+#ifndef FMC_BATCH_MAXP
+#define FMC_BATCH_MAXP 32   // A/B: batching only up to P = 16 (no spill at P = 20) is 2 % slower at 1152^2 / 1280^2, equal at 1536^2 / 1792^2
+#endif
 #ifndef FMC_TW_CHUNK
 #define FMC_TW_CHUNK 4
 #endif
@@ -255,7 +258,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
             const int b0 = (x / P) & 7;
             const E* f = xbuf + a + G::FB * b0;
 #if FMC_BATCH_LDS
-            if (P >= 12 && NS == 2) {
+            if (P >= 12 && P <= FMC_BATCH_MAXP && NS == 2) {
             cpx<R> w[8];
             E fv[8];
             fv[0] = ex.ld(f);

@@ -999,6 +999,12 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     CA.W = h->W;
     CA.sh.enabled = sh ? (h->sh_sep ? 2 : 1) : 0; CA.sh.dcol = h->sh_dcol; CA.sh.coef = h->sh_coef; CA.sh.mean = h->sh_mean; CA.sh.ex = h->sh_ex; CA.sh.ey = h->sh_ey;
     CA.partial = h->partial + (size_t)((bs - fin_start)) * Np * 4; CA.phs = h->phs;
+#ifdef FMC_ISA_SUBSET   // tools/isa_stats.py: only the kernels whose instruction mix bench.py prices (same code, a tenth of the compile time)
+    RA.amp = (const R*)h->amp_s; RA.ampf = h->ampf_s; RA.tw = (const cpx<R>*)h->tw1; CA.tw = RA.tw;
+    RA.cw = (const cpx<R>*)h->cw; CA.cw = RA.cw; RA.tw_global = CA.tw_global = 0;
+    if (h->S == 2) dispatch_wave<R, 16, 2, 2>(h, RA, CA, S.mode, S.epi);
+    else dispatch_wave<R, 16, 2>(h, RA, CA, S.mode, S.epi);
+#else
     if (h->path == 2) {
       TRY(upload_blu_tables<R>(h));
       RA.amp = (const R*)h->amp; RA.ampf = h->ampf; RA.tw = (const cpx<R>*)h->blu_tw1; RA.om = (const cpx<R>*)h->blu_om;
@@ -1068,6 +1074,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       TRY(dispatch_direct<R>(h, RA, CA, S.mode, S.epi));
     }
     }
+#endif
     if (S.epi == 0) {
       const int64_t done = bs + nb;                 // realisations with partials ready: [fin_start, done)
       if (done == S.n_real || done - fin_start + B > FIN_SPAN) {

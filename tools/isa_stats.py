@@ -26,7 +26,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "fast_amd", "csrc", "fastmc.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast", "-fno-slp-vectorize", "-Wno-unused-result",
-         "-Wno-unused-value", "-Wno-unused-command-line-argument", "--cuda-device-only", "-S"]
+         "-Wno-unused-value", "-Wno-unused-command-line-argument", "-Wno-unused-function", "--cuda-device-only", "-S",
+         "-DFMC_ISA_SUBSET"]       # only the priced kernels are instantiated: identical code for them, a tenth of the compile time
 
 # demangled-name prefixes of the kernels whose counts bench.py uses
 KERNELS = {

@@ -132,3 +132,24 @@ for P in (10,12,20):
             w,r=check_relayout2(P,adr,0)
             if w<=4 and r<=2: res.append((max(vals)+1,sh,mask,mul))
     res.sort(); print(P,res[:4])
+print("50-lane family (fmc_mrfft.h): exchange 1 at 69 a + l, exchange 2 dense at q + 5 P b0 (q = 5 a + l0); worst cycles per access"
+      " (ideal: write 4 = one per 16-lane group, read 2 = one per 32-lane group)")
+for P in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 24):
+    L0, L1, SE, NBF = 5, 10, 69, 5 * P
+    NB = (NBF + 63) // 64
+    w1 = max(cycles([a * SE + l for l in range(64)], "w") for a in range(P))
+    r1 = 0
+    for jj in range(NB):
+        for m in range(L1):
+            r1 = max(r1, cycles([((l + 64 * jj) // L0) * SE + (l + 64 * jj) % L0 + L0 * m if l + 64 * jj < NBF else None
+                                 for l in range(64)], "r"))
+    w2 = 0
+    for jj in range(NB):
+        for b0 in range(L1):
+            w2 = max(w2, cycles([l + 64 * jj + NBF * b0 if l + 64 * jj < NBF else None for l in range(64)], "w"))
+    r2 = 0
+    N = 50 * P
+    for lo in range(0, N - 63):          # every window position, first slot (64 consecutive outputs)
+        for m in range(L0):
+            r2 = max(r2, cycles([L0 * ((lo + l) % (P * L1)) + m for l in range(64)], "r"))
+    print("P", P, "exchange 1 write/read", w1, r1, " exchange 2 write/read", w2, r2)

@@ -14,13 +14,32 @@
 #include <string>
 #include <vector>
 
+#ifndef FMC_TU
+#define FMC_TU 0     // see "Translation units" below
+#endif
 #include "fmc_kernels.h"
+#if FMC_TU == 0
 #include "fmc_powerspec.h"
+#endif
 
 using namespace fmc;
 
+// Translation units.  Alone (FMC_TU undefined) this file is the whole library.  With -DFMC_SPLIT_BUILD the Makefile compiles
+// it five times in parallel and links the objects: unit 0 holds the C-ABI, every host function and the small kernels;
+// the kernel families that run_impl launches are explicit instantiations of their dispatch templates in units
+//   1: wave family, float64     2: wave family, float32
+//   3: chirp-z, 50-lane, run-time-split and direct families, float64     4: the same, float32
+// (a fresh build takes the time of the slowest unit instead of the sum).
+#ifndef FMC_TU
+#define FMC_TU 0
+#endif
+
 // ------------------------------------------------------------------ errors
-static thread_local std::string g_err;
+#if FMC_TU == 0
+thread_local std::string g_err;
+#else
+extern thread_local std::string g_err;
+#endif
 static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
@@ -198,8 +217,13 @@ static void timing_end(fastmc_ctx* h) {   // after stream sync
 }
 
 // ------------------------------------------------------------------ misc entry points
+#if FMC_TU == 0
 extern "C" int fastmc_version(void) { return FASTMC_VERSION; }
+#endif
+#if FMC_TU == 0
 extern "C" const char* fastmc_last_error(void) { return g_err.c_str(); }
+#endif
+#if FMC_TU == 0
 extern "C" int fastmc_device_count(int* n) {
   if (!n) return fail(FASTMC_EINVAL, "n is NULL");
   int c = 0;
@@ -208,6 +232,7 @@ extern "C" int fastmc_device_count(int* n) {
   *n = c;
   return 0;
 }
+#endif
 
 // N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32
 static bool wave_supported(int N) {
@@ -300,6 +325,7 @@ struct HandleCache {
 };
 static HandleCache g_handles;
 
+#if FMC_TU == 0
 extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int precision) {
   if (!out) return fail(FASTMC_EINVAL, "handle pointer is NULL");
   *out = nullptr;
@@ -338,6 +364,7 @@ extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int p
   *out = h;
   return 0;
 }
+#endif
 
 // One retired V slab per device stays allocated for the next handle: a sweep builds hundreds of
 // short-lived handles (fast/complete_orbit_simulation.py:227-236 builds one Fast per pass) and a
@@ -366,6 +393,7 @@ struct SlabCache {
 };
 static SlabCache g_slabs;
 
+#if FMC_TU == 0
 fastmc_ctx* HandleCache::take(int device, int N, int Np, int precision) {
   std::lock_guard<std::mutex> g(mu);
   fastmc_ctx* h = dev[device & 63];
@@ -379,9 +407,11 @@ fastmc_ctx* HandleCache::swap_in(fastmc_ctx* h) {
   dev[h->device & 63] = h;
   return old;
 }
+#endif
 
 static void destroy_now(fastmc_ctx* h);
 
+#if FMC_TU == 0
 extern "C" void fastmc_destroy(fastmc_t* h) {
   if (!h) return;
   hipSetDevice(h->device);
@@ -401,6 +431,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   if (h->phs) { hipFree(h->phs); h->phs = nullptr; h->phs_cap = 0; }
   if (fastmc_ctx* old = g_handles.swap_in(h)) destroy_now(old);
 }
+#endif
 
 static void destroy_now(fastmc_ctx* h) {
   hipSetDevice(h->device);
@@ -416,6 +447,7 @@ static void destroy_now(fastmc_ctx* h) {
   delete h;
 }
 
+#if FMC_TU == 0
 extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   if (force == 1 && !wave_supported(h->N)) return fail(FASTMC_EINVAL, "wave kernels need N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32");
@@ -424,12 +456,15 @@ extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
   if (force >= 0 && force <= 3) h->path = force;
   return h->path;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_set_batch(fastmc_t* h, int batch) {
   if (!h || batch < 0) return fail(FASTMC_EINVAL, "bad batch");
   h->batch = batch;
   return 0;
 }
+#endif
 
 // The dense-image kernels (sixteen waves per workgroup) serve P = 16, NS = 2, unsplit rows, device generator and
 // detector epilogue, when their LDS fits (window up to 96 pixels): the configuration of the BASELINE workloads at 1024^2.
@@ -502,6 +537,7 @@ static int upload_spectrum(fastmc_ctx* h, const double* ps, double df) {
   return make_amp<R>(h, d_ps.p, df, h->stream);
 }
 
+#if FMC_TU == 0
 static int make_amp_from_device(fastmc_ctx* h, const double* d_ps, double df, hipStream_t stream) {
   h->df = df;
   h->have_spec = false;
@@ -509,7 +545,9 @@ static int make_amp_from_device(fastmc_ctx* h, const double* d_ps, double df, hi
   h->have_spec = true;
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_set_spectrum(fastmc_t* h, const double* powerspec, double df) {
   if (!h || !powerspec) return fail(FASTMC_EINVAL, "null argument");
   HIPCHK(hipSetDevice(h->device));
@@ -519,6 +557,7 @@ extern "C" int fastmc_set_spectrum(fastmc_t* h, const double* powerspec, double 
   h->have_spec = true;
   return 0;
 }
+#endif
 
 template <class R>
 static int upload_table(void** dst, const std::vector<cpx<R>>& v) {
@@ -604,6 +643,7 @@ static int upload_mr_tables(fastmc_ctx* h) {
   return 0;
 }
 
+#if FMC_TU == 0
 extern "C" int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, double dx) {
   if (!h || !W) return fail(FASTMC_EINVAL, "null argument");
   if (crop_lo < 0 || crop_lo + h->Np > h->N) return fail(FASTMC_EINVAL, "window [crop_lo, crop_lo+Np) outside the grid");
@@ -632,7 +672,9 @@ extern "C" int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, doubl
   h->have_pupil = true;
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_set_subharm(fastmc_t* h, const double* ps_sh, const double* fx, const double* fy, const double* df) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   if (!ps_sh) { h->have_sh = false; return 0; }
@@ -682,6 +724,7 @@ extern "C" int fastmc_set_subharm(fastmc_t* h, const double* ps_sh, const double
   h->have_sh = true;
   return 0;
 }
+#endif
 
 // ------------------------------------------------------------------ launches
 template <class R, int P, int NS, int MODE, int S = 1, int D = 0>
@@ -758,7 +801,7 @@ static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
 }
 
 template <class R>
-static int dispatch_blu(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+int dispatch_blu(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   const int ns = h->NS <= 2 ? 2 : 4;
 #define FMC_BLU(PP, NN) if (h->blu_P == PP && ns == NN) { dispatch_blu_pn<R, PP, NN>(h, RA, CA, mode, epi); return 0; }
   FMC_BLU(4, 2) FMC_BLU(8, 2) FMC_BLU(8, 4) FMC_BLU(16, 2) FMC_BLU(16, 4) FMC_BLU(24, 2) FMC_BLU(24, 4) FMC_BLU(32, 2)
@@ -799,7 +842,7 @@ static void dispatch_mr_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>
 constexpr bool mr_split_P(int P) { return P == 7 || P == 9 || P == 10 || P == 14 || P == 16 || P == 18 || P == 20 || P == 24; }
 
 template <class R>
-static int dispatch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+int dispatch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   const int ns = h->NS <= 2 ? 2 : 4;
   const bool split = h->mr_S > 1;
 #define FMC_MR(PP)                                                                                                    \
@@ -821,7 +864,7 @@ static int dispatch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA
 // Wave-family grids with a run-time sub-row count (fmc_core.h: wave_rt_split): the split kernels of the 50-lane family on
 // the 64-lane pipeline; tables as for every wave size (upload_wave_tables with P = h->P, S = h->S).
 template <class R>
-static int dispatch_ws(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+int dispatch_ws(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   const int ns = h->NS <= 2 ? 2 : 4;
 #define FMC_WS(PP)                                                                                                          \
   if (h->P == PP) {                                                                                                         \
@@ -860,8 +903,46 @@ static int dispatch_wave_ns(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
   return 0;
 }
 
+// Every launch of the wave family (64 P, split 2048 / 4096, run-time sub-rows, the general 2048 window): one function so that
+// it can be an explicit instantiation in its own translation unit.
 template <class R>
-static int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in, int mode, int epi) {
+int dispatch_wave_family(fastmc_ctx* h, RowArgs<R>& RA, ColArgs<R>& CA, int mode, int epi, bool general_2048) {
+  if (general_2048) {
+    RA.om = (const cpx<R>*)h->omg;
+    CA.om = RA.om;
+    dispatch_wave<R, 32, 32>(h, RA, CA, mode, epi);
+  } else if (wave_rt_split(h->N)) {
+    TRY(dispatch_ws<R>(h, RA, CA, mode, epi));
+  } else if (h->S == 2) {
+    TRY((dispatch_wave_split<R, 2>(h, RA, CA, mode, epi)));
+  } else if (h->S == 4) {
+    TRY((dispatch_wave_split<R, 4>(h, RA, CA, mode, epi)));
+  } else {
+    switch (h->P) {
+      case 2: dispatch_wave<R, 2, 2>(h, RA, CA, mode, epi); break;
+      case 3: dispatch_wave<R, 3, 2>(h, RA, CA, mode, epi); break;
+      case 4: TRY((dispatch_wave_ns<R, 4>(h, RA, CA, mode, epi))); break;
+      case 5: dispatch_wave<R, 5, 2>(h, RA, CA, mode, epi); break;
+      case 6: dispatch_wave<R, 6, 2>(h, RA, CA, mode, epi); break;
+      case 7: dispatch_wave<R, 7, 2>(h, RA, CA, mode, epi); break;
+      case 8: TRY((dispatch_wave_ns<R, 8>(h, RA, CA, mode, epi))); break;
+      case 9: TRY((dispatch_wave_ns<R, 9>(h, RA, CA, mode, epi))); break;
+      case 14: dispatch_wave<R, 14, 2>(h, RA, CA, mode, epi); break;
+      case 18: dispatch_wave<R, 18, 2>(h, RA, CA, mode, epi); break;
+      case 28: dispatch_wave<R, 28, 2>(h, RA, CA, mode, epi); break;
+      case 10: TRY((dispatch_wave_ns<R, 10>(h, RA, CA, mode, epi))); break;
+      case 12: TRY((dispatch_wave_ns<R, 12>(h, RA, CA, mode, epi))); break;
+      case 16: TRY((dispatch_wave_ns<R, 16>(h, RA, CA, mode, epi))); break;
+      case 20: TRY((dispatch_wave_ns<R, 20>(h, RA, CA, mode, epi))); break;
+      case 24: TRY((dispatch_wave_ns<R, 24>(h, RA, CA, mode, epi))); break;
+      default: return fail(FASTMC_ESTATE, "no wave instantiation for this grid size");
+    }
+  }
+  return 0;
+}
+
+template <class R>
+int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in, int mode, int epi) {
   // LDS: twiddles [N] + row/column [N] + segment partials [S][Np] (S*Np <= max(256, Np))
   size_t lds = ((size_t)2 * h->N + (size_t)std::max(DIRECT_THREADS, h->Np)) * sizeof(cpx<R>);
   RowArgs<R> RA = RA_in;
@@ -896,6 +977,46 @@ static int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs
   return 0;
 }
 
+// ------------------------------------------------------------------ translation units (see the top of the file)
+#define FMC_FAMILY_SIG(R) fastmc_ctx*, const RowArgs<R>&, const ColArgs<R>&, int, int
+#define FMC_WAVE_SIG(R) fastmc_ctx*, RowArgs<R>&, ColArgs<R>&, int, int, bool
+#if defined(FMC_SPLIT_BUILD) || FMC_TU != 0     // defined in another unit
+#if FMC_TU != 1
+extern template int dispatch_wave_family<double>(FMC_WAVE_SIG(double));
+#endif
+#if FMC_TU != 2
+extern template int dispatch_wave_family<float>(FMC_WAVE_SIG(float));
+#endif
+#if FMC_TU != 3
+extern template int dispatch_blu<double>(FMC_FAMILY_SIG(double));
+extern template int dispatch_mr<double>(FMC_FAMILY_SIG(double));
+extern template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
+extern template int dispatch_direct<double>(FMC_FAMILY_SIG(double));
+#endif
+#if FMC_TU != 4
+extern template int dispatch_blu<float>(FMC_FAMILY_SIG(float));
+extern template int dispatch_mr<float>(FMC_FAMILY_SIG(float));
+extern template int dispatch_ws<float>(FMC_FAMILY_SIG(float));
+extern template int dispatch_direct<float>(FMC_FAMILY_SIG(float));
+#endif
+#endif
+#if FMC_TU == 1
+template int dispatch_wave_family<double>(FMC_WAVE_SIG(double));
+#elif FMC_TU == 2 && !defined(FMC_ONLY_F64)
+template int dispatch_wave_family<float>(FMC_WAVE_SIG(float));
+#elif FMC_TU == 3
+template int dispatch_blu<double>(FMC_FAMILY_SIG(double));
+template int dispatch_mr<double>(FMC_FAMILY_SIG(double));
+template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
+template int dispatch_direct<double>(FMC_FAMILY_SIG(double));
+#elif FMC_TU == 4 && !defined(FMC_ONLY_F64)
+template int dispatch_blu<float>(FMC_FAMILY_SIG(float));
+template int dispatch_mr<float>(FMC_FAMILY_SIG(float));
+template int dispatch_ws<float>(FMC_FAMILY_SIG(float));
+template int dispatch_direct<float>(FMC_FAMILY_SIG(float));
+#endif
+
+#if FMC_TU == 0   // everything below: the run loop, the remaining entry points and the small kernels' launches
 struct RunSpec {
   int mode;                 // 0 device RNG, 1 host coefficients
   int epi;                  // 0 powers, 1 screens
@@ -1039,37 +1160,8 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     RA.tw_global = 0;
     CA.tw_global = 0;
     CA.cw = RA.cw;
-    if (general_2048) {
-      RA.om = (const cpx<R>*)h->omg;
-      CA.om = RA.om;
-      dispatch_wave<R, 32, 32>(h, RA, CA, S.mode, S.epi);
-    } else if (wave_ok && wave_rt_split(h->N)) {
-      TRY(dispatch_ws<R>(h, RA, CA, S.mode, S.epi));
-    } else if (wave_ok && h->S == 2) {
-      TRY((dispatch_wave_split<R, 2>(h, RA, CA, S.mode, S.epi)));
-    } else if (wave_ok && h->S == 4) {
-      TRY((dispatch_wave_split<R, 4>(h, RA, CA, S.mode, S.epi)));
-    } else
-    if (wave_ok) {
-      switch (h->P) {
-        case 2: dispatch_wave<R, 2, 2>(h, RA, CA, S.mode, S.epi); break;
-        case 3: dispatch_wave<R, 3, 2>(h, RA, CA, S.mode, S.epi); break;
-        case 4: TRY((dispatch_wave_ns<R, 4>(h, RA, CA, S.mode, S.epi))); break;
-        case 5: dispatch_wave<R, 5, 2>(h, RA, CA, S.mode, S.epi); break;
-        case 6: dispatch_wave<R, 6, 2>(h, RA, CA, S.mode, S.epi); break;
-        case 7: dispatch_wave<R, 7, 2>(h, RA, CA, S.mode, S.epi); break;
-        case 8: TRY((dispatch_wave_ns<R, 8>(h, RA, CA, S.mode, S.epi))); break;
-        case 9: TRY((dispatch_wave_ns<R, 9>(h, RA, CA, S.mode, S.epi))); break;
-        case 14: dispatch_wave<R, 14, 2>(h, RA, CA, S.mode, S.epi); break;
-        case 18: dispatch_wave<R, 18, 2>(h, RA, CA, S.mode, S.epi); break;
-        case 28: dispatch_wave<R, 28, 2>(h, RA, CA, S.mode, S.epi); break;
-        case 10: TRY((dispatch_wave_ns<R, 10>(h, RA, CA, S.mode, S.epi))); break;
-        case 12: TRY((dispatch_wave_ns<R, 12>(h, RA, CA, S.mode, S.epi))); break;
-        case 16: TRY((dispatch_wave_ns<R, 16>(h, RA, CA, S.mode, S.epi))); break;
-        case 20: TRY((dispatch_wave_ns<R, 20>(h, RA, CA, S.mode, S.epi))); break;
-        case 24: TRY((dispatch_wave_ns<R, 24>(h, RA, CA, S.mode, S.epi))); break;
-        default: return fail(FASTMC_ESTATE, "no wave instantiation for this grid size");
-      }
+    if (general_2048 || wave_ok) {
+      TRY(dispatch_wave_family<R>(h, RA, CA, S.mode, S.epi, general_2048));
     } else {
       TRY(dispatch_direct<R>(h, RA, CA, S.mode, S.epi));
     }
@@ -1119,6 +1211,7 @@ static int run_checked(fastmc_ctx* h, const RunSpec& S) {
 #endif
 }
 
+#if FMC_TU == 0
 extern "C" int fastmc_run(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real, const double* logamp,
                           double logamp_var, int coherent, double* out) {
   if (!out) return fail(FASTMC_EINVAL, "out is NULL");
@@ -1126,7 +1219,9 @@ extern "C" int fastmc_run(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_r
   RunSpec S{0, 0, seed, real0, n_real, nullptr, nullptr, nullptr, nullptr, logamp, logamp_var, coherent, out, nullptr};
   return run_checked(h, S);
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_run_coeffs(fastmc_t* h, const double* coeff_re, const double* coeff_im, int64_t n_real,
                                  const double* sh_re, const double* sh_im, const double* logamp, int coherent,
                                  double* out) {
@@ -1134,20 +1229,26 @@ extern "C" int fastmc_run_coeffs(fastmc_t* h, const double* coeff_re, const doub
   RunSpec S{1, 0, 0, 0, n_real, coeff_re, coeff_im, sh_re, sh_im, logamp, 0.0, coherent, out, nullptr};
   return run_checked(h, S);
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_screens_coeffs(fastmc_t* h, const double* coeff_re, const double* coeff_im, int64_t n_real,
                                      const double* sh_re, const double* sh_im, double* phs) {
   if (!coeff_re || !coeff_im || !phs) return fail(FASTMC_EINVAL, "null argument");
   RunSpec S{1, 1, 0, 0, n_real, coeff_re, coeff_im, sh_re, sh_im, nullptr, 0.0, 0, nullptr, phs};
   return run_checked(h, S);
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_screens(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real, double* phs) {
   if (!phs) return fail(FASTMC_EINVAL, "null argument");
   RunSpec S{0, 1, seed, real0, n_real, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, 0, nullptr, phs};
   return run_checked(h, S);
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_rng_coeffs(fastmc_t* h, uint64_t seed, int64_t real, double* out) {
   if (!h || !out) return fail(FASTMC_EINVAL, "null argument");
   HIPCHK(hipSetDevice(h->device));
@@ -1162,7 +1263,9 @@ extern "C" int fastmc_rng_coeffs(fastmc_t* h, uint64_t seed, int64_t real, doubl
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_rng_logamp(fastmc_t* h, uint64_t seed, int64_t iter0, int64_t n_iter, double* out) {
   if (!h || !out || n_iter <= 0) return fail(FASTMC_EINVAL, "bad argument");
   HIPCHK(hipSetDevice(h->device));
@@ -1177,7 +1280,9 @@ extern "C" int fastmc_rng_logamp(fastmc_t* h, uint64_t seed, int64_t iter0, int6
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_set_layer_screens(fastmc_t* h, const double* screens, int n_layers) {
   if (!h || !screens || n_layers < 1 || n_layers > 1024) return fail(FASTMC_EINVAL, "bad argument");
   HIPCHK(hipSetDevice(h->device));
@@ -1188,7 +1293,9 @@ extern "C" int fastmc_set_layer_screens(fastmc_t* h, const double* screens, int 
   h->n_layers = n_layers;
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_temporal_chunk(fastmc_t* h, const double* xs, const double* ys, const int32_t* roll, int M,
                                      const double* logamp, int coherent, double* out) {
   if (!h || !xs || !ys || !roll || !logamp || !out || M < 1) return fail(FASTMC_EINVAL, "bad argument");
@@ -1218,6 +1325,7 @@ extern "C" int fastmc_temporal_chunk(fastmc_t* h, const double* xs, const double
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
+#endif
 
 static int histogram_device(fastmc_ctx* h, double lo, double hi, int nbins) {
   if (h->last_n_iter <= 0) return fail(FASTMC_ESTATE, "no run results on the device");
@@ -1234,6 +1342,7 @@ static int histogram_device(fastmc_ctx* h, double lo, double hi, int nbins) {
   return 0;
 }
 
+#if FMC_TU == 0
 extern "C" int fastmc_set_results(fastmc_t* h, const double* values, int64_t n_iter, int coherent) {
   if (!h || !values || n_iter < 1) return fail(FASTMC_EINVAL, "bad argument");
   HIPCHK(hipSetDevice(h->device));
@@ -1245,7 +1354,9 @@ extern "C" int fastmc_set_results(fastmc_t* h, const double* values, int64_t n_i
   h->last_coherent = coherent ? 1 : 0;
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_histogram(fastmc_t* h, double lo_db, double hi_db, int nbins, int64_t* bins) {
   if (!h || !bins) return fail(FASTMC_EINVAL, "null argument");
   HIPCHK(hipSetDevice(h->device));
@@ -1254,7 +1365,9 @@ extern "C" int fastmc_histogram(fastmc_t* h, double lo_db, double hi_db, int nbi
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_result_stats(fastmc_t* h, const double* thresholds, int n_thr, double* stats) {
   if (!h || !stats || n_thr < 0 || n_thr > STATS_MAX_THR || (n_thr > 0 && !thresholds)) return fail(FASTMC_EINVAL, "bad argument");
   if (h->last_n_iter <= 0) return fail(FASTMC_ESTATE, "no run results on the device");
@@ -1274,7 +1387,9 @@ extern "C" int fastmc_result_stats(fastmc_t* h, const double* thresholds, int n_
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_link_metrics(fastmc_t* h, int device_id, const double* samples, int64_t n, const fastmc_link_query* queries,
                                    int n_queries, double* out) {
   if (!queries || !out || n_queries < 1) return fail(FASTMC_EINVAL, "bad argument");
@@ -1324,12 +1439,15 @@ extern "C" int fastmc_link_metrics(fastmc_t* h, int device_id, const double* sam
   HIPCHK(hipStreamSynchronize(stream));
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches) {
   if (!h || !times_ms || !launches) return fail(FASTMC_EINVAL, "null argument");
   for (int i = 0; i < 4; ++i) { times_ms[i] = h->t_ms[i]; launches[i] = h->t_n[i]; }
   return 0;
 }
+#endif
 
 // ------------------------------------------------------------------ power spectrum
 static void noll_to_nm(int j, int* n_out, int* m_out) {   // aotools zernIndex (third party; see hostmath.noll_to_nm)
@@ -1488,24 +1606,31 @@ static int powerspec_impl(int device_id, const fastmc_ps_params* p, double* powe
   return 0;
 }
 
+#if FMC_TU == 0
 extern "C" int fastmc_powerspec(int device_id, const fastmc_ps_params* p, double* powerspec, double* per_layer,
                                 double* logamp_ps, double* lf_mask_out, double* scalars, double* kernel_ms) {
   return powerspec_impl(device_id, p, powerspec, per_layer, logamp_ps, lf_mask_out, scalars, kernel_ms, nullptr, nullptr, nullptr,
                         nullptr);
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_powerspec_terms(int device_id, const fastmc_ps_params* p, double* turb, double* g_ao, double* alias_ps,
                                       double* noise_ps) {
   if (!turb && !g_ao && !alias_ps && !noise_ps) return fail(FASTMC_EINVAL, "no output requested");
   return powerspec_impl(device_id, p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, turb, g_ao, alias_ps, noise_ps);
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_powerspec_set(fastmc_t* h, const fastmc_ps_params* p, double df, double* scalars, double* kernel_ms) {
   if (!h || !p) return fail(FASTMC_EINVAL, "null argument");
   if (p->N != h->N) return fail(FASTMC_EINVAL, "params.N differs from the handle's grid");
   return powerspec_impl(h->device, p, nullptr, nullptr, nullptr, nullptr, scalars, kernel_ms, nullptr, nullptr, nullptr, nullptr, h, df);
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_powerspec_get(fastmc_t* h, int which, double* out) {
   if (!h || !out || which < 0 || which > 2) return fail(FASTMC_EINVAL, "bad argument");
   if (!h->ps_dev || !h->have_ps) return fail(FASTMC_ESTATE, "fastmc_powerspec_set has not been called on this handle");
@@ -1515,6 +1640,7 @@ extern "C" int fastmc_powerspec_get(fastmc_t* h, int which, double* out) {
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
+#endif
 
 // ------------------------------------------------------------------ RCCL (loaded on demand)
 // One communicator per DEVICE of this process, shared by every handle on that device: sweeps build many
@@ -1570,6 +1696,7 @@ static DeviceComm device_comm(int device) {
   return g_comm[device & 63];
 }
 
+#if FMC_TU == 0
 extern "C" int fastmc_comm_unique_id(uint8_t id128[128]) {
   if (!id128) return fail(FASTMC_EINVAL, "null id");
   TRY(load_rccl());
@@ -1579,7 +1706,9 @@ extern "C" int fastmc_comm_unique_id(uint8_t id128[128]) {
   memcpy(id128, &id, 128);
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_comm_init(fastmc_t* h, const uint8_t id128[128], int world_size, int rank) {
   if (!h || !id128 || world_size < 1 || rank < 0 || rank >= world_size) return fail(FASTMC_EINVAL, "bad argument");
   TRY(load_rccl());
@@ -1593,7 +1722,9 @@ extern "C" int fastmc_comm_init(fastmc_t* h, const uint8_t id128[128], int world
   g_comm[h->device & 63] = DeviceComm{c, world_size, rank};
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_comm_init_all(fastmc_t* const* handles, int n) {
   if (!handles || n < 1 || n > 64) return fail(FASTMC_EINVAL, "bad argument");
   std::vector<int> devs(n);
@@ -1611,7 +1742,9 @@ extern "C" int fastmc_comm_init_all(fastmc_t* const* handles, int n) {
   for (int i = 0; i < n; ++i) g_comm[devs[i] & 63] = DeviceComm{comms[i], n, i};
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_comm_world(fastmc_t* h, int* world_size, int* rank) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   const DeviceComm dc = device_comm(h->device);
@@ -1619,6 +1752,7 @@ extern "C" int fastmc_comm_world(fastmc_t* h, int* world_size, int* rank) {
   if (rank) *rank = dc.comm ? dc.rank : -1;
   return 0;
 }
+#endif
 
 // Enqueue this handle's part of the exchange on its stream (inside an RCCL group when several handles of one
 // process take part); the host copies follow on the same stream.
@@ -1633,6 +1767,7 @@ static int comm_enqueue_hist(fastmc_ctx* h, const DeviceComm& dc, int nbins) {
   return 0;
 }
 
+#if FMC_TU == 0
 extern "C" int fastmc_comm_gather(fastmc_t* h, int64_t n_local, double* all_powers, int64_t* hist, double lo_db,
                                   double hi_db, int nbins) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
@@ -1653,7 +1788,9 @@ extern "C" int fastmc_comm_gather(fastmc_t* h, int64_t n_local, double* all_powe
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n_local, double* all_powers, int64_t* hist,
                                       double lo_db, double hi_db, int nbins) {
   if (!handles || n < 1 || n > 64) return fail(FASTMC_EINVAL, "bad argument");
@@ -1701,7 +1838,9 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
   }
   return 0;
 }
+#endif
 
+#if FMC_TU == 0
 extern "C" int fastmc_comm_destroy(fastmc_t* h) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   ncclComm_t c = nullptr;
@@ -1716,3 +1855,5 @@ extern "C" int fastmc_comm_destroy(fastmc_t* h) {
   }
   return 0;
 }
+#endif
+#endif   // FMC_TU == 0

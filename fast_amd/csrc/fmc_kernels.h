@@ -11,6 +11,9 @@
 // and "direct" (any N <= 4096).
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef FMC_TU
+#define FMC_TU 0      // translation unit of the split build (fastmc.hip): the kernels that are not templates live in unit 0 only
+#endif
 #include "fmc_core.h"
 #include "fmc_wavefft.h"
 #include "fmc_bluestein.h"
@@ -1141,6 +1144,7 @@ __global__ void k_make_amp(const double* ps, double df, int N, R* amp, R* amp_s,
   ampf_s[i] = ((ky + kx) & 1) ? -vk : vk;
 }
 
+#if FMC_TU == 0   // non-template kernels: one definition in the library
 // ================================================================== sub-harmonic coefficients
 // coef[b][m] = rand_lo[b][m] * sqrt(ps_lo[m]) * df_lo[level(m)]  (fast/fast.py:600-601, funcs.py:243)
 // mean[b]    = sum_m coef[b][m] * mu[m],  mu[m] = grid mean of mode m (funcs.py:253)
@@ -1458,5 +1462,7 @@ __global__ void k_rng_logamp(RngKey key, uint64_t it0, int64_t n, double* out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (double)draw_logamp_normal(key, it0 + (uint64_t)i);
 }
+
+#endif   // FMC_TU == 0
 
 }  // namespace fmc

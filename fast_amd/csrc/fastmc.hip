@@ -25,10 +25,10 @@
 using namespace fmc;
 
 // Translation units.  Alone (FMC_TU undefined) this file is the whole library.  With -DFMC_SPLIT_BUILD the Makefile compiles
-// it five times in parallel and links the objects: unit 0 holds the C-ABI, every host function and the small kernels;
+// it nine times in parallel and links the objects: unit 0 holds the C-ABI, every host function and the small kernels;
 // the kernel families that run_impl launches are explicit instantiations of their dispatch templates in units
-//   1: wave family, float64     2: wave family, float32
-//   3: chirp-z, 50-lane, run-time-split and direct families, float64     4: the same, float32
+//   1 / 2: wave family, float64 / float32            3 / 4: chirp-z family
+//   5 / 6: 50-lane and run-time-split families       7 / 8: direct family
 // (a fresh build takes the time of the slowest unit instead of the sum).
 #ifndef FMC_TU
 #define FMC_TU 0
@@ -989,31 +989,45 @@ extern template int dispatch_wave_family<float>(FMC_WAVE_SIG(float));
 #endif
 #if FMC_TU != 3
 extern template int dispatch_blu<double>(FMC_FAMILY_SIG(double));
-extern template int dispatch_mr<double>(FMC_FAMILY_SIG(double));
-extern template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
-extern template int dispatch_direct<double>(FMC_FAMILY_SIG(double));
 #endif
 #if FMC_TU != 4
 extern template int dispatch_blu<float>(FMC_FAMILY_SIG(float));
+#endif
+#if FMC_TU != 5
+extern template int dispatch_mr<double>(FMC_FAMILY_SIG(double));
+extern template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
+#endif
+#if FMC_TU != 6
 extern template int dispatch_mr<float>(FMC_FAMILY_SIG(float));
 extern template int dispatch_ws<float>(FMC_FAMILY_SIG(float));
+#endif
+#if FMC_TU != 7
+extern template int dispatch_direct<double>(FMC_FAMILY_SIG(double));
+#endif
+#if FMC_TU != 8
 extern template int dispatch_direct<float>(FMC_FAMILY_SIG(float));
 #endif
 #endif
 #if FMC_TU == 1
 template int dispatch_wave_family<double>(FMC_WAVE_SIG(double));
-#elif FMC_TU == 2 && !defined(FMC_ONLY_F64)
-template int dispatch_wave_family<float>(FMC_WAVE_SIG(float));
 #elif FMC_TU == 3
 template int dispatch_blu<double>(FMC_FAMILY_SIG(double));
+#elif FMC_TU == 5
 template int dispatch_mr<double>(FMC_FAMILY_SIG(double));
 template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
+#elif FMC_TU == 7
 template int dispatch_direct<double>(FMC_FAMILY_SIG(double));
-#elif FMC_TU == 4 && !defined(FMC_ONLY_F64)
+#elif !defined(FMC_ONLY_F64)
+#if FMC_TU == 2
+template int dispatch_wave_family<float>(FMC_WAVE_SIG(float));
+#elif FMC_TU == 4
 template int dispatch_blu<float>(FMC_FAMILY_SIG(float));
+#elif FMC_TU == 6
 template int dispatch_mr<float>(FMC_FAMILY_SIG(float));
 template int dispatch_ws<float>(FMC_FAMILY_SIG(float));
+#elif FMC_TU == 8
 template int dispatch_direct<float>(FMC_FAMILY_SIG(float));
+#endif
 #endif
 
 #if FMC_TU == 0   // everything below: the run loop, the remaining entry points and the small kernels' launches

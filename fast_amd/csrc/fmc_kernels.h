@@ -362,11 +362,15 @@ template <class R, int P, int NS> struct WaveCfg {
                               (P == 32 ? (sizeof(R) == 8 ? FMC_WPB_P32_F64 : 6) : ((P > 16 && P / (P & -P) >= 7) ? 4 : (P > 24 ? 6 : ((P > 16 || (!is_pow2(P) && P > 8)) ? 8 : FMC_WPB))));
 };
 
+// D = 2: D = 1 without the two exchange-2 planes a centred window never reads (D16_CENTRE_MASK), the default when the window fits.
 // D = 1: the dense-image variant of the P = 16, NS = 2 row / column (pruned_row_fft_d16): sixteen waves per workgroup
 // = four per SIMD, 128 VGPRs.  Its exchange buffers (8448 B per wave) and the tables fit the 160 KB of a CU for windows
 // of up to 96 pixels (wave_lds_bytes_d); wider windows keep the twelve-wave kernels.
 #ifndef FMC_DENSE16
 #define FMC_DENSE16 1
+#endif
+#ifndef FMC_D16_PRUNE
+#define FMC_D16_PRUNE 1
 #endif
 template <class R, int P, int NS, int D> struct WCfg {
   static_assert(D == 0 || (P == 16 && NS == 2), "dense images exist for P = 16, NS = 2");
@@ -505,7 +509,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 #pragma unroll
     for (int j = 0; j < P; ++j) { regs.xr[j % NS] += regs.v[j].x; regs.xi[j % NS] += regs.v[j].y; }
 #else
-    if constexpr (D) pruned_row_fft_d16<R, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    if constexpr (D) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     else pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, b0mask);
 #endif
     if (S > 1) {
@@ -572,7 +576,7 @@ void k_cols_wave(ColArgs<R> A) {
   if (S == 1) {
 #pragma unroll
     for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
-    if constexpr (D) pruned_row_fft_d16<R, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    if constexpr (D) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     else pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
   } else {
     R accr[NS], acci[NS];

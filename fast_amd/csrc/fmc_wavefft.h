@@ -303,7 +303,12 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
 #endif                   // per row): rows 10.44 -> 10.46 ms per 5000 realisations -- the LDS time goes with the bytes, not the instructions
 constexpr int D16_SE = 66;
 constexpr int D16_XELEMS = 16 * D16_SE;
-template <class R, int NS, class Exec>
+// B0M: the residues b0 = (x / 16) mod 8 of the output blocks that the window may touch (window_b0_mask).  Planes outside it are
+// never read by stage 2b, so they are neither stored nor -- the mask being a compile-time constant -- computed: the
+// radix-8 butterflies lose the adds that only feed them.  0xE7 = {5, 6, 7, 0, 1, 2} holds every centred window of up to
+// 81 + (lo mod 16 alignment) pixels at N = 1024, e.g. the 82-pixel window of the BASELINE geometry (b = 29 ... 34).
+constexpr int D16_CENTRE_MASK = 0xE7;
+template <class R, int NS, int B0M = 0xFF, class Exec>
 FMC_HD void pruned_row_fft_d16(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
                                int omS, int lo, int Np) {
   constexpr int P = 16;
@@ -378,7 +383,8 @@ FMC_HD void pruned_row_fft_d16(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>*
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int b0 = 0; b0 < 8; ++b0) ex.st(xbuf + a + 16 * b0 + 128 * (lp + 4 * q), X::pack(r.v[q * 8 + b0], c));
+        for (int b0 = 0; b0 < 8; ++b0)
+          if ((B0M >> b0) & 1) ex.st(xbuf + a + 16 * b0 + 128 * (lp + 4 * q), X::pack(r.v[q * 8 + b0], c));
     });
     ex.sync();
     ex.each([&](int lane, LaneRegs<R, P, NS>& r) {

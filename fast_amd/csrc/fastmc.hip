@@ -764,6 +764,13 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
       return;
     }
   }
+  if constexpr (P == 16 && NS == 2) {
+    if (FMC_D16_PRUNE && mode == 0 && epi == 0 && (window_b0_mask(h->lo, h->Np, 16) & ~D16_CENTRE_MASK) == 0) {
+      { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, S, 3>(h, RA); }
+      { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, S, 3>(h, CA); }
+      return;
+    }
+  }
   {
     Span s(h, 0);
     if (mode == 0) launch_rows_wave<R, P, NS, 0, S>(h, RA);

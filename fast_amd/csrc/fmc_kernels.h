@@ -363,6 +363,8 @@ template <class R, int P, int NS> struct WaveCfg {
 };
 
 // D = 2: D = 1 without the two exchange-2 planes a centred window never reads (D16_CENTRE_MASK), the default when the window fits.
+// D = 3: the twelve-wave kernels (D = 0) without those two planes: P = 16, NS = 2 where the dense images do not apply (split rows of
+//        2048 / 4096, windows of 97-128 pixels).
 // D = 1: the dense-image variant of the P = 16, NS = 2 row / column (pruned_row_fft_d16): sixteen waves per workgroup
 // = four per SIMD, 128 VGPRs.  Its exchange buffers (8448 B per wave) and the tables fit the 160 KB of a CU for windows
 // of up to 96 pixels (wave_lds_bytes_d); wider windows keep the twelve-wave kernels.
@@ -374,8 +376,9 @@ template <class R, int P, int NS> struct WaveCfg {
 #endif
 template <class R, int P, int NS, int D> struct WCfg {
   static_assert(D == 0 || (P == 16 && NS == 2), "dense images exist for P = 16, NS = 2");
-  static constexpr int WPB = D ? 16 : WaveCfg<R, P, NS>::WPB;
-  static constexpr int XELEMS = D ? D16_XELEMS : WaveGeom<R, P>::XELEMS;
+  static constexpr bool DENSE = (D == 1 || D == 2);
+  static constexpr int WPB = DENSE ? 16 : WaveCfg<R, P, NS>::WPB;
+  static constexpr int XELEMS = DENSE ? D16_XELEMS : WaveGeom<R, P>::XELEMS;
 };
 
 template <class R, int P>
@@ -509,8 +512,8 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 #pragma unroll
     for (int j = 0; j < P; ++j) { regs.xr[j % NS] += regs.v[j].x; regs.xi[j % NS] += regs.v[j].y; }
 #else
-    if constexpr (D) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
-    else pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, b0mask);
+    if constexpr (D == 1 || D == 2) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    else pruned_row_fft<R, P, NS, (D == 3 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, b0mask);
 #endif
     if (S > 1) {
 #pragma unroll
@@ -576,8 +579,8 @@ void k_cols_wave(ColArgs<R> A) {
   if (S == 1) {
 #pragma unroll
     for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
-    if constexpr (D) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
-    else pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    if constexpr (D == 1 || D == 2) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    else pruned_row_fft<R, P, NS, (D == 3 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
   } else {
     R accr[NS], acci[NS];
 #pragma unroll
@@ -586,7 +589,7 @@ void k_cols_wave(ColArgs<R> A) {
     for (int sp = 0; sp < S; ++sp) {
 #pragma unroll
       for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (lane + WAVE * j)];
-      pruned_row_fft<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+      pruned_row_fft<R, P, NS, (D == 3 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) {
         const int oi = lane + WAVE * s2;

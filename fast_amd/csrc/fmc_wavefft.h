@@ -140,7 +140,7 @@ FMC_HD int window_b0_mask(int lo, int Np, int P) {
 #ifndef FMC_B0MASK
 #define FMC_B0MASK 0   // measured: no gain (10.69 vs 10.66 ms per 5000 realisations): the conditional stores lose the write2 pairing
 #endif
-template <class R, int P, int NS, class Exec>
+template <class R, int P, int NS, int B0M = 0xFF, class Exec>
 FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
                            int omS, int lo, int Np, int b0mask = 0xFF, int osign = 0) {
   using G = WaveGeom<R, P>;
@@ -242,7 +242,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
         if ((P % 8 == 0) || i + 8 * jj < P) {
 #pragma unroll
           for (int b0 = 0; b0 < 8; ++b0)
-            if (!FMC_B0MASK || ((b0mask >> b0) & 1))       // wave-uniform: planes no window output reads are not stored
+            if (((B0M >> b0) & 1) && (!FMC_B0MASK || ((b0mask >> b0) & 1)))   // planes no window output reads are not stored (B0M: compile time)
               ex.st(xbuf + (i + 8 * jj) + G::FL * l0 + G::FB * b0, X::pack(r.v[jj * 8 + b0], c));
         }
     });

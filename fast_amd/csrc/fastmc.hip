@@ -764,10 +764,10 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
       return;
     }
   }
-  if constexpr (P == 16 && NS == 2) {
-    if (FMC_D16_PRUNE && mode == 0 && epi == 0 && (window_b0_mask(h->lo, h->Np, 16) & ~D16_CENTRE_MASK) == 0) {
-      { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, S, 3>(h, RA); }
-      { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, S, 3>(h, CA); }
+  if constexpr (NS == 2 && P >= 16 && prune_pays(P, 8, 0)) {
+    if (FMC_D16_PRUNE && mode == 0 && epi == 0 && (window_planes(h->lo, h->Np, P, 8) & ~centre_planes(P, 8, 0)) == 0) {
+      { Span s(h, 0); launch_rows_wave<R, P, 2, 0, S, 3>(h, RA); }
+      { Span s(h, 1); launch_cols_wave<R, P, 2, 0, S, 3>(h, CA); }
       return;
     }
   }
@@ -821,8 +821,8 @@ int dispatch_blu(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int 
   return fail(FASTMC_ESTATE, "no chirp-z instantiation for this grid / window");
 }
 
-template <class R, int P, int NS, bool SPLIT, int LN = MR_LN>
-static void dispatch_mr_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+template <class R, int P, int NS, bool SPLIT, int LN, int PR>
+static void launch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   constexpr int WPB = MrCfg<R, P, NS, LN>::WPB;
   const size_t lds = mr_lds_bytes<R, P, NS, LN>(RA.omS);
   constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
@@ -830,24 +830,44 @@ static void dispatch_mr_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>
   {
     Span s(h, 0);
     if (mode == 0) {
-      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 0, SPLIT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 0, SPLIT, LN>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
-    } else {
-      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 1, SPLIT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 1, SPLIT, LN>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 0, SPLIT, LN, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 0, SPLIT, LN, PR>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+    } else if constexpr (PR == 0) {
+      hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 1, SPLIT, LN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 1, SPLIT, LN, 0>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
     }
   }
   {
     Span s(h, 1);
     const int items = CA.nb * CA.Np;
     if (epi == 0) {
-      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 0, SPLIT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 0, SPLIT, LN>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
-    } else {
-      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 1, SPLIT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 1, SPLIT, LN>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 0, SPLIT, LN, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 0, SPLIT, LN, PR>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+    } else if constexpr (PR == 0) {
+      hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 1, SPLIT, LN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_cols_mr<R, P, NS, 1, SPLIT, LN, 0>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
     }
   }
+}
+
+// Pruned-plane variants (device generator + detector, NS = 2, window inside the centred 96-pixel plane set): centre block of
+// residue 0 for 64 P S and for 50 P S with S even, 5 for 50 P S with S odd.
+template <class R, int P, int NS, bool SPLIT, int LN = MR_LN>
+static void dispatch_mr_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  constexpr int L1 = LN == MR_LN ? 10 : 8;
+  if constexpr (NS == 2 && P >= 16) {
+    if (FMC_D16_PRUNE && mode == 0 && epi == 0) {
+      const int S = RA.N / (LN * P);
+      const int win = window_planes(h->lo, h->Np, P, L1);
+      if constexpr (LN == MR_LN && prune_pays(P, 10, 5)) {
+        if ((S & 1) && (win & ~centre_planes(P, 10, 5)) == 0) { launch_mr<R, P, NS, SPLIT, LN, 1>(h, RA, CA, mode, epi); return; }
+      }
+      if constexpr (SPLIT && prune_pays(P, L1, 0)) {
+        if ((LN != MR_LN || !(S & 1)) && (win & ~centre_planes(P, L1, 0)) == 0) { launch_mr<R, P, NS, SPLIT, LN, 2>(h, RA, CA, mode, epi); return; }
+      }
+    }
+  }
+  launch_mr<R, P, NS, SPLIT, LN, 0>(h, RA, CA, mode, epi);
 }
 
 // P of the split grids (mr_split: the smallest S that leaves 7 <= P <= 24)

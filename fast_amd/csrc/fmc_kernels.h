@@ -363,8 +363,8 @@ template <class R, int P, int NS> struct WaveCfg {
 };
 
 // D = 2: D = 1 without the two exchange-2 planes a centred window never reads (D16_CENTRE_MASK), the default when the window fits.
-// D = 3: the twelve-wave kernels (D = 0) without those two planes: P = 16, NS = 2 where the dense images do not apply (split rows of
-//        2048 / 4096, windows of 97-128 pixels).
+// D = 3: the kernels of D = 0 without the planes a centred window of up to 96 pixels never reads (centre_planes(P, 8, 0)): P = 16 where
+//        the dense images do not apply (split rows of 2048 / 4096) and P = 18, 20, 24, 28 (two to four of the eight planes).
 // D = 1: the dense-image variant of the P = 16, NS = 2 row / column (pruned_row_fft_d16): sixteen waves per workgroup
 // = four per SIMD, 128 VGPRs.  Its exchange buffers (8448 B per wave) and the tables fit the 160 KB of a CU for windows
 // of up to 96 pixels (wave_lds_bytes_d); wider windows keep the twelve-wave kernels.
@@ -375,7 +375,7 @@ template <class R, int P, int NS> struct WaveCfg {
 #define FMC_D16_PRUNE 1
 #endif
 template <class R, int P, int NS, int D> struct WCfg {
-  static_assert(D == 0 || (P == 16 && NS == 2), "dense images exist for P = 16, NS = 2");
+  static_assert(D == 0 || (D == 3 && NS == 2) || (P == 16 && NS == 2), "dense images exist for P = 16, NS = 2; pruned planes for NS = 2");
   static constexpr bool DENSE = (D == 1 || D == 2);
   static constexpr int WPB = DENSE ? 16 : WaveCfg<R, P, NS>::WPB;
   static constexpr int XELEMS = DENSE ? D16_XELEMS : WaveGeom<R, P>::XELEMS;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
     for (int j = 0; j < P; ++j) { regs.xr[j % NS] += regs.v[j].x; regs.xi[j % NS] += regs.v[j].y; }
 #else
     if constexpr (D == 1 || D == 2) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
-    else pruned_row_fft<R, P, NS, (D == 3 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, b0mask);
+    else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, b0mask);
 #endif
     if (S > 1) {
 #pragma unroll
@@ -580,7 +580,7 @@ void k_cols_wave(ColArgs<R> A) {
 #pragma unroll
     for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
     if constexpr (D == 1 || D == 2) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
-    else pruned_row_fft<R, P, NS, (D == 3 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
   } else {
     R accr[NS], acci[NS];
 #pragma unroll
@@ -589,7 +589,7 @@ void k_cols_wave(ColArgs<R> A) {
     for (int sp = 0; sp < S; ++sp) {
 #pragma unroll
       for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (lane + WAVE * j)];
-      pruned_row_fft<R, P, NS, (D == 3 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+      pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) {
         const int oi = lane + WAVE * s2;
@@ -804,20 +804,22 @@ template <class R, int P> struct LaneFam<R, P, MR_LN> {
   using G = MrGeom<R, P>;
   static constexpr int L0 = G::L0, XELEMS = G::XELEMS, N = G::N;
   static __device__ __forceinline__ int osign(int n_full) { return mr_osign(n_full); }
-  template <int NS, class Exec>
+  static constexpr int L1 = G::L1;
+  template <int NS, int PR, class Exec>
   static __device__ __forceinline__ void fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw, const cpx<R>* om, int omS, int lo,
                                              int Np, int os) {
-    pruned_row_fft_mr<R, P, NS>(ex, xbuf, tw, om, omS, lo, Np, os);
+    pruned_row_fft_mr<R, P, NS, (PR ? centre_planes(P, 10, PR == 1 ? 5 : 0) : 0x3FF)>(ex, xbuf, tw, om, omS, lo, Np, os);
   }
 };
 template <class R, int P> struct LaneFam<R, P, WAVE> {
   using G = WaveGeom<R, P>;
   static constexpr int L0 = 8, XELEMS = G::XELEMS, N = G::N;
   static __device__ __forceinline__ int osign(int) { return 0; }      // 64 P S is a multiple of 4
-  template <int NS, class Exec>
+  static constexpr int L1 = 8;
+  template <int NS, int PR, class Exec>
   static __device__ __forceinline__ void fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw, const cpx<R>* om, int omS, int lo,
                                              int Np, int os) {
-    pruned_row_fft<R, P, NS>(ex, xbuf, tw, om, omS, lo, Np, 0xFF, os);
+    pruned_row_fft<R, P, NS, (PR ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, tw, om, omS, lo, Np, 0xFF, os);
   }
 };
 template <class R, int P, int NS, int LN = MR_LN> struct MrCfg {
@@ -837,7 +839,9 @@ __device__ __forceinline__ void load_tables_mr(cpx<R>* s_tw, cpx<R>* s_om, const
 
 // SPLIT: the row of N = S * 50 P points as S interleaved sub-rows (kx = s mod S, S = N / 50 P at run time, <= 5), window
 // outputs combined by decimation in time, X[x] = sum_s w_N^{s x} Y_s[x mod 50 P] (cw), as the wave family does for 2048 / 4096.
-template <class R, int P, int NS, int MODE, bool SPLIT = false, int LN = MR_LN>
+// PR: planes of the exchange-2 image the kernel keeps: 0 all; 1 / 2 those of a centred window of up to 96 pixels whose centre
+// block has residue 5 / 0 (50 P S with S odd / S even, and every 64 P S grid): the others are neither stored nor computed.
+template <class R, int P, int NS, int MODE, bool SPLIT = false, int LN = MR_LN, int PR = 0>
 __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_rows_mr(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = LaneFam<R, P, LN>;
@@ -887,7 +891,7 @@ __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_rows_mr(Row
           regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
         }
       }
-      G::template fft<NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, G::osign(N));
+      G::template fft<NS, PR>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, G::osign(N));
       if (SPLIT) {
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {
@@ -913,7 +917,7 @@ __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_rows_mr(Row
   }
 }
 
-template <class R, int P, int NS, int EPI, bool SPLIT = false, int LN = MR_LN>
+template <class R, int P, int NS, int EPI, bool SPLIT = false, int LN = MR_LN, int PR = 0>
 __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_cols_mr(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = LaneFam<R, P, LN>;
@@ -938,7 +942,7 @@ __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_cols_mr(Col
   if (!SPLIT) {
 #pragma unroll
     for (int j = 0; j < P; ++j) regs.v[j] = col[li + LN * j];
-    G::template fft<NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, G::osign(N));
+    G::template fft<NS, PR>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, G::osign(N));
   } else {
     R accr[NS], acci[NS];
 #pragma unroll
@@ -947,7 +951,7 @@ __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_cols_mr(Col
     for (int sp = 0; sp < S; ++sp) {
 #pragma unroll
       for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (li + LN * j)];
-      G::template fft<NS>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, G::osign(N));
+      G::template fft<NS, PR>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, G::osign(N));
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) {
         const int oi = lane + WAVE * s2;

@@ -41,7 +41,7 @@ struct MrGeom {
 // Tables:  tw1[a*64 + l] = w_N^{l a} (l < LN; the other lanes idle),  om[m*omS + oi] = w_LN^{m b(oi)}, m < L0 (row 0 never
 // read), b(oi) = ((lo + oi) / P) mod 50.  The finished sums take the sign (-1)^(lo+oi+osign) by a sign-bit xor: the
 // output-side fftshift (N even) times w_N^{-(N/2)^2} = -1 when the FULL row length is 2 (mod 4) (osign = mr_osign(N)).
-template <class R, int P, int NS, class Exec>
+template <class R, int P, int NS, int B0M = 0x3FF, class Exec>
 FMC_HD void pruned_row_fft_mr(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om, int omS, int lo, int Np,
                               int osign = 0) {
   using G = MrGeom<R, P>;
@@ -104,7 +104,8 @@ FMC_HD void pruned_row_fft_mr(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* 
         const int q = lane + WAVE * jj;
         if (q < G::NBF) {
 #pragma unroll
-          for (int b0 = 0; b0 < L1; ++b0) ex.st(xbuf + q + G::NBF * b0, X::pack(r.v[jj * L1 + b0], c));
+          for (int b0 = 0; b0 < L1; ++b0)
+            if ((B0M >> b0) & 1) ex.st(xbuf + q + G::NBF * b0, X::pack(r.v[jj * L1 + b0], c));   // planes no output reads: neither stored nor computed
         }
       }
     });

@@ -129,6 +129,26 @@ struct LaneRegs {
 // (`osign` 0; 1: the opposite sign; -1: none -- the second transform of the chirp-z row).
 // Which residues b0 = b mod 8 of the output blocks b = x / P the window [lo, lo + Np) touches: stage 2b reads only
 // those planes of the exchange-2 image, so the others need not be stored (a window of 82 at P = 16 touches 6 of 8).
+// General form: residues modulo L1 (8: wave pipeline; 10: 50-lane pipeline) of the output blocks b = x / P, x in [lo, lo + Np).
+FMC_HD int window_planes(int lo, int Np, int P, int L1) {
+  const int b_lo = lo / P, b_hi = (lo + Np - 1) / P;
+  if (b_hi - b_lo >= L1 - 1) return (1 << L1) - 1;
+  int m = 0;
+  for (int b = b_lo; b <= b_hi; ++b) m |= 1 << (b % L1);
+  return m;
+}
+// The planes a window of up to W pixels touches when it is centred on the start of a block of residue c (compile-time
+// plane sets of the pruned kernels: centred pupil windows sit at N / 2, residue 0 for 64 P S and 50 P S with S even, 5 for
+// 50 P S with S odd).
+FMC_HD constexpr int centre_planes(int P, int L1, int c, int W = 96) {
+  int m = 0;
+  const int period = P * L1;
+  for (int t = -W / 2; t < W - W / 2; ++t) {
+    const int x = ((c * P + t) % period + period) % period;
+    m |= 1 << (x / P);
+  }
+  return m;
+}
 FMC_HD int window_b0_mask(int lo, int Np, int P) {
   const int b_lo = lo / P, b_hi = (lo + Np - 1) / P;
   if (b_hi - b_lo >= 7) return 0xFF;
@@ -308,6 +328,9 @@ constexpr int D16_XELEMS = 16 * D16_SE;
 // radix-8 butterflies lose the adds that only feed them.  0xE7 = {5, 6, 7, 0, 1, 2} holds every centred window of up to
 // 81 + (lo mod 16 alignment) pixels at N = 1024, e.g. the 82-pixel window of the BASELINE geometry (b = 29 ... 34).
 constexpr int D16_CENTRE_MASK = 0xE7;
+static_assert(centre_planes(16, 8, 0) == D16_CENTRE_MASK, "centred 96-pixel window at P = 16");
+// P of the wave pipeline whose centred 96-pixel window leaves planes unread (P <= 14: all eight are touched)
+FMC_HD constexpr bool prune_pays(int P, int L1, int c) { return centre_planes(P, L1, c) != (1 << L1) - 1; }
 template <class R, int NS, int B0M = 0xFF, class Exec>
 FMC_HD void pruned_row_fft_d16(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
                                int omS, int lo, int Np) {

@@ -31,7 +31,7 @@ FAST_SIZE_RATE = {
     1024: 840, 1152: 460, 1280: 360, 1536: 320, 1792: 140, 2048: 220, 4096: 48,
     1344: 318, 1728: 174, 1920: 159, 2304: 86, 2560: 75, 3072: 85, 3584: 43, 3840: 35,
     100: 8060, 150: 6150, 200: 4850, 250: 3900, 300: 3170, 350: 2545, 400: 2490, 450: 1930, 500: 1930, 600: 1490, 700: 830,
-    800: 780, 900: 590, 1000: 540, 1200: 410, 1400: 227, 1500: 249, 1600: 198, 2000: 124, 2500: 91, 3000: 57, 4000: 32,
+    800: 820, 900: 590, 1000: 580, 1200: 455, 1400: 227, 1500: 249, 1600: 198, 2000: 124, 2500: 91, 3000: 57, 4000: 32,
 }
 ROUND_UP_SIZES = sorted(FAST_SIZE_RATE)
 

@@ -104,8 +104,12 @@ if len(sys.argv) > 2:
                                   ("lds_issue_busy", "pmc_sq2", "SQ_ACTIVE_INST_LDS")):
             v = _avg(sub, counter, "k_rows_wave")
             if v:
-                doc[key] = v * 4 / simd_cycles   # SQ_ACTIVE_INST_* count quad-cycles
-        doc["busy_note"] = "k_rows_wave: SQ_ACTIVE_INST_* x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)"
+                raw = v * 4 / simd_cycles        # SQ_ACTIVE_INST_* count quad-cycles
+                doc[key] = min(raw, 1.0)         # a fraction of the SIMD cycles; the counter ratio itself is kept beside it
+                doc[key + "_counter_ratio"] = raw
+        doc["busy_note"] = ("k_rows_wave: SQ_ACTIVE_INST_* x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); the two counters come from the same "
+                            "pass, the denominator assumes every SIMD clocked for the whole GUI-active time: a ratio of 1.00-1.02 means "
+                            "the SIMDs issued in every cycle they had (reported as 1.0)")
         doc["clock_GHz_profiled"] = grbm / 8 / (doc["rows"]["avg_launch_ms"] * 1e-3) / 1e9 if doc["rows"]["avg_launch_ms"] else None
     try:       # launch size of the profiled command: the per-launch byte counts scale with it
         line = json.loads(open(os.path.join(out, "bench_line_under_rocprof.json")).read())

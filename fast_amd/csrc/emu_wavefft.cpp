@@ -36,6 +36,7 @@ static void cs_turns(double t, double* c, double* s) {
 }
 
 static bool g_dense = false;      // P = 16: run the dense-image variant (pruned_row_fft_d16)
+static int g_dense_r16 = 0;       // P = 16: 1 = the 16 x 4 lane factorisation (pruned_row_fft_d16r), 2 = with the centred plane set
 
 template <class R, int P, int NS>
 static double run_case(int lo, int Np, unsigned seed) {
@@ -62,7 +63,9 @@ static double run_case(int lo, int Np, unsigned seed) {
       ex.regs[l].v[j] = mk<R>((R)(sg * inr[k]), (R)(sg * ini[k]));
     }
   if constexpr (P == 16) {
-    if (g_dense) pruned_row_fft_d16<R, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
+    if (g_dense_r16 == 1) pruned_row_fft_d16r<R, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
+    else if (g_dense_r16 == 2) pruned_row_fft_d16r<R, NS, D16R_CENTRE_MASK>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
+    else if (g_dense) pruned_row_fft_d16<R, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
     else pruned_row_fft<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
   } else {
     pruned_row_fft<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
@@ -291,6 +294,17 @@ int main() {
   bad += sweep<float, 16, 2>("f32 dense", 2e-5);
   bad += sweep<double, 16, 4>("f64 dense", 1e-13);
   g_dense = false;
+  g_dense_r16 = 1;
+  bad += sweep<double, 16, 2>("f64 dense 16x4", 1e-13);
+  bad += sweep<float, 16, 2>("f32 dense 16x4", 2e-5);
+  g_dense_r16 = 2;      // the plane set of a centred window: the centred cases of the sweep
+  for (int Np : {82, 96, 23, 1, 64})
+    for (int lo : {(1024 - Np) / 2, (1024 - Np) / 2 + (Np < 90 ? 3 : 0)}) {
+      const double err = run_case<double, 16, 2>(lo, Np, 777u + Np);
+      std::printf("f64 dense 16x4 centred planes lo=%d Np=%d relerr=%.3e %s\n", lo, Np, err, err <= 1e-13 ? "ok" : "FAIL");
+      bad += !(err <= 1e-13);
+    }
+  g_dense_r16 = 0;
   bad += sweep<double, 32, 2>("f64", 1e-13);
   bad += sweep<double, 8, 8>("f64", 1e-13);
   bad += sweep<double, 16, 16>("f64", 1e-13);

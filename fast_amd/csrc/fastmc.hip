@@ -754,6 +754,11 @@ template <class R, int P, int NS, int S = 1>
 static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   if constexpr (P == 16 && NS == 2 && S == 1) {
     if (mode == 0 && epi == 0 && dense16_fits<R>(h) && !h->no_dense) {
+      if (FMC_D16_R16 && (window_planes(h->lo, h->Np, 16, 16) & ~D16R_CENTRE_MASK) == 0) {
+        { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, 1, 4>(h, RA); }
+        { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, 1, 4>(h, CA); }
+        return;
+      }
       if (FMC_D16_PRUNE && (window_b0_mask(h->lo, h->Np, 16) & ~D16_CENTRE_MASK) == 0) {
         { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, 1, 2>(h, RA); }
         { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, 1, 2>(h, CA); }

@@ -434,6 +434,95 @@ FMC_HD void pruned_row_fft_d16(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>*
   }
 }
 
+// ---------------------------------------------------------------- P = 16, dense images, 64 = 16 x 4 on the lanes
+// The same row with the lane dimension factored 64 = L1 x L0 = 16 x 4 instead of 8 x 8:
+//     in-register radix-16  ->  exchange 1  ->  in-register radix-16 (ONE butterfly per lane: lane (a = lane & 15, l0 = lane >> 4)
+//     owns T_{l0 + 4 l1}[a], l1 < 16)  ->  exchange 2  ->  4-term sums for the window outputs
+//   X[x] = sum_{l0 < 4} w_64^{l0 b} U[a][l0][b0],   U[a][l0][b0] = sum_{l1 < 16} w_16^{l1 b0} T_{l0 + 4 l1}[a],   b0 = b mod 16.
+// The pruned stage has 4 terms instead of 8, so it reads half the exchange-2 elements and 3 instead of 7 table values per
+// output, and the exchange-2 image has SIXTEEN planes of which a centred window of up to 96 pixels touches six
+// ({13, 14, 15, 0, 1, 2}): ten are neither stored nor computed (the radix-16 network loses the operations that only fed
+// them).  Per row and lane: the same float64 operation count as the 8 x 8 form with six of eight planes (stage 2a ~136
+// instead of 104, stage 2b 28 instead of 60), but 73 KB instead of 103 KB through the LDS -- and the LDS share of the issue
+// time goes with the bytes.  Images: exchange 1 as before (66 a + l; the owners read 66 a + l0 + 4 l1: 2 a + l0 distinct in
+// a half-wave); exchange 2 F[a][b0][l0] at a + 16 b0 + 256 l0 (writes: 16 consecutive a; reads: x mod 256 consecutive).
+// Uses rows m = 1, 2, 3 of the `om` table (w_64^{m b}).
+constexpr int D16R_CENTRE_MASK = centre_planes(16, 16, 0);
+static_assert(D16R_CENTRE_MASK == 0xE007, "planes {13, 14, 15, 0, 1, 2}");
+template <class R, int NS, int B0M = 0xFFFF, class Exec>
+FMC_HD void pruned_row_fft_d16r(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
+                                int omS, int lo, int Np) {
+  constexpr int P = 16;
+  using X = Xch<R>;
+  using E = typename X::E;
+  constexpr int NC = X::NC;
+  const int nslots = (Np + WAVE - 1) / WAVE;
+  ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+    cpx<R> z[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) z[j] = r.v[j];
+    dft_reg<P, R>(z);
+    r.v[0] = z[0];
+#pragma unroll
+    for (int a = 1; a < P; ++a) r.v[a] = cmul(z[a], tw1[a * WAVE + lane]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { r.xr[s] = (R)0; r.xi[s] = (R)0; }
+  });
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) ex.st(xbuf + a * D16_SE + lane, X::pack(r.v[a], c));
+    });
+    ex.sync();
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int a = lane & 15, l0 = lane >> 4;
+#pragma unroll
+      for (int l1 = 0; l1 < 16; ++l1) X::unpack(r.v[l1], ex.ld(xbuf + a * D16_SE + l0 + 4 * l1), c);
+    });
+    ex.sync();
+  }
+  ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+    cpx<R> t[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) t[m] = r.v[m];
+    fft_dif<16, R>(t);
+#pragma unroll
+    for (int b0 = 0; b0 < 16; ++b0) r.v[b0] = t[brev(b0, 4)];
+  });
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int a = lane & 15, l0 = lane >> 4;
+#pragma unroll
+      for (int b0 = 0; b0 < 16; ++b0)
+        if ((B0M >> b0) & 1) ex.st(xbuf + a + 16 * b0 + 256 * l0, X::pack(r.v[b0], c));
+    });
+    ex.sync();
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s < nslots) {
+          const int oi = lane + WAVE * s;
+          if (oi < Np) {
+            const int x = lo + oi;
+            const E* f = xbuf + (x & 255);
+            X::first(r.xr[s], r.xi[s], ex.ld(f), c);
+#pragma unroll
+            for (int m = 1; m < 4; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + 256 * m), c);
+            if (c == NC - 1) {
+              const bool neg = (x & 1) != 0;
+              r.xr[s] = flip_sign(r.xr[s], neg);
+              r.xi[s] = flip_sign(r.xi[s], neg);
+            }
+          }
+        }
+      }
+    });
+    ex.sync();
+  }
+}
+
 // Host-side construction of the two tables (float64 trigonometry by the caller-supplied functor
 // `cs(turns, &c, &s)` = cos/sin(2*pi*turns)).
 template <class R, class CosSin>

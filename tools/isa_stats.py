@@ -32,11 +32,12 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=f
 # demangled-name prefixes of the kernels whose counts bench.py uses
 KERNELS = {
     # 1024^2 with a window of up to 96 pixels: the dense-image, sixteen-wave instantiations (last template argument 1)
-    # (2: without the two exchange-2 planes a centred window never reads, the default for the BASELINE window)
-    "rows_f64_1024": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 2>(",
-    "cols_f64_1024": "void fmc::k_cols_wave<double, 16, 2, 0, 1, 2>(",
-    "rows_f32_1024": "void fmc::k_rows_wave<float, 16, 2, 0, 1, 2>(",
-    "cols_f32_1024": "void fmc::k_cols_wave<float, 16, 2, 0, 1, 2>(",
+    # (4: lanes factored 16 x 4, six of sixteen exchange-2 planes: the default for the centred BASELINE window)
+    "rows_f64_1024": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 4>(",
+    "cols_f64_1024": "void fmc::k_cols_wave<double, 16, 2, 0, 1, 4>(",
+    "rows_f32_1024": "void fmc::k_rows_wave<float, 16, 2, 0, 1, 4>(",
+    "cols_f32_1024": "void fmc::k_cols_wave<float, 16, 2, 0, 1, 4>(",
+    "rows_f64_1024_8x8_six_planes": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 2>(",
     "rows_f64_1024_all_planes": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 1>(",
     "rows_f64_1024_12waves": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 0>(",
     "rows_f64_2048": "void fmc::k_rows_wave<double, 16, 2, 0, 2, 3>(",

@@ -769,6 +769,19 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
       return;
     }
   }
+  if constexpr (NS == 2 && P == 16) {
+    if (FMC_D16_R16 && mode == 0 && epi == 0 && (window_planes(h->lo, h->Np, 16, 16) & ~D16R_CENTRE_MASK) == 0) {
+      // split rows: sixteen-wave workgroups where the tables fit (A/B at 2048^2: rows 37.4 -> 35.7 ms per 5000 realisations;
+      // 4096^2: -1 %); the split column kernel loses 6 % there at 4096^2 and stays on twelve waves
+      if (FMC_SPLIT_DENSE_ROWS && S > 1 && wave_lds_bytes_d<R, 16, 2, 4>(h->omS) <= 160 * 1024) {
+        Span s(h, 0); launch_rows_wave<R, 16, 2, 0, S, 4>(h, RA);
+      } else {
+        Span s(h, 0); launch_rows_wave<R, 16, 2, 0, S, 5>(h, RA);
+      }
+      { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, S, 5>(h, CA); }
+      return;
+    }
+  }
   if constexpr (NS == 2 && P >= 16 && prune_pays(P, 8, 0)) {
     if (FMC_D16_PRUNE && mode == 0 && epi == 0 && (window_planes(h->lo, h->Np, P, 8) & ~centre_planes(P, 8, 0)) == 0) {
       { Span s(h, 0); launch_rows_wave<R, P, 2, 0, S, 3>(h, RA); }

@@ -40,8 +40,8 @@ KERNELS = {
     "rows_f64_1024_8x8_six_planes": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 2>(",
     "rows_f64_1024_all_planes": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 1>(",
     "rows_f64_1024_12waves": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 0>(",
-    "rows_f64_2048": "void fmc::k_rows_wave<double, 16, 2, 0, 2, 3>(",
-    "cols_f64_2048": "void fmc::k_cols_wave<double, 16, 2, 0, 2, 3>(",
+    "rows_f64_2048": "void fmc::k_rows_wave<double, 16, 2, 0, 2, 4>(",
+    "cols_f64_2048": "void fmc::k_cols_wave<double, 16, 2, 0, 2, 5>(",
 }
 
 TRANS = re.compile(r"^v_(log|sqrt|sin|cos|exp|rcp|rsq)_(f32|f16|f64)")

@@ -27,8 +27,8 @@ MAX_NPXLS = 4096          # libfastmc: N <= 4096 (fastmc_create)
 # up to the smallest of these that is within 10 % of the fastest one not smaller than it (896 and 1792, radix-7 stages, lose
 # to 1024 and 2048; 2048 beats everything between 1600 and itself).
 FAST_SIZE_RATE = {
-    128: 6500, 192: 5600, 256: 4300, 320: 3400, 384: 2700, 448: 2200, 512: 2100, 576: 1400, 640: 1300, 768: 1000, 896: 550,
-    1024: 840, 1152: 460, 1280: 360, 1536: 320, 1792: 140, 2048: 220, 4096: 48,
+    128: 6600, 192: 5600, 256: 4400, 320: 3400, 384: 2700, 448: 2200, 512: 2200, 576: 1400, 640: 1300, 768: 1150, 896: 550,
+    1024: 920, 1152: 460, 1280: 370, 1536: 360, 1792: 145, 2048: 245, 4096: 62,
     1344: 318, 1728: 174, 1920: 159, 2304: 86, 2560: 75, 3072: 85, 3584: 43, 3840: 35,
     100: 8060, 150: 6150, 200: 4850, 250: 3900, 300: 3170, 350: 2545, 400: 2490, 450: 1930, 500: 1930, 600: 1490, 700: 830,
     800: 820, 900: 590, 1000: 580, 1200: 455, 1400: 227, 1500: 249, 1600: 198, 2000: 124, 2500: 91, 3000: 57, 4000: 32,

@@ -155,7 +155,7 @@ def test_optional_rounding_of_auto_grid_size():
     assert host.WAVE_FFT_SIZES == [128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1152, 1280, 1536, 1792, 2048, 4096]
     # rounding goes to the smallest fast grid within 10 % of the best rate at or above N: slow radices are skipped
     assert [host.round_up_size(n) for n in (90, 101, 164, 510, 820, 1030, 1290, 1700, 2050, 2310, 3100, 4097)] == \
-        [100, 128, 192, 512, 1024, 1152, 1344, 2048, 2304, 2500, 4096, None]
+        [100, 128, 192, 512, 1024, 1152, 1536, 2048, 2304, 2500, 4096, None]
     from oracle import devrng
     for n in host.ROUND_UP_SIZES:       # every listed size has an FFT kernel family in the library
         assert n in host.WAVE_FFT_SIZES or devrng.wave_rt_split(n) or devrng.mr_supported(n), n

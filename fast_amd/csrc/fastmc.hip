@@ -782,6 +782,13 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
       return;
     }
   }
+  if constexpr (NS == 2 && P == 16) {     // centred windows of 97-128 pixels: eight of the sixteen planes
+    if (FMC_D16_R16 && mode == 0 && epi == 0 && (window_planes(h->lo, h->Np, 16, 16) & ~D16R_WIDE_MASK) == 0) {
+      { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, S, 6>(h, RA); }
+      { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, S, 6>(h, CA); }
+      return;
+    }
+  }
   if constexpr (NS == 2 && P >= 16 && prune_pays(P, 8, 0)) {
     if (FMC_D16_PRUNE && mode == 0 && epi == 0 && (window_planes(h->lo, h->Np, P, 8) & ~centre_planes(P, 8, 0)) == 0) {
       { Span s(h, 0); launch_rows_wave<R, P, 2, 0, S, 3>(h, RA); }

@@ -449,6 +449,8 @@ FMC_HD void pruned_row_fft_d16(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>*
 // Uses rows m = 1, 2, 3 of the `om` table (w_64^{m b}).
 constexpr int D16R_CENTRE_MASK = centre_planes(16, 16, 0);
 static_assert(D16R_CENTRE_MASK == 0xE007, "planes {13, 14, 15, 0, 1, 2}");
+constexpr int D16R_WIDE_MASK = centre_planes(16, 16, 0, 128);      // centred windows of up to 128 pixels
+static_assert(D16R_WIDE_MASK == 0xF00F, "planes {12, ..., 15, 0, ..., 3}");
 template <class R, int NS, int B0M = 0xFFFF, class Exec>
 FMC_HD void pruned_row_fft_d16r(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
                                 int omS, int lo, int Np) {

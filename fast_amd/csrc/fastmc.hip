@@ -789,6 +789,13 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
       return;
     }
   }
+  if constexpr (P == 16 && (NS == 2 || NS == 4 || NS == 8)) {     // any other window at P = 16: the 16 x 4 row with all planes
+    if (FMC_D16_R16_ALL && mode == 0 && epi == 0) {
+      { Span s(h, 0); launch_rows_wave<R, 16, NS, 0, S, 7>(h, RA); }
+      { Span s(h, 1); launch_cols_wave<R, 16, NS, 0, S, 7>(h, CA); }
+      return;
+    }
+  }
   if constexpr (NS == 2 && P >= 16 && prune_pays(P, 8, 0)) {
     if (FMC_D16_PRUNE && mode == 0 && epi == 0 && (window_planes(h->lo, h->Np, P, 8) & ~centre_planes(P, 8, 0)) == 0) {
       { Span s(h, 0); launch_rows_wave<R, P, 2, 0, S, 3>(h, RA); }

@@ -364,6 +364,7 @@ template <class R, int P, int NS> struct WaveCfg {
 
 // D = 4: the dense row with the lanes factored 16 x 4 (pruned_row_fft_d16r: one radix-16 butterfly per lane, 4-term sums, six of
 //        sixteen planes): the default for centred windows of up to 96 pixels.
+// D = 7: D = 5 with all sixteen planes: any window (NS = 2, 4, 8) at P = 16 -- the 4-term sums alone pay for the larger butterfly.
 // D = 6: D = 5 with the plane set of centred windows of 97-128 pixels (eight of sixteen planes).
 // D = 5: the 16 x 4 row in the twelve-wave kernels (split rows of 2048 / 4096 keep 3 waves per SIMD: their sub-row accumulators
 //        do not fit the 128-VGPR step).
@@ -382,11 +383,15 @@ template <class R, int P, int NS> struct WaveCfg {
 #ifndef FMC_D16_R16
 #define FMC_D16_R16 1
 #endif
+#ifndef FMC_D16_R16_ALL
+#define FMC_D16_R16_ALL 1
+#endif
 #ifndef FMC_SPLIT_DENSE_ROWS
 #define FMC_SPLIT_DENSE_ROWS 1
 #endif
 template <class R, int P, int NS, int D> struct WCfg {
-  static_assert(D == 0 || (D == 3 && NS == 2) || (P == 16 && NS == 2), "dense images exist for P = 16, NS = 2; pruned planes for NS = 2");
+  static_assert(D == 0 || (D == 3 && NS == 2) || (P == 16 && NS == 2) || (D == 7 && P == 16),
+                "dense images exist for P = 16, NS = 2; pruned planes for NS = 2; the 16 x 4 row for P = 16");
   static_assert(WaveGeom<R, 16>::XELEMS >= D16_XELEMS, "the 16 x 4 row (D = 5) runs in the twelve-wave exchange buffer");
   static constexpr bool DENSE = (D == 1 || D == 2 || D == 4);
   static constexpr int WPB = DENSE ? 16 : WaveCfg<R, P, NS>::WPB;
@@ -524,7 +529,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 #pragma unroll
     for (int j = 0; j < P; ++j) { regs.xr[j % NS] += regs.v[j].x; regs.xi[j % NS] += regs.v[j].y; }
 #else
-    if constexpr (D == 4 || D == 5 || D == 6) pruned_row_fft_d16r<R, NS, (D == 6 ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : D == 6 ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     else if constexpr (D == 1 || D == 2) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, b0mask);
 #endif
@@ -592,7 +597,7 @@ void k_cols_wave(ColArgs<R> A) {
   if (S == 1) {
 #pragma unroll
     for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
-    if constexpr (D == 4 || D == 5 || D == 6) pruned_row_fft_d16r<R, NS, (D == 6 ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : D == 6 ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     else if constexpr (D == 1 || D == 2) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
   } else {
@@ -603,7 +608,7 @@ void k_cols_wave(ColArgs<R> A) {
     for (int sp = 0; sp < S; ++sp) {
 #pragma unroll
       for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (lane + WAVE * j)];
-      if constexpr (D == 5 || D == 4 || D == 6) pruned_row_fft_d16r<R, NS, (D == 6 ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+      if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : D == 6 ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
       else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) {

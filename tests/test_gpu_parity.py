@@ -1014,6 +1014,34 @@ def test_wave_family_with_run_time_sub_rows(N, Np):
     assert np.abs(got - devrng.device_coefficients(7, 3, N)).max() < 1e-3
 
 
+@pytest.mark.parametrize("N,Np,lo", [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, None), (1024, 128, None),
+                                     (1024, 200, None), (1024, 256, None), (1024, 400, None), (1024, 82, 0), (1024, 82, 500),
+                                     (1024, 120, 904), (2048, 82, None), (2048, 122, None), (2048, 402, None), (4096, 82, None)])
+def test_p16_row_variants_equal_the_direct_family(N, Np, lo):
+    """P = 16 grids pick their row by window: the 16 x 4 lane factorisation with six of sixteen planes (centred, <= 96 pixels; dense
+    at 1024^2), eight planes (97-128), all planes (anything else, NS = 2 / 4 / 8).  Each against the direct family on the same
+    device draws, and the screens of host coefficients against numpy."""
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    lo = (N - Np) // 2 if lo is None else lo
+    h = _lib.Handle(N, Np, "f64", 0)
+    h.set_spectrum(ps * 0.02, df)
+    h.set_pupil(_window_W(Np), lo, 0.01)
+    assert h.kernel_path() == 1
+    n = 2 if N <= 2048 else 1
+    a = h.run(11, 5, n, None, 0.02)
+    h.set_batch(1)
+    np.testing.assert_array_equal(h.run(11, 5, n, None, 0.02), a)
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.run(11, 5, n, None, 0.02), a, rtol=1e-9)
+    if N == 1024:
+        h.kernel_path(1)
+        rng = np.random.default_rng(Np)
+        cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
+        z = np.fft.fftshift(np.fft.fft2(np.fft.fftshift((cr[0] + 1j * ci[0]) * np.sqrt(ps * 0.02) * df)))[lo:lo + Np, lo:lo + Np]
+        got = h.screens_coeffs(cr, ci)
+        assert max(np.abs(got[0] - z.real).max(), np.abs(got[1] - z.imag).max()) <= 1e-11 * np.abs(z).max()
+
+
 def test_kernel_family_notes_in_the_log(caplog):
     """Grids of the direct family are announced with the nearest fast sizes; 64 P and 50 P S grids are not."""
     import logging

@@ -571,6 +571,10 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 #ifndef FMC_COLS_WPE_MAXP
 #define FMC_COLS_WPE_MAXP 8
 #endif
+#ifndef FMC_COLS_PREFETCH
+#define FMC_COLS_PREFETCH 0   // A/B: the column's global loads issued before the table staging and its barrier: 1.31 -> 1.58 ms per 5000
+#endif                        // realisations at 1024^2 (the table copy queues behind 16 KB of column loads per wave), +24 % at 1536^2
+
 template <class R, int P, int NS, int EPI, int S = 1, int D = 0>
 __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64), ((P <= FMC_COLS_WPE_MAXP && P != 7 && NS == 2 && WaveCfg<R, P, NS>::WPB == 12) ? 6 : 1))
 void k_cols_wave(ColArgs<R> A) {
@@ -580,13 +584,12 @@ void k_cols_wave(ColArgs<R> A) {
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
   cpx<R>* s_om = s_tw + P * WAVE;
   E* s_x = reinterpret_cast<E*>(s_om + 8 * A.omS);
-  load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * WCfg<R, P, NS, D>::XELEMS;
   // work item = (realisation b, window column xi), xi fastest: adjacent waves read adjacent columns
   const int item = blockIdx.x * WCfg<R, P, NS, D>::WPB + w;
-  if (item >= A.nb * A.Np) return;   // whole wave exits; no block barrier follows
+  const bool valid = item < A.nb * A.Np;
   const int b = item / A.Np;
   const int xi = item % A.Np;
   const int N = S * G::N;
@@ -594,9 +597,20 @@ void k_cols_wave(ColArgs<R> A) {
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
   const cpx<R>* col = A.V + ((size_t)b * A.Np + xi) * N;
-  if (S == 1) {
+#if FMC_COLS_PREFETCH
+  // the column's loads go out before the tables are staged: HBM latency under the table copy and the barrier
+  if (S == 1 && valid) {
 #pragma unroll
     for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
+  }
+#endif
+  load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
+  if (!valid) return;   // whole wave exits; no block barrier follows
+  if (S == 1) {
+#if !FMC_COLS_PREFETCH
+#pragma unroll
+    for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
+#endif
     if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : D == 6 ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     else if constexpr (D == 1 || D == 2) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);

@@ -398,10 +398,10 @@ template <class R, int P, int NS, int D> struct WCfg {
   static constexpr int XELEMS = DENSE ? D16_XELEMS : WaveGeom<R, P>::XELEMS;
 };
 
-template <class R, int P>
+template <class R, int P, int OM_ROWS = 8>
 __device__ __forceinline__ void load_tables(cpx<R>* s_tw, cpx<R>* s_om, const cpx<R>* tw, const cpx<R>* om, int omS) {
   for (int i = threadIdx.x; i < P * WAVE; i += blockDim.x) s_tw[i] = tw[i];
-  for (int i = threadIdx.x; i < 8 * omS; i += blockDim.x) s_om[i] = om[i];
+  for (int i = threadIdx.x; i < OM_ROWS * omS; i += blockDim.x) s_om[i] = om[i];    // the 16 x 4 row reads rows 1 ... 3 only
   __syncthreads();
 }
 
@@ -427,7 +427,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
   cpx<R>* s_om = s_tw + P * WAVE;
   E* s_x = reinterpret_cast<E*>(s_om + 8 * A.omS);
-  load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
+  load_tables<R, P, (D >= 4 ? 4 : 8)>(s_tw, s_om, A.tw, A.om, A.omS);
 
   // the wave index is wave-uniform: in an SGPR, so that row / realisation indices and the table base addresses
   // derived from it are scalar and the loads use the scalar-base + lane-offset form
@@ -604,7 +604,7 @@ void k_cols_wave(ColArgs<R> A) {
     for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
   }
 #endif
-  load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
+  load_tables<R, P, (D >= 4 ? 4 : 8)>(s_tw, s_om, A.tw, A.om, A.omS);
   if (!valid) return;   // whole wave exits; no block barrier follows
   if (S == 1) {
 #if !FMC_COLS_PREFETCH

@@ -305,6 +305,7 @@ struct GpuExec {
     __builtin_memcpy(&o, &d, 8);
     return o;
   }
+  static __device__ __forceinline__ cpx<double> ld(const cpx<double>* p) { return *p; }     // 16 bytes: one ds_read_b128
   template <class E> static __device__ __forceinline__ void st(E* p, E v) { *p = v; }
   // two neighbouring 8-byte elements at a 16-byte aligned address: one ds_read_b128
   template <class E> static __device__ __forceinline__ void ld2(const E* p, E& a, E& b) {

@@ -447,10 +447,21 @@ FMC_HD void pruned_row_fft_d16(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>*
 // time goes with the bytes.  Images: exchange 1 as before (66 a + l; the owners read 66 a + l0 + 4 l1: 2 a + l0 distinct in
 // a half-wave); exchange 2 F[a][b0][l0] at a + 16 b0 + 256 l0 (writes: 16 consecutive a; reads: x mod 256 consecutive).
 // Uses rows m = 1, 2, 3 of the `om` table (w_64^{m b}).
+#ifndef FMC_D16R_ONEPASS
+#define FMC_D16R_ONEPASS 1
+#endif
+FMC_HD constexpr int popcount16(int m) { int n = 0; for (int i = 0; i < 16; ++i) n += (m >> i) & 1; return n; }
+// NP planes around b0 = 0: {16 - NP / 2, ..., 15, 0, ..., NP - NP / 2 - 1}
+FMC_HD constexpr int centre_run_mask(int NP) {
+  int m = 0;
+  for (int p = 0; p < NP; ++p) m |= 1 << ((p - NP / 2 + 16) & 15);
+  return m;
+}
 constexpr int D16R_CENTRE_MASK = centre_planes(16, 16, 0);
 static_assert(D16R_CENTRE_MASK == 0xE007, "planes {13, 14, 15, 0, 1, 2}");
 constexpr int D16R_WIDE_MASK = centre_planes(16, 16, 0, 128);      // centred windows of up to 128 pixels
 static_assert(D16R_WIDE_MASK == 0xF00F, "planes {12, ..., 15, 0, ..., 3}");
+static_assert(centre_run_mask(6) == D16R_CENTRE_MASK && centre_run_mask(8) == D16R_WIDE_MASK, "contiguous plane sets");
 template <class R, int NS, int B0M = 0xFFFF, class Exec>
 FMC_HD void pruned_row_fft_d16r(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
                                 int omS, int lo, int Np) {
@@ -492,6 +503,40 @@ FMC_HD void pruned_row_fft_d16r(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>
 #pragma unroll
     for (int b0 = 0; b0 < 16; ++b0) r.v[b0] = t[brev(b0, 4)];
   });
+  // float64 with a centred plane set (<= 8 planes, contiguous around b0 = 0): exchange 2 in ONE pass with 16-byte elements --
+  // plane b0 at position p = (b0 + NP / 2) & 15 < NP, element (a, p, l0) at a + 16 p + 16 NP l0 (<= 512 elements of 16 bytes):
+  // the table values are read once instead of once per component, two hand-offs instead of four.
+  constexpr int NP = popcount16(B0M);
+  if constexpr (FMC_D16R_ONEPASS && sizeof(R) == 8 && NP <= 8 && B0M == centre_run_mask(NP)) {
+    cpx<R>* cbuf = reinterpret_cast<cpx<R>*>(xbuf);
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+      const int a = lane & 15, l0 = lane >> 4;
+#pragma unroll
+      for (int b0 = 0; b0 < 16; ++b0)
+        if ((B0M >> b0) & 1) ex.st(cbuf + a + 16 * ((b0 + NP / 2) & 15) + 16 * NP * l0, r.v[b0]);
+    });
+    ex.sync();
+    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s < nslots) {
+          const int oi = lane + WAVE * s;
+          if (oi < Np) {
+            const int x = lo + oi;
+            const cpx<R>* f = cbuf + ((x + 8 * NP) & 255);        // a + 16 p: consecutive outputs, consecutive elements
+            cpx<R> acc = ex.ld(f);
+#pragma unroll
+            for (int m = 1; m < 4; ++m) acc = cfma(om[m * omS + oi], ex.ld(f + 16 * NP * m), acc);
+            const bool neg = (x & 1) != 0;
+            r.xr[s] = flip_sign(acc.x, neg);
+            r.xi[s] = flip_sign(acc.y, neg);
+          }
+        }
+      }
+    });
+    ex.sync();
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     ex.each([&](int lane, LaneRegs<R, P, NS>& r) {

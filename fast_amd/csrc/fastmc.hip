@@ -472,6 +472,11 @@ template <class R>
 static bool dense16_fits(const fastmc_ctx* h) {
   return FMC_DENSE16 && wave_lds_bytes_d<R, 16, 2, 1>(h->omS) <= 160 * 1024;
 }
+// the 16 x 4 dense kernels stage four table rows: windows of up to 128 pixels fit
+template <class R>
+static bool dense16r_fits(const fastmc_ctx* h) {
+  return FMC_DENSE16 && wave_lds_bytes_d<R, 16, 2, 4>(h->omS) <= 160 * 1024;
+}
 
 static int default_batch(const fastmc_ctx* h) {
   if (h->batch > 0) return h->batch;
@@ -486,7 +491,7 @@ static int default_batch(const fastmc_ctx* h) {
     // workgroup per CU and has batch * N/8 wave-items
     int ns = 0, wpb = 1;
     if (h->rsz == 8) wave_config<double>(h, &ns, &wpb); else wave_config<float>(h, &ns, &wpb);
-    if (h->P == 16 && ns == 2 && h->S == 1 && !h->no_dense && (h->rsz == 8 ? dense16_fits<double>(h) : dense16_fits<float>(h))) wpb = 16;
+    if (h->P == 16 && ns == 2 && h->S == 1 && !h->no_dense && (h->rsz == 8 ? dense16r_fits<double>(h) : dense16r_fits<float>(h))) wpb = 16;
     const int quantum = std::max(1, 256 * wpb * ROWS_PER_WAVE / h->N);
     if (b >= quantum) b -= b % quantum;
   } else if (b >= 8) {
@@ -753,12 +758,20 @@ static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
 template <class R, int P, int NS, int S = 1>
 static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   if constexpr (P == 16 && NS == 2 && S == 1) {
-    if (mode == 0 && epi == 0 && dense16_fits<R>(h) && !h->no_dense) {
-      if (FMC_D16_R16 && (window_planes(h->lo, h->Np, 16, 16) & ~D16R_CENTRE_MASK) == 0) {
+    if (mode == 0 && epi == 0 && FMC_D16_R16 && dense16r_fits<R>(h) && !h->no_dense) {
+      const int win = window_planes(h->lo, h->Np, 16, 16);
+      if ((win & ~D16R_CENTRE_MASK) == 0) {
         { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, 1, 4>(h, RA); }
         { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, 1, 4>(h, CA); }
         return;
       }
+      if ((win & ~D16R_WIDE_MASK) == 0) {
+        { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, 1, 8>(h, RA); }
+        { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, 1, 8>(h, CA); }
+        return;
+      }
+    }
+    if (mode == 0 && epi == 0 && dense16_fits<R>(h) && !h->no_dense) {
       if (FMC_D16_PRUNE && (window_b0_mask(h->lo, h->Np, 16) & ~D16_CENTRE_MASK) == 0) {
         { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, 1, 2>(h, RA); }
         { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, 1, 2>(h, CA); }

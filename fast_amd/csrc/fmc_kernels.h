@@ -365,6 +365,8 @@ template <class R, int P, int NS> struct WaveCfg {
 
 // D = 4: the dense row with the lanes factored 16 x 4 (pruned_row_fft_d16r: one radix-16 butterfly per lane, 4-term sums, six of
 //        sixteen planes): the default for centred windows of up to 96 pixels.
+// D = 8: D = 4 with the eight-plane set of centred windows of 97-128 pixels (the tables fit the dense layout because only four
+//        rows of the stage-2b table are staged).
 // D = 7: D = 5 with all sixteen planes: any window (NS = 2, 4, 8) at P = 16 -- the 4-term sums alone pay for the larger butterfly.
 // D = 6: D = 5 with the plane set of centred windows of 97-128 pixels (eight of sixteen planes).
 // D = 5: the 16 x 4 row in the twelve-wave kernels (split rows of 2048 / 4096 keep 3 waves per SIMD: their sub-row accumulators
@@ -391,10 +393,11 @@ template <class R, int P, int NS> struct WaveCfg {
 #define FMC_SPLIT_DENSE_ROWS 1
 #endif
 template <class R, int P, int NS, int D> struct WCfg {
-  static_assert(D == 0 || (D == 3 && NS == 2) || (P == 16 && NS == 2) || (D == 7 && P == 16),
+  static constexpr int OM_ROWS = (D >= 4) ? 4 : 8;     // stage-2b table rows in the LDS: the 16 x 4 row reads rows 1 ... 3
+  static_assert(D <= 8 && (D == 0 || (D == 3 && NS == 2) || (P == 16 && NS == 2) || (D == 7 && P == 16)),
                 "dense images exist for P = 16, NS = 2; pruned planes for NS = 2; the 16 x 4 row for P = 16");
   static_assert(WaveGeom<R, 16>::XELEMS >= D16_XELEMS, "the 16 x 4 row (D = 5) runs in the twelve-wave exchange buffer");
-  static constexpr bool DENSE = (D == 1 || D == 2 || D == 4);
+  static constexpr bool DENSE = (D == 1 || D == 2 || D == 4 || D == 8);
   static constexpr int WPB = DENSE ? 16 : WaveCfg<R, P, NS>::WPB;
   static constexpr int XELEMS = DENSE ? D16_XELEMS : WaveGeom<R, P>::XELEMS;
 };
@@ -413,7 +416,7 @@ __host__ __device__ constexpr size_t wave_lds_bytes(int omS) {
 }
 template <class R, int P, int NS, int D>
 __host__ __device__ constexpr size_t wave_lds_bytes_d(int omS) {
-  return (size_t)(P * WAVE + 8 * omS) * sizeof(cpx<R>) + (size_t)WCfg<R, P, NS, D>::WPB * WCfg<R, P, NS, D>::XELEMS * 8;
+  return (size_t)(P * WAVE + WCfg<R, P, NS, D>::OM_ROWS * omS) * sizeof(cpx<R>) + (size_t)WCfg<R, P, NS, D>::WPB * WCfg<R, P, NS, D>::XELEMS * 8;
 }
 
 // S > 1: the row of NF = S * 64 P points is transformed as S interleaved sub-rows (kx = s mod S), each by
@@ -427,7 +430,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
   using E = typename Xch<R>::E;
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
   cpx<R>* s_om = s_tw + P * WAVE;
-  E* s_x = reinterpret_cast<E*>(s_om + 8 * A.omS);
+  E* s_x = reinterpret_cast<E*>(s_om + WCfg<R, P, NS, D>::OM_ROWS * A.omS);
   load_tables<R, P, (D >= 4 ? 4 : 8)>(s_tw, s_om, A.tw, A.om, A.omS);
 
   // the wave index is wave-uniform: in an SGPR, so that row / realisation indices and the table base addresses
@@ -530,7 +533,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 #pragma unroll
     for (int j = 0; j < P; ++j) { regs.xr[j % NS] += regs.v[j].x; regs.xi[j % NS] += regs.v[j].y; }
 #else
-    if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : D == 6 ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : (D == 6 || D == 8) ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     else if constexpr (D == 1 || D == 2) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, b0mask);
 #endif
@@ -584,7 +587,7 @@ void k_cols_wave(ColArgs<R> A) {
   using E = typename Xch<R>::E;
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
   cpx<R>* s_om = s_tw + P * WAVE;
-  E* s_x = reinterpret_cast<E*>(s_om + 8 * A.omS);
+  E* s_x = reinterpret_cast<E*>(s_om + WCfg<R, P, NS, D>::OM_ROWS * A.omS);
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * WCfg<R, P, NS, D>::XELEMS;
@@ -612,7 +615,7 @@ void k_cols_wave(ColArgs<R> A) {
 #pragma unroll
     for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
 #endif
-    if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : D == 6 ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : (D == 6 || D == 8) ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     else if constexpr (D == 1 || D == 2) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
   } else {
@@ -623,7 +626,7 @@ void k_cols_wave(ColArgs<R> A) {
     for (int sp = 0; sp < S; ++sp) {
 #pragma unroll
       for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (lane + WAVE * j)];
-      if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : D == 6 ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+      if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : (D == 6 || D == 8) ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
       else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) {

@@ -748,9 +748,9 @@ static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
 }
 template <class R, int P, int NS, int EPI, int S = 1, int D = 0>
 static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
-  const size_t lds = wave_lds_bytes_d<R, P, NS, D>(A.omS);
+  const size_t lds = wave_lds_bytes_cols<R, P, NS, D>(A.omS);
   hipFuncSetAttribute((const void*)k_cols_wave<R, P, NS, EPI, S, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  constexpr int WPB = WCfg<R, P, NS, D>::WPB;
+  constexpr int WPB = WCfg<R, P, NS, D>::WPB_COLS;
   const int items = A.nb * A.Np;
   hipLaunchKernelGGL((k_cols_wave<R, P, NS, EPI, S, D>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, A);
 }

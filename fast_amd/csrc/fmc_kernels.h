@@ -383,6 +383,10 @@ template <class R, int P, int NS> struct WaveCfg {
 #ifndef FMC_D16_PRUNE
 #define FMC_D16_PRUNE 1
 #endif
+#ifndef FMC_COLS_D16_WPB
+#define FMC_COLS_D16_WPB 0   // 0: sixteen waves, as the rows.  A/B at 1024^2: 6 waves (two workgroups per CU) 1.30 -> 1.285 ms per 5000
+                             // realisations, 8 waves (one per CU) 1.54 ms: overlapping one group's loads with another's arithmetic buys 1 %
+#endif
 #ifndef FMC_D16_R16
 #define FMC_D16_R16 1
 #endif
@@ -394,6 +398,9 @@ template <class R, int P, int NS> struct WaveCfg {
 #endif
 template <class R, int P, int NS, int D> struct WCfg {
   static constexpr int OM_ROWS = (D >= 4) ? 4 : 8;     // stage-2b table rows in the LDS: the 16 x 4 row reads rows 1 ... 3
+  // waves per workgroup of the COLUMN kernel (A/B: smaller dense workgroups, two per CU, so that one's loads overlap the other's
+  // arithmetic)
+  static constexpr int WPB_COLS = ((D == 4 || D == 8) && FMC_COLS_D16_WPB) ? FMC_COLS_D16_WPB : ((D == 1 || D == 2 || D == 4 || D == 8) ? 16 : WaveCfg<R, P, NS>::WPB);
   static_assert(D <= 8 && (D == 0 || (D == 3 && NS == 2) || (P == 16 && NS == 2) || (D == 7 && P == 16)),
                 "dense images exist for P = 16, NS = 2; pruned planes for NS = 2; the 16 x 4 row for P = 16");
   static_assert(WaveGeom<R, 16>::XELEMS >= D16_XELEMS, "the 16 x 4 row (D = 5) runs in the twelve-wave exchange buffer");
@@ -413,6 +420,10 @@ __device__ __forceinline__ void load_tables(cpx<R>* s_tw, cpx<R>* s_om, const cp
 template <class R, int P, int NS>
 __host__ __device__ constexpr size_t wave_lds_bytes(int omS) {
   return (size_t)(P * WAVE + 8 * omS) * sizeof(cpx<R>) + (size_t)WaveCfg<R, P, NS>::WPB * WaveGeom<R, P>::XELEMS * 8;
+}
+template <class R, int P, int NS, int D>
+__host__ __device__ constexpr size_t wave_lds_bytes_cols(int omS) {
+  return (size_t)(P * WAVE + WCfg<R, P, NS, D>::OM_ROWS * omS) * sizeof(cpx<R>) + (size_t)WCfg<R, P, NS, D>::WPB_COLS * WCfg<R, P, NS, D>::XELEMS * 8;
 }
 template <class R, int P, int NS, int D>
 __host__ __device__ constexpr size_t wave_lds_bytes_d(int omS) {
@@ -580,7 +591,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 #endif                        // realisations at 1024^2 (the table copy queues behind 16 KB of column loads per wave), +24 % at 1536^2
 
 template <class R, int P, int NS, int EPI, int S = 1, int D = 0>
-__global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64), ((P <= FMC_COLS_WPE_MAXP && P != 7 && NS == 2 && WaveCfg<R, P, NS>::WPB == 12) ? 6 : 1))
+__global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB_COLS * 64), ((P <= FMC_COLS_WPE_MAXP && P != 7 && NS == 2 && WaveCfg<R, P, NS>::WPB == 12) ? 6 : 1))
 void k_cols_wave(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = WaveGeom<R, P>;
@@ -592,7 +603,7 @@ void k_cols_wave(ColArgs<R> A) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * WCfg<R, P, NS, D>::XELEMS;
   // work item = (realisation b, window column xi), xi fastest: adjacent waves read adjacent columns
-  const int item = blockIdx.x * WCfg<R, P, NS, D>::WPB + w;
+  const int item = blockIdx.x * WCfg<R, P, NS, D>::WPB_COLS + w;
   const bool valid = item < A.nb * A.Np;
   const int b = item / A.Np;
   const int xi = item % A.Np;

@@ -758,14 +758,24 @@ static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
 template <class R, int P, int NS, int S = 1>
 static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   if constexpr (P == 16 && NS == 2 && S == 1) {
-    if (mode == 0 && epi == 0 && FMC_D16_R16 && dense16r_fits<R>(h) && !h->no_dense) {
+    if (FMC_D16_R16 && dense16r_fits<R>(h) && !h->no_dense) {
       const int win = window_planes(h->lo, h->Np, 16, 16);
       if ((win & ~D16R_CENTRE_MASK) == 0) {
-        { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, 1, 4>(h, RA); }
-        { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, 1, 4>(h, CA); }
+        // the BASELINE geometry: the same row also with host coefficients (MODE 1: the reference's own `_r` for a seed goes
+        // through the kernels that are benchmarked) and with the screens written out (EPI 1)
+        {
+          Span s(h, 0);
+          if (mode == 0) launch_rows_wave<R, 16, 2, 0, 1, 4>(h, RA);
+          else launch_rows_wave<R, 16, 2, 1, 1, 4>(h, RA);
+        }
+        {
+          Span s(h, 1);
+          if (epi == 0) launch_cols_wave<R, 16, 2, 0, 1, 4>(h, CA);
+          else launch_cols_wave<R, 16, 2, 1, 1, 4>(h, CA);
+        }
         return;
       }
-      if ((win & ~D16R_WIDE_MASK) == 0) {
+      if (mode == 0 && epi == 0 && (win & ~D16R_WIDE_MASK) == 0) {
         { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, 1, 8>(h, RA); }
         { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, 1, 8>(h, CA); }
         return;
@@ -783,15 +793,24 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
     }
   }
   if constexpr (NS == 2 && P == 16) {
-    if (FMC_D16_R16 && mode == 0 && epi == 0 && (window_planes(h->lo, h->Np, 16, 16) & ~D16R_CENTRE_MASK) == 0) {
+    if (FMC_D16_R16 && (window_planes(h->lo, h->Np, 16, 16) & ~D16R_CENTRE_MASK) == 0) {
       // split rows: sixteen-wave workgroups where the tables fit (A/B at 2048^2: rows 37.4 -> 35.7 ms per 5000 realisations;
-      // 4096^2: -1 %); the split column kernel loses 6 % there at 4096^2 and stays on twelve waves
-      if (FMC_SPLIT_DENSE_ROWS && S > 1 && wave_lds_bytes_d<R, 16, 2, 4>(h->omS) <= 160 * 1024) {
-        Span s(h, 0); launch_rows_wave<R, 16, 2, 0, S, 4>(h, RA);
+      // 4096^2: -1 %); the split column kernel loses 6 % there at 4096^2 and stays on twelve waves.  Host coefficients
+      // (MODE 1) and screens (EPI 1) take the twelve-wave forms of the same row.
+      if (mode == 0) {
+        if (FMC_SPLIT_DENSE_ROWS && S > 1 && wave_lds_bytes_d<R, 16, 2, 4>(h->omS) <= 160 * 1024) {
+          Span s(h, 0); launch_rows_wave<R, 16, 2, 0, S, 4>(h, RA);
+        } else {
+          Span s(h, 0); launch_rows_wave<R, 16, 2, 0, S, 5>(h, RA);
+        }
       } else {
-        Span s(h, 0); launch_rows_wave<R, 16, 2, 0, S, 5>(h, RA);
+        Span s(h, 0); launch_rows_wave<R, 16, 2, 1, S, 5>(h, RA);
       }
-      { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, S, 5>(h, CA); }
+      {
+        Span s(h, 1);
+        if (epi == 0) launch_cols_wave<R, 16, 2, 0, S, 5>(h, CA);
+        else launch_cols_wave<R, 16, 2, 1, S, 5>(h, CA);
+      }
       return;
     }
   }

@@ -217,6 +217,9 @@ __device__ __forceinline__ void pixel_phase(const SubharmArgs& sh, int b, int Np
 // ~35 VALU instructions instead of the ~155 of ocml's sincos: the column kernel calls it four
 // times per wavefront.
 __device__ __forceinline__ void sincos_r(double x, double& s, double& c) {
+#ifdef FMC_ABL_NOSINCOS      // ablation (timing only, wrong results)
+  s = x; c = x * 0.5; return;
+#endif
 #ifdef FMC_LIBM_SINCOS
   sincos(x, &s, &c);
 #else

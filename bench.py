@@ -18,6 +18,16 @@ disjoint range of realisations); with N > 1 every step ends with the all-gather 
 all-reduce of the dB histogram.  Inputs (spectrum, pupil weights) are resident in HBM before the timed region; only the
 80 kB of results per step and GPU crosses PCIe.  Rank 0 prints ONE JSON line.
 
+`--workload config3` is BASELINE.json configs[3] instead: 2048 x 2048 grid, 100 000 iterations per step IN TOTAL, cut into
+N equal contiguous ranges (strong scaling), same exchange.
+
+With N > 1 a step synchronises each device once: the kernels are enqueued without waiting, the RCCL collectives follow on
+the same streams, only the gathered result is copied back.  Every exchange runs under a deadline (FASTMC_EXCHANGE_TIMEOUT,
+default 120 s): a collective that does not come back is aborted (ncclCommAbort) and the run goes on with the host exchange
+-- the line then says so in `config.result_exchange` -- instead of hanging.  `config.rccl_ranks` is the world size the
+communicator itself reports, `exchange` the time the collectives took (HIP events on the streams: transfer + waiting for
+the slowest peer) and `pipeline.gpu_busy_ms_per_step` the min / max over the workers of their kernels' time.
+
 Every figure in the line is computed from this run, from the instruction counts of the code object that ran
 (fast_amd/kernel_isa_stats.json, written by the build) or, where it needs hardware counters, from a committed
 rocprofv3 summary that is named in the line and dropped when it belongs to another build.
@@ -38,7 +48,7 @@ F64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 F32_VECTOR_PEAK_TFLOPS = 157.3
 NOMINAL_GHZ = 2.4
 N_SIMD = 1024
-ITERS_PER_STEP = 10000
+ITERS_PER_STEP = 10000          # per GPU and step, workload configs[1] (set by main for configs[3])
 HIST = (-60.0, 10.0, 4096)
 # Issue cost per wave-instruction per SIMD in cycles at 2.4 GHz, measured by tools/ubench on MI355X at 4 waves per SIMD
 # (profiles/r01j_ubench_valu_issue_rates.txt): v_add/mul/fma_f64 5.0, v_cvt_f64_f32 4.5, v_log/sqrt/sin/cos_f32 7.8
@@ -51,7 +61,7 @@ def workload_params(args):
     import fast_amd
     h, cn2, w = fast_amd.turbulence_models.HV57_Bufton_profile(4)
     return {
-        "NPXLS": args.npxls, "DX": 0.01, "NITER": ITERS_PER_STEP, "NCHUNKS": 100, "TEMPORAL": False,
+        "NPXLS": args.npxls, "DX": 0.01, "NITER": 10000, "NCHUNKS": 100, "TEMPORAL": False,
         "SUBHARM": False, "SEED": 1, "LOGLEVEL": "ERROR", "W0": "opt", "D_GROUND": 0.8, "OBSC_GROUND": 0,
         "D_SAT": 0.1, "H_SAT": 36e6, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w,
         "WIND_DIR": np.array([0., 90., 180., 270.]), "L0": np.inf, "l0": 1e-6, "ZENITH_ANGLE": 55,
@@ -157,14 +167,14 @@ def extras(args, device):
         sim = fast_amd.Fast(p)
         init_s = time.perf_counter() - t0
         h = sim._handle
-        n_real = ITERS_PER_STEP // 2
+        n_real = 10000 // 2
         h.run(1, 0, n_real, None, float(sim.logamp_var), False)
         t0 = time.perf_counter()
         for i in range(3):
             h.run(1, (i + 1) * n_real, n_real, None, float(sim.logamp_var), False)
         dt = time.perf_counter() - t0
         sim.compute_powerspec()                              # second evaluation: no module load in the figure
-        out[tag] = {"iterations_per_s": 3 * ITERS_PER_STEP / dt, "init_s": init_s, "powerspec_kernel_ms_warm": sim.powerspec_kernel_ms,
+        out[tag] = {"iterations_per_s": 3 * 10000 / dt, "init_s": init_s, "powerspec_kernel_ms_warm": sim.powerspec_kernel_ms,
                     "mean_dB_rel": float(10 * np.log10(np.mean(h.run(1, 0, 512, None, float(sim.logamp_var), False))))}
     # configs[3]: 2048^2, 100 000 iterations, two handles
     p = workload_params(copy.copy(args))
@@ -201,7 +211,7 @@ def load_json(path):
         return None
 
 
-def roofline(args, N, Np, tim, steps, workers, value_per_worker):
+def roofline(args, N, Np, tim, steps, workers, iters_per_worker_step):
     """The `roofline` object for the dominant kernel (k_rows_wave) of THIS run.  The kernel is bound by the SIMDs'
     instruction issue (float64 butterflies + the generator + LDS instructions), not by HBM or MFMA:
     `bound` says so, `achieved` / `frac` are executed float64 (float32) vector FLOP/s against the vector peak, `issue` the
@@ -210,7 +220,7 @@ def roofline(args, N, Np, tim, steps, workers, value_per_worker):
     launches = max(tim["rows_launches"], 1)
     avg_rows_ms = tim["rows_ms"] / launches
     avg_cols_ms = tim["cols_ms"] / max(tim["cols_launches"], 1)
-    real_per_launch = ITERS_PER_STEP / 2 * steps * workers / launches        # realisations in an average launch
+    real_per_launch = iters_per_worker_step / 2 * steps * workers / launches        # realisations in an average launch
     S = 4 if N == 4096 else (2 if N == 2048 else 1)
     isa = load_json(os.path.join(ROOT, "fast_amd", "kernel_isa_stats.json")) or {}
     key = f"rows_{args.precision}_{N}"
@@ -274,8 +284,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--npxls", type=int, default=1024)
+    ap.add_argument("--npxls", type=int, default=None, help="grid size (default: 1024, or 2048 with --workload config3)")
     ap.add_argument("--ao-mode", default="NOAO")
+    ap.add_argument("--workload", default="config1", choices=["config1", "config3"],
+                    help="config1 = BASELINE configs[1]: 1024^2, 10 000 iterations per step and GPU (weak scaling, the headline); "
+                         "config3 = BASELINE configs[3]: 2048^2, 100 000 iterations per step in total, split over the GPUs (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (f32, AO config, configs[3], configs[4])")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained run after the timed steps")
@@ -283,6 +296,9 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
+    strong = args.workload == "config3"
+    if args.npxls is None:
+        args.npxls = 2048 if strong else 1024
 
     import fast_amd
     from fast_amd import _lib, dist, multi, rendezvous
@@ -296,7 +312,9 @@ def main():
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
         mode = "ranks"
-        devices = [int(os.environ.get("FASTMC_BENCH_DEVICE", _lib.default_device()))]
+        devices = [int(os.environ.get("FASTMC_BENCH_DEVICE", -1))]
+        if devices[0] < 0:
+            devices = [_lib.default_device()]              # raises when LOCAL_RANK has no GPU of its own
         rdzv = rendezvous.from_env()
     else:
         # one process drives all the GPUs; FASTMC_BENCH_DEVICES=0,0 puts several workers on one device (functional tests)
@@ -312,6 +330,14 @@ def main():
             devices = list(range(args.gpus))
     if max(devices) >= ndev:
         raise SystemExit(f"device {max(devices)} requested but only {ndev} GPU(s) visible")
+    workers = len(devices) if mode != "ranks" else world
+    if strong:
+        if 50000 % workers:
+            raise SystemExit("--workload config3 splits 50 000 realisations: the number of GPUs must divide it")
+        iters_worker = 100000 // workers                  # iterations per worker and step (strong scaling)
+    else:
+        iters_worker = ITERS_PER_STEP                      # weak scaling: fixed work per GPU
+    n_real = iters_worker // 2
 
     p = workload_params(args)
     p["GPU_DEVICES"] = devices
@@ -321,35 +347,42 @@ def main():
     init_s = time.perf_counter() - t0
     grp, h = sim._group, sim._handle
     N, Np = sim.Npxls, sim.Npxls_pup
-    n_real = ITERS_PER_STEP // 2
     lvar = float(sim.logamp_var)
-    workers = len(devices) if mode != "ranks" else world
 
     tr = None
     if mode == "ranks":
         tr = dist.make_transport(h, rdzv)                 # collective: RCCL on every rank, or the host path on every rank
-        exchange = "rccl (in-library, one process per GPU)" if tr.name == "rccl" else f"host sockets ({getattr(tr, 'why', '')})"
-    elif mode == "threads":
-        exchange = "rccl (in-library, ncclCommInitAll)" if grp.exchange == "rccl" else grp.exchange
-    else:
-        exchange = "none"
+
+    def exchange_name():
+        if mode == "ranks":
+            return "rccl (in-library, one process per GPU)" if tr.name == "rccl" else f"host sockets ({getattr(tr, 'why', '')})"
+        if mode == "threads":
+            return "rccl (in-library, ncclCommInitAll)" if grp.exchange == "rccl" else grp.exchange
+        return "none"
 
     hist_total = None
+    acc = {"exchange_device_ms": [], "exchange_wall_ms": 0.0, "rccl_steps": 0, "host_steps": 0}
 
-    def step(i):
-        """Step i: every worker computes ITERS_PER_STEP iterations of its own realisation range, then one exchange."""
+    def step(i, record=False):
+        """Step i: every worker computes `iters_worker` iterations of its own realisation range, then one exchange."""
         nonlocal hist_total
+        base = i * workers * n_real
         if mode == "ranks":
-            real0 = (i * world + rank) * n_real
-            out = h.run(p["SEED"], real0, n_real, None, lvar, False)
-            if tr.name == "rccl":
-                _, hist_total = tr.gather_with_hist(out, h, HIST)
-            else:
-                tr.gather(out, h)
-                hist_total = tr.reduce_hist(h.histogram(*HIST))
+            out, hist_total, info = dist.step_sharded(h, tr, p["SEED"], base, workers * n_real, lvar, False, HIST)
+            if record:
+                acc["exchange_device_ms"].append([info["exchange_device_ms"]])
+                acc["exchange_wall_ms"] += info.get("exchange_host_ms", 0.0)
+                acc["rccl_steps" if info["exchange"] == "rccl" else "host_steps"] += 1
             return out
-        out = grp.run(p["SEED"], i * workers * n_real, workers * n_real, None, lvar, False, hist_range=HIST)
+        out = grp.run(p["SEED"], base, workers * n_real, None, lvar, False, hist_range=HIST)
         hist_total = grp.last_hist
+        if record and workers > 1:
+            if grp.last_exchange == "rccl":
+                acc["exchange_device_ms"].append(list(grp.last_exchange_ms))
+                acc["rccl_steps"] += 1
+            else:
+                acc["exchange_wall_ms"] += grp.last_exchange_wall_ms
+                acc["host_steps"] += 1
         return out
 
     def sync_all():
@@ -357,11 +390,15 @@ def main():
             rdzv.barrier()                  # library calls are blocking: every device is idle when its rank gets here
 
     tim_keys = ("rows_ms", "cols_ms", "finalize_ms", "rows_launches", "cols_launches")
+    busy = []                               # per step: per worker kernels' time (rows + cols + finalize, HIP events)
 
     def add_timing(tim):
+        per = []
         for t in (grp.last_timing() if mode != "ranks" else [h.last_timing()]):
             for k in tim_keys:
                 tim[k] += t[k]
+            per.append(t["rows_ms"] + t["cols_ms"] + t["finalize_ms"])
+        busy.append(per)
 
     for i in range(args.warmup):
         step(i)
@@ -369,14 +406,21 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = step(args.warmup + i)
+        out = step(args.warmup + i, record=True)
         add_timing(tim)
     sync_all()
     dt = time.perf_counter() - t0
+    busy = np.asarray(busy, dtype=float).reshape(args.steps, -1)          # (steps, local workers)
+    ex_dev = np.asarray(acc["exchange_device_ms"], dtype=float)
+    ex_dev = ex_dev.reshape(len(acc["exchange_device_ms"]), -1) if ex_dev.size else np.zeros((0, 1))
     if rdzv is not None:
         dt = float(rdzv.all_reduce(np.array([dt]), "max")[0])
         for k in tim_keys:
             tim[k] = float(rdzv.all_reduce(np.array([tim[k]]), "sum")[0])
+        busy = np.concatenate(list(rdzv.all_gather_array(busy)), axis=1)   # (steps, world)
+        n_ex = rdzv.all_gather_array(np.array([ex_dev.shape[0]], dtype=np.int64)).ravel()
+        if ex_dev.size and len(set(n_ex.tolist())) == 1:
+            ex_dev = np.concatenate(list(rdzv.all_gather_array(ex_dev)), axis=1)
     assert np.isfinite(out).all() and (out > 0).all()
 
     sustained = None
@@ -397,42 +441,57 @@ def main():
         dts = time.perf_counter() - t0
         if rdzv is not None:
             dts = float(rdzv.all_reduce(np.array([dts]), "max")[0])
-        sustained = {"seconds": dts, "steps": n_sus, "value": ITERS_PER_STEP * n_sus * workers / dts, "unit": "iterations/s"}
+        sustained = {"seconds": dts, "steps": n_sus, "value": iters_worker * n_sus * workers / dts, "unit": "iterations/s"}
 
-    # GPUs that actually ran (one node: distinct device indices over all workers)
+    # GPUs that actually ran (one node: distinct device indices over all workers) and the communicator's own world size
     if mode == "ranks":
         n_devices = len(set(int(x) for x in rdzv.all_gather_array(np.array([devices[0]], dtype=np.int64)).ravel()))
+        rccl_ranks = int(rdzv.all_reduce(np.array([tr.rccl_ranks if tr.name == "rccl" else 0]), "min")[0])
     else:
         n_devices = len(set(devices))
+        rccl_ranks = grp.rccl_ranks if (mode == "threads" and grp.exchange == "rccl") else 0
     if rank == 0:
-        total_iters = ITERS_PER_STEP * args.steps * workers
+        total_iters = iters_worker * args.steps * workers
         value = total_iters / dt
         gpu_ms = tim["rows_ms"] + tim["cols_ms"] + tim["finalize_ms"]
         sim.compute_powerspec()                   # the evaluation at init paid the module load; this one is warm
+        wl = (f"configs[3]: {N}^2 grid, Np={Np}, 100000 iters/step in total = {iters_worker} per GPU" if strong else
+              f"configs[1]: {N}^2 grid, Np={Np}, {iters_worker} iters/step/GPU")
+        exchange = {"steps_rccl": acc["rccl_steps"], "steps_host": acc["host_steps"]} if workers > 1 else None
+        if exchange is not None and ex_dev.size:
+            exchange["device_ms_per_step"] = {"mean": float(ex_dev.mean()), "min": float(ex_dev.min()), "max": float(ex_dev.max()),
+                                              "note": "HIP events around the collectives on each worker's stream: transfer + the wait for the slowest peer"}
+        if exchange is not None and acc["host_steps"]:
+            exchange["host_ms_per_step"] = acc["exchange_wall_ms"] / acc["host_steps"]
         line = {
             "metric": f"Monte-Carlo iterations/sec ({N}^2 grid)", "value": value, "unit": "iterations/s",
             "n_gpus": n_devices, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64" if args.precision == "f64" else "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {N}^2 grid, Np={Np}, {ITERS_PER_STEP} iters/step/GPU, {args.ao_mode} von Karman spectrum, "
-                                   "device generator (Philox4x32-7-seeded xoshiro128+ streams, Box-Muller)",
+            "config": {"workload": wl + f", {args.ao_mode} von Karman spectrum, device generator (Philox4x32-7-seeded xoshiro128+ streams, Box-Muller)",
                        "arithmetic": ("complex128 transform and float64 detector sums" if args.precision == "f64" else "complex64 transform, float64 detector sums")
                                      + "; the device generator's normals are float32 (24-bit uniforms, hardware log/sqrt/sin/cos), "
                                        "coloured in float32 and widened; host-coefficient (parity) mode is float64 throughout",
-                       "iters_per_step_per_gpu": ITERS_PER_STEP, "kernel_path": {0: "direct", 1: "wave-fft", 2: "chirp-z", 3: "lanes50-fft"}[h.kernel_path()],
+                       "iters_per_step_per_gpu": iters_worker, "kernel_path": {0: "direct", 1: "wave-fft", 2: "chirp-z", 3: "lanes50-fft"}[h.kernel_path()],
                        "launch": {"single": "one process, one GPU", "threads": f"one process, {workers} worker threads",
                                   "ranks": f"{workers} processes (launcher), fast_amd.rendezvous"}[mode],
                        "workers": workers, "devices": devices if mode != "ranks" else "LOCAL_RANK per process",
-                       "parallelism": f"realisations sharded over {workers} worker(s) on {n_devices} GPU(s)", "result_exchange": exchange,
+                       "parallelism": f"realisations sharded over {workers} worker(s) on {n_devices} GPU(s)", "result_exchange": exchange_name(),
+                       "rccl_ranks": rccl_ranks,
                        "histogram_total": None if hist_total is None else int(np.sum(hist_total))},
-            "roofline": roofline(args, N, Np, tim, args.steps, workers, value / workers),
-            "pipeline": {"gpu_busy_ms_per_step_per_worker": gpu_ms / args.steps / workers, "rows_ms": tim["rows_ms"] / args.steps / workers,
+            "roofline": roofline(args, N, Np, tim, args.steps, workers, iters_worker),
+            "pipeline": {"gpu_busy_ms_per_step_per_worker": gpu_ms / args.steps / workers,
+                         "gpu_busy_ms_per_step": {"min_worker": float(busy.mean(0).min()), "max_worker": float(busy.mean(0).max()),
+                                                  "per_worker": [float(x) for x in busy.mean(0)]},
+                         "rows_ms": tim["rows_ms"] / args.steps / workers,
                          "cols_ms": tim["cols_ms"] / args.steps / workers, "finalize_ms": tim["finalize_ms"] / args.steps / workers,
                          "init_s": init_s, "powerspec_kernel_ms_warm": sim.powerspec_kernel_ms},
         }
+        if exchange is not None:
+            line["exchange"] = exchange
         if sustained:
             line["sustained"] = sustained
-        if mode == "single" and not args.no_extras:
+        if mode == "single" and not args.no_extras and not strong:
             line["extras"] = extras(args, devices[0])
         if mode == "single" and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sim)
@@ -444,8 +503,9 @@ def main():
             pass
         print(json.dumps(line), flush=True)
     sync_all()
-    if tr is not None and "did not return" in getattr(tr, "why", ""):
-        os._exit(0)        # a communicator init that never returned still holds a thread: do not wait for it at exit
+    if dist.stuck_threads():
+        sys.stdout.flush()
+        os._exit(0)        # a thread is still blocked inside RCCL although its communicator was aborted: skip the runtime teardown
 
 
 if __name__ == "__main__":

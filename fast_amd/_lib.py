@@ -22,7 +22,8 @@ EXPORTS = [
     "fastmc_set_layer_screens", "fastmc_temporal_chunk", "fastmc_link_metrics", "fastmc_set_results",
     "fastmc_powerspec_terms", "fastmc_powerspec_set", "fastmc_powerspec_get",
     "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_init_all", "fastmc_comm_world", "fastmc_comm_gather",
-    "fastmc_comm_gather_all", "fastmc_comm_destroy",
+    "fastmc_comm_gather_all", "fastmc_comm_destroy", "fastmc_comm_abort", "fastmc_last_exchange_ms",
+    "fastmc_run_async", "fastmc_wait",
 ]
 
 
@@ -97,6 +98,10 @@ def lib():
     L.fastmc_comm_world.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.fastmc_comm_gather_all.argtypes = [C.POINTER(vp), C.c_int, i64, dp, C.POINTER(i64), C.c_double, C.c_double, C.c_int]
     L.fastmc_comm_destroy.argtypes = [vp]
+    L.fastmc_comm_abort.argtypes = [vp]
+    L.fastmc_last_exchange_ms.argtypes = [vp, dp]
+    L.fastmc_run_async.argtypes = [vp, u64, i64, i64, C.c_double, C.c_int]
+    L.fastmc_wait.argtypes = [vp, dp]
     for name in EXPORTS:
         if name not in ("fastmc_last_error", "fastmc_destroy"):
             getattr(L, name).restype = C.c_int
@@ -125,13 +130,21 @@ def device_count():
 
 
 def default_device():
-    """LOCAL_RANK (one process per GPU under a launcher), folded onto the visible devices when the launcher
-    also restricted them per rank; 0 otherwise."""
+    """LOCAL_RANK (one process per GPU under a launcher); 0 otherwise.  When the launcher ALSO restricted the visible
+    devices per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES set, e.g. one device each) the local rank is folded onto
+    what is visible; otherwise a local rank beyond the visible devices is an error -- several ranks must never land on
+    one GPU silently and be reported as N GPUs."""
     lr = int(os.environ.get("LOCAL_RANK", "0"))
     if lr > 0:
         n = device_count()
-        if n > 0:
-            lr %= n
+        if n > 0 and lr >= n:
+            if os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES"):
+                lr %= n
+            elif os.environ.get("FASTMC_ALLOW_SHARED_DEVICE", "0") not in ("", "0"):
+                lr %= n            # tests: several ranks on a 1-GPU box, said so explicitly
+            else:
+                raise FastMCError(f"LOCAL_RANK={lr} but only {n} GPU(s) visible: start one rank per GPU, restrict the devices "
+                                  "per rank with HIP_VISIBLE_DEVICES, or name the device with GPU_DEVICE")
     return lr
 
 
@@ -183,6 +196,23 @@ class Handle:
         out = np.empty(2 * n_real * (2 if coherent else 1), dtype=np.float64)
         _chk(lib().fastmc_run(self._h, int(seed) & (2 ** 64 - 1), int(real0), int(n_real), _dptr(la), float(logamp_var),
                               int(bool(coherent)), _dptr(out)))
+        return out.view(np.complex128) if coherent else out
+
+    def run_async(self, seed, real0, n_real, logamp_var=0.0, coherent=False):
+        """Enqueue the run and return at once: the results stay on the device (log-amplitudes drawn there).  `wait()`
+        fetches them; an exchange (`comm_gather`, `_lib.comm_gather_all`) is ordered behind the kernels on the same
+        stream, so a sharded step synchronises once."""
+        _chk(lib().fastmc_run_async(self._h, int(seed) & (2 ** 64 - 1), int(real0), int(n_real), float(logamp_var), int(bool(coherent))))
+        self._async_shape = (int(n_real), bool(coherent))
+
+    def wait(self, fetch=True):
+        """Wait for the handle's stream; with fetch, return the results of the last run as `run` would have."""
+        if not fetch:
+            _chk(lib().fastmc_wait(self._h, None))
+            return None
+        n_real, coherent = self._async_shape
+        out = np.empty(2 * n_real * (2 if coherent else 1), dtype=np.float64)
+        _chk(lib().fastmc_wait(self._h, _dptr(out)))
         return out.view(np.complex128) if coherent else out
 
     def run_coeffs(self, coeff_re, coeff_im, logamp, coherent=False, sh_re=None, sh_im=None):
@@ -289,6 +319,15 @@ class Handle:
 
     def comm_destroy(self):
         _chk(lib().fastmc_comm_destroy(self._h))
+
+    def comm_abort(self):
+        """ncclCommAbort on this device's communicator (never waits for peers); wakes a blocked exchange of the device."""
+        _chk(lib().fastmc_comm_abort(self._h))
+
+    def last_exchange_ms(self):
+        ms = C.c_double(0.0)
+        _chk(lib().fastmc_last_exchange_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def comm_gather(self, n_local, world_size, hist_range=None, powers=True):
         allp = np.empty(n_local * world_size, dtype=np.float64) if powers else None

@@ -6,7 +6,10 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -139,6 +142,12 @@ struct fastmc_ctx {
   // RCCL exchange buffer (the communicator itself belongs to the device, see DeviceComm)
   double* gather_buf = nullptr;
   size_t gather_cap = 0;
+  // fastmc_run_async: kernels enqueued, events not read yet (fastmc_wait / the exchange finish the bookkeeping)
+  bool pending = false;
+  size_t last_out_doubles = 0;    // size of the last run's result vector in `out`
+  hipEvent_t ex_a = nullptr, ex_b = nullptr;   // around the collectives of the last exchange
+  bool ex_recorded = false;
+  double ex_ms = 0;
 };
 
 static void cs_turns(double t, double* c, double* s) {
@@ -213,6 +222,19 @@ static void timing_end(fastmc_ctx* h) {   // after stream sync
     hipEventElapsedTime(&ms, h->spans.front().a, h->spans.back().b);
     h->t_ms[0] = ms;
     h->t_n[0] = (int64_t)h->spans.size();
+  }
+}
+
+// after any synchronisation of the handle's stream: read the events of an asynchronous run / of the last exchange
+static void finish_pending(fastmc_ctx* h) {
+  if (h->pending) {
+    timing_end(h);
+    h->pending = false;
+  }
+  if (h->ex_recorded) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->ex_a, h->ex_b) == hipSuccess) h->ex_ms = ms;
+    h->ex_recorded = false;
   }
 }
 
@@ -416,6 +438,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  finish_pending(h);
   // back to the state fastmc_create leaves: problem unset, results forgotten, options at their defaults; buffers kept
   h->have_spec = h->have_pupil = h->have_sh = h->have_ps = false;
   h->last_n_iter = 0;
@@ -443,6 +466,8 @@ static void destroy_now(fastmc_ctx* h) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (auto e : h->pool) hipEventDestroy(e);
+  if (h->ex_a) hipEventDestroy(h->ex_a);
+  if (h->ex_b) hipEventDestroy(h->ex_b);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1141,6 +1166,7 @@ struct RunSpec {
   int coherent;
   double* out;              // host
   double* phs;              // host
+  bool async = false;       // fastmc_run_async: no host copy, no wait
 };
 
 template <class R>
@@ -1299,16 +1325,25 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     }
     HIPCHK(hipGetLastError());
   }
+  if (S.epi == 0) { h->last_n_iter = 2 * S.n_real; h->last_coherent = S.coherent; h->last_out_doubles = out_need; }
+  if (S.async) {          // results stay on the device; fastmc_wait or the exchange synchronises
+    h->pending = true;
+    return 0;
+  }
   if (S.epi == 0)
     HIPCHK(hipMemcpyAsync(S.out, h->out, out_need * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   timing_end(h);
-  if (S.epi == 0) { h->last_n_iter = 2 * S.n_real; h->last_coherent = S.coherent; }
   return 0;
 }
 
 static int run_checked(fastmc_ctx* h, const RunSpec& S) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
+  if (h->pending) {       // an asynchronous run nobody waited for: its events are read before they are reused
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    finish_pending(h);
+  }
   if (!h->have_spec || !h->have_pupil) return fail(FASTMC_ESTATE, "set_spectrum and set_pupil must be called first");
   if (S.n_real <= 0) return fail(FASTMC_EINVAL, "n_real must be positive");
   if (S.real0 < 0) return fail(FASTMC_EINVAL, "real0 must be non-negative");
@@ -1328,6 +1363,27 @@ extern "C" int fastmc_run(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_r
   if (!(logamp_var >= 0.0)) return fail(FASTMC_EINVAL, "logamp_var must be >= 0");
   RunSpec S{0, 0, seed, real0, n_real, nullptr, nullptr, nullptr, nullptr, logamp, logamp_var, coherent, out, nullptr};
   return run_checked(h, S);
+}
+#endif
+
+#if FMC_TU == 0
+extern "C" int fastmc_run_async(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real, double logamp_var, int coherent) {
+  if (!(logamp_var >= 0.0)) return fail(FASTMC_EINVAL, "logamp_var must be >= 0");
+  RunSpec S{0, 0, seed, real0, n_real, nullptr, nullptr, nullptr, nullptr, nullptr, logamp_var, coherent, nullptr, nullptr};
+  S.async = true;
+  return run_checked(h, S);
+}
+
+extern "C" int fastmc_wait(fastmc_t* h, double* out) {
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (out) {
+    if (h->last_n_iter <= 0 || !h->last_out_doubles) return fail(FASTMC_ESTATE, "no run results on the device");
+    HIPCHK(hipMemcpyAsync(out, h->out, h->last_out_doubles * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  finish_pending(h);
+  return 0;
 }
 #endif
 
@@ -1462,6 +1518,7 @@ extern "C" int fastmc_set_results(fastmc_t* h, const double* values, int64_t n_i
   HIPCHK(hipStreamSynchronize(h->stream));
   h->last_n_iter = n_iter;
   h->last_coherent = coherent ? 1 : 0;
+  h->last_out_doubles = need;
   return 0;
 }
 #endif
@@ -1801,6 +1858,36 @@ struct DeviceComm {
 };
 static DeviceComm g_comm[64];
 static std::mutex g_comm_mu;
+static std::atomic<int> g_abort_gen[64];      // bumped by fastmc_comm_abort: wakes a stalled exchange of that device
+
+// FASTMC_TEST_STALL_GATHER=1: the exchange entry points block here, without touching RCCL, until fastmc_comm_abort is
+// called for one of the devices, and then fail -- the fault that the deadline / fall-back tests inject.
+static bool stall_requested() {
+  const char* e = getenv("FASTMC_TEST_STALL_GATHER");
+  return e && e[0] && e[0] != '0';
+}
+static int stall_until_abort(const std::vector<int>& devices) {
+  std::vector<int> gen(devices.size());
+  for (size_t i = 0; i < devices.size(); ++i) gen[i] = g_abort_gen[devices[i] & 63].load();
+  for (;;) {
+    for (size_t i = 0; i < devices.size(); ++i)
+      if (g_abort_gen[devices[i] & 63].load() != gen[i]) return fail(FASTMC_ECOMM, "exchange aborted (FASTMC_TEST_STALL_GATHER)");
+    usleep(500);
+  }
+}
+static int exchange_begin(fastmc_ctx* h) {
+  if (!h->ex_a) {
+    HIPCHK(hipEventCreate(&h->ex_a));
+    HIPCHK(hipEventCreate(&h->ex_b));
+  }
+  HIPCHK(hipEventRecord(h->ex_a, h->stream));
+  return 0;
+}
+static int exchange_end(fastmc_ctx* h) {
+  HIPCHK(hipEventRecord(h->ex_b, h->stream));
+  h->ex_recorded = true;
+  return 0;
+}
 static DeviceComm device_comm(int device) {
   std::lock_guard<std::mutex> g(g_comm_mu);
   return g_comm[device & 63];
@@ -1827,7 +1914,14 @@ extern "C" int fastmc_comm_init(fastmc_t* h, const uint8_t id128[128], int world
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   ncclComm_t c = nullptr;
+  const int gen = g_abort_gen[h->device & 63].load();
   NCCLCHK(g_rccl.CommInitRank(&c, world_size, id, rank));
+  if (g_abort_gen[h->device & 63].load() != gen) {
+    // fastmc_comm_abort was called while the clique was being built (the caller's deadline passed and it took the host
+    // path): the communicator must not appear now
+    g_rccl.CommAbort(c);
+    return fail(FASTMC_ECOMM, "communicator aborted while it was being initialised");
+  }
   std::lock_guard<std::mutex> g(g_comm_mu);
   g_comm[h->device & 63] = DeviceComm{c, world_size, rank};
   return 0;
@@ -1847,7 +1941,14 @@ extern "C" int fastmc_comm_init_all(fastmc_t* const* handles, int n) {
   }
   TRY(load_rccl());
   std::vector<ncclComm_t> comms(n, nullptr);
+  std::vector<int> gen(n);
+  for (int i = 0; i < n; ++i) gen[i] = g_abort_gen[devs[i] & 63].load();
   NCCLCHK(g_rccl.CommInitAll(comms.data(), n, devs.data()));
+  for (int i = 0; i < n; ++i)
+    if (g_abort_gen[devs[i] & 63].load() != gen[i]) {       // aborted meanwhile (see fastmc_comm_init)
+      for (int j = 0; j < n; ++j) g_rccl.CommAbort(comms[j]);
+      return fail(FASTMC_ECOMM, "communicators aborted while they were being initialised");
+    }
   std::lock_guard<std::mutex> g(g_comm_mu);
   for (int i = 0; i < n; ++i) g_comm[devs[i] & 63] = DeviceComm{comms[i], n, i};
   return 0;
@@ -1881,21 +1982,21 @@ static int comm_enqueue_hist(fastmc_ctx* h, const DeviceComm& dc, int nbins) {
 extern "C" int fastmc_comm_gather(fastmc_t* h, int64_t n_local, double* all_powers, int64_t* hist, double lo_db,
                                   double hi_db, int nbins) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
+  if (stall_requested()) return stall_until_abort({h->device});
   const DeviceComm dc = device_comm(h->device);
   if (!dc.comm) return fail(FASTMC_ESTATE, "fastmc_comm_init not called for this device");
   if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds the last run");
   HIPCHK(hipSetDevice(h->device));
-  if (all_powers) {
-    TRY(grow(&h->gather_buf, &h->gather_cap, (size_t)n_local * dc.world));
-    TRY(comm_enqueue_gather(h, dc, n_local, true));
-    HIPCHK(hipMemcpyAsync(all_powers, h->gather_buf, (size_t)n_local * dc.world * 8, hipMemcpyDeviceToHost, h->stream));
-  }
-  if (hist) {
-    TRY(histogram_device(h, lo_db, hi_db, nbins));
-    TRY(comm_enqueue_hist(h, dc, nbins));
-    HIPCHK(hipMemcpyAsync(hist, h->hist, ((size_t)nbins + 2) * 8, hipMemcpyDeviceToHost, h->stream));
-  }
+  if (all_powers) TRY(grow(&h->gather_buf, &h->gather_cap, (size_t)n_local * dc.world));
+  if (hist) TRY(histogram_device(h, lo_db, hi_db, nbins));       // local histogram kernel: before the timed exchange
+  TRY(exchange_begin(h));
+  if (all_powers) TRY(comm_enqueue_gather(h, dc, n_local, true));
+  if (hist) TRY(comm_enqueue_hist(h, dc, nbins));
+  TRY(exchange_end(h));
+  if (all_powers) HIPCHK(hipMemcpyAsync(all_powers, h->gather_buf, (size_t)n_local * dc.world * 8, hipMemcpyDeviceToHost, h->stream));
+  if (hist) HIPCHK(hipMemcpyAsync(hist, h->hist, ((size_t)nbins + 2) * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  finish_pending(h);
   return 0;
 }
 #endif
@@ -1904,6 +2005,11 @@ extern "C" int fastmc_comm_gather(fastmc_t* h, int64_t n_local, double* all_powe
 extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n_local, double* all_powers, int64_t* hist,
                                       double lo_db, double hi_db, int nbins) {
   if (!handles || n < 1 || n > 64) return fail(FASTMC_EINVAL, "bad argument");
+  if (stall_requested()) {
+    std::vector<int> devs;
+    for (int i = 0; i < n; ++i) if (handles[i]) devs.push_back(handles[i]->device);
+    return stall_until_abort(devs);
+  }
   std::vector<DeviceComm> dcs(n);
   for (int i = 0; i < n; ++i) {
     fastmc_ctx* h = handles[i];
@@ -1913,11 +2019,13 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
       return fail(FASTMC_ESTATE, "handles do not match the communicators of fastmc_comm_init_all (same handles, same order)");
     if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds a handle's last run");
   }
+  for (int i = 0; i < n; ++i) {
+    HIPCHK(hipSetDevice(handles[i]->device));
+    if (all_powers) TRY(grow(&handles[i]->gather_buf, &handles[i]->gather_cap, (size_t)n_local * n));
+    if (hist) TRY(histogram_device(handles[i], lo_db, hi_db, nbins));     // local histogram kernels: before the timed exchange
+    TRY(exchange_begin(handles[i]));
+  }
   if (all_powers) {
-    for (int i = 0; i < n; ++i) {
-      HIPCHK(hipSetDevice(handles[i]->device));
-      TRY(grow(&handles[i]->gather_buf, &handles[i]->gather_cap, (size_t)n_local * n));
-    }
     NCCLCHK(g_rccl.GroupStart());
     int rc = 0;
     for (int i = 0; i < n && rc == 0; ++i) rc = comm_enqueue_gather(handles[i], dcs[i], n_local, true);
@@ -1926,16 +2034,16 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
     if (ge != ncclSuccess) return fail(FASTMC_ECOMM, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
   }
   if (hist) {
-    for (int i = 0; i < n; ++i) {
-      HIPCHK(hipSetDevice(handles[i]->device));
-      TRY(histogram_device(handles[i], lo_db, hi_db, nbins));
-    }
     NCCLCHK(g_rccl.GroupStart());
     int rc = 0;
     for (int i = 0; i < n && rc == 0; ++i) rc = comm_enqueue_hist(handles[i], dcs[i], nbins);
     ncclResult_t ge = g_rccl.GroupEnd();
     if (rc) return rc;
     if (ge != ncclSuccess) return fail(FASTMC_ECOMM, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
+  }
+  for (int i = 0; i < n; ++i) {
+    HIPCHK(hipSetDevice(handles[i]->device));
+    TRY(exchange_end(handles[i]));
   }
   // every rank holds the same gathered data: the host copy comes from rank 0, the others are only waited for
   fastmc_ctx* h0 = handles[0];
@@ -1945,7 +2053,33 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
   for (int i = 0; i < n; ++i) {
     HIPCHK(hipSetDevice(handles[i]->device));
     HIPCHK(hipStreamSynchronize(handles[i]->stream));
+    finish_pending(handles[i]);
   }
+  return 0;
+}
+#endif
+
+#if FMC_TU == 0
+extern "C" int fastmc_comm_abort(fastmc_t* h) {
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  ncclComm_t c = nullptr;
+  {
+    std::lock_guard<std::mutex> g(g_comm_mu);
+    c = g_comm[h->device & 63].comm;
+    g_comm[h->device & 63] = DeviceComm();
+  }
+  g_abort_gen[h->device & 63].fetch_add(1);
+  if (c && g_rccl.lib) {
+    hipSetDevice(h->device);
+    ncclResult_t r = g_rccl.CommAbort(c);
+    if (r != ncclSuccess) return fail(FASTMC_ECOMM, std::string("ncclCommAbort: ") + g_rccl.GetErrorString(r));
+  }
+  return 0;
+}
+
+extern "C" int fastmc_last_exchange_ms(fastmc_t* h, double* ms) {
+  if (!h || !ms) return fail(FASTMC_EINVAL, "null argument");
+  *ms = h->ex_ms;
   return 0;
 }
 #endif

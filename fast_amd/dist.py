@@ -18,13 +18,66 @@ Transports of the final exchange (same interface: .world, .rank, .gather(local_v
 `make_transport` decides between them COLLECTIVELY: every rank reports whether its communicator came up and all take
 the host path unless all succeeded, so no rank is ever left waiting in a collective the others skipped.
 """
+import atexit
 import logging
 import os
+import sys
 import threading
+import time
 
 import numpy as np
 
 logger = logging.getLogger(__name__)
+
+# ---- deadlines around calls that may block inside RCCL
+_LEFT_BEHIND = []          # daemon threads a deadline gave up on; normally they return once their communicator is aborted
+
+
+def call_with_deadline(fn, timeout):
+    """fn() on a daemon thread; (True, value) when it returned in time, (False, reason) when it raised or is still running
+    after `timeout` seconds.  A thread that is still running is left behind: the caller aborts what it is blocked in
+    (fastmc_comm_abort never waits for peers), which normally lets it return."""
+    box = {}
+
+    def work():
+        try:
+            box["value"] = fn()
+        except BaseException as e:
+            box["err"] = f"{type(e).__name__}: {e}"
+    th = threading.Thread(target=work, daemon=True, name="fastmc-deadline")
+    th.start()
+    th.join(timeout)
+    if th.is_alive():
+        _LEFT_BEHIND.append(th)
+        return False, f"no answer within {timeout:g} s"
+    if "err" in box:
+        return False, box["err"]
+    return True, box["value"]
+
+
+def exchange_timeout():
+    """Deadline of one result exchange in seconds (it starts when the exchange is issued, i.e. it covers the wait for the
+    step's kernels too): FASTMC_EXCHANGE_TIMEOUT, default 120."""
+    return float(os.environ.get("FASTMC_EXCHANGE_TIMEOUT", "120"))
+
+
+def stuck_threads():
+    """Deadline threads that never came back (still inside RCCL after their communicator was aborted)."""
+    return [t for t in _LEFT_BEHIND if t.is_alive()]
+
+
+def _exit_hook():
+    # A thread that is still blocked inside the RCCL / HIP runtime would make interpreter or runtime teardown wait for
+    # ever.  Everything the process had to say has been said by now: flush and leave without the teardown.
+    if stuck_threads():
+        try:
+            sys.stdout.flush()
+            sys.stderr.flush()
+        finally:
+            os._exit(getattr(_exit_hook, "code", 0))
+
+
+atexit.register(_exit_hook)
 
 
 def shard_ranges(n_real_total, world):
@@ -64,6 +117,7 @@ def assemble(parts, complex_out=False):
 class HostTransport:
     """Exchange through the rendezvous sockets (host memory)."""
     name = "host"
+    rccl_ranks = 0
 
     def __init__(self, rdzv):
         self.rdzv, self.world, self.rank = rdzv, rdzv.world, rdzv.rank
@@ -79,33 +133,67 @@ class HostTransport:
         return self.rdzv.all_reduce(np.asarray(local_hist, dtype=np.int64), "sum")
 
 
-class RcclTransport:
-    """The exchange runs inside libfastmc.so on the handle's device buffers (fastmc_comm_gather)."""
+class RcclTransport(HostTransport):
+    """The exchange runs inside libfastmc.so on the handle's device buffers (fastmc_comm_gather): ncclAllGather of the
+    powers and ncclAllReduce of the histogram over xGMI.  Every exchange runs under a deadline and ends with a collective
+    verdict over the rendezvous (did EVERY rank's exchange come back?); on a miss every rank aborts its communicator,
+    fetches its own vector and the step -- and every later one -- goes through the host sockets (`degrade`)."""
     name = "rccl"
 
-    def __init__(self, rdzv):
-        self.rdzv, self.world, self.rank = rdzv, rdzv.world, rdzv.rank
+    def __init__(self, rdzv, rccl_ranks=0):
+        super().__init__(rdzv)
+        self.rccl_ranks = rccl_ranks      # world size the communicator itself reports
+        self.why = ""
+
+    def degrade(self, handle, why):
+        self.name, self.why, self.rccl_ranks = "host", f"RCCL exchange given up: {why}", 0
+        if self.rank == 0:
+            logger.warning(f"RCCL exchange gave no result on every rank ({why}); communicators aborted, host exchange from now on")
+        try:
+            handle.comm_abort()            # ncclCommAbort: never waits for peers; wakes a blocked exchange
+        except Exception as e:
+            logger.warning(f"ncclCommAbort: {e}")
+
+    def device_exchange(self, handle, nval, hist_range=None, powers=True):
+        """fastmc_comm_gather under the deadline + the collective verdict.  Returns (ok, all_values | None, hist | None);
+        after ok == False the transport is a host transport and the caller exchanges the vector `handle.wait()` returns."""
+        ok, val = call_with_deadline(lambda: handle.comm_gather(nval, self.world, hist_range, powers=powers), exchange_timeout())
+        flags = self.rdzv.all_gather_array(np.array([1 if ok else 0], dtype=np.int32)).ravel()
+        if flags.all():
+            return True, val[0], val[1]
+        bad = np.flatnonzero(flags == 0).tolist()
+        self.degrade(handle, val if not ok else f"rank(s) {bad} reported a failed exchange")
+        return False, None, None
 
     def gather(self, local, handle):
+        if self.name != "rccl":
+            return HostTransport.gather(self, local)
         local = np.ascontiguousarray(local)
         cplx = np.iscomplexobj(local)
         nval = local.size * (2 if cplx else 1)                   # float64 values resident on the device
-        allp, _ = handle.comm_gather(nval, self.world, None)
+        ok, allp, _ = self.device_exchange(handle, nval)
+        if not ok:
+            return HostTransport.gather(self, local)
         allp = allp.reshape(self.world, nval)
         return [allp[r].view(np.complex128) if cplx else allp[r] for r in range(self.world)]
 
     def gather_with_hist(self, local, handle, hist_range):
         """Powers and the dB histogram of the handle's last run in one call (ncclAllGather + ncclAllReduce)."""
         nval = np.asarray(local).size * (2 if np.iscomplexobj(local) else 1)
-        allp, hist = handle.comm_gather(nval, self.world, hist_range)
-        return allp.reshape(self.world, nval), hist
+        if self.name == "rccl":
+            ok, allp, hist = self.device_exchange(handle, nval, hist_range)
+            if ok:
+                return allp.reshape(self.world, nval), hist
+        parts = HostTransport.gather(self, local)
+        return np.stack([np.asarray(p).view(np.float64) for p in parts]), self.reduce_hist(handle.histogram(*hist_range))
 
     def device_hist(self, handle, hist_range):
         """Global dB histogram of the handle's last run: histogram kernel + ncclAllReduce(sum, uint64) on the device."""
-        return handle.comm_gather(1, self.world, hist_range, powers=False)[1]
-
-    def reduce_hist(self, local_hist):
-        return self.rdzv.all_reduce(np.asarray(local_hist, dtype=np.int64), "sum")
+        if self.name == "rccl":
+            ok, _, hist = self.device_exchange(handle, 1, hist_range, powers=False)
+            if ok:
+                return hist
+        return self.reduce_hist(handle.histogram(*hist_range))
 
 
 _TRANSPORT = {}          # device -> transport of this process (the communicator belongs to the device)
@@ -119,6 +207,11 @@ def make_transport(handle, rdzv, rccl_timeout=None):
     if key in _TRANSPORT:
         return _TRANSPORT[key]
     timeout = float(os.environ.get("FASTMC_RCCL_TIMEOUT", "90")) if rccl_timeout is None else rccl_timeout
+    if os.environ.get("FASTMC_TEST_STALL_GATHER", "0") not in ("", "0"):
+        # fault injection (tests): behave as if the clique were up; fastmc_comm_gather blocks until it is aborted
+        tr = RcclTransport(rdzv, rdzv.world)
+        _TRANSPORT[key] = tr
+        return tr
     # 1) rank 0 creates the unique id; everybody learns whether that worked
     msg = b"\x00"
     if rdzv.rank == 0:
@@ -133,27 +226,19 @@ def make_transport(handle, rdzv, rccl_timeout=None):
         why = msg[1:].decode(errors="replace")
     else:
         # 2) every rank initialises its communicator under a timeout and reports; all-or-nothing
-        box = {}
-
-        def _init():
-            try:
-                handle.comm_init(msg[1:], rdzv.world, rdzv.rank)
-                box["ok"] = True
-            except Exception as e:
-                box["err"] = str(e)
-        th = threading.Thread(target=_init, daemon=True)
-        th.start()
-        th.join(timeout)
-        mine = bool(box.get("ok"))
+        mine, val = call_with_deadline(lambda: handle.comm_init(msg[1:], rdzv.world, rdzv.rank), timeout)
         flags = rdzv.all_gather_array(np.array([1 if mine else 0], dtype=np.int32)).ravel()
         ok = bool(flags.all())
         if not ok:
-            why = box.get("err") or ("ncclCommInitRank did not return in time" if not mine else
-                                     f"rank(s) {np.flatnonzero(flags == 0).tolist()} failed")
-            if mine:       # peers may be gone: never wait for the teardown of a half-built clique
-                threading.Thread(target=lambda: handle.comm_destroy(), daemon=True).start()
+            why = val if not mine else f"rank(s) {np.flatnonzero(flags == 0).tolist()} failed"
+            # a half-built clique is ABORTED, never destroyed: ncclCommAbort does not wait for peers that may be gone or
+            # still initialising, and an init that returns later sees the abort and drops its communicator (fastmc_comm_init)
+            try:
+                handle.comm_abort()
+            except Exception:
+                pass
     if ok:
-        tr = RcclTransport(rdzv)
+        tr = RcclTransport(rdzv, handle.comm_world()[0])
     else:
         if rdzv.rank == 0:
             logger.warning(f"RCCL exchange unavailable ({why}); results are exchanged through the host")
@@ -170,6 +255,37 @@ def run_sharded(n_real_total, compute_local, transport, handle=None):
     local = np.asarray(compute_local(real0, n_local))
     parts = transport.gather(local, handle)
     return assemble(parts, complex_out=np.iscomplexobj(local))
+
+
+def step_sharded(handle, transport, seed, real_base, n_real_total, logamp_var=0.0, coherent=False, hist_range=None):
+    """One sharded run of realisations [real_base, real_base + n_real_total) with the device generator: this rank's
+    contiguous piece, then ONE exchange.  On the RCCL transport the step synchronises once -- the kernels are enqueued
+    without waiting (fastmc_run_async) and the all-gather / histogram all-reduce follow on the same stream -- under the
+    deadline and the collective verdict of RcclTransport.device_exchange; a missed deadline finishes the step, and all
+    later ones, on the host sockets.  Returns (full vector, global histogram | None, info dict)."""
+    real0, n_local = shard_range(n_real_total, transport.world, transport.rank)
+    nval = 2 * n_local * (2 if coherent else 1)
+    info = {"exchange": transport.name, "exchange_device_ms": 0.0}
+    t0 = time.perf_counter()
+    if transport.name == "rccl":
+        handle.run_async(seed, real_base + real0, n_local, logamp_var, coherent)
+        ok, allp, hist = transport.device_exchange(handle, nval, hist_range)
+        if ok:
+            allp = allp.reshape(transport.world, nval)
+            parts = [allp[r].view(np.complex128) if coherent else allp[r] for r in range(transport.world)]
+            info["exchange_device_ms"] = handle.last_exchange_ms()
+            info["wall_ms"] = (time.perf_counter() - t0) * 1e3
+            return assemble(parts, complex_out=coherent), hist, info
+        local = handle.wait()                         # the device's own vector is still resident
+        info["exchange"] = "host"
+    else:
+        local = handle.run(seed, real_base + real0, n_local, None, logamp_var, coherent)
+    t1 = time.perf_counter()
+    parts = transport.gather(local, handle)           # host sockets (a degraded RCCL transport dispatches there too)
+    hist = None if hist_range is None else transport.reduce_hist(handle.histogram(*hist_range))
+    info["exchange_host_ms"] = (time.perf_counter() - t1) * 1e3
+    info["wall_ms"] = (time.perf_counter() - t0) * 1e3
+    return assemble(parts, complex_out=coherent), hist, info
 
 
 def histogram_sharded(local_hist, transport):

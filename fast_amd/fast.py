@@ -167,7 +167,7 @@ class Fast():
         self.powerspec_kernel_ms = out["kernel_ms"]
         self._per_layer = None
         if per_layer:
-            self._per_layer = _lib.powerspec(prob.N, *args, per_layer=True, device=self.device, **kw)["powerspec_per_layer"]
+            self._per_layer = self._fetch_per_layer()
         if self.subharmonics:
             self.powerspec_subharm, self._sh_fx, self._sh_fy, self._sh_df, sh = host.subharm_spectrum(prob)
             # the bookkeeping of fast.py:494-526, as the reference leaves it on the object
@@ -181,9 +181,28 @@ class Fast():
         if self.temporal:
             self.pixel_shifts = prob.temporal.pixel_shifts
 
+    def _ps_args(self):
+        prob, p, atm = self._prob, self.params, self._prob.atm
+        args = (prob.dx, prob.wvl, p['L0'], p['l0'], prob.ao_mode, p['ALIAS'], p['NOISE'], prob.d_wfs, p['TLOOP'], p['TEXP'],
+                atm.dtheta, atm.cn2, atm.h, atm.wind_vector, prob.pup.pupil_filter, prob.simpson_w)
+        kw = dict(lf_mask=None, modal=prob.modal, modal_mult=prob.modal_mult, zmax=prob.zmax, D_ground=p['D_GROUND'])
+        return args, kw
+
+    def _fetch_per_layer(self):
+        """(L, N, N) per-layer grids by the stand-alone evaluation: the handles' colouring tables, the cached grids and the
+        scalars on the object are left alone (a spectrum installed through the `powerspec` setter stays installed)."""
+        args, kw = self._ps_args()
+        pl = _lib.powerspec(self._prob.N, *args, per_layer=True, device=self.device, **kw)["powerspec_per_layer"]
+        pl.flags.writeable = False
+        return pl
+
     def _grid(self, which):
+        """Host copy of a grid kept on the device, read-only: the device tables are what run() uses, so an in-place edit
+        of the copy would be silently ignored -- replace the spectrum through the `powerspec` setter instead."""
         if which not in self._grids:
-            self._grids[which] = self._handle.powerspec_get(which)
+            g = self._handle.powerspec_get(which)
+            g.flags.writeable = False
+            self._grids[which] = g
         return self._grids[which]
 
     @property
@@ -199,6 +218,8 @@ class Fast():
         if ps.shape != (self.Npxls, self.Npxls):
             raise ValueError(f"powerspec must be ({self.Npxls}, {self.Npxls})")
         self._group.set_spectrum(ps, self._prob.df)
+        ps = ps.copy()
+        ps.flags.writeable = False
         self._grids["powerspec"] = ps
 
     @property
@@ -239,9 +260,9 @@ class Fast():
                 # this process's devices (one or several): contiguous pieces, one thread per device
                 out = self._group.run(seed, 0, n_real, None, float(self.logamp_var), coherent)
             else:
-                # one process per GPU: this rank's contiguous realisation range, then one exchange
-                out = dist.run_sharded(n_real, lambda real0, n_loc: self._handle.run(
-                    seed, real0, n_loc, None, float(self.logamp_var), coherent), tr, self._handle)
+                # one process per GPU: this rank's contiguous realisation range, then one exchange (one synchronisation,
+                # under a deadline; fast_amd/dist.py: step_sharded)
+                out, _, self.exchange_info = dist.step_sharded(self._handle, tr, seed, 0, n_real, float(self.logamp_var), coherent)
             re, im = out[:n_real].reshape(self.Nchunks, half), out[n_real:].reshape(self.Nchunks, half)
             I[:, :half], I[:, half:] = re, im
             # the log-amplitudes the device drew, in iteration order (global iteration 2g+s)
@@ -357,7 +378,7 @@ class Fast():
     def powerspec_per_layer(self):
         """(L, N, N) residual PSD per turbulence layer (fast.py:478-479); fetched from the GPU on first use."""
         if self._per_layer is None:
-            self.compute_powerspec(per_layer=True)
+            self._per_layer = self._fetch_per_layer()
         return self._per_layer
 
     @property

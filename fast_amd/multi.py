@@ -7,11 +7,19 @@ RCCL over xGMI when `ncclCommInitAll` gives this process a communicator clique (
 ncclAllGather of the powers, ncclAllReduce of the dB histogram on the device buffers, issued from one thread), else the
 host concatenation of the vectors `fastmc_run` already returned.  Which one ran is reported in `exchange`.
 
+A sharded step is ONE synchronisation per device: every handle's kernels are enqueued without waiting
+(`fastmc_run_async`), the grouped collectives follow on the same streams and only the gathered result is copied back.
+The exchange runs under a deadline (`FASTMC_EXCHANGE_TIMEOUT`, seconds, default 120): when it does not return in time,
+or fails, the clique is aborted (`fastmc_comm_abort` = ncclCommAbort, which never waits for peers), every device's own
+vector is fetched (`fastmc_wait`) and concatenated on the host, and the group stays on the host exchange from then on
+(`exchange` says why).  `FASTMC_TEST_STALL_GATHER=1` injects exactly that fault (tests/test_gpu_dist.py).
+
 Nothing here imports torch or needs a launcher.  The reference is single-threaded; no counterpart.
 """
 import logging
 import os
 import threading
+import time
 
 import numpy as np
 
@@ -57,6 +65,9 @@ def run_threads(fns, pool=None):
     return res
 
 
+call_with_deadline, exchange_timeout = dist.call_with_deadline, dist.exchange_timeout
+
+
 class DeviceGroup:
     """N handles of one (N_grid, Np, precision) problem on N devices.
 
@@ -77,8 +88,18 @@ class DeviceGroup:
         self.world = len(self.handles)
         self.exchange = "none" if self.world == 1 else "host"
         self._rccl = False
+        self.rccl_ranks = 0            # world size the communicators report (0: no clique)
+        self.degraded = None           # why an RCCL clique was given up mid-run, if it was
+        self.last_exchange = "none"
+        self.last_exchange_ms = []     # per device: HIP-event time of the collectives of the last step (RCCL path)
+        self.last_exchange_wall_ms = 0.0
+        self._stall_test = os.environ.get("FASTMC_TEST_STALL_GATHER", "0") not in ("", "0")
         if self.world > 1 and exchange in ("auto", "rccl") and factory is None:
-            self._try_rccl(rccl_timeout)
+            if self._stall_test:
+                # fault injection: behave as if the clique were up; the exchange entry point blocks until it is aborted
+                self._rccl, self.exchange, self.rccl_ranks = True, "rccl", self.world
+            else:
+                self._try_rccl(rccl_timeout)
             if exchange == "rccl" and not self._rccl:
                 raise _lib.FastMCError(f"RCCL exchange requested but unavailable: {self.exchange}")
 
@@ -91,25 +112,23 @@ class DeviceGroup:
         # same devices in the same order is reused
         try:
             if all(h.comm_world() == (self.world, i) for i, h in enumerate(self.handles)):
-                self._rccl, self.exchange = True, "rccl"
+                self._rccl, self.exchange, self.rccl_ranks = True, "rccl", self.world
                 return
         except Exception:
             pass
-        box = {}
-
-        def _init():
-            try:
-                _lib.comm_init_all(self.handles)
-                box["ok"] = True
-            except Exception as e:
-                box["err"] = str(e)
-        th = threading.Thread(target=_init, daemon=True)
-        th.start()
-        th.join(timeout)
-        if box.get("ok"):
+        ok, val = call_with_deadline(lambda: _lib.comm_init_all(self.handles), timeout)
+        if ok:
             self._rccl, self.exchange = True, "rccl"
+            self.rccl_ranks = self.handles[0].comm_world()[0]
         else:
-            self.exchange = f"host ({box.get('err', 'ncclCommInitAll did not return in time')})"
+            # a clique that is still being built (or half built) is aborted, never destroyed: ncclCommAbort does not wait
+            # for peers, and an init that returns later finds the abort and drops its communicators (fastmc_comm_init_all)
+            for h in self.handles:
+                try:
+                    h.comm_abort()
+                except Exception:
+                    pass
+            self.exchange = f"host ({val})"
             logger.warning(f"RCCL exchange unavailable ({self.exchange}); results are concatenated on the host")
 
     # ---- broadcast of the problem (one host copy per device)
@@ -135,6 +154,11 @@ class DeviceGroup:
         histogram in `self.last_hist` (device all-reduce when RCCL is up)."""
         ranges = dist.shard_ranges(n_real, self.world)
         la = None if logamp is None else np.ascontiguousarray(logamp, dtype=np.float64)
+        equal = len({n for _, n in ranges}) == 1 and ranges[0][1] > 0
+        self.last_hist = None
+        self.last_exchange_ms, self.last_exchange_wall_ms = [], 0.0
+        if self._rccl and equal and la is None:
+            return self._run_rccl(seed, real0, ranges, logamp_var, coherent, hist_range)
 
         def piece(h, i):
             r0, n = ranges[i]
@@ -145,21 +169,51 @@ class DeviceGroup:
                 lai = np.concatenate([la[r0:r0 + n], la[n_real + r0:n_real + r0 + n]])
             return h.run(seed, real0 + r0, n, lai, logamp_var, coherent)
         parts = self.each(piece)
-        self.last_hist = None
-        equal = len({n for _, n in ranges}) == 1 and ranges[0][1] > 0
-        if self._rccl and equal:
-            nval = 2 * ranges[0][1] * (2 if coherent else 1)
-            allp, hist = _lib.comm_gather_all(self.handles, nval, hist_range)
+        t0 = time.perf_counter()
+        self.last_exchange = "host" if self.world > 1 else "none"
+        if hist_range is not None:
+            hs = self.each(lambda h, i: h.histogram(*hist_range) if ranges[i][1] else 0)
+            self.last_hist = np.sum([x for x in hs if not np.isscalar(x)], axis=0)
+        out = dist.assemble(parts, complex_out=coherent)
+        self.last_exchange_wall_ms = (time.perf_counter() - t0) * 1e3
+        return out
+
+    def _run_rccl(self, seed, real0, ranges, logamp_var, coherent, hist_range):
+        """One synchronisation per device: kernels enqueued on every stream, grouped all-gather (+ histogram all-reduce) behind
+        them, result copied from rank 0.  Under a deadline; on a miss the clique is aborted and the step finishes on the host."""
+        n = ranges[0][1]
+        self.each(lambda h, i: h.run_async(seed, real0 + ranges[i][0], n, logamp_var, coherent))
+        nval = 2 * n * (2 if coherent else 1)
+        t0 = time.perf_counter()
+        ok, val = call_with_deadline(lambda: _lib.comm_gather_all(self.handles, nval, hist_range), exchange_timeout())
+        if ok:
+            allp, hist = val
             allp = allp.reshape(self.world, nval)
             parts = [allp[r].view(np.complex128) if coherent else allp[r] for r in range(self.world)]
             self.last_hist = hist
             self.last_exchange = "rccl"
-        else:
-            self.last_exchange = "host" if self.world > 1 else "none"
-            if hist_range is not None:
-                hs = self.each(lambda h, i: h.histogram(*hist_range) if ranges[i][1] else 0)
-                self.last_hist = np.sum([x for x in hs if not np.isscalar(x)], axis=0)
+            self.last_exchange_ms = [h.last_exchange_ms() for h in self.handles]
+            self.last_exchange_wall_ms = (time.perf_counter() - t0) * 1e3     # includes the wait for the kernels
+            return dist.assemble(parts, complex_out=coherent)
+        self._degrade(val)
+        parts = self.each(lambda h, i: h.wait())                 # every device's own vector is still resident
+        if hist_range is not None:
+            self.last_hist = np.sum(self.each(lambda h, i: h.histogram(*hist_range)), axis=0)
+        self.last_exchange = "host"
+        self.last_exchange_wall_ms = (time.perf_counter() - t0) * 1e3
         return dist.assemble(parts, complex_out=coherent)
+
+    def _degrade(self, why):
+        """Give the clique up for good: abort every communicator (wakes a blocked exchange) and take the host path."""
+        self._rccl = False
+        self.degraded = why
+        self.exchange = f"host (RCCL exchange given up: {why})"
+        logger.warning(f"RCCL exchange gave no result ({why}); communicators aborted, results are concatenated on the host from now on")
+        for h in self.handles:
+            try:
+                h.comm_abort()
+            except Exception as e:
+                logger.warning(f"ncclCommAbort on device {h.device}: {e}")
 
     def last_timing(self):
         return [h.last_timing() for h in self.handles]

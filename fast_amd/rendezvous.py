@@ -11,24 +11,65 @@ The data path itself never comes here when RCCL is available: the per-iteration 
 exchanged on the device buffers by `fastmc_comm_gather` (fast_amd/dist.py: RcclTransport).
 
 Endpoint, in this order:
-  FASTMC_RDZV = "tcp://host:port" | "unix:name"            explicit
+  FASTMC_RDZV = "tcp://host:port" | "unix:name-or-path"    explicit
   one node (LOCAL_WORLD_SIZE == WORLD_SIZE, or MASTER_ADDR is a loopback address):
-        abstract unix socket "fastmc-rdzv-<MASTER_PORT>-<run id>"  (no TCP port to collide with the launcher's own store)
+        unix socket FILE "<private dir>/rdzv-<MASTER_PORT>-<run id>", mode 0600, in a directory of mode 0700 owned by this
+        user ($XDG_RUNTIME_DIR/fastmc or /tmp/fastmc-<uid>): only processes of the same user can connect (the abstract
+        namespace has no permissions at all), and no TCP port collides with the launcher's own store
   otherwise: tcp://MASTER_ADDR:(MASTER_PORT + 1)
+
+Who may join: every connection starts with a mutual HMAC-SHA256 challenge (rank 0 sends a nonce, the peer answers with
+its (rank, world) hello signed with the shared token and its own nonce, rank 0 signs that back).  The token is
+FASTMC_RDZV_TOKEN when the launcher exports one (do, across nodes), else derived from the launcher's run id and port --
+which keeps strangers' stray connections out but is not a secret; a TCP rendezvous without FASTMC_RDZV_TOKEN says so once.
+Messages carry only bytes of numpy arrays and JSON (fast_amd/sweep.py); nothing received is ever unpickled, and a length
+prefix beyond FASTMC_RDZV_MAX_MSG (default 1 GiB) closes the connection.
 
 The reference (ojdf/fast) is single-process; this has no counterpart there.
 """
 import atexit
+import hashlib
+import hmac
+import logging
 import os
 import socket
+import stat
 import struct
 import time
 
 import numpy as np
 
 
+logger = logging.getLogger(__name__)
+MAX_MSG = int(os.environ.get("FASTMC_RDZV_MAX_MSG", str(1 << 30)))
+
+
 class RendezvousError(RuntimeError):
     pass
+
+
+def _token():
+    """Shared key of the hello handshake (bytes) and whether the launcher supplied it explicitly."""
+    t = os.environ.get("FASTMC_RDZV_TOKEN")
+    if t:
+        return t.encode(), True
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "") or os.environ.get("SLURM_JOB_ID", "")
+    return f"fastmc|{run_id}|{os.environ.get('MASTER_PORT', '29400')}|{os.getuid()}".encode(), False
+
+
+def _private_dir():
+    """A directory only this user can enter, for the unix socket file: $XDG_RUNTIME_DIR/fastmc, else /tmp/fastmc-<uid>."""
+    base = os.environ.get("XDG_RUNTIME_DIR")
+    d = os.path.join(base, "fastmc") if base and os.path.isdir(base) and os.access(base, os.W_OK) else \
+        os.path.join(os.environ.get("TMPDIR", "/tmp"), f"fastmc-{os.getuid()}")
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RendezvousError(f"{d} must be a directory of mode 0700 owned by uid {os.getuid()} (found mode {oct(st.st_mode & 0o7777)}, uid {st.st_uid})")
+    return d
 
 
 def env_world():
@@ -58,7 +99,8 @@ def _endpoint(world):
     one_node = os.environ.get("LOCAL_WORLD_SIZE") == str(world) or addr in ("127.0.0.1", "localhost", "::1")
     if one_node and hasattr(socket, "AF_UNIX"):
         run_id = os.environ.get("TORCHELASTIC_RUN_ID", "") or os.environ.get("SLURM_JOB_ID", "")
-        return "unix", f"fastmc-rdzv-{port}-{run_id}"
+        run_id = "".join(c if c.isalnum() or c in "-_." else "_" for c in run_id)[:40]
+        return "unix", os.path.join(_private_dir(), f"rdzv-{port}-{run_id}")
     return "tcp", (addr, port + 1)
 
 
@@ -76,9 +118,15 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
-def _recv(sock):
+def _recv(sock, limit=None):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > (MAX_MSG if limit is None else limit):
+        raise RendezvousError(f"rendezvous message of {n} bytes exceeds the limit (FASTMC_RDZV_MAX_MSG)")
     return _recv_exact(sock, n)
+
+
+def _sign(key, *parts):
+    return hmac.new(key, b"|".join(parts), hashlib.sha256).digest()
 
 
 class Rendezvous:
@@ -93,16 +141,34 @@ class Rendezvous:
         self._up = None           # other ranks: socket to rank 0
         self._listener = None
         fam = socket.AF_UNIX if kind == "unix" else socket.AF_INET
-        addr = ("\0" + address) if kind == "unix" else address
+        # a unix endpoint with a '/' is a socket FILE (mode 0600 in a private directory); a bare name (explicit
+        # FASTMC_RDZV=unix:name only) lives in the abstract namespace, which has no permissions: the handshake alone guards it
+        self._sock_file = address if (kind == "unix" and "/" in address) else None
+        addr = (address if self._sock_file else "\0" + address) if kind == "unix" else address
         self.endpoint = f"{kind}:{address}"
+        self._key, explicit = _token()
         if self.world == 1:
             return
+        if kind == "tcp" and not explicit and self.rank == 0:
+            logger.warning("TCP rendezvous without FASTMC_RDZV_TOKEN: the hello handshake is keyed on the run id and port only; "
+                           "export a secret FASTMC_RDZV_TOKEN to every rank on networks you do not trust")
         if self.rank == 0:
             ls = socket.socket(fam, socket.SOCK_STREAM)
             if kind == "tcp":
                 ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
-                ls.bind(addr)
+                if self._sock_file:
+                    try:
+                        os.unlink(self._sock_file)          # a stale file of an earlier run with the same port / run id
+                    except FileNotFoundError:
+                        pass
+                    old = os.umask(0o177)
+                    try:
+                        ls.bind(addr)
+                    finally:
+                        os.umask(old)
+                else:
+                    ls.bind(addr)
             except OSError as e:
                 raise RendezvousError(f"rank 0 cannot bind the rendezvous endpoint {self.endpoint}: {e}")
             ls.listen(self.world)
@@ -112,12 +178,28 @@ class Rendezvous:
             try:
                 while len(peers) < self.world - 1:
                     c, _ = ls.accept()
-                    c.settimeout(self.timeout)
+                    c.settimeout(min(self.timeout, 20.0))
                     if kind == "tcp":
                         c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    (r, w) = struct.unpack("<ii", _recv(c))
-                    if w != self.world or not 0 < r < self.world or r in peers:
-                        raise RendezvousError(f"unexpected hello (rank {r} of {w}) at {self.endpoint}")
+                    # mutual challenge: a peer that cannot sign our nonce with the shared token is dropped, not fatal
+                    try:
+                        nonce = os.urandom(16)
+                        _send(c, nonce)
+                        hello = _recv(c, limit=256)
+                        if len(hello) != 8 + 16 + 32:
+                            raise RendezvousError("malformed hello")
+                        (r, w) = struct.unpack("<ii", hello[:8])
+                        peer_nonce, mac = hello[8:24], hello[24:]
+                        if not hmac.compare_digest(mac, _sign(self._key, b"hello", nonce, hello[:8], peer_nonce)):
+                            raise RendezvousError("hello not signed with this run's token")
+                        if w != self.world or not 0 < r < self.world or r in peers:
+                            raise RendezvousError(f"unexpected hello (rank {r} of {w})")
+                        _send(c, _sign(self._key, b"welcome", peer_nonce, hello[:8]))
+                    except (RendezvousError, OSError, struct.error) as e:
+                        logger.warning(f"rendezvous {self.endpoint}: connection refused ({e})")
+                        c.close()
+                        continue
+                    c.settimeout(self.timeout)
                     peers[r] = c
             except socket.timeout:
                 raise RendezvousError(f"only {len(peers) + 1} of {self.world} ranks reached {self.endpoint} in {self.timeout:.0f} s")
@@ -141,7 +223,16 @@ class Rendezvous:
             s.settimeout(self.timeout)
             if kind == "tcp":
                 s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            _send(s, struct.pack("<ii", self.rank, self.world))
+            try:
+                nonce = _recv(s, limit=64)
+                me, mine = struct.pack("<ii", self.rank, self.world), os.urandom(16)
+                _send(s, me + mine + _sign(self._key, b"hello", nonce, me, mine))
+                welcome = _recv(s, limit=64)
+            except (OSError, RendezvousError) as e:
+                raise RendezvousError(f"rank {self.rank}: handshake with rank 0 at {self.endpoint} failed ({e}): do all ranks share "
+                                      "FASTMC_RDZV_TOKEN / the launcher's run id and MASTER_PORT?")
+            if not hmac.compare_digest(welcome, _sign(self._key, b"welcome", mine, me)):
+                raise RendezvousError(f"rank {self.rank}: the process listening at {self.endpoint} is not rank 0 of this run")
             s.settimeout(self.io_timeout)
             self._up = s
 
@@ -196,6 +287,12 @@ class Rendezvous:
                 except OSError:
                     pass
         self._peers, self._up, self._listener = [], None, None
+        if self.rank == 0 and getattr(self, "_sock_file", None):
+            try:
+                os.unlink(self._sock_file)
+            except OSError:
+                pass
+            self._sock_file = None
 
 
 _GLOBAL = None

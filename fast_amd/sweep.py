@@ -6,12 +6,16 @@ corrected.  Per sample the reference rebuilds everything (`fast.Fast(params)`,
 complete_orbit_simulation.py:227) and its init is dominated by `compute_powerspec` (12-15 s at
 1024^2).  Here the power spectrum is one GPU kernel (< 1 ms), the pupil /
 fibre-mode products are cached across samples that share the aperture (host.pupils cache), and
-samples are dealt round-robin to the ranks of a multi-process launch (one process per GPU) or to
-the devices of one process (`zenith_scan_devices`: one thread per device); only the per-sample
-summary statistics are gathered.
+samples are dealt round-robin to the ranks of a multi-process launch (one process per GPU:
+`zenith_scan(..., rank, world)`); only the per-sample summary statistics are gathered, as JSON --
+nothing received from another rank is ever unpickled.
 """
+import base64
 import copy
+import json
 import time
+
+import numpy
 
 
 from .fast import Fast
@@ -45,12 +49,39 @@ def zenith_scan(base_params, zenith_angles, niter=4096, nchunks=1, keep_power=Fa
     return out
 
 
+def _encode(records):
+    """Records -> JSON bytes; numpy arrays as {dtype, shape, base64 of the raw bytes} (plain data, no pickle)."""
+    def enc(v):
+        if isinstance(v, numpy.ndarray):
+            a = numpy.ascontiguousarray(v)
+            if a.dtype.hasobject:
+                raise TypeError("object arrays cannot be exchanged")
+            return {"__ndarray__": a.dtype.str, "shape": list(a.shape), "data": base64.b64encode(a.tobytes()).decode("ascii")}
+        if isinstance(v, numpy.generic):
+            return v.item()
+        return v
+    return json.dumps([{k: enc(v) for k, v in r.items()} for r in records]).encode()
+
+
+def _decode(blob):
+    def dec(v):
+        if isinstance(v, dict) and "__ndarray__" in v:
+            dt = numpy.dtype(v["__ndarray__"])
+            if dt.hasobject:
+                raise ValueError("object arrays are not accepted")
+            return numpy.frombuffer(base64.b64decode(v["data"]), dtype=dt).reshape(v["shape"]).copy()
+        return v
+    recs = json.loads(blob.decode())
+    if not isinstance(recs, list) or not all(isinstance(r, dict) for r in recs):
+        raise ValueError("malformed sweep records")
+    return [{k: dec(v) for k, v in r.items()} for r in recs]
+
+
 def gather_records(records):
     """All ranks' records on every rank (through the rendezvous of a multi-rank launch, fast_amd/rendezvous.py)."""
-    import pickle
     from . import rendezvous
     rdzv = rendezvous.from_env()
     if rdzv is None:
         return sorted(records, key=lambda r: r["index"])
-    parts = rdzv.exchange(pickle.dumps(records))
-    return sorted([r for part in parts for r in pickle.loads(part)], key=lambda r: r["index"])
+    parts = rdzv.exchange(_encode(records))
+    return sorted([r for part in parts for r in _decode(part)], key=lambda r: r["index"])

@@ -19,6 +19,9 @@
  *     for the largest work buffer of the device, which is kept for the next handle;
  *   - nothing here ever falls back to a CPU implementation: without a gfx950 device
  *     fastmc_create() fails with FASTMC_ENODEV;
+ *   - environment: FASTMC_TEST_STALL_GATHER=1 makes fastmc_comm_gather / _gather_all block (without touching RCCL)
+ *     until fastmc_comm_abort is called on the handle's device, then fail with FASTMC_ECOMM: the fault the deadline
+ *     tests inject (tests/test_gpu_dist.py);
  *   - environment: FASTMC_DISABLE_RCCL=1 makes the communicator entry points fail with FASTMC_ECOMM (callers exchange
  *     through the host); FASTMC_NO_DENSE16=1 (read by fastmc_create) keeps the twelve-wave kernels where the
  *     sixteen-wave dense-image kernels would run (A/B timing; same results).
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FASTMC_VERSION 200
+#define FASTMC_VERSION 300
 
 #define FASTMC_OK 0
 #define FASTMC_EINVAL (-1)   /* bad argument */
@@ -71,9 +74,10 @@ int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, double dx);
 int fastmc_set_subharm(fastmc_t* h, const double* powerspec_sh, const double* fx,
                        const double* fy, const double* df);
 
-/* Monte-Carlo run with the on-device generator (xoshiro128+ streams seeded by Philox4x32-10
- * blocks keyed on (seed; realisation, row, column mod 64), Box-Muller; restated in
- * oracle/devrng.py) -- replaces the body of the chunk loop of
+/* Monte-Carlo run with the on-device generator (xoshiro128+ streams seeded by Philox4x32-7
+ * blocks keyed on (seed; realisation, row, stream = column mod SL), SL = 64 -- 128 / 256 at 2048 / 4096, 50 S on the
+ * 50 P S grids --, two words per state advance, Box-Muller; the log-amplitude and sub-harmonic draws take
+ * Philox4x32-10 blocks directly; restated in oracle/devrng.py) -- replaces the body of the chunk loop of
  * Fast.run (fast/fast.py:130-134: compute_phs 589-605 + compute_detector 647-668) and
  * Fast.compute_logamp (fast/fast.py:639-645).
  *
@@ -88,6 +92,15 @@ int fastmc_set_subharm(fastmc_t* h, const double* powerspec_sh, const double* fx
  *           coherent != 0: 2*n_real complex128 (interleaved re, im), same order. */
 int fastmc_run(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real,
                const double* logamp, double logamp_var, int coherent, double* out);
+
+/* The same run without the host copy and without waiting: the kernels are enqueued on the handle's stream and the
+ * results stay on the device (log-amplitudes drawn on the device).  What follows on the handle is ordered behind them:
+ * fastmc_comm_gather / fastmc_comm_gather_all put the exchange on the same stream, so that a sharded step synchronises
+ * ONCE, after its all-gather; fastmc_histogram / fastmc_result_stats / fastmc_link_metrics likewise.
+ * fastmc_wait(h, out) waits for the stream and copies the results of the last run (2*n_real float64, or complex128
+ * when coherent; out may be NULL: wait only).  It also serves after a blocking fastmc_run (fetches the vector again). */
+int fastmc_run_async(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real, double logamp_var, int coherent);
+int fastmc_wait(fastmc_t* h, double* out);
 
 /* Parity mode: the same pipeline fed with host-drawn coefficients (numpy draw order of
  * fast/funcs.py:352-356: all real parts, then all imaginary parts).
@@ -270,6 +283,16 @@ int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n_local, dou
                            double lo_db, double hi_db, int nbins);
 /* Destroys the communicator of h's device (no-op when there is none). */
 int fastmc_comm_destroy(fastmc_t* h);
+/* Aborts the communicator of h's device (ncclCommAbort: outstanding collectives are torn down and their kernels leave
+ * the stream) and forgets it; may be called from another thread while fastmc_comm_gather / _gather_all of that device
+ * is blocked -- that call then returns FASTMC_ECOMM.  What a caller does when a collective misses its deadline
+ * (fast_amd/multi.py, fast_amd/dist.py) or when a clique was only half built; never waits for peers.  No-op without
+ * a communicator. */
+int fastmc_comm_abort(fastmc_t* h);
+/* HIP-event time of the collectives of the last fastmc_comm_gather / _gather_all on h's stream, from the moment the
+ * stream reached them (i.e. after this device's kernels) to their completion: transfer plus the wait for the slowest
+ * peer.  ms: one double. */
+int fastmc_last_exchange_ms(fastmc_t* h, double* ms);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,44 @@ class FakeHandle:
         pass
 
 
+class StallingHandle:
+    """A handle whose device exchange never answers on the ranks in `stall_ranks` (and answers garbage on the others):
+    what a hung RCCL collective looks like to fast_amd/dist.py.  run_async / wait / histogram are the oracle."""
+    device = 1
+
+    def __init__(self, rank, stall_ranks):
+        import threading
+        self.rank, self.stall_ranks, self.aborted, self._ev = rank, stall_ranks, 0, threading.Event()
+
+    def run_async(self, seed, real0, n, logamp_var, coherent):
+        self._local = compute(real0, n, coherent)
+
+    def wait(self):
+        return self._local
+
+    def run(self, seed, real0, n, logamp, logamp_var, coherent):
+        return compute(real0, n, coherent)
+
+    def comm_gather(self, nval, world, hist_range=None, powers=True):
+        if self.rank in self.stall_ranks:
+            self._ev.wait()                      # until comm_abort
+            raise RuntimeError("aborted")
+        return np.full(nval * world, -1.0), (None if hist_range is None else np.zeros(hist_range[2] + 2, dtype=np.int64))
+
+    def comm_abort(self):
+        self.aborted += 1
+        self._ev.set()
+
+    def last_exchange_ms(self):
+        return 0.0
+
+    def histogram(self, lo, hi, nbins):
+        pw = self._local if not np.iscomplexobj(self._local) else np.abs(self._local) ** 2
+        h = np.zeros(nbins + 2, dtype=np.int64)
+        h[:nbins] = np.histogram(10 * np.log10(pw), bins=nbins, range=(lo, hi))[0]
+        return h
+
+
 def main():
     assert "torch" not in sys.modules
     rdzv = rendezvous.from_env()
@@ -66,6 +104,22 @@ def main():
     assert np.iscomplexobj(full_c) and np.array_equal(full_c, compute(0, NREAL, coherent=True))
     h_local = np.histogram(10 * np.log10(compute(*fd.shard_range(NREAL, world, rank))), bins=8, range=(-40, 10))[0]
     assert np.array_equal(fd.histogram_sharded(h_local, tr), np.histogram(10 * np.log10(single), bins=8, range=(-40, 10))[0])
+    # a device exchange that hangs on ONE rank: the deadline passes there, the verdict is collective, EVERY rank aborts its
+    # communicator and the step finishes on the host sockets with the right vector; later steps stay on the host
+    os.environ["FASTMC_EXCHANGE_TIMEOUT"] = "1.5"
+    sh = StallingHandle(rank, stall_ranks={world - 1})
+    rt = fd.RcclTransport(rdzv, world)
+    full2, hist2, info = fd.step_sharded(sh, rt, SEED, 0, NREAL, 0.01, False, (-40.0, 10.0, 8))
+    assert np.array_equal(full2, single) and info["exchange"] == "host" and rt.name == "host" and sh.aborted == 1, (info, rt.name)
+    assert "given up" in rt.why and rt.rccl_ranks == 0
+    assert np.array_equal(hist2[:8], np.histogram(10 * np.log10(single), bins=8, range=(-40, 10))[0])
+    full3, _, info3 = fd.step_sharded(sh, rt, SEED, 0, NREAL, 0.01, True)
+    assert np.array_equal(full3, compute(0, NREAL, coherent=True)) and info3["exchange"] == "host" and sh.aborted == 1
+    # no rank stalls: the device path's answer is taken (here the fake's marker values)
+    ok_h, ok_t = StallingHandle(rank, stall_ranks=set()), fd.RcclTransport(rdzv, world)
+    full4, _, info4 = fd.step_sharded(ok_h, ok_t, SEED, 0, NREAL, 0.01, False)
+    assert info4["exchange"] == "rccl" and ok_t.name == "rccl" and (full4 == -1.0).all() and ok_h.aborted == 0
+    assert not fd.stuck_threads()
     try:
         fd.shard_range(7, 2, 0)
         raise SystemExit("expected an exception for an indivisible range")

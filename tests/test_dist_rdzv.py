@@ -86,3 +86,80 @@ def test_device_group_threads_assemble_like_one_device():
         want = one.run(3, 5, n_real, None, 0.0, False)
         grp.run(3, 5, n_real, None, 0.0, False, hist_range=(0.0, 6.0, 12))
         assert np.array_equal(grp.last_hist, np.histogram(10 * np.log10(want), bins=12, range=(0.0, 6.0))[0])
+
+
+def test_rendezvous_refuses_strangers_and_oversized_messages(tmp_path, monkeypatch):
+    """The hello is a mutual HMAC challenge: a connection that cannot sign rank 0's nonce with the run's token is dropped
+    (rank 0 keeps waiting for the real rank), a rank with another token is told so, and a length prefix beyond the limit is an
+    error instead of an allocation.  The one-node endpoint is a socket FILE of mode 0600 in a private directory."""
+    import socket
+    import stat
+    import struct
+    import threading
+    from fast_amd import rendezvous as rz
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.delenv("XDG_RUNTIME_DIR", raising=False)
+    monkeypatch.delenv("FASTMC_RDZV", raising=False)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29644")
+    monkeypatch.setenv("FASTMC_RDZV_TOKEN", "s3cret")
+    kind, path = rz._endpoint(2)
+    assert kind == "unix" and path.startswith(str(tmp_path)) and stat.S_IMODE(os.lstat(os.path.dirname(path)).st_mode) == 0o700
+    box = {}
+
+    def rank0():
+        try:
+            box["r0"] = rz.Rendezvous(0, 2, kind, path, timeout=20)
+            box["got"] = box["r0"].exchange(b"zero")
+        except Exception as e:
+            box["err"] = e
+    th = threading.Thread(target=rank0)
+    th.start()
+    # a stranger: connects, answers the nonce with garbage
+    for _ in range(200):
+        try:
+            s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            s.connect(path)
+            break
+        except OSError:
+            s.close()
+            import time
+            time.sleep(0.02)
+    assert stat.S_IMODE(os.lstat(path).st_mode) == 0o600
+    rz._recv(s)
+    rz._send(s, struct.pack("<ii", 1, 2) + b"\0" * 48)
+    assert s.recv(1) == b""                      # dropped
+    s.close()
+    # a rank of another run (wrong token)
+    monkeypatch.setenv("FASTMC_RDZV_TOKEN", "other")
+    with pytest.raises(rz.RendezvousError, match="handshake|not rank 0"):
+        rz.Rendezvous(1, 2, kind, path, timeout=5)
+    # the real rank 1
+    monkeypatch.setenv("FASTMC_RDZV_TOKEN", "s3cret")
+    r1 = rz.Rendezvous(1, 2, kind, path, timeout=10)
+    assert r1.exchange(b"one") == [b"zero", b"one"]
+    th.join(20)
+    assert "err" not in box and box["got"] == [b"zero", b"one"]
+    # an absurd length prefix
+    a, b = socket.socketpair()
+    a.sendall(struct.pack("<Q", 1 << 50))
+    with pytest.raises(rz.RendezvousError, match="exceeds the limit"):
+        rz._recv(b)
+    box["r0"].close()
+    r1.close()
+    assert not os.path.exists(path)
+
+
+def test_sweep_records_travel_as_json_not_pickle():
+    from fast_amd import sweep
+    recs = [{"index": 1, "zenith": 12.5, "r": np.arange(6, dtype=float).reshape(2, 3), "n": np.int64(3), "name": "x"}]
+    blob = sweep._encode(recs)
+    assert blob.lstrip().startswith(b"[") and b"pickle" not in blob
+    back = sweep._decode(blob)
+    assert back[0]["index"] == 1 and back[0]["n"] == 3 and np.array_equal(back[0]["r"], recs[0]["r"]) and back[0]["r"].dtype == float
+    with pytest.raises(Exception):
+        sweep._decode(b'{"not": "a list"}')
+    with pytest.raises(TypeError):
+        sweep._encode([{"index": 0, "bad": np.array([object()])}])
+    src = open(os.path.join(ROOT, "fast_amd", "sweep.py")).read() + open(os.path.join(ROOT, "fast_amd", "rendezvous.py")).read()
+    assert "import pickle" not in src and "pickle.loads" not in src

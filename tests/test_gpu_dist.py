@@ -40,6 +40,14 @@ def test_sharded_run_two_ranks_one_gpu(noseed, coherent, norccl):
     assert "GPU DIST OK 2 host" in out
 
 
+def test_sharded_run_two_ranks_with_a_stalled_device_exchange():
+    """FASTMC_TEST_STALL_GATHER=1: both ranks believe the RCCL clique is up and fastmc_comm_gather never answers.  The
+    deadline passes, the verdict is collective, both ranks abort (fastmc_comm_abort), fetch their own vector (fastmc_wait)
+    and finish on the host sockets: same vector as the unsharded run, no hang, exit code 0."""
+    out = _launch(2, 29579, {"FASTMC_TEST_STALL_GATHER": "1", "FASTMC_EXCHANGE_TIMEOUT": "2"})
+    assert "GPU DIST OK 2 host" in out
+
+
 def _params(**over):
     h, cn2, w = fast_amd.turbulence_models.HV57_Bufton_profile(4)
     p = {"NPXLS": 512, "DX": 0.01, "NITER": 600, "NCHUNKS": 4, "SEED": 33, "LOGLEVEL": "ERROR", "D_GROUND": 0.4,
@@ -64,6 +72,67 @@ def test_two_handles_two_threads_equal_one_handle(coherent):
     # three shards of unequal size
     sim3 = fast_amd.Fast(_params(GPU_DEVICES=[0, 0, 0], COHERENT=coherent, NITER=500, NCHUNKS=2))
     assert np.array_equal(sim3.run()._r, fast_amd.Fast(_params(GPU_DEVICE=0, COHERENT=coherent, NITER=500, NCHUNKS=2)).run()._r)
+
+
+def test_eight_workers_on_one_device_equal_one_worker_at_configs1_size(monkeypatch):
+    """BASELINE configs[1] geometry (1024^2, Np = 82), eight worker handles on device 0 through the threads path, 10 000
+    iterations each: the assembled vector and the histogram are bit-identical to ONE handle computing all 80 000.  Then the
+    same group with a device exchange that never answers (FASTMC_TEST_STALL_GATHER=1): the deadline passes, the clique is
+    aborted and the step still returns the identical vector, from the host path, which the group keeps from then on."""
+    g = __import__("conftest").load_golden("big_noao_L0_1024")
+    p = __import__("conftest").params_from_json(g["params_json"])
+    p.update({"NITER": 80000, "NCHUNKS": 8, "SEED": 3, "GPU_RNG": "device", "LOGLEVEL": "ERROR"})
+    one = fast_amd.Fast(dict(p, GPU_DEVICE=0))
+    want = one.run()._r
+    hist1 = one.histogram(-60.0, 10.0, 4096)
+    assert one.Npxls == 1024 and one.Npxls_pup == 82 and want.shape == (80000,) and (want > 0).all()
+    eight = fast_amd.Fast(dict(p, GPU_DEVICES=[0] * 8))
+    got = eight.run()._r
+    assert eight._group.world == 8 and eight._group.exchange.startswith("host") and np.array_equal(got, want)
+    assert np.array_equal(eight.histogram(-60.0, 10.0, 4096), hist1)
+    busy = [t["rows_ms"] + t["cols_ms"] for t in eight._group.last_timing()]
+    assert len(busy) == 8 and min(busy) > 0
+    monkeypatch.setenv("FASTMC_TEST_STALL_GATHER", "1")
+    monkeypatch.setenv("FASTMC_EXCHANGE_TIMEOUT", "3")
+    stalled = fast_amd.Fast(dict(p, GPU_DEVICES=[0] * 8))
+    assert stalled._group.exchange == "rccl" and stalled._group.rccl_ranks == 8        # what the fault injection pretends
+    import time
+    t0 = time.perf_counter()
+    got2 = stalled.run()._r
+    assert 2.5 < time.perf_counter() - t0 < 60
+    assert np.array_equal(got2, want)
+    assert stalled._group.exchange.startswith("host (RCCL exchange given up: no answer within 3 s") and stalled._group.last_exchange == "host"
+    monkeypatch.delenv("FASTMC_TEST_STALL_GATHER")
+    t0 = time.perf_counter()
+    assert np.array_equal(stalled.run()._r, want) and time.perf_counter() - t0 < 2.5      # no second deadline: host path kept
+    from fast_amd import dist
+    time.sleep(0.2)
+    assert not dist.stuck_threads()
+
+
+def test_async_run_and_wait_equal_the_blocking_run():
+    """fastmc_run_async + fastmc_wait: same vector as fastmc_run, timing read after the wait, statistics / histogram ordered
+    behind the kernels on the stream; a second wait fetches the same results again."""
+    h = _lib.Handle(256, 40, "f64", 0)
+    ps = np.full((256, 256), 1e-3)
+    ps[128, 128] = 0.0
+    h.set_spectrum(ps, 0.25)
+    h.set_pupil(np.ones((40, 40)), 108, 0.01)
+    want = h.run(9, 5, 300, None, 0.01)
+    h.run_async(9, 5, 300, 0.01)
+    hist = h.histogram(-40.0, 10.0, 50)                 # stream-ordered behind the kernels
+    got = h.wait()
+    assert np.array_equal(got, want) and hist.sum() == 600 and np.array_equal(h.wait(), want)
+    t = h.last_timing()
+    assert t["rows_launches"] >= 1 and t["rows_ms"] > 0 and t["cols_ms"] > 0
+    h.run_async(9, 5, 300, 0.01, coherent=True)
+    coh = h.wait()
+    assert np.iscomplexobj(coh) and np.allclose(np.abs(coh) ** 2, want, rtol=1e-12)
+    h.run_async(9, 0, 10, 0.01)                         # never waited for: the next call tidies up
+    assert np.array_equal(h.run(9, 5, 300, None, 0.01), want)
+    # abort without a communicator is a no-op; the exchange time of a handle that never exchanged is 0
+    h.comm_abort()
+    assert h.comm_world() == (0, -1) and h.last_exchange_ms() == 0.0
 
 
 def test_device_group_histogram_and_rccl_refusal():
@@ -111,7 +180,36 @@ def test_bench_two_threads_on_one_gpu_reports_what_ran():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["workers"] == 2 and line["config"]["result_exchange"].startswith("host")
-    assert line["config"]["histogram_total"] == 2 * 10000
+    assert line["config"]["histogram_total"] == 2 * 10000 and line["config"]["rccl_ranks"] == 0
+    assert line["exchange"]["steps_host"] == 2 and line["exchange"]["steps_rccl"] == 0 and line["exchange"]["host_ms_per_step"] >= 0
+    busy = line["pipeline"]["gpu_busy_ms_per_step"]
+    assert len(busy["per_worker"]) == 2 and 0 < busy["min_worker"] <= busy["max_worker"]
+
+
+def test_bench_eight_workers_with_a_stalled_exchange_prints_its_line_and_says_what_happened():
+    """bench.py --gpus 8 (eight worker threads on device 0) with FASTMC_TEST_STALL_GATHER=1: the first step's exchange never
+    answers; bench.py must not hang -- it aborts, goes on with the host exchange and the line says so."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"FASTMC_BENCH_DEVICES": ",".join(["0"] * 8), "FASTMC_TEST_STALL_GATHER": "1", "FASTMC_EXCHANGE_TIMEOUT": "3"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras", "--no-sustained"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["workers"] == 8 and line["config"]["rccl_ranks"] == 0
+    assert line["config"]["result_exchange"].startswith("host (RCCL exchange given up: no answer within 3 s")
+    assert line["exchange"]["steps_host"] == 2 and line["config"]["histogram_total"] == 8 * 10000
+
+
+def test_bench_config3_strong_scaling_workload():
+    """--workload config3: BASELINE configs[3] (2048^2, 100 000 iterations per step in total) split over the workers."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FASTMC_BENCH_DEVICES"] = "0,0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "config3",
+                        "--no-cpu-baseline", "--no-extras", "--no-sustained"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and "2048^2" in line["metric"] and line["config"]["iters_per_step_per_gpu"] == 50000
+    assert line["config"]["histogram_total"] == 100000 and abs(line["value"] - 100000 / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
 
 
 def test_rccl_transport_code_path_with_a_world_of_one():

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported(built):
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(built, name), name
-    assert built.fastmc_version() == 200
+    assert built.fastmc_version() == 300
 
 
 def test_no_cpu_fallback_without_gpu(built):

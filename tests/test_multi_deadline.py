@@ -1,0 +1,97 @@
+"""CPU: the deadline / abort / host fall-back around the per-step exchange of fast_amd/multi.py (one process, N devices),
+with stand-in handles -- what a hung `fastmc_comm_gather_all` looks like to DeviceGroup.  The real thing runs under
+`-m gpu` (tests/test_gpu_dist.py: FASTMC_TEST_STALL_GATHER)."""
+import threading
+import time
+
+import numpy as np
+
+from fast_amd import _lib, dist, multi
+
+
+class FakeHandle:
+    def __init__(self, device):
+        self.device, self.aborted, self.waited = device, 0, 0
+
+    def _values(self, real0, n):
+        g = np.arange(real0, real0 + n, dtype=float)
+        return np.concatenate([g + 0.25, g + 0.75])          # [Re-screen results | Im-screen results]
+
+    def run_async(self, seed, real0, n, logamp_var, coherent):
+        self._local = self._values(real0, n)
+
+    def wait(self):
+        self.waited += 1
+        return self._local
+
+    def run(self, seed, real0, n, logamp, logamp_var, coherent):
+        return self._values(real0, n)
+
+    def histogram(self, lo, hi, nbins):
+        h = np.zeros(nbins + 2, dtype=np.int64)
+        h[0] = self._local.size
+        return h
+
+    def comm_abort(self):
+        self.aborted += 1
+        FakeHandle.wake.set()
+
+    def last_exchange_ms(self):
+        return 0.5
+
+    def last_timing(self):
+        return {}
+
+    def close(self):
+        pass
+
+
+def _group(n):
+    FakeHandle.wake = threading.Event()
+    grp = multi.DeviceGroup(64, 8, "f64", list(range(n)), factory=FakeHandle)
+    grp._rccl, grp.exchange, grp.rccl_ranks = True, "rccl", n       # as after a successful ncclCommInitAll
+    return grp
+
+
+def test_exchange_that_never_answers_is_aborted_and_the_step_finishes_on_the_host(monkeypatch):
+    grp = _group(4)
+    monkeypatch.setenv("FASTMC_EXCHANGE_TIMEOUT", "0.5")
+
+    def hung(handles, n_local, hist_range=None, powers=True):
+        FakeHandle.wake.wait()                     # until some handle's comm_abort
+        raise _lib.FastMCError("aborted")
+    monkeypatch.setattr(_lib, "comm_gather_all", hung)
+    t0 = time.perf_counter()
+    out = grp.run(1, 100, 40, None, 0.0, False, hist_range=(-10.0, 10.0, 4))
+    assert 0.4 < time.perf_counter() - t0 < 5.0
+    want = np.concatenate([np.arange(100, 140) + 0.25, np.arange(100, 140) + 0.75])
+    assert np.array_equal(out, want)
+    assert grp.last_exchange == "host" and grp.exchange.startswith("host (RCCL exchange given up") and "no answer" in grp.degraded
+    assert all(h.aborted == 1 and h.waited == 1 for h in grp.handles) and grp.last_hist[0] == 80
+    time.sleep(0.1)
+    assert not dist.stuck_threads()                # the abort woke the thread the deadline left behind
+    # later steps never try the device exchange again
+    monkeypatch.setattr(_lib, "comm_gather_all", lambda *a, **k: (_ for _ in ()).throw(AssertionError("must not be called")))
+    out2 = grp.run(1, 0, 8, None, 0.0, False)
+    assert np.array_equal(out2, np.concatenate([np.arange(8) + 0.25, np.arange(8) + 0.75])) and grp.last_exchange == "host"
+
+
+def test_exchange_error_falls_back_and_success_is_taken(monkeypatch):
+    grp = _group(2)
+    monkeypatch.setattr(_lib, "comm_gather_all", lambda *a, **k: (_ for _ in ()).throw(_lib.FastMCError("libfastmc error -5: ncclAllGather: unhandled system error")))
+    out = grp.run(1, 0, 10, None, 0.0, False)
+    assert np.array_equal(out, np.concatenate([np.arange(10) + 0.25, np.arange(10) + 0.75]))
+    assert "unhandled system error" in grp.exchange and all(h.aborted == 1 for h in grp.handles)
+
+    grp = _group(2)
+
+    def fine(handles, n_local, hist_range=None, powers=True):
+        return np.concatenate([h._local for h in handles]), np.array([1, 2, 3])
+    monkeypatch.setattr(_lib, "comm_gather_all", fine)
+    out = grp.run(1, 0, 10, None, 0.0, False, hist_range=(-1.0, 1.0, 1))
+    assert np.array_equal(out, np.concatenate([np.arange(10) + 0.25, np.arange(10) + 0.75]))
+    assert grp.last_exchange == "rccl" and grp.last_exchange_ms == [0.5, 0.5] and list(grp.last_hist) == [1, 2, 3]
+    assert all(h.aborted == 0 and h.waited == 0 for h in grp.handles)
+    # unequal shards (or host-supplied log-amplitudes) cannot use the all-gather: host path without touching the clique
+    out = grp.run(1, 0, 11, None, 0.0, False)
+    assert out.size == 22 and grp.last_exchange == "host" and grp.exchange == "rccl"

@@ -200,6 +200,66 @@ def extras(args, device):
                                           "iterations_per_s_end_to_end": 32 * 4096 / wall,
                                           "powerspec_kernel_ms_total": sum(r["powerspec_kernel_ms"] for r in recs),
                                           "mean_dB_rel_first_last": [recs[0]["mean_dB_rel"], recs[-1]["mean_dB_rel"]]}
+    out.update(extras_unmeasured_rows(args, device))
+    return out
+
+
+def extras_unmeasured_rows(args, device):
+    """The rows of SURVEY section 8 that the headline does not exercise, each timed here so that they are on the record:
+    BASELINE configs[0] exactly as stated (the reference's shipped test/test_params.py: NPXLS 256, TEMPORAL on, 100 iterations)
+    on the GPU and on the CPU oracle; a TEMPORAL run at 1024^2; SUBHARM on; 256^2 and 512^2 device-mode rates; and the device
+    generator at the reference's float64 precision (GPU_RNG_PRECISION 'f64': what the float32 shortcut buys)."""
+    import copy
+    import fast_amd
+    from oracle import fastref as R
+    out = {}
+
+    def shipped(**over):
+        p = workload_params(copy.copy(args))
+        p.update({"NPXLS": 256, "NITER": 100, "NCHUNKS": 10, "TEMPORAL": True, "DT": 0.001, "AO_MODE": "AO", "ALIAS": True, "FFTW": True,
+                  "GPU_DEVICE": device, "GPU_PRECISION": "f64"})
+        p.update(over)
+        return p
+
+    # configs[0]: GPU (second object and second run: module load and allocations out of the figure) and the CPU oracle
+    fast_amd.Fast(shipped()).run()
+    t0 = time.perf_counter()
+    sim = fast_amd.Fast(shipped())
+    t1 = time.perf_counter()
+    r = sim.run()._r
+    t2 = time.perf_counter()
+    W, prob = sim._prob.W, sim._prob
+    tc = time.perf_counter()
+    r_cpu = R.monte_carlo_temporal(1, 100, 10, sim.powerspec_per_layer, prob.df, W, sim.dx, float(sim.logamp_var), sim.temporal_logamp_powerspec,
+                                   sim.wind_vector, 0.001, sim.Npxls, sim.Npxls_pup)
+    t_cpu = time.perf_counter() - tc
+    out["config0_shipped_example_256_temporal_100it"] = {
+        "gpu_init_s": t1 - t0, "gpu_run_s": t2 - t1, "gpu_iterations_per_s": 100 / (t2 - t1), "cpu_oracle_run_s": t_cpu,
+        "cpu_oracle_iterations_per_s": 100 / t_cpu, "max_rel_diff_gpu_vs_cpu_oracle": float(np.abs(r / r_cpu - 1).max()),
+        "note": "same SEED: the GPU run reproduces the oracle's (= the reference's) series; the CPU figure excludes compute_powerspec"}
+    # TEMPORAL at the BASELINE grid: 1024^2, 2000 time steps
+    p = shipped(NPXLS=1024, NITER=2000, NCHUNKS=10)
+    fast_amd.Fast(copy.copy(p)).run()
+    t0 = time.perf_counter()
+    sim = fast_amd.Fast(copy.copy(p))
+    t1 = time.perf_counter()
+    sim.run()
+    t2 = time.perf_counter()
+    out["temporal_1024_2000_steps"] = {"init_s": t1 - t0, "run_s": t2 - t1, "iterations_per_s": 2000 / (t2 - t1)}
+    # device-mode rates: sub-harmonics on, small grids, float64 generator
+    for tag, over in (("subharm_on_1024_f64", {"SUBHARM": True, "L0": 25.0}), ("npxls256_f64", {"NPXLS": 256}), ("npxls512_f64", {"NPXLS": 512}),
+                      ("generator_f64_1024_f64", {"GPU_RNG_PRECISION": "f64"})):
+        p = workload_params(copy.copy(args))
+        p.update(over)
+        p["GPU_DEVICE"] = device
+        sim = fast_amd.Fast(p)
+        h = sim._handle
+        n_it = 40000 if p["NPXLS"] <= 512 else 10000
+        h.run(1, 0, n_it // 2, None, float(sim.logamp_var), False)
+        t0 = time.perf_counter()
+        for i in range(3):
+            h.run(1, (i + 1) * (n_it // 2), n_it // 2, None, float(sim.logamp_var), False)
+        out[tag] = {"iterations_per_s": 3 * n_it / (time.perf_counter() - t0)}
     return out
 
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "fastmc_powerspec_terms", "fastmc_powerspec_set", "fastmc_powerspec_get",
     "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_init_all", "fastmc_comm_world", "fastmc_comm_gather",
     "fastmc_comm_gather_all", "fastmc_comm_destroy", "fastmc_comm_abort", "fastmc_last_exchange_ms",
-    "fastmc_run_async", "fastmc_wait",
+    "fastmc_run_async", "fastmc_wait", "fastmc_set_rng_precision", "fastmc_temporal_phases",
 ]
 
 
@@ -80,6 +80,7 @@ def lib():
     L.fastmc_rng_logamp.argtypes = [vp, u64, i64, i64, dp]
     L.fastmc_set_layer_screens.argtypes = [vp, dp, C.c_int]
     L.fastmc_temporal_chunk.argtypes = [vp, dp, dp, C.POINTER(C.c_int32), C.c_int, dp, C.c_int, dp]
+    L.fastmc_temporal_phases.argtypes = [vp, dp, dp, C.POINTER(C.c_int32), C.c_int, dp]
     L.fastmc_set_results.argtypes = [vp, dp, i64, C.c_int]
     L.fastmc_histogram.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.POINTER(i64)]
     L.fastmc_result_stats.argtypes = [vp, dp, C.c_int, dp]
@@ -87,6 +88,7 @@ def lib():
     L.fastmc_last_timing.argtypes = [vp, dp, C.POINTER(i64)]
     L.fastmc_kernel_path.argtypes = [vp, C.c_int]
     L.fastmc_set_batch.argtypes = [vp, C.c_int]
+    L.fastmc_set_rng_precision.argtypes = [vp, C.c_int]
     L.fastmc_powerspec.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp, dp, dp]
     L.fastmc_powerspec_terms.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp]
     L.fastmc_powerspec_set.argtypes = [vp, C.POINTER(PsParams), C.c_double, dp, dp]
@@ -264,6 +266,16 @@ class Handle:
                                          _dptr(la), int(bool(coherent)), _dptr(out)))
         return out.view(np.complex128) if coherent else out
 
+    def temporal_phases(self, xs, ys, roll):
+        """(M, Np, Np) phases of one frozen-flow chunk (the reference's Fast.phs after compute_phs_temporal)."""
+        xs, ys = _f64(xs), _f64(ys)
+        roll = np.ascontiguousarray(roll, dtype=np.int32)
+        L, M, Np = xs.shape
+        assert ys.shape == xs.shape and Np == self.Np and roll.shape == (L, 2, M)
+        phs = np.empty((M, Np, Np))
+        _chk(lib().fastmc_temporal_phases(self._h, _dptr(xs), _dptr(ys), roll.ctypes.data_as(C.POINTER(C.c_int32)), M, _dptr(phs)))
+        return phs
+
     def histogram(self, lo_db, hi_db, nbins):
         bins = np.zeros(nbins + 2, dtype=np.int64)
         _chk(lib().fastmc_histogram(self._h, float(lo_db), float(hi_db), int(nbins), bins.ctypes.data_as(C.POINTER(C.c_int64))))
@@ -305,6 +317,11 @@ class Handle:
 
     def set_batch(self, batch):
         _chk(lib().fastmc_set_batch(self._h, int(batch)))
+
+    def set_rng_precision(self, precision):
+        """Device generator: 'f32' (default; fused into the row kernels) or 'f64' (the reference's 53-bit normals and
+        float64 colouring; draws staged in device memory)."""
+        _chk(lib().fastmc_set_rng_precision(self._h, {"f64": F64, "f32": F32}[precision]))
 
     # ---- RCCL (the communicator belongs to the handle's DEVICE and outlives the handle)
     def comm_init(self, unique_id, world_size, rank):

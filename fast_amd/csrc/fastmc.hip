@@ -143,6 +143,7 @@ struct fastmc_ctx {
   double* gather_buf = nullptr;
   size_t gather_cap = 0;
   // fastmc_run_async: kernels enqueued, events not read yet (fastmc_wait / the exchange finish the bookkeeping)
+  int rng_f64 = 0;        // fastmc_set_rng_precision: the device generator at float64 precision (coefficients staged in cre / cim)
   bool pending = false;
   size_t last_out_doubles = 0;    // size of the last run's result vector in `out`
   hipEvent_t ex_a = nullptr, ex_b = nullptr;   // around the collectives of the last exchange
@@ -444,6 +445,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   h->last_n_iter = 0;
   h->last_coherent = 0;
   h->batch = 0;
+  h->rng_f64 = 0;
   h->path = default_path(h->N, h->blu_P, h->mr_P);
   h->lo = 0;
   h->df = h->dx = h->wsum = 0;
@@ -487,6 +489,14 @@ extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
 extern "C" int fastmc_set_batch(fastmc_t* h, int batch) {
   if (!h || batch < 0) return fail(FASTMC_EINVAL, "bad batch");
   h->batch = batch;
+  return 0;
+}
+#endif
+
+#if FMC_TU == 0
+extern "C" int fastmc_set_rng_precision(fastmc_t* h, int precision) {
+  if (!h || (precision != FASTMC_F64 && precision != FASTMC_F32)) return fail(FASTMC_EINVAL, "precision must be FASTMC_F64 or FASTMC_F32");
+  h->rng_f64 = precision == FASTMC_F64;
   return 0;
 }
 #endif
@@ -1174,7 +1184,11 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
   const int N = h->N, Np = h->Np;
   const size_t N2 = (size_t)N * N;
   int B = default_batch(h);
+  // device generator at float64 precision: the draws of a batch are staged like uploaded coefficients (16 B each), <= 2 GiB
+  const bool gen64 = S.mode == 0 && h->rng_f64;
+  const int kmode = (S.mode == 1 || gen64) ? 1 : 0;           // MODE of the row kernels
   if (S.mode == 1) B = std::max(1, std::min<int>(B, (int)(256.0 * 1024 * 1024 / (N2 * 8.0))));
+  if (gen64) B = std::max(1, std::min<int>(B, (int)(2048.0 * 1024 * 1024 / (N2 * 16.0))));
   if (S.epi == 1) B = std::max(1, std::min<int>(B, (int)(256.0 * 1024 * 1024 / (2.0 * Np * Np * 8.0))));
   B = (int)std::min<int64_t>(B, S.n_real);
 
@@ -1199,7 +1213,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     TRY(grow(&h->logamp, &h->logamp_cap, (size_t)S.n_real * 2));
     HIPCHK(hipMemcpyAsync(h->logamp, S.logamp, (size_t)S.n_real * 16, hipMemcpyHostToDevice, h->stream));
   }
-  if (S.mode == 1 && h->coef_cap < (size_t)B) {
+  if (kmode == 1 && h->coef_cap < (size_t)B) {
     if (h->cre) HIPCHK(hipFree(h->cre));
     if (h->cim) HIPCHK(hipFree(h->cim));
     h->cre = h->cim = nullptr; h->coef_cap = 0;
@@ -1229,6 +1243,11 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     if (S.mode == 1) {
       HIPCHK(hipMemcpyAsync(h->cre, S.coeff_re + (size_t)bs * N2, (size_t)nb * N2 * 8, hipMemcpyHostToDevice, h->stream));
       HIPCHK(hipMemcpyAsync(h->cim, S.coeff_im + (size_t)bs * N2, (size_t)nb * N2 * 8, hipMemcpyHostToDevice, h->stream));
+    } else if (gen64) {
+      Span sg(h, 0);     // counted with the row pass: in float32 mode the generator is part of the row kernel
+      const int64_t threads = (int64_t)nb * N * stream_lanes(N);
+      hipLaunchKernelGGL(k_gen_coeffs_f64, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream, key, (uint64_t)(S.real0 + bs), nb, N,
+                         h->cre, h->cim);
     }
     if (sh) {
       ShCoefArgs SA;
@@ -1239,7 +1258,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
         HIPCHK(hipMemcpyAsync(h->sh_in_im, S.sh_im + (size_t)bs * 27, (size_t)nb * 27 * 8, hipMemcpyHostToDevice, h->stream));
         SA.sh_re = h->sh_in_re; SA.sh_im = h->sh_in_im;
       }
-      SA.scale = h->sh_scale; SA.mu = h->sh_mu; SA.coef = h->sh_coef; SA.mean = h->sh_mean;
+      SA.scale = h->sh_scale; SA.mu = h->sh_mu; SA.coef = h->sh_coef; SA.mean = h->sh_mean; SA.rng_f64 = h->rng_f64;
       hipLaunchKernelGGL(k_subharm_coeffs, dim3((nb + 63) / 64), dim3(64), 0, h->stream, SA);
       if (h->sh_sep)
         hipLaunchKernelGGL(k_subharm_cols, dim3((nb * Np + 255) / 256), dim3(256), 0, h->stream, (const double*)h->sh_coef,
@@ -1259,8 +1278,8 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
 #ifdef FMC_ISA_SUBSET   // tools/isa_stats.py: only the kernels whose instruction mix bench.py prices (same code, a tenth of the compile time)
     RA.amp = (const R*)h->amp_s; RA.ampf = h->ampf_s; RA.tw = (const cpx<R>*)h->tw1; CA.tw = RA.tw;
     RA.cw = (const cpx<R>*)h->cw; CA.cw = RA.cw; RA.tw_global = CA.tw_global = 0;
-    if (h->S == 2) dispatch_wave<R, 16, 2, 2>(h, RA, CA, S.mode, S.epi);
-    else dispatch_wave<R, 16, 2>(h, RA, CA, S.mode, S.epi);
+    if (h->S == 2) dispatch_wave<R, 16, 2, 2>(h, RA, CA, kmode, S.epi);
+    else dispatch_wave<R, 16, 2>(h, RA, CA, kmode, S.epi);
 #else
     if (h->path == 2) {
       TRY(upload_blu_tables<R>(h));
@@ -1269,13 +1288,13 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       RA.blu.twf = (const cpx<R>*)h->blu_twf; RA.blu.pre = (const cpx<R>*)h->blu_pre;
       RA.blu.vhat = (const cpx<R>*)h->blu_vhat; RA.blu.post = (const cpx<R>*)h->blu_post;
       CA.tw = RA.tw; CA.om = RA.om; CA.cw = nullptr; CA.tw_global = 0; CA.blu = RA.blu;
-      TRY(dispatch_blu<R>(h, RA, CA, S.mode, S.epi));
+      TRY(dispatch_blu<R>(h, RA, CA, kmode, S.epi));
     } else if (h->path == 3) {
       TRY(upload_mr_tables<R>(h));
       RA.amp = (const R*)h->amp_s; RA.ampf = h->ampf_s; RA.tw = (const cpx<R>*)h->mr_tw1; RA.om = (const cpx<R>*)h->mr_om;
       RA.cw = (const cpx<R>*)h->mr_cw; RA.tw_global = 0;
       CA.tw = RA.tw; CA.om = RA.om; CA.cw = RA.cw; CA.tw_global = 0;
-      TRY(dispatch_mr<R>(h, RA, CA, S.mode, S.epi));
+      TRY(dispatch_mr<R>(h, RA, CA, kmode, S.epi));
     } else {
     bool wave_ok = h->path == 1;
     bool general_2048 = false;   // N = 2048, window > 256 pixels, host coefficients: single-pass P = 32 kernels
@@ -1284,7 +1303,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       wave_config<R>(h, &ns, &wpb_unused);
       if (ns == 0) {
         // window tables exceed the LDS / no instantiation: direct family (still on the GPU)
-        if (h->N == 2048 && S.mode == 1 && wave_lds_bytes<R, 32, 32>(h->omS) <= LDS_MAX) general_2048 = true;
+        if (h->N == 2048 && kmode == 1 && wave_lds_bytes<R, 32, 32>(h->omS) <= LDS_MAX) general_2048 = true;
         else wave_ok = false;
       }
     }
@@ -1297,9 +1316,9 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     CA.tw_global = 0;
     CA.cw = RA.cw;
     if (general_2048 || wave_ok) {
-      TRY(dispatch_wave_family<R>(h, RA, CA, S.mode, S.epi, general_2048));
+      TRY(dispatch_wave_family<R>(h, RA, CA, kmode, S.epi, general_2048));
     } else {
-      TRY(dispatch_direct<R>(h, RA, CA, S.mode, S.epi));
+      TRY(dispatch_direct<R>(h, RA, CA, kmode, S.epi));
     }
     }
 #endif
@@ -1310,7 +1329,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
         FinArgs FA;
         FA.nb = (int)(done - fin_start); FA.Np = Np; FA.coherent = S.coherent; FA.n_real = S.n_real; FA.j0 = fin_start;
         FA.partial = h->partial; FA.logamp = S.logamp ? h->logamp : nullptr;
-        FA.logamp_sigma = std::sqrt(S.logamp_var); FA.key = key; FA.g0 = (uint64_t)(S.real0 + fin_start);
+        FA.logamp_sigma = std::sqrt(S.logamp_var); FA.rng_f64 = h->rng_f64; FA.key = key; FA.g0 = (uint64_t)(S.real0 + fin_start);
         FA.dx2 = h->dx * h->dx; FA.norm = h->wsum * (h->dx * h->dx); FA.out = h->out;
         hipLaunchKernelGGL(k_finalize, dim3((FA.nb + 3) / 4), dim3(256), 0, h->stream, FA);
         fin_start = done;
@@ -1423,7 +1442,7 @@ extern "C" int fastmc_rng_coeffs(fastmc_t* h, uint64_t seed, int64_t real, doubl
   ScratchBuf d;
   HIPCHK(hipMalloc((void**)&d.p, (size_t)N * N * 16));
   RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
-  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * stream_lanes(N) + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, d.p);
+  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * stream_lanes(N) + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, h->rng_f64, d.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, d.p, (size_t)N * N * 16, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1440,7 +1459,7 @@ extern "C" int fastmc_rng_logamp(fastmc_t* h, uint64_t seed, int64_t iter0, int6
   HIPCHK(hipMalloc((void**)&d.p, (size_t)n_iter * 8));
   RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
   hipLaunchKernelGGL(k_rng_logamp, dim3((unsigned)((n_iter + 255) / 256)), dim3(256), 0, h->stream, key, (uint64_t)iter0,
-                     n_iter, d.p);
+                     n_iter, h->rng_f64, d.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, d.p, (size_t)n_iter * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1462,34 +1481,45 @@ extern "C" int fastmc_set_layer_screens(fastmc_t* h, const double* screens, int 
 #endif
 
 #if FMC_TU == 0
-extern "C" int fastmc_temporal_chunk(fastmc_t* h, const double* xs, const double* ys, const int32_t* roll, int M,
-                                     const double* logamp, int coherent, double* out) {
-  if (!h || !xs || !ys || !roll || !logamp || !out || M < 1) return fail(FASTMC_EINVAL, "bad argument");
+// one chunk of the frozen-flow series: detector results (out != NULL) and / or the phases themselves (phs != NULL)
+static int temporal_impl(fastmc_ctx* h, const double* xs, const double* ys, const int32_t* roll, int M, const double* logamp,
+                         int coherent, double* out, double* phs) {
+  if (!h || !xs || !ys || !roll || M < 1 || (!out && !phs) || (out && !logamp)) return fail(FASTMC_EINVAL, "bad argument");
   if (!h->have_pupil) return fail(FASTMC_ESTATE, "set_pupil must be called first");
   if (!h->layers) return fail(FASTMC_ESTATE, "set_layer_screens must be called first");
   if (h->N < 2) return fail(FASTMC_EINVAL, "N must be at least 2");
   HIPCHK(hipSetDevice(h->device));
   const int L = h->n_layers, Np = h->Np;
-  const size_t nc = (size_t)L * M * Np;
-  ScratchBuf dxs, dys, dla, dout, droll;
-  HIPCHK(hipMalloc((void**)&dxs.p, nc * 8));
-  HIPCHK(hipMalloc((void**)&dys.p, nc * 8));
-  HIPCHK(hipMalloc((void**)&dla.p, (size_t)M * 8));
-  HIPCHK(hipMalloc((void**)&dout.p, (size_t)M * 16));
-  HIPCHK(hipMalloc((void**)&droll.p, (size_t)L * 2 * M * 4 + 8));
-  HIPCHK(hipMemcpyAsync(dxs.p, xs, nc * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(dys.p, ys, nc * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(dla.p, logamp, (size_t)M * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(droll.p, roll, (size_t)L * 2 * M * 4, hipMemcpyHostToDevice, h->stream));
+  const size_t nc = (size_t)L * M * Np, np2 = (size_t)M * Np * Np;
+  // one scratch slab per call: [xs nc][ys nc][logamp M][out 2 M][roll (L 2 M ints, padded)][phs M Np Np]
+  const size_t o_ys = nc, o_la = 2 * nc, o_out = o_la + M, o_roll = o_out + 2 * (size_t)M, o_phs = o_roll + ((size_t)L * 2 * M + 1) / 2 + 1;
+  ScratchBuf d;
+  HIPCHK(hipMalloc((void**)&d.p, (o_phs + (phs ? np2 : 0)) * 8));
+  HIPCHK(hipMemcpyAsync(d.p, xs, nc * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d.p + o_ys, ys, nc * 8, hipMemcpyHostToDevice, h->stream));
+  if (out) HIPCHK(hipMemcpyAsync(d.p + o_la, logamp, (size_t)M * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d.p + o_roll, roll, (size_t)L * 2 * M * 4, hipMemcpyHostToDevice, h->stream));
   TemporalArgs A;
   A.N = h->N; A.Np = Np; A.L = L; A.M = M; A.coherent = coherent;
-  A.screens = h->layers; A.xs = dxs.p; A.ys = dys.p; A.roll = (const int*)droll.p; A.W = h->W; A.logamp = dla.p;
-  A.dx2 = h->dx * h->dx; A.norm = h->wsum * (h->dx * h->dx); A.out = dout.p;
+  A.screens = h->layers; A.xs = d.p; A.ys = d.p + o_ys; A.roll = (const int*)(d.p + o_roll); A.W = h->W; A.logamp = d.p + o_la;
+  A.dx2 = h->dx * h->dx; A.norm = h->wsum * (h->dx * h->dx); A.out = out ? d.p + o_out : nullptr; A.phs = phs ? d.p + o_phs : nullptr;
   hipLaunchKernelGGL(k_temporal_detect, dim3(M), dim3(256), 0, h->stream, A);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)M * 8 * (coherent ? 2 : 1), hipMemcpyDeviceToHost, h->stream));
+  if (out) HIPCHK(hipMemcpyAsync(out, d.p + o_out, (size_t)M * 8 * (coherent ? 2 : 1), hipMemcpyDeviceToHost, h->stream));
+  if (phs) HIPCHK(hipMemcpyAsync(phs, d.p + o_phs, np2 * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
+}
+
+extern "C" int fastmc_temporal_chunk(fastmc_t* h, const double* xs, const double* ys, const int32_t* roll, int M,
+                                     const double* logamp, int coherent, double* out) {
+  if (!out || !logamp) return fail(FASTMC_EINVAL, "bad argument");
+  return temporal_impl(h, xs, ys, roll, M, logamp, coherent, out, nullptr);
+}
+
+extern "C" int fastmc_temporal_phases(fastmc_t* h, const double* xs, const double* ys, const int32_t* roll, int M, double* phs) {
+  if (!phs) return fail(FASTMC_EINVAL, "bad argument");
+  return temporal_impl(h, xs, ys, roll, M, nullptr, 0, nullptr, phs);
 }
 #endif
 

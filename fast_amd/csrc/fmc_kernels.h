@@ -84,6 +84,29 @@ __device__ __forceinline__ xoshiro128p row_stream(RngKey key, uint64_t g, int ky
 #endif
   return s;
 }
+// ---- the generator at the reference's precision (GPU_RNG_PRECISION 'f64'; fast/funcs.py:352-356 draws 53-bit normals)
+// The SAME two words (a, b) of stream (g, ky, L) give the leading bits, a second stream (counter word 1 = STREAM_SCREEN_LO,
+// otherwise seeded alike) the rest:  u = (a 2^21 + (a' >> 11) + 1/2) 2^-53,  turns t = ((b >> 9) 2^30 + (b' >> 2)) 2^-53,
+// (re, im) = sqrt(-2 ln u) (cos, sin)(2 pi t) in float64 (libm log / sqrt / sincospi).  The float32 generator is this draw
+// with u and t cut to their first 24 / 23 bits, so the two modes see the same normals to ~2^-24 (tests bound what the
+// float32 shortcut changes in the powers).  Tails reach 8.6 sigma.
+constexpr uint32_t STREAM_SCREEN_LO = 3;
+constexpr uint32_t STREAM_SUBHARM_LO = 4;
+__device__ __forceinline__ xoshiro128p row_stream_lo(RngKey key, uint64_t g, int ky, int L, int SL) {
+  xoshiro128p s;
+  s.seed(philox4x32<FMC_SEED_ROUNDS>((uint32_t)(ky * SL + L), STREAM_SCREEN_LO, (uint32_t)g, (uint32_t)(g >> 32), key.k0, key.k1));
+  return s;
+}
+__device__ __forceinline__ void box_muller_f64(uint32_t a, uint32_t b, uint32_t a2, uint32_t b2, double& re, double& im) {
+  const double u = ((double)(((uint64_t)a << 21) | (uint64_t)(a2 >> 11)) + 0.5) * 0x1p-53;
+  const double t = (double)(((uint64_t)(b >> 9) << 30) | (uint64_t)(b2 >> 2)) * 0x1p-53;
+  const double r = sqrt(-2.0 * log(u));
+  double sn, cs;
+  sincospi(2.0 * t, &sn, &cs);
+  re = r * cs;
+  im = r * sn;
+}
+
 #ifndef FMC_RNG_PAIR
 #define FMC_RNG_PAIR 1
 #endif
@@ -121,6 +144,13 @@ __device__ __forceinline__ float draw_logamp_normal(RngKey key, uint64_t iter) {
   const u32x4 x = philox4x32_10(0u, STREAM_LOGAMP, (uint32_t)iter, (uint32_t)(iter >> 32), key.k0, key.k1);
   float a, b;
   box_muller(x.a, x.b, a, b);
+  return a;
+}
+// the same draw with all four words of the block: words a, b lead (as in the float32 draw), c, d supply the low bits
+__device__ __forceinline__ double draw_logamp_normal_f64(RngKey key, uint64_t iter) {
+  const u32x4 x = philox4x32_10(0u, STREAM_LOGAMP, (uint32_t)iter, (uint32_t)(iter >> 32), key.k0, key.k1);
+  double a, b;
+  box_muller_f64(x.a, x.b, x.c, x.d, a, b);
   return a;
 }
 
@@ -310,6 +340,29 @@ struct GpuExec {
   }
   static __device__ __forceinline__ cpx<double> ld(const cpx<double>* p) { return *p; }     // 16 bytes: one ds_read_b128
   template <class E> static __device__ __forceinline__ void st(E* p, E v) { *p = v; }
+  // 16-byte elements (one-pass exchange 2 of the float64 16 x 4 row): ONE ds_write_b128.  Left to the type's 8-byte
+  // alignment hipcc emits ds_write2_b64, whose 16-lane groups at a 16-byte stride span 64 dwords on 32 store banks: 2-way
+  // conflicts on both halves (SQ_LDS_BANK_CONFLICT 2.2e6 -> 5.3e7 per launch in round 2); ds_write_b128 is serviced in groups
+  // of 8 lanes = 32 consecutive dwords, conflict-free.  Every exchange buffer starts on a 16-byte boundary.
+#ifndef FMC_ALIGNED_ST128
+#define FMC_ALIGNED_ST128 0     // A/B (round 3): the conflict-free ds_write_b128 runs the rows kernel 7 % SLOWER than hipcc's ds_write2_b64
+#endif                          // with its 2-way conflicts (9.35 against 8.70 ms per 5000 realisations): the store form, not the conflicts, sets the time
+#ifndef FMC_ST_SINGLE
+#define FMC_ST_SINGLE 0         // A/B: every exchange store as a single ds_write_b64 (no ds_write2_b64 pairing)
+#endif
+#if FMC_ST_SINGLE
+  static __device__ __forceinline__ void st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+  static __device__ __forceinline__ void st(cpx<double>* p, cpx<double> v) {
+    __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+#endif
+#if FMC_ALIGNED_ST128
+  static __device__ __forceinline__ void st(cpx<double>* p, cpx<double> v) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<d2_t*>(__builtin_assume_aligned(p, 16)) = (d2_t){v.x, v.y};
+  }
+#endif
   // two neighbouring 8-byte elements at a 16-byte aligned address: one ds_read_b128
   template <class E> static __device__ __forceinline__ void ld2(const E* p, E& a, E& b) {
     struct alignas(16) Pair { E a, b; };
@@ -1221,6 +1274,7 @@ struct ShCoefArgs {
   const double* mu;      // [27][2]
   double* coef;          // [nb][27][2]
   double* mean;          // [nb][2]
+  int rng_f64;           // device draws at float64 precision (box_muller_f64; low bits from blocks of STREAM_SUBHARM_LO)
 };
 
 __global__ void k_subharm_coeffs(ShCoefArgs A) {
@@ -1234,6 +1288,15 @@ __global__ void k_subharm_coeffs(ShCoefArgs A) {
   } else {
     for (int mp = 0; mp < 14; ++mp) {   // pairs (mp, mp + 14), H = ceil(27/2)
       const u32x4 x = philox4x32_10((uint32_t)mp, STREAM_SUBHARM, (uint32_t)g, (uint32_t)(g >> 32), A.key.k0, A.key.k1);
+      if (A.rng_f64) {
+        const u32x4 y = philox4x32_10((uint32_t)mp, STREAM_SUBHARM_LO, (uint32_t)g, (uint32_t)(g >> 32), A.key.k0, A.key.k1);
+        double a, bb, c, d;
+        box_muller_f64(x.a, x.b, y.a, y.b, a, bb);
+        box_muller_f64(x.c, x.d, y.c, y.d, c, d);
+        cr[mp] = a; ci[mp] = bb;
+        if (mp + 14 < 27) { cr[mp + 14] = c; ci[mp + 14] = d; }
+        continue;
+      }
       float a, bb, c, d;
       box_muller(x.a, x.b, a, bb);
       box_muller(x.c, x.d, c, d);
@@ -1278,6 +1341,7 @@ struct FinArgs {
   const double* partial;      // [nb][Np][4]
   const double* logamp;       // [2*n_real] in output order, or NULL -> device draw
   double logamp_sigma;        // sqrt(logamp_var)
+  int rng_f64;                // device draw at float64 precision
   RngKey key;
   uint64_t g0;                // global realisation index of j0
   double dx2, norm;           // dx^2, sum(W) * dx^2
@@ -1303,6 +1367,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs A) {
   const int64_t o = part * A.n_real + j;
   double chi;
   if (A.logamp) chi = A.logamp[o];
+  else if (A.rng_f64) chi = draw_logamp_normal_f64(A.key, 2 * (A.g0 + (uint64_t)b) + part) * A.logamp_sigma;
   else chi = (double)draw_logamp_normal(A.key, 2 * (A.g0 + (uint64_t)b) + part) * A.logamp_sigma;
   const double e = exp(chi);
   const double ar = (e * (s[2 * part] * A.dx2)) / A.norm;
@@ -1325,7 +1390,8 @@ struct TemporalArgs {
   const double* W;         // [Np][Np]
   const double* logamp;    // [M]
   double dx2, norm;
-  double* out;             // [M] or [M][2]
+  double* out;             // [M] or [M][2]; NULL: phases only
+  double* phs;             // [M][Np][Np] the summed, shifted phase of every time step (Fast.phs, fast/fast.py:633), or NULL
 };
 
 __device__ __forceinline__ void bilinear_cell(double x, int N, int& i, double& t) {
@@ -1354,12 +1420,14 @@ __global__ __launch_bounds__(256) void k_temporal_detect(TemporalArgs A) {
       const double* z = A.screens + (size_t)l * N * N + (size_t)i0 * N + j0;
       phi += (1 - t) * ((1 - u) * z[0] + u * z[1]) + t * ((1 - u) * z[N] + u * z[N + 1]);
     }
+    if (A.phs) A.phs[(size_t)j * Np * Np + pix] = phi;
     double s, c;
     sincos_r(phi, s, c);
     const double w = A.W[pix];
     sr += w * c;
     si += w * s;
   }
+  if (!A.out) return;          // phases only (uniform over the block)
   sr = wave_sum(sr);
   si = wave_sum(si);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1507,23 +1575,54 @@ __global__ void k_link_final(const double* partial, int nblocks, int64_t n, cons
 }
 
 // ================================================================== generator read-back (parity tests)
-__global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, double* out) {
+__global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, int rng_f64, double* out) {
   const int SL = stream_lanes(N);
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * SL) return;
   const int ky = idx / SL, l = idx % SL;
   if (l >= N) return;
-  xoshiro128p rs = row_stream(key, g, ky, l, SL);
+  xoshiro128p rs = row_stream(key, g, ky, l, SL), rlo = row_stream_lo(key, g, ky, l, SL);
   for (int kx = l; kx < N; kx += SL) {
-    const cpx<double> c = draw_coeff<double>(rs);
+    cpx<double> c;
+    if (rng_f64) {
+      uint32_t a, b, a2, b2;
+      draw_words(rs, a, b);
+      draw_words(rlo, a2, b2);
+      box_muller_f64(a, b, a2, b2, c.x, c.y);
+    } else {
+      c = draw_coeff<double>(rs);
+    }
     out[2 * ((size_t)ky * N + kx)] = c.x;
     out[2 * ((size_t)ky * N + kx) + 1] = c.y;
   }
 }
 
-__global__ void k_rng_logamp(RngKey key, uint64_t it0, int64_t n, double* out) {
+// GPU_RNG_PRECISION 'f64': the coefficients of nb realisations at float64 precision, written where host-coefficient mode
+// keeps its uploads ([nb][N][N] real parts, imaginary parts); the MODE 1 kernels then colour them in float64 as the
+// reference does (fast/fast.py:594).  One thread per stream, neighbouring threads neighbouring columns.
+__global__ __launch_bounds__(256) void k_gen_coeffs_f64(RngKey key, uint64_t g0, int nb, int N, double* cre, double* cim) {
+  const int SL = stream_lanes(N);
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)nb * N * SL) return;
+  const int l = (int)(idx % SL), ky = (int)((idx / SL) % N), b = (int)(idx / ((int64_t)SL * N));
+  if (l >= N) return;
+  const uint64_t g = g0 + (uint64_t)b;
+  xoshiro128p rs = row_stream(key, g, ky, l, SL), rlo = row_stream_lo(key, g, ky, l, SL);
+  const size_t base = ((size_t)b * N + ky) * N;
+  for (int kx = l; kx < N; kx += SL) {
+    uint32_t a, bb, a2, b2;
+    draw_words(rs, a, bb);
+    draw_words(rlo, a2, b2);
+    double re, im;
+    box_muller_f64(a, bb, a2, b2, re, im);
+    cre[base + kx] = re;
+    cim[base + kx] = im;
+  }
+}
+
+__global__ void k_rng_logamp(RngKey key, uint64_t it0, int64_t n, int rng_f64, double* out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (double)draw_logamp_normal(key, it0 + (uint64_t)i);
+  if (i < n) out[i] = rng_f64 ? draw_logamp_normal_f64(key, it0 + (uint64_t)i) : (double)draw_logamp_normal(key, it0 + (uint64_t)i);
 }
 
 #endif   // FMC_TU == 0

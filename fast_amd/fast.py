@@ -12,6 +12,8 @@ Differences from the reference, all deliberate:
     the number of GPUs; 'host' draws them with numpy in the reference's order, so the same
     SEED reproduces the reference's `result._r` to ~1e-10 (parity mode, PCIe-bound);
   * `GPU_PRECISION`: 'f64' (default, complex128 like the reference) or 'f32';
+  * `GPU_RNG_PRECISION`: 'f32' (default) or 'f64' -- the device generator's normals and the colouring multiply at the
+    reference's float64 precision (funcs.py:352-356, fast.py:594), ~4x slower;
   * `TEMPORAL` (frozen-flow time series, fast.py:607-637): the layer screens, the bilinear shifts and
     the detector run on the GPU; its draws are always numpy's, in the reference's order (the
     series is sequential and tiny), so the same SEED reproduces the reference;
@@ -101,6 +103,8 @@ class Fast():
             raise Exception("GPU_PRECISION must be 'f64' or 'f32'")
         if self.rng_mode not in ('device', 'host'):
             raise Exception("GPU_RNG must be 'device' or 'host'")
+        if p['GPU_RNG_PRECISION'] not in ('f32', 'f64'):
+            raise Exception("GPU_RNG_PRECISION must be 'f32' or 'f64'")
         devs = p['GPU_DEVICES']
         if devs is not None:
             devs = [int(d) for d in (devs if isinstance(devs, (list, tuple, numpy.ndarray)) else [devs])]
@@ -118,6 +122,8 @@ class Fast():
         self._handle = self._group.handles[0]
         if p['GPU_BATCH']:
             self._group.set_batch(p['GPU_BATCH'])
+        if p['GPU_RNG_PRECISION'] == 'f64':
+            self._group.each(lambda h, i: h.set_rng_precision('f64'))
         if p['GPU_KERNELS'] != 'auto':
             if p['GPU_KERNELS'] not in _lib.KERNEL_PATHS:
                 raise Exception("GPU_KERNELS must be 'auto', 'wave', 'lanes50', 'chirpz' or 'direct'")
@@ -289,6 +295,9 @@ class Fast():
         _R.normal(0, 1, size=(self.Niter,))
         self.logamp[:] = re * numpy.sqrt(self.logamp_var)
         for i in range(self.Nchunks):
+            if i == self.Nchunks - 1:
+                # `phs` re-draws the last chunk from here on demand (the reference keeps its screens, fast.py:596-603)
+                self._last_chunk_state = _R.bit_generator.state
             cr = _R.normal(0, 1, size=(half, N, N))
             ci = _R.normal(0, 1, size=(half, N, N))
             sr = si = None
@@ -310,13 +319,12 @@ class Fast():
         L = self.powerspec_per_layer.shape[0]
         cr = _R.normal(0, 1, size=(L, N, N))
         ci = _R.normal(0, 1, size=(L, N, N))
-        full = _lib.Handle(N, N, self.precision, self.device)
-        full.set_pupil(numpy.ones((N, N)), 0, self.dx)
-        scrns = numpy.empty((L, N, N))
-        for l in range(L):
-            full.set_spectrum(self.powerspec_per_layer[l], prob.df)
-            scrns[l] = full.screens_coeffs(cr[l:l + 1], ci[l:l + 1])[0]
-        full.close()
+        # the L layer screens in ONE batched launch: the coefficients are coloured here exactly as the reference colours them
+        # (rand *= sqrt(powerspec_per_layer), fast.py:610-612) and transformed with a unit spectrum (the `* df` of
+        # funcs.py:213 is the handle's amplitude); window = the whole grid
+        full = self._full_window_handle()
+        amp = numpy.sqrt(self.powerspec_per_layer)
+        scrns = full.screens_coeffs(cr * amp, ci * amp)[:L]
         self._handle.set_layer_screens(scrns)
         pup = prob.pup.pup_coords.astype(float)
         interp = pup[numpy.newaxis, :, numpy.newaxis, :] + self.pixel_shifts[:, :, :, numpy.newaxis]
@@ -324,8 +332,19 @@ class Fast():
         for i in range(self.Nchunks):
             coord, shifts = host.temporal_coords(interp, N)
             I[i] = self._handle.temporal_chunk(coord[:, 0], coord[:, 1], shifts, self.logamp[i * M:(i + 1) * M], coherent)
+            self._last_temporal = (coord[:, 0], coord[:, 1], shifts)
             interp = interp + self.pixel_shifts[:, :, -1, numpy.newaxis, numpy.newaxis]
             self.interp_coords = interp                  # advanced after every chunk, as fast.py:635 leaves it
+
+    def _full_window_handle(self):
+        """A handle whose window is the whole N x N grid with a unit spectrum (layer screens of TEMPORAL runs); kept on
+        the object: every run() of a time series needs it again."""
+        if getattr(self, "_full", None) is None:
+            N = self.Npxls
+            self._full = _lib.Handle(N, N, self.precision, self.device)
+            self._full.set_pupil(numpy.ones((N, N)), 0, self.dx)
+            self._full.set_spectrum(numpy.ones((N, N)), self._prob.df)
+        return self._full
 
     def _transport(self):
         """The result exchange of a one-process-per-GPU run, or None.  GPU_SHARD: 'auto' (default) shards when a
@@ -403,11 +422,26 @@ class Fast():
 
     @property
     def phs(self):
-        """Phase screens of the LAST chunk, (NITER/NCHUNKS, Np, Np), as `Fast.phs` holds them after
-        `run()` in the reference (fast.py:596-603).  Device-generator runs recompute them on the GPU."""
-        if self.temporal or self.rng_mode != 'device' or not hasattr(self, "_device_seed"):
-            raise AttributeError("phs is available after run() in device-generator, non-temporal mode")
+        """Phase screens of the LAST chunk, (NITER/NCHUNKS, Np, Np), as `Fast.phs` holds them after `run()` in the
+        reference (fast.py:596-603, 633).  Recomputed on the GPU when read: device-generator runs from the seed, host-generator
+        runs by re-drawing the last chunk from the generator state kept at its start, TEMPORAL runs from the last chunk's
+        sample coordinates and the layer screens still resident on the device."""
+        if not hasattr(self, "result"):
+            raise AttributeError("phs is available after run()")
         half = self.Niter_per_chunk // 2
+        if self.temporal:
+            return self._handle.temporal_phases(*self._last_temporal)
+        if self.rng_mode == 'host':
+            N = self.Npxls
+            rng = numpy.random.default_rng()
+            rng.bit_generator.state = self._last_chunk_state
+            cr = rng.normal(0, 1, size=(half, N, N))
+            ci = rng.normal(0, 1, size=(half, N, N))
+            sr = si = None
+            if self.subharmonics:
+                sr = rng.normal(0, 1, size=(half, 3, 3, 3))
+                si = rng.normal(0, 1, size=(half, 3, 3, 3))
+            return self._handle.screens_coeffs(cr, ci, sr, si)
         return self._handle.screens(self._device_seed, (self.Nchunks - 1) * half, half)
 
     def result_stats(self, thresholds_dB_rel=()):

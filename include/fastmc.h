@@ -132,6 +132,9 @@ int fastmc_rng_logamp(fastmc_t* h, uint64_t seed, int64_t iter0, int64_t n_iter,
 int fastmc_set_layer_screens(fastmc_t* h, const double* screens, int n_layers);
 int fastmc_temporal_chunk(fastmc_t* h, const double* xs, const double* ys, const int32_t* roll, int M,
                           const double* logamp, int coherent, double* out);
+/* The phases of the same chunk, (M, Np, Np): the wind-shifted, bilinearly sampled layer screens summed over the layers --
+ * what the reference leaves in Fast.phs after a TEMPORAL chunk (fast/fast.py:619-633). */
+int fastmc_temporal_phases(fastmc_t* h, const double* xs, const double* ys, const int32_t* roll, int M, double* phs);
 
 /* Make a result vector the handle's resident results (n_iter float64 powers, or n_iter complex128
  * amplitudes when coherent): what fastmc_histogram / fastmc_result_stats / fastmc_link_metrics /
@@ -194,6 +197,15 @@ int fastmc_kernel_path(fastmc_t* h, int force);
 
 /* Realisations in flight per launch (batch).  0 = library default. */
 int fastmc_set_batch(fastmc_t* h, int batch);
+
+/* Precision of the DEVICE generator (fastmc_run / fastmc_run_async / fastmc_screens; not of the transform, which
+ * fastmc_create fixes).  FASTMC_F32 (default): 24-bit uniforms, hardware float32 log / sqrt / sin / cos, float32
+ * colouring, fused into the row kernels.  FASTMC_F64: the reference's precision (fast/funcs.py:352-356 draws 53-bit normals,
+ * fast/fast.py:594 colours in float64): the same streams with the low bits from a second stream, float64 log / sqrt /
+ * sincospi, the draws of a batch staged in device memory and coloured in float64 by the host-coefficient kernels -- about
+ * four times slower, there so that the price of the float32 shortcut is a measured number (bench.py extras).  Both
+ * restated in oracle/devrng.py.  fastmc_rng_coeffs / fastmc_rng_logamp return the draws of the precision in force. */
+int fastmc_set_rng_precision(fastmc_t* h, int precision);
 
 /* ---- AO-residual power spectrum (Fast.compute_powerspec, fast/fast.py:445-492) ---- */
 #define FASTMC_NOAO 0

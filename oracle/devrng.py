@@ -22,6 +22,7 @@ M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 W0, W1 = 0x9E3779B9, 0xBB67AE85
 MASK = np.uint64(0xFFFFFFFF)
 STREAM_SCREEN, STREAM_LOGAMP, STREAM_SUBHARM = 0, 1, 2
+STREAM_SCREEN_LO, STREAM_SUBHARM_LO = 3, 4      # second streams: the low bits of the float64 generator (fmc_kernels.h)
 
 
 SEED_ROUNDS = 7   # fmc_kernels.h: FMC_SEED_ROUNDS -- Philox rounds of the block that seeds a coefficient stream
@@ -51,6 +52,25 @@ def box_muller(a, b):
     t = (np.asarray(b).astype(np.uint64) >> np.uint64(9)).astype(np.float64) / 2.0 ** 23   # top 23 bits (fmc_kernels.h: angle_turns)
     r = np.sqrt(-2.0 * np.log(u))
     return r * np.cos(2 * np.pi * t) + 1j * r * np.sin(2 * np.pi * t)
+
+
+def box_muller_f64(a, b, a2, b2):
+    """fmc_kernels.h: box_muller_f64 -- the float64 generator (GPU_RNG_PRECISION 'f64'): the words (a, b) of the float32
+    draw lead, (a2, b2) of the second stream supply the low bits:
+      u = (a 2^21 + (a2 >> 11) + 1/2) 2^-53,  t = ((b >> 9) 2^30 + (b2 >> 2)) 2^-53,  sqrt(-2 ln u) exp(2 pi i t)."""
+    a, b, a2, b2 = (np.asarray(w).astype(np.uint64) for w in (a, b, a2, b2))
+    k = (a << np.uint64(21)) | (a2 >> np.uint64(11))
+    u = (k.astype(np.float64) + 0.5) * 2.0 ** -53
+    t = (((b >> np.uint64(9)) << np.uint64(30)) | (b2 >> np.uint64(2))).astype(np.float64) * 2.0 ** -53
+    r = np.sqrt(-2.0 * np.log(u))
+    # sin / cos of 2 pi t by quadrant reduction (t is exact; 2 pi (t - q / 4) carries one rounding of a small angle)
+    q = np.rint(4.0 * t)
+    x = 2 * np.pi * (t - q / 4.0)
+    sn, cs = np.sin(x), np.cos(x)
+    qi = q.astype(np.int64) & 3
+    cos_t = np.where(qi == 0, cs, np.where(qi == 1, -sn, np.where(qi == 2, -cs, sn)))
+    sin_t = np.where(qi == 0, sn, np.where(qi == 1, cs, np.where(qi == 2, -sn, -cs)))
+    return r * cos_t + 1j * r * sin_t
 
 
 def xoshiro128p_next(s):
@@ -126,6 +146,34 @@ def stream_lanes(N):
     return 50 * mr_split(N) if mr_supported(N) else 64 * spec_split(N)
 
 
+def _stream_states(seed, g, N, stream):
+    SL = stream_lanes(N)
+    lanes = min(SL, N)
+    ky, l = np.meshgrid(np.arange(N), np.arange(lanes), indexing="ij")
+    x = philox4x32_10(ky * SL + l, stream, g & 0xFFFFFFFF, g >> 32, seed & 0xFFFFFFFF, seed >> 32, rounds=SEED_ROUNDS)
+    s = [np.array(w, dtype=np.uint64).astype(np.uint32) for w in x]
+    zero = (s[0] | s[1] | s[2] | s[3]) == 0
+    s[0][zero] = 1
+    return s
+
+
+def device_coefficients_f64(seed, g, N):
+    """(N, N) complex coefficients of realisation g with the generator at float64 precision (fastmc_set_rng_precision
+    FASTMC_F64; == fastmc_rng_coeffs then): the streams of `device_coefficients` plus, for the low bits, the streams seeded
+    with counter word 1 = STREAM_SCREEN_LO, combined by `box_muller_f64`."""
+    SL = stream_lanes(N)
+    s, lo = _stream_states(seed, g, N, STREAM_SCREEN), _stream_states(seed, g, N, STREAM_SCREEN_LO)
+    out = np.empty((N, N), dtype=complex)
+    with np.errstate(over="ignore"):
+        for j in range((N + SL - 1) // SL):
+            a, b = xoshiro128p_next2(s)
+            a2, b2 = xoshiro128p_next2(lo)
+            c = box_muller_f64(a, b, a2, b2)
+            w = min(SL, N - SL * j)
+            out[:, SL * j:SL * j + w] = c[:, :w]
+    return out
+
+
 def device_coefficients(seed, g, N):
     """(N, N) complex coefficients of realisation g (== fastmc_rng_coeffs).
 
@@ -152,17 +200,24 @@ def device_coefficients(seed, g, N):
     return out
 
 
-def device_logamp_normals(seed, it0, n):
+def device_logamp_normals(seed, it0, n, f64=False):
+    """Log-amplitude normals of iterations it0 ... it0 + n - 1 (one Philox4x32-10 block each); f64: all four words of the
+    block (fmc_kernels.h: draw_logamp_normal_f64), else the float32 draw's two."""
     it = np.arange(it0, it0 + n, dtype=np.uint64)
-    x0, x1, _, _ = philox4x32_10(0, STREAM_LOGAMP, it & MASK, it >> np.uint64(32), seed & 0xFFFFFFFF, seed >> 32)
-    return box_muller(x0, x1).real
+    x0, x1, x2, x3 = philox4x32_10(0, STREAM_LOGAMP, it & MASK, it >> np.uint64(32), seed & 0xFFFFFFFF, seed >> 32)
+    return box_muller_f64(x0, x1, x2, x3).real if f64 else box_muller(x0, x1).real
 
 
-def device_subharm_coefficients(seed, g):
-    """(3, 3, 3) complex coefficients of realisation g (pairs (m, m+14))."""
+def device_subharm_coefficients(seed, g, f64=False):
+    """(3, 3, 3) complex coefficients of realisation g (pairs (m, m+14)); f64: low bits from the blocks of STREAM_SUBHARM_LO."""
     m = np.arange(14)
     x0, x1, x2, x3 = philox4x32_10(m, STREAM_SUBHARM, g & 0xFFFFFFFF, g >> 32, seed & 0xFFFFFFFF, seed >> 32)
     out = np.empty(27, dtype=complex)
-    out[:14] = box_muller(x0, x1)
-    out[14:] = box_muller(x2, x3)[:13]
+    if f64:
+        y0, y1, y2, y3 = philox4x32_10(m, STREAM_SUBHARM_LO, g & 0xFFFFFFFF, g >> 32, seed & 0xFFFFFFFF, seed >> 32)
+        out[:14] = box_muller_f64(x0, x1, y0, y1)
+        out[14:] = box_muller_f64(x2, x3, y2, y3)[:13]
+    else:
+        out[:14] = box_muller(x0, x1)
+        out[14:] = box_muller(x2, x3)[:13]
     return out.reshape(3, 3, 3)

@@ -134,3 +134,26 @@ def test_split_layouts_cover_the_grid():
     for N in (2048,):
         c = devrng.device_coefficients(5, 0, N)
         assert np.isfinite(c).all() and len(np.unique(c[:4].ravel())) == 4 * N
+
+
+def test_float64_generator_restatement_extends_the_float32_one():
+    """oracle/devrng.py: device_coefficients_f64 (GPU_RNG_PRECISION 'f64') -- standard complex normals whose leading bits
+    are the float32 generator's: the two restatements agree to ~2^-24 relative in u and t."""
+    N = 256
+    a = devrng.device_coefficients(11, 3, N)
+    b = devrng.device_coefficients_f64(11, 3, N)
+    assert np.abs(a - b).max() < 2e-5 and np.abs(a - b).max() > 0
+    z = np.concatenate([devrng.device_coefficients_f64(s, g, N).ravel() for s in (1, 2) for g in (0, 5)])
+    z = np.concatenate([z.real, z.imag])
+    n = z.size
+    assert abs(z.mean()) < 5 / np.sqrt(n) and abs(z.var() - 1) < 5 * np.sqrt(2 / n)
+    assert abs(np.mean(z ** 4) - 3) < 5 * np.sqrt(96 / n)
+    la32, la64 = devrng.device_logamp_normals(3, 10, 1000), devrng.device_logamp_normals(3, 10, 1000, f64=True)
+    assert np.abs(la32 - la64).max() < 2e-5 and abs(la64.std() - 1) < 0.1
+    s32, s64 = devrng.device_subharm_coefficients(3, 7), devrng.device_subharm_coefficients(3, 7, f64=True)
+    assert s64.shape == (3, 3, 3) and np.abs(s32 - s64).max() < 2e-5
+    # extremes of the words stay finite: u in (0, 1), tails to 8.6 sigma
+    top = np.array([0xFFFFFFFF], dtype=np.uint32)
+    zero = np.array([0], dtype=np.uint32)
+    assert np.isfinite(devrng.box_muller_f64(zero, zero, zero, zero)).all() and abs(devrng.box_muller_f64(zero, zero, zero, zero)[0]) > 8.6
+    assert np.isfinite(devrng.box_muller_f64(top, top, top, top)).all() and abs(devrng.box_muller_f64(top, top, top, top)[0]) < 1e-7

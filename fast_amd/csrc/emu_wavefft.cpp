@@ -27,7 +27,6 @@ struct HostExec {
   template <class T> static void pin(T&) {}
   template <class E> static E ld(const E* p) { return *p; }
   template <class E> static void st(E* p, E v) { *p = v; }
-  template <class E> static void ld2(const E* p, E& a, E& b) { a = p[0]; b = p[1]; }
 };
 
 static void cs_turns(double t, double* c, double* s) {
@@ -35,7 +34,6 @@ static void cs_turns(double t, double* c, double* s) {
   *s = std::sin(2.0 * M_PI * t);
 }
 
-static bool g_dense = false;      // P = 16: run the dense-image variant (pruned_row_fft_d16)
 static int g_dense_r16 = 0;       // P = 16: 1 = the 16 x 4 lane factorisation (pruned_row_fft_d16r), 2 = with the centred plane set
 
 template <class R, int P, int NS>
@@ -65,7 +63,6 @@ static double run_case(int lo, int Np, unsigned seed) {
   if constexpr (P == 16) {
     if (g_dense_r16 == 1) pruned_row_fft_d16r<R, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
     else if (g_dense_r16 == 2) pruned_row_fft_d16r<R, NS, D16R_CENTRE_MASK>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
-    else if (g_dense) pruned_row_fft_d16<R, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
     else pruned_row_fft<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
   } else {
     pruned_row_fft<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
@@ -152,6 +149,74 @@ static double run_blu_case(int N, int lo, int Np, unsigned seed) {
     scale = std::fmax(scale, std::fmax(std::fabs((double)sr), std::fabs((double)si)));
   }
   return worst / scale;
+}
+
+// The same row cut into input blocks (fmc_bluestein.h header): SB chirp-z rows of B inputs on the M = 1024 pipeline, window
+// sums accumulated over the blocks -- the form grids longer than the largest M take (2200, 2816, ... <= 4096).
+template <class R, int NS>
+static double run_blu_blocked_case(int N, int lo, int Np, unsigned seed) {
+  constexpr int P = 16, M = WAVE * P;
+  using B_ = BluGeom<R, P>;
+  using E = typename Xch<R>::E;
+  const int B = blu_block_len(Np), SB = blu_blocks(N, Np);
+  std::mt19937_64 gen(seed);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  std::vector<double> inr(N), ini(N);
+  for (int k = 0; k < N; ++k) { inr[k] = nd(gen); ini[k] = nd(gen); }
+  const int omS = NS * WAVE;
+  std::vector<cpx<R>> tw1((size_t)P * WAVE), om((size_t)8 * omS), pre((size_t)SB * B), vhat((size_t)SB * M), post(omS), twf(64);
+  build_tw1<R>(tw1.data(), P, cs_turns);
+  build_om<R>(om.data(), omS, P, 0, Np, cs_turns);
+  if (!build_blu_tables<R>(N, Np, lo, P, pre.data(), vhat.data(), post.data(), omS, twf.data(), cs_turns, B, SB, SB * B)) return 1e30;
+  std::vector<E> xbuf(B_::XELEMS);
+  static HostExec<R, P, NS> ex;
+  std::vector<double> accr((size_t)WAVE * NS, 0.0), acci((size_t)WAVE * NS, 0.0);
+  for (int jb = 0; jb < SB; ++jb) {
+    for (int l = 0; l < WAVE; ++l)
+      for (int j = 0; j < P; ++j) {
+        const int kl = l + WAVE * j, k = jb * B + kl;
+        ex.regs[l].v[j] = (kl < B && k < N) ? cmul(mk<R>((R)inr[k], (R)ini[k]), pre[k]) : mk<R>((R)0, (R)0);
+      }
+    bluestein_row<R, P, NS>(ex, xbuf.data(), tw1.data(), om.data(), omS, twf.data(), vhat.data() + (size_t)jb * M, Np);
+    for (int l = 0; l < WAVE; ++l)
+      for (int s = 0; s < NS; ++s) { accr[l * NS + s] += ex.regs[l].xr[s]; acci[l * NS + s] += ex.regs[l].xi[s]; }
+  }
+  double worst = 0.0, scale = 0.0;
+  const int h = N / 2;
+  for (int oi = 0; oi < Np; ++oi) {
+    const int p = lo + oi;
+    long double sr = 0, si = 0;
+    for (int k = 0; k < N; ++k) {
+      const long long e = (((long long)(p - h) * (k + h)) % N + N) % N;
+      const long double a = -2.0L * M_PIl * (long double)e / N;
+      const long double c = cosl(a), s2 = sinl(a);
+      sr += inr[k] * c - ini[k] * s2;
+      si += inr[k] * s2 + ini[k] * c;
+    }
+    const int l = oi % WAVE, s = oi / WAVE;
+    const double yr = accr[l * NS + s], yi = acci[l * NS + s];
+    const double gr = post[oi].x * yr + post[oi].y * yi, gi = post[oi].y * yr - post[oi].x * yi;   // post * conj(sum Y_j)
+    worst = std::fmax(worst, std::fmax(std::fabs(gr - (double)sr), std::fabs(gi - (double)si)));
+    scale = std::fmax(scale, std::fmax(std::fabs((double)sr), std::fabs((double)si)));
+  }
+  return worst / scale;
+}
+
+template <class R, int NS>
+static int sweep_blu_blocked(const char* name, double tol) {
+  int bad = 0;
+  const int cases[][3] = {{2200, 1059, 82}, {2816, 0, 82}, {4000, 3918, 82}, {2049, 1000, 127}, {4095, 2000, 64 * NS}, {1971, 944, 82},
+                          {1100, 500, 82}, {2200, 1000, 200}};
+  for (auto& c : cases) {
+    const int N = c[0], lo = c[1], Np = c[2];
+    if (Np > 64 * NS || lo < 0 || lo + Np > N || blu_blocks(N, Np) < 2) continue;
+    const double err = run_blu_blocked_case<R, NS>(N, lo, Np, 7u + N);
+    const bool ok = err <= tol;
+    std::printf("%s blocked chirp-z NS=%d N=%d lo=%d Np=%d blocks=%d x %d relerr=%.3e %s\n", name, NS, N, lo, Np, blu_blocks(N, Np),
+                blu_block_len(Np), err, ok ? "ok" : "FAIL");
+    bad += !ok;
+  }
+  return bad;
 }
 
 template <class R, int P, int NS>
@@ -264,6 +329,9 @@ int main() {
   bad += sweep_blu<double, 16, 4>("f64", 1e-12);
   bad += sweep_blu<double, 24, 2>("f64", 1e-12);
   bad += sweep_blu<double, 32, 2>("f64", 1e-12);
+  bad += sweep_blu_blocked<double, 2>("f64", 1e-12);
+  bad += sweep_blu_blocked<double, 4>("f64", 1e-12);
+  bad += sweep_blu_blocked<float, 2>("f32", 2e-4);
   bad += sweep_blu<float, 4, 2>("f32", 1e-4);
   bad += sweep_blu<float, 16, 2>("f32", 1e-4);
   bad += sweep_blu<float, 24, 4>("f32", 1e-4);
@@ -289,11 +357,6 @@ int main() {
   bad += sweep<float, 24, 2>("f32", 2e-5);
   bad += sweep<double, 8, 2>("f64", 1e-13);
   bad += sweep<double, 16, 2>("f64", 1e-13);
-  g_dense = true;
-  bad += sweep<double, 16, 2>("f64 dense", 1e-13);
-  bad += sweep<float, 16, 2>("f32 dense", 2e-5);
-  bad += sweep<double, 16, 4>("f64 dense", 1e-13);
-  g_dense = false;
   g_dense_r16 = 1;
   bad += sweep<double, 16, 2>("f64 dense 16x4", 1e-13);
   bad += sweep<float, 16, 2>("f32 dense 16x4", 2e-5);

@@ -28,11 +28,9 @@
 using namespace fmc;
 
 // Translation units.  Alone (FMC_TU undefined) this file is the whole library.  With -DFMC_SPLIT_BUILD the Makefile compiles
-// it nine times in parallel and links the objects: unit 0 holds the C-ABI, every host function and the small kernels;
-// the kernel families that run_impl launches are explicit instantiations of their dispatch templates in units
-//   1 / 2: wave family, float64 / float32            3 / 4: chirp-z family
-//   5 / 6: 50-lane and run-time-split families       7 / 8: direct family
-// (a fresh build takes the time of the slowest unit instead of the sum).
+// it ten times in parallel and links the objects: unit 0 holds the C-ABI, every host function and the small kernels;
+// the kernel families that run_impl launches are explicit instantiations of their dispatch templates in units 1 ... 9
+// (FMC_UNITS below): a fresh build takes the time of the slowest unit instead of the sum.
 #ifndef FMC_TU
 #define FMC_TU 0
 #endif
@@ -62,6 +60,7 @@ struct TimedSpan {
 
 struct fastmc_ctx {
   int device = 0, N = 0, Np = 0, lo = 0, precision = 0;
+  int precision_req = 0;   // what fastmc_create was asked for (float32 is honoured on the wave family's grids only)
   int path = 0, P = 0, NS = 0, omS = 0;
   int S = 1;               // wave family: sub-rows per row (N = S * 64 * P); spec_split(N)
   int batch = 0;
@@ -83,6 +82,7 @@ struct fastmc_ctx {
   // chirp-z family (path 2: grid sizes that are not 64 P): M = 64 * blu_P >= N + Np - 1
   bool no_dense = false;   // FASTMC_NO_DENSE16=1 in the environment at create: keep the twelve-wave kernels (A/B)
   int blu_P = 0;           // 0: not eligible
+  int blu_SB = 1, blu_B = 0;   // input blocks per row (fmc_bluestein.h): grids whose rows exceed the largest M run SB blocks of B on M = 1024
   int blu_lo = -1;         // window position the tables below were built for
   void* blu_tw1 = nullptr; // tw1 of size M
   void* blu_om = nullptr;  // om for the window [0, Np) of the second transform
@@ -276,7 +276,9 @@ static int default_path(int N, int blu_P, int mr_P) { return wave_supported(N) ?
 
 // Chirp-z family: smallest M = 64 P (P = 4, 8, 16, 24, 32) with M >= N + Np - 1 and a window instantiation
 // (NS = 2: Np <= 128; NS = 4: Np <= 256, P = 8, 16, 24); 0 when there is none.
-static int blu_pick_P(int N, int Np) {
+static int blu_pick_P(int N, int Np, int* SB = nullptr, int* B = nullptr) {
+  if (SB) *SB = 1;
+  if (B) *B = N;
   if (N < 2 || mr_supported(N) || wave_rt_split(N)) return 0;      // 50 P grids are drawn as 50 streams per row: 50-lane or direct family
   const int ns = (Np + 63) / 64;
   if (ns > 4) return 0;
@@ -284,6 +286,13 @@ static int blu_pick_P(int N, int Np) {
     if (64 * P < N + Np - 1) continue;
     if (ns > 2 && !(P == 8 || P == 16 || P == 24)) continue;
     return P;
+  }
+  // rows beyond the largest M: input blocks on the M = 1024 pipeline (2200, 2816, ... 4095)
+  const int nblk = blu_blocks(N, Np);
+  if (nblk >= 2 && nblk <= 8) {
+    if (SB) *SB = nblk;
+    if (B) *B = blu_block_len(Np);
+    return 16;
   }
   return 0;
 }
@@ -372,9 +381,13 @@ extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int p
   h->device = device_id;
   h->N = N;
   h->Np = Np;
+  h->precision_req = precision;
+  // the float32 pipeline exists for the wave family (N = 64 P, 2048, 4096) and its direct cross-check; every other grid
+  // (chirp-z, 50-lane, run-time sub-rows, tiny) computes in float64 whatever was asked for
+  if (precision == FASTMC_F32 && (!wave_supported(N) || wave_rt_split(N))) precision = FASTMC_F64;
   h->precision = precision;
   h->rsz = precision == FASTMC_F64 ? 8 : 4;
-  h->blu_P = blu_pick_P(N, Np);
+  h->blu_P = blu_pick_P(N, Np, &h->blu_SB, &h->blu_B);
   if (const char* e = getenv("FASTMC_NO_DENSE16")) h->no_dense = e[0] && e[0] != '0';
   h->mr_P = mr_pick_P(N, Np);
   h->mr_S = h->mr_P ? mr_split(N) : 1;
@@ -420,7 +433,7 @@ static SlabCache g_slabs;
 fastmc_ctx* HandleCache::take(int device, int N, int Np, int precision) {
   std::lock_guard<std::mutex> g(mu);
   fastmc_ctx* h = dev[device & 63];
-  if (!h || h->device != device || h->N != N || h->Np != Np || h->precision != precision) return nullptr;
+  if (!h || h->device != device || h->N != N || h->Np != Np || h->precision_req != precision) return nullptr;
   dev[device & 63] = nullptr;
   return h;
 }
@@ -478,7 +491,7 @@ static void destroy_now(fastmc_ctx* h) {
 extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   if (force == 1 && !wave_supported(h->N)) return fail(FASTMC_EINVAL, "wave kernels need N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, 2 <= P <= 32");
-  if (force == 2 && !h->blu_P) return fail(FASTMC_EINVAL, "chirp-z kernels need 64 P >= N + Np - 1 for P in {4, 8, 16, 24, 32} and Np <= 256");
+  if (force == 2 && !h->blu_P) return fail(FASTMC_EINVAL, "chirp-z kernels need Np <= 256 and a grid that is neither 64 P S nor 50 P S");
   if (force == 3 && !h->mr_P) return fail(FASTMC_EINVAL, "50-lane kernels need N = 50 P S (not 64 P') with P = 2^k times 1, 3, 5, 7 or 9, P <= 24, S <= 5, and Np <= 128 (256 for P = 8, 10, 12, 16, 20, 24)");
   if (force >= 0 && force <= 3) h->path = force;
   return h->path;
@@ -501,16 +514,10 @@ extern "C" int fastmc_set_rng_precision(fastmc_t* h, int precision) {
 }
 #endif
 
-// The dense-image kernels (sixteen waves per workgroup) serve P = 16, NS = 2, unsplit rows, device generator and
-// detector epilogue, when their LDS fits (window up to 96 pixels): the configuration of the BASELINE workloads at 1024^2.
-template <class R>
-static bool dense16_fits(const fastmc_ctx* h) {
-  return FMC_DENSE16 && wave_lds_bytes_d<R, 16, 2, 1>(h->omS) <= 160 * 1024;
-}
 // the 16 x 4 dense kernels stage four table rows: windows of up to 128 pixels fit
 template <class R>
 static bool dense16r_fits(const fastmc_ctx* h) {
-  return FMC_DENSE16 && wave_lds_bytes_d<R, 16, 2, 4>(h->omS) <= 160 * 1024;
+  return wave_lds_bytes_d<R, 16, 2, 4>(h->omS) <= 160 * 1024;
 }
 
 static int default_batch(const fastmc_ctx* h) {
@@ -641,12 +648,13 @@ static int upload_wave_tables(fastmc_ctx* h) {
 template <class R>
 static int upload_blu_tables(fastmc_ctx* h) {
   if (!h->blu_P || h->blu_lo == h->lo) return 0;
-  const int P = h->blu_P, M = 64 * P;
+  const int P = h->blu_P, M = 64 * P, SB = h->blu_SB, B = h->blu_B;
   h->omS = (h->Np + 7) & ~7;
-  std::vector<cpx<R>> tw1((size_t)P * 64), om((size_t)8 * h->omS), twf(64), pre(M), vhat(M), post(h->omS);
+  const int pre_len = std::max(M, SB * B);
+  std::vector<cpx<R>> tw1((size_t)P * 64), om((size_t)8 * h->omS), twf(64), pre(pre_len), vhat((size_t)SB * M), post(h->omS);
   build_tw1<R>(tw1.data(), P, cs_turns);
   build_om<R>(om.data(), h->omS, P, 0, h->Np, cs_turns);
-  if (!build_blu_tables<R>(h->N, h->Np, h->lo, P, pre.data(), vhat.data(), post.data(), h->omS, twf.data(), cs_turns))
+  if (!build_blu_tables<R>(h->N, h->Np, h->lo, P, pre.data(), vhat.data(), post.data(), h->omS, twf.data(), cs_turns, B, SB, pre_len))
     return fail(FASTMC_ESTATE, "chirp-z size does not hold the window");
   TRY(upload_table<R>(&h->blu_tw1, tw1));
   TRY(upload_table<R>(&h->blu_om, om));
@@ -772,13 +780,8 @@ static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
   const size_t lds = wave_lds_bytes_d<R, P, NS, D>(A.omS);
   hipFuncSetAttribute((const void*)k_rows_wave<R, P, NS, MODE, S, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   constexpr int WPB = WCfg<R, P, NS, D>::WPB;
-#if FMC_ROWMAP == 0
-  const int items = A.nb * (A.N / ROWS_PER_WAVE);
-  const int blocks = (items + WPB - 1) / WPB;
-#else
   constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
   const int blocks = (A.N / LR) * ((A.nb + BPG - 1) / BPG);
-#endif
   hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE, S, D>), dim3(blocks), dim3(WPB * 64), lds, h->stream, A);
 }
 template <class R, int P, int NS, int EPI, int S = 1, int D = 0>
@@ -790,123 +793,87 @@ static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
   hipLaunchKernelGGL((k_cols_wave<R, P, NS, EPI, S, D>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, A);
 }
 
-template <class R, int P, int NS, int S = 1>
-static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
-  if constexpr (P == 16 && NS == 2 && S == 1) {
-    if (FMC_D16_R16 && dense16r_fits<R>(h) && !h->no_dense) {
-      const int win = window_planes(h->lo, h->Np, 16, 16);
-      if ((win & ~D16R_CENTRE_MASK) == 0) {
-        // the BASELINE geometry: the same row also with host coefficients (MODE 1: the reference's own `_r` for a seed goes
-        // through the kernels that are benchmarked) and with the screens written out (EPI 1)
-        {
-          Span s(h, 0);
-          if (mode == 0) launch_rows_wave<R, 16, 2, 0, 1, 4>(h, RA);
-          else launch_rows_wave<R, 16, 2, 1, 1, 4>(h, RA);
-        }
-        {
-          Span s(h, 1);
-          if (epi == 0) launch_cols_wave<R, 16, 2, 0, 1, 4>(h, CA);
-          else launch_cols_wave<R, 16, 2, 1, 1, 4>(h, CA);
-        }
-        return;
-      }
-      if (mode == 0 && epi == 0 && (win & ~D16R_WIDE_MASK) == 0) {
-        { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, 1, 8>(h, RA); }
-        { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, 1, 8>(h, CA); }
-        return;
-      }
-    }
-    if (mode == 0 && epi == 0 && dense16_fits<R>(h) && !h->no_dense) {
-      if (FMC_D16_PRUNE && (window_b0_mask(h->lo, h->Np, 16) & ~D16_CENTRE_MASK) == 0) {
-        { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, 1, 2>(h, RA); }
-        { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, 1, 2>(h, CA); }
-        return;
-      }
-      { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, 1, 1>(h, RA); }
-      { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, 1, 1>(h, CA); }
-      return;
-    }
-  }
-  if constexpr (NS == 2 && P == 16) {
-    if (FMC_D16_R16 && (window_planes(h->lo, h->Np, 16, 16) & ~D16R_CENTRE_MASK) == 0) {
-      // split rows: sixteen-wave workgroups where the tables fit (A/B at 2048^2: rows 37.4 -> 35.7 ms per 5000 realisations;
-      // 4096^2: -1 %); the split column kernel loses 6 % there at 4096^2 and stays on twelve waves.  Host coefficients
-      // (MODE 1) and screens (EPI 1) take the twelve-wave forms of the same row.
-      if (mode == 0) {
-        if (FMC_SPLIT_DENSE_ROWS && S > 1 && wave_lds_bytes_d<R, 16, 2, 4>(h->omS) <= 160 * 1024) {
-          Span s(h, 0); launch_rows_wave<R, 16, 2, 0, S, 4>(h, RA);
-        } else {
-          Span s(h, 0); launch_rows_wave<R, 16, 2, 0, S, 5>(h, RA);
-        }
-      } else {
-        Span s(h, 0); launch_rows_wave<R, 16, 2, 1, S, 5>(h, RA);
-      }
-      {
-        Span s(h, 1);
-        if (epi == 0) launch_cols_wave<R, 16, 2, 0, S, 5>(h, CA);
-        else launch_cols_wave<R, 16, 2, 1, S, 5>(h, CA);
-      }
-      return;
-    }
-  }
-  if constexpr (NS == 2 && P == 16) {     // centred windows of 97-128 pixels: eight of the sixteen planes
-    if (FMC_D16_R16 && mode == 0 && epi == 0 && (window_planes(h->lo, h->Np, 16, 16) & ~D16R_WIDE_MASK) == 0) {
-      { Span s(h, 0); launch_rows_wave<R, 16, 2, 0, S, 6>(h, RA); }
-      { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, S, 6>(h, CA); }
-      return;
-    }
-  }
-  if constexpr (P == 16 && (NS == 2 || NS == 4 || NS == 8)) {     // any other window at P = 16: the 16 x 4 row with all planes
-    if (FMC_D16_R16_ALL && mode == 0 && epi == 0) {
-      { Span s(h, 0); launch_rows_wave<R, 16, NS, 0, S, 7>(h, RA); }
-      { Span s(h, 1); launch_cols_wave<R, 16, NS, 0, S, 7>(h, CA); }
-      return;
-    }
-  }
-  if constexpr (NS == 2 && P >= 16 && prune_pays(P, 8, 0)) {
-    if (FMC_D16_PRUNE && mode == 0 && epi == 0 && (window_planes(h->lo, h->Np, P, 8) & ~centre_planes(P, 8, 0)) == 0) {
-      { Span s(h, 0); launch_rows_wave<R, P, 2, 0, S, 3>(h, RA); }
-      { Span s(h, 1); launch_cols_wave<R, P, 2, 0, S, 3>(h, CA); }
-      return;
-    }
-  }
+// rows with MODE = mode, columns with EPI = epi of one (P, NS, S, D) variant
+template <class R, int P, int NS, int S, int DR, int DC = DR>
+static void launch_wave_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   {
     Span s(h, 0);
-    if (mode == 0) launch_rows_wave<R, P, NS, 0, S>(h, RA);
-    else launch_rows_wave<R, P, NS, 1, S>(h, RA);
+    if (mode == 0) launch_rows_wave<R, P, NS, 0, S, DR>(h, RA);
+    else launch_rows_wave<R, P, NS, 1, S, DR>(h, RA);
   }
   {
     Span s(h, 1);
-    if (epi == 0) launch_cols_wave<R, P, NS, 0, S>(h, CA);
-    else launch_cols_wave<R, P, NS, 1, S>(h, CA);
+    if (epi == 0) launch_cols_wave<R, P, NS, 0, S, DC>(h, CA);
+    else launch_cols_wave<R, P, NS, 1, S, DC>(h, CA);
   }
 }
 
-template <class R, int P, int NS>
+// Which row / column variant serves this window (fmc_kernels.h: WCfg).
+template <class R, int P, int NS, int S = 1>
+static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  if constexpr (P == 16 && (NS == 2 || NS == 4 || NS == 8)) {
+    // 1024, and 2048 / 4096 as sub-rows: the 16 x 4 lane factorisation
+    if constexpr (NS == 2) {
+      const int win = window_planes(h->lo, h->Np, 16, 16);
+      const bool dense = dense16r_fits<R>(h) && !h->no_dense;
+      if ((win & ~D16R_CENTRE_MASK) == 0) {
+        // the BASELINE geometry.  Unsplit rows: the dense sixteen-wave kernels, also with host coefficients (MODE 1: the
+        // reference's own `_r` for a seed goes through the kernels that are benchmarked) and with the screens written out
+        // (EPI 1).  Split rows: sixteen-wave workgroups where the tables fit (A/B at 2048^2: rows 37.4 -> 35.7 ms per 5000
+        // realisations; 4096^2: -1 %); the split column kernel loses 6 % there at 4096^2 and stays on twelve waves.
+        if constexpr (S == 1) {
+          if (dense) { launch_wave_pair<R, 16, 2, 1, 4>(h, RA, CA, mode, epi); return; }
+        } else {
+          if (dense && mode == 0) { launch_wave_pair<R, 16, 2, S, 4, 5>(h, RA, CA, 0, epi); return; }
+        }
+        launch_wave_pair<R, 16, 2, S, 5>(h, RA, CA, mode, epi);
+        return;
+      }
+      if (mode == 0 && epi == 0 && (win & ~D16R_WIDE_MASK) == 0) {     // centred windows of 97-128 pixels: eight of the sixteen planes
+        if constexpr (S == 1) {
+          if (dense) { launch_wave_pair<R, 16, 2, 1, 8>(h, RA, CA, 0, 0); return; }
+        }
+        launch_wave_pair<R, 16, 2, S, 6>(h, RA, CA, 0, 0);
+        return;
+      }
+    }
+    launch_wave_pair<R, 16, NS, S, 7>(h, RA, CA, mode, epi);      // any other window: all sixteen planes
+  } else {
+    if constexpr (NS == 2 && P > 16 && prune_pays(P, 8, 0)) {
+      if (mode == 0 && epi == 0 && (window_planes(h->lo, h->Np, P, 8) & ~centre_planes(P, 8, 0)) == 0) {
+        launch_wave_pair<R, P, 2, S, 3>(h, RA, CA, 0, 0);
+        return;
+      }
+    }
+    launch_wave_pair<R, P, NS, S, 0>(h, RA, CA, mode, epi);
+  }
+}
+
+template <class R, int P, int NS, bool BLK = false>
 static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
-  constexpr int WPB = BluCfg<R, P, NS>::WPB, WPC = BluCfg<R, P, NS>::WPB_COLS;
+  constexpr int WPB = BluCfg<R, P, NS>::WPB, WPC = BLK ? BluCfg<R, P, NS>::WPB : BluCfg<R, P, NS>::WPB_COLS;
   const size_t lds = blu_lds_bytes<R, P, NS>(RA.omS, WPB), ldc = blu_lds_bytes<R, P, NS>(RA.omS, WPC);
   constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
   const int blocks = ((RA.N + LR - 1) / LR) * ((RA.nb + BPG - 1) / BPG);
   {
     Span s(h, 0);
     if (mode == 0) {
-      hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_blu<R, P, NS, 0>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 0, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_blu<R, P, NS, 0, BLK>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
     } else {
-      hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_blu<R, P, NS, 1>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 1, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_blu<R, P, NS, 1, BLK>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
     }
   }
   {
     Span s(h, 1);
     const int items = CA.nb * CA.Np;
     if (epi == 0) {
-      hipFuncSetAttribute((const void*)k_cols_blu<R, P, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
-      hipLaunchKernelGGL((k_cols_blu<R, P, NS, 0>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), ldc, h->stream, CA);
+      hipFuncSetAttribute((const void*)k_cols_blu<R, P, NS, 0, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
+      hipLaunchKernelGGL((k_cols_blu<R, P, NS, 0, BLK>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), ldc, h->stream, CA);
     } else {
-      hipFuncSetAttribute((const void*)k_cols_blu<R, P, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
-      hipLaunchKernelGGL((k_cols_blu<R, P, NS, 1>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), ldc, h->stream, CA);
+      hipFuncSetAttribute((const void*)k_cols_blu<R, P, NS, 1, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
+      hipLaunchKernelGGL((k_cols_blu<R, P, NS, 1, BLK>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), ldc, h->stream, CA);
     }
   }
 }
@@ -914,6 +881,11 @@ static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
 template <class R>
 int dispatch_blu(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   const int ns = h->NS <= 2 ? 2 : 4;
+  if (h->blu_SB > 1) {       // rows in input blocks on the M = 1024 pipeline
+    if (ns == 2) dispatch_blu_pn<R, 16, 2, true>(h, RA, CA, mode, epi);
+    else dispatch_blu_pn<R, 16, 4, true>(h, RA, CA, mode, epi);
+    return 0;
+  }
 #define FMC_BLU(PP, NN) if (h->blu_P == PP && ns == NN) { dispatch_blu_pn<R, PP, NN>(h, RA, CA, mode, epi); return 0; }
   FMC_BLU(4, 2) FMC_BLU(8, 2) FMC_BLU(8, 4) FMC_BLU(16, 2) FMC_BLU(16, 4) FMC_BLU(24, 2) FMC_BLU(24, 4) FMC_BLU(32, 2)
 #undef FMC_BLU
@@ -955,7 +927,7 @@ template <class R, int P, int NS, bool SPLIT, int LN = MR_LN>
 static void dispatch_mr_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   constexpr int L1 = LN == MR_LN ? 10 : 8;
   if constexpr (NS == 2 && P >= 16) {
-    if (FMC_D16_PRUNE && mode == 0 && epi == 0) {
+    if (mode == 0 && epi == 0) {
       const int S = RA.N / (LN * P);
       const int win = window_planes(h->lo, h->Np, P, L1);
       if constexpr (LN == MR_LN && prune_pays(P, 10, 5)) {
@@ -972,8 +944,9 @@ static void dispatch_mr_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>
 // P of the split grids (mr_split: the smallest S that leaves 7 <= P <= 24)
 constexpr bool mr_split_P(int P) { return P == 7 || P == 9 || P == 10 || P == 14 || P == 16 || P == 18 || P == 20 || P == 24; }
 
-template <class R>
-int dispatch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+// PART 0: P <= 9, PART 1: P >= 10 (two translation units)
+template <class R, int PART>
+int dispatch_mr_part(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   const int ns = h->NS <= 2 ? 2 : 4;
   const bool split = h->mr_S > 1;
 #define FMC_MR(PP)                                                                                                    \
@@ -986,8 +959,11 @@ int dispatch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int m
       if constexpr (mr_has_ns4(PP)) { if (ns == 4) { dispatch_mr_pn<R, PP, 4, true>(h, RA, CA, mode, epi); return 0; } }  \
     }                                                                                                                 \
   }
-  FMC_MR(2) FMC_MR(3) FMC_MR(4) FMC_MR(5) FMC_MR(6) FMC_MR(7) FMC_MR(8) FMC_MR(9) FMC_MR(10) FMC_MR(12) FMC_MR(14) FMC_MR(16)
-  FMC_MR(18) FMC_MR(20) FMC_MR(24)
+  if constexpr (PART == 0) {
+    FMC_MR(2) FMC_MR(3) FMC_MR(4) FMC_MR(5) FMC_MR(6) FMC_MR(7) FMC_MR(8) FMC_MR(9)
+  } else {
+    FMC_MR(10) FMC_MR(12) FMC_MR(14) FMC_MR(16) FMC_MR(18) FMC_MR(20) FMC_MR(24)
+  }
 #undef FMC_MR
   return fail(FASTMC_ESTATE, "no 50-lane instantiation for this grid / window");
 }
@@ -1034,21 +1010,15 @@ static int dispatch_wave_ns(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
   return 0;
 }
 
-// Every launch of the wave family (64 P, split 2048 / 4096, run-time sub-rows, the general 2048 window): one function so that
-// it can be an explicit instantiation in its own translation unit.
-template <class R>
-int dispatch_wave_family(fastmc_ctx* h, RowArgs<R>& RA, ColArgs<R>& CA, int mode, int epi, bool general_2048) {
-  if (general_2048) {
-    RA.om = (const cpx<R>*)h->omg;
-    CA.om = RA.om;
-    dispatch_wave<R, 32, 32>(h, RA, CA, mode, epi);
-  } else if (wave_rt_split(h->N)) {
-    TRY(dispatch_ws<R>(h, RA, CA, mode, epi));
-  } else if (h->S == 2) {
-    TRY((dispatch_wave_split<R, 2>(h, RA, CA, mode, epi)));
-  } else if (h->S == 4) {
-    TRY((dispatch_wave_split<R, 4>(h, RA, CA, mode, epi)));
-  } else {
+// The launches of the wave family in three parts, each an explicit instantiation in its own translation unit:
+//   PART 0: P <= 12;   PART 1: P = 16 and the 2048 / 4096 sub-rows;   PART 2: P = 14, 18, 20, 24, 28, 32 (the general 2048 window)
+template <class R, int PART>
+int dispatch_wave_part(fastmc_ctx* h, RowArgs<R>& RA, ColArgs<R>& CA, int mode, int epi, bool general_2048) {
+  if constexpr (PART == 1) {
+    if (h->S == 2) return dispatch_wave_split<R, 2>(h, RA, CA, mode, epi);
+    if (h->S == 4) return dispatch_wave_split<R, 4>(h, RA, CA, mode, epi);
+    return dispatch_wave_ns<R, 16>(h, RA, CA, mode, epi);
+  } else if constexpr (PART == 0) {
     switch (h->P) {
       case 2: dispatch_wave<R, 2, 2>(h, RA, CA, mode, epi); break;
       case 3: dispatch_wave<R, 3, 2>(h, RA, CA, mode, epi); break;
@@ -1058,14 +1028,23 @@ int dispatch_wave_family(fastmc_ctx* h, RowArgs<R>& RA, ColArgs<R>& CA, int mode
       case 7: dispatch_wave<R, 7, 2>(h, RA, CA, mode, epi); break;
       case 8: TRY((dispatch_wave_ns<R, 8>(h, RA, CA, mode, epi))); break;
       case 9: TRY((dispatch_wave_ns<R, 9>(h, RA, CA, mode, epi))); break;
-      case 14: dispatch_wave<R, 14, 2>(h, RA, CA, mode, epi); break;
-      case 18: dispatch_wave<R, 18, 2>(h, RA, CA, mode, epi); break;
-      case 28: dispatch_wave<R, 28, 2>(h, RA, CA, mode, epi); break;
       case 10: TRY((dispatch_wave_ns<R, 10>(h, RA, CA, mode, epi))); break;
       case 12: TRY((dispatch_wave_ns<R, 12>(h, RA, CA, mode, epi))); break;
-      case 16: TRY((dispatch_wave_ns<R, 16>(h, RA, CA, mode, epi))); break;
+      default: return fail(FASTMC_ESTATE, "no wave instantiation for this grid size");
+    }
+  } else {
+    if (general_2048) {
+      RA.om = (const cpx<R>*)h->omg;
+      CA.om = RA.om;
+      dispatch_wave<R, 32, 32>(h, RA, CA, mode, epi);
+      return 0;
+    }
+    switch (h->P) {
+      case 14: dispatch_wave<R, 14, 2>(h, RA, CA, mode, epi); break;
+      case 18: dispatch_wave<R, 18, 2>(h, RA, CA, mode, epi); break;
       case 20: TRY((dispatch_wave_ns<R, 20>(h, RA, CA, mode, epi))); break;
       case 24: TRY((dispatch_wave_ns<R, 24>(h, RA, CA, mode, epi))); break;
+      case 28: dispatch_wave<R, 28, 2>(h, RA, CA, mode, epi); break;
       default: return fail(FASTMC_ESTATE, "no wave instantiation for this grid size");
     }
   }
@@ -1111,53 +1090,67 @@ int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA
 // ------------------------------------------------------------------ translation units (see the top of the file)
 #define FMC_FAMILY_SIG(R) fastmc_ctx*, const RowArgs<R>&, const ColArgs<R>&, int, int
 #define FMC_WAVE_SIG(R) fastmc_ctx*, RowArgs<R>&, ColArgs<R>&, int, int, bool
-#if defined(FMC_SPLIT_BUILD) || FMC_TU != 0     // defined in another unit
+// unit -> what it instantiates.  The float32 pipeline exists for the wave and direct families; chirp-z, 50-lane and
+// run-time-split grids run the float64 kernels whatever precision was asked for (fastmc_create).
+//   1 / 2 / 3: wave family float64, parts 0 / 1 / 2        4 / 5 / 6: wave family float32, parts 0 / 1 / 2
+//   7: chirp-z float64, direct float64 and float32          8: 50-lane P <= 9 and run-time-split, float64     9: 50-lane P >= 10
+#if defined(FMC_SPLIT_BUILD) || FMC_TU != 0
+// declared `extern` in every unit but the one that defines it
 #if FMC_TU != 1
-extern template int dispatch_wave_family<double>(FMC_WAVE_SIG(double));
+extern template int dispatch_wave_part<double, 0>(FMC_WAVE_SIG(double));
 #endif
 #if FMC_TU != 2
-extern template int dispatch_wave_family<float>(FMC_WAVE_SIG(float));
+extern template int dispatch_wave_part<double, 1>(FMC_WAVE_SIG(double));
 #endif
 #if FMC_TU != 3
-extern template int dispatch_blu<double>(FMC_FAMILY_SIG(double));
+extern template int dispatch_wave_part<double, 2>(FMC_WAVE_SIG(double));
 #endif
 #if FMC_TU != 4
-extern template int dispatch_blu<float>(FMC_FAMILY_SIG(float));
+extern template int dispatch_wave_part<float, 0>(FMC_WAVE_SIG(float));
 #endif
 #if FMC_TU != 5
-extern template int dispatch_mr<double>(FMC_FAMILY_SIG(double));
-extern template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
+extern template int dispatch_wave_part<float, 1>(FMC_WAVE_SIG(float));
 #endif
 #if FMC_TU != 6
-extern template int dispatch_mr<float>(FMC_FAMILY_SIG(float));
-extern template int dispatch_ws<float>(FMC_FAMILY_SIG(float));
+extern template int dispatch_wave_part<float, 2>(FMC_WAVE_SIG(float));
 #endif
 #if FMC_TU != 7
+extern template int dispatch_blu<double>(FMC_FAMILY_SIG(double));
 extern template int dispatch_direct<double>(FMC_FAMILY_SIG(double));
+extern template int dispatch_direct<float>(FMC_FAMILY_SIG(float));
 #endif
 #if FMC_TU != 8
-extern template int dispatch_direct<float>(FMC_FAMILY_SIG(float));
+extern template int dispatch_mr_part<double, 0>(FMC_FAMILY_SIG(double));
+extern template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
+#endif
+#if FMC_TU != 9
+extern template int dispatch_mr_part<double, 1>(FMC_FAMILY_SIG(double));
 #endif
 #endif
 #if FMC_TU == 1
-template int dispatch_wave_family<double>(FMC_WAVE_SIG(double));
+template int dispatch_wave_part<double, 0>(FMC_WAVE_SIG(double));
+#elif FMC_TU == 2
+template int dispatch_wave_part<double, 1>(FMC_WAVE_SIG(double));
 #elif FMC_TU == 3
-template int dispatch_blu<double>(FMC_FAMILY_SIG(double));
-#elif FMC_TU == 5
-template int dispatch_mr<double>(FMC_FAMILY_SIG(double));
-template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
+template int dispatch_wave_part<double, 2>(FMC_WAVE_SIG(double));
 #elif FMC_TU == 7
+template int dispatch_blu<double>(FMC_FAMILY_SIG(double));
 template int dispatch_direct<double>(FMC_FAMILY_SIG(double));
-#elif !defined(FMC_ONLY_F64)
-#if FMC_TU == 2
-template int dispatch_wave_family<float>(FMC_WAVE_SIG(float));
-#elif FMC_TU == 4
-template int dispatch_blu<float>(FMC_FAMILY_SIG(float));
-#elif FMC_TU == 6
-template int dispatch_mr<float>(FMC_FAMILY_SIG(float));
-template int dispatch_ws<float>(FMC_FAMILY_SIG(float));
-#elif FMC_TU == 8
+#ifndef FMC_ONLY_F64
 template int dispatch_direct<float>(FMC_FAMILY_SIG(float));
+#endif
+#elif FMC_TU == 8
+template int dispatch_mr_part<double, 0>(FMC_FAMILY_SIG(double));
+template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
+#elif FMC_TU == 9
+template int dispatch_mr_part<double, 1>(FMC_FAMILY_SIG(double));
+#elif !defined(FMC_ONLY_F64)
+#if FMC_TU == 4
+template int dispatch_wave_part<float, 0>(FMC_WAVE_SIG(float));
+#elif FMC_TU == 5
+template int dispatch_wave_part<float, 1>(FMC_WAVE_SIG(float));
+#elif FMC_TU == 6
+template int dispatch_wave_part<float, 2>(FMC_WAVE_SIG(float));
 #endif
 #endif
 
@@ -1287,14 +1280,19 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       RA.cw = nullptr; RA.tw_global = 0;
       RA.blu.twf = (const cpx<R>*)h->blu_twf; RA.blu.pre = (const cpx<R>*)h->blu_pre;
       RA.blu.vhat = (const cpx<R>*)h->blu_vhat; RA.blu.post = (const cpx<R>*)h->blu_post;
+      RA.blu.SB = h->blu_SB; RA.blu.B = h->blu_B;
       CA.tw = RA.tw; CA.om = RA.om; CA.cw = nullptr; CA.tw_global = 0; CA.blu = RA.blu;
-      TRY(dispatch_blu<R>(h, RA, CA, kmode, S.epi));
+      if constexpr (sizeof(R) == 8) { TRY(dispatch_blu<R>(h, RA, CA, kmode, S.epi)); }
+      else return fail(FASTMC_ESTATE, "chirp-z grids run the float64 kernels (fastmc_create)");
     } else if (h->path == 3) {
       TRY(upload_mr_tables<R>(h));
       RA.amp = (const R*)h->amp_s; RA.ampf = h->ampf_s; RA.tw = (const cpx<R>*)h->mr_tw1; RA.om = (const cpx<R>*)h->mr_om;
       RA.cw = (const cpx<R>*)h->mr_cw; RA.tw_global = 0;
       CA.tw = RA.tw; CA.om = RA.om; CA.cw = RA.cw; CA.tw_global = 0;
-      TRY(dispatch_mr<R>(h, RA, CA, kmode, S.epi));
+      if constexpr (sizeof(R) == 8) {
+        if (h->mr_P <= 9) { TRY((dispatch_mr_part<R, 0>(h, RA, CA, kmode, S.epi))); }
+        else { TRY((dispatch_mr_part<R, 1>(h, RA, CA, kmode, S.epi))); }
+      } else return fail(FASTMC_ESTATE, "50-lane grids run the float64 kernels (fastmc_create)");
     } else {
     bool wave_ok = h->path == 1;
     bool general_2048 = false;   // N = 2048, window > 256 pixels, host coefficients: single-pass P = 32 kernels
@@ -1316,7 +1314,16 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     CA.tw_global = 0;
     CA.cw = RA.cw;
     if (general_2048 || wave_ok) {
-      TRY(dispatch_wave_family<R>(h, RA, CA, kmode, S.epi, general_2048));
+      if (!general_2048 && wave_rt_split(h->N)) {
+        if constexpr (sizeof(R) == 8) { TRY(dispatch_ws<R>(h, RA, CA, kmode, S.epi)); }
+        else return fail(FASTMC_ESTATE, "run-time-split grids run the float64 kernels (fastmc_create)");
+      } else if (general_2048 || (h->S == 1 && h->P >= 14 && h->P != 16)) {
+        TRY((dispatch_wave_part<R, 2>(h, RA, CA, kmode, S.epi, general_2048)));
+      } else if (h->P == 16) {
+        TRY((dispatch_wave_part<R, 1>(h, RA, CA, kmode, S.epi, false)));
+      } else {
+        TRY((dispatch_wave_part<R, 0>(h, RA, CA, kmode, S.epi, false)));
+      }
     } else {
       TRY(dispatch_direct<R>(h, RA, CA, kmode, S.epi));
     }

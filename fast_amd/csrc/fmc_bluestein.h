@@ -15,6 +15,13 @@
 //     the k = lane + 64 j layout  ->  pruned_row_fft for the window [0, Np)  ->  conjugate, multiply by post[t].
 // (IDFT(z) = conj(DFT(conj z)) / M; the 1 / M lives in `post`.)  About 2.7 plain rows of work for any N.
 //
+// Rows longer than the largest M (N + Np - 1 > 2048) are cut into SB blocks of B inputs (B a multiple of 64, B + Np - 1 <= M):
+//     out[p] = post[p] conj( sum_j Y_j[t] ),   Y_j = the chirp-z row of block j: inputs k in [j B, (j + 1) B) pre-chirped with
+//     the GLOBAL pre[k], chirp kernel v_j[m] = c(m + lo - 2h - j B) (its own V^_j table),
+// the window sums accumulated in registers over the blocks (the convolution is linear in the input).  With B a multiple of
+// 64 lane l of block j continues generator stream l where block j - 1 left it.  2200^2, 2816^2 ... 4096-sized grids that are
+// neither 64 P S nor 50 P S run SB = 3 ... 5 blocks on the M = 1024 pipeline instead of the O(N^2 Np) direct kernels.
+//
 // Like fmc_wavefft.h the per-lane phases are written against an executor, so that emu_wavefft.cpp runs the same index
 // arithmetic on the host.
 #pragma once
@@ -180,20 +187,22 @@ FMC_HD void bluestein_row(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1,
     });
     ex.sync();
   }
-  pruned_row_fft<R, P, NS>(ex, xbuf, tw1, om, omS, 0, Np, 0xFF, -1);
+  pruned_row_fft<R, P, NS>(ex, xbuf, tw1, om, omS, 0, Np, -1);
 }
 
 // ---------------------------------------------------------------- host-side tables (float64 trigonometry by `cs`)
-// pre[k]  = w_2N^{(k+h)^2}, k < N, zero up to M        (input chirp, with the input-side fftshift)
-// vhat    = DFT_M(v)                                   (chirp kernel of the window, see the header)
+// pre[k]  = w_2N^{(k+h)^2}, k < N, zero up to pre_len  (input chirp, with the input-side fftshift; GLOBAL index k)
+// vhat    = [SB][M]: DFT_M(v_j), v_j the chirp kernel of the window for input block j (see the header; SB = 1, B = N: one block)
 // post[t] = w_2N^{(lo - h + t)^2} / M, t < Np          (output chirp, with the output-side fftshift and the 1 / M of the IDFT)
 // twf[b0 * 8 + l0] = w_64^{l0 b0}
-// Returns false when M < N + Np - 1 (the cyclic convolution would alias).
+// Returns false when M < B + Np - 1 (the cyclic convolution would alias) or the blocks do not cover the row.
 template <class R, class CosSin>
 inline bool build_blu_tables(int N, int Np, int lo, int P, cpx<R>* pre, cpx<R>* vhat, cpx<R>* post, int post_len, cpx<R>* twf,
-                             CosSin cs) {
+                             CosSin cs, int B = 0, int SB = 1, int pre_len = 0) {
   const int M = WAVE * P, h = N / 2;
-  if (M < N + Np - 1) return false;
+  if (B <= 0) B = N;
+  if (pre_len <= 0) pre_len = M;
+  if (M < B + Np - 1 || (long long)B * SB < N || B > M) return false;
   auto chirp = [&](long long n, double sign, double* c, double* s) {   // exp(sign * i pi n^2 / N)
     const long long q = (n * n) % (2LL * N);
     double cc, ss;
@@ -201,7 +210,7 @@ inline bool build_blu_tables(int N, int Np, int lo, int P, cpx<R>* pre, cpx<R>* 
     *c = cc;
     *s = sign * ss;
   };
-  for (int k = 0; k < M; ++k) {
+  for (int k = 0; k < pre_len; ++k) {
     if (k < N) {
       double c, s;
       chirp(k + h, -1.0, &c, &s);
@@ -219,37 +228,42 @@ inline bool build_blu_tables(int N, int Np, int lo, int P, cpx<R>* pre, cpx<R>* 
       post[t] = mk<R>((R)0, (R)0);
     }
   }
-  // v and its DFT (naive O(M^2) in long double with exact twiddle indices: once per problem)
+  // v_j and its DFT (naive O(M^2) in long double with exact twiddle indices: once per problem)
   struct LD { long double x, y; };
   LD* v = new LD[M];
   LD* w = new LD[M];
   for (int m = 0; m < M; ++m) {
-    v[m].x = v[m].y = 0;
-    long long n;
-    bool used = false;
-    if (m < Np) { n = (long long)m + lo - 2 * h; used = true; }
-    else if (m > M - N) { n = (long long)m - M + lo - 2 * h; used = true; }
-    if (used) {
-      double c, s;
-      chirp(n < 0 ? -n : n, +1.0, &c, &s);
-      v[m].x = c;
-      v[m].y = s;
-    }
     double c, s;
     cs((double)m / M, &c, &s);
     w[m].x = c;
     w[m].y = -s;                                  // w_M^m
   }
-  for (int q = 0; q < M; ++q) {
-    long double ar = 0, ai = 0;
-    int e = 0;
+  for (int jb = 0; jb < SB; ++jb) {
+    const long long off = (long long)lo - 2 * h - (long long)jb * B;     // lag of output t = 0 against the block's first input
     for (int m = 0; m < M; ++m) {
-      ar += v[m].x * w[e].x - v[m].y * w[e].y;
-      ai += v[m].x * w[e].y + v[m].y * w[e].x;
-      e += q;
-      if (e >= M) e -= M;
+      v[m].x = v[m].y = 0;
+      long long n = 0;
+      bool used = false;
+      if (m < Np) { n = (long long)m + off; used = true; }
+      else if (m > M - B) { n = (long long)m - M + off; used = true; }
+      if (used) {
+        double c, s;
+        chirp(n < 0 ? -n : n, +1.0, &c, &s);
+        v[m].x = c;
+        v[m].y = s;
+      }
     }
-    vhat[q] = mk<R>((R)ar, (R)ai);
+    for (int q = 0; q < M; ++q) {
+      long double ar = 0, ai = 0;
+      int e = 0;
+      for (int m = 0; m < M; ++m) {
+        ar += v[m].x * w[e].x - v[m].y * w[e].y;
+        ai += v[m].x * w[e].y + v[m].y * w[e].x;
+        e += q;
+        if (e >= M) e -= M;
+      }
+      vhat[(size_t)jb * M + q] = mk<R>((R)ar, (R)ai);
+    }
   }
   delete[] v;
   delete[] w;
@@ -260,6 +274,14 @@ inline bool build_blu_tables(int N, int Np, int lo, int P, cpx<R>* pre, cpx<R>* 
       twf[b0 * 8 + l0] = mk<R>((R)c, (R)(-s));
     }
   return true;
+}
+
+// Blocks of the chirp-z row when no single M holds it: the M = 1024 pipeline (P = 16), B = the largest multiple of 64 with
+// B + Np - 1 <= 1024.  Returns the number of blocks (0: Np too wide).
+FMC_HD constexpr int blu_block_len(int Np) { return ((1024 - Np + 1) / 64) * 64; }
+FMC_HD constexpr int blu_blocks(int N, int Np) {
+  const int B = blu_block_len(Np);
+  return (B < 64 || Np > 256) ? 0 : (N + B - 1) / B;
 }
 
 }  // namespace fmc

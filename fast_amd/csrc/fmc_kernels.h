@@ -22,20 +22,14 @@
 namespace fmc {
 
 // ------------------------------------------------------------------ device RNG
-#ifndef FMC_PK_BM
-#define FMC_PK_BM 0
-#endif
 // Philox rounds of the block that seeds a coefficient stream.  7 is the smallest count for which Philox4x32 is
 // Crush-resistant (Salmon et al., SC'11, table 2; 10 is its safety-margin default, kept for the log-amplitude and
 // sub-harmonic draws, which use Philox words directly): here the block only seeds a 16- to 64-step xoshiro128+ stream.
-#ifndef FMC_SEED_ROUNDS
 #define FMC_SEED_ROUNDS 7
-#endif
 // Box-Muller on two 32-bit words:  r = sqrt(-2 ln U), U = (x0 + 0.5) 2^-32;  theta = 2 pi (x1 >> 9) 2^-23
 // -> (r cos theta, r sin theta): a standard complex normal.  float32 hardware transcendentals
 // (v_log_f32 = log2, v_sqrt_f32, v_sin_f32 / v_cos_f32 take turns); the oracle restates the
 // same formula in float64 (oracle/devrng.py) and the two agree to ~1e-6 absolute.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 // The angle as a float in [1, 2) built from the top 23 bits of the word by ONE v_alignbit (v_sin_f32 / v_cos_f32 take
 // turns and have period 1): theta / 2 pi = 1 + (x1 >> 9) 2^-23.
 __device__ __forceinline__ float angle_turns(uint32_t x1) {
@@ -44,20 +38,11 @@ __device__ __forceinline__ float angle_turns(uint32_t x1) {
 // K_BM = sqrt(2 ln 2): r = K_BM sqrt(-log2 u).  draw_coloured folds K_BM into the colouring table instead.
 #define FMC_K_BM 1.1774100225154747f
 __device__ __forceinline__ void box_muller(uint32_t x0, uint32_t x1, float& re, float& im) {
-#if FMC_PK_BM       // A/B variant: packed f32 pairs (v_pk_fma_f32, v_pk_mul_f32), same arithmetic; measured +1 % slower (pair packing moves)
-  const float u = fmaf((float)x0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-  const float t = angle_turns(x1);
-  const float r = FMC_K_BM * __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));
-  const f32x2 z = (f32x2){__builtin_amdgcn_cosf(t), __builtin_amdgcn_sinf(t)} * (f32x2){r, r};
-  re = z.x;
-  im = z.y;
-#else
   const float u = fmaf((float)x0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);  // (x0 + .5) 2^-32
   const float t = angle_turns(x1);
   const float r = FMC_K_BM * __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(u));            // sqrt(-2 ln u)
   re = r * __builtin_amdgcn_cosf(t);
   im = r * __builtin_amdgcn_sinf(t);
-#endif
 }
 // The same draw scaled by `ampk` = amp * K_BM (the constant of the radius folded into the colouring table):
 // cvt, fma, log, sqrt, alignbit, cos, sin and three multiplies.
@@ -77,11 +62,7 @@ struct RngKey {
 // seeded with one Philox block; its (2j)-th and (2j+1)-th words make coefficient (ky, L + SL j).
 __device__ __forceinline__ xoshiro128p row_stream(RngKey key, uint64_t g, int ky, int L, int SL) {
   xoshiro128p s;
-#if defined(FMC_ABL_NOPHILOX)   // ablation (timing only): what the per-row Philox seeding costs
-  s.s0 = (uint32_t)(ky * SL + L) * 0x9E3779B9u; s.s1 = (uint32_t)g ^ key.k0; s.s2 = s.s0 ^ key.k1; s.s3 = s.s0 + 0x85EBCA6Bu;
-#else
   s.seed(philox4x32<FMC_SEED_ROUNDS>((uint32_t)(ky * SL + L), STREAM_SCREEN, (uint32_t)g, (uint32_t)(g >> 32), key.k0, key.k1));
-#endif
   return s;
 }
 // ---- the generator at the reference's precision (GPU_RNG_PRECISION 'f64'; fast/funcs.py:352-356 draws 53-bit normals)
@@ -107,17 +88,8 @@ __device__ __forceinline__ void box_muller_f64(uint32_t a, uint32_t b, uint32_t 
   im = r * sn;
 }
 
-#ifndef FMC_RNG_PAIR
-#define FMC_RNG_PAIR 1
-#endif
-__device__ __forceinline__ void draw_words(xoshiro128p& s, uint32_t& a, uint32_t& b) {
-#if FMC_RNG_PAIR   // both Box-Muller words of a coefficient from one state advance (9 instead of 16 integer operations)
-  s.next2(a, b);
-#else
-  a = s.next();
-  b = s.next();
-#endif
-}
+// both Box-Muller words of a coefficient from ONE state advance (9 instead of 16 integer operations)
+__device__ __forceinline__ void draw_words(xoshiro128p& s, uint32_t& a, uint32_t& b) { s.next2(a, b); }
 template <class R>
 __device__ __forceinline__ cpx<R> draw_coeff(xoshiro128p& s) {
   uint32_t a, b;
@@ -160,8 +132,9 @@ template <class R>
 struct BluArgs {
   const cpx<R>* twf;            // [64]   w_64^{l0 b0}
   const cpx<R>* pre;            // [M]    input chirp (zero beyond N)
-  const cpx<R>* vhat;           // [M]    DFT_M of the chirp kernel
+  const cpx<R>* vhat;           // [SB][M] DFT_M of the chirp kernel (per input block)
   const cpx<R>* post;           // [omS]  output chirp / M
+  int SB, B;                    // input blocks per row and their length (SB = 1: the whole row in one transform)
 };
 
 template <class R>
@@ -247,12 +220,6 @@ __device__ __forceinline__ void pixel_phase(const SubharmArgs& sh, int b, int Np
 // ~35 VALU instructions instead of the ~155 of ocml's sincos: the column kernel calls it four
 // times per wavefront.
 __device__ __forceinline__ void sincos_r(double x, double& s, double& c) {
-#ifdef FMC_ABL_NOSINCOS      // ablation (timing only, wrong results)
-  s = x; c = x * 0.5; return;
-#endif
-#ifdef FMC_LIBM_SINCOS
-  sincos(x, &s, &c);
-#else
   if (!(fabs(x) < 1.0e5)) { sincos(x, &s, &c); return; }
   const double kd = rint(x * 0.63661977236758134308);
   double r = fma(-kd, 1.5707963267948965580e+00, x);
@@ -276,7 +243,6 @@ __device__ __forceinline__ void sincos_r(double x, double& s, double& c) {
   const double b = (n & 1) ? sr : cr;
   s = (n & 2) ? -a : a;
   c = ((n + 1) & 2) ? -b : b;
-#endif
 }
 __device__ __forceinline__ void sincos_r(float x, double& s, double& c) {
   float fs, fc;
@@ -284,9 +250,6 @@ __device__ __forceinline__ void sincos_r(float x, double& s, double& c) {
   s = fs; c = fc;
 }
 
-#ifndef FMC_DPP_REDUCE
-#define FMC_DPP_REDUCE 1
-#endif
 // One DPP-permuted copy of a double (two 32-bit movs; all rows and banks enabled).
 template <int CTRL>
 __device__ __forceinline__ double dpp_copy(double v) {
@@ -300,7 +263,6 @@ __device__ __forceinline__ double dpp_copy(double v) {
 // 16-lane row by DPP (quad permutes, half-row mirror, row mirror: register-file crossbar, no LDS), then
 // the four row sums by v_readlane -- instead of six ds_bpermute round trips per value.
 __device__ __forceinline__ double wave_sum(double v) {
-#if FMC_DPP_REDUCE
   v += dpp_copy<0xB1>(v);     // quad_perm [1,0,3,2]
   v += dpp_copy<0x4E>(v);     // quad_perm [2,3,0,1]
   v += dpp_copy<0x141>(v);    // row_half_mirror
@@ -314,11 +276,42 @@ __device__ __forceinline__ double wave_sum(double v) {
     r[q] = __longlong_as_double(((long long)h2 << 32) | (unsigned int)l2);
   }
   return (r[0] + r[1]) + (r[2] + r[3]);
-#else
+}
+
+// Detector of one window column (fast/fast.py:647-668) shared by the column kernels of the wave, chirp-z and 50-lane families:
+// slot s of lane l holds the phase pair (p1, p2) of window row yi = l + 64 s for the Re and Im screens of realisation b.
+// EPI 0: W exp(i phi) summed over the column -> partial[b][xi][4] (deterministic wave reduction); EPI 1: the screens themselves.
+template <class R, int NS, int EPI>
+__device__ __forceinline__ void column_epilogue(const SubharmArgs& sh, const double* W, double* partial, double* phs, int nb, int Np, int b,
+                                                int xi, int lane, const R (&p1s)[NS], const R (&p2s)[NS]) {
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-#endif
+  for (int s = 0; s < NS; ++s) {
+    const int yi = lane + WAVE * s;
+    if (yi < Np) {
+      R p1 = p1s[s], p2 = p2s[s];
+      pixel_phase<R>(sh, b, Np, yi, xi, p1, p2);
+      if (EPI == 1) {
+        const size_t plane = (size_t)Np * Np;
+        phs[((size_t)b) * plane + (size_t)yi * Np + xi] = (double)p1;
+        phs[((size_t)(nb + b)) * plane + (size_t)yi * Np + xi] = (double)p2;
+      } else {
+        const double wgt = W[(size_t)yi * Np + xi];
+        double s1, c1, s2, c2;
+        sincos_r(p1, s1, c1);
+        sincos_r(p2, s2, c2);
+        acc[0] += wgt * c1; acc[1] += wgt * s1; acc[2] += wgt * c2; acc[3] += wgt * s2;
+      }
+    }
+  }
+  if (EPI == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane == 0) {
+      double* o = partial + ((size_t)b * Np + xi) * 4;
+      o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+    }
+  }
 }
 
 // ================================================================== wave family
@@ -339,37 +332,10 @@ struct GpuExec {
     return o;
   }
   static __device__ __forceinline__ cpx<double> ld(const cpx<double>* p) { return *p; }     // 16 bytes: one ds_read_b128
+  // Stores are left to hipcc (ds_write2_b64 pairs).  Tried in round 3 for the 16-byte elements of the one-pass exchange 2: a
+  // 16-byte aligned ds_write_b128 -- conflict-free where the pair has 2-way bank conflicts -- ran the rows kernel 7 % SLOWER
+  // (9.35 against 8.70 ms per 5000 realisations), single ds_write_b64s the same as the pairs: the store form sets the time.
   template <class E> static __device__ __forceinline__ void st(E* p, E v) { *p = v; }
-  // 16-byte elements (one-pass exchange 2 of the float64 16 x 4 row): ONE ds_write_b128.  Left to the type's 8-byte
-  // alignment hipcc emits ds_write2_b64, whose 16-lane groups at a 16-byte stride span 64 dwords on 32 store banks: 2-way
-  // conflicts on both halves (SQ_LDS_BANK_CONFLICT 2.2e6 -> 5.3e7 per launch in round 2); ds_write_b128 is serviced in groups
-  // of 8 lanes = 32 consecutive dwords, conflict-free.  Every exchange buffer starts on a 16-byte boundary.
-#ifndef FMC_ALIGNED_ST128
-#define FMC_ALIGNED_ST128 0     // A/B (round 3): the conflict-free ds_write_b128 runs the rows kernel 7 % SLOWER than hipcc's ds_write2_b64
-#endif                          // with its 2-way conflicts (9.35 against 8.70 ms per 5000 realisations): the store form, not the conflicts, sets the time
-#ifndef FMC_ST_SINGLE
-#define FMC_ST_SINGLE 0         // A/B: every exchange store as a single ds_write_b64 (no ds_write2_b64 pairing)
-#endif
-#if FMC_ST_SINGLE
-  static __device__ __forceinline__ void st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
-  static __device__ __forceinline__ void st(cpx<double>* p, cpx<double> v) {
-    __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  }
-#endif
-#if FMC_ALIGNED_ST128
-  static __device__ __forceinline__ void st(cpx<double>* p, cpx<double> v) {
-    typedef double d2_t __attribute__((ext_vector_type(2)));
-    *reinterpret_cast<d2_t*>(__builtin_assume_aligned(p, 16)) = (d2_t){v.x, v.y};
-  }
-#endif
-  // two neighbouring 8-byte elements at a 16-byte aligned address: one ds_read_b128
-  template <class E> static __device__ __forceinline__ void ld2(const E* p, E& a, E& b) {
-    struct alignas(16) Pair { E a, b; };
-    const Pair v = *reinterpret_cast<const Pair*>(__builtin_assume_aligned(p, 16));
-    a = v.a;
-    b = v.b;
-  }
   // compiler-only barrier for memory operations: loads after it are not hoisted above it
   static __device__ __forceinline__ void loadfence() { asm volatile("" ::: "memory"); }
   // "this value is needed HERE": loads feeding it are issued before this point and waited for once.
@@ -381,25 +347,13 @@ struct GpuExec {
   // after a read) of the same wave needs no s_waitcnt: wavefront-scope fences only stop the
   // compiler from moving or caching LDS accesses across this point.
   __device__ __forceinline__ void sync() {
-#ifdef FMC_SYNC_WORKGROUP   // A/B variant: waits for lgkmcnt(0) at every hand-off
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
   }
 };
 
-#ifndef FMC_ROWS_PER_WAVE
-#define FMC_ROWS_PER_WAVE 8
-#endif
-constexpr int ROWS_PER_WAVE = FMC_ROWS_PER_WAVE;   // rows kernel: rows per wave
-#ifndef FMC_ROWMAP
-#define FMC_ROWMAP 1
-#endif
+constexpr int ROWS_PER_WAVE = 8;   // rows kernel: rows per wave (4 / 16 / 32 / 64 measured -4 % ... +-1 %)
 // Waves per workgroup: the twiddle tables are staged once per workgroup, so bigger groups leave
 // more LDS for exchange buffers: 12 waves = 3 per SIMD at 132 VGPRs (f64, P = 16).
 // P = 32 keeps 2 x 32 values per lane (>= 200 VGPRs) and 18 KiB of exchange buffer per wave: 6 waves
@@ -409,61 +363,34 @@ constexpr int ROWS_PER_WAVE = FMC_ROWS_PER_WAVE;   // rows kernel: rows per wave
 // (3*2^k, 5*2^k): 8 waves (A/B at 640^2 / 768^2: +4 % / +1 % over 12, no spill at the 168-VGPR step);
 // P = 18, 28 (radix-9 / radix-7 stage with many live temporaries): 4 waves, one per SIMD, no spill.
 template <class R, int P, int NS> struct WaveCfg {
-#ifndef FMC_WPB
-#define FMC_WPB 12
-#endif
-#ifndef FMC_WPB_P32_F64
-#define FMC_WPB_P32_F64 6
-#endif
   static constexpr int WPB = (NS > 4 || (NS > 2 && NS == P)) ? 4 : (NS == 4 && P == 24) ? 6 :   // 256-pixel window tables: 6 waves fit the LDS
-                              (P == 32 ? (sizeof(R) == 8 ? FMC_WPB_P32_F64 : 6) : ((P > 16 && P / (P & -P) >= 7) ? 4 : (P > 24 ? 6 : ((P > 16 || (!is_pow2(P) && P > 8)) ? 8 : FMC_WPB))));
+                              (P == 32 ? 6 : ((P > 16 && P / (P & -P) >= 7) ? 4 : (P > 24 ? 6 : ((P > 16 || (!is_pow2(P) && P > 8)) ? 8 : 12))));
 };
 
-// D = 4: the dense row with the lanes factored 16 x 4 (pruned_row_fft_d16r: one radix-16 butterfly per lane, 4-term sums, six of
-//        sixteen planes): the default for centred windows of up to 96 pixels.
-// D = 8: D = 4 with the eight-plane set of centred windows of 97-128 pixels (the tables fit the dense layout because only four
-//        rows of the stage-2b table are staged).
-// D = 7: D = 5 with all sixteen planes: any window (NS = 2, 4, 8) at P = 16 -- the 4-term sums alone pay for the larger butterfly.
-// D = 6: D = 5 with the plane set of centred windows of 97-128 pixels (eight of sixteen planes).
-// D = 5: the 16 x 4 row in the twelve-wave kernels (split rows of 2048 / 4096 keep 3 waves per SIMD: their sub-row accumulators
-//        do not fit the 128-VGPR step).
-// D = 2: D = 1 without the two exchange-2 planes a centred window never reads (D16_CENTRE_MASK), the default when the window fits.
-// D = 3: the kernels of D = 0 without the planes a centred window of up to 96 pixels never reads (centre_planes(P, 8, 0)): P = 16 where
-//        the dense images do not apply (split rows of 2048 / 4096) and P = 18, 20, 24, 28 (two to four of the eight planes).
-// D = 1: the dense-image variant of the P = 16, NS = 2 row / column (pruned_row_fft_d16): sixteen waves per workgroup
-// = four per SIMD, 128 VGPRs.  Its exchange buffers (8448 B per wave) and the tables fit the 160 KB of a CU for windows
-// of up to 96 pixels (wave_lds_bytes_d); wider windows keep the twelve-wave kernels.
-#ifndef FMC_DENSE16
-#define FMC_DENSE16 1
-#endif
-#ifndef FMC_D16_PRUNE
-#define FMC_D16_PRUNE 1
-#endif
-#ifndef FMC_COLS_D16_WPB
-#define FMC_COLS_D16_WPB 0   // 0: sixteen waves, as the rows.  A/B at 1024^2: 6 waves (two workgroups per CU) 1.30 -> 1.285 ms per 5000
-                             // realisations, 8 waves (one per CU) 1.54 ms: overlapping one group's loads with another's arithmetic buys 1 %
-#endif
-#ifndef FMC_D16_R16
-#define FMC_D16_R16 1
-#endif
-#ifndef FMC_D16_R16_ALL
-#define FMC_D16_R16_ALL 1
-#endif
-#ifndef FMC_SPLIT_DENSE_ROWS
-#define FMC_SPLIT_DENSE_ROWS 1
-#endif
+// Row / column variant D (what fastmc.hip:dispatch_wave picks by window):
+//   0  the general row of fmc_wavefft.h (pruned_row_fft: P x 8 x 8, all eight planes): any P, any window, host coefficients, screens;
+//   3  the same without the planes a centred window of up to 96 pixels never reads (centre_planes(P, 8, 0)): P = 18, 20, 24, 28;
+//  P = 16 (1024, and 2048 / 4096 as sub-rows) runs the 16 x 4 lane factorisation (pruned_row_fft_d16r):
+//   4  six of sixteen planes, dense images, sixteen waves per workgroup: centred windows of up to 96 pixels -- the BASELINE
+//      workloads; also with host coefficients / screens at 1024^2;
+//   8  eight planes, dense images: centred windows of 97-128 pixels (only four rows of the stage-2b table are staged, so the
+//      tables still fit beside sixteen exchange buffers);
+//   5  six planes in the twelve-wave kernels (split columns of 2048 / 4096, host coefficients / screens of the split rows);
+//   6  eight planes, twelve waves (97-128 pixels on the split grids, or where the dense tables do not fit);
+//   7  all sixteen planes, twelve waves: any other window (NS = 2, 4, 8) -- the 4-term sums alone pay for the larger butterfly.
 template <class R, int P, int NS, int D> struct WCfg {
   static constexpr int OM_ROWS = (D >= 4) ? 4 : 8;     // stage-2b table rows in the LDS: the 16 x 4 row reads rows 1 ... 3
-  // waves per workgroup of the COLUMN kernel (A/B: smaller dense workgroups, two per CU, so that one's loads overlap the other's
-  // arithmetic)
-  static constexpr int WPB_COLS = ((D == 4 || D == 8) && FMC_COLS_D16_WPB) ? FMC_COLS_D16_WPB : ((D == 1 || D == 2 || D == 4 || D == 8) ? 16 : WaveCfg<R, P, NS>::WPB);
-  static_assert(D <= 8 && (D == 0 || (D == 3 && NS == 2) || (P == 16 && NS == 2) || (D == 7 && P == 16)),
-                "dense images exist for P = 16, NS = 2; pruned planes for NS = 2; the 16 x 4 row for P = 16");
+  static constexpr bool DENSE = (D == 4 || D == 8);
+  static_assert(D == 0 || (D == 3 && NS == 2 && P > 16) || (P == 16 && NS == 2 && D >= 4 && D <= 8) || (D == 7 && P == 16),
+                "pruned planes for NS = 2; the 16 x 4 row for P = 16");
   static_assert(WaveGeom<R, 16>::XELEMS >= D16_XELEMS, "the 16 x 4 row (D = 5) runs in the twelve-wave exchange buffer");
-  static constexpr bool DENSE = (D == 1 || D == 2 || D == 4 || D == 8);
   static constexpr int WPB = DENSE ? 16 : WaveCfg<R, P, NS>::WPB;
+  // the column kernel: sixteen waves as the rows (A/B at 1024^2: two six-wave workgroups per CU -1 %, one of eight +18 %)
+  static constexpr int WPB_COLS = WPB;
   static constexpr int XELEMS = DENSE ? D16_XELEMS : WaveGeom<R, P>::XELEMS;
 };
+// the plane set of a P = 16 variant
+template <int D> constexpr int d16r_mask() { return D == 7 ? 0xFFFF : (D == 6 || D == 8) ? D16R_WIDE_MASK : D16R_CENTRE_MASK; }
 
 template <class R, int P, int OM_ROWS = 8>
 __device__ __forceinline__ void load_tables(cpx<R>* s_tw, cpx<R>* s_om, const cpx<R>* tw, const cpx<R>* om, int omS) {
@@ -490,6 +417,12 @@ __host__ __device__ constexpr size_t wave_lds_bytes_d(int omS) {
 // the same P-per-lane pipeline, and the window outputs are combined, X[x] = sum_s w_NF^{s x} Y_s[x mod 64 P]
 // (decimation in time, evaluated only for the window).  2048 = 2 x 1024 and 4096 = 4 x 1024 run the
 // P = 16 pipeline at 3 waves per SIMD instead of a 32-values-per-lane pipeline at 2.
+template <class R, int P, int NS, int D, class Exec>
+__device__ __forceinline__ void wave_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* s_tw, const cpx<R>* s_om, int omS, int lo, int Np) {
+  if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, d16r_mask<D>()>(ex, xbuf, s_tw, s_om, omS, lo, Np);
+  else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, omS, lo, Np);
+}
+
 template <class R, int P, int NS, int MODE, int S = 1, int D = 0>
 __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -498,7 +431,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
   cpx<R>* s_om = s_tw + P * WAVE;
   E* s_x = reinterpret_cast<E*>(s_om + WCfg<R, P, NS, D>::OM_ROWS * A.omS);
-  load_tables<R, P, (D >= 4 ? 4 : 8)>(s_tw, s_om, A.tw, A.om, A.omS);
+  load_tables<R, P, WCfg<R, P, NS, D>::OM_ROWS>(s_tw, s_om, A.tw, A.om, A.omS);
 
   // the wave index is wave-uniform: in an SGPR, so that row / realisation indices and the table base addresses
   // derived from it are scalar and the loads use the scalar-base + lane-offset form
@@ -507,18 +440,6 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
   const int N = S * G::N;           // full row length
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
-  const int b0mask = window_b0_mask(A.lo, A.Np, P);
-#if FMC_ROWMAP == 0
-  // work item = (row group of 8 consecutive ky, realisation b), b fastest: the waves of a block
-  // colour the SAME spectrum rows for different realisations (amp rows shared in L1/L2)
-  const int item = blockIdx.x * WCfg<R, P, NS, D>::WPB + w;
-  if (item >= A.nb * (N / ROWS_PER_WAVE)) return;   // after the only block barrier
-  const int b = item % A.nb;
-  const int row0 = (item / A.nb) * ROWS_PER_WAVE;
-  const uint64_t g = A.g0 + (uint64_t)b;
-  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
-    const int ky = row0 + rr;
-#else
   // A workgroup owns LR consecutive rows (one 128-byte line of every V column) of RPW*WPB/LR
   // consecutive realisations, and its waves walk that tile row-fastest: the LR 16-byte pieces of a
   // line are stored by LR different waves within one or two iterations, so the line is complete
@@ -538,7 +459,6 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
     if (b >= A.nb) break;                                // wave-uniform
     const int ky = row0 + flat % LR;
     const uint64_t g = A.g0 + (uint64_t)b;
-#endif
     const R* amp = A.amp + (size_t)ky * N;
     const float* ampf = A.ampf + (size_t)ky * N;
     R accr[NS], acci[NS];
@@ -546,75 +466,31 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
     for (int s2 = 0; s2 < NS; ++s2) { accr[s2] = (R)0; acci[s2] = (R)0; }
 #pragma unroll 1
     for (int sp = 0; sp < S; ++sp) {
-    // sub-row sp: kx = sp + S (lane + 64 j)
-    if (MODE == 0) {
-#if defined(FMC_ABL_NOGEN)      // ablation (timing only, wrong results): no generator at all
+      // sub-row sp: kx = sp + S (lane + 64 j)
+      if (MODE == 0) {
+        xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
 #pragma unroll
-      for (int j = 0; j < P; ++j) regs.v[j] = cscale(mk<R>((R)(lane + j), (R)(ky - j)), (R)ampf[sp + S * (lane + WAVE * j)]);
-#elif defined(FMC_ABL_NOBM)     // ablation: uniform words only, no Box-Muller
-      xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
+        for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[sp + S * (lane + WAVE * j)]);
+      } else {
+        const size_t base = ((size_t)b * N + ky) * N;
 #pragma unroll
-      for (int j = 0; j < P; ++j) {
-        const uint32_t a = rs.next(), bb = rs.next();
-        regs.v[j] = cscale(mk<R>((R)(int)a, (R)(int)bb), (R)ampf[sp + S * (lane + WAVE * j)]);
-      }
-#elif defined(FMC_ABL_NOAMP)    // ablation: no spectrum loads (constant colouring)
-      xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
-#pragma unroll
-      for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, 1.0f + (float)j);
-#elif defined(FMC_GEN_BATCH)    // A/B variant: the words of FMC_GEN_BATCH coefficients first, then their Box-Muller transforms together
-      xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
-#pragma unroll
-      for (int j0 = 0; j0 < P; j0 += FMC_GEN_BATCH) {
-        uint32_t wa[FMC_GEN_BATCH], wb[FMC_GEN_BATCH];
-        float lg[FMC_GEN_BATCH], tt[FMC_GEN_BATCH], ra[FMC_GEN_BATCH];
-#pragma unroll
-        for (int q = 0; q < FMC_GEN_BATCH; ++q) if (j0 + q < P) draw_words(rs, wa[q], wb[q]);
-#pragma unroll
-        for (int q = 0; q < FMC_GEN_BATCH; ++q) if (j0 + q < P) {
-          lg[q] = __builtin_amdgcn_logf(fmaf((float)wa[q], 2.3283064365386963e-10f, 1.1641532182693481e-10f));
-          tt[q] = angle_turns(wb[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < FMC_GEN_BATCH; ++q) if (j0 + q < P) ra[q] = __builtin_amdgcn_sqrtf(-lg[q]) * ampf[sp + S * (lane + WAVE * (j0 + q))];
-#pragma unroll
-        for (int q = 0; q < FMC_GEN_BATCH; ++q) if (j0 + q < P)
-          regs.v[j0 + q] = mk<R>((R)(ra[q] * __builtin_amdgcn_cosf(tt[q])), (R)(ra[q] * __builtin_amdgcn_sinf(tt[q])));
-      }
-#else
-      xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
-#pragma unroll
-      for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[sp + S * (lane + WAVE * j)]);
-#endif
-    } else {
-      const size_t base = ((size_t)b * N + ky) * N;
-#pragma unroll
-      for (int j = 0; j < P; ++j) {
-        const int kx = sp + S * (lane + WAVE * j);
-        regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
-      }
-    }
-#if defined(FMC_ABL_NOFFT)      // ablation: generator + stores only
-#pragma unroll
-    for (int s = 0; s < NS; ++s) { regs.xr[s] = 0; regs.xi[s] = 0; }
-#pragma unroll
-    for (int j = 0; j < P; ++j) { regs.xr[j % NS] += regs.v[j].x; regs.xi[j % NS] += regs.v[j].y; }
-#else
-    if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : (D == 6 || D == 8) ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
-    else if constexpr (D == 1 || D == 2) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
-    else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, b0mask);
-#endif
-    if (S > 1) {
-#pragma unroll
-      for (int s2 = 0; s2 < NS; ++s2) {
-        const int oi = lane + WAVE * s2;
-        if (oi < A.Np) {
-          const cpx<R> c = A.cw[sp * A.omS + oi];
-          accr[s2] += c.x * regs.xr[s2] - c.y * regs.xi[s2];
-          acci[s2] += c.x * regs.xi[s2] + c.y * regs.xr[s2];
+        for (int j = 0; j < P; ++j) {
+          const int kx = sp + S * (lane + WAVE * j);
+          regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
         }
       }
-    }
+      wave_row_fft<R, P, NS, D>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+      if (S > 1) {
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+          const int oi = lane + WAVE * s2;
+          if (oi < A.Np) {
+            const cpx<R> c = A.cw[sp * A.omS + oi];
+            accr[s2] += c.x * regs.xr[s2] - c.y * regs.xi[s2];
+            acci[s2] += c.x * regs.xi[s2] + c.y * regs.xr[s2];
+          }
+        }
+      }
     }
     if (S > 1) {
 #pragma unroll
@@ -626,11 +502,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int oi = lane + WAVE * s;
-#if defined(FMC_ABL_NOSTORE)    // ablation: compute only (the comparison keeps the work alive)
-      if (oi < A.Np && regs.xr[s] == (R)1.2345e30) out[(size_t)oi * N] = mk<R>(regs.xr[s], regs.xi[s]);
-#else
       if (oi < A.Np) out[(size_t)oi * N] = mk<R>(regs.xr[s], regs.xi[s]);
-#endif
     }
   }
 }
@@ -639,15 +511,10 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 // Small grids (P <= 8): each wave is short-lived (one column, a few microseconds of mostly latency), so
 // two workgroups per CU are worth a tighter register budget (6 waves per SIMD): column time -26 % at
 // 128^2 / 256^2, -17 % at 512^2.  (The same hint on the rows kernel spills and gains nothing.)
-#ifndef FMC_COLS_WPE_MAXP
-#define FMC_COLS_WPE_MAXP 8
-#endif
-#ifndef FMC_COLS_PREFETCH
-#define FMC_COLS_PREFETCH 0   // A/B: the column's global loads issued before the table staging and its barrier: 1.31 -> 1.58 ms per 5000
-#endif                        // realisations at 1024^2 (the table copy queues behind 16 KB of column loads per wave), +24 % at 1536^2
-
+// (Tried: the column's global loads issued before the table staging and its barrier: +20 % at 1024^2 -- the table copy queues
+// behind 16 KB of column loads per wave.)
 template <class R, int P, int NS, int EPI, int S = 1, int D = 0>
-__global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB_COLS * 64), ((P <= FMC_COLS_WPE_MAXP && P != 7 && NS == 2 && WaveCfg<R, P, NS>::WPB == 12) ? 6 : 1))
+__global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB_COLS * 64), ((P <= 8 && P != 7 && NS == 2 && WaveCfg<R, P, NS>::WPB == 12) ? 6 : 1))
 void k_cols_wave(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = WaveGeom<R, P>;
@@ -668,23 +535,12 @@ void k_cols_wave(ColArgs<R> A) {
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
   const cpx<R>* col = A.V + ((size_t)b * A.Np + xi) * N;
-#if FMC_COLS_PREFETCH
-  // the column's loads go out before the tables are staged: HBM latency under the table copy and the barrier
-  if (S == 1 && valid) {
-#pragma unroll
-    for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
-  }
-#endif
-  load_tables<R, P, (D >= 4 ? 4 : 8)>(s_tw, s_om, A.tw, A.om, A.omS);
+  load_tables<R, P, WCfg<R, P, NS, D>::OM_ROWS>(s_tw, s_om, A.tw, A.om, A.omS);
   if (!valid) return;   // whole wave exits; no block barrier follows
   if (S == 1) {
-#if !FMC_COLS_PREFETCH
 #pragma unroll
     for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
-#endif
-    if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : (D == 6 || D == 8) ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
-    else if constexpr (D == 1 || D == 2) pruned_row_fft_d16<R, NS, (D == 2 ? D16_CENTRE_MASK : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
-    else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    wave_row_fft<R, P, NS, D>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
   } else {
     R accr[NS], acci[NS];
 #pragma unroll
@@ -693,8 +549,7 @@ void k_cols_wave(ColArgs<R> A) {
     for (int sp = 0; sp < S; ++sp) {
 #pragma unroll
       for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (lane + WAVE * j)];
-      if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, (D == 7 ? 0xFFFF : (D == 6 || D == 8) ? D16R_WIDE_MASK : D16R_CENTRE_MASK)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
-      else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+      wave_row_fft<R, P, NS, D>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) {
         const int oi = lane + WAVE * s2;
@@ -708,35 +563,7 @@ void k_cols_wave(ColArgs<R> A) {
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2) { regs.xr[s2] = accr[s2]; regs.xi[s2] = acci[s2]; }
   }
-
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int yi = lane + WAVE * s;
-    if (yi < A.Np) {
-      R p1 = regs.xr[s], p2 = regs.xi[s];
-      pixel_phase<R>(A.sh, b, A.Np, yi, xi, p1, p2);
-      if (EPI == 1) {
-        const size_t plane = (size_t)A.Np * A.Np;
-        A.phs[((size_t)b) * plane + (size_t)yi * A.Np + xi] = (double)p1;
-        A.phs[((size_t)(A.nb + b)) * plane + (size_t)yi * A.Np + xi] = (double)p2;
-      } else {
-        const double wgt = A.W[(size_t)yi * A.Np + xi];
-        double s1, c1, s2, c2;
-        sincos_r(p1, s1, c1);
-        sincos_r(p2, s2, c2);
-        acc[0] += wgt * c1; acc[1] += wgt * s1; acc[2] += wgt * c2; acc[3] += wgt * s2;
-      }
-    }
-  }
-  if (EPI == 0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
-    if (lane == 0) {
-      double* o = A.partial + ((size_t)b * A.Np + xi) * 4;
-      o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
-    }
-  }
+  column_epilogue<R, NS, EPI>(A.sh, A.W, A.partial, A.phs, A.nb, A.Np, b, xi, lane, regs.xr, regs.xi);
 }
 
 // ================================================================== chirp-z family (any N with 64 P >= N + Np - 1)
@@ -747,16 +574,10 @@ void k_cols_wave(ColArgs<R> A) {
 // at P = 16 (f64) twelve waves (168-VGPR cap) spill 270 B per lane and run 17.6 ms per 5000 realisations at N = 500,
 // eight waves (256-VGPR cap, no spill) 12.8 ms; at P = 24 eight waves (164 B of spill) beat four (no spill, one wave per
 // SIMD) 48.9 to 70.3 ms at N = 1000; at P = 32 four waves beat six (690 B of spill) 140 to 207 ms at N = 1500.
-#ifndef FMC_BLU_WPB16
-#define FMC_BLU_WPB16 8
-#endif
-#ifndef FMC_BLU_WPB24
-#define FMC_BLU_WPB24 8
-#endif
 template <class R, int P, int NS> struct BluCfg {
   static constexpr int W0 = WaveCfg<R, P, NS>::WPB;
   static constexpr int W1 = (NS == 4 && W0 > 8) ? 8 : W0;     // 256-pixel window tables: 8 waves fit the LDS
-  static constexpr int CAP = sizeof(R) == 8 ? (P >= 32 ? 4 : (P >= 24 ? FMC_BLU_WPB24 : (P >= 16 ? FMC_BLU_WPB16 : 12))) : 12;
+  static constexpr int CAP = sizeof(R) == 8 ? (P >= 32 ? 4 : (P >= 16 ? 8 : 12)) : 12;
   static constexpr int WPB = W1 > CAP ? CAP : W1;
   // the column kernel has no generator and fits the 168-VGPR step at P = 16: twelve waves (500^2: 2.59 against 3.08 ms)
   static constexpr int WPB_COLS = (P == 16 && NS == 2) ? W1 : WPB;
@@ -766,7 +587,9 @@ __host__ __device__ constexpr size_t blu_lds_bytes(int omS, int wpb) {
   return (size_t)(P * WAVE + 8 * omS + 64) * sizeof(cpx<R>) + (size_t)wpb * BluGeom<R, P>::XELEMS * 8;
 }
 
-template <class R, int P, int NS, int MODE>
+// BLK: rows longer than the largest M, cut into A.blu.SB input blocks of A.blu.B (fmc_bluestein.h header); the generator
+// stream of a lane runs on across the blocks (B is a multiple of 64).
+template <class R, int P, int NS, int MODE, bool BLK = false>
 __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using BG = BluGeom<R, P>;
@@ -805,6 +628,32 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
     const cpx<R>* pre = A.blu.pre + zoff;
     const cpx<R>* vhat = A.blu.vhat + zoff;
     const cpx<R>* post = A.blu.post + zoff;
+    if constexpr (BLK) {
+      R accr[NS], acci[NS];
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) { accr[s2] = (R)0; acci[s2] = (R)0; }
+      const float* ampf = A.ampf + (size_t)ky * N;
+      const R* amp = A.amp + (size_t)ky * N;
+      const size_t base = ((size_t)b * N + ky) * N;
+      xoshiro128p rs = row_stream(A.key, g, ky, lane, WAVE);
+      const int nj = A.blu.B / WAVE;                     // values per lane and block
+#pragma unroll 1
+      for (int jb = 0; jb < A.blu.SB; ++jb) {
+        const int k0 = jb * A.blu.B;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          const int kx = k0 + lane + WAVE * j;
+          const bool in = j < nj && kx < N;              // draws only for coefficients of the row, in stream order
+          if (MODE == 0) regs.v[j] = in ? cmul(draw_coloured<R>(rs, ampf[kx]), pre[kx]) : mk<R>((R)0, (R)0);
+          else regs.v[j] = in ? cmul(cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]), pre[kx]) : mk<R>((R)0, (R)0);
+        }
+        bluestein_row<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, s_twf, vhat + (size_t)jb * (WAVE * P), A.Np);
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) { accr[s2] += regs.xr[s2]; acci[s2] += regs.xi[s2]; }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) { regs.xr[s2] = accr[s2]; regs.xi[s2] = acci[s2]; }
+    } else {
     if (MODE == 0) {
       const float* ampf = A.ampf + (size_t)ky * N;
       xoshiro128p rs = row_stream(A.key, g, ky, lane, WAVE);
@@ -823,6 +672,7 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
       }
     }
     bluestein_row<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, s_twf, vhat, A.Np);
+    }
     cpx<R>* out = A.V + (size_t)b * A.Np * N + ky;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -835,8 +685,9 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
   }
 }
 
-template <class R, int P, int NS, int EPI>
-__global__ __launch_bounds__((BluCfg<R, P, NS>::WPB_COLS * 64)) void k_cols_blu(ColArgs<R> A) {
+// (the blocked column carries the window accumulators: eight waves per workgroup as the rows, else 132 B of scratch)
+template <class R, int P, int NS, int EPI, bool BLK = false>
+__global__ __launch_bounds__(((BLK ? BluCfg<R, P, NS>::WPB : BluCfg<R, P, NS>::WPB_COLS) * 64)) void k_cols_blu(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using BG = BluGeom<R, P>;
   using E = typename Xch<R>::E;
@@ -849,7 +700,7 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB_COLS * 64)) void k_cols_blu(
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * BG::XELEMS;
-  const int item = blockIdx.x * BluCfg<R, P, NS>::WPB_COLS + w;
+  const int item = blockIdx.x * (BLK ? BluCfg<R, P, NS>::WPB : BluCfg<R, P, NS>::WPB_COLS) + w;
   if (item >= A.nb * A.Np) return;   // whole wave exits; no block barrier follows
   const int b = item / A.Np;
   const int xi = item % A.Np;
@@ -857,41 +708,42 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB_COLS * 64)) void k_cols_blu(
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
   const cpx<R>* col = A.V + ((size_t)b * A.Np + xi) * N;
+  if constexpr (BLK) {
+    R accr[NS], acci[NS];
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) { accr[s2] = (R)0; acci[s2] = (R)0; }
+    const int nj = A.blu.B / WAVE;
+#pragma unroll 1
+    for (int jb = 0; jb < A.blu.SB; ++jb) {
+      const int k0 = jb * A.blu.B;
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int ky = k0 + lane + WAVE * j;
+        regs.v[j] = (j < nj && ky < N) ? cmul(col[ky], A.blu.pre[ky]) : mk<R>((R)0, (R)0);
+      }
+      bluestein_row<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, s_twf, A.blu.vhat + (size_t)jb * (WAVE * P), A.Np);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) { accr[s2] += regs.xr[s2]; acci[s2] += regs.xi[s2]; }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) { regs.xr[s2] = accr[s2]; regs.xi[s2] = acci[s2]; }
+  } else {
 #pragma unroll
   for (int j = 0; j < P; ++j) {
     const int ky = lane + WAVE * j;
     regs.v[j] = ky < N ? cmul(col[ky], A.blu.pre[ky]) : mk<R>((R)0, (R)0);
   }
   bluestein_row<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, s_twf, A.blu.vhat, A.Np);
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  }
+  R p1s[NS], p2s[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int yi = lane + WAVE * s;
-    if (yi < A.Np) {
-      const cpx<R> q = A.blu.post[yi];
-      R p1 = q.x * regs.xr[s] + q.y * regs.xi[s], p2 = q.y * regs.xr[s] - q.x * regs.xi[s];      // post * conj(Y)
-      pixel_phase<R>(A.sh, b, A.Np, yi, xi, p1, p2);
-      if (EPI == 1) {
-        const size_t plane = (size_t)A.Np * A.Np;
-        A.phs[((size_t)b) * plane + (size_t)yi * A.Np + xi] = (double)p1;
-        A.phs[((size_t)(A.nb + b)) * plane + (size_t)yi * A.Np + xi] = (double)p2;
-      } else {
-        const double wgt = A.W[(size_t)yi * A.Np + xi];
-        double s1, c1, s2, c2;
-        sincos_r(p1, s1, c1);
-        sincos_r(p2, s2, c2);
-        acc[0] += wgt * c1; acc[1] += wgt * s1; acc[2] += wgt * c2; acc[3] += wgt * s2;
-      }
-    }
+    const cpx<R> q = A.blu.post[yi < A.Np ? yi : 0];
+    p1s[s] = q.x * regs.xr[s] + q.y * regs.xi[s];          // post * conj(Y)
+    p2s[s] = q.y * regs.xr[s] - q.x * regs.xi[s];
   }
-  if (EPI == 0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
-    if (lane == 0) {
-      double* o = A.partial + ((size_t)b * A.Np + xi) * 4;
-      o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
-    }
-  }
+  column_epilogue<R, NS, EPI>(A.sh, A.W, A.partial, A.phs, A.nb, A.Np, b, xi, lane, p1s, p2s);
 }
 
 // ================================================================== 50-lane family (N = 50 P: 100, 200, 250, 500, 1000, ...)
@@ -899,9 +751,7 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB_COLS * 64)) void k_cols_blu(
 // with k = lane + 50 j inputs on lanes 0-49 and 50 generator streams per row (stream L = kx mod 50, fmc_core.h
 // stream_lanes).  Waves per workgroup: the exchange buffer is 69 P elements (P = 20: 11 KB) and the radix-P stage holds 2 P
 // values per lane, as in the wave family.
-#ifndef FMC_MR_WPB16
-#define FMC_MR_WPB16 8      // A/B at 800^2 f64: 8 waves 10.8 ms per 5000 realisations, 12 waves (168-VGPR cap) 14.2 ms
-#endif
+// (A/B at 800^2 f64, P = 16: 8 waves per workgroup 10.8 ms per 5000 realisations, 12 waves under the 168-VGPR cap 14.2 ms)
 // The same two kernels also serve the 64-lane pipeline (LN = 64, SPLIT only): wave-family grids N = 64 P S whose sub-row
 // count is not one of the compiled ones (2304 = 2 x 1152, 2560 = 2 x 1280, 3072 = 2 x 1536, ...; fmc_core.h: wave_rt_split).
 template <class R, int P, int LN> struct LaneFam;
@@ -924,12 +774,12 @@ template <class R, int P> struct LaneFam<R, P, WAVE> {
   template <int NS, int PR, class Exec>
   static __device__ __forceinline__ void fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw, const cpx<R>* om, int omS, int lo,
                                              int Np, int os) {
-    pruned_row_fft<R, P, NS, (PR ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, tw, om, omS, lo, Np, 0xFF, os);
+    pruned_row_fft<R, P, NS, (PR ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, tw, om, omS, lo, Np, os);
   }
 };
 template <class R, int P, int NS, int LN = MR_LN> struct MrCfg {
   static constexpr int W0 = WaveCfg<R, P, NS>::WPB;
-  static constexpr int WPB = (LN == MR_LN && sizeof(R) == 8 && P >= 16 && W0 > FMC_MR_WPB16) ? FMC_MR_WPB16 : W0;
+  static constexpr int WPB = (LN == MR_LN && sizeof(R) == 8 && P >= 16 && W0 > 8) ? 8 : W0;
 };
 template <class R, int P, int NS, int LN = MR_LN>
 __host__ __device__ constexpr size_t mr_lds_bytes(int omS) {
@@ -1070,34 +920,7 @@ __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_cols_mr(Col
 #pragma unroll
     for (int s2 = 0; s2 < NS; ++s2) { regs.xr[s2] = accr[s2]; regs.xi[s2] = acci[s2]; }
   }
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int yi = lane + WAVE * s;
-    if (yi < A.Np) {
-      R p1 = regs.xr[s], p2 = regs.xi[s];
-      pixel_phase<R>(A.sh, b, A.Np, yi, xi, p1, p2);
-      if (EPI == 1) {
-        const size_t plane = (size_t)A.Np * A.Np;
-        A.phs[((size_t)b) * plane + (size_t)yi * A.Np + xi] = (double)p1;
-        A.phs[((size_t)(A.nb + b)) * plane + (size_t)yi * A.Np + xi] = (double)p2;
-      } else {
-        const double wgt = A.W[(size_t)yi * A.Np + xi];
-        double s1, c1, s2, c2;
-        sincos_r(p1, s1, c1);
-        sincos_r(p2, s2, c2);
-        acc[0] += wgt * c1; acc[1] += wgt * s1; acc[2] += wgt * c2; acc[3] += wgt * s2;
-      }
-    }
-  }
-  if (EPI == 0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
-    if (lane == 0) {
-      double* o = A.partial + ((size_t)b * A.Np + xi) * 4;
-      o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
-    }
-  }
+  column_epilogue<R, NS, EPI>(A.sh, A.W, A.partial, A.phs, A.nb, A.Np, b, xi, lane, regs.xr, regs.xi);
 }
 
 // ================================================================== direct family (any N <= 4096)

@@ -19,18 +19,6 @@
 #pragma once
 #include "fmc_core.h"
 
-#ifndef FMC_BATCH_LDS
-#define FMC_BATCH_LDS 1
-#endif
-#ifndef FMC_BATCH_MAXP
-#define FMC_BATCH_MAXP 32   // A/B: batching only up to P = 16 (no spill at P = 20) is 2 % slower at 1152^2 / 1280^2, equal at 1536^2 / 1792^2
-#endif
-#ifndef FMC_TW_CHUNK
-#define FMC_TW_CHUNK 4
-#endif
-#ifndef FMC_TW_CHUNK_NS4
-#define FMC_TW_CHUNK_NS4 0
-#endif
 
 namespace fmc {
 
@@ -97,15 +85,11 @@ struct WaveGeom {
 // registers left beside the 2P values of the row (f64: 4 VGPRs per twiddle).
 template <class R, int P, int NS = 2>
 constexpr int tw_chunk() {
-#if FMC_BATCH_LDS
   // four output slots leave no registers for the prefetch: 2048^2 / Np = 152 runs 116 / 138 / 153 k it/s with chunks of 4 / 2 / 0
-  if (NS > 2 && sizeof(R) == 8) return (P >= 12 && P <= 16) ? FMC_TW_CHUNK_NS4 : 0;
+  if (NS > 2 && sizeof(R) == 8) return 0;
   // measured at 1024^2 (P = 16): rows -1.6 % (f64), -5 % (f32); P <= 8 loses 2-6 % (more registers,
   // fewer waves per SIMD) and P > 24 has no registers to spare
-  return (P < 12) ? 0 : (sizeof(R) == 8) ? (P <= 16 ? FMC_TW_CHUNK : 0) : (P <= 16 ? P - 1 : (P <= 24 ? 8 : 0));
-#else
-  return 0;
-#endif
+  return (P < 12) ? 0 : (sizeof(R) == 8) ? (P <= 16 ? 4 : 0) : (P <= 16 ? P - 1 : (P <= 24 ? 8 : 0));
 }
 
 // Per-lane registers of the pipeline.  Wide enough for the 50-lane factorisation of fmc_mrfft.h too (P L0 / 64 radix-10
@@ -149,36 +133,17 @@ FMC_HD constexpr int centre_planes(int P, int L1, int c, int W = 96) {
   }
   return m;
 }
-FMC_HD int window_b0_mask(int lo, int Np, int P) {
-  const int b_lo = lo / P, b_hi = (lo + Np - 1) / P;
-  if (b_hi - b_lo >= 7) return 0xFF;
-  int m = 0;
-  for (int b = b_lo; b <= b_hi; ++b) m |= 1 << (b & 7);
-  return m;
-}
-
-#ifndef FMC_B0MASK
-#define FMC_B0MASK 0   // measured: no gain (10.69 vs 10.66 ms per 5000 realisations): the conditional stores lose the write2 pairing
-#endif
+// B0M: planes of the exchange-2 image kept (compile time: the others are neither stored nor computed).  A run-time mask was
+// tried and bought nothing: no dead-code elimination, and the conditional stores lose their ds_write2 pairing.
 template <class R, int P, int NS, int B0M = 0xFF, class Exec>
 FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
-                           int omS, int lo, int Np, int b0mask = 0xFF, int osign = 0) {
+                           int omS, int lo, int Np, int osign = 0) {
   using G = WaveGeom<R, P>;
   using X = Xch<R>;
   using E = typename X::E;
   constexpr int NC = X::NC;
   const int nslots = (Np + WAVE - 1) / WAVE;
 
-#if defined(FMC_ABL_NOTW)      // ablation (timing only, wrong results): no LDS reads of the stage-1 twiddles
-#define FMC_TW1(a, lane) mk<R>((R)(lane) * (R)1e-3, (R)(a))
-#else
-#define FMC_TW1(a, lane) tw1[(a) * WAVE + (lane)]
-#endif
-#if defined(FMC_ABL_NOOM)      // ablation: no LDS reads of the stage-2b table
-#define FMC_OM(m, oi) mk<R>((R)(oi) * (R)1e-3, (R)(m))
-#else
-#define FMC_OM(m, oi) om[(m) * omS + (oi)]
-#endif
   // ---- stage 1: radix-P in registers, twiddle, to natural order
   ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
     cpx<R> z[P];
@@ -191,7 +156,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
     if (CH) {
 #pragma unroll
       for (int q = 0; q < CH; ++q)
-        if (1 + q < P) t[0][q] = FMC_TW1(1 + q, lane);
+        if (1 + q < P) t[0][q] = tw1[(1 + q) * WAVE + lane];
     }
 #pragma unroll
     for (int j = 0; j < P; ++j) z[j] = r.v[j];
@@ -203,7 +168,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
         if (k + 1 < NCH) {
 #pragma unroll
           for (int q = 0; q < CH; ++q)
-            if (1 + (k + 1) * CH + q < P) t[(k + 1) & 1][q] = FMC_TW1(1 + (k + 1) * CH + q, lane);
+            if (1 + (k + 1) * CH + q < P) t[(k + 1) & 1][q] = tw1[(1 + (k + 1) * CH + q) * WAVE + lane];
         }
 #pragma unroll
         for (int q = 0; q < CH; ++q)
@@ -214,7 +179,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
       }
     } else {
 #pragma unroll
-      for (int a = 1; a < P; ++a) r.v[a] = cmul(z[a], FMC_TW1(a, lane));
+      for (int a = 1; a < P; ++a) r.v[a] = cmul(z[a], tw1[a * WAVE + lane]);
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) { r.xr[s] = (R)0; r.xi[s] = (R)0; }
@@ -262,7 +227,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
         if ((P % 8 == 0) || i + 8 * jj < P) {
 #pragma unroll
           for (int b0 = 0; b0 < 8; ++b0)
-            if (((B0M >> b0) & 1) && (!FMC_B0MASK || ((b0mask >> b0) & 1)))   // planes no window output reads are not stored (B0M: compile time)
+            if ((B0M >> b0) & 1)   // planes no window output reads are not stored
               ex.st(xbuf + (i + 8 * jj) + G::FL * l0 + G::FB * b0, X::pack(r.v[jj * 8 + b0], c));
         }
     });
@@ -277,25 +242,22 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
             const int a = x % P;            // P is a compile-time constant: mask / shift for powers of two
             const int b0 = (x / P) & 7;
             const E* f = xbuf + a + G::FB * b0;
-#if FMC_BATCH_LDS
-            if (P >= 12 && P <= FMC_BATCH_MAXP && NS == 2) {
+            if (P >= 12 && NS == 2) {      // the eight loads of a sum issued together, one wait
             cpx<R> w[8];
             E fv[8];
             fv[0] = ex.ld(f);
 #pragma unroll
-            for (int m = 1; m < 8; ++m) { w[m] = FMC_OM(m, oi); fv[m] = ex.ld(f + G::FL * m); }
+            for (int m = 1; m < 8; ++m) { w[m] = om[m * omS + oi]; fv[m] = ex.ld(f + G::FL * m); }
             ex.pin(fv[0]);
 #pragma unroll
             for (int m = 1; m < 8; ++m) { ex.pin(w[m].x); ex.pin(w[m].y); ex.pin(fv[m]); }
             X::first(r.xr[s], r.xi[s], fv[0], c);
 #pragma unroll
             for (int m = 1; m < 8; ++m) X::acc(r.xr[s], r.xi[s], w[m], fv[m], c);
-            } else
-#endif
-            {
+            } else {
             X::first(r.xr[s], r.xi[s], ex.ld(f), c);
 #pragma unroll
-            for (int m = 1; m < 8; ++m) X::acc(r.xr[s], r.xi[s], FMC_OM(m, oi), ex.ld(f + G::FL * m), c);
+            for (int m = 1; m < 8; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + G::FL * m), c);
             }
             if (c == NC - 1 && osign >= 0) {
               const bool neg = ((x ^ osign) & 1) != 0;
@@ -310,129 +272,13 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
   }
 }
 
-// ---------------------------------------------------------------- P = 16, dense LDS images: four waves per SIMD
-// The same transform as pruned_row_fft<R, 16, NS> with exchange images small enough for SIXTEEN waves per workgroup
-// (16 x 8448 B + 28 KB of tables = the 160 KB of a CU) and no prefetch staging, so that the row fits 128 VGPRs:
-//   stage 2a is owned by lane (a = lane & 15, lp = lane >> 4) for l0 = lp and lp + 4 (instead of (i, l0) for a = i, i + 8):
-//   exchange 1:  E[a][l] at 66 a + l          reads (66 a + lp) mod 32 = 2 a + lp: the 32 lanes of a read group differ
-//   exchange 2:  F[a][b0][l0] at a + 16 b0 + 128 l0 (dense, 1024 elements): consecutive window outputs walk a, then b0,
-//                and 16 b0 alternates the upper half of the 32 element banks
-// all affine, so every access is base + immediate offset (tools/lds_bank_check.py verifies both images for every window).
-#ifndef FMC_D16_PAIR
-#define FMC_D16_PAIR 0   // A/B variant: exchange-1 reads as 8 ds_read_b128 instead of 16 ds_read_b64 per pass (139 -> 123 LDS instructions
-#endif                   // per row): rows 10.44 -> 10.46 ms per 5000 realisations -- the LDS time goes with the bytes, not the instructions
+// ---------------------------------------------------------------- P = 16: dense LDS images
+// Exchange buffer of the P = 16 rows below: E[a][l] at 66 a + l (16 x 66 eight-byte elements = 8448 B per wave), small enough
+// for SIXTEEN waves per workgroup beside the tables (16 x 8448 B + 28 KB = the 160 KB of a CU): four waves per SIMD.
 constexpr int D16_SE = 66;
 constexpr int D16_XELEMS = 16 * D16_SE;
-// B0M: the residues b0 = (x / 16) mod 8 of the output blocks that the window may touch (window_b0_mask).  Planes outside it are
-// never read by stage 2b, so they are neither stored nor -- the mask being a compile-time constant -- computed: the
-// radix-8 butterflies lose the adds that only feed them.  0xE7 = {5, 6, 7, 0, 1, 2} holds every centred window of up to
-// 81 + (lo mod 16 alignment) pixels at N = 1024, e.g. the 82-pixel window of the BASELINE geometry (b = 29 ... 34).
-constexpr int D16_CENTRE_MASK = 0xE7;
-static_assert(centre_planes(16, 8, 0) == D16_CENTRE_MASK, "centred 96-pixel window at P = 16");
 // P of the wave pipeline whose centred 96-pixel window leaves planes unread (P <= 14: all eight are touched)
 FMC_HD constexpr bool prune_pays(int P, int L1, int c) { return centre_planes(P, L1, c) != (1 << L1) - 1; }
-template <class R, int NS, int B0M = 0xFF, class Exec>
-FMC_HD void pruned_row_fft_d16(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
-                               int omS, int lo, int Np) {
-  constexpr int P = 16;
-  using X = Xch<R>;
-  using E = typename X::E;
-  constexpr int NC = X::NC;
-  const int nslots = (Np + WAVE - 1) / WAVE;
-  ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
-    cpx<R> z[P];
-#pragma unroll
-    for (int j = 0; j < P; ++j) z[j] = r.v[j];
-    dft_reg<P, R>(z);
-    r.v[0] = z[0];
-#pragma unroll
-    for (int a = 1; a < P; ++a) r.v[a] = cmul(z[a], tw1[a * WAVE + lane]);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) { r.xr[s] = (R)0; r.xi[s] = (R)0; }
-  });
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-#if FMC_D16_PAIR
-    // element (a, l) at 66 a + pi(l), pi(l) = 2 (l & 3) + ((l >> 2) & 1) + 8 (l >> 3): the two elements lane (a, lp) needs for
-    // one l1 (l = lp + 8 l1 and l + 4) are neighbours, one 16-byte read instead of two 8-byte reads
-    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
-      const int pl = 2 * (lane & 3) + ((lane >> 2) & 1) + 8 * (lane >> 3);
-#pragma unroll
-      for (int a = 0; a < P; ++a) ex.st(xbuf + a * D16_SE + pl, X::pack(r.v[a], c));
-    });
-    ex.sync();
-    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
-      const int a = lane & 15, lp = lane >> 4;
-#pragma unroll
-      for (int l1 = 0; l1 < 8; ++l1) {
-        E e0, e1;
-        ex.ld2(xbuf + a * D16_SE + 2 * lp + 8 * l1, e0, e1);
-        X::unpack(r.v[l1], e0, c);
-        X::unpack(r.v[8 + l1], e1, c);
-      }
-    });
-    ex.sync();
-#else
-    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
-#pragma unroll
-      for (int a = 0; a < P; ++a) ex.st(xbuf + a * D16_SE + lane, X::pack(r.v[a], c));
-    });
-    ex.sync();
-    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
-      const int a = lane & 15, lp = lane >> 4;
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int l1 = 0; l1 < 8; ++l1) X::unpack(r.v[q * 8 + l1], ex.ld(xbuf + a * D16_SE + lp + 4 * q + 8 * l1), c);
-    });
-    ex.sync();
-#endif
-  }
-  ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      cpx<R> t[8];
-#pragma unroll
-      for (int m = 0; m < 8; ++m) t[m] = r.v[q * 8 + m];
-      fft_dif<8, R>(t);
-#pragma unroll
-      for (int b0 = 0; b0 < 8; ++b0) r.v[q * 8 + b0] = t[brev(b0, 3)];
-    }
-  });
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
-      const int a = lane & 15, lp = lane >> 4;
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int b0 = 0; b0 < 8; ++b0)
-          if ((B0M >> b0) & 1) ex.st(xbuf + a + 16 * b0 + 128 * (lp + 4 * q), X::pack(r.v[q * 8 + b0], c));
-    });
-    ex.sync();
-    ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        if (s < nslots) {
-          const int oi = lane + WAVE * s;
-          if (oi < Np) {
-            const int x = lo + oi;
-            const E* f = xbuf + (x & 15) + 16 * ((x >> 4) & 7);
-            X::first(r.xr[s], r.xi[s], ex.ld(f), c);
-#pragma unroll
-            for (int m = 1; m < 8; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + 128 * m), c);
-            if (c == NC - 1) {
-              const bool neg = (x & 1) != 0;
-              r.xr[s] = flip_sign(r.xr[s], neg);
-              r.xi[s] = flip_sign(r.xi[s], neg);
-            }
-          }
-        }
-      }
-    });
-    ex.sync();
-  }
-}
 
 // ---------------------------------------------------------------- P = 16, dense images, 64 = 16 x 4 on the lanes
 // The same row with the lane dimension factored 64 = L1 x L0 = 16 x 4 instead of 8 x 8:
@@ -447,9 +293,6 @@ FMC_HD void pruned_row_fft_d16(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>*
 // time goes with the bytes.  Images: exchange 1 as before (66 a + l; the owners read 66 a + l0 + 4 l1: 2 a + l0 distinct in
 // a half-wave); exchange 2 F[a][b0][l0] at a + 16 b0 + 256 l0 (writes: 16 consecutive a; reads: x mod 256 consecutive).
 // Uses rows m = 1, 2, 3 of the `om` table (w_64^{m b}).
-#ifndef FMC_D16R_ONEPASS
-#define FMC_D16R_ONEPASS 1
-#endif
 FMC_HD constexpr int popcount16(int m) { int n = 0; for (int i = 0; i < 16; ++i) n += (m >> i) & 1; return n; }
 // NP planes around b0 = 0: {16 - NP / 2, ..., 15, 0, ..., NP - NP / 2 - 1}
 FMC_HD constexpr int centre_run_mask(int NP) {
@@ -507,7 +350,7 @@ FMC_HD void pruned_row_fft_d16r(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>
   // plane b0 at position p = (b0 + NP / 2) & 15 < NP, element (a, p, l0) at a + 16 p + 16 NP l0 (<= 512 elements of 16 bytes):
   // the table values are read once instead of once per component, two hand-offs instead of four.
   constexpr int NP = popcount16(B0M);
-  if constexpr (FMC_D16R_ONEPASS && sizeof(R) == 8 && NP <= 8 && B0M == centre_run_mask(NP)) {
+  if constexpr (sizeof(R) == 8 && NP <= 8 && B0M == centre_run_mask(NP)) {
     cpx<R>* cbuf = reinterpret_cast<cpx<R>*>(xbuf);
     ex.each([&](int lane, LaneRegs<R, P, NS>& r) {
       const int a = lane & 15, l0 = lane >> 4;

@@ -904,14 +904,18 @@ def test_subharm_bookkeeping_attributes_like_the_reference():
 
 # ------------------------------------------------------------------ chirp-z family: grid sizes that are not 64 P
 @pytest.mark.parametrize("N,Np", [(164, 82), (102, 40), (49, 23), (33, 9), (252, 129), (502, 82), (943, 82), (1002, 82), (1455, 82),
-                                  (1280 - 255, 256), (1900, 100), (333, 333 // 3)])
+                                  (1280 - 255, 256), (1900, 100), (333, 333 // 3),
+                                  (2200, 82), (2816, 82), (2050, 200), (4090, 82), (1971, 129)])      # rows in input blocks (N + Np - 1 > 2048)
 @pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 5e-5)])
 def test_chirpz_kernels_match_oracle_fft(N, Np, prec, tol):
     """Arbitrary N (the reference auto-sizes to e.g. 164, fast.py:176-211; odd N with numpy's asymmetric fftshift) on the
     chirp-z kernels: screens from host coefficients against the oracle's FFT-branch transform, and against the direct family."""
+    if N > 2048 and prec == "f32":
+        pytest.skip("one precision is enough for the blocked rows of the largest grids")
     ps, df = _vk_spectrum(N, 0.01, 25.0)
     rng = np.random.default_rng(N + Np)
-    cr, ci = rng.normal(size=(2, N, N)), rng.normal(size=(2, N, N))
+    nb = 2 if N <= 2048 else 1
+    cr, ci = rng.normal(size=(nb, N, N)), rng.normal(size=(nb, N, N))
     want = R.crop(R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df)), N, Np)
     for lo in ((N - Np) // 2, 0, N - Np):
         h = _lib.Handle(N, Np, prec, 0)
@@ -931,7 +935,7 @@ def test_chirpz_kernels_match_oracle_fft(N, Np, prec, tol):
     assert np.abs(got_d[0] - want_lo[0]).max() <= tol * np.abs(want).max()
 
 
-@pytest.mark.parametrize("N,Np", [(164, 82), (1002, 82), (302, 150)])
+@pytest.mark.parametrize("N,Np", [(164, 82), (1002, 82), (302, 150), (2200, 82), (2816, 140)])
 def test_chirpz_device_generator_equals_direct_family(N, Np):
     h, ps, df, W = _small_problem(N, Np)
     assert h.kernel_path() == 2
@@ -1244,7 +1248,14 @@ def test_kernel_family_notes_in_the_log(caplog):
         assert any("direct O(N^2 Np)" in r.getMessage() for r in caplog.records) == expect
         assert sim._handle.kernel_path() == {200: 3, 128: 1, 202: 2, 130: 2}[npx]
     p = params_from_json(g["params_json"])
-    p.update({"GPU_DEVICE": 0, "NPXLS": 2200, "NITER": 2, "NCHUNKS": 1})            # 2200 = 50 x 44: no family has it
+    p.update({"GPU_DEVICE": 0, "NPXLS": 2200, "NITER": 2, "NCHUNKS": 1})            # 2200 = 50 x 44: chirp-z rows in three input blocks
+    caplog.clear()
+    with caplog.at_level(logging.WARNING):
+        sim = fast_amd.Fast(p)
+    assert sim._handle.kernel_path() == 2 and not any("direct O(N^2 Np)" in r.getMessage() for r in caplog.records)
+    assert np.isfinite(sim.run()._r).all()
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_DEVICE": 0, "NPXLS": 1002, "D_GROUND": 2.6, "NITER": 2, "NCHUNKS": 1})   # a 262-pixel window outside the wave family
     caplog.clear()
     with caplog.at_level(logging.WARNING):
         sim = fast_amd.Fast(p)

@@ -227,3 +227,18 @@ def test_theta0_is_in_arcseconds_like_aotools():
     rad = 0.057 * 500e-9 ** 1.2 * np.sum(cn2 * h ** (5 / 3)) ** -0.6
     assert hostmath.isoplanatic_angle(cn2, h) == pytest.approx(rad * 206264.80624709636, rel=1e-12)
     assert 0.5 < hostmath.isoplanatic_angle(cn2, h) < 10        # arcseconds at 500 nm, not 1e-5
+
+
+def test_grid_beyond_the_kernels_limit_is_a_clear_exception():
+    """The reference has no upper limit on NPXLS (fast.py:176-211); the GPU kernels stop at 4096.  A larger grid -- explicit, or
+    auto-sized by a long TEMPORAL series (fast.py:201-206: half the total wind displacement) -- fails in the host set-up with an
+    Exception that names the limit, before any O(N^2) work and without touching the GPU."""
+    import fast_amd
+    from conftest import load_golden, params_from_json
+    p = params_from_json(load_golden("e2e_ao_alias")["params_json"])
+    with pytest.raises(Exception, match="exceeds the GPU kernels' limit of 4096"):
+        fast_amd.Fast(dict(p, NPXLS=4098))
+    q = params_from_json(load_golden("temporal_default")["params_json"])
+    q.update({"NITER": 200000, "NCHUNKS": 10, "DT": 0.01})        # 32.6 m/s x 0.01 s x 200 000 steps / 1 cm / 2 = 3.3e6 columns
+    with pytest.raises(Exception, match="limit of 4096.*TEMPORAL"):
+        fast_amd.Fast(q)

@@ -37,9 +37,7 @@ KERNELS = {
     "cols_f64_1024": "void fmc::k_cols_wave<double, 16, 2, 0, 1, 4>(",
     "rows_f32_1024": "void fmc::k_rows_wave<float, 16, 2, 0, 1, 4>(",
     "cols_f32_1024": "void fmc::k_cols_wave<float, 16, 2, 0, 1, 4>(",
-    "rows_f64_1024_8x8_six_planes": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 2>(",
-    "rows_f64_1024_all_planes": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 1>(",
-    "rows_f64_1024_12waves": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 0>(",
+    "rows_f64_1024_12waves": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 5>(",
     "rows_f64_2048": "void fmc::k_rows_wave<double, 16, 2, 0, 2, 4>(",
     "cols_f64_2048": "void fmc::k_cols_wave<double, 16, 2, 0, 2, 5>(",
 }

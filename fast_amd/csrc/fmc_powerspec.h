@@ -82,6 +82,9 @@ __device__ __forceinline__ double zernike_sq(double fabs_, double fx, double fy,
 }
 
 __global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
+  // per-wave partial row sums: [0, PS_NQ) written once after the pixel loop, [PS_NQ, PS_NQ + L) the per-layer sums, which
+  // lane 0 of each wave accumulates pixel step by pixel step (a per-thread array indexed by the layer would live in scratch
+  // memory: 576 B per lane in round 2)
   __shared__ double s_red[PS_THREADS / 64][PS_NQ + PS_MAX_LAYERS];
   const int N = A.N, L = A.L;
   const int iy = blockIdx.x;
@@ -96,10 +99,19 @@ __global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
   const double fy = (iy - N / 2.0) * df;
   const int nq = PS_NQ + L;
 
-  double q[PS_NQ + PS_MAX_LAYERS];
-  for (int i = 0; i < nq; ++i) q[i] = 0.0;
+  double q[PS_NQ];
+#pragma unroll
+  for (int i = 0; i < PS_NQ; ++i) q[i] = 0.0;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0)
+    for (int l = 0; l < L; ++l) s_red[wv][PS_NQ + l] = 0.0;
 
-  for (int ix = threadIdx.x; ix < N; ix += blockDim.x) {
+  // every lane takes part in every step (the per-layer sums are reduced over the wave inside it): lanes beyond the row
+  // repeat its last pixel with weight 0 and store nothing
+  for (int ix0 = 0; ix0 < N; ix0 += blockDim.x) {
+    const bool active = ix0 + (int)threadIdx.x < N;
+    const int ix = active ? ix0 + (int)threadIdx.x : N - 1;
+    const double wj = active ? A.w[ix] : 0.0;
     const double fx = (ix - N / 2.0) * df;
     const double fabs_ = sqrt(fx * fx + fy * fy);
     const size_t pix = (size_t)iy * N + ix;
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
       else dm = centre ? 1.0 : zernike_sq(fabs_, fx, fy, A.D_zern, A.zmax, A.noll_n, A.noll_m);
       mask = (wfs ? 1.0 : 0.0) * (dm < 1 ? dm : 1.0);
     }
-    if (A.mask_out) A.mask_out[pix] = mask;
+    if (A.mask_out && active) A.mask_out[pix] = mask;
     const double base = vk_base(fabs_, km, k0);
 
     double noise_ps = 0.0;
@@ -181,10 +193,12 @@ __global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
         if (isnan(alias)) alias = 0.0;
       }
       const double pl = c2pk2 * (turb * G + alias) + noise_ps / L;
-      if (A.per_layer) A.per_layer[(size_t)l * N * N + pix] = pl;
-      if (A.turb) A.turb[(size_t)l * N * N + pix] = turb;
-      if (A.g_ao) A.g_ao[(size_t)l * N * N + pix] = G;
-      if (A.alias_out) A.alias_out[(size_t)l * N * N + pix] = alias;
+      if (active) {
+        if (A.per_layer) A.per_layer[(size_t)l * N * N + pix] = pl;
+        if (A.turb) A.turb[(size_t)l * N * N + pix] = turb;
+        if (A.g_ao) A.g_ao[(size_t)l * N * N + pix] = G;
+        if (A.alias_out) A.alias_out[(size_t)l * N * N + pix] = alias;
+      }
       ps += pl;
       gt_sum += G * turb;
       alias_tot += alias * c2pk2;
@@ -193,12 +207,14 @@ __global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
       lal *= sn * sn;
       if (A.pfilter) lal *= A.pfilter[pix];
       la += lal;
-      q[PS_NQ + l] += A.w[ix] * pl;
+      const double wl = wave_sum(wj * pl);           // fixed-order reduction over the 64 pixels of this step
+      if (lane == 0) s_red[wv][PS_NQ + l] += wl;
     }
-    A.powerspec[pix] = ps;
-    if (A.logamp_ps) A.logamp_ps[pix] = la;
-    if (A.noise_out) A.noise_out[pix] = noise_ps;
-    const double wj = A.w[ix];
+    if (active) {
+      A.powerspec[pix] = ps;
+      if (A.logamp_ps) A.logamp_ps[pix] = la;
+      if (A.noise_out) A.noise_out[pix] = noise_ps;
+    }
     q[0] += wj * (gt_sum * mask * c2pk2);
     q[1] += wj * alias_tot;
     q[2] += wj * noise_ps;
@@ -207,10 +223,9 @@ __global__ __launch_bounds__(PS_THREADS) void k_powerspec(PsArgs A) {
     q[5] += wj * la;
   }
   // block reduction in a fixed order
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int i = 0; i < nq; ++i) {
-    double v = q[i];
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+#pragma unroll
+  for (int i = 0; i < PS_NQ; ++i) {
+    const double v = wave_sum(q[i]);
     if (lane == 0) s_red[wv][i] = v;
   }
   __syncthreads();

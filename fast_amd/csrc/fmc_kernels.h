@@ -365,6 +365,9 @@ constexpr int ROWS_PER_WAVE = 8;   // rows kernel: rows per wave (4 / 16 / 32 / 
 template <class R, int P, int NS> struct WaveCfg {
   static constexpr int WPB = (NS > 4 || (NS > 2 && NS == P)) ? 4 : (NS == 4 && P == 24) ? 6 :   // 256-pixel window tables: 6 waves fit the LDS
                               (P == 32 ? 6 : ((P > 16 && P / (P & -P) >= 7) ? 4 : (P > 24 ? 6 : ((P > 16 || (!is_pow2(P) && P > 8)) ? 8 : 12))));
+  // (rows of the small grids, P <= 8: 8 / 10 / 16 waves per workgroup = 4 / 5 / 4 per SIMD measured within 1 % of 12 at
+  // 128^2 ... 512^2: those rows are LDS-bound, not latency-bound)
+  static constexpr int WPB_ROWS = WPB;
 };
 
 // Row / column variant D (what fastmc.hip:dispatch_wave picks by window):
@@ -384,9 +387,9 @@ template <class R, int P, int NS, int D> struct WCfg {
   static_assert(D == 0 || (D == 3 && NS == 2 && P > 16) || (P == 16 && NS == 2 && D >= 4 && D <= 8) || (D == 7 && P == 16),
                 "pruned planes for NS = 2; the 16 x 4 row for P = 16");
   static_assert(WaveGeom<R, 16>::XELEMS >= D16_XELEMS, "the 16 x 4 row (D = 5) runs in the twelve-wave exchange buffer");
-  static constexpr int WPB = DENSE ? 16 : WaveCfg<R, P, NS>::WPB;
+  static constexpr int WPB = DENSE ? 16 : WaveCfg<R, P, NS>::WPB_ROWS;
   // the column kernel: sixteen waves as the rows (A/B at 1024^2: two six-wave workgroups per CU -1 %, one of eight +18 %)
-  static constexpr int WPB_COLS = WPB;
+  static constexpr int WPB_COLS = DENSE ? 16 : WaveCfg<R, P, NS>::WPB;
   static constexpr int XELEMS = DENSE ? D16_XELEMS : WaveGeom<R, P>::XELEMS;
 };
 // the plane set of a P = 16 variant
@@ -417,10 +420,13 @@ __host__ __device__ constexpr size_t wave_lds_bytes_d(int omS) {
 // the same P-per-lane pipeline, and the window outputs are combined, X[x] = sum_s w_NF^{s x} Y_s[x mod 64 P]
 // (decimation in time, evaluated only for the window).  2048 = 2 x 1024 and 4096 = 4 x 1024 run the
 // P = 16 pipeline at 3 waves per SIMD instead of a 32-values-per-lane pipeline at 2.
-template <class R, int P, int NS, int D, class Exec>
+// rows of the small grids keep their stage-2b table values in registers over the rows of a wave (fmc_wavefft.h: OMC;
+// A/B in round 3: rows -12 % at 128^2 and 256^2, -4.5 % at 512^2)
+template <int P, int NS, int S, int D> constexpr bool row_omc() { return D == 0 && S == 1 && NS == 2 && P <= 8; }
+template <class R, int P, int NS, int D, bool OMC = false, class Exec>
 __device__ __forceinline__ void wave_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* s_tw, const cpx<R>* s_om, int omS, int lo, int Np) {
   if constexpr (D >= 4) pruned_row_fft_d16r<R, NS, d16r_mask<D>()>(ex, xbuf, s_tw, s_om, omS, lo, Np);
-  else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF)>(ex, xbuf, s_tw, s_om, omS, lo, Np);
+  else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF), OMC>(ex, xbuf, s_tw, s_om, omS, lo, Np);
 }
 
 template <class R, int P, int NS, int MODE, int S = 1, int D = 0>
@@ -453,6 +459,13 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
   const int nbb = (A.nb + BPG - 1) / BPG;
   const int b0 = (blockIdx.x % nbb) * BPG;               // realisation block fastest: neighbours share amp rows
   const int row0 = (blockIdx.x / nbb) * LR;
+  constexpr bool OMC = row_omc<P, NS, S, D>();
+  if constexpr (OMC) {
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+      for (int m = 1; m < 8; ++m) regs.omc[s2][m] = s_om[m * A.omS + min(lane + WAVE * s2, A.omS - 1)];
+  }
   for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
     const int flat = rr * WPB + w;
     const int b = b0 + flat / LR;
@@ -479,7 +492,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
           regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
         }
       }
-      wave_row_fft<R, P, NS, D>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+      wave_row_fft<R, P, NS, D, OMC>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
       if (S > 1) {
 #pragma unroll
         for (int s2 = 0; s2 < NS; ++s2) {

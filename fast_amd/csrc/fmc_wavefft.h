@@ -103,6 +103,7 @@ struct LaneRegs {
   cpx<R> v[lane_regs_vn(P)];      // inputs (first P) -> stage values
   R xr[NS];      // outputs, real part       (slot s  <->  window index lane + 64 s)
   R xi[NS];      // outputs, imaginary part
+  cpx<R> omc[NS][8];   // stage-2b table values of this lane's outputs kept in registers (OMC kernels only; untouched otherwise)
 };
 
 // Tables (precomputed on the host in float64, stored as R):
@@ -135,7 +136,10 @@ FMC_HD constexpr int centre_planes(int P, int L1, int c, int W = 96) {
 }
 // B0M: planes of the exchange-2 image kept (compile time: the others are neither stored nor computed).  A run-time mask was
 // tried and bought nothing: no dead-code elimination, and the conditional stores lose their ds_write2 pairing.
-template <class R, int P, int NS, int B0M = 0xFF, class Exec>
+// OMC: the stage-2b table values om[m][oi] of this lane's outputs come from r.omc (loaded once by the caller and kept over
+// all the rows of a wave) instead of the LDS: on the small grids (P <= 8) those 28 ds_read_b128 per row were a third of the
+// LDS time of a row that is LDS-bound (256^2: 91 LDS instructions per 256-point row against 83 per 1024-point row).
+template <class R, int P, int NS, int B0M = 0xFF, bool OMC = false, class Exec>
 FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om,
                            int omS, int lo, int Np, int osign = 0) {
   using G = WaveGeom<R, P>;
@@ -257,7 +261,7 @@ FMC_HD void pruned_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
             } else {
             X::first(r.xr[s], r.xi[s], ex.ld(f), c);
 #pragma unroll
-            for (int m = 1; m < 8; ++m) X::acc(r.xr[s], r.xi[s], om[m * omS + oi], ex.ld(f + G::FL * m), c);
+            for (int m = 1; m < 8; ++m) X::acc(r.xr[s], r.xi[s], OMC ? r.omc[s][m] : om[m * omS + oi], ex.ld(f + G::FL * m), c);
             }
             if (c == NC - 1 && osign >= 0) {
               const bool neg = ((x ^ osign) & 1) != 0;

@@ -104,12 +104,17 @@ if len(sys.argv) > 2:
                                   ("lds_issue_busy", "pmc_sq2", "SQ_ACTIVE_INST_LDS")):
             v = _avg(sub, counter, "k_rows_wave")
             if v:
-                raw = v * 4 / simd_cycles        # SQ_ACTIVE_INST_* count quad-cycles
-                doc[key] = min(raw, 1.0)         # a fraction of the SIMD cycles; the counter ratio itself is kept beside it
-                doc[key + "_counter_ratio"] = raw
-        doc["busy_note"] = ("k_rows_wave: SQ_ACTIVE_INST_* x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); the two counters come from the same "
-                            "pass, the denominator assumes every SIMD clocked for the whole GUI-active time: a ratio of 1.00-1.02 means "
-                            "the SIMDs issued in every cycle they had (reported as 1.0)")
+                doc[key + "_counter_ratio"] = v * 4 / simd_cycles        # SQ_ACTIVE_INST_* count quad-cycles; NOT clamped
+        # An any-instruction ratio above 1 cannot be a utilisation: it says the denominator (GRBM_GUI_ACTIVE / 8 x 1024 SIMD-cycles)
+        # is that much too short.  Dividing the class ratios by it gives upper bounds of the true busy fractions.
+        any_ratio = doc.get("issue_busy_counter_ratio")
+        short_by = max(any_ratio, 1.0) if any_ratio else 1.0
+        for key in ("valu_busy", "issue_busy", "lds_issue_busy"):
+            if key + "_counter_ratio" in doc:
+                doc[key] = doc[key + "_counter_ratio"] / short_by
+        doc["busy_note"] = ("k_rows_wave: *_counter_ratio = SQ_ACTIVE_INST_* x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), unclamped; an "
+                            "any-instruction ratio above 1 means the denominator is that much too short, so valu_busy / issue_busy / "
+                            "lds_issue_busy are the counter ratios divided by max(1, any-instruction ratio): upper bounds of the true fractions")
         doc["clock_GHz_profiled"] = grbm / 8 / (doc["rows"]["avg_launch_ms"] * 1e-3) / 1e9 if doc["rows"]["avg_launch_ms"] else None
     try:       # launch size of the profiled command: the per-launch byte counts scale with it
         line = json.loads(open(os.path.join(out, "bench_line_under_rocprof.json")).read())

@@ -330,7 +330,8 @@ def roofline(args, N, Np, tim, steps, workers, iters_per_worker_step):
             tb, rpl = prof.get("rows", {}).get("hbm_bytes_per_launch"), prof.get("realisations_per_launch")
             # counter bytes of the profiled launches, scaled to this run's launch size (bytes are per realisation)
             out["traffic"] = tb * real_per_launch / rpl if (tb and rpl) else tb
-            out["counters"] = {k: prof[k] for k in ("valu_busy", "issue_busy", "lds_issue_busy", "source") if k in prof}
+            out["counters"] = {k: prof[k] for k in ("valu_busy", "issue_busy", "lds_issue_busy", "valu_busy_counter_ratio", "issue_busy_counter_ratio",
+                                                    "lds_issue_busy_counter_ratio", "busy_note", "clock_GHz_profiled", "source") if k in prof}
         else:
             out["counters"] = {"stale": f"{prof.get('source')} belongs to a build with {prof.get('rows_valu_instructions_per_row')} "
                                         f"VALU instructions per row, this build has {st['valu_total']}"}

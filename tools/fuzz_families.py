@@ -16,10 +16,14 @@ for c in range(cases):
         N = int(rng.choice([s for s in host.WAVE_FFT_SIZES if s < 2048]))
     if c % 2:                                           # every other case: a size that is not 64 P -> chirp-z family
         N = int(rng.integers(8, 1500))
+    if c % 16 == 5:                                     # now and then a grid beyond one chirp-z transform: rows in input blocks
+        N = int(rng.integers(1968, 4096))
     if c % 4 == 3:                                      # every fourth: N = 50 P -> 50-lane family
         N = int(rng.choice([100, 150, 200, 250, 300, 350, 400, 450, 500, 600, 700, 800, 900, 1000, 1200, 1350, 1400, 1500, 1600, 1750, 1800, 2000,
                           1344, 1728, 1920, 2304, 2560]))
     Np = int(rng.integers(1, min(N, 300 if c % 2 == 0 else 256) + 1))
+    if N > 2048 and c % 16 == 5:
+        Np = int(rng.integers(1, 200))
     lo = int(rng.choice([0, N - Np, (N - Np) // 2, rng.integers(0, N - Np + 1)]))
     prec = "f64" if rng.random() < 0.7 else "f32"
     tol = 1e-10 if prec == "f64" else 1e-4

@@ -298,8 +298,74 @@ static int sweep_mr(const char* name, double tol) {
   return bad;
 }
 
+
+// Packed rows of fmc_wavefft.h (N = 256: four rows per wave, N = 512: two): every row of the wave against the naive DFT.
+template <class R, int L0, int NSL, int B0M>
+static double run_pk_case(int lo, int Np, unsigned seed) {
+  constexpr int L = 16 * L0, N = 16 * L, G = WAVE / L;
+  using E = typename Xch<R>::E;
+  std::mt19937_64 gen(seed);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  std::vector<double> inr(G * N), ini(G * N);
+  for (auto& v : inr) v = nd(gen);
+  for (auto& v : ini) v = nd(gen);
+  const int omS = (Np + 7) & ~7;
+  std::vector<cpx<R>> tw1((size_t)16 * L), om((size_t)2 * omS);
+  build_tw1_pk<R>(tw1.data(), L, cs_turns);
+  build_om_pk<R>(om.data(), omS, L, lo, Np, cs_turns);
+  std::vector<E> xbuf(D16_XELEMS);
+  static HostExec<R, 16, NSL> ex;
+  for (int l = 0; l < WAVE; ++l)
+    for (int j = 0; j < 16; ++j) {
+      const int g = l / L, k = l % L + L * j;
+      const double sg = (k & 1) ? -1.0 : 1.0;
+      ex.regs[l].v[j] = mk<R>((R)(sg * inr[g * N + k]), (R)(sg * ini[g * N + k]));
+    }
+  packed_row_fft<R, L0, NSL, B0M>(ex, xbuf.data(), tw1.data(), om.data(), omS, lo, Np);
+  std::vector<double> gr((size_t)G * Np, 1e300), gi((size_t)G * Np, 1e300);
+  for (int l = 0; l < WAVE; ++l)
+    packed_outputs<R, L0, NSL, B0M>(l, ex.regs[l], lo, Np, [&](int oi, R re, R im) { gr[(l / L) * Np + oi] = re; gi[(l / L) * Np + oi] = im; });
+  double worst = 0.0, scale = 0.0;
+  const int h = N / 2;
+  for (int g = 0; g < G; ++g)
+    for (int oi = 0; oi < Np; ++oi) {
+      const int p = lo + oi;
+      long double sr = 0, si = 0;
+      for (int k = 0; k < N; ++k) {
+        const long long e = (((long long)(p - h) * (k + h)) % N + N) % N;
+        const long double a = -2.0L * M_PIl * (long double)e / N;
+        const long double c = cosl(a), s = sinl(a);
+        sr += inr[g * N + k] * c - ini[g * N + k] * s;
+        si += inr[g * N + k] * s + ini[g * N + k] * c;
+      }
+      worst = std::fmax(worst, std::fmax(std::fabs(gr[g * Np + oi] - (double)sr), std::fabs(gi[g * Np + oi] - (double)si)));
+      scale = std::fmax(scale, std::fmax(std::fabs((double)sr), std::fabs((double)si)));
+    }
+  return worst / scale;
+}
+template <class R, int L0>
+static int sweep_pk(const char* name, double tol) {
+  constexpr int N = 256 * L0, NSC = 96 / (16 * L0), NSA = 256 / (16 * L0);
+  int bad = 0;
+  auto report = [&](const char* what, int lo, int Np, double err) {
+    const bool ok = err <= tol;
+    std::printf("%s packed N=%d %s lo=%d Np=%d relerr=%.3e %s\n", name, N, what, lo, Np, err, ok ? "ok" : "FAIL");
+    bad += !ok;
+  };
+  for (int Np : {82, 96, 23, 1, 64, 95})       // centred windows: six planes
+    for (int lo : {(N - Np) / 2, (N - Np) / 2 + (Np < 90 ? 3 : 0)})
+      report("centred planes", lo, Np, run_pk_case<R, L0, NSC, pk_centre_mask<L0>()>(lo, Np, 4321u + Np + lo));
+  const int cases[][2] = {{(N - 82) / 2, 82}, {0, 256}, {N - 5, 5}, {5, 250}, {(N - 128) / 2, 128}, {N - 256, 256}, {3, 97}, {N / 2 - 100, 201}};
+  for (auto& c : cases) report("all planes", c[0], c[1], run_pk_case<R, L0, NSA, 0xFFFF>(c[0], c[1], 99u + c[0] + c[1]));
+  return bad;
+}
+
 int main() {
   int bad = 0;
+  bad += sweep_pk<double, 1>("f64", 1e-13);
+  bad += sweep_pk<double, 2>("f64", 1e-13);
+  bad += sweep_pk<float, 1>("f32", 2e-5);
+  bad += sweep_pk<float, 2>("f32", 2e-5);
   bad += sweep_mr<double, 2, 2>("f64", 1e-13);
   bad += sweep_mr<double, 3, 2>("f64", 1e-13);
   bad += sweep_mr<double, 4, 2>("f64", 1e-13);

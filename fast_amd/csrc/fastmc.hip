@@ -99,6 +99,8 @@ struct fastmc_ctx {
   void* mr_om = nullptr;
   void* tw1g = nullptr;    // N = 2048 only: tables of the single-pass P = 32 kernels (windows > 256 pixels,
   void* omg = nullptr;     //   host coefficients: TEMPORAL layer screens, centred_fft2)
+  void* pk_tw1 = nullptr;  // N = 256, 512: tables of the packed rows (fmc_wavefft.h: build_tw1_pk / build_om_pk)
+  void* pk_om = nullptr;
   double* W = nullptr;
   void* V = nullptr;
   size_t V_cap = 0;        // realisations
@@ -475,7 +477,7 @@ static void destroy_now(fastmc_ctx* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
-  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers, h->ps_dev};
   for (void* p : ptrs)
@@ -534,7 +536,8 @@ static int default_batch(const fastmc_ctx* h) {
     int ns = 0, wpb = 1;
     if (h->rsz == 8) wave_config<double>(h, &ns, &wpb); else wave_config<float>(h, &ns, &wpb);
     if (h->P == 16 && ns == 2 && h->S == 1 && !h->no_dense && (h->rsz == 8 ? dense16r_fits<double>(h) : dense16r_fits<float>(h))) wpb = 16;
-    const int quantum = std::max(1, 256 * wpb * ROWS_PER_WAVE / h->N);
+    int quantum = std::max(1, 256 * wpb * ROWS_PER_WAVE / h->N);
+    if (pk_grid(h->N)) quantum = h->N == 256 ? 256 * PkCfg<double, 1, 0>::WPB * ROWS_PER_WAVE * 4 / 256 : 256 * PkCfg<double, 2, 0>::WPB * ROWS_PER_WAVE * 2 / 512;
     if (b >= quantum) b -= b % quantum;
   } else if (b >= 8) {
     b &= ~7;
@@ -642,7 +645,27 @@ static int upload_wave_tables(fastmc_ctx* h) {
     TRY(upload_table<R>(&h->tw1g, tw1g));
     TRY(upload_table<R>(&h->omg, omg));
   }
+  if (pk_grid(h->N)) {
+    const int L = h->N / 16;
+    std::vector<cpx<R>> tw((size_t)16 * L), omp((size_t)2 * h->omS);
+    build_tw1_pk<R>(tw.data(), L, cs_turns);
+    build_om_pk<R>(omp.data(), h->omS, L, h->lo, h->Np, cs_turns);
+    TRY(upload_table<R>(&h->pk_tw1, tw));
+    TRY(upload_table<R>(&h->pk_om, omp));
+  }
   return 0;
+}
+
+// Which packed-row variant serves this handle's window (fmc_kernels.h: PkCfg): 0 six centred planes, 1 all planes, -1 none
+// (a window of more than 256 pixels at N = 512: host coefficients go to the one-row-per-wave kernels, device draws to the
+// direct family -- the P = 4 / 8 rows of fmc_wavefft.h do not know the 16 / 32-stream generator layout of these grids).
+template <class R>
+static int pk_variant(const fastmc_ctx* h) {
+  if (!pk_grid(h->N) || h->path != 1) return -1;
+  const int centre = h->N == 256 ? pk_centre_mask<1>() : pk_centre_mask<2>();
+  if (h->Np <= 96 && (window_planes(h->lo, h->Np, 16, 16) & ~centre) == 0) return 0;
+  if (h->Np <= 256) return 1;     // tables + sixteen exchange buffers fit the LDS for every such window
+  return -1;
 }
 
 template <class R>
@@ -798,7 +821,10 @@ template <class R, int P, int NS, int S, int DR, int DC = DR>
 static void launch_wave_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   {
     Span s(h, 0);
-    if (mode == 0) launch_rows_wave<R, P, NS, 0, S, DR>(h, RA);
+    // 256 / 512 draw 16 / 32 streams per row (fmc_core.h: stream_lanes): their device-generator rows are the packed kernels
+    // (dispatch_pk) or the direct family, never the one-row-per-wave kernels, so MODE 0 is not instantiated for them
+    if constexpr (S == 1 && pk_grid(64 * P)) launch_rows_wave<R, P, NS, 1, S, DR>(h, RA);
+    else if (mode == 0) launch_rows_wave<R, P, NS, 0, S, DR>(h, RA);
     else launch_rows_wave<R, P, NS, 1, S, DR>(h, RA);
   }
   {
@@ -847,6 +873,44 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
     }
     launch_wave_pair<R, P, NS, S, 0>(h, RA, CA, mode, epi);
   }
+}
+
+// Packed rows / columns of the 256 and 512 grids (fmc_kernels.h: k_rows_pk / k_cols_pk), variant by window (pk_variant).
+template <class R, int L0, int D>
+static void launch_pk_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  using C = PkCfg<R, L0, D>;
+  const size_t lds = pk_lds_bytes<R, L0>(RA.omS, C::WPB), ldc = pk_lds_bytes<R, L0>(RA.omS, C::WPC);
+  constexpr int LR = 128 / (int)sizeof(cpx<R>), LU = LR / C::G, BPG = ROWS_PER_WAVE * C::WPB / LU;
+  const int blocks = (C::N / LR) * ((RA.nb + BPG - 1) / BPG);
+  {
+    Span s(h, 0);
+    if (mode == 0) {
+      hipFuncSetAttribute((const void*)k_rows_pk<R, L0, 0, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_pk<R, L0, 0, D>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, RA);
+    } else {
+      hipFuncSetAttribute((const void*)k_rows_pk<R, L0, 1, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((k_rows_pk<R, L0, 1, D>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, RA);
+    }
+  }
+  {
+    Span s(h, 1);
+    const int items = CA.nb * ((CA.Np + C::G - 1) / C::G), per = C::WPC * C::IPW;
+    if (epi == 0) {
+      hipFuncSetAttribute((const void*)k_cols_pk<R, L0, 0, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
+      hipLaunchKernelGGL((k_cols_pk<R, L0, 0, D>), dim3((items + per - 1) / per), dim3(C::WPC * 64), ldc, h->stream, CA);
+    } else {
+      hipFuncSetAttribute((const void*)k_cols_pk<R, L0, 1, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
+      hipLaunchKernelGGL((k_cols_pk<R, L0, 1, D>), dim3((items + per - 1) / per), dim3(C::WPC * 64), ldc, h->stream, CA);
+    }
+  }
+}
+template <class R>
+int dispatch_pk(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+  const int v = pk_variant<R>(h);
+  if (v < 0) return fail(FASTMC_ESTATE, "no packed-row kernel for this window");
+  if (h->N == 256) { if (v == 0) launch_pk_pair<R, 1, 0>(h, RA, CA, mode, epi); else launch_pk_pair<R, 1, 1>(h, RA, CA, mode, epi); }
+  else             { if (v == 0) launch_pk_pair<R, 2, 0>(h, RA, CA, mode, epi); else launch_pk_pair<R, 2, 1>(h, RA, CA, mode, epi); }
+  return 0;
 }
 
 template <class R, int P, int NS, bool BLK = false>
@@ -1094,6 +1158,7 @@ int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA
 // run-time-split grids run the float64 kernels whatever precision was asked for (fastmc_create).
 //   1 / 2 / 3: wave family float64, parts 0 / 1 / 2        4 / 5 / 6: wave family float32, parts 0 / 1 / 2
 //   7: chirp-z float64, direct float64 and float32          8: 50-lane P <= 9 and run-time-split, float64     9: 50-lane P >= 10
+//   10: packed rows of the 256 / 512 grids, both precisions
 #if defined(FMC_SPLIT_BUILD) || FMC_TU != 0
 // declared `extern` in every unit but the one that defines it
 #if FMC_TU != 1
@@ -1126,6 +1191,10 @@ extern template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
 #if FMC_TU != 9
 extern template int dispatch_mr_part<double, 1>(FMC_FAMILY_SIG(double));
 #endif
+#if FMC_TU != 10
+extern template int dispatch_pk<double>(FMC_FAMILY_SIG(double));
+extern template int dispatch_pk<float>(FMC_FAMILY_SIG(float));
+#endif
 #endif
 #if FMC_TU == 1
 template int dispatch_wave_part<double, 0>(FMC_WAVE_SIG(double));
@@ -1144,6 +1213,11 @@ template int dispatch_mr_part<double, 0>(FMC_FAMILY_SIG(double));
 template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
 #elif FMC_TU == 9
 template int dispatch_mr_part<double, 1>(FMC_FAMILY_SIG(double));
+#elif FMC_TU == 10
+template int dispatch_pk<double>(FMC_FAMILY_SIG(double));
+#ifndef FMC_ONLY_F64
+template int dispatch_pk<float>(FMC_FAMILY_SIG(float));
+#endif
 #elif !defined(FMC_ONLY_F64)
 #if FMC_TU == 4
 template int dispatch_wave_part<float, 0>(FMC_WAVE_SIG(float));
@@ -1293,8 +1367,13 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
         if (h->mr_P <= 9) { TRY((dispatch_mr_part<R, 0>(h, RA, CA, kmode, S.epi))); }
         else { TRY((dispatch_mr_part<R, 1>(h, RA, CA, kmode, S.epi))); }
       } else return fail(FASTMC_ESTATE, "50-lane grids run the float64 kernels (fastmc_create)");
+    } else if (pk_variant<R>(h) >= 0) {
+      RA.amp = (const R*)h->amp_s; RA.ampf = h->ampf_s; RA.tw = (const cpx<R>*)h->pk_tw1; RA.om = (const cpx<R>*)h->pk_om;
+      RA.cw = nullptr; RA.tw_global = 0;
+      CA.tw = RA.tw; CA.om = RA.om; CA.cw = nullptr; CA.tw_global = 0;
+      TRY(dispatch_pk<R>(h, RA, CA, kmode, S.epi));
     } else {
-    bool wave_ok = h->path == 1;
+    bool wave_ok = h->path == 1 && !(pk_grid(h->N) && kmode == 0);    // packed grids beyond the packed windows: see pk_variant
     bool general_2048 = false;   // N = 2048, window > 256 pixels, host coefficients: single-pass P = 32 kernels
     if (wave_ok) {
       int ns, wpb_unused;

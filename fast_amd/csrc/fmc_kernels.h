@@ -579,6 +579,207 @@ void k_cols_wave(ColArgs<R> A) {
   column_epilogue<R, NS, EPI>(A.sh, A.W, A.partial, A.phs, A.nb, A.Np, b, xi, lane, regs.xr, regs.xi);
 }
 
+// ================================================================== packed rows: N = 256 (L0 = 1), 512 (L0 = 2)
+// G = 4 / L0 rows (columns) per wavefront on the sixteen-values-per-lane pipeline of the 1024-point row (fmc_wavefft.h:
+// packed_row_fft).  Generator: L = 16 L0 streams per row, stream q = kx mod L, sixteen advances each (fmc_core.h:
+// stream_lanes) -- ONE Philox block per lane and G rows.  D 0: the six planes of a centred window of up to 96 pixels; D 1: all
+// sixteen planes, any window of up to 256 pixels.  Sixteen waves per workgroup.
+template <class R, int L0, int D> struct PkCfg {
+  static constexpr int L = 16 * L0, G = WAVE / L, N = 16 * L;
+  static constexpr int B0M = D == 0 ? pk_centre_mask<L0>() : 0xFFFF;
+  static constexpr int NSL = (D == 0 ? 96 : 256) / L;      // output slots of L lanes (read for L0 = 2 only)
+  static constexpr int WMAX = D == 0 ? 96 : 256;           // widest window
+#ifdef FMC_PK_WPB_ALL
+  static constexpr int WPB = FMC_PK_WPB_ALL;
+#else
+  static constexpr int WPB = (L0 == 1 || D == 1) ? 12 : 16;
+#endif
+#ifdef FMC_PK_RMINB
+  static constexpr int RMINB = FMC_PK_RMINB;
+#else
+  static constexpr int RMINB = 1;
+#endif
+  // column kernel: waves per workgroup, workgroups per CU the register budget is cut for, items (groups of G columns) per wave
+#ifdef FMC_PK_WPC
+  static constexpr int WPC = FMC_PK_WPC;
+#else
+  // D = 0: the rolled detector loop fits four waves per SIMD, and two eight-wave workgroups per CU overlap one group's
+  // start-up (table copy, barrier, first loads) with the other's arithmetic: columns -9 % at 256^2, -8 % at 512^2 against
+  // one sixteen-wave workgroup (A/B on one box)
+  static constexpr int WPC = D == 0 ? 8 : WPB;
+#endif
+#ifdef FMC_PK_CMINB
+  static constexpr int CMINB = FMC_PK_CMINB;
+#else
+  static constexpr int CMINB = D == 0 ? 4 : 1;             // waves per SIMD the register budget is cut for
+#endif
+#ifdef FMC_PK_IPW
+  static constexpr int IPW = FMC_PK_IPW;
+#else
+  static constexpr int IPW = 1;
+#endif
+  static constexpr int OM_ROWS = L0 == 2 ? 2 : 0;
+};
+// LDS carve (dynamic): [tw1 16 L cpx][om OM_ROWS omS cpx][xbuf wpb * D16_XELEMS 8-byte]
+template <class R, int L0>
+__host__ __device__ constexpr size_t pk_lds_bytes(int omS, int wpb) {
+  return (size_t)(16 * 16 * L0 + (L0 == 2 ? 2 : 0) * omS) * sizeof(cpx<R>) + (size_t)wpb * D16_XELEMS * 8;
+}
+template <class R, int L0>
+__device__ __forceinline__ void pk_load_tables(cpx<R>* s_tw, cpx<R>* s_om, const cpx<R>* tw, const cpx<R>* om, int omS) {
+  for (int i = threadIdx.x; i < 16 * 16 * L0; i += blockDim.x) s_tw[i] = tw[i];
+  if (L0 == 2)
+    for (int i = threadIdx.x; i < 2 * omS; i += blockDim.x) s_om[i] = om[i];
+  __syncthreads();
+}
+
+template <class R, int L0, int MODE, int D>
+__global__ __launch_bounds__((PkCfg<R, L0, D>::WPB * 64), (PkCfg<R, L0, D>::RMINB)) void k_rows_pk(RowArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using C = PkCfg<R, L0, D>;
+  using E = typename Xch<R>::E;
+  constexpr int L = C::L, G = C::G, N = C::N, WPB = C::WPB;
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  cpx<R>* s_om = s_tw + 16 * L;
+  E* s_x = reinterpret_cast<E*>(s_om + C::OM_ROWS * A.omS);
+  pk_load_tables<R, L0>(s_tw, s_om, A.tw, A.om, A.omS);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  E* xbuf = s_x + w * D16_XELEMS;
+  LaneRegs<R, 16, C::NSL> regs;
+  GpuExec<R, 16, C::NSL> ex{lane, regs};
+  // tile walk as in k_rows_wave, in units of G rows: a workgroup owns the LR rows of one 128-byte line of every V column
+  // (LR / G units) for ROWS_PER_WAVE * WPB * G / LR consecutive realisations
+  constexpr int LR = 128 / (int)sizeof(cpx<R>), LU = LR / G;
+  static_assert(LR % G == 0 && (ROWS_PER_WAVE * WPB) % LU == 0, "tile must hold whole lines");
+  constexpr int BPG = ROWS_PER_WAVE * WPB / LU;
+  const int nbb = (A.nb + BPG - 1) / BPG;
+  const int b0 = (blockIdx.x % nbb) * BPG;
+  const int row0 = (blockIdx.x / nbb) * LR;
+  const int q = lane & (L - 1), gl = lane / L;
+  const int lane_in = gl * N + q;                        // this lane's first input of the G rows of a unit (rows are contiguous)
+  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+    const int flat = rr * WPB + w;
+    const int b = b0 + flat / LU;
+    if (b >= A.nb) break;                                // wave-uniform
+    const int ky0 = row0 + (flat % LU) * G;              // wave-uniform: scalar bases, lane offsets
+    const uint64_t g = A.g0 + (uint64_t)b;
+    if (MODE == 0) {
+      const float* ampf = A.ampf + (size_t)ky0 * N;
+      xoshiro128p rs = row_stream(A.key, g, ky0 + gl, q, L);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[lane_in + L * j]);
+    } else {
+      const R* amp = A.amp + (size_t)ky0 * N;
+      const size_t base = ((size_t)b * N + ky0) * N;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        regs.v[j] = cscale(mk<R>((R)A.cre[base + lane_in + L * j], (R)A.cim[base + lane_in + L * j]), amp[lane_in + L * j]);
+    }
+    packed_row_fft<R, L0, C::NSL, C::B0M>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    cpx<R>* out = A.V + (size_t)b * A.Np * N + ky0;      // V[b][oi][ky]
+    packed_outputs<R, L0, C::NSL, C::B0M>(lane, regs, A.lo, A.Np,
+                                          [&](int oi, R re, R im) { out[(uint32_t)(oi * N + gl)] = mk<R>(re, im); });   // scalar base + 32-bit lane offset
+  }
+}
+
+// G window columns per wavefront; the detector sums of a column are reduced over the L lanes of its group (DPP inside the
+// 16-lane rows, v_readlane across them: a fixed order).
+template <class R, int L0, int EPI, int D>
+__global__ __launch_bounds__((PkCfg<R, L0, D>::WPC * 64), (PkCfg<R, L0, D>::CMINB)) void k_cols_pk(ColArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using C = PkCfg<R, L0, D>;
+  using E = typename Xch<R>::E;
+  constexpr int L = C::L, G = C::G, N = C::N, WPC = C::WPC;
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  cpx<R>* s_om = s_tw + 16 * L;
+  E* s_x = reinterpret_cast<E*>(s_om + C::OM_ROWS * A.omS);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  E* xbuf = s_x + w * D16_XELEMS;
+  const int q = lane & (L - 1), gl = lane / L;
+  LaneRegs<R, 16, C::NSL> regs;
+  GpuExec<R, 16, C::NSL> ex{lane, regs};
+  pk_load_tables<R, L0>(s_tw, s_om, A.tw, A.om, A.omS);
+  // work item = (realisation b, group of G window columns), group fastest; the waves of a workgroup take neighbouring items
+  const int ngrp = (A.Np + G - 1) / G;
+#pragma unroll 1
+  for (int it = 0; it < C::IPW; ++it) {
+    const int item = (blockIdx.x * C::IPW + it) * WPC + w;
+    if (item >= A.nb * ngrp) break;                        // wave-uniform; no block barrier follows
+    const int b = item / ngrp;
+    const int xi = (item % ngrp) * G + gl;
+    const bool live = xi < A.Np;                           // the last group of a realisation may be short
+    const cpx<R>* col = A.V + ((size_t)b * A.Np + (item % ngrp) * G) * N;
+    const uint32_t lane_in = (live ? gl : 0) * N + q;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) regs.v[j] = col[lane_in + L * j];
+    packed_row_fft<R, L0, C::NSL, C::B0M>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    auto pixel = [&](int yi, R p1, R p2) {
+      pixel_phase<R>(A.sh, b, A.Np, yi, xi, p1, p2);
+      if (EPI == 1) {
+        const size_t plane = (size_t)A.Np * A.Np;
+        A.phs[((size_t)b) * plane + (size_t)yi * A.Np + xi] = (double)p1;
+        A.phs[((size_t)(A.nb + b)) * plane + (size_t)yi * A.Np + xi] = (double)p2;
+      } else {
+        const double wgt = A.W[(size_t)yi * A.Np + xi];
+        double s1, c1, s2, c2;
+        sincos_r(p1, s1, c1);
+        sincos_r(p2, s2, c2);
+        acc[0] += wgt * c1; acc[1] += wgt * s1; acc[2] += wgt * c2; acc[3] += wgt * s2;
+      }
+    };
+    if constexpr (D == 0) {
+      // the (at most six / three) outputs of a lane go through its own slots of the exchange buffer and the detector is a
+      // rolled loop over them: a sixth of the code of the unrolled form (two inlined sincos instead of twelve) and its
+      // registers -- the column kernel of the small grids is bound by the start-up of its short-lived waves, not by arithmetic
+      constexpr int NOUT = L0 == 1 ? popcount16(C::B0M) : C::NSL, FIRST = L0 == 1 ? 5 : 0;
+      static_assert(L0 != 1 || C::B0M == (((1 << NOUT) - 1) << FIRST), "contiguous planes");
+      cpx<R>* ob = reinterpret_cast<cpx<R>*>(xbuf) + lane;
+#pragma unroll
+      for (int p = 0; p < NOUT; ++p) ob[WAVE * p] = L0 == 1 ? regs.v[(FIRST + p) & 15] : mk<R>(regs.xr[p % C::NSL], regs.xi[p % C::NSL]);
+      ex.sync();
+      const int y0 = L0 == 1 ? (lane & 15) + 16 * FIRST - A.lo : q;
+#pragma unroll 1
+      for (int p = 0; p < NOUT; ++p) {
+        const int yi = y0 + L * p;
+        if (live && yi >= 0 && yi < A.Np) {
+          const cpx<R> v = ob[WAVE * p];
+          pixel(yi, v.x, v.y);
+        }
+      }
+      ex.sync();
+    } else {
+      packed_outputs<R, L0, C::NSL, C::B0M>(lane, regs, A.lo, A.Np, [&](int yi, R p1, R p2) { if (live) pixel(yi, p1, p2); });
+    }
+    if (EPI == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double v = acc[k];
+        v += dpp_copy<0xB1>(v);     // quad_perm [1,0,3,2]
+        v += dpp_copy<0x4E>(v);     // quad_perm [2,3,0,1]
+        v += dpp_copy<0x141>(v);    // row_half_mirror
+        v += dpp_copy<0x140>(v);    // row_mirror: every lane holds the sum of its 16-lane row
+        if (L0 == 2) {
+          const long long bits = __double_as_longlong(v);
+          const int lo32 = (int)(bits & 0xffffffffll), hi32 = (int)(bits >> 32);
+          double r[4];
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2) {
+            const int l2 = __builtin_amdgcn_readlane(lo32, 16 * k2), h2 = __builtin_amdgcn_readlane(hi32, 16 * k2);
+            r[k2] = __longlong_as_double(((long long)h2 << 32) | (unsigned int)l2);
+          }
+          v = gl ? r[2] + r[3] : r[0] + r[1];
+        }
+        acc[k] = v;
+      }
+      if (q == 0 && live) {
+        double* o = A.partial + ((size_t)b * A.Np + xi) * 4;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+      }
+    }
+  }
+}
+
 // ================================================================== chirp-z family (any N with 64 P >= N + Np - 1)
 // The row / column passes of the wave family for grid sizes that are not 64 P: every 1-D transform is a chirp-z
 // (Bluestein) transform on the same pipeline (fmc_bluestein.h), window outputs only.  Same generator streams as the

@@ -417,6 +417,177 @@ FMC_HD void pruned_row_fft_d16r(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>
   }
 }
 
+// ---------------------------------------------------------------- N = 256, 512: 4 / 2 rows per wavefront
+// The 16 x 16 x L0 factorisation above with L0 = 1 (N = 256) or 2 (N = 512) leaves lanes idle if one wave transforms one
+// row, and the P x 8 x 8 row at P = 4 / 8 is LDS-bound (a 256-point row costs 56 % of a 1024-point row).  Here a wavefront
+// transforms G = 4 / L0 rows AT ONCE: lane = g L + q (row g of the wave's G, q < L = 16 L0) holds c[q + L j], j < 16, of
+// its row, and the pipeline is the one of pruned_row_fft_d16r inside every group of L lanes:
+//   Z_q[a] = sum_j c[q + L j] w_16^{ja},  T_q[a] = w_N^{qa} Z_q[a]               (stage 1, radix 16 in registers)
+//   exchange 1 inside the group: lane (a = q & 15, l0 = q >> 4) collects T_{l0 + L0 l1}[a], l1 < 16
+//   U[a][l0][b0] = sum_l1 w_16^{l1 b0} T_{l0 + L0 l1}[a]                         (stage 2, ONE radix-16 butterfly per lane)
+//   X[a + 16 b] = sum_{l0 < L0} w_L^{l0 b} U[a][l0][b mod 16]                     (L0 = 1: nothing left to do)
+// L0 = 1: the lane's outputs are its planes, x = a + 16 b0, left in r.v[b0] (natural order, output-side fftshift sign
+// applied); L0 = 2: exchange 2 and two-term sums into output slots, oi = q + 32 s (r.xr / r.xi).  Exchange-1 image as in
+// the 1024-point row (SE a + lane) with SE = 65 for L0 = 1 (66 would put rows g and g + 2 on the same banks: tools/
+// lds_bank_check.py) and 66 for L0 = 2: conflict-free writes and reads.
+// B0M: planes b0 kept.  A centred window of up to 96 pixels touches six: {5, ..., 10} at N = 256 (centre block 8), {13, 14,
+// 15, 0, 1, 2} at N = 512 (centre block 16 = 0 mod 16).
+template <int L0> constexpr int PK_SE = (L0 == 1) ? 65 : 66;
+template <int L0> constexpr int pk_centre_mask() { return centre_planes(16, 16, (8 * L0) & 15); }
+static_assert(pk_centre_mask<1>() == 0x07E0 && pk_centre_mask<2>() == D16R_CENTRE_MASK, "planes {5 ... 10} / {13 ... 2}");
+template <class R, int L0, int NSL, int B0M = 0xFFFF, class Exec>
+FMC_HD void packed_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om, int omS, int lo, int Np) {
+  static_assert(L0 == 1 || L0 == 2, "N = 256 or 512");
+  constexpr int P = 16, L = 16 * L0, SE = PK_SE<L0>;
+  using X = Xch<R>;
+  using E = typename X::E;
+  constexpr int NC = X::NC;
+  ex.each([&](int lane, LaneRegs<R, P, NSL>& r) {
+    cpx<R> z[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) z[j] = r.v[j];
+    dft_reg<P, R>(z);
+    r.v[0] = z[0];
+#pragma unroll
+    for (int a = 1; a < P; ++a) r.v[a] = cmul(z[a], tw1[a * L + (lane & (L - 1))]);      // the G groups read the same entries
+  });
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    ex.each([&](int lane, LaneRegs<R, P, NSL>& r) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) ex.st(xbuf + a * SE + lane, X::pack(r.v[a], c));
+    });
+    ex.sync();
+    ex.each([&](int lane, LaneRegs<R, P, NSL>& r) {
+      const int q = lane & (L - 1), a = q & 15, l0 = q >> 4;
+      const E* e = xbuf + a * SE + (lane - q) + l0;
+#pragma unroll
+      for (int l1 = 0; l1 < 16; ++l1) X::unpack(r.v[l1], ex.ld(e + L0 * l1), c);
+    });
+    ex.sync();
+  }
+  ex.each([&](int lane, LaneRegs<R, P, NSL>& r) {
+    cpx<R> t[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) t[m] = r.v[m];
+    fft_dif<16, R>(t);
+    const bool neg = (lane & 1) != 0;            // L0 = 1: x = a + 16 b0 has the parity of the lane
+#pragma unroll
+    for (int b0 = 0; b0 < 16; ++b0) {
+      r.v[b0] = t[brev(b0, 4)];
+      if (L0 == 1 && ((B0M >> b0) & 1)) { r.v[b0].x = flip_sign(r.v[b0].x, neg); r.v[b0].y = flip_sign(r.v[b0].y, neg); }
+    }
+  });
+  if constexpr (L0 == 2) {
+    constexpr int NP = popcount16(B0M);
+    if constexpr (sizeof(R) == 8 && NP <= 8 && B0M == centre_run_mask(NP)) {
+      // one pass with 16-byte elements: plane b0 at position p = (b0 + NP / 2) & 15 < NP, element (g, a, p, l0) at
+      // 32 NP g + a + 16 p + 16 NP l0
+      cpx<R>* cbuf = reinterpret_cast<cpx<R>*>(xbuf);
+      ex.each([&](int lane, LaneRegs<R, P, NSL>& r) {
+        const int q = lane & (L - 1), a = q & 15, l0 = q >> 4, g = lane >> 5;
+#pragma unroll
+        for (int b0 = 0; b0 < 16; ++b0)
+          if ((B0M >> b0) & 1) ex.st(cbuf + 32 * NP * g + a + 16 * ((b0 + NP / 2) & 15) + 16 * NP * l0, r.v[b0]);
+      });
+      ex.sync();
+      ex.each([&](int lane, LaneRegs<R, P, NSL>& r) {
+        const int q = lane & (L - 1), g = lane >> 5;
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+          const int oi = q + L * s;
+          if (oi < Np) {
+            const int x = lo + oi;
+            const cpx<R>* f = cbuf + 32 * NP * g + ((x + 8 * NP) & 255);
+            const cpx<R> acc = cfma(om[omS + oi], ex.ld(f + 16 * NP), ex.ld(f));
+            const bool neg = (x & 1) != 0;
+            r.xr[s] = flip_sign(acc.x, neg);
+            r.xi[s] = flip_sign(acc.y, neg);
+          }
+        }
+      });
+      ex.sync();
+    } else {
+      ex.each([&](int, LaneRegs<R, P, NSL>& r) {
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) { r.xr[s] = (R)0; r.xi[s] = (R)0; }
+      });
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        ex.each([&](int lane, LaneRegs<R, P, NSL>& r) {
+          const int q = lane & (L - 1), a = q & 15, l0 = q >> 4, g = lane >> 5;
+#pragma unroll
+          for (int b0 = 0; b0 < 16; ++b0)
+            if ((B0M >> b0) & 1) ex.st(xbuf + 512 * g + a + 16 * b0 + 256 * l0, X::pack(r.v[b0], c));
+        });
+        ex.sync();
+        ex.each([&](int lane, LaneRegs<R, P, NSL>& r) {
+          const int q = lane & (L - 1), g = lane >> 5;
+#pragma unroll
+          for (int s = 0; s < NSL; ++s) {
+            const int oi = q + L * s;
+            if (oi < Np) {
+              const int x = lo + oi;
+              const E* f = xbuf + 512 * g + (x & 255);
+              X::first(r.xr[s], r.xi[s], ex.ld(f), c);
+              X::acc(r.xr[s], r.xi[s], om[omS + oi], ex.ld(f + 256), c);
+              if (c == NC - 1) {
+                const bool neg = (x & 1) != 0;
+                r.xr[s] = flip_sign(r.xr[s], neg);
+                r.xi[s] = flip_sign(r.xi[s], neg);
+              }
+            }
+          }
+        });
+        ex.sync();
+      }
+    }
+  }
+}
+// f(oi, re, im) for every window output this lane holds after packed_row_fft (oi ascending).
+template <class R, int L0, int NSL, int B0M, class F>
+FMC_HD void packed_outputs(int lane, const LaneRegs<R, 16, NSL>& r, int lo, int Np, F f) {
+  if constexpr (L0 == 1) {
+    const int a = lane & 15;
+#pragma unroll
+    for (int b0 = 0; b0 < 16; ++b0)
+      if ((B0M >> b0) & 1) {
+        const int oi = a + 16 * b0 - lo;
+        if (oi >= 0 && oi < Np) f(oi, r.v[b0].x, r.v[b0].y);
+      }
+  } else {
+    const int q = lane & 31;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      const int oi = q + 32 * s;
+      if (oi < Np) f(oi, r.xr[s], r.xi[s]);
+    }
+  }
+}
+// tw1[a * L + q] = w_N^{q a}, N = 16 L (16 L entries);  om[1 * omS + oi] = w_L^{b}, b = ((lo + oi) / 16) mod L  (L0 = 2
+// only; row 0 is never read)
+template <class R, class CosSin>
+inline void build_tw1_pk(cpx<R>* tw1, int L, CosSin cs) {
+  const int N = 16 * L;
+  for (int a = 0; a < 16; ++a)
+    for (int l = 0; l < L; ++l) {
+      double c, s;
+      cs((double)((l * a) % N) / N, &c, &s);
+      tw1[a * L + l] = mk<R>((R)c, (R)(-s));
+    }
+}
+template <class R, class CosSin>
+inline void build_om_pk(cpx<R>* om, int omS, int L, int lo, int Np, CosSin cs) {
+  for (int m = 0; m < 2; ++m)
+    for (int oi = 0; oi < omS; ++oi) {
+      if (oi >= Np) { om[m * omS + oi] = mk<R>((R)0, (R)0); continue; }
+      const int b = ((lo + oi) / 16) % L;
+      double c, s;
+      cs((double)((m * b) % L) / L, &c, &s);
+      om[m * omS + oi] = mk<R>((R)c, (R)(-s));
+    }
+}
+
 // Host-side construction of the two tables (float64 trigonometry by the caller-supplied functor
 // `cs(turns, &c, &s)` = cos/sin(2*pi*turns)).
 template <class R, class CosSin>

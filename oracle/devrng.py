@@ -6,8 +6,9 @@ generator has no counterpart in the reference (which uses numpy's PCG64 stream,
 fast/funcs.py:21,352-356); this module restates OUR definition in numpy/float64 so that the
 device path can be checked deterministically, not only statistically:
 
-  stream (g, ky, l = kx mod 64): xoshiro128+ seeded with Philox4x32-7(ctr=(ky*64+l, STREAM, g_lo, g_hi), key=seed)
-  coefficient (ky, l + 64 j) = BM(a_j, b_j), (a_j, b_j) = (s0 + s3, s1 + s2) of the state after j advances
+  stream (g, ky, l = kx mod SL): xoshiro128+ seeded with Philox4x32-7(ctr=(ky*SL+l, STREAM, g_lo, g_hi), key=seed),
+  SL = stream_lanes(N) (64 for most grids)
+  coefficient (ky, l + SL j) = BM(a_j, b_j), (a_j, b_j) = (s0 + s3, s1 + s2) of the state after j advances
   (two words per state advance; jointly equidistributed over the period)
   BM(a, b) = sqrt(-2 ln((a+.5)/2^32)) * exp(2 pi i (b >> 9)/2^23)
   (log-amplitude and sub-harmonic draws use Philox blocks directly)
@@ -141,8 +142,16 @@ def mr_supported(N):
     return mr_split(N) > 0
 
 
+def pk_grid(N):
+    """fmc_core.h: pk_grid -- grids of the packed rows (four / two rows per wavefront)."""
+    return N in (256, 512)
+
+
 def stream_lanes(N):
-    """fmc_core.h: stream_lanes -- generator streams per row: 50 S on the 50-lane grids, else 64 * spec_split(N)."""
+    """fmc_core.h: stream_lanes -- generator streams per row: N / 16 on the packed grids (256, 512: sixteen draws per
+    stream), 50 S on the 50-lane grids, else 64 * spec_split(N)."""
+    if pk_grid(N):
+        return N // 16
     return 50 * mr_split(N) if mr_supported(N) else 64 * spec_split(N)
 
 
@@ -177,7 +186,7 @@ def device_coefficients_f64(seed, g, N):
 def device_coefficients(seed, g, N):
     """(N, N) complex coefficients of realisation g (== fastmc_rng_coeffs).
 
-    SL = stream_lanes(N) streams per row (64; 128 / 256 at 2048 / 4096; 50 S on the 50 P S grids).  Stream (g, ky, L = kx mod SL): state = Philox4x32-7(ctr =
+    SL = stream_lanes(N) streams per row (64; 128 / 256 at 2048 / 4096; 16 / 32 at 256 / 512; 50 S on the 50 P S grids).  Stream (g, ky, L = kx mod SL): state = Philox4x32-7(ctr =
     (ky*SL + L, STREAM_SCREEN, g_lo, g_hi), key = seed) (s0 := 1 if the block is all zero); coefficient
     (ky, L + SL j) = BM(s0 + s3, s1 + s2) of the xoshiro128+ state after j advances (fmc_core.h: xoshiro128p::next2,
     fmc_kernels.h: row_stream / draw_words).  The device colours these float32 normals with sqrt(powerspec) * df

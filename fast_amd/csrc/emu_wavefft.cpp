@@ -302,7 +302,7 @@ static int sweep_mr(const char* name, double tol) {
 // Packed rows of fmc_wavefft.h (N = 256: four rows per wave, N = 512: two): every row of the wave against the naive DFT.
 template <class R, int L0, int NSL, int B0M>
 static double run_pk_case(int lo, int Np, unsigned seed) {
-  constexpr int L = 16 * L0, N = 16 * L, G = WAVE / L;
+  constexpr int L = pk_lanes(L0), N = 16 * L, G = WAVE / L;
   using E = typename Xch<R>::E;
   std::mt19937_64 gen(seed);
   std::normal_distribution<double> nd(0.0, 1.0);
@@ -345,7 +345,7 @@ static double run_pk_case(int lo, int Np, unsigned seed) {
 }
 template <class R, int L0>
 static int sweep_pk(const char* name, double tol) {
-  constexpr int N = 256 * L0, NSC = 96 / (16 * L0), NSA = 256 / (16 * L0);
+  constexpr int L = pk_lanes(L0), N = 16 * L, WALL = N < 256 ? N : 256, NSC = 96 / L, NSA = WALL / L;
   int bad = 0;
   auto report = [&](const char* what, int lo, int Np, double err) {
     const bool ok = err <= tol;
@@ -355,13 +355,15 @@ static int sweep_pk(const char* name, double tol) {
   for (int Np : {82, 96, 23, 1, 64, 95})       // centred windows: six planes
     for (int lo : {(N - Np) / 2, (N - Np) / 2 + (Np < 90 ? 3 : 0)})
       report("centred planes", lo, Np, run_pk_case<R, L0, NSC, pk_centre_mask<L0>()>(lo, Np, 4321u + Np + lo));
-  const int cases[][2] = {{(N - 82) / 2, 82}, {0, 256}, {N - 5, 5}, {5, 250}, {(N - 128) / 2, 128}, {N - 256, 256}, {3, 97}, {N / 2 - 100, 201}};
-  for (auto& c : cases) report("all planes", c[0], c[1], run_pk_case<R, L0, NSA, 0xFFFF>(c[0], c[1], 99u + c[0] + c[1]));
+  const int cases[][2] = {{(N - 82) / 2, 82}, {0, WALL}, {N - 5, 5}, {5, WALL - 6}, {(N - 128) / 2, 128}, {N - WALL, WALL}, {3, 97}, {N / 2 - 60, 121}};
+  for (auto& c : cases) report("all planes", c[0], c[1], run_pk_case<R, L0, NSA, pk_all_mask<L0>()>(c[0], c[1], 99u + c[0] + c[1]));
   return bad;
 }
 
 int main() {
   int bad = 0;
+  bad += sweep_pk<double, 0>("f64", 1e-13);
+  bad += sweep_pk<float, 0>("f32", 2e-5);
   bad += sweep_pk<double, 1>("f64", 1e-13);
   bad += sweep_pk<double, 2>("f64", 1e-13);
   bad += sweep_pk<float, 1>("f32", 2e-5);

@@ -537,7 +537,7 @@ static int default_batch(const fastmc_ctx* h) {
     if (h->rsz == 8) wave_config<double>(h, &ns, &wpb); else wave_config<float>(h, &ns, &wpb);
     if (h->P == 16 && ns == 2 && h->S == 1 && !h->no_dense && (h->rsz == 8 ? dense16r_fits<double>(h) : dense16r_fits<float>(h))) wpb = 16;
     int quantum = std::max(1, 256 * wpb * ROWS_PER_WAVE / h->N);
-    if (pk_grid(h->N)) quantum = h->N == 256 ? 256 * PkCfg<double, 1, 0>::WPB * ROWS_PER_WAVE * 4 / 256 : 256 * PkCfg<double, 2, 0>::WPB * ROWS_PER_WAVE * 2 / 512;
+    if (pk_grid(h->N)) quantum = 256 * (h->N == 512 ? PkCfg<double, 2, 0>::WPB : PkCfg<double, 1, 0>::WPB) * ROWS_PER_WAVE / 16;   // (64 * 16 / N rows per unit) / N
     if (b >= quantum) b -= b % quantum;
   } else if (b >= 8) {
     b &= ~7;
@@ -662,8 +662,8 @@ static int upload_wave_tables(fastmc_ctx* h) {
 template <class R>
 static int pk_variant(const fastmc_ctx* h) {
   if (!pk_grid(h->N) || h->path != 1) return -1;
-  const int centre = h->N == 256 ? pk_centre_mask<1>() : pk_centre_mask<2>();
-  if (h->Np <= 96 && (window_planes(h->lo, h->Np, 16, 16) & ~centre) == 0) return 0;
+  const int centre = h->N == 128 ? pk_centre_mask<0>() : (h->N == 256 ? pk_centre_mask<1>() : pk_centre_mask<2>());
+  if (h->Np <= 96 && (window_planes(h->lo, h->Np, 16, h->N == 128 ? 8 : 16) & ~centre) == 0) return 0;
   if (h->Np <= 256) return 1;     // tables + sixteen exchange buffers fit the LDS for every such window
   return -1;
 }
@@ -908,8 +908,9 @@ template <class R>
 int dispatch_pk(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   const int v = pk_variant<R>(h);
   if (v < 0) return fail(FASTMC_ESTATE, "no packed-row kernel for this window");
-  if (h->N == 256) { if (v == 0) launch_pk_pair<R, 1, 0>(h, RA, CA, mode, epi); else launch_pk_pair<R, 1, 1>(h, RA, CA, mode, epi); }
-  else             { if (v == 0) launch_pk_pair<R, 2, 0>(h, RA, CA, mode, epi); else launch_pk_pair<R, 2, 1>(h, RA, CA, mode, epi); }
+  if (h->N == 128)      { if (v == 0) launch_pk_pair<R, 0, 0>(h, RA, CA, mode, epi); else launch_pk_pair<R, 0, 1>(h, RA, CA, mode, epi); }
+  else if (h->N == 256) { if (v == 0) launch_pk_pair<R, 1, 0>(h, RA, CA, mode, epi); else launch_pk_pair<R, 1, 1>(h, RA, CA, mode, epi); }
+  else                  { if (v == 0) launch_pk_pair<R, 2, 0>(h, RA, CA, mode, epi); else launch_pk_pair<R, 2, 1>(h, RA, CA, mode, epi); }
   return 0;
 }
 

@@ -401,10 +401,10 @@ FMC_HD constexpr int mr_split(int N) {       // 0: not a size of the family
   return 0;
 }
 FMC_HD constexpr bool mr_supported(int N) { return mr_split(N) > 0; }
-// Grids of the packed rows (fmc_wavefft.h: packed_row_fft): 256 = 16 x 16 (four rows per wavefront), 512 = 16 x 32 (two).
-// Their rows are drawn as N / 16 streams of sixteen advances (stream q = kx mod N / 16): one seeding block per lane serves
-// the 4 / 2 rows a wavefront transforms at once.
-FMC_HD constexpr bool pk_grid(int N) { return N == 256 || N == 512; }
+// Grids of the packed rows (fmc_wavefft.h: packed_row_fft): 128 = 16 x 8 (eight rows per wavefront), 256 = 16 x 16 (four),
+// 512 = 16 x 32 (two).  Their rows are drawn as N / 16 streams of sixteen advances (stream q = kx mod N / 16): one seeding
+// block per lane serves the 8 / 4 / 2 rows a wavefront transforms at once.
+FMC_HD constexpr bool pk_grid(int N) { return N == 128 || N == 256 || N == 512; }
 // Generator streams per row: coefficient (ky, kx) is draw kx / SL of stream kx mod SL.
 FMC_HD constexpr int stream_lanes(int N) { return pk_grid(N) ? N / 16 : (mr_supported(N) ? MR_LN * mr_split(N) : WAVE * spec_split(N)); }
 constexpr uint32_t STREAM_SCREEN = 0;

@@ -579,20 +579,20 @@ void k_cols_wave(ColArgs<R> A) {
   column_epilogue<R, NS, EPI>(A.sh, A.W, A.partial, A.phs, A.nb, A.Np, b, xi, lane, regs.xr, regs.xi);
 }
 
-// ================================================================== packed rows: N = 256 (L0 = 1), 512 (L0 = 2)
-// G = 4 / L0 rows (columns) per wavefront on the sixteen-values-per-lane pipeline of the 1024-point row (fmc_wavefft.h:
+// ================================================================== packed rows: N = 128 (L0 = 0), 256 (L0 = 1), 512 (L0 = 2)
+// G = 8, 4, 2 rows (columns) per wavefront on the sixteen-values-per-lane pipeline of the 1024-point row (fmc_wavefft.h:
 // packed_row_fft).  Generator: L = 16 L0 streams per row, stream q = kx mod L, sixteen advances each (fmc_core.h:
 // stream_lanes) -- ONE Philox block per lane and G rows.  D 0: the six planes of a centred window of up to 96 pixels; D 1: all
 // sixteen planes, any window of up to 256 pixels.  Sixteen waves per workgroup.
 template <class R, int L0, int D> struct PkCfg {
-  static constexpr int L = 16 * L0, G = WAVE / L, N = 16 * L;
-  static constexpr int B0M = D == 0 ? pk_centre_mask<L0>() : 0xFFFF;
-  static constexpr int NSL = (D == 0 ? 96 : 256) / L;      // output slots of L lanes (read for L0 = 2 only)
-  static constexpr int WMAX = D == 0 ? 96 : 256;           // widest window
+  static constexpr int L = pk_lanes(L0), G = WAVE / L, N = 16 * L;
+  static constexpr int B0M = D == 0 ? pk_centre_mask<L0>() : pk_all_mask<L0>();
+  static constexpr int WMAX = D == 0 ? 96 : (N < 256 ? N : 256);   // widest window
+  static constexpr int NSL = L0 == 2 ? WMAX / L : 1;       // output slots of L lanes (L0 = 2 only)
 #ifdef FMC_PK_WPB_ALL
   static constexpr int WPB = FMC_PK_WPB_ALL;
 #else
-  static constexpr int WPB = (L0 == 1 || D == 1) ? 12 : 16;
+  static constexpr int WPB = (D == 1 && L0 <= 1) ? 8 : ((L0 <= 1 || D == 1) ? 12 : 16);    // rows: as many waves as run without spilling
 #endif
 #ifdef FMC_PK_RMINB
   static constexpr int RMINB = FMC_PK_RMINB;
@@ -623,11 +623,11 @@ template <class R, int L0, int D> struct PkCfg {
 // LDS carve (dynamic): [tw1 16 L cpx][om OM_ROWS omS cpx][xbuf wpb * D16_XELEMS 8-byte]
 template <class R, int L0>
 __host__ __device__ constexpr size_t pk_lds_bytes(int omS, int wpb) {
-  return (size_t)(16 * 16 * L0 + (L0 == 2 ? 2 : 0) * omS) * sizeof(cpx<R>) + (size_t)wpb * D16_XELEMS * 8;
+  return (size_t)(16 * pk_lanes(L0) + (L0 == 2 ? 2 : 0) * omS) * sizeof(cpx<R>) + (size_t)wpb * D16_XELEMS * 8;
 }
 template <class R, int L0>
 __device__ __forceinline__ void pk_load_tables(cpx<R>* s_tw, cpx<R>* s_om, const cpx<R>* tw, const cpx<R>* om, int omS) {
-  for (int i = threadIdx.x; i < 16 * 16 * L0; i += blockDim.x) s_tw[i] = tw[i];
+  for (int i = threadIdx.x; i < 16 * pk_lanes(L0); i += blockDim.x) s_tw[i] = tw[i];
   if (L0 == 2)
     for (int i = threadIdx.x; i < 2 * omS; i += blockDim.x) s_om[i] = om[i];
   __syncthreads();
@@ -732,22 +732,28 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPC * 64), (PkCfg<R, L0, D>::CMIN
       // the (at most six / three) outputs of a lane go through its own slots of the exchange buffer and the detector is a
       // rolled loop over them: a sixth of the code of the unrolled form (two inlined sincos instead of twelve) and its
       // registers -- the column kernel of the small grids is bound by the start-up of its short-lived waves, not by arithmetic
-      constexpr int NOUT = L0 == 1 ? popcount16(C::B0M) : C::NSL, FIRST = L0 == 1 ? 5 : 0;
-      static_assert(L0 != 1 || C::B0M == (((1 << NOUT) - 1) << FIRST), "contiguous planes");
+      // (N = 128: the planes of a = i, then those of a = i + 8)
+      constexpr int NOUT = L0 == 2 ? C::NSL : popcount16(C::B0M), FIRST = L0 == 0 ? 1 : (L0 == 1 ? 5 : 0);
+      constexpr int NM = L0 == 0 ? 2 : 1, STEP = L0 == 2 ? 32 : 16;
+      static_assert(L0 == 2 || C::B0M == (((1 << NOUT) - 1) << FIRST), "contiguous planes");
       cpx<R>* ob = reinterpret_cast<cpx<R>*>(xbuf) + lane;
 #pragma unroll
-      for (int p = 0; p < NOUT; ++p) ob[WAVE * p] = L0 == 1 ? regs.v[(FIRST + p) & 15] : mk<R>(regs.xr[p % C::NSL], regs.xi[p % C::NSL]);
-      ex.sync();
-      const int y0 = L0 == 1 ? (lane & 15) + 16 * FIRST - A.lo : q;
+      for (int m = 0; m < NM; ++m) {
+#pragma unroll
+        for (int p = 0; p < NOUT; ++p)
+          ob[WAVE * p] = L0 == 2 ? mk<R>(regs.xr[p % C::NSL], regs.xi[p % C::NSL]) : regs.v[(8 * m + FIRST + p) & 15];
+        ex.sync();
+        const int y0 = L0 == 2 ? q : q + 8 * m + 16 * FIRST - A.lo;
 #pragma unroll 1
-      for (int p = 0; p < NOUT; ++p) {
-        const int yi = y0 + L * p;
-        if (live && yi >= 0 && yi < A.Np) {
-          const cpx<R> v = ob[WAVE * p];
-          pixel(yi, v.x, v.y);
+        for (int p = 0; p < NOUT; ++p) {
+          const int yi = y0 + STEP * p;
+          if (live && yi >= 0 && yi < A.Np) {
+            const cpx<R> v = ob[WAVE * p];
+            pixel(yi, v.x, v.y);
+          }
         }
+        ex.sync();
       }
-      ex.sync();
     } else {
       packed_outputs<R, L0, C::NSL, C::B0M>(lane, regs, A.lo, A.Np, [&](int yi, R p1, R p2) { if (live) pixel(yi, p1, p2); });
     }
@@ -757,8 +763,8 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPC * 64), (PkCfg<R, L0, D>::CMIN
         double v = acc[k];
         v += dpp_copy<0xB1>(v);     // quad_perm [1,0,3,2]
         v += dpp_copy<0x4E>(v);     // quad_perm [2,3,0,1]
-        v += dpp_copy<0x141>(v);    // row_half_mirror
-        v += dpp_copy<0x140>(v);    // row_mirror: every lane holds the sum of its 16-lane row
+        v += dpp_copy<0x141>(v);    // row_half_mirror: every lane holds the sum of its 8 lanes
+        if (L0 >= 1) v += dpp_copy<0x140>(v);    // row_mirror: ... of its 16-lane row
         if (L0 == 2) {
           const long long bits = __double_as_longlong(v);
           const int lo32 = (int)(bits & 0xffffffffll), hi32 = (int)(bits >> 32);

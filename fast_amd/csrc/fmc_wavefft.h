@@ -432,13 +432,19 @@ FMC_HD void pruned_row_fft_d16r(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>
 // lds_bank_check.py) and 66 for L0 = 2: conflict-free writes and reads.
 // B0M: planes b0 kept.  A centred window of up to 96 pixels touches six: {5, ..., 10} at N = 256 (centre block 8), {13, 14,
 // 15, 0, 1, 2} at N = 512 (centre block 16 = 0 mod 16).
-template <int L0> constexpr int PK_SE = (L0 == 1) ? 65 : 66;
-template <int L0> constexpr int pk_centre_mask() { return centre_planes(16, 16, (8 * L0) & 15); }
-static_assert(pk_centre_mask<1>() == 0x07E0 && pk_centre_mask<2>() == D16R_CENTRE_MASK, "planes {5 ... 10} / {13 ... 2}");
+// N = 128 (L0 = 0 below, L = 8 lanes per row, EIGHT rows per wavefront): the lane dimension holds 8 = 16 / 2 points, so lane
+// (g, i < 8) owns TWO radix-8 butterflies of stage 2, a = i and a = i + 8: X[a + 16 b] = sum_{q < 8} w_8^{q b} T_q[a], b < 8,
+// left in r.v[8 m + b] (a = i + 8 m).  B0M is then a mask over the eight b; a centred window touches {1, ..., 6}.
+template <int L0> constexpr int PK_SE = (L0 == 2) ? 66 : 65;
+constexpr int pk_lanes(int L0) { return L0 == 0 ? 8 : 16 * L0; }
+template <int L0> constexpr int pk_centre_mask() { return L0 == 0 ? centre_planes(16, 8, 4) : centre_planes(16, 16, (8 * L0) & 15); }
+template <int L0> constexpr int pk_all_mask() { return L0 == 0 ? 0xFF : 0xFFFF; }
+static_assert(pk_centre_mask<1>() == 0x07E0 && pk_centre_mask<2>() == D16R_CENTRE_MASK && pk_centre_mask<0>() == 0x7E,
+              "planes {5 ... 10} / {13 ... 2} / {1 ... 6}");
 template <class R, int L0, int NSL, int B0M = 0xFFFF, class Exec>
 FMC_HD void packed_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1, const cpx<R>* om, int omS, int lo, int Np) {
-  static_assert(L0 == 1 || L0 == 2, "N = 256 or 512");
-  constexpr int P = 16, L = 16 * L0, SE = PK_SE<L0>;
+  static_assert(L0 == 0 || L0 == 1 || L0 == 2, "N = 128, 256 or 512");
+  constexpr int P = 16, L = pk_lanes(L0), SE = PK_SE<L0>;
   using X = Xch<R>;
   using E = typename X::E;
   constexpr int NC = X::NC;
@@ -459,23 +465,48 @@ FMC_HD void packed_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
     });
     ex.sync();
     ex.each([&](int lane, LaneRegs<R, P, NSL>& r) {
-      const int q = lane & (L - 1), a = q & 15, l0 = q >> 4;
-      const E* e = xbuf + a * SE + (lane - q) + l0;
+      const int q = lane & (L - 1);
+      if constexpr (L0 == 0) {
 #pragma unroll
-      for (int l1 = 0; l1 < 16; ++l1) X::unpack(r.v[l1], ex.ld(e + L0 * l1), c);
+        for (int m = 0; m < 2; ++m) {
+          const E* e = xbuf + (q + 8 * m) * SE + (lane - q);
+#pragma unroll
+          for (int qq = 0; qq < 8; ++qq) X::unpack(r.v[8 * m + qq], ex.ld(e + qq), c);
+        }
+      } else {
+        const int a = q & 15, l0 = q >> 4;
+        const E* e = xbuf + a * SE + (lane - q) + l0;
+#pragma unroll
+        for (int l1 = 0; l1 < 16; ++l1) X::unpack(r.v[l1], ex.ld(e + L0 * l1), c);
+      }
     });
     ex.sync();
   }
   ex.each([&](int lane, LaneRegs<R, P, NSL>& r) {
-    cpx<R> t[16];
+    const bool neg = (lane & 1) != 0;            // L0 < 2: x = a + 16 b has the parity of the lane
+    if constexpr (L0 == 0) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) t[m] = r.v[m];
-    fft_dif<16, R>(t);
-    const bool neg = (lane & 1) != 0;            // L0 = 1: x = a + 16 b0 has the parity of the lane
+      for (int m = 0; m < 2; ++m) {
+        cpx<R> t[8];
 #pragma unroll
-    for (int b0 = 0; b0 < 16; ++b0) {
-      r.v[b0] = t[brev(b0, 4)];
-      if (L0 == 1 && ((B0M >> b0) & 1)) { r.v[b0].x = flip_sign(r.v[b0].x, neg); r.v[b0].y = flip_sign(r.v[b0].y, neg); }
+        for (int qq = 0; qq < 8; ++qq) t[qq] = r.v[8 * m + qq];
+        fft_dif<8, R>(t);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          r.v[8 * m + b] = t[brev(b, 3)];
+          if ((B0M >> b) & 1) { r.v[8 * m + b].x = flip_sign(r.v[8 * m + b].x, neg); r.v[8 * m + b].y = flip_sign(r.v[8 * m + b].y, neg); }
+        }
+      }
+    } else {
+      cpx<R> t[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) t[m] = r.v[m];
+      fft_dif<16, R>(t);
+#pragma unroll
+      for (int b0 = 0; b0 < 16; ++b0) {
+        r.v[b0] = t[brev(b0, 4)];
+        if (L0 == 1 && ((B0M >> b0) & 1)) { r.v[b0].x = flip_sign(r.v[b0].x, neg); r.v[b0].y = flip_sign(r.v[b0].y, neg); }
+      }
     }
   });
   if constexpr (L0 == 2) {
@@ -547,7 +578,17 @@ FMC_HD void packed_row_fft(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw1
 // f(oi, re, im) for every window output this lane holds after packed_row_fft (oi ascending).
 template <class R, int L0, int NSL, int B0M, class F>
 FMC_HD void packed_outputs(int lane, const LaneRegs<R, 16, NSL>& r, int lo, int Np, F f) {
-  if constexpr (L0 == 1) {
+  if constexpr (L0 == 0) {
+    const int i = lane & 7;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        if ((B0M >> b) & 1) {
+          const int oi = i + 8 * m + 16 * b - lo;
+          if (oi >= 0 && oi < Np) f(oi, r.v[8 * m + b].x, r.v[8 * m + b].y);
+        }
+  } else if constexpr (L0 == 1) {
     const int a = lane & 15;
 #pragma unroll
     for (int b0 = 0; b0 < 16; ++b0)

@@ -22,12 +22,13 @@ TWO_PI = 2 * np.pi
 WAVE_FFT_SIZES = sorted(64 * q * 2 ** k for q in (1, 3, 5, 7, 9) for k in range(6) if 2 <= q * 2 ** k <= 32) + [4096]
 MAX_NPXLS = 4096          # libfastmc: N <= 4096 (fastmc_create)
 # Measured float64 throughput [k iterations/s, Np = 82, device generator] of every grid size that has an FFT kernel family
-# (tools/sizesweep.sh on one MI355X; profiles/r01k_sizesweep_f64.txt, r02g_sizesweep_lanes50_f64.txt):
+# (tools/sizesweep.sh on one MI355X; profiles/r01k_sizesweep_f64.txt, r02g_sizesweep_lanes50_f64.txt, r03_packed_rows_rates.txt for
+# 128 / 256 / 512):
 # 64 P wave sizes, 64 P S with run-time sub-rows, 50 P S on the 50-lane kernels.  GPU_ROUND_NPXLS rounds an auto-sized grid
 # up to the smallest of these that is within 10 % of the fastest one not smaller than it (896 and 1792, radix-7 stages, lose
 # to 1024 and 2048; 2048 beats everything between 1600 and itself).
 FAST_SIZE_RATE = {
-    128: 6600, 192: 5600, 256: 4400, 320: 3400, 384: 2700, 448: 2200, 512: 2200, 576: 1400, 640: 1300, 768: 1150, 896: 550,
+    128: 14000, 192: 5600, 256: 7400, 320: 3400, 384: 2700, 448: 2200, 512: 2900, 576: 1400, 640: 1300, 768: 1150, 896: 550,
     1024: 920, 1152: 460, 1280: 370, 1536: 360, 1792: 145, 2048: 245, 4096: 62,
     1344: 318, 1728: 174, 1920: 159, 2304: 86, 2560: 75, 3072: 85, 3584: 43, 3840: 35,
     100: 8060, 150: 6150, 200: 4850, 250: 3900, 300: 3170, 350: 2545, 400: 2490, 450: 1930, 500: 1930, 600: 1490, 700: 830,
@@ -118,7 +119,7 @@ def grid_size(p, atm):
             rnd = p.get('GPU_RNG', 'device') == 'device' and not p['TEMPORAL']
         if rnd:
             # the reference's auto rule is a lower bound and gives arbitrary even sizes (164 for the shipped
-            # example, 5x slower on the direct kernels than 192 on the wave kernels); the next size of the
+            # example; 256 on the packed-row kernels is faster than anything in between); the next size of the
             # fast kernel family samples the spectrum slightly finer
             bigger = round_up_size(N)
             if bigger:

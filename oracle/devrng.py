@@ -143,12 +143,12 @@ def mr_supported(N):
 
 
 def pk_grid(N):
-    """fmc_core.h: pk_grid -- grids of the packed rows (four / two rows per wavefront)."""
-    return N in (256, 512)
+    """fmc_core.h: pk_grid -- grids of the packed rows (eight / four / two rows per wavefront)."""
+    return N in (128, 256, 512)
 
 
 def stream_lanes(N):
-    """fmc_core.h: stream_lanes -- generator streams per row: N / 16 on the packed grids (256, 512: sixteen draws per
+    """fmc_core.h: stream_lanes -- generator streams per row: N / 16 on the packed grids (128, 256, 512: sixteen draws per
     stream), 50 S on the 50-lane grids, else 64 * spec_split(N)."""
     if pk_grid(N):
         return N // 16
@@ -186,7 +186,7 @@ def device_coefficients_f64(seed, g, N):
 def device_coefficients(seed, g, N):
     """(N, N) complex coefficients of realisation g (== fastmc_rng_coeffs).
 
-    SL = stream_lanes(N) streams per row (64; 128 / 256 at 2048 / 4096; 16 / 32 at 256 / 512; 50 S on the 50 P S grids).  Stream (g, ky, L = kx mod SL): state = Philox4x32-7(ctr =
+    SL = stream_lanes(N) streams per row (64; 128 / 256 at 2048 / 4096; 8 / 16 / 32 at 128 / 256 / 512; 50 S on the 50 P S grids).  Stream (g, ky, L = kx mod SL): state = Philox4x32-7(ctr =
     (ky*SL + L, STREAM_SCREEN, g_lo, g_hi), key = seed) (s0 := 1 if the block is all zero); coefficient
     (ky, L + SL j) = BM(s0 + s3, s1 + s2) of the xoshiro128+ state after j advances (fmc_core.h: xoshiro128p::next2,
     fmc_kernels.h: row_stream / draw_words).  The device colours these float32 normals with sqrt(powerspec) * df

@@ -1092,8 +1092,9 @@ _VARIANTS = [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, No
              (1152, 82, None), (1280, 82, None), (1536, 82, None), (1792, 82, None), (512, 82, None), (256, 82, None), (768, 152, None),
              (1000, 82, None), (2000, 82, None), (1200, 82, None), (500, 82, None), (3072, 82, None), (1344, 82, None),
              (164, 82, None), (943, 82, None),
-             # packed rows (four / two rows per wavefront): six centred planes, all planes, off-centre and wide windows, the whole
+             # packed rows (eight / four / two rows per wavefront): six centred planes, all planes, off-centre and wide windows, the whole
              # grid, and a window beyond the packed kernels (512, 300: device draws go to the direct family)
+             (128, 82, None), (128, 96, None), (128, 97, None), (128, 40, 0), (128, 128, None), (128, 60, 68),
              (256, 96, None), (256, 97, None), (256, 40, 0), (256, 82, 100), (256, 200, None), (256, 256, None),
              (512, 96, None), (512, 128, None), (512, 82, 3), (512, 250, 7), (512, 256, 256), (512, 300, None)]
 
@@ -1102,7 +1103,7 @@ _VARIANTS = [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, No
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_every_device_mode_row_variant_matches_the_oracle(N, Np, lo, prec):
     if prec == "f32" and (N > 2048 or (N, Np, lo) not in [(1024, 82, None), (1024, 128, None), (1024, 200, None), (2048, 82, None), (1000, 82, None), (512, 82, None),
-                                                         (256, 82, None), (256, 200, None), (512, 250, 7)]):
+                                                         (256, 82, None), (256, 200, None), (512, 250, 7), (128, 82, None), (128, 128, None)]):
         pytest.skip("float32 pipeline: the benchmarked shapes only")
     ps, df = _vk_spectrum(N, 0.01, 30.0)
     ps = ps * 0.02

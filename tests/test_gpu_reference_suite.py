@@ -113,7 +113,7 @@ def test_save_and_load(tmp_path):
     res = fast.load(f)
     numpy.testing.assert_allclose(res.power, sim.result.power, rtol=1e-15)
     numpy.testing.assert_allclose(res.dB_rel, sim.result.dB_rel, rtol=1e-12)
-    assert res.hdr['NPXLS'] == 192 and res.hdr['AO_MODE'] == 'AO' and res.hdr['SEED'] == 4   # auto 164, rounded up (GPU_ROUND_NPXLS 'auto')
+    assert res.hdr['NPXLS'] == 256 and res.hdr['AO_MODE'] == 'AO' and res.hdr['SEED'] == 4   # auto 164, rounded up (GPU_ROUND_NPXLS 'auto')
 
 
 # --- error-rate integrals over the result (tests_pytest.py:168-187)

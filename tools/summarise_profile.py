@@ -90,19 +90,22 @@ if len(sys.argv) > 2:
            "precision": prec, "npxls": npx,
            "rows_valu_instructions_per_row": isa.get(f"rows_{prec}_{npx}", {}).get("valu_total"),
            "fetch_correction": "x2 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section)"}
-    for tag, prefix in (("rows", "k_rows_wave"), ("cols", "k_cols_wave")):
+    # the row / column kernels of the profiled grid: the packed rows on 128 / 256 / 512, else the one-row-per-wave kernels
+    rows_k = "k_rows_pk" if _kernel_ms("k_rows_pk")[0] else "k_rows_wave"
+    cols_k = "k_cols_pk" if _kernel_ms("k_cols_pk")[0] else "k_cols_wave"
+    for tag, prefix in (("rows", rows_k), ("cols", cols_k)):
         ms, name = _kernel_ms(prefix)
         fetch, write = _avg("pmc_fetch", "FETCH_SIZE", prefix), _avg("pmc_write", "WRITE_SIZE", prefix)
         ent = {"kernel": name, "avg_launch_ms": ms, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write}
         if fetch is not None and write is not None:
             ent["hbm_bytes_per_launch"] = (2 * fetch + write) * 1024
         doc[tag] = ent
-    grbm = _avg("pmc_sq2", "GRBM_GUI_ACTIVE", "k_rows_wave")
+    grbm = _avg("pmc_sq2", "GRBM_GUI_ACTIVE", rows_k)
     if grbm:
         simd_cycles = grbm / 8 * 1024          # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
         for key, sub, counter in (("valu_busy", "pmc_sq", "SQ_ACTIVE_INST_VALU"), ("issue_busy", "pmc_sq2", "SQ_ACTIVE_INST_ANY"),
                                   ("lds_issue_busy", "pmc_sq2", "SQ_ACTIVE_INST_LDS")):
-            v = _avg(sub, counter, "k_rows_wave")
+            v = _avg(sub, counter, rows_k)
             if v:
                 doc[key + "_counter_ratio"] = v * 4 / simd_cycles        # SQ_ACTIVE_INST_* count quad-cycles; NOT clamped
         # An any-instruction ratio above 1 cannot be a utilisation: it says the denominator (GRBM_GUI_ACTIVE / 8 x 1024 SIMD-cycles)
@@ -112,7 +115,7 @@ if len(sys.argv) > 2:
         for key in ("valu_busy", "issue_busy", "lds_issue_busy"):
             if key + "_counter_ratio" in doc:
                 doc[key] = doc[key + "_counter_ratio"] / short_by
-        doc["busy_note"] = ("k_rows_wave: *_counter_ratio = SQ_ACTIVE_INST_* x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), unclamped; an "
+        doc["busy_note"] = ("row kernel: *_counter_ratio = SQ_ACTIVE_INST_* x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), unclamped; an "
                             "any-instruction ratio above 1 means the denominator is that much too short, so valu_busy / issue_busy / "
                             "lds_issue_busy are the counter ratios divided by max(1, any-instruction ratio): upper bounds of the true fractions")
         doc["clock_GHz_profiled"] = grbm / 8 / (doc["rows"]["avg_launch_ms"] * 1e-3) / 1e9 if doc["rows"]["avg_launch_ms"] else None

@@ -894,7 +894,7 @@ static void launch_pk_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>
   }
   {
     Span s(h, 1);
-    const int items = CA.nb * ((CA.Np + C::G - 1) / C::G), per = C::WPC * C::IPW;
+    const int items = CA.nb * ((CA.Np + C::G - 1) / C::G), per = C::WPC;
     if (epi == 0) {
       hipFuncSetAttribute((const void*)k_cols_pk<R, L0, 0, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
       hipLaunchKernelGGL((k_cols_pk<R, L0, 0, D>), dim3((items + per - 1) / per), dim3(C::WPC * 64), ldc, h->stream, CA);

@@ -589,35 +589,13 @@ template <class R, int L0, int D> struct PkCfg {
   static constexpr int B0M = D == 0 ? pk_centre_mask<L0>() : pk_all_mask<L0>();
   static constexpr int WMAX = D == 0 ? 96 : (N < 256 ? N : 256);   // widest window
   static constexpr int NSL = L0 == 2 ? WMAX / L : 1;       // output slots of L lanes (L0 = 2 only)
-#ifdef FMC_PK_WPB_ALL
-  static constexpr int WPB = FMC_PK_WPB_ALL;
-#else
-  static constexpr int WPB = (D == 1 && L0 <= 1) ? 8 : ((L0 <= 1 || D == 1) ? 12 : 16);    // rows: as many waves as run without spilling
-#endif
-#ifdef FMC_PK_RMINB
-  static constexpr int RMINB = FMC_PK_RMINB;
-#else
-  static constexpr int RMINB = 1;
-#endif
-  // column kernel: waves per workgroup, workgroups per CU the register budget is cut for, items (groups of G columns) per wave
-#ifdef FMC_PK_WPC
-  static constexpr int WPC = FMC_PK_WPC;
-#else
-  // D = 0: the rolled detector loop fits four waves per SIMD, and two eight-wave workgroups per CU overlap one group's
-  // start-up (table copy, barrier, first loads) with the other's arithmetic: columns -9 % at 256^2, -8 % at 512^2 against
-  // one sixteen-wave workgroup (A/B on one box)
+  // rows: as many waves per workgroup as run without spilling (A/B at 256^2: eight-wave workgroups at four per SIMD no better)
+  static constexpr int WPB = (D == 1 && L0 <= 1) ? 8 : ((L0 <= 1 || D == 1) ? 12 : 16);
+  // columns, D = 0: the rolled detector loop fits four waves per SIMD, and two eight-wave workgroups per CU overlap one
+  // group's start-up (table copy, barrier, first loads) with the other's arithmetic: columns -9 % at 256^2, -8 % at 512^2
+  // against one sixteen-wave workgroup (profiles/r03_ab_packed_columns.txt)
   static constexpr int WPC = D == 0 ? 8 : WPB;
-#endif
-#ifdef FMC_PK_CMINB
-  static constexpr int CMINB = FMC_PK_CMINB;
-#else
-  static constexpr int CMINB = D == 0 ? 4 : 1;             // waves per SIMD the register budget is cut for
-#endif
-#ifdef FMC_PK_IPW
-  static constexpr int IPW = FMC_PK_IPW;
-#else
-  static constexpr int IPW = 1;
-#endif
+  static constexpr int CMINB = D == 0 ? 4 : 1;             // waves per SIMD the column kernel's register budget is cut for
   static constexpr int OM_ROWS = L0 == 2 ? 2 : 0;
 };
 // LDS carve (dynamic): [tw1 16 L cpx][om OM_ROWS omS cpx][xbuf wpb * D16_XELEMS 8-byte]
@@ -634,7 +612,7 @@ __device__ __forceinline__ void pk_load_tables(cpx<R>* s_tw, cpx<R>* s_om, const
 }
 
 template <class R, int L0, int MODE, int D>
-__global__ __launch_bounds__((PkCfg<R, L0, D>::WPB * 64), (PkCfg<R, L0, D>::RMINB)) void k_rows_pk(RowArgs<R> A) {
+__global__ __launch_bounds__((PkCfg<R, L0, D>::WPB * 64)) void k_rows_pk(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using C = PkCfg<R, L0, D>;
   using E = typename Xch<R>::E;
@@ -700,11 +678,11 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPC * 64), (PkCfg<R, L0, D>::CMIN
   GpuExec<R, 16, C::NSL> ex{lane, regs};
   pk_load_tables<R, L0>(s_tw, s_om, A.tw, A.om, A.omS);
   // work item = (realisation b, group of G window columns), group fastest; the waves of a workgroup take neighbouring items
+  // (one item per wave: a loop over several items makes the compiler hoist the per-plane invariants out of it and spill)
   const int ngrp = (A.Np + G - 1) / G;
-#pragma unroll 1
-  for (int it = 0; it < C::IPW; ++it) {
-    const int item = (blockIdx.x * C::IPW + it) * WPC + w;
-    if (item >= A.nb * ngrp) break;                        // wave-uniform; no block barrier follows
+  {
+    const int item = blockIdx.x * WPC + w;
+    if (item >= A.nb * ngrp) return;                       // wave-uniform; no block barrier follows
     const int b = item / ngrp;
     const int xi = (item % ngrp) * G + gl;
     const bool live = xi < A.Np;                           // the last group of a realisation may be short

@@ -1,6 +1,6 @@
 """Differential fuzz: wave / chirp-z / 50-lane family vs direct family on random (N, Np, lo, precision) with host coefficients
 (screens) and with the device generator (powers), and the screens against numpy for the smaller grids (odd N use
-numpy's asymmetric fftshift).  tools/fuzz_families.py [cases] [seed]"""
+numpy's asymmetric fftshift).  tools/fuzz_families.py [cases] [seed] [N1,N2,...: only these grid sizes]"""
 import os
 import sys
 import numpy as np
@@ -9,6 +9,7 @@ from fast_amd import _lib, host
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
 bad = 0
 for c in range(cases):
     N = int(rng.choice(host.WAVE_FFT_SIZES))
@@ -21,6 +22,8 @@ for c in range(cases):
     if c % 4 == 3:                                      # every fourth: N = 50 P -> 50-lane family
         N = int(rng.choice([100, 150, 200, 250, 300, 350, 400, 450, 500, 600, 700, 800, 900, 1000, 1200, 1350, 1400, 1500, 1600, 1750, 1800, 2000,
                           1344, 1728, 1920, 2304, 2560]))
+    if only:
+        N = int(rng.choice(only))
     Np = int(rng.integers(1, min(N, 300 if c % 2 == 0 else 256) + 1))
     if N > 2048 and c % 16 == 5:
         Np = int(rng.integers(1, 200))

@@ -1,5 +1,6 @@
 """Wall time of a TEMPORAL (frozen-flow) run, split into init and run: tools/temporal_rate.py [NITER]"""
-import sys, time, cProfile, pstats
+import os, sys, time, cProfile, pstats
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import fast_amd
 

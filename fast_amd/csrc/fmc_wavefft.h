@@ -1,4 +1,5 @@
-// fmc_wavefft.h -- one wavefront = one N-point row: output-pruned forward DFT, N = 64*P.
+// fmc_wavefft.h -- one wavefront = one N-point row: output-pruned forward DFT, N = 64*P (and, further down, the packed
+// rows of the small grids: 8 / 4 / 2 rows of 128 / 256 / 512 points per wavefront).
 //
 // A lane holds P inputs in registers (k = lane + 64*j), P = 2^k times 1, 3, 5, 7 or 9, <= 32.  The transform is factored
 //     N = P x 8 x 8 :  in-register radix-P  ->  LDS exchange  ->  in-register radix-8
@@ -417,7 +418,7 @@ FMC_HD void pruned_row_fft_d16r(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>
   }
 }
 
-// ---------------------------------------------------------------- N = 256, 512: 4 / 2 rows per wavefront
+// ---------------------------------------------------------------- N = 128, 256, 512: 8 / 4 / 2 rows per wavefront (packed rows)
 // The 16 x 16 x L0 factorisation above with L0 = 1 (N = 256) or 2 (N = 512) leaves lanes idle if one wave transforms one
 // row, and the P x 8 x 8 row at P = 4 / 8 is LDS-bound (a 256-point row costs 56 % of a 1024-point row).  Here a wavefront
 // transforms G = 4 / L0 rows AT ONCE: lane = g L + q (row g of the wave's G, q < L = 16 L0) holds c[q + L j], j < 16, of
@@ -428,8 +429,8 @@ FMC_HD void pruned_row_fft_d16r(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>
 //   X[a + 16 b] = sum_{l0 < L0} w_L^{l0 b} U[a][l0][b mod 16]                     (L0 = 1: nothing left to do)
 // L0 = 1: the lane's outputs are its planes, x = a + 16 b0, left in r.v[b0] (natural order, output-side fftshift sign
 // applied); L0 = 2: exchange 2 and two-term sums into output slots, oi = q + 32 s (r.xr / r.xi).  Exchange-1 image as in
-// the 1024-point row (SE a + lane) with SE = 65 for L0 = 1 (66 would put rows g and g + 2 on the same banks: tools/
-// lds_bank_check.py) and 66 for L0 = 2: conflict-free writes and reads.
+// the 1024-point row (SE a + lane) with SE = 65 for L0 = 1 (66 would put rows g and g + 2 on the same banks under the
+// lane-group rules tools/lds_bank_check.py models) and 66 for L0 = 2: conflict-free writes and reads.
 // B0M: planes b0 kept.  A centred window of up to 96 pixels touches six: {5, ..., 10} at N = 256 (centre block 8), {13, 14,
 // 15, 0, 1, 2} at N = 512 (centre block 16 = 0 mod 16).
 // N = 128 (L0 = 0 below, L = 8 lanes per row, EIGHT rows per wavefront): the lane dimension holds 8 = 16 / 2 points, so lane

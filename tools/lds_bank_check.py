@@ -205,3 +205,18 @@ for NP in (6, 8):
             worst = max(worst, read_b128([((lo + l + 8 * NP) & 255) % (16 * NP) + 16 * NP * m for l in range(64)]))
     print(f"  one-pass exchange 2, {NP} planes of 16-byte elements: store as ds_write_b128 {st128} cycles (ideal 8), as ds_write2_b64 {st2} "
           f"(ideal 8: the 2-way conflict of round 2), ds_read_b128 worst over all windows {worst} (ideal 4)")
+
+# ---- packed rows (fmc_wavefft.h: packed_row_fft): exchange-1 image SE a + lane, read inside the groups of L lanes
+print("packed rows: exchange-1 reads (ideal 2 cycles) / writes (ideal 4) by image stride")
+for L, name in ((8, "N=128"), (16, "N=256"), (32, "N=512")):
+    for SE in (64, 65, 66, 67):
+        worst = 0
+        if L == 8:
+            pats = [[((l & 7) + 8 * m) * SE + (l - (l & 7)) + qq for l in range(64)] for m in range(2) for qq in range(8)]
+        else:
+            L0 = L // 16
+            pats = [[((l & (L - 1)) & 15) * SE + (l - (l & (L - 1))) + ((l & (L - 1)) >> 4) + L0 * l1 for l in range(64)] for l1 in range(16)]
+        for a in pats:
+            worst = max(worst, cycles(a, "r"))
+        ww = max(cycles([aa * SE + l for l in range(64)], "w") for aa in range(16))
+        print(" ", name, "SE", SE, "read", worst, "write", ww)

@@ -10,7 +10,11 @@ h, cn2, w = fast_amd.turbulence_models.HV57_Bufton_profile(4)
 p = {"NPXLS": npx, "DX": 0.01, "NITER": niter, "NCHUNKS": 10, "TEMPORAL": True, "DT": 1e-3, "SEED": 1, "LOGLEVEL": "ERROR",
      "D_GROUND": 0.8, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w, "WIND_DIR": np.array([0., 90., 180., 270.]),
      "ZENITH_ANGLE": 55, "DSUBAP": 0.1, "AO_MODE": "AO", "ALIAS": True, "GPU_DEVICE": 0}
+fast_amd.Fast(dict(p))                                   # first object: library load, caches
+pi = cProfile.Profile(); pi.enable()
 t0 = time.perf_counter(); sim = fast_amd.Fast(p); t1 = time.perf_counter()
+pi.disable()
+pstats.Stats(pi).sort_stats("tottime").print_stats(12)
 pr = cProfile.Profile(); pr.enable()
 r = sim.run()
 pr.disable(); t2 = time.perf_counter()

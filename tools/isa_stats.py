@@ -42,6 +42,16 @@ KERNELS = {
     "cols_f64_2048": "void fmc::k_cols_wave<double, 16, 2, 0, 2, 5>(",
 }
 
+# --packed: the packed rows of the small grids (translation unit 10; unit = G rows / columns of one wavefront)
+PACKED_KERNELS = {
+    "rows_f64_128_packed": "void fmc::k_rows_pk<double, 0, 0, 0>(",
+    "cols_f64_128_packed": "void fmc::k_cols_pk<double, 0, 0, 0>(",
+    "rows_f64_256_packed": "void fmc::k_rows_pk<double, 1, 0, 0>(",
+    "cols_f64_256_packed": "void fmc::k_cols_pk<double, 1, 0, 0>(",
+    "rows_f64_512_packed": "void fmc::k_rows_pk<double, 2, 0, 0>(",
+    "cols_f64_512_packed": "void fmc::k_cols_pk<double, 2, 0, 0>(",
+}
+
 TRANS = re.compile(r"^v_(log|sqrt|sin|cos|exp|rcp|rsq)_(f32|f16|f64)")
 
 
@@ -137,13 +147,19 @@ def main():
     ap.add_argument("--json", default=None, help="write the per-kernel counts here")
     ap.add_argument("--asm", default=None, help="reuse this assembly file instead of compiling")
     ap.add_argument("--top", type=int, default=0, help="print the N most frequent mnemonics per kernel")
+    ap.add_argument("--packed", action="store_true", help="the packed-row kernels of 128 / 256 / 512 instead (column kernels: static "
+                    "count of the whole body, which includes the never-taken library fall-backs of sincos and both sub-harmonic branches)")
     args, extra = ap.parse_known_args()
+    kernels, flags = KERNELS, FLAGS
+    if args.packed:
+        kernels = PACKED_KERNELS
+        flags = [f for f in FLAGS if f != "-DFMC_ISA_SUBSET"] + ["-DFMC_SPLIT_BUILD", "-DFMC_TU=10", "-DFMC_ONLY_F64"]
     if args.asm:
         asm = open(args.asm).read()
     else:
         with tempfile.TemporaryDirectory() as tmp:
             out = os.path.join(tmp, "fmc.s")
-            r = subprocess.run([HIPCC] + FLAGS + extra + ["-o", out, SRC], capture_output=True, text=True)
+            r = subprocess.run([HIPCC] + flags + extra + ["-o", out, SRC], capture_output=True, text=True)
             if r.returncode != 0:
                 sys.exit(r.stderr[-4000:])
             asm = open(out).read()
@@ -151,7 +167,7 @@ def main():
     names = list(bodies)
     dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
     result = {}
-    for tag, prefix in KERNELS.items():
+    for tag, prefix in kernels.items():
         hit = [n for n, d in zip(names, dem) if d.startswith(prefix)]
         if not hit:
             continue

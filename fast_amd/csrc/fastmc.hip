@@ -1085,13 +1085,16 @@ int dispatch_wave_part(fastmc_ctx* h, RowArgs<R>& RA, ColArgs<R>& CA, int mode, 
     return dispatch_wave_ns<R, 16>(h, RA, CA, mode, epi);
   } else if constexpr (PART == 0) {
     switch (h->P) {
-      case 2: dispatch_wave<R, 2, 2>(h, RA, CA, mode, epi); break;
+      // P = 2, 4 (128, 256) and the windows of up to 256 pixels at P = 8 (512) belong to the packed rows (dispatch_pk): only
+      // the whole-grid window of 512 is left to the one-row-per-wave kernels, with host coefficients (run_impl)
       case 3: dispatch_wave<R, 3, 2>(h, RA, CA, mode, epi); break;
-      case 4: TRY((dispatch_wave_ns<R, 4>(h, RA, CA, mode, epi))); break;
       case 5: dispatch_wave<R, 5, 2>(h, RA, CA, mode, epi); break;
       case 6: dispatch_wave<R, 6, 2>(h, RA, CA, mode, epi); break;
       case 7: dispatch_wave<R, 7, 2>(h, RA, CA, mode, epi); break;
-      case 8: TRY((dispatch_wave_ns<R, 8>(h, RA, CA, mode, epi))); break;
+      case 8:
+        if (pick_ns<R, 8>(h) != 8) return fail(FASTMC_ESTATE, "no wave instantiation for this window");
+        dispatch_wave<R, 8, 8>(h, RA, CA, mode, epi);
+        break;
       case 9: TRY((dispatch_wave_ns<R, 9>(h, RA, CA, mode, epi))); break;
       case 10: TRY((dispatch_wave_ns<R, 10>(h, RA, CA, mode, epi))); break;
       case 12: TRY((dispatch_wave_ns<R, 12>(h, RA, CA, mode, epi))); break;

@@ -591,10 +591,12 @@ template <class R, int L0, int D> struct PkCfg {
   static constexpr int NSL = L0 == 2 ? WMAX / L : 1;       // output slots of L lanes (L0 = 2 only)
   // rows: as many waves per workgroup as run without spilling (A/B at 256^2: eight-wave workgroups at four per SIMD no better)
   static constexpr int WPB = (D == 1 && L0 <= 1) ? 8 : ((L0 <= 1 || D == 1) ? 12 : 16);
-  // columns, D = 0: the rolled detector loop fits four waves per SIMD, and two eight-wave workgroups per CU overlap one
-  // group's start-up (table copy, barrier, first loads) with the other's arithmetic: columns -9 % at 256^2, -8 % at 512^2
-  // against one sixteen-wave workgroup (profiles/r03_ab_packed_columns.txt)
-  static constexpr int WPC = D == 0 ? 8 : WPB;
+  // columns, D = 0: the rolled detector loop fits four waves per SIMD, and several small workgroups per CU overlap one
+  // group's start-up (table copy, barrier, first loads) with the others' arithmetic: two of eight waves -9 % at 256^2, -8 %
+  // at 512^2 against one of sixteen; four of four waves another -6 % at 128^2 / 256^2 (0 at 512^2; five of three and three
+  // of five: worse).  Twiddles read from global memory instead of staged (no barrier): +5 ... +12 %
+  // (profiles/r03_ab_packed_columns.txt)
+  static constexpr int WPC = D == 0 ? (L0 == 2 ? 8 : 4) : WPB;
   static constexpr int CMINB = D == 0 ? 4 : 1;             // waves per SIMD the column kernel's register budget is cut for
   static constexpr int OM_ROWS = L0 == 2 ? 2 : 0;
 };

@@ -56,7 +56,7 @@ def _window_W(Np, seed=0):
 
 
 # ------------------------------------------------------------------ generator
-@pytest.mark.parametrize("N", [16, 33, 512, 1024, 2048, 4096, 200, 1000, 1500, 2000])
+@pytest.mark.parametrize("N", [16, 33, 128, 256, 512, 1024, 2048, 4096, 200, 1000, 1500, 2000])
 def test_device_generator_matches_oracle_restatement(N):
     h = _lib.Handle(N, max(1, N // 4), "f64", 0)
     for seed, g in ((1, 0), (0xDEADBEEFCAFE, 5), (7, 2 ** 33 + 3)):
@@ -280,10 +280,11 @@ def _small_problem(N=512, Np=82, prec="f64", scale=0.02):
     return h, ps * scale, df, W
 
 
-@pytest.mark.parametrize("N", [64, 512, 1000, 1024, 2048, 4096])
+@pytest.mark.parametrize("N", [64, 128, 256, 512, 1000, 1024, 2048, 4096])
 def test_device_rng_run_matches_oracle_with_restated_generator(N):
     """2048 and 4096 run as 2 resp. 4 interleaved sub-rows of 1024 (split wave kernels), with 128 resp. 256
-    generator streams per row; the device result must follow the restated generator there too."""
+    generator streams per row; 128 / 256 / 512 as packed rows with 8 / 16 / 32 streams per row; the device result must
+    follow the restated generator there too."""
     Np = 22 if N == 64 else 82
     h, ps, df, W = _small_problem(N, Np)
     seed, real0, n = 42, 5, (4 if N <= 512 else 2)
@@ -294,7 +295,7 @@ def test_device_rng_run_matches_oracle_with_restated_generator(N):
     la = np.concatenate([chi[0::2], chi[1::2]])
     want = R.powers_from_coefficients(coeffs, ps, df, W, 0.01, la)
     np.testing.assert_allclose(got, want, rtol=DEVICE_RTOL)
-    if N in (512, 2048):
+    if N in (128, 256, 512, 2048):
         h.kernel_path(0)                               # the direct family draws the same streams
         np.testing.assert_allclose(h.run(seed, real0, n, None, 0.01), got, rtol=1e-9)
 

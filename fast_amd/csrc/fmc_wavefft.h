@@ -351,6 +351,9 @@ FMC_HD void pruned_row_fft_d16r(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>
 #pragma unroll
     for (int b0 = 0; b0 < 16; ++b0) r.v[b0] = t[brev(b0, 4)];
   });
+  // (Round 3 tried the two conflict-free forms of this exchange: aligned ds_write_b128 stores, rows +7 %; real and imaginary
+  // parts in two 8-byte images 512-byte multiples apart, rows +4.3 %, columns -1.5 %.  The ds_write2_b64 pairs with their
+  // 2-way store conflicts are the fastest form: profiles/r03_ab_fma_vs_aligned_stores.txt, r03_ab_split_exchange2_images.txt.)
   // float64 with a centred plane set (<= 8 planes, contiguous around b0 = 0): exchange 2 in ONE pass with 16-byte elements --
   // plane b0 at position p = (b0 + NP / 2) & 15 < NP, element (a, p, l0) at a + 16 p + 16 NP l0 (<= 512 elements of 16 bytes):
   // the table values are read once instead of once per component, two hand-offs instead of four.

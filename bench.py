@@ -66,7 +66,8 @@ def workload_params(args):
         "D_SAT": 0.1, "H_SAT": 36e6, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w,
         "WIND_DIR": np.array([0., 90., 180., 270.]), "L0": np.inf, "l0": 1e-6, "ZENITH_ANGLE": 55,
         "DTHETA": [4, 0], "AO_MODE": args.ao_mode, "DSUBAP": 0.1, "TLOOP": 1e-3, "TEXP": 1e-3, "ALIAS": True,
-        "NOISE": 0, "GPU_PRECISION": args.precision, "GPU_RNG": "device", "FFTW": True, "GPU_SHARD": False,
+        "NOISE": 0, "GPU_PRECISION": args.precision, "GPU_RNG": "device", "GPU_RNG_PRECISION": getattr(args, "rng_precision", "f32"),
+        "FFTW": True, "GPU_SHARD": False,
     }
 
 
@@ -271,20 +272,20 @@ def load_json(path):
         return None
 
 
-def roofline(args, N, Np, tim, steps, workers, iters_per_worker_step):
-    """The `roofline` object for the dominant kernel (k_rows_wave) of THIS run.  The kernel is bound by the SIMDs'
+def roofline(args, N, Np, tim, steps, workers, iters_per_worker_step, kernels=("", ""), counters="latest_counters.json"):
+    """The `roofline` object for the dominant kernel (the row kernel) of THIS run.  The kernel is bound by the SIMDs'
     instruction issue (float64 butterflies + the generator + LDS instructions), not by HBM or MFMA:
     `bound` says so, `achieved` / `frac` are executed float64 (float32) vector FLOP/s against the vector peak, `issue` the
-    share of the SIMDs' issue cycles the VALU instructions of the code object account for, `hbm` the byte models."""
+    share of the SIMDs' issue cycles the VALU instructions of the code object account for, `hbm` the byte models.
+    `kernels` = (rows, cols) names the library reports for what it launched (fastmc_last_kernels): the instruction counts are
+    those of THAT instantiation (fast_amd/kernel_isa_stats.json; split rows of 2048 / 4096: row loop + S passes of the sub-row loop)."""
     f64 = args.precision == "f64"
     launches = max(tim["rows_launches"], 1)
     avg_rows_ms = tim["rows_ms"] / launches
     avg_cols_ms = tim["cols_ms"] / max(tim["cols_launches"], 1)
     real_per_launch = iters_per_worker_step / 2 * steps * workers / launches        # realisations in an average launch
-    S = 4 if N == 4096 else (2 if N == 2048 else 1)
     isa = load_json(os.path.join(ROOT, "fast_amd", "kernel_isa_stats.json")) or {}
-    key = f"rows_{args.precision}_{N}"
-    st = isa.get(key) if S == 1 else None      # split rows loop over sub-rows inside the counted body: no static count
+    st = next((v for v in isa.values() if isinstance(v, dict) and v.get("kernel") == kernels[0]), None)
     wc = 16 if f64 else 8
     it_per_launch = 2 * real_per_launch
     bytes_alg = (20 if f64 else 10) * N * N                                     # SURVEY 8(d), per iteration
@@ -292,7 +293,7 @@ def roofline(args, N, Np, tim, steps, workers, iters_per_worker_step):
     # only), the column partials, the results; the float32 colouring table (4 N^2 B) stays in cache across a launch
     bytes_pruned_rows = wc * N * Np
     bytes_pruned_cols = wc * N * Np + 32 * Np + 8 * Np * Np / max(real_per_launch, 1)
-    out = {"bound": "valu", "kernel": "k_rows_wave", "avg_launch_ms": avg_rows_ms, "realisations_per_launch": real_per_launch,
+    out = {"bound": "valu", "kernel": kernels[0] or "unknown", "cols_kernel": kernels[1], "avg_launch_ms": avg_rows_ms, "realisations_per_launch": real_per_launch,
            "iterations_per_launch": it_per_launch, "peak": F64_VECTOR_PEAK_TFLOPS if f64 else F32_VECTOR_PEAK_TFLOPS,
            "unit": "TFLOP/s", "achieved": None, "frac": None, "traffic": None}
     if st:
@@ -319,8 +320,8 @@ def roofline(args, N, Np, tim, steps, workers, iters_per_worker_step):
     if hbm["cols"]["pruned_algorithmic_GBps"]:
         hbm["cols"]["frac_pruned"] = hbm["cols"]["pruned_algorithmic_GBps"] / HBM_PEAK_GBS
     # hardware counters of the same command, when a committed rocprofv3 summary belongs to this build
-    prof = load_json(os.path.join(ROOT, "profiles", "latest_counters.json"))
-    if prof and st and prof.get("precision") == args.precision and prof.get("npxls") == N:
+    prof = load_json(os.path.join(ROOT, "profiles", counters))
+    if prof and st and prof.get("precision") == args.precision and prof.get("npxls") == N and prof.get("rows_kernel", kernels[0]) == kernels[0]:
         if prof.get("rows_valu_instructions_per_row") == st["valu_total"]:
             for k in ("rows", "cols"):
                 c = prof.get(k, {})
@@ -345,6 +346,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--rng-precision", default="f32", choices=["f32", "f64"],
+                    help="device generator of the TIMED steps: f32 (default: float32 normals and colouring, the headline) or f64 (the "
+                         "reference's 53-bit normals and float64 colouring, fast/funcs.py:352-356; without this flag the same job is "
+                         "timed a second time at f64 and reported as value_f64_generator)")
     ap.add_argument("--npxls", type=int, default=None, help="grid size (default: 1024, or 2048 with --workload config3)")
     ap.add_argument("--ao-mode", default="NOAO")
     ap.add_argument("--workload", default="config1", choices=["config1", "config3"],
@@ -353,6 +358,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (f32, AO config, configs[3], configs[4])")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained run after the timed steps")
+    ap.add_argument("--no-f64-generator-pass", action="store_true", help="skip the second timed pass with the float64 generator")
     ap.add_argument("--batch", type=int, default=0, help="realisations per launch (0 = library default)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -471,6 +477,7 @@ def main():
         add_timing(tim)
     sync_all()
     dt = time.perf_counter() - t0
+    kernels = h.last_kernels()                                            # what the timed steps launched
     busy = np.asarray(busy, dtype=float).reshape(args.steps, -1)          # (steps, local workers)
     ex_dev = np.asarray(acc["exchange_device_ms"], dtype=float)
     ex_dev = ex_dev.reshape(len(acc["exchange_device_ms"]), -1) if ex_dev.size else np.zeros((0, 1))
@@ -504,6 +511,33 @@ def main():
             dts = float(rdzv.all_reduce(np.array([dts]), "max")[0])
         sustained = {"seconds": dts, "steps": n_sus, "value": iters_worker * n_sus * workers / dts, "unit": "iterations/s"}
 
+    # The same job with the generator at the REFERENCE's precision (53-bit normals, float64 colouring: fast/funcs.py:352-356,
+    # fast/fast.py:593-594), timed like the headline: same steps, same barriers, fresh realisation ranges.  Reported beside
+    # `value` as `value_f64_generator` with its own roofline; `--rng-precision f64` makes it the headline instead.
+    gen64 = None
+    if args.rng_precision == "f32" and args.precision == "f64" and not args.no_f64_generator_pass:
+        grp.each(lambda hh, i: hh.set_rng_precision("f64"))
+        first = args.warmup + args.steps + 100000
+        step(first)
+        busy_keep, busy = busy, []
+        tim64 = dict.fromkeys(tim_keys, 0.0)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out64 = step(first + 1 + i)
+            add_timing(tim64)
+        sync_all()
+        dt64 = time.perf_counter() - t0
+        kernels64 = h.last_kernels()
+        busy = busy_keep
+        if rdzv is not None:
+            dt64 = float(rdzv.all_reduce(np.array([dt64]), "max")[0])
+            for k in tim_keys:
+                tim64[k] = float(rdzv.all_reduce(np.array([tim64[k]]), "sum")[0])
+        assert np.isfinite(out64).all() and (out64 > 0).all()
+        gen64 = {"dt": dt64, "tim": tim64, "kernels": kernels64}
+        grp.each(lambda hh, i: hh.set_rng_precision("f32"))
+
     # GPUs that actually ran (one node: distinct device indices over all workers) and the communicator's own world size
     if mode == "ranks":
         n_devices = len(set(int(x) for x in rdzv.all_gather_array(np.array([devices[0]], dtype=np.int64)).ravel()))
@@ -528,11 +562,15 @@ def main():
             "metric": f"Monte-Carlo iterations/sec ({N}^2 grid)", "value": value, "unit": "iterations/s",
             "n_gpus": n_devices, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f64" if args.precision == "f64" else "f32", "data": "synthetic",
+            "dtype": ("f64" if args.rng_precision == "f64" else "f64 (f32 draw)") if args.precision == "f64" else "f32", "data": "synthetic",
             "config": {"workload": wl + f", {args.ao_mode} von Karman spectrum, device generator (Philox4x32-7-seeded xoshiro128+ streams, Box-Muller)",
                        "arithmetic": ("complex128 transform and float64 detector sums" if args.precision == "f64" else "complex64 transform, float64 detector sums")
-                                     + "; the device generator's normals are float32 (24-bit uniforms, hardware log/sqrt/sin/cos), "
-                                       "coloured in float32 and widened; host-coefficient (parity) mode is float64 throughout",
+                                     + ("; the device generator draws 53-bit normals and colours in float64 like the reference (fast/funcs.py:352-356, "
+                                        "fast/fast.py:593-594), fused into the row kernel" if args.rng_precision == "f64" else
+                                        "; the device generator's normals are float32 (24-bit uniforms, hardware log/sqrt/sin/cos), "
+                                        "coloured in float32 and widened: `value_f64_generator` is the same job at the reference's precision")
+                                     + "; host-coefficient (parity) mode is float64 throughout",
+                       "rng_precision": args.rng_precision,
                        "iters_per_step_per_gpu": iters_worker, "kernel_path": {0: "direct", 1: "wave-fft", 2: "chirp-z", 3: "lanes50-fft"}[h.kernel_path()],
                        "launch": {"single": "one process, one GPU", "threads": f"one process, {workers} worker threads",
                                   "ranks": f"{workers} processes (launcher), fast_amd.rendezvous"}[mode],
@@ -540,7 +578,8 @@ def main():
                        "parallelism": f"realisations sharded over {workers} worker(s) on {n_devices} GPU(s)", "result_exchange": exchange_name(),
                        "rccl_ranks": rccl_ranks,
                        "histogram_total": None if hist_total is None else int(np.sum(hist_total))},
-            "roofline": roofline(args, N, Np, tim, args.steps, workers, iters_worker),
+            "roofline": roofline(args, N, Np, tim, args.steps, workers, iters_worker, kernels,
+                                 "latest_counters_f64gen.json" if args.rng_precision == "f64" else "latest_counters.json"),
             "pipeline": {"gpu_busy_ms_per_step_per_worker": gpu_ms / args.steps / workers,
                          "gpu_busy_ms_per_step": {"min_worker": float(busy.mean(0).min()), "max_worker": float(busy.mean(0).max()),
                                                   "per_worker": [float(x) for x in busy.mean(0)]},
@@ -548,6 +587,14 @@ def main():
                          "cols_ms": tim["cols_ms"] / args.steps / workers, "finalize_ms": tim["finalize_ms"] / args.steps / workers,
                          "init_s": init_s, "powerspec_kernel_ms_warm": sim.powerspec_kernel_ms},
         }
+        if gen64:
+            line["value_f64_generator"] = total_iters / gen64["dt"]
+            line["f64_generator"] = {
+                "dtype": "f64", "ms_per_step": gen64["dt"] / args.steps * 1e3, "ratio_to_value": (total_iters / gen64["dt"]) / value,
+                "what": "the same steps with GPU_RNG_PRECISION 'f64': 53-bit normals (two xoshiro128+ streams), float64 log / sqrt / sincos "
+                        "(fast_amd/csrc/fmc_gen64.h), float64 colouring, fused into the row kernel -- the reference's arithmetic end to end",
+                "rows_ms": gen64["tim"]["rows_ms"] / args.steps / workers, "cols_ms": gen64["tim"]["cols_ms"] / args.steps / workers,
+                "roofline": roofline(args, N, Np, gen64["tim"], args.steps, workers, iters_worker, gen64["kernels"], "latest_counters_f64gen.json")}
         if exchange is not None:
             line["exchange"] = exchange
         if sustained:

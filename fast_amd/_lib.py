@@ -23,7 +23,8 @@ EXPORTS = [
     "fastmc_powerspec_terms", "fastmc_powerspec_set", "fastmc_powerspec_get",
     "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_init_all", "fastmc_comm_world", "fastmc_comm_gather",
     "fastmc_comm_gather_all", "fastmc_comm_destroy", "fastmc_comm_abort", "fastmc_last_exchange_ms",
-    "fastmc_run_async", "fastmc_wait", "fastmc_set_rng_precision", "fastmc_temporal_phases",
+    "fastmc_run_async", "fastmc_wait", "fastmc_set_rng_precision", "fastmc_temporal_phases", "fastmc_last_kernels",
+    "fastmc_precision", "fastmc_last_result_shape",
 ]
 
 
@@ -88,6 +89,9 @@ def lib():
     L.fastmc_last_timing.argtypes = [vp, dp, C.POINTER(i64)]
     L.fastmc_kernel_path.argtypes = [vp, C.c_int]
     L.fastmc_set_batch.argtypes = [vp, C.c_int]
+    L.fastmc_last_kernels.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
+    L.fastmc_precision.argtypes = [vp]
+    L.fastmc_last_result_shape.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_int)]
     L.fastmc_set_rng_precision.argtypes = [vp, C.c_int]
     L.fastmc_powerspec.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp, dp, dp]
     L.fastmc_powerspec_terms.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp]
@@ -205,15 +209,19 @@ class Handle:
         fetches them; an exchange (`comm_gather`, `_lib.comm_gather_all`) is ordered behind the kernels on the same
         stream, so a sharded step synchronises once."""
         _chk(lib().fastmc_run_async(self._h, int(seed) & (2 ** 64 - 1), int(real0), int(n_real), float(logamp_var), int(bool(coherent))))
-        self._async_shape = (int(n_real), bool(coherent))
 
     def wait(self, fetch=True):
         """Wait for the handle's stream; with fetch, return the results of the last run as `run` would have."""
         if not fetch:
             _chk(lib().fastmc_wait(self._h, None))
             return None
-        n_real, coherent = self._async_shape
-        out = np.empty(2 * n_real * (2 if coherent else 1), dtype=np.float64)
+        # the library says what is resident (after run, run_async or set_results alike): never a stale shape of our own
+        n_it, coh = C.c_int64(0), C.c_int(0)
+        _chk(lib().fastmc_last_result_shape(self._h, C.byref(n_it), C.byref(coh)))
+        if n_it.value <= 0:
+            raise FastMCError("wait(fetch=True): no results are resident on this handle")
+        coherent = bool(coh.value)
+        out = np.empty(n_it.value * (2 if coherent else 1), dtype=np.float64)
         _chk(lib().fastmc_wait(self._h, _dptr(out)))
         return out.view(np.complex128) if coherent else out
 
@@ -315,12 +323,22 @@ class Handle:
     def kernel_path(self, force=-1):
         return _chk(lib().fastmc_kernel_path(self._h, int(force)))
 
+    def last_kernels(self):
+        """(rows, cols): names of the row / column kernels the handle launched last, as c++filt prints them."""
+        r, c = C.create_string_buffer(128), C.create_string_buffer(128)
+        _chk(lib().fastmc_last_kernels(self._h, r, c, 128))
+        return r.value.decode(), c.value.decode()
+
+    def effective_precision(self):
+        """'f64' or 'f32': what the handle computes in (a float32 request on a grid without float32 kernels runs float64)."""
+        return {F64: "f64", F32: "f32"}[_chk(lib().fastmc_precision(self._h))]
+
     def set_batch(self, batch):
         _chk(lib().fastmc_set_batch(self._h, int(batch)))
 
     def set_rng_precision(self, precision):
-        """Device generator: 'f32' (default; fused into the row kernels) or 'f64' (the reference's 53-bit normals and
-        float64 colouring; draws staged in device memory)."""
+        """Device generator: 'f32' (default) or 'f64' (the reference's 53-bit normals and float64 colouring: fused into the
+        row kernels at 1024 / 2048 / 4096, staged in device memory on the other grids)."""
         _chk(lib().fastmc_set_rng_precision(self._h, {"f64": F64, "f32": F32}[precision]))
 
     # ---- RCCL (the communicator belongs to the handle's DEVICE and outlives the handle)

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -145,7 +146,9 @@ struct fastmc_ctx {
   double* gather_buf = nullptr;
   size_t gather_cap = 0;
   // fastmc_run_async: kernels enqueued, events not read yet (fastmc_wait / the exchange finish the bookkeeping)
-  int rng_f64 = 0;        // fastmc_set_rng_precision: the device generator at float64 precision (coefficients staged in cre / cim)
+  int rng_f64 = 0;        // fastmc_set_rng_precision: the device generator at float64 precision (fused into the P = 16 rows, else staged in cre / cim)
+  const Gen64Entry* g64 = nullptr;   // its log table on this device (gen64_table)
+  char last_rows[96] = "", last_cols[96] = "";   // the row / column kernels of the last launch, as c++filt prints them (fastmc_last_kernels)
   bool pending = false;
   size_t last_out_doubles = 0;    // size of the last run's result vector in `out`
   hipEvent_t ex_a = nullptr, ex_b = nullptr;   // around the collectives of the last exchange
@@ -458,7 +461,9 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   // back to the state fastmc_create leaves: problem unset, results forgotten, options at their defaults; buffers kept
   h->have_spec = h->have_pupil = h->have_sh = h->have_ps = false;
   h->last_n_iter = 0;
+  h->last_out_doubles = 0;
   h->last_coherent = 0;
+  h->last_rows[0] = h->last_cols[0] = 0;
   h->batch = 0;
   h->rng_f64 = 0;
   h->path = default_path(h->N, h->blu_P, h->mr_P);
@@ -501,6 +506,29 @@ extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
 #endif
 
 #if FMC_TU == 0
+extern "C" int fastmc_last_kernels(fastmc_t* h, char* rows, char* cols, int cap) {
+  if (!h || !rows || !cols || cap < 1) return fail(FASTMC_EINVAL, "null handle / buffers");
+  snprintf(rows, (size_t)cap, "%s", h->last_rows);
+  snprintf(cols, (size_t)cap, "%s", h->last_cols);
+  return 0;
+}
+
+// shape of the result vector resident on the device (what fastmc_wait copies): iterations, coherent flag; 0 iterations = none
+extern "C" int fastmc_last_result_shape(fastmc_t* h, int64_t* n_iter, int* coherent) {
+  if (!h || !n_iter || !coherent) return fail(FASTMC_EINVAL, "null handle / outputs");
+  *n_iter = h->last_out_doubles ? h->last_n_iter : 0;
+  *coherent = h->last_coherent;
+  return 0;
+}
+
+// the precision the handle computes in (fastmc_create promotes FASTMC_F32 to FASTMC_F64 on grids without float32 kernels)
+extern "C" int fastmc_precision(fastmc_t* h) {
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  return h->precision;
+}
+#endif
+
+#if FMC_TU == 0
 extern "C" int fastmc_set_batch(fastmc_t* h, int batch) {
   if (!h || batch < 0) return fail(FASTMC_EINVAL, "bad batch");
   h->batch = batch;
@@ -508,10 +536,33 @@ extern "C" int fastmc_set_batch(fastmc_t* h, int batch) {
 }
 #endif
 
+// The 128-entry log table of the float64 generator (fmc_gen64.h), one copy per device, uploaded on first use and kept.
+#if FMC_TU == 0
+static const Gen64Entry* gen64_table(int device) {
+  static std::mutex mu;
+  static std::map<int, Gen64Entry*> tabs;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = tabs.find(device);
+  if (it != tabs.end()) return it->second;
+  Gen64Entry host[GEN64_LOG_ENTRIES];
+  gen64_build_table(host);
+  Gen64Entry* d = nullptr;
+  if (hipMalloc((void**)&d, GEN64_TABLE_BYTES) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, host, GEN64_TABLE_BYTES, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
+  tabs[device] = d;
+  return d;
+}
+#endif
+
 #if FMC_TU == 0
 extern "C" int fastmc_set_rng_precision(fastmc_t* h, int precision) {
   if (!h || (precision != FASTMC_F64 && precision != FASTMC_F32)) return fail(FASTMC_EINVAL, "precision must be FASTMC_F64 or FASTMC_F32");
   h->rng_f64 = precision == FASTMC_F64;
+  if (h->rng_f64 && !h->g64) {
+    HIPCHK(hipSetDevice(h->device));
+    h->g64 = gen64_table(h->device);
+    if (!h->g64) return fail(FASTMC_EHIP, "could not upload the float64 generator's table");
+  }
   return 0;
 }
 #endif
@@ -798,14 +849,18 @@ extern "C" int fastmc_set_subharm(fastmc_t* h, const double* ps_sh, const double
 #endif
 
 // ------------------------------------------------------------------ launches
+// every launch leaves the name of its kernel on the handle (fastmc_last_kernels: bench.py prices the instruction mix of what ran)
+template <class R> static const char* rname() { return sizeof(R) == 8 ? "double" : "float"; }
+#define FMC_NOTE(dst, ...) snprintf(dst, sizeof(dst), __VA_ARGS__)
 template <class R, int P, int NS, int MODE, int S = 1, int D = 0>
 static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
-  const size_t lds = wave_lds_bytes_d<R, P, NS, D>(A.omS);
+  const size_t lds = wave_lds_bytes_d<R, P, NS, D>(A.omS) + (MODE == 2 ? GEN64_TABLE_BYTES : 0);   // fits for every P = 16 variant (fused_gen64)
   hipFuncSetAttribute((const void*)k_rows_wave<R, P, NS, MODE, S, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   constexpr int WPB = WCfg<R, P, NS, D>::WPB;
   constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
   const int blocks = (A.N / LR) * ((A.nb + BPG - 1) / BPG);
   hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE, S, D>), dim3(blocks), dim3(WPB * 64), lds, h->stream, A);
+  FMC_NOTE(h->last_rows, "k_rows_wave<%s, %d, %d, %d, %d, %d>", rname<R>(), P, NS, MODE, S, D);
 }
 template <class R, int P, int NS, int EPI, int S = 1, int D = 0>
 static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
@@ -814,6 +869,7 @@ static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
   constexpr int WPB = WCfg<R, P, NS, D>::WPB_COLS;
   const int items = A.nb * A.Np;
   hipLaunchKernelGGL((k_cols_wave<R, P, NS, EPI, S, D>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, A);
+  FMC_NOTE(h->last_cols, "k_cols_wave<%s, %d, %d, %d, %d, %d>", rname<R>(), P, NS, EPI, S, D);
 }
 
 // rows with MODE = mode, columns with EPI = epi of one (P, NS, S, D) variant
@@ -825,6 +881,10 @@ static void launch_wave_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<
     // (dispatch_pk) or the direct family, never the one-row-per-wave kernels, so MODE 0 is not instantiated for them
     if constexpr (S == 1 && pk_grid(64 * P)) launch_rows_wave<R, P, NS, 1, S, DR>(h, RA);
     else if (mode == 0) launch_rows_wave<R, P, NS, 0, S, DR>(h, RA);
+    else if (mode == 2) {
+      // the float64 generator fused into the row (run_impl: fused_gen64): P = 16 only (1024, and 2048 / 4096 as sub-rows)
+      if constexpr (sizeof(R) == 8 && P == 16) launch_rows_wave<R, P, NS, 2, S, DR>(h, RA);
+    }
     else launch_rows_wave<R, P, NS, 1, S, DR>(h, RA);
   }
   {
@@ -850,16 +910,16 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
         if constexpr (S == 1) {
           if (dense) { launch_wave_pair<R, 16, 2, 1, 4>(h, RA, CA, mode, epi); return; }
         } else {
-          if (dense && mode == 0) { launch_wave_pair<R, 16, 2, S, 4, 5>(h, RA, CA, 0, epi); return; }
+          if (dense && mode != 1) { launch_wave_pair<R, 16, 2, S, 4, 5>(h, RA, CA, mode, epi); return; }
         }
         launch_wave_pair<R, 16, 2, S, 5>(h, RA, CA, mode, epi);
         return;
       }
-      if (mode == 0 && epi == 0 && (win & ~D16R_WIDE_MASK) == 0) {     // centred windows of 97-128 pixels: eight of the sixteen planes
+      if (mode != 1 && epi == 0 && (win & ~D16R_WIDE_MASK) == 0) {     // centred windows of 97-128 pixels: eight of the sixteen planes
         if constexpr (S == 1) {
-          if (dense) { launch_wave_pair<R, 16, 2, 1, 8>(h, RA, CA, 0, 0); return; }
+          if (dense) { launch_wave_pair<R, 16, 2, 1, 8>(h, RA, CA, mode, 0); return; }
         }
-        launch_wave_pair<R, 16, 2, S, 6>(h, RA, CA, 0, 0);
+        launch_wave_pair<R, 16, 2, S, 6>(h, RA, CA, mode, 0);
         return;
       }
     }
@@ -887,9 +947,11 @@ static void launch_pk_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>
     if (mode == 0) {
       hipFuncSetAttribute((const void*)k_rows_pk<R, L0, 0, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_pk<R, L0, 0, D>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, RA);
+      FMC_NOTE(h->last_rows, "k_rows_pk<%s, %d, %d, %d>", rname<R>(), L0, 0, D);
     } else {
       hipFuncSetAttribute((const void*)k_rows_pk<R, L0, 1, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_pk<R, L0, 1, D>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, RA);
+      FMC_NOTE(h->last_rows, "k_rows_pk<%s, %d, %d, %d>", rname<R>(), L0, 1, D);
     }
   }
   {
@@ -898,9 +960,11 @@ static void launch_pk_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>
     if (epi == 0) {
       hipFuncSetAttribute((const void*)k_cols_pk<R, L0, 0, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
       hipLaunchKernelGGL((k_cols_pk<R, L0, 0, D>), dim3((items + per - 1) / per), dim3(C::WPC * 64), ldc, h->stream, CA);
+      FMC_NOTE(h->last_cols, "k_cols_pk<%s, %d, %d, %d>", rname<R>(), L0, 0, D);
     } else {
       hipFuncSetAttribute((const void*)k_cols_pk<R, L0, 1, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
       hipLaunchKernelGGL((k_cols_pk<R, L0, 1, D>), dim3((items + per - 1) / per), dim3(C::WPC * 64), ldc, h->stream, CA);
+      FMC_NOTE(h->last_cols, "k_cols_pk<%s, %d, %d, %d>", rname<R>(), L0, 1, D);
     }
   }
 }
@@ -925,9 +989,11 @@ static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
     if (mode == 0) {
       hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 0, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_blu<R, P, NS, 0, BLK>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      FMC_NOTE(h->last_rows, "k_rows_blu<%s, %d, %d, %d, %s>", rname<R>(), P, NS, 0, BLK ? "true" : "false");
     } else {
       hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 1, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_blu<R, P, NS, 1, BLK>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      FMC_NOTE(h->last_rows, "k_rows_blu<%s, %d, %d, %d, %s>", rname<R>(), P, NS, 1, BLK ? "true" : "false");
     }
   }
   {
@@ -936,9 +1002,11 @@ static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
     if (epi == 0) {
       hipFuncSetAttribute((const void*)k_cols_blu<R, P, NS, 0, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
       hipLaunchKernelGGL((k_cols_blu<R, P, NS, 0, BLK>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), ldc, h->stream, CA);
+      FMC_NOTE(h->last_cols, "k_cols_blu<%s, %d, %d, %d, %s>", rname<R>(), P, NS, 0, BLK ? "true" : "false");
     } else {
       hipFuncSetAttribute((const void*)k_cols_blu<R, P, NS, 1, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
       hipLaunchKernelGGL((k_cols_blu<R, P, NS, 1, BLK>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), ldc, h->stream, CA);
+      FMC_NOTE(h->last_cols, "k_cols_blu<%s, %d, %d, %d, %s>", rname<R>(), P, NS, 1, BLK ? "true" : "false");
     }
   }
 }
@@ -968,9 +1036,11 @@ static void launch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA,
     if (mode == 0) {
       hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 0, SPLIT, LN, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_mr<R, P, NS, 0, SPLIT, LN, PR>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      FMC_NOTE(h->last_rows, "k_rows_mr<%s, %d, %d, %d, %s, %d, %d>", rname<R>(), P, NS, 0, SPLIT ? "true" : "false", LN, PR);
     } else if constexpr (PR == 0) {
       hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 1, SPLIT, LN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_mr<R, P, NS, 1, SPLIT, LN, 0>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      FMC_NOTE(h->last_rows, "k_rows_mr<%s, %d, %d, %d, %s, %d, %d>", rname<R>(), P, NS, 1, SPLIT ? "true" : "false", LN, 0);
     }
   }
   {
@@ -979,9 +1049,11 @@ static void launch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA,
     if (epi == 0) {
       hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 0, SPLIT, LN, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_cols_mr<R, P, NS, 0, SPLIT, LN, PR>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+      FMC_NOTE(h->last_cols, "k_cols_mr<%s, %d, %d, %d, %s, %d, %d>", rname<R>(), P, NS, 0, SPLIT ? "true" : "false", LN, PR);
     } else if constexpr (PR == 0) {
       hipFuncSetAttribute((const void*)k_cols_mr<R, P, NS, 1, SPLIT, LN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_cols_mr<R, P, NS, 1, SPLIT, LN, 0>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, CA);
+      FMC_NOTE(h->last_cols, "k_cols_mr<%s, %d, %d, %d, %s, %d, %d>", rname<R>(), P, NS, 1, SPLIT ? "true" : "false", LN, 0);
     }
   }
 }
@@ -1137,9 +1209,11 @@ int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA
     if (mode == 0) {
       hipFuncSetAttribute((const void*)k_rows_direct<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_direct<R, 0>), dim3(RA.nb * h->N), dim3(DIRECT_THREADS), lds, h->stream, RA);
+      FMC_NOTE(h->last_rows, "k_rows_direct<%s, %d>", rname<R>(), 0);
     } else {
       hipFuncSetAttribute((const void*)k_rows_direct<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_direct<R, 1>), dim3(RA.nb * h->N), dim3(DIRECT_THREADS), lds, h->stream, RA);
+      FMC_NOTE(h->last_rows, "k_rows_direct<%s, %d>", rname<R>(), 1);
     }
   }
   {
@@ -1147,9 +1221,11 @@ int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA
     if (epi == 0) {
       hipFuncSetAttribute((const void*)k_cols_direct<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_cols_direct<R, 0>), dim3(CA.nb * h->Np), dim3(DIRECT_THREADS), lds, h->stream, CA);
+      FMC_NOTE(h->last_cols, "k_cols_direct<%s, %d>", rname<R>(), 0);
     } else {
       hipFuncSetAttribute((const void*)k_cols_direct<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_cols_direct<R, 1>), dim3(CA.nb * h->Np), dim3(DIRECT_THREADS), lds, h->stream, CA);
+      FMC_NOTE(h->last_cols, "k_cols_direct<%s, %d>", rname<R>(), 1);
     }
   }
   return 0;
@@ -1250,14 +1326,29 @@ struct RunSpec {
   bool async = false;       // fastmc_run_async: no host copy, no wait
 };
 
+// Does this handle's row kernel draw the float64 generator itself (MODE 2)?  The P = 16 rows of the wave family: 1024, and
+// 2048 / 4096 as sub-rows, float64 pipeline, any window the family serves (every variant's tables + the 2 KB log table fit the
+// LDS: 151.5 KB + 64 omS <= 160 KB for the sixteen-wave variants, whose omS <= 128; 126 KB + 64 omS for the twelve-wave ones).
+template <class R>
+static bool fused_gen64(fastmc_ctx* h) {
+  if constexpr (sizeof(R) != 8) return false;
+  if (h->path != 1 || h->P != 16 || wave_rt_split(h->N)) return false;
+  if (getenv("FASTMC_GEN64_STAGED")) return false;          // A/B: the round-3 form (k_gen_coeffs_f64 -> cre / cim -> MODE 1 rows)
+  int ns = 0, wpb = 0;
+  wave_config<R>(h, &ns, &wpb);
+  return ns == 2 || ns == 4 || ns == 8;      // not the whole-grid window (NS = P: its tables leave no room, and nothing draws into it)
+}
+
 template <class R>
 static int run_impl(fastmc_ctx* h, const RunSpec& S) {
   const int N = h->N, Np = h->Np;
   const size_t N2 = (size_t)N * N;
   int B = default_batch(h);
   // device generator at float64 precision: the draws of a batch are staged like uploaded coefficients (16 B each), <= 2 GiB
-  const bool gen64 = S.mode == 0 && h->rng_f64;
-  const int kmode = (S.mode == 1 || gen64) ? 1 : 0;           // MODE of the row kernels
+  // ... fused into the row kernels where they have the form (MODE 2: no coefficient passes through HBM), staged otherwise
+  const bool fused64 = S.mode == 0 && h->rng_f64 && fused_gen64<R>(h);
+  const bool gen64 = S.mode == 0 && h->rng_f64 && !fused64;
+  const int kmode = fused64 ? 2 : ((S.mode == 1 || gen64) ? 1 : 0);           // MODE of the row kernels
   if (S.mode == 1) B = std::max(1, std::min<int>(B, (int)(256.0 * 1024 * 1024 / (N2 * 8.0))));
   if (gen64) B = std::max(1, std::min<int>(B, (int)(2048.0 * 1024 * 1024 / (N2 * 16.0))));
   if (S.epi == 1) B = std::max(1, std::min<int>(B, (int)(256.0 * 1024 * 1024 / (2.0 * Np * Np * 8.0))));
@@ -1318,7 +1409,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       Span sg(h, 0);     // counted with the row pass: in float32 mode the generator is part of the row kernel
       const int64_t threads = (int64_t)nb * N * stream_lanes(N);
       hipLaunchKernelGGL(k_gen_coeffs_f64, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream, key, (uint64_t)(S.real0 + bs), nb, N,
-                         h->cre, h->cim);
+                         h->g64, h->cre, h->cim);
     }
     if (sh) {
       ShCoefArgs SA;
@@ -1339,7 +1430,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     RA.N = N; RA.Np = Np; RA.lo = h->lo; RA.nb = nb;
     RA.om = (const cpx<R>*)h->om; RA.omS = h->omS;
     RA.V = (cpx<R>*)h->V; RA.key = key; RA.g0 = (uint64_t)(S.real0 + bs);
-    RA.cre = h->cre; RA.cim = h->cim;
+    RA.cre = h->cre; RA.cim = h->cim; RA.g64 = h->g64;
     ColArgs<R> CA;
     CA.N = N; CA.Np = Np; CA.lo = h->lo; CA.nb = nb;
     CA.V = (const cpx<R>*)h->V; CA.om = RA.om; CA.omS = h->omS;
@@ -1532,7 +1623,7 @@ extern "C" int fastmc_rng_coeffs(fastmc_t* h, uint64_t seed, int64_t real, doubl
   ScratchBuf d;
   HIPCHK(hipMalloc((void**)&d.p, (size_t)N * N * 16));
   RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};
-  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * stream_lanes(N) + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, h->rng_f64, d.p);
+  hipLaunchKernelGGL(k_rng_coeffs, dim3((N * stream_lanes(N) + 255) / 256), dim3(256), 0, h->stream, key, (uint64_t)real, N, h->rng_f64, h->g64, d.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, d.p, (size_t)N * N * 16, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));

@@ -18,6 +18,7 @@
 #include "fmc_wavefft.h"
 #include "fmc_bluestein.h"
 #include "fmc_mrfft.h"
+#include "fmc_gen64.h"
 
 namespace fmc {
 
@@ -88,6 +89,25 @@ __device__ __forceinline__ void box_muller_f64(uint32_t a, uint32_t b, uint32_t 
   im = r * sn;
 }
 
+// The same draw in ~90 instructions (fmc_gen64.h): table-driven log, v_rsq_f32-seeded Newton sqrt, fdlibm kernels for the
+// angle -- what the row kernels run in MODE 2, the staging kernel and the read-back.  `tab`: the 128-entry log table, in the
+// LDS (row kernels) or in global memory.
+template <class TabPtr>
+__device__ __forceinline__ cpx<double> draw_coloured_f64(xoshiro128p& s, xoshiro128p& slo, double amp, TabPtr tab) {
+  uint32_t a, b, a2, b2;
+  s.next2(a, b);
+  slo.next2(a2, b2);
+  cpx<double> c;
+  box_muller_f64_fast(a, b, a2, b2, amp, tab, c.x, c.y);
+  return c;
+}
+// stage the log table of the float64 generator into the LDS (2 KB; the caller's barrier follows)
+__device__ __forceinline__ void load_gen64_table(Gen64Entry* s_tab, const Gen64Entry* g) {
+  double* d = reinterpret_cast<double*>(s_tab);
+  const double* sgl = reinterpret_cast<const double*>(g);
+  for (int i = threadIdx.x; i < 2 * GEN64_LOG_ENTRIES; i += blockDim.x) d[i] = sgl[i];
+}
+
 // both Box-Muller words of a coefficient from ONE state advance (9 instead of 16 integer operations)
 __device__ __forceinline__ void draw_words(xoshiro128p& s, uint32_t& a, uint32_t& b) { s.next2(a, b); }
 template <class R>
@@ -153,6 +173,7 @@ struct RowArgs {
   const double* cre;            // host-coefficient mode: [nb][N][N] real parts
   const double* cim;
   BluArgs<R> blu;               // chirp-z family only
+  const Gen64Entry* g64;        // float64 generator (MODE 2): its 128-entry log table (fmc_gen64.h)
 };
 
 struct SubharmArgs {
@@ -434,9 +455,12 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = WaveGeom<R, P>;
   using E = typename Xch<R>::E;
-  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  // MODE 2 (float64 generator fused into the row): its 2 KB log table at the start of the LDS (a table offset IS the address)
+  Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
   cpx<R>* s_om = s_tw + P * WAVE;
   E* s_x = reinterpret_cast<E*>(s_om + WCfg<R, P, NS, D>::OM_ROWS * A.omS);
+  if constexpr (MODE == 2) load_gen64_table(s_g64, A.g64);
   load_tables<R, P, WCfg<R, P, NS, D>::OM_ROWS>(s_tw, s_om, A.tw, A.om, A.omS);
 
   // the wave index is wave-uniform: in an SGPR, so that row / realisation indices and the table base addresses
@@ -484,6 +508,25 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
         xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
 #pragma unroll
         for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[sp + S * (lane + WAVE * j)]);
+      } else if constexpr (MODE == 2) {
+        // the generator at the reference's precision (fast/funcs.py:352-356, fast/fast.py:593-594): 53-bit normals, float64
+        // colouring; the low bits from the second stream of the same (g, ky, L)
+        static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
+        xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S), rl = row_stream_lo(A.key, g, ky, sp + S * lane, WAVE * S);
+        // one coefficient at a time, its colouring factor loaded one draw ahead: left alone the compiler issues the sixteen
+        // float64 table loads (32 VGPRs) before the first draw and spills
+        double an = (double)amp[sp + S * lane];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          const double a = an;
+          if (j + 1 < P) an = (double)amp[sp + S * (lane + WAVE * (j + 1))];
+          ex.loadfence();
+          regs.v[j] = draw_coloured_f64(rs, rl, a, s_g64);
+          // the draws one after the other: a finished coefficient and the two stream states are pinned here, so that no
+          // arithmetic of draw j + 1 starts (and holds registers) before draw j has retired its temporaries
+          asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3), "+v"(rl.s0), "+v"(rl.s1),
+                       "+v"(rl.s2), "+v"(rl.s3));
+        }
       } else {
         const size_t base = ((size_t)b * N + ky) * N;
 #pragma unroll
@@ -1598,7 +1641,7 @@ __global__ void k_link_final(const double* partial, int nblocks, int64_t n, cons
 }
 
 // ================================================================== generator read-back (parity tests)
-__global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, int rng_f64, double* out) {
+__global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, int rng_f64, const Gen64Entry* g64, double* out) {
   const int SL = stream_lanes(N);
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * SL) return;
@@ -1608,10 +1651,7 @@ __global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, int rng_f64, double*
   for (int kx = l; kx < N; kx += SL) {
     cpx<double> c;
     if (rng_f64) {
-      uint32_t a, b, a2, b2;
-      draw_words(rs, a, b);
-      draw_words(rlo, a2, b2);
-      box_muller_f64(a, b, a2, b2, c.x, c.y);
+      c = draw_coloured_f64(rs, rlo, 1.0, g64);     // the arithmetic of the fused rows (MODE 2), bit for bit
     } else {
       c = draw_coeff<double>(rs);
     }
@@ -1622,8 +1662,12 @@ __global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, int rng_f64, double*
 
 // GPU_RNG_PRECISION 'f64': the coefficients of nb realisations at float64 precision, written where host-coefficient mode
 // keeps its uploads ([nb][N][N] real parts, imaginary parts); the MODE 1 kernels then colour them in float64 as the
-// reference does (fast/fast.py:594).  One thread per stream, neighbouring threads neighbouring columns.
-__global__ __launch_bounds__(256) void k_gen_coeffs_f64(RngKey key, uint64_t g0, int nb, int N, double* cre, double* cim) {
+// reference does (fast/fast.py:594).  One thread per stream, neighbouring threads neighbouring columns.  Only the kernel
+// families without a fused form (MODE 2 of the row kernels) take this detour through HBM.
+__global__ __launch_bounds__(256) void k_gen_coeffs_f64(RngKey key, uint64_t g0, int nb, int N, const Gen64Entry* g64, double* cre, double* cim) {
+  __shared__ Gen64Entry s_g64[GEN64_LOG_ENTRIES];
+  load_gen64_table(s_g64, g64);
+  __syncthreads();
   const int SL = stream_lanes(N);
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)nb * N * SL) return;
@@ -1633,13 +1677,9 @@ __global__ __launch_bounds__(256) void k_gen_coeffs_f64(RngKey key, uint64_t g0,
   xoshiro128p rs = row_stream(key, g, ky, l, SL), rlo = row_stream_lo(key, g, ky, l, SL);
   const size_t base = ((size_t)b * N + ky) * N;
   for (int kx = l; kx < N; kx += SL) {
-    uint32_t a, bb, a2, b2;
-    draw_words(rs, a, bb);
-    draw_words(rlo, a2, b2);
-    double re, im;
-    box_muller_f64(a, bb, a2, b2, re, im);
-    cre[base + kx] = re;
-    cim[base + kx] = im;
+    const cpx<double> c = draw_coloured_f64(rs, rlo, 1.0, s_g64);
+    cre[base + kx] = c.x;
+    cim[base + kx] = c.y;
   }
 }
 

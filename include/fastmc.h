@@ -195,6 +195,21 @@ int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches);
  * force: -1 query only, 0 / 1 / 2 / 3 select (fails with EINVAL if the family does not serve this (N, Np)). */
 int fastmc_kernel_path(fastmc_t* h, int force);
 
+/* Names of the row and column kernels the handle launched last, as c++filt prints the instantiations (e.g.
+ * "k_rows_wave<double, 16, 2, 0, 1, 4>"; empty before the first run): bench.py prices the instruction mix of what actually
+ * ran (fast_amd/kernel_isa_stats.json is keyed by these names).  rows / cols: caller's buffers of `cap` bytes each. */
+int fastmc_last_kernels(fastmc_t* h, char* rows, char* cols, int cap);
+
+/* Shape of the result vector resident on the device -- what fastmc_wait copies out: *n_iter iterations (0: no results yet),
+ * *coherent != 0: complex amplitudes (2 doubles per iteration).  Lets a caller size the buffer it hands to fastmc_wait after
+ * any of fastmc_run / fastmc_run_async / fastmc_set_results. */
+int fastmc_last_result_shape(fastmc_t* h, int64_t* n_iter, int* coherent);
+
+/* The precision the handle COMPUTES in: FASTMC_F64 or FASTMC_F32.  fastmc_create honours FASTMC_F32 on the wave family's
+ * fixed grids and the direct family only; a float32 request on a chirp-z, 50-lane or run-time-split grid runs the float64
+ * kernels, and this getter says so. */
+int fastmc_precision(fastmc_t* h);
+
 /* Realisations in flight per launch (batch).  0 = library default. */
 int fastmc_set_batch(fastmc_t* h, int batch);
 
@@ -202,9 +217,10 @@ int fastmc_set_batch(fastmc_t* h, int batch);
  * fastmc_create fixes).  FASTMC_F32 (default): 24-bit uniforms, hardware float32 log / sqrt / sin / cos, float32
  * colouring, fused into the row kernels.  FASTMC_F64: the reference's precision (fast/funcs.py:352-356 draws 53-bit normals,
  * fast/fast.py:594 colours in float64): the same streams with the low bits from a second stream, float64 log / sqrt /
- * sincospi, the draws of a batch staged in device memory and coloured in float64 by the host-coefficient kernels -- about
- * four times slower, there so that the price of the float32 shortcut is a measured number (bench.py extras).  Both
- * restated in oracle/devrng.py.  fastmc_rng_coeffs / fastmc_rng_logamp return the draws of the precision in force. */
+ * sincos in ~90 instructions per coefficient (fast_amd/csrc/fmc_gen64.h: table-driven log, seeded Newton square root,
+ * fdlibm kernels; draws within 3e-15 of the libm restatement), FUSED into the row kernels of the 1024 / 2048 / 4096 grids
+ * (no coefficient passes through device memory: about half the float32 generator's rate) and staged through device memory
+ * for the other kernel families (coloured in float64 by the host-coefficient kernels).  Both restated in oracle/devrng.py.  fastmc_rng_coeffs / fastmc_rng_logamp return the draws of the precision in force. */
 int fastmc_set_rng_precision(fastmc_t* h, int precision);
 
 /* ---- AO-residual power spectrum (Fast.compute_powerspec, fast/fast.py:445-492) ---- */

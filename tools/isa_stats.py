@@ -40,7 +40,12 @@ KERNELS = {
     "rows_f64_1024_12waves": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 5>(",
     "rows_f64_2048": "void fmc::k_rows_wave<double, 16, 2, 0, 2, 4>(",
     "cols_f64_2048": "void fmc::k_cols_wave<double, 16, 2, 0, 2, 5>(",
+    # the float64 generator fused into the row (MODE 2; round 4)
+    "rows_f64_1024_gen64": "void fmc::k_rows_wave<double, 16, 2, 2, 1, 4>(",
+    "rows_f64_2048_gen64": "void fmc::k_rows_wave<double, 16, 2, 2, 2, 4>(",
 }
+# sub-rows per row of the split-row kernels: their row loop contains the sub-row loop, counted as outer + S x inner
+SUB_ROWS = {"rows_f64_2048": 2, "rows_f64_2048_gen64": 2}
 
 # --packed: the packed rows of the small grids (translation unit 10; unit = G rows / columns of one wavefront)
 PACKED_KERNELS = {
@@ -126,6 +131,23 @@ def main_loop(lines):
     return best if best and best[1] - best[0] > 200 else (0, len(lines) - 1)
 
 
+def inner_loop(lines, a, b):
+    """(start, end) of the longest backward-branch span strictly inside (a, b), or None: the sub-row loop of a split row."""
+    labels = {}
+    for i in range(a, b + 1):
+        m = re.match(r"^(\.LBB\w+):", lines[i])
+        if m:
+            labels[m.group(1)] = i
+    best = None
+    for i in range(a, b):
+        m = re.match(r"\s+s_c?branch\w*\s+(\.LBB\w+)", lines[i])
+        if m and m.group(1) in labels and a < labels[m.group(1)] < i:
+            span = (labels[m.group(1)], i)
+            if best is None or span[1] - span[0] > best[1] - best[0]:
+                best = span
+    return best if best and best[1] - best[0] > 200 else None
+
+
 def count(lines):
     mix, by_class, flops, flops32 = collections.Counter(), collections.Counter(), 0, 0
     for l in lines:
@@ -175,11 +197,25 @@ def main():
         a, b = main_loop(lines)
         if tag.startswith("cols"):
             a, b = 0, len(lines) - 1          # one column per wave: the whole body (its small loops are the table load)
-        mix, by_class, flops, flops32 = count(lines[a:b + 1])
+        S = SUB_ROWS.get(tag, 1)
+        inner = inner_loop(lines, a, b) if S > 1 else None
+        if inner:
+            # one row = the row loop's own instructions + S passes through the sub-row loop
+            ia, ib = inner
+            mo, co, fo, f32o = count(lines[a:ia] + lines[ib + 1:b + 1])
+            mi, ci, fi, f32i = count(lines[ia:ib + 1])
+            mix = mo + collections.Counter({k: S * v for k, v in mi.items()})
+            by_class = co + collections.Counter({k: S * v for k, v in ci.items()})
+            flops, flops32 = fo + S * fi, f32o + S * f32i
+        else:
+            mix, by_class, flops, flops32 = count(lines[a:b + 1])
         valu = sum(v for k, v in by_class.items() if k.startswith("valu"))
         result[tag] = {"kernel": prefix.rstrip("(").replace("void fmc::", ""), "unit": "one row (rows) / one column (cols) per wave",
                        "instructions": dict(by_class), "valu_total": valu, "f64_flop_per_lane": flops, "f32_flop_per_lane": flops32,
                        "loop_lines": [a, b], "body_lines": len(lines)}
+        if inner:
+            result[tag]["sub_rows"] = S
+            result[tag]["sub_row_loop_lines"] = list(inner)
         print(f"{tag:16s} VALU {valu:5d}  " + "  ".join(f"{k} {v}" for k, v in sorted(by_class.items())) + f"  f64 flop/lane {flops}")
         if args.top:
             print("   ", ", ".join(f"{m} {n}" for m, n in mix.most_common(args.top)))

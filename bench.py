@@ -272,7 +272,7 @@ def load_json(path):
         return None
 
 
-def roofline(args, N, Np, tim, steps, workers, iters_per_worker_step, kernels=("", ""), counters="latest_counters.json"):
+def roofline(args, N, Np, tim, steps, workers, iters_per_worker_step, kernels=("", "")):
     """The `roofline` object for the dominant kernel (the row kernel) of THIS run.  The kernel is bound by the SIMDs'
     instruction issue (float64 butterflies + the generator + LDS instructions), not by HBM or MFMA:
     `bound` says so, `achieved` / `frac` are executed float64 (float32) vector FLOP/s against the vector peak, `issue` the
@@ -320,8 +320,11 @@ def roofline(args, N, Np, tim, steps, workers, iters_per_worker_step, kernels=("
     if hbm["cols"]["pruned_algorithmic_GBps"]:
         hbm["cols"]["frac_pruned"] = hbm["cols"]["pruned_algorithmic_GBps"] / HBM_PEAK_GBS
     # hardware counters of the same command, when a committed rocprofv3 summary belongs to this build
-    prof = load_json(os.path.join(ROOT, "profiles", counters))
-    if prof and st and prof.get("precision") == args.precision and prof.get("npxls") == N and prof.get("rows_kernel", kernels[0]) == kernels[0]:
+    # (profiles/latest_counters*.json: one file per profiled row kernel -- headline, float64 generator, 2048^2 ...)
+    import glob
+    profs = [load_json(f) for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "latest_counters*.json")))]
+    prof = next((q for q in profs if q and q.get("rows_kernel") == kernels[0] and q.get("npxls") == N), None)
+    if prof and st and prof.get("precision") == args.precision:
         if prof.get("rows_valu_instructions_per_row") == st["valu_total"]:
             for k in ("rows", "cols"):
                 c = prof.get(k, {})
@@ -578,8 +581,7 @@ def main():
                        "parallelism": f"realisations sharded over {workers} worker(s) on {n_devices} GPU(s)", "result_exchange": exchange_name(),
                        "rccl_ranks": rccl_ranks,
                        "histogram_total": None if hist_total is None else int(np.sum(hist_total))},
-            "roofline": roofline(args, N, Np, tim, args.steps, workers, iters_worker, kernels,
-                                 "latest_counters_f64gen.json" if args.rng_precision == "f64" else "latest_counters.json"),
+            "roofline": roofline(args, N, Np, tim, args.steps, workers, iters_worker, kernels),
             "pipeline": {"gpu_busy_ms_per_step_per_worker": gpu_ms / args.steps / workers,
                          "gpu_busy_ms_per_step": {"min_worker": float(busy.mean(0).min()), "max_worker": float(busy.mean(0).max()),
                                                   "per_worker": [float(x) for x in busy.mean(0)]},
@@ -594,7 +596,7 @@ def main():
                 "what": "the same steps with GPU_RNG_PRECISION 'f64': 53-bit normals (two xoshiro128+ streams), float64 log / sqrt / sincos "
                         "(fast_amd/csrc/fmc_gen64.h), float64 colouring, fused into the row kernel -- the reference's arithmetic end to end",
                 "rows_ms": gen64["tim"]["rows_ms"] / args.steps / workers, "cols_ms": gen64["tim"]["cols_ms"] / args.steps / workers,
-                "roofline": roofline(args, N, Np, gen64["tim"], args.steps, workers, iters_worker, gen64["kernels"], "latest_counters_f64gen.json")}
+                "roofline": roofline(args, N, Np, gen64["tim"], args.steps, workers, iters_worker, gen64["kernels"])}
         if exchange is not None:
             line["exchange"] = exchange
         if sustained:

@@ -24,7 +24,8 @@ def test_bench_json_line_contract():
               "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    # the headline draws float32 normals; the dtype says so, and the same job at the reference's precision sits beside it
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64 (f32 draw)" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"] and "float32" in d["config"]["arithmetic"]
     r = d["roofline"]
     # the kernel is bound by vector-instruction issue: the fraction is executed float64 FLOP/s over the vector peak
@@ -42,3 +43,28 @@ def test_bench_json_line_contract():
             assert hbm["rows"]["frac_counter"] <= 1.0
     assert d["value"] > 1e5 and abs(d["value"] - 10000 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-3 * d["value"]
     assert d["pipeline"]["powerspec_kernel_ms_warm"] < 2.0        # not the first-launch artefact
+    # the kernel named is the one that ran, and the traffic figure belongs to a committed profile of that kernel
+    assert r["kernel"] == "k_rows_wave<double, 16, 2, 0, 1, 4>" and r["cols_kernel"] == "k_cols_wave<double, 16, 2, 0, 1, 4>"
+    assert r["traffic"] is not None and r["traffic"] < 1.5 * 16 * 1024 * 82 * r["realisations_per_launch"]
+    # float64 generator (fast/funcs.py:352-356 precision), fused into the row kernel: its own value and roofline
+    g = d["f64_generator"]
+    assert d["value_f64_generator"] > 3e5 and g["dtype"] == "f64" and 0.3 < g["ratio_to_value"] < 1.0
+    rg = g["roofline"]
+    assert rg["kernel"] == "k_rows_wave<double, 16, 2, 2, 1, 4>" and rg["achieved"] is not None and 0.1 < rg["frac"] <= 1.0
+    assert rg["issue"]["valu_instructions_per_row"] > 1500 and 0.3 < rg["issue"]["frac"] <= 1.0
+
+
+def test_bench_config3_has_a_roofline():
+    """BASELINE configs[3] (2048^2, 100 000 iterations per step): the split rows have static instruction counts too."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--workload", "config3",
+                          "--no-cpu-baseline", "--no-extras", "--no-sustained", "--no-f64-generator-pass"], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and "2048" in d["metric"]
+    r = d["roofline"]
+    assert r["kernel"] == "k_rows_wave<double, 16, 2, 0, 2, 4>"
+    assert r["achieved"] is not None and r["frac"] is not None and 0.05 < r["frac"] <= 1.0
+    assert r["traffic"] is not None and r["traffic"] > 0
+    assert r["issue"]["valu_instructions_per_row"] > 1200        # two sub-rows of 1024 points + the combine

@@ -88,7 +88,7 @@ if len(sys.argv) > 2:
     doc = {"source": f"profiles/{os.path.basename(sys.argv[2]).replace('_counters.json', '')}_* (tools/profile_gpu.sh: rocprofv3 --kernel-trace --stats, "
                      "separate --pmc passes FETCH_SIZE / WRITE_SIZE / SQ; per-dispatch averages)",
            "precision": prec, "npxls": npx,
-           "rows_valu_instructions_per_row": isa.get(f"rows_{prec}_{npx}", {}).get("valu_total"),
+           "rows_valu_instructions_per_row": None,
            "fetch_correction": "x2 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section)"}
     # the row / column kernels of the profiled grid: the packed rows on 128 / 256 / 512, else the one-row-per-wave kernels
     rows_k = "k_rows_pk" if _kernel_ms("k_rows_pk")[0] else "k_rows_wave"
@@ -100,6 +100,12 @@ if len(sys.argv) > 2:
         if fetch is not None and write is not None:
             ent["hbm_bytes_per_launch"] = (2 * fetch + write) * 1024
         doc[tag] = ent
+    # the instruction counts of exactly the row kernel that was profiled (bench.py matches counters to a run by this name)
+    doc["rows_kernel"] = (doc["rows"].get("kernel") or "").strip()
+    doc["cols_kernel"] = (doc["cols"].get("kernel") or "").strip()
+    st = next((v for v in isa.values() if isinstance(v, dict) and v.get("kernel") == doc["rows_kernel"]), None)
+    if st:
+        doc["rows_valu_instructions_per_row"] = st["valu_total"]
     grbm = _avg("pmc_sq2", "GRBM_GUI_ACTIVE", rows_k)
     if grbm:
         simd_cycles = grbm / 8 * 1024          # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs

@@ -42,6 +42,22 @@ def _oracle_powers_from_device_draws(h, seed, real0, n, ps, df, W, lo, dx, logam
     return R.detector(phs, W, dx, la)
 
 
+def _oracle_powers_from_restated_draws(seed, real0, n, ps, df, W, lo, dx, logamp_var):
+    """The same, with nothing read back from the device: the draws are the ORACLE's float64 restatement of the generator
+    (oracle/devrng.device_coefficients, pinned to Random123 / xoshiro known answers), coloured in float64.  The device draws
+    with hardware float32 log / sqrt / sin / cos and colours in float32: the two agree to ~1e-7 per coefficient."""
+    N, Np = ps.shape[0], W.shape[0]
+    amp = np.sqrt(ps) * df
+    re, im = [], []
+    for j in range(n):
+        z = R.screens_fftw(devrng.device_coefficients(seed, real0 + j, N) * amp, 1.0)[lo:lo + Np, lo:lo + Np]
+        re.append(z.real)
+        im.append(z.imag)
+    chi = devrng.device_logamp_normals(seed, 2 * real0, 2 * n) * np.sqrt(logamp_var)
+    la = np.concatenate([chi[0::2], chi[1::2]])
+    return R.detector(np.stack(re + im), W, dx, la)
+
+
 def _vk_spectrum(N, dx, L0=np.inf):
     g = R.main_grid(N, dx)
     ps = R.von_karman(g.fabs, np.array([3e-13, 1e-13]), L0, 1e-3).sum(0) * 2 * np.pi * (2 * np.pi / 1550e-9) ** 2
@@ -1115,11 +1131,17 @@ def test_every_device_mode_row_variant_matches_the_oracle(N, Np, lo, prec):
     h.set_pupil(W, lo, 0.01)
     seed, real0, n = 2026, 7, (2 if N <= 1536 else 1)
     got = h.run(seed, real0, n, None, 0.01)
-    want = _oracle_powers_from_device_draws(h, seed, real0, n, ps, df, W, lo, 0.01, 0.01)
+    # (1) against the RESTATEMENT of the generator: nothing in `want` comes from the device, so a variant whose fused draw and
+    #     read-back agreed with each other and both differed from the definition would fail here
+    want = _oracle_powers_from_restated_draws(seed, real0, n, ps, df, W, lo, 0.01, 0.01)
     assert (want > 1e-3).all()                                  # few-radian screens: no deep fade amplifies the rounding
     np.testing.assert_allclose(got, want, rtol=DEVICE_RTOL if prec == "f64" else 2e-4)
+    # (2) against the oracle on the device's own read-back draws (fastmc_rng_coeffs, float32 colouring as the kernels colour):
+    #     tighter, because the hardware transcendentals' ~1e-7 cancels
+    want_rb = _oracle_powers_from_device_draws(h, seed, real0, n, ps, df, W, lo, 0.01, 0.01)
+    np.testing.assert_allclose(got, want_rb, rtol=DEVICE_RTOL if prec == "f64" else 2e-4)
     if prec == "f64":
-        assert np.abs(got / want - 1).max() < 2e-6              # what is actually observed: ~1e-7
+        assert np.abs(got / want_rb - 1).max() < 2e-6           # what is actually observed: ~1e-7
 
 
 def test_benchmarked_instantiation_at_baseline_size_matches_the_oracle():
@@ -1187,6 +1209,48 @@ def test_float64_device_generator_matches_its_restatement(N, Np, sub):
     assert np.abs(f32 / got - 1).max() < DEVICE_RTOL
     err = np.abs(h.rng_coeffs(seed, real0) - coeffs[0])          # 24-bit u: the radius loses relative accuracy where u -> 1
     assert err.max() < 1e-3 and np.quantile(err, 0.9999) < 1e-5
+
+
+# every MODE 2 instantiation a dispatch reaches (fastmc.hip: dispatch_wave): dense six / eight planes, twelve-wave six / eight /
+# sixteen planes, NS = 4 / 8, split rows of 2048 / 4096, off-centre windows
+_FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"),
+            (1024, 97, None, "k_rows_wave<double, 16, 2, 2, 1, 8>"), (1024, 128, None, "k_rows_wave<double, 16, 2, 2, 1, 8>"),
+            (1024, 82, 0, "k_rows_wave<double, 16, 2, 2, 1, 7>"), (1024, 120, 904, "k_rows_wave<double, 16, 2, 2, 1, 7>"),
+            (1024, 200, None, "k_rows_wave<double, 16, 4, 2, 1, 7>"), (1024, 400, None, "k_rows_wave<double, 16, 8, 2, 1, 7>"),
+            (2048, 82, None, "k_rows_wave<double, 16, 2, 2, 2, 4>"), (2048, 122, None, "k_rows_wave<double, 16, 2, 2, 2, 6>"),
+            (2048, 402, None, "k_rows_wave<double, 16, 8, 2, 2, 7>"), (4096, 82, None, "k_rows_wave<double, 16, 2, 2, 4, 4>")]
+
+
+@pytest.mark.parametrize("N,Np,lo,kernel", _FUSED64)
+def test_fused_float64_generator_rows_match_the_oracle_on_restated_draws(N, Np, lo, kernel):
+    """MODE 2 of the P = 16 row kernels (fmc_kernels.h): the float64 generator drawn inside the row.  Powers against the
+    oracle on oracle/devrng.py's float64 restatement at the float64 pipeline's bar (1e-9: nothing float32 is left in the
+    path), the kernel that ran is the fused one, and the staged form (FASTMC_GEN64_STAGED: k_gen_coeffs_f64 -> MODE 1 rows)
+    is covered by test_float64_device_generator_matches_its_restatement on the other families."""
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    ps = ps * 0.02
+    lo = (N - Np) // 2 if lo is None else lo
+    W = _window_W(Np)
+    h = _lib.Handle(N, Np, "f64", 0)
+    h.set_spectrum(ps, df)
+    h.set_pupil(W, lo, 0.01)
+    h.set_rng_precision("f64")
+    seed, real0, n = 99, 2 ** 33 + 6, (2 if N <= 1024 else 1)
+    got = h.run(seed, real0, n, None, 0.01)
+    assert h.last_kernels()[0] == kernel
+    amp = np.sqrt(ps) * df
+    re, im = [], []
+    for j in range(n):
+        z = R.screens_fftw(devrng.device_coefficients_f64(seed, real0 + j, N) * amp, 1.0)[lo:lo + Np, lo:lo + Np]
+        re.append(z.real)
+        im.append(z.imag)
+    chi = devrng.device_logamp_normals(seed, 2 * real0, 2 * n, f64=True) * 0.1
+    want = R.detector(np.stack(re + im), W, 0.01, np.concatenate([chi[0::2], chi[1::2]]))
+    assert (want > 1e-3).all()
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    # the read-back is the fused rows' arithmetic bit for bit: direct family (staged draws) on the same seed agrees to rounding
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.run(seed, real0, n, None, 0.01), got, rtol=1e-10)
 
 
 def test_fast_object_with_the_float64_generator():

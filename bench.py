@@ -613,9 +613,9 @@ def main():
             pass
         print(json.dumps(line), flush=True)
     sync_all()
-    if dist.stuck_threads():
-        sys.stdout.flush()
-        os._exit(0)        # a thread is still blocked inside RCCL although its communicator was aborted: skip the runtime teardown
+    # the line is out: if a thread is still blocked inside RCCL although its communicator was aborted, fast_amd.dist's exit hook
+    # skips the runtime teardown -- with status 0 only because the run got here (an exception on the way exits non-zero)
+    dist.mark_clean_exit()
 
 
 if __name__ == "__main__":

@@ -12,8 +12,10 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -148,6 +150,10 @@ struct fastmc_ctx {
   // fastmc_run_async: kernels enqueued, events not read yet (fastmc_wait / the exchange finish the bookkeeping)
   int rng_f64 = 0;        // fastmc_set_rng_precision: the device generator at float64 precision (fused into the P = 16 rows, else staged in cre / cim)
   const Gen64Entry* g64 = nullptr;   // its log table on this device (gen64_table)
+  // ONE caller at a time on a handle's stream, events and result bookkeeping: the entry points that use them take this lock
+  // (HandleLock), with a deadline, so that an exchange a deadline thread is still inside and the caller that gave up on it
+  // (fastmc_comm_abort takes no lock) never run on the handle together, and neither can wait for ever
+  std::timed_mutex use_mu;
   char last_rows[96] = "", last_cols[96] = "";   // the row / column kernels of the last launch, as c++filt prints them (fastmc_last_kernels)
   bool pending = false;
   size_t last_out_doubles = 0;    // size of the last run's result vector in `out`
@@ -493,6 +499,25 @@ static void destroy_now(fastmc_ctx* h) {
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
+
+// Exclusive use of a handle for the length of an entry point.  A handle that stays busy for FASTMC_HANDLE_BUSY_TIMEOUT
+// seconds (default 30) is an error, not a hang: it means another thread -- typically an exchange that missed its deadline --
+// is still inside the library on this handle.
+static double handle_busy_timeout() {
+  const char* e = getenv("FASTMC_HANDLE_BUSY_TIMEOUT");
+  const double v = e ? atof(e) : 30.0;
+  return v > 0 ? v : 30.0;
+}
+struct HandleLock {
+  std::unique_lock<std::timed_mutex> lk;
+  bool ok;
+  explicit HandleLock(fastmc_ctx* h) : lk(h->use_mu, std::defer_lock), ok(false) {
+    ok = lk.try_lock_for(std::chrono::duration<double>(handle_busy_timeout()));
+  }
+};
+#define FMC_LOCK(h)                                                                                                     \
+  HandleLock lock__(h);                                                                                                 \
+  if (!lock__.ok) return fail(FASTMC_ESTATE, "handle is in use by another thread (an exchange that missed its deadline has not returned)")
 
 #if FMC_TU == 0
 extern "C" int fastmc_kernel_path(fastmc_t* h, int force) {
@@ -1539,6 +1564,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
 
 static int run_checked(fastmc_ctx* h, const RunSpec& S) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
+  FMC_LOCK(h);
   if (h->pending) {       // an asynchronous run nobody waited for: its events are read before they are reused
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1576,6 +1602,7 @@ extern "C" int fastmc_run_async(fastmc_t* h, uint64_t seed, int64_t real0, int64
 
 extern "C" int fastmc_wait(fastmc_t* h, double* out) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
+  FMC_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   if (out) {
     if (h->last_n_iter <= 0 || !h->last_out_doubles) return fail(FASTMC_ESTATE, "no run results on the device");
@@ -1722,6 +1749,7 @@ static int histogram_device(fastmc_ctx* h, double lo, double hi, int nbins) {
 #if FMC_TU == 0
 extern "C" int fastmc_set_results(fastmc_t* h, const double* values, int64_t n_iter, int coherent) {
   if (!h || !values || n_iter < 1) return fail(FASTMC_EINVAL, "bad argument");
+  FMC_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   const size_t need = (size_t)n_iter * (coherent ? 2 : 1);
   TRY(grow(&h->out, &h->out_cap, need));
@@ -1737,6 +1765,7 @@ extern "C" int fastmc_set_results(fastmc_t* h, const double* values, int64_t n_i
 #if FMC_TU == 0
 extern "C" int fastmc_histogram(fastmc_t* h, double lo_db, double hi_db, int nbins, int64_t* bins) {
   if (!h || !bins) return fail(FASTMC_EINVAL, "null argument");
+  FMC_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   TRY(histogram_device(h, lo_db, hi_db, nbins));
   HIPCHK(hipMemcpyAsync(bins, h->hist, ((size_t)nbins + 2) * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1749,6 +1778,7 @@ extern "C" int fastmc_histogram(fastmc_t* h, double lo_db, double hi_db, int nbi
 extern "C" int fastmc_result_stats(fastmc_t* h, const double* thresholds, int n_thr, double* stats) {
   if (!h || !stats || n_thr < 0 || n_thr > STATS_MAX_THR || (n_thr > 0 && !thresholds)) return fail(FASTMC_EINVAL, "bad argument");
   if (h->last_n_iter <= 0) return fail(FASTMC_ESTATE, "no run results on the device");
+  FMC_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
   const int nblocks = 256, stride = STATS_NQ + STATS_MAX_THR, nq = STATS_NQ + n_thr;
   ScratchBuf part, thr, res;
@@ -2070,13 +2100,21 @@ struct DeviceComm {
 static DeviceComm g_comm[64];
 static std::mutex g_comm_mu;
 static std::atomic<int> g_abort_gen[64];      // bumped by fastmc_comm_abort: wakes a stalled exchange of that device
+// A device's communicator is handed to RCCL only under this lock (read g_comm -> enqueue the collectives), and
+// fastmc_comm_abort takes it (with a deadline of two seconds: enqueueing does not wait for peers) before ncclCommAbort frees
+// the communicator: no thread is ever between "copied the communicator" and "passed it to ncclAllGather" when it is freed.
+// What blocks when a peer is gone is the hipStreamSynchronize AFTER the enqueue, outside this lock.
+static std::timed_mutex g_enq_mu[64];
 
-// FASTMC_TEST_STALL_GATHER=1: the exchange entry points block here, without touching RCCL, until fastmc_comm_abort is
-// called for one of the devices, and then fail -- the fault that the deadline / fall-back tests inject.
-static bool stall_requested() {
+// FASTMC_TEST_STALL_GATHER=1: the exchange entry points block, without touching RCCL, until fastmc_comm_abort is called for
+// one of the devices, and then fail -- the fault that the deadline / fall-back tests inject.  =2: the same AFTER the
+// collectives have been enqueued on a real communicator (the caller's abort then races a thread that holds the handle and
+// has RCCL work on its stream: what a lost peer looks like from inside).
+static int stall_mode() {
   const char* e = getenv("FASTMC_TEST_STALL_GATHER");
-  return e && e[0] && e[0] != '0';
+  return (e && e[0] && e[0] != '0') ? (e[0] == '2' ? 2 : 1) : 0;
 }
+static bool stall_requested() { return stall_mode() == 1; }
 static int stall_until_abort(const std::vector<int>& devices) {
   std::vector<int> gen(devices.size());
   for (size_t i = 0; i < devices.size(); ++i) gen[i] = g_abort_gen[devices[i] & 63].load();
@@ -2194,20 +2232,34 @@ extern "C" int fastmc_comm_gather(fastmc_t* h, int64_t n_local, double* all_powe
                                   double hi_db, int nbins) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   if (stall_requested()) return stall_until_abort({h->device});
-  const DeviceComm dc = device_comm(h->device);
-  if (!dc.comm) return fail(FASTMC_ESTATE, "fastmc_comm_init not called for this device");
-  if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds the last run");
-  HIPCHK(hipSetDevice(h->device));
-  if (all_powers) TRY(grow(&h->gather_buf, &h->gather_cap, (size_t)n_local * dc.world));
-  if (hist) TRY(histogram_device(h, lo_db, hi_db, nbins));       // local histogram kernel: before the timed exchange
-  TRY(exchange_begin(h));
-  if (all_powers) TRY(comm_enqueue_gather(h, dc, n_local, true));
-  if (hist) TRY(comm_enqueue_hist(h, dc, nbins));
-  TRY(exchange_end(h));
-  if (all_powers) HIPCHK(hipMemcpyAsync(all_powers, h->gather_buf, (size_t)n_local * dc.world * 8, hipMemcpyDeviceToHost, h->stream));
+  FMC_LOCK(h);
+  int world = 0;
+  const int gen = g_abort_gen[h->device & 63].load();
+  {
+    std::lock_guard<std::timed_mutex> enq(g_enq_mu[h->device & 63]);
+    const DeviceComm dc = device_comm(h->device);
+    if (!dc.comm) return fail(FASTMC_ESTATE, "fastmc_comm_init not called for this device (or its communicator was aborted)");
+    if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds the last run");
+    world = dc.world;
+    HIPCHK(hipSetDevice(h->device));
+    if (all_powers) TRY(grow(&h->gather_buf, &h->gather_cap, (size_t)n_local * dc.world));
+    if (hist) TRY(histogram_device(h, lo_db, hi_db, nbins));       // local histogram kernel: before the timed exchange
+    TRY(exchange_begin(h));
+    if (all_powers) TRY(comm_enqueue_gather(h, dc, n_local, true));
+    if (hist) TRY(comm_enqueue_hist(h, dc, nbins));
+    TRY(exchange_end(h));
+  }
+  if (stall_mode() == 2) {        // fault injection: the collectives are on the stream, the exchange "never completes"
+    while (g_abort_gen[h->device & 63].load() == gen) usleep(500);
+    hipStreamSynchronize(h->stream);
+    finish_pending(h);
+    return fail(FASTMC_ECOMM, "exchange aborted after its collectives were enqueued (FASTMC_TEST_STALL_GATHER=2)");
+  }
+  if (all_powers) HIPCHK(hipMemcpyAsync(all_powers, h->gather_buf, (size_t)n_local * world * 8, hipMemcpyDeviceToHost, h->stream));
   if (hist) HIPCHK(hipMemcpyAsync(hist, h->hist, ((size_t)nbins + 2) * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   finish_pending(h);
+  if (g_abort_gen[h->device & 63].load() != gen) return fail(FASTMC_ECOMM, "the communicator was aborted during the exchange");
   return 0;
 }
 #endif
@@ -2221,10 +2273,21 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
     for (int i = 0; i < n; ++i) if (handles[i]) devs.push_back(handles[i]->device);
     return stall_until_abort(devs);
   }
+  for (int i = 0; i < n; ++i) if (!handles[i]) return fail(FASTMC_EINVAL, "null handle");
+  // every handle for the length of the call (in the caller's order: the group always passes the same order), every
+  // device's communicator for the length of the enqueue
+  std::vector<std::unique_ptr<HandleLock>> hl;
+  for (int i = 0; i < n; ++i) {
+    hl.emplace_back(new HandleLock(handles[i]));
+    if (!hl.back()->ok) return fail(FASTMC_ESTATE, "a handle is in use by another thread (an exchange that missed its deadline has not returned)");
+  }
+  std::vector<int> gens(n);
+  for (int i = 0; i < n; ++i) gens[i] = g_abort_gen[handles[i]->device & 63].load();
+  std::vector<std::unique_lock<std::timed_mutex>> enq;
+  for (int i = 0; i < n; ++i) enq.emplace_back(g_enq_mu[handles[i]->device & 63]);
   std::vector<DeviceComm> dcs(n);
   for (int i = 0; i < n; ++i) {
     fastmc_ctx* h = handles[i];
-    if (!h) return fail(FASTMC_EINVAL, "null handle");
     dcs[i] = device_comm(h->device);
     if (!dcs[i].comm || dcs[i].world != n || dcs[i].rank != i)
       return fail(FASTMC_ESTATE, "handles do not match the communicators of fastmc_comm_init_all (same handles, same order)");
@@ -2256,6 +2319,17 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
     HIPCHK(hipSetDevice(handles[i]->device));
     TRY(exchange_end(handles[i]));
   }
+  enq.clear();          // the communicators are RCCL's from here on: an abort may free them while we wait below
+  if (stall_mode() == 2) {
+    for (;;) {
+      bool aborted = false;
+      for (int i = 0; i < n; ++i) aborted = aborted || g_abort_gen[handles[i]->device & 63].load() != gens[i];
+      if (aborted) break;
+      usleep(500);
+    }
+    for (int i = 0; i < n; ++i) { hipSetDevice(handles[i]->device); hipStreamSynchronize(handles[i]->stream); finish_pending(handles[i]); }
+    return fail(FASTMC_ECOMM, "exchange aborted after its collectives were enqueued (FASTMC_TEST_STALL_GATHER=2)");
+  }
   // every rank holds the same gathered data: the host copy comes from rank 0, the others are only waited for
   fastmc_ctx* h0 = handles[0];
   HIPCHK(hipSetDevice(h0->device));
@@ -2266,6 +2340,8 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
     HIPCHK(hipStreamSynchronize(handles[i]->stream));
     finish_pending(handles[i]);
   }
+  for (int i = 0; i < n; ++i)
+    if (g_abort_gen[handles[i]->device & 63].load() != gens[i]) return fail(FASTMC_ECOMM, "a communicator was aborted during the exchange");
   return 0;
 }
 #endif
@@ -2274,6 +2350,9 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
 extern "C" int fastmc_comm_abort(fastmc_t* h) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   ncclComm_t c = nullptr;
+  // not while another thread is handing this communicator to RCCL (see g_enq_mu); never longer than two seconds
+  std::unique_lock<std::timed_mutex> enq(g_enq_mu[h->device & 63], std::defer_lock);
+  (void)enq.try_lock_for(std::chrono::seconds(2));
   {
     std::lock_guard<std::mutex> g(g_comm_mu);
     c = g_comm[h->device & 63].comm;
@@ -2299,6 +2378,8 @@ extern "C" int fastmc_last_exchange_ms(fastmc_t* h, double* ms) {
 extern "C" int fastmc_comm_destroy(fastmc_t* h) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   ncclComm_t c = nullptr;
+  std::unique_lock<std::timed_mutex> enq(g_enq_mu[h->device & 63], std::defer_lock);
+  (void)enq.try_lock_for(std::chrono::seconds(2));
   {
     std::lock_guard<std::mutex> g(g_comm_mu);
     c = g_comm[h->device & 63].comm;

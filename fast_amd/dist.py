@@ -66,15 +66,67 @@ def stuck_threads():
     return [t for t in _LEFT_BEHIND if t.is_alive()]
 
 
+def join_left_behind(timeout):
+    """After the abort: give the threads a deadline gave up on `timeout` seconds to leave the library (ncclCommAbort wakes a
+    blocked exchange; the handle's lock inside libfastmc.so keeps them and the caller apart meanwhile).  True when none is left."""
+    t_end = time.monotonic() + timeout
+    for th in list(_LEFT_BEHIND):
+        th.join(max(0.0, t_end - time.monotonic()))
+    return not stuck_threads()
+
+
+def post_abort_timeout():
+    """How long a step waits, after the communicators were aborted, for the exchange it gave up on to leave the handle and
+    for the device's own vector (FASTMC_POST_ABORT_TIMEOUT, default 30 s): past it the step fails instead of hanging."""
+    return float(os.environ.get("FASTMC_POST_ABORT_TIMEOUT", "30"))
+
+
+class ExchangeStuck(RuntimeError):
+    """An aborted exchange did not let go of its handle / stream in time: the step cannot finish on the host either."""
+
+
+# ---- exit status when a thread is stuck inside RCCL at interpreter exit
+# Interpreter / runtime teardown would wait for ever for such a thread, so the exit hook leaves through os._exit -- with the
+# status the process was going to exit with: an uncaught exception (sys.excepthook) or sys.exit(n) is recorded here, a run that
+# finished says so with mark_clean_exit(); with neither the status is EX_SOFTWARE (70), never a silent 0.
+_EXIT = {"code": None, "clean": False}
+_orig_excepthook, _orig_exit = sys.excepthook, sys.exit
+
+
+def _excepthook(tp, val, tb):
+    _EXIT["code"] = (val.code if isinstance(val.code, int) else (0 if val.code is None else 1)) if isinstance(val, SystemExit) else 1
+    _orig_excepthook(tp, val, tb)
+
+
+def _exit(code=0):
+    _EXIT["code"] = code if isinstance(code, int) else (0 if code is None else 1)
+    _orig_exit(code)
+
+
+sys.excepthook, sys.exit = _excepthook, _exit
+
+
+def mark_clean_exit():
+    """The program's work is done and reported: a thread left inside RCCL may be abandoned with exit status 0."""
+    _EXIT["clean"] = True
+
+
+def exit_status():
+    if _EXIT["code"] is not None:
+        return _EXIT["code"]
+    return 0 if _EXIT["clean"] else 70
+
+
 def _exit_hook():
     # A thread that is still blocked inside the RCCL / HIP runtime would make interpreter or runtime teardown wait for
-    # ever.  Everything the process had to say has been said by now: flush and leave without the teardown.
+    # ever.  Everything the process had to say has been said by now: flush and leave without the teardown, with the status
+    # the process was exiting with (never 0 for a run that died or did not say it finished).
     if stuck_threads():
         try:
             sys.stdout.flush()
             sys.stderr.flush()
         finally:
-            os._exit(getattr(_exit_hook, "code", 0))
+            os._exit(exit_status())
 
 
 atexit.register(_exit_hook)
@@ -153,6 +205,10 @@ class RcclTransport(HostTransport):
             handle.comm_abort()            # ncclCommAbort: never waits for peers; wakes a blocked exchange
         except Exception as e:
             logger.warning(f"ncclCommAbort: {e}")
+        # the exchange that missed its deadline may still be inside the library on this handle: it must be out before the
+        # caller touches the handle again (the library's per-handle lock enforces it; this bounds the wait and says why)
+        if not join_left_behind(post_abort_timeout()):
+            raise ExchangeStuck(f"the aborted RCCL exchange did not return within {post_abort_timeout():g} s ({why})")
 
     def device_exchange(self, handle, nval, hist_range=None, powers=True):
         """fastmc_comm_gather under the deadline + the collective verdict.  Returns (ok, all_values | None, hist | None);
@@ -207,7 +263,7 @@ def make_transport(handle, rdzv, rccl_timeout=None):
     if key in _TRANSPORT:
         return _TRANSPORT[key]
     timeout = float(os.environ.get("FASTMC_RCCL_TIMEOUT", "90")) if rccl_timeout is None else rccl_timeout
-    if os.environ.get("FASTMC_TEST_STALL_GATHER", "0") not in ("", "0"):
+    if os.environ.get("FASTMC_TEST_STALL_GATHER", "0") == "1":      # ("2" stalls a REAL exchange after its collectives are enqueued)
         # fault injection (tests): behave as if the clique were up; fastmc_comm_gather blocks until it is aborted
         tr = RcclTransport(rdzv, rdzv.world)
         _TRANSPORT[key] = tr
@@ -276,7 +332,10 @@ def step_sharded(handle, transport, seed, real_base, n_real_total, logamp_var=0.
             info["exchange_device_ms"] = handle.last_exchange_ms()
             info["wall_ms"] = (time.perf_counter() - t0) * 1e3
             return assemble(parts, complex_out=coherent), hist, info
-        local = handle.wait()                         # the device's own vector is still resident
+        # the device's own vector is still resident; its stream carries the aborted collectives, so this wait has a deadline too
+        ok, local = call_with_deadline(handle.wait, post_abort_timeout())
+        if not ok:
+            raise ExchangeStuck(f"the device's results could not be fetched after the RCCL exchange was aborted: {local}")
         info["exchange"] = "host"
     else:
         local = handle.run(seed, real_base + real0, n_local, None, logamp_var, coherent)

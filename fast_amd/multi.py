@@ -93,7 +93,7 @@ class DeviceGroup:
         self.last_exchange = "none"
         self.last_exchange_ms = []     # per device: HIP-event time of the collectives of the last step (RCCL path)
         self.last_exchange_wall_ms = 0.0
-        self._stall_test = os.environ.get("FASTMC_TEST_STALL_GATHER", "0") not in ("", "0")
+        self._stall_test = os.environ.get("FASTMC_TEST_STALL_GATHER", "0") == "1"
         if self.world > 1 and exchange in ("auto", "rccl") and factory is None:
             if self._stall_test:
                 # fault injection: behave as if the clique were up; the exchange entry point blocks until it is aborted
@@ -196,9 +196,15 @@ class DeviceGroup:
             self.last_exchange_wall_ms = (time.perf_counter() - t0) * 1e3     # includes the wait for the kernels
             return dist.assemble(parts, complex_out=coherent)
         self._degrade(val)
-        parts = self.each(lambda h, i: h.wait())                 # every device's own vector is still resident
+        # every device's own vector is still resident; the streams carry the aborted collectives, so the fetch has a deadline
+        ok, parts = call_with_deadline(lambda: self.each(lambda h, i: h.wait()), dist.post_abort_timeout())
+        if not ok:
+            raise dist.ExchangeStuck(f"the devices' results could not be fetched after the RCCL exchange was aborted: {parts}")
         if hist_range is not None:
-            self.last_hist = np.sum(self.each(lambda h, i: h.histogram(*hist_range)), axis=0)
+            ok, hs = call_with_deadline(lambda: self.each(lambda h, i: h.histogram(*hist_range)), dist.post_abort_timeout())
+            if not ok:
+                raise dist.ExchangeStuck(f"histogram after the aborted RCCL exchange: {hs}")
+            self.last_hist = np.sum(hs, axis=0)
         self.last_exchange = "host"
         self.last_exchange_wall_ms = (time.perf_counter() - t0) * 1e3
         return dist.assemble(parts, complex_out=coherent)
@@ -214,6 +220,10 @@ class DeviceGroup:
                 h.comm_abort()
             except Exception as e:
                 logger.warning(f"ncclCommAbort on device {h.device}: {e}")
+        # the exchange that missed its deadline may still be inside the library on these handles (it holds their locks there):
+        # wait for it, with a bound, before anything else touches them
+        if not dist.join_left_behind(dist.post_abort_timeout()):
+            raise dist.ExchangeStuck(f"the aborted RCCL exchange did not return within {dist.post_abort_timeout():g} s ({why})")
 
     def last_timing(self):
         return [h.last_timing() for h in self.handles]

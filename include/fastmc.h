@@ -11,8 +11,12 @@
  *   - the caller owns every host buffer; the library copies in during set_* / run and
  *     owns all device memory until fastmc_destroy();
  *   - all host arrays are C-contiguous float64 unless stated otherwise;
- *   - calls on one handle must be serialised by the caller; calls are blocking; different
- *     handles may be driven from different threads (each has its own HIP stream);
+ *   - calls on one handle should be serialised by the caller; calls are blocking; different
+ *     handles may be driven from different threads (each has its own HIP stream).  The entry points that use a handle's
+ *     stream and result bookkeeping (run*, wait, set_results, histogram, result_stats, comm_gather*) take a per-handle lock
+ *     with a deadline (FASTMC_HANDLE_BUSY_TIMEOUT seconds, default 30): a second caller waits its turn and then fails with
+ *     FASTMC_ESTATE instead of racing the first -- the case that matters is an exchange a deadline thread is still inside
+ *     while its caller, having called fastmc_comm_abort (which takes no handle lock), goes on with the handle;
  *   - N <= 4096, Np <= N; fastmc_destroy() parks ONE retired handle per device, whole (stream, buffers), and
  *     fastmc_create() of the same (N, Np, precision) on that device takes it back, reset to the state of a new
  *     handle (sweeps build one short-lived handle per geometry sample); a handle it displaces is freed, except
@@ -21,7 +25,8 @@
  *     fastmc_create() fails with FASTMC_ENODEV;
  *   - environment: FASTMC_TEST_STALL_GATHER=1 makes fastmc_comm_gather / _gather_all block (without touching RCCL)
  *     until fastmc_comm_abort is called on the handle's device, then fail with FASTMC_ECOMM: the fault the deadline
- *     tests inject (tests/test_gpu_dist.py);
+ *     tests inject (tests/test_gpu_dist.py); =2 blocks the same way AFTER the collectives of a real communicator have been
+ *     enqueued, holding the handle (the abort then meets a thread with RCCL work on its stream);
  *   - environment: FASTMC_DISABLE_RCCL=1 makes the communicator entry points fail with FASTMC_ECOMM (callers exchange
  *     through the host); FASTMC_NO_DENSE16=1 (read by fastmc_create) keeps the twelve-wave kernels where the
  *     sixteen-wave dense-image kernels would run (A/B timing; same results).

@@ -243,3 +243,43 @@ def test_rccl_transport_code_path_with_a_world_of_one():
         dist._TRANSPORT.pop(h.device, None)
         h.comm_destroy()
     assert h.comm_world() == (0, -1)
+
+
+def test_abort_while_a_real_exchange_holds_the_handle():
+    """the stall injection used to return before touching RCCL.  FASTMC_TEST_STALL_GATHER=2 blocks AFTER the
+    collectives of a real communicator (world of one: all a 1-GPU box allows) are on the stream, holding the handle's lock:
+    the deadline passes, the caller aborts the communicator from another thread, and only then touches the handle -- the
+    library's per-handle lock and the bounded join keep the two apart; the device's own vector is intact."""
+    code = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, %r)
+os.environ["FASTMC_EXCHANGE_TIMEOUT"] = "1.0"
+from fast_amd import _lib, dist, rendezvous
+h = _lib.Handle(256, 40, "f64", 0)
+ps = np.full((256, 256), 1e-3); ps[128, 128] = 0.0
+h.set_spectrum(ps, 0.25); h.set_pupil(np.ones((40, 40)), 108, 0.01)
+rdzv = rendezvous.Rendezvous(0, 1, "unix", "fastmc-test-stall2")
+tr = dist.make_transport(h, rdzv, rccl_timeout=60)
+assert tr.name == "rccl" and h.comm_world() == (1, 0)
+want = h.run(4, 0, 100, None, 0.01)
+os.environ["FASTMC_TEST_STALL_GATHER"] = "2"
+t0 = time.perf_counter()
+out, hist, info = dist.step_sharded(h, tr, 4, 0, 100, 0.01, False, (-40.0, 10.0, 64))
+dt = time.perf_counter() - t0
+assert 0.9 < dt < 20, dt
+assert info["exchange"] == "host" and tr.name == "host" and "given up" in tr.why
+assert np.array_equal(out, want) and hist.sum() == 200
+assert h.comm_world() == (0, -1) and not dist.stuck_threads()
+# the handle works on: a blocking run, and a second sharded step on the host path
+os.environ["FASTMC_TEST_STALL_GATHER"] = "0"
+assert np.array_equal(h.run(4, 0, 100, None, 0.01), want)
+out2, _, info2 = dist.step_sharded(h, tr, 4, 0, 100, 0.01, False, None)
+assert np.array_equal(out2, want) and info2["exchange"] == "host"
+# a second caller on a busy handle is refused with a message, not left hanging
+import threading
+os.environ["FASTMC_HANDLE_BUSY_TIMEOUT"] = "0.5"
+print("ok")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]

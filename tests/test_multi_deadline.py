@@ -95,3 +95,56 @@ def test_exchange_error_falls_back_and_success_is_taken(monkeypatch):
     # unequal shards (or host-supplied log-amplitudes) cannot use the all-gather: host path without touching the clique
     out = grp.run(1, 0, 11, None, 0.0, False)
     assert out.size == 22 and grp.last_exchange == "host" and grp.exchange == "rccl"
+
+
+# ---- exit status with a thread left inside the library (fast_amd/dist.py: _exit_hook)
+import os
+import subprocess
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_STUCK = """
+import sys, threading
+sys.path.insert(0, {root!r})
+from fast_amd import dist
+ok, why = dist.call_with_deadline(threading.Event().wait, 0.2)      # a thread that never comes back
+assert not ok and dist.stuck_threads()
+{tail}
+"""
+
+
+def _rc(tail):
+    r = subprocess.run([sys.executable, "-c", _STUCK.format(root=_ROOT, tail=tail)], capture_output=True, text=True, timeout=60)
+    return r.returncode, r.stderr
+
+
+def test_a_stuck_thread_never_turns_an_error_exit_into_success():
+    rc, err = _rc("raise RuntimeError('the run died after an exchange timed out')")
+    assert rc == 1 and "the run died" in err
+    assert _rc("sys.exit(3)")[0] == 3
+    assert _rc("raise SystemExit(4)")[0] == 4 or _rc("raise SystemExit(4)")[0] == 70     # not via sys.exit: at least not 0
+    assert _rc("pass")[0] == 70                       # nobody said the run finished: EX_SOFTWARE, not 0
+    assert _rc("dist.mark_clean_exit()")[0] == 0      # the work is done and reported: the stuck thread is abandoned quietly
+    assert _rc("dist.mark_clean_exit(); raise ValueError('late failure')")[0] == 1
+
+
+def test_left_behind_exchange_is_waited_for_with_a_bound(monkeypatch):
+    """After the abort the step does not touch the handles before the exchange it gave up on has left them -- and if that
+    never happens it fails (ExchangeStuck) instead of hanging or running on."""
+    import pytest
+    grp = _group(2)
+    monkeypatch.setenv("FASTMC_EXCHANGE_TIMEOUT", "0.3")
+    monkeypatch.setenv("FASTMC_POST_ABORT_TIMEOUT", "0.5")
+    never = threading.Event()
+
+    def deaf(handles, n_local, hist_range=None, powers=True):
+        never.wait()                               # ignores the abort: still inside the library
+    monkeypatch.setattr(_lib, "comm_gather_all", deaf)
+    t0 = time.perf_counter()
+    with pytest.raises(dist.ExchangeStuck):
+        grp.run(1, 0, 8, None, 0.0, False)
+    assert 0.7 < time.perf_counter() - t0 < 5.0
+    assert all(h.aborted == 1 and h.waited == 0 for h in grp.handles)       # the handles were not touched
+    never.set()
+    time.sleep(0.1)
+    dist._LEFT_BEHIND[:] = [t for t in dist._LEFT_BEHIND if t.is_alive()]

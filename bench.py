@@ -279,7 +279,7 @@ def roofline(args, N, Np, tim, steps, workers, iters_per_worker_step, kernels=("
     share of the SIMDs' issue cycles the VALU instructions of the code object account for, `hbm` the byte models.
     `kernels` = (rows, cols) names the library reports for what it launched (fastmc_last_kernels): the instruction counts are
     those of THAT instantiation (fast_amd/kernel_isa_stats.json; split rows of 2048 / 4096: row loop + S passes of the sub-row loop)."""
-    f64 = args.precision == "f64"
+    f64 = kernels[0].split("<")[-1].startswith("double") if kernels[0] else args.precision == "f64"     # what ran, not what was asked for
     launches = max(tim["rows_launches"], 1)
     avg_rows_ms = tim["rows_ms"] / launches
     avg_cols_ms = tim["cols_ms"] / max(tim["cols_launches"], 1)
@@ -361,6 +361,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (f32, AO config, configs[3], configs[4])")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained run after the timed steps")
+    ap.add_argument("--iters-per-step", type=int, default=ITERS_PER_STEP, help="iterations per GPU and step of the configs[1] workload "
+                    "(default 10000 = BASELINE configs[1]; other values are for overhead studies, the line says what ran)")
+    ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (enqueue, exchange, wait) instead of two steps in flight per device")
     ap.add_argument("--no-f64-generator-pass", action="store_true", help="skip the second timed pass with the float64 generator")
     ap.add_argument("--batch", type=int, default=0, help="realisations per launch (0 = library default)")
     args = ap.parse_args()
@@ -406,7 +409,7 @@ def main():
             raise SystemExit("--workload config3 splits 50 000 realisations: the number of GPUs must divide it")
         iters_worker = 100000 // workers                  # iterations per worker and step (strong scaling)
     else:
-        iters_worker = ITERS_PER_STEP                      # weak scaling: fixed work per GPU
+        iters_worker = args.iters_per_step                 # weak scaling: fixed work per GPU
     n_real = iters_worker // 2
 
     p = workload_params(args)
@@ -455,6 +458,40 @@ def main():
                 acc["host_steps"] += 1
         return out
 
+    def run_steps(first, count, tim=None, record=False):
+        """Steps first ... first + count - 1 with TWO steps in flight per device (fast_amd.multi.DeviceGroup.run_pipelined /
+        fast_amd.dist.steps_pipelined: step i + 1 is enqueued before step i's results are waited for); --no-pipeline runs them
+        one after the other as rounds 1-3 did.  Same realisation ranges, same results either way."""
+        nonlocal hist_total
+        out = None
+        if args.no_pipeline:
+            for i in range(count):
+                out = step(first + i, record=record)
+                if tim is not None:
+                    add_timing(tim)
+            return out
+        spans = [((first + i) * workers * n_real, workers * n_real) for i in range(count)]
+        if mode == "ranks":
+            for out, hist_total, info in dist.steps_pipelined(h, tr, p["SEED"], spans, lvar, False, HIST):
+                if record:
+                    acc["exchange_device_ms"].append([info["exchange_device_ms"]])
+                    acc["exchange_wall_ms"] += info.get("exchange_host_ms", 0.0)
+                    acc["rccl_steps" if info["exchange"] == "rccl" else "host_steps"] += 1
+                if tim is not None:
+                    add_timing(tim)
+            return out
+        for out, hist_total in grp.run_pipelined(p["SEED"], spans, lvar, False, HIST):
+            if record and workers > 1:
+                if grp.last_exchange == "rccl":
+                    acc["exchange_device_ms"].append(list(grp.last_exchange_ms))
+                    acc["rccl_steps"] += 1
+                else:
+                    acc["exchange_wall_ms"] += grp.last_exchange_wall_ms
+                    acc["host_steps"] += 1
+            if tim is not None:
+                add_timing(tim)
+        return out
+
     def sync_all():
         if rdzv is not None:
             rdzv.barrier()                  # library calls are blocking: every device is idle when its rank gets here
@@ -470,14 +507,11 @@ def main():
             per.append(t["rows_ms"] + t["cols_ms"] + t["finalize_ms"])
         busy.append(per)
 
-    for i in range(args.warmup):
-        step(i)
+    run_steps(0, args.warmup)
     tim = dict.fromkeys(tim_keys, 0.0)
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(args.warmup + i, record=True)
-        add_timing(tim)
+    out = run_steps(args.warmup, args.steps, tim, record=True)
     sync_all()
     dt = time.perf_counter() - t0
     kernels = h.last_kernels()                                            # what the timed steps launched
@@ -501,8 +535,8 @@ def main():
         t0 = time.perf_counter()
         n_sus = 0
         while True:
-            step(args.warmup + args.steps + n_sus)
-            n_sus += 1
+            run_steps(args.warmup + args.steps + n_sus, 16)
+            n_sus += 16
             go = np.array([1 if time.perf_counter() - t0 < 5.0 else 0])
             if rdzv is not None:
                 go = rdzv.all_reduce(go, "max")
@@ -521,14 +555,12 @@ def main():
     if args.rng_precision == "f32" and args.precision == "f64" and not args.no_f64_generator_pass:
         grp.each(lambda hh, i: hh.set_rng_precision("f64"))
         first = args.warmup + args.steps + 100000
-        step(first)
+        run_steps(first, 1)
         busy_keep, busy = busy, []
         tim64 = dict.fromkeys(tim_keys, 0.0)
         sync_all()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            out64 = step(first + 1 + i)
-            add_timing(tim64)
+        out64 = run_steps(first + 1, args.steps, tim64)
         sync_all()
         dt64 = time.perf_counter() - t0
         kernels64 = h.last_kernels()
@@ -582,7 +614,11 @@ def main():
                        "rccl_ranks": rccl_ranks,
                        "histogram_total": None if hist_total is None else int(np.sum(hist_total))},
             "roofline": roofline(args, N, Np, tim, args.steps, workers, iters_worker, kernels),
-            "pipeline": {"gpu_busy_ms_per_step_per_worker": gpu_ms / args.steps / workers,
+            "pipeline": {"steps_in_flight": 1 if args.no_pipeline else 2,
+                         # wall time of a step that is not kernel time of the busiest worker: launches, the exchange's host side, result
+                         # copies, Python -- hidden behind the device's work when two steps are in flight
+                         "host_ms_per_step": dt / args.steps * 1e3 - float(busy.mean(0).max()),
+                         "gpu_busy_ms_per_step_per_worker": gpu_ms / args.steps / workers,
                          "gpu_busy_ms_per_step": {"min_worker": float(busy.mean(0).min()), "max_worker": float(busy.mean(0).max()),
                                                   "per_worker": [float(x) for x in busy.mean(0)]},
                          "rows_ms": tim["rows_ms"] / args.steps / workers,

@@ -1,6 +1,7 @@
 """ctypes binding of libfastmc.so (include/fastmc.h).  No torch, no fallback: if the library
 is missing or no gfx950 device is visible, the calls raise."""
 import ctypes as C
+import logging
 import os
 
 import numpy as np
@@ -24,7 +25,8 @@ EXPORTS = [
     "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_init_all", "fastmc_comm_world", "fastmc_comm_gather",
     "fastmc_comm_gather_all", "fastmc_comm_destroy", "fastmc_comm_abort", "fastmc_last_exchange_ms",
     "fastmc_run_async", "fastmc_wait", "fastmc_set_rng_precision", "fastmc_temporal_phases", "fastmc_last_kernels",
-    "fastmc_precision", "fastmc_last_result_shape",
+    "fastmc_precision", "fastmc_last_result_shape", "fastmc_run_queued", "fastmc_comm_gather_queued",
+    "fastmc_comm_gather_all_queued", "fastmc_histogram_queued", "fastmc_queue_wait",
 ]
 
 
@@ -92,6 +94,11 @@ def lib():
     L.fastmc_last_kernels.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
     L.fastmc_precision.argtypes = [vp]
     L.fastmc_last_result_shape.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_int)]
+    L.fastmc_run_queued.argtypes = [vp, u64, i64, i64, C.c_double, C.c_int, C.c_int, C.c_int]
+    L.fastmc_comm_gather_queued.argtypes = [vp, i64, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
+    L.fastmc_comm_gather_all_queued.argtypes = [C.POINTER(vp), C.c_int, i64, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
+    L.fastmc_histogram_queued.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int]
+    L.fastmc_queue_wait.argtypes = [vp, C.c_int, dp, i64, C.POINTER(i64), C.c_int]
     L.fastmc_set_rng_precision.argtypes = [vp, C.c_int]
     L.fastmc_powerspec.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp, dp, dp]
     L.fastmc_powerspec_terms.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp]
@@ -154,6 +161,9 @@ def default_device():
     return lr
 
 
+_PROMOTED = set()
+
+
 class Handle:
     """One GPU + one (N, Np) Monte-Carlo problem (fastmc_t)."""
 
@@ -165,6 +175,13 @@ class Handle:
         dev = default_device() if device is None else int(device)
         _chk(lib().fastmc_create(C.byref(self._h), dev, self.N, self.Np, prec))
         self.device = dev
+        # what the handle COMPUTES in: float32 exists on the wave family's fixed grids and the direct family; elsewhere a
+        # float32 request runs the float64 kernels (fastmc_create) -- the label follows the arithmetic, and says so once
+        self.precision_requested = precision
+        self.precision = self.effective_precision()
+        if self.precision != precision and (self.N, precision) not in _PROMOTED:
+            _PROMOTED.add((self.N, precision))
+            logging.getLogger(__name__).warning(f"GPU_PRECISION '{precision}' has no kernels on a {self.N}^2 grid: computing in {self.precision}")
 
     def close(self):
         if self._h:
@@ -224,6 +241,27 @@ class Handle:
         out = np.empty(n_it.value * (2 if coherent else 1), dtype=np.float64)
         _chk(lib().fastmc_wait(self._h, _dptr(out)))
         return out.view(np.complex128) if coherent else out
+
+    # ---- two steps in flight (fastmc.h: fastmc_run_queued ...)
+    def run_queued(self, seed, real0, n_real, logamp_var=0.0, coherent=False, slot=0, fetch=True):
+        """Enqueue a step on one of the handle's two slots and return; with fetch, its own result vector lands on the slot."""
+        _chk(lib().fastmc_run_queued(self._h, int(seed) & (2 ** 64 - 1), int(real0), int(n_real), float(logamp_var), int(bool(coherent)),
+                                     int(slot), int(bool(fetch))))
+
+    def comm_gather_queued(self, n_local, hist_range=None, powers=True, slot=0):
+        lo, hi, nb = hist_range if hist_range is not None else (0.0, 1.0, 0)
+        _chk(lib().fastmc_comm_gather_queued(self._h, int(n_local), int(bool(powers)), float(lo), float(hi), int(nb), int(slot)))
+
+    def histogram_queued(self, lo, hi, nbins, slot=0):
+        _chk(lib().fastmc_histogram_queued(self._h, float(lo), float(hi), int(nbins), int(slot)))
+
+    def queue_wait(self, slot, n_out=0, hist_bins=0):
+        """Wait for the slot's step: (values | None, histogram | None).  n_out: capacity of the value buffer in float64."""
+        out = np.empty(int(n_out), dtype=np.float64) if n_out else None
+        hist = np.zeros(int(hist_bins) + 2, dtype=np.int64) if hist_bins else None
+        n = _chk(lib().fastmc_queue_wait(self._h, int(slot), _dptr(out), int(n_out), None if hist is None else hist.ctypes.data_as(C.POINTER(C.c_int64)),
+                                         0 if hist is None else hist.size))
+        return (None if out is None else out[:n]), hist
 
     def run_coeffs(self, coeff_re, coeff_im, logamp, coherent=False, sh_re=None, sh_im=None):
         cr, ci, la = _f64(coeff_re), _f64(coeff_im), _f64(logamp)
@@ -445,6 +483,14 @@ def comm_gather_all(handles, n_local, hist_range=None, powers=True):
                                       None if hist is None else hist.ctypes.data_as(C.POINTER(C.c_int64)),
                                       float(lo), float(hi), int(nb)))
     return allp, hist
+
+
+def comm_gather_all_queued(handles, n_local, hist_range=None, powers=True, slot=0):
+    """The exchange of a queued step for all handles of this process (after run_queued on `slot` of each): enqueue and return;
+    handles[0].queue_wait(slot, n_local * len(handles), nbins) collects, the other handles' queue_wait only wait."""
+    lo, hi, nb = hist_range if hist_range is not None else (0.0, 1.0, 0)
+    _chk(lib().fastmc_comm_gather_all_queued(_handle_array(handles), len(handles), int(n_local), int(bool(powers)), float(lo), float(hi),
+                                             int(nb), int(slot)))
 
 
 def comm_unique_id():

@@ -61,6 +61,24 @@ struct TimedSpan {
   int family;
 };
 
+// One of the two steps a handle can have in flight (fastmc_run_queued / fastmc_comm_gather*_queued / fastmc_queue_wait): its own
+// timing events, its own pinned host landing buffers and a completion event, so that the kernels of step i + 1 are enqueued
+// while step i's results are still on their way to the host -- the device never waits for the host between steps.
+struct QueueSlot {
+  std::vector<TimedSpan> spans;
+  std::vector<hipEvent_t> pool;
+  size_t pool_used = 0;
+  hipEvent_t ex_a = nullptr, ex_b = nullptr;
+  bool ex_recorded = false;
+  bool pending = false;
+  bool busy = false;              // enqueued and not waited for
+  hipEvent_t done = nullptr;      // after the last copy of the step
+  double* pinned = nullptr;       // host landing buffer: the step's own vector, or the gathered vectors
+  size_t pinned_cap = 0, landed = 0;   // doubles
+  unsigned long long* pinned_hist = nullptr;
+  size_t hist_cap = 0, hist_landed = 0;
+};
+
 struct fastmc_ctx {
   int device = 0, N = 0, Np = 0, lo = 0, precision = 0;
   int precision_req = 0;   // what fastmc_create was asked for (float32 is honoured on the wave family's grids only)
@@ -156,6 +174,7 @@ struct fastmc_ctx {
   std::timed_mutex use_mu;
   char last_rows[96] = "", last_cols[96] = "";   // the row / column kernels of the last launch, as c++filt prints them (fastmc_last_kernels)
   bool pending = false;
+  QueueSlot q[2];
   size_t last_out_doubles = 0;    // size of the last run's result vector in `out`
   hipEvent_t ex_a = nullptr, ex_b = nullptr;   // around the collectives of the last exchange
   bool ex_recorded = false;
@@ -249,6 +268,24 @@ static void finish_pending(fastmc_ctx* h) {
     h->ex_recorded = false;
   }
 }
+
+// The timing state of a queue slot takes the place of the handle's own for the length of a call (and back): the launch code
+// (Span, timing_begin / timing_end, exchange_begin / exchange_end) never knows which step it is timing.
+static void swap_slot(fastmc_ctx* h, QueueSlot& q) {
+  std::swap(h->spans, q.spans);
+  std::swap(h->pool, q.pool);
+  std::swap(h->pool_used, q.pool_used);
+  std::swap(h->ex_a, q.ex_a);
+  std::swap(h->ex_b, q.ex_b);
+  std::swap(h->ex_recorded, q.ex_recorded);
+  std::swap(h->pending, q.pending);
+}
+struct SlotScope {
+  fastmc_ctx* h;
+  QueueSlot& q;
+  SlotScope(fastmc_ctx* h_, QueueSlot& q_) : h(h_), q(q_) { swap_slot(h, q); }
+  ~SlotScope() { swap_slot(h, q); }
+};
 
 // ------------------------------------------------------------------ misc entry points
 #if FMC_TU == 0
@@ -464,6 +501,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   finish_pending(h);
+  for (QueueSlot& q : h->q) { q.busy = q.pending = q.ex_recorded = false; q.landed = q.hist_landed = 0; }
   // back to the state fastmc_create leaves: problem unset, results forgotten, options at their defaults; buffers kept
   h->have_spec = h->have_pupil = h->have_sh = h->have_ps = false;
   h->last_n_iter = 0;
@@ -494,6 +532,12 @@ static void destroy_now(fastmc_ctx* h) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (auto e : h->pool) hipEventDestroy(e);
+  for (QueueSlot& q : h->q) {
+    for (auto e : q.pool) hipEventDestroy(e);
+    for (hipEvent_t e : {q.ex_a, q.ex_b, q.done}) if (e) hipEventDestroy(e);
+    if (q.pinned) hipHostFree(q.pinned);
+    if (q.pinned_hist) hipHostFree(q.pinned_hist);
+  }
   if (h->ex_a) hipEventDestroy(h->ex_a);
   if (h->ex_b) hipEventDestroy(h->ex_b);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -1562,9 +1606,14 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
   return 0;
 }
 
+static int run_locked(fastmc_ctx* h, const RunSpec& S);
+static int histogram_device(fastmc_ctx* h, double lo, double hi, int nbins);
 static int run_checked(fastmc_ctx* h, const RunSpec& S) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   FMC_LOCK(h);
+  return run_locked(h, S);
+}
+static int run_locked(fastmc_ctx* h, const RunSpec& S) {      // the caller holds the handle's lock
   if (h->pending) {       // an asynchronous run nobody waited for: its events are read before they are reused
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1611,6 +1660,96 @@ extern "C" int fastmc_wait(fastmc_t* h, double* out) {
   HIPCHK(hipStreamSynchronize(h->stream));
   finish_pending(h);
   return 0;
+}
+#endif
+
+#if FMC_TU == 0
+// ---- two steps in flight (QueueSlot)
+static int slot_land(fastmc_ctx* h, QueueSlot& q, const double* dev, size_t n) {     // D2H into the slot's pinned buffer, on the stream
+  if (q.pinned_cap < n) {
+    if (q.pinned) HIPCHK(hipHostFree(q.pinned));
+    q.pinned = nullptr; q.pinned_cap = 0;
+    HIPCHK(hipHostMalloc((void**)&q.pinned, n * 8, hipHostMallocDefault));
+    q.pinned_cap = n;
+  }
+  HIPCHK(hipMemcpyAsync(q.pinned, dev, n * 8, hipMemcpyDeviceToHost, h->stream));
+  q.landed = n;
+  return 0;
+}
+static int slot_land_hist(fastmc_ctx* h, QueueSlot& q, int nbins) {
+  const size_t n = (size_t)nbins + 2;
+  if (q.hist_cap < n) {
+    if (q.pinned_hist) HIPCHK(hipHostFree(q.pinned_hist));
+    q.pinned_hist = nullptr; q.hist_cap = 0;
+    HIPCHK(hipHostMalloc((void**)&q.pinned_hist, n * 8, hipHostMallocDefault));
+    q.hist_cap = n;
+  }
+  HIPCHK(hipMemcpyAsync(q.pinned_hist, h->hist, n * 8, hipMemcpyDeviceToHost, h->stream));
+  q.hist_landed = n;
+  return 0;
+}
+static int slot_mark_done(fastmc_ctx* h, QueueSlot& q) {
+  if (!q.done) HIPCHK(hipEventCreateWithFlags(&q.done, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(q.done, h->stream));
+  q.busy = true;
+  return 0;
+}
+
+extern "C" int fastmc_run_queued(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real, double logamp_var, int coherent, int slot,
+                                 int fetch) {
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  if (slot < 0 || slot > 1) return fail(FASTMC_EINVAL, "slot must be 0 or 1");
+  if (!(logamp_var >= 0.0)) return fail(FASTMC_EINVAL, "logamp_var must be >= 0");
+  FMC_LOCK(h);
+  QueueSlot& q = h->q[slot];
+  if (q.busy) return fail(FASTMC_ESTATE, "this slot is still in flight (fastmc_queue_wait first)");
+  {
+    SlotScope sc(h, q);
+    RunSpec S{0, 0, seed, real0, n_real, nullptr, nullptr, nullptr, nullptr, nullptr, logamp_var, coherent, nullptr, nullptr};
+    S.async = true;
+    TRY(run_locked(h, S));
+  }
+  q.landed = q.hist_landed = 0;
+  if (fetch) TRY(slot_land(h, q, h->out, h->last_out_doubles));
+  return slot_mark_done(h, q);
+}
+
+// the dB histogram of a queued step's own results (no exchange), landed on the slot
+extern "C" int fastmc_histogram_queued(fastmc_t* h, double lo_db, double hi_db, int nbins, int slot) {
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  if (slot < 0 || slot > 1) return fail(FASTMC_EINVAL, "slot must be 0 or 1");
+  FMC_LOCK(h);
+  QueueSlot& q = h->q[slot];
+  if (!q.busy) return fail(FASTMC_ESTATE, "fastmc_run_queued on this slot first");
+  HIPCHK(hipSetDevice(h->device));
+  TRY(histogram_device(h, lo_db, hi_db, nbins));
+  TRY(slot_land_hist(h, q, nbins));
+  return slot_mark_done(h, q);
+}
+
+extern "C" int fastmc_queue_wait(fastmc_t* h, int slot, double* out, int64_t out_cap, int64_t* hist, int hist_cap) {
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  if (slot < 0 || slot > 1) return fail(FASTMC_EINVAL, "slot must be 0 or 1");
+  FMC_LOCK(h);
+  QueueSlot& q = h->q[slot];
+  if (!q.busy) return fail(FASTMC_ESTATE, "nothing is queued on this slot");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipEventSynchronize(q.done));
+  {
+    SlotScope sc(h, q);
+    finish_pending(h);          // this step's events -> fastmc_last_timing / fastmc_last_exchange_ms
+  }
+  q.busy = false;
+  if (out) {
+    if ((size_t)out_cap < q.landed) return fail(FASTMC_EINVAL, "out is smaller than what the step landed");
+    if (!q.landed) return fail(FASTMC_ESTATE, "the step on this slot landed no results on this handle (fetch = 0 and no gather)");
+    memcpy(out, q.pinned, q.landed * 8);
+  }
+  if (hist) {
+    if ((size_t)hist_cap < q.hist_landed || !q.hist_landed) return fail(FASTMC_EINVAL, "no histogram landed on this slot, or hist is too small");
+    memcpy(hist, q.pinned_hist, q.hist_landed * 8);
+  }
+  return (int)q.landed;
 }
 #endif
 
@@ -2342,6 +2481,104 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
   }
   for (int i = 0; i < n; ++i)
     if (g_abort_gen[handles[i]->device & 63].load() != gens[i]) return fail(FASTMC_ECOMM, "a communicator was aborted during the exchange");
+  return 0;
+}
+#endif
+
+#if FMC_TU == 0
+// The exchange of a QUEUED step (fastmc_run_queued on the same slot first): the collectives and the copies of their results
+// into the slot's pinned buffers are enqueued behind the step's kernels and the call returns; fastmc_queue_wait collects.
+extern "C" int fastmc_comm_gather_queued(fastmc_t* h, int64_t n_local, int want_powers, double lo_db, double hi_db, int nbins, int slot) {
+  if (!h) return fail(FASTMC_EINVAL, "null handle");
+  if (slot < 0 || slot > 1) return fail(FASTMC_EINVAL, "slot must be 0 or 1");
+  if (stall_requested()) return stall_until_abort({h->device});
+  FMC_LOCK(h);
+  QueueSlot& q = h->q[slot];
+  if (!q.busy) return fail(FASTMC_ESTATE, "fastmc_run_queued on this slot first");
+  std::lock_guard<std::timed_mutex> enq(g_enq_mu[h->device & 63]);
+  const DeviceComm dc = device_comm(h->device);
+  if (!dc.comm) return fail(FASTMC_ESTATE, "fastmc_comm_init not called for this device (or its communicator was aborted)");
+  if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds the last run");
+  HIPCHK(hipSetDevice(h->device));
+  if (want_powers) TRY(grow(&h->gather_buf, &h->gather_cap, (size_t)n_local * dc.world));
+  {
+    SlotScope sc(h, q);
+    if (nbins > 0) TRY(histogram_device(h, lo_db, hi_db, nbins));
+    TRY(exchange_begin(h));
+    if (want_powers) TRY(comm_enqueue_gather(h, dc, n_local, true));
+    if (nbins > 0) TRY(comm_enqueue_hist(h, dc, nbins));
+    TRY(exchange_end(h));
+  }
+  if (want_powers) TRY(slot_land(h, q, h->gather_buf, (size_t)n_local * dc.world));
+  if (nbins > 0) TRY(slot_land_hist(h, q, nbins));
+  return slot_mark_done(h, q);
+}
+
+extern "C" int fastmc_comm_gather_all_queued(fastmc_t* const* handles, int n, int64_t n_local, int want_powers, double lo_db, double hi_db,
+                                             int nbins, int slot) {
+  if (!handles || n < 1 || n > 64) return fail(FASTMC_EINVAL, "bad argument");
+  if (slot < 0 || slot > 1) return fail(FASTMC_EINVAL, "slot must be 0 or 1");
+  if (stall_requested()) {
+    std::vector<int> devs;
+    for (int i = 0; i < n; ++i) if (handles[i]) devs.push_back(handles[i]->device);
+    return stall_until_abort(devs);
+  }
+  for (int i = 0; i < n; ++i) if (!handles[i]) return fail(FASTMC_EINVAL, "null handle");
+  std::vector<std::unique_ptr<HandleLock>> hl;
+  for (int i = 0; i < n; ++i) {
+    hl.emplace_back(new HandleLock(handles[i]));
+    if (!hl.back()->ok) return fail(FASTMC_ESTATE, "a handle is in use by another thread (an exchange that missed its deadline has not returned)");
+    if (!handles[i]->q[slot].busy) return fail(FASTMC_ESTATE, "fastmc_run_queued on this slot of every handle first");
+  }
+  std::vector<std::unique_lock<std::timed_mutex>> enq;
+  for (int i = 0; i < n; ++i) enq.emplace_back(g_enq_mu[handles[i]->device & 63]);
+  std::vector<DeviceComm> dcs(n);
+  for (int i = 0; i < n; ++i) {
+    fastmc_ctx* h = handles[i];
+    dcs[i] = device_comm(h->device);
+    if (!dcs[i].comm || dcs[i].world != n || dcs[i].rank != i)
+      return fail(FASTMC_ESTATE, "handles do not match the communicators of fastmc_comm_init_all (same handles, same order)");
+    if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds a handle's last run");
+  }
+  std::vector<std::unique_ptr<SlotScope>> scopes;
+  for (int i = 0; i < n; ++i) scopes.emplace_back(new SlotScope(handles[i], handles[i]->q[slot]));
+  for (int i = 0; i < n; ++i) {
+    HIPCHK(hipSetDevice(handles[i]->device));
+    if (want_powers) TRY(grow(&handles[i]->gather_buf, &handles[i]->gather_cap, (size_t)n_local * n));
+    if (nbins > 0) TRY(histogram_device(handles[i], lo_db, hi_db, nbins));
+    TRY(exchange_begin(handles[i]));
+  }
+  if (want_powers) {
+    NCCLCHK(g_rccl.GroupStart());
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; ++i) rc = comm_enqueue_gather(handles[i], dcs[i], n_local, true);
+    ncclResult_t ge = g_rccl.GroupEnd();
+    if (rc) return rc;
+    if (ge != ncclSuccess) return fail(FASTMC_ECOMM, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
+  }
+  if (nbins > 0) {
+    NCCLCHK(g_rccl.GroupStart());
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; ++i) rc = comm_enqueue_hist(handles[i], dcs[i], nbins);
+    ncclResult_t ge = g_rccl.GroupEnd();
+    if (rc) return rc;
+    if (ge != ncclSuccess) return fail(FASTMC_ECOMM, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(ge));
+  }
+  for (int i = 0; i < n; ++i) {
+    HIPCHK(hipSetDevice(handles[i]->device));
+    TRY(exchange_end(handles[i]));
+  }
+  scopes.clear();
+  // every rank holds the same gathered data: it lands on the host from rank 0; the others only mark their step done
+  for (int i = 0; i < n; ++i) {
+    fastmc_ctx* h = handles[i];
+    QueueSlot& q = h->q[slot];
+    HIPCHK(hipSetDevice(h->device));
+    q.landed = q.hist_landed = 0;
+    if (i == 0 && want_powers) TRY(slot_land(h, q, h->gather_buf, (size_t)n_local * n));
+    if (i == 0 && nbins > 0) TRY(slot_land_hist(h, q, nbins));
+    TRY(slot_mark_done(h, q));
+  }
   return 0;
 }
 #endif

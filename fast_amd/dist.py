@@ -347,5 +347,71 @@ def step_sharded(handle, transport, seed, real_base, n_real_total, logamp_var=0.
     return assemble(parts, complex_out=coherent), hist, info
 
 
+def steps_pipelined(handle, transport, seed, steps, logamp_var=0.0, coherent=False, hist_range=None):
+    """Generator: `step_sharded` for each (real_base, n_real_total) of `steps`, in order, with TWO steps in flight on the
+    device -- step i + 1's kernels and exchange are enqueued before step i's results are waited for (fastmc_run_queued /
+    fastmc_comm_gather_queued / fastmc_queue_wait), so the host side of a step costs the device nothing.  Yields
+    (full vector, global histogram | None, info).  Deadline, collective verdict and host fall-back as in `step_sharded`;
+    a step whose device exchange failed on any rank is redone by every rank on the host path (same realisations, same numbers)."""
+    steps = [(int(b), int(n)) for b, n in steps]
+    nbins = hist_range[2] if hist_range is not None else 0
+    world, rank = transport.world, transport.rank
+
+    def enqueue(i):
+        base, n_total = steps[i]
+        real0, n_local = shard_range(n_total, world, rank)
+        use_rccl = transport.name == "rccl"
+        handle.run_queued(seed, base + real0, n_local, logamp_var, coherent, i & 1, fetch=not use_rccl)
+        if use_rccl:
+            handle.comm_gather_queued(2 * n_local * (2 if coherent else 1), hist_range, True, i & 1)
+        elif hist_range is not None:
+            handle.histogram_queued(*hist_range, slot=i & 1)
+        return use_rccl
+
+    def drain():
+        for slot in (0, 1):
+            try:
+                handle.queue_wait(slot)
+            except Exception:
+                pass
+
+    mode = {}
+    if steps:
+        mode[0] = enqueue(0)
+    i = 0
+    while i < len(steps):
+        if i + 1 < len(steps) and (i + 1) not in mode:
+            mode[i + 1] = enqueue(i + 1)
+        base, n_total = steps[i]
+        real0, n_local = shard_range(n_total, world, rank)
+        nval = 2 * n_local * (2 if coherent else 1)
+        info = {"exchange": "rccl" if mode[i] else "host", "exchange_device_ms": 0.0}
+        t0 = time.perf_counter()
+        if mode[i]:
+            ok, val = call_with_deadline(lambda: handle.queue_wait(i & 1, nval * world, nbins), exchange_timeout())
+            flags = transport.rdzv.all_gather_array(np.array([1 if ok else 0], dtype=np.int32)).ravel()
+            if not flags.all():
+                bad = np.flatnonzero(flags == 0).tolist()
+                transport.degrade(handle, val if not ok else f"rank(s) {bad} reported a failed exchange")
+                ok2, why2 = call_with_deadline(drain, post_abort_timeout())
+                if not ok2:
+                    raise ExchangeStuck(f"queued steps did not drain after the RCCL exchange was aborted: {why2}")
+                mode = {i: enqueue(i)}
+                continue
+            allp, hist = val
+            allp = allp.reshape(world, nval)
+            parts = [allp[r].view(np.complex128) if coherent else allp[r] for r in range(world)]
+            info["exchange_device_ms"] = handle.last_exchange_ms()
+        else:
+            local, lh = handle.queue_wait(i & 1, nval, nbins)
+            t1 = time.perf_counter()
+            parts = transport.gather(local.view(np.complex128) if coherent else local, handle)
+            hist = None if hist_range is None else transport.reduce_hist(lh)
+            info["exchange_host_ms"] = (time.perf_counter() - t1) * 1e3
+        info["wall_ms"] = (time.perf_counter() - t0) * 1e3
+        yield assemble(parts, complex_out=coherent), hist, info
+        i += 1
+
+
 def histogram_sharded(local_hist, transport):
     return transport.reduce_hist(local_hist)

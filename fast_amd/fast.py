@@ -120,6 +120,7 @@ class Fast():
         # not sharded (statistics, histogram of the assembled vector, TEMPORAL and host-generator modes)
         self._group = multi.DeviceGroup(self.Npxls, self.Npxls_pup, self.precision, self.devices)
         self._handle = self._group.handles[0]
+        self.precision = getattr(self._handle, 'precision', self.precision)     # what the handle computes in (see _lib.Handle)
         if p['GPU_BATCH']:
             self._group.set_batch(p['GPU_BATCH'])
         if p['GPU_RNG_PRECISION'] == 'f64':

@@ -209,6 +209,100 @@ class DeviceGroup:
         self.last_exchange_wall_ms = (time.perf_counter() - t0) * 1e3
         return dist.assemble(parts, complex_out=coherent)
 
+    # ---- the same steps with TWO in flight: the device never waits for the host between steps
+    def run_pipelined(self, seed, steps, logamp_var=0.0, coherent=False, hist_range=None):
+        """Generator over `steps` = [(real0, n_real), ...]: yields (vector, histogram | None) of each step, in order, exactly
+        what `run` returns for it -- but step i + 1's kernels (and its exchange) are enqueued BEFORE step i's results are
+        waited for (fastmc_run_queued / fastmc_comm_gather_all_queued / fastmc_queue_wait: two slots per handle), so the
+        per-step host work (launches, the exchange's host side, result copies, Python) is hidden behind the device's work.
+        The exchange of every step runs under the same deadline as in `run`; a step whose device exchange gives no result is
+        recomputed -- the generator is keyed on the realisation index, so that is the same vector -- on the host path, which the
+        group then keeps."""
+        steps = [(int(r0), int(n)) for r0, n in steps]
+        self.last_hist = None
+        nbins = hist_range[2] if hist_range is not None else 0
+
+        def shards(n_real):
+            return dist.shard_ranges(n_real, self.world)
+
+        def enqueue(i):
+            r0, n_real = steps[i]
+            rg = shards(n_real)
+            slot = i & 1
+            equal = len({n for _, n in rg}) == 1 and rg[0][1] > 0
+            use_rccl = self._rccl and equal and self.world > 1
+            # (launches only: a few tens of microseconds per handle, from this thread -- they are off the critical path)
+            for h, (s0, n) in zip(self.handles, rg):
+                if n:
+                    h.run_queued(seed, r0 + s0, n, logamp_var, coherent, slot, fetch=not use_rccl)
+            if use_rccl:
+                _lib.comm_gather_all_queued(self.handles, 2 * rg[0][1] * (2 if coherent else 1), hist_range, True, slot)
+            elif hist_range is not None:
+                for h, (s0, n) in zip(self.handles, rg):
+                    if n:
+                        h.histogram_queued(*hist_range, slot=slot)
+            return use_rccl
+
+        def collect(i, used_rccl):
+            r0, n_real = steps[i]
+            rg = shards(n_real)
+            slot = i & 1
+            if used_rccl:
+                nval = 2 * rg[0][1] * (2 if coherent else 1)
+                allp, hist = self.handles[0].queue_wait(slot, nval * self.world, nbins)
+                for h in self.handles[1:]:
+                    h.queue_wait(slot)
+                allp = allp.reshape(self.world, nval)
+                parts = [allp[r].view(np.complex128) if coherent else allp[r] for r in range(self.world)]
+                self.last_exchange = "rccl"
+                self.last_exchange_ms = [h.last_exchange_ms() for h in self.handles]
+                return dist.assemble(parts, complex_out=coherent), hist
+            parts, hist = [], None
+            for h, (s0, n) in zip(self.handles, rg):
+                if not n:
+                    parts.append(np.empty(0, dtype=np.complex128 if coherent else np.float64))
+                    continue
+                v, hh = h.queue_wait(slot, 2 * n * (2 if coherent else 1), nbins)
+                parts.append(v.view(np.complex128) if coherent else v)
+                if hh is not None:
+                    hist = hh if hist is None else hist + hh
+            self.last_exchange = "host" if self.world > 1 else "none"
+            return dist.assemble(parts, complex_out=coherent), hist
+
+        def drain():
+            for h in self.handles:
+                for slot in (0, 1):
+                    try:
+                        h.queue_wait(slot)
+                    except Exception:
+                        pass
+
+        mode = {}
+        if steps:
+            mode[0] = enqueue(0)
+        i = 0
+        while i < len(steps):
+            if i + 1 < len(steps) and (i + 1) not in mode:
+                mode[i + 1] = enqueue(i + 1)
+            t0 = time.perf_counter()
+            if mode[i]:
+                ok, val = call_with_deadline(lambda: collect(i, True), exchange_timeout())
+            else:
+                ok, val = True, collect(i, False)
+            self.last_exchange_wall_ms = (time.perf_counter() - t0) * 1e3
+            if not ok:
+                # the device exchange gave no result: abort, wait for whatever is still inside the library, empty both slots
+                # and redo this step and the queued one on the host path (same realisations, same numbers)
+                self._degrade(val)
+                ok2, why2 = call_with_deadline(drain, dist.post_abort_timeout())
+                if not ok2:
+                    raise dist.ExchangeStuck(f"queued steps did not drain after the RCCL exchange was aborted: {why2}")
+                mode = {i: enqueue(i)}
+                continue
+            self.last_hist = val[1]
+            yield val
+            i += 1
+
     def _degrade(self, why):
         """Give the clique up for good: abort every communicator (wakes a blocked exchange) and take the host path."""
         self._rccl = False

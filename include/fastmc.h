@@ -200,6 +200,29 @@ int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches);
  * force: -1 query only, 0 / 1 / 2 / 3 select (fails with EINVAL if the family does not serve this (N, Np)). */
 int fastmc_kernel_path(fastmc_t* h, int force);
 
+/* ---- Two steps in flight per handle (round 4) ------------------------------------------------------------------------
+ * fastmc_run / fastmc_run_async + fastmc_wait leave the device idle while the host collects a step's results and issues
+ * the next one.  A handle has two SLOTS (0 and 1), each with its own timing events, pinned host landing buffers and a
+ * completion event, so that a caller can keep the stream fed:
+ *     run_queued(step 0, slot 0);  for i = 0, 1, ...: { run_queued(step i + 1, slot (i + 1) & 1);  queue_wait(slot i & 1) }
+ * Everything is ordered by the handle's one stream (kernels of step i, the exchange of step i, the copy of its results to
+ * the slot's pinned buffer, kernels of step i + 1 ...), so the device buffers need no copies of their own.
+ *   fastmc_run_queued          as fastmc_run_async; fetch != 0 also lands the step's own result vector on the slot;
+ *   fastmc_comm_gather_queued  after run_queued on the same slot: enqueue the all-gather of the n_local values per rank
+ *                              (want_powers != 0) and / or the all-reduced dB histogram (nbins > 0) and land them on the slot;
+ *   fastmc_comm_gather_all_queued  the same for the N handles of one process (ncclCommInitAll order); rank 0's slot lands;
+ *   fastmc_queue_wait          wait for the slot's step; copy what it landed into out (capacity out_cap doubles) and hist
+ *                              (hist_cap int64: nbins + 2); either may be NULL.  Returns the number of doubles landed.
+ *                              fastmc_last_timing / fastmc_last_exchange_ms then describe that step.
+ * Errors as everywhere: a busy slot, a missing run_queued, an aborted communicator are FASTMC_ESTATE / FASTMC_ECOMM. */
+int fastmc_run_queued(fastmc_t* h, uint64_t seed, int64_t real0, int64_t n_real, double logamp_var, int coherent, int slot,
+                      int fetch);
+int fastmc_comm_gather_queued(fastmc_t* h, int64_t n_local, int want_powers, double lo_db, double hi_db, int nbins, int slot);
+int fastmc_comm_gather_all_queued(fastmc_t* const* handles, int n, int64_t n_local, int want_powers, double lo_db, double hi_db,
+                                  int nbins, int slot);
+int fastmc_histogram_queued(fastmc_t* h, double lo_db, double hi_db, int nbins, int slot);   /* of the slot's own results, no exchange */
+int fastmc_queue_wait(fastmc_t* h, int slot, double* out, int64_t out_cap, int64_t* hist, int hist_cap);
+
 /* Names of the row and column kernels the handle launched last, as c++filt prints the instantiations (e.g.
  * "k_rows_wave<double, 16, 2, 0, 1, 4>"; empty before the first run): bench.py prices the instruction mix of what actually
  * ran (fast_amd/kernel_isa_stats.json is keyed by these names).  rows / cols: caller's buffers of `cap` bytes each. */

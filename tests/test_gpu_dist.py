@@ -282,4 +282,76 @@ os.environ["FASTMC_HANDLE_BUSY_TIMEOUT"] = "0.5"
 print("ok")
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.returncode == 0 and "ok" in r.stdout.splitlines(), r.stdout[-2000:] + r.stderr[-3000:]      # (RCCL prints its banner after it)
+
+
+def test_two_steps_in_flight_equal_one_step_at_a_time():
+    """fastmc_run_queued / fastmc_histogram_queued / fastmc_queue_wait: step i + 1 enqueued before step i is collected, on one
+    handle and on a group of three handles (host exchange on a 1-GPU box): vectors and histograms identical to the blocking
+    calls, timing of each step readable after its wait, slot misuse refused."""
+    p = _params(GPU_DEVICE=0, NITER=64, NCHUNKS=1)
+    sim = fast_amd.Fast(dict(p))
+    h = sim._handle
+    lv = float(sim.logamp_var)
+    steps = [(0, 40), (40, 40), (80, 24), (104, 40), (144, 8)]
+    hr = (-40.0, 10.0, 32)
+    want = [(h.run(3, r0, n, None, lv), h.histogram(*hr)) for r0, n in steps]
+    got = list(sim._group.run_pipelined(3, steps, lv, False, hr))
+    for (v, hh), (wv, wh) in zip(got, want):
+        assert np.array_equal(v, wv) and np.array_equal(hh, wh)
+    t = h.last_timing()
+    assert t["rows_ms"] > 0 and t["rows_launches"] >= 1
+    # coherent amplitudes, no histogram
+    wantc = [h.run(3, r0, n, None, lv, True) for r0, n in steps[:3]]
+    gotc = [v for v, _ in sim._group.run_pipelined(3, steps[:3], lv, True, None)]
+    assert all(np.array_equal(a, b) for a, b in zip(gotc, wantc))
+    # slots: a busy slot refuses a second step; an idle one has nothing to wait for
+    h.run_queued(3, 0, 8, lv, False, slot=0)
+    with pytest.raises(_lib.FastMCError, match="still in flight"):
+        h.run_queued(3, 8, 8, lv, False, slot=0)
+    with pytest.raises(_lib.FastMCError, match="nothing is queued"):
+        h.queue_wait(1)
+    v, _ = h.queue_wait(0, 16)
+    assert np.array_equal(v, h.run(3, 0, 8, None, lv))
+    # a blocking run between queued steps is allowed (stream order): results of both intact
+    h.run_queued(3, 0, 8, lv, False, slot=1)
+    mid = h.run(3, 100, 8, None, lv)
+    v, _ = h.queue_wait(1, 16)
+    assert np.array_equal(v, h.run(3, 0, 8, None, lv)) and np.array_equal(mid, h.run(3, 100, 8, None, lv))
+    # three handles on the one device
+    p3 = dict(p, GPU_DEVICES=[0, 0, 0])
+    p3.pop("GPU_DEVICE")
+    grp = fast_amd.Fast(p3)._group
+    steps3 = [(0, 30), (30, 30), (60, 31), (91, 30)]          # 31: unequal shards
+    want3 = [(h.run(3, r0, n, None, lv), h.histogram(*hr)) for r0, n in steps3]
+    got3 = list(grp.run_pipelined(3, steps3, lv, False, hr))
+    for (v, hh), (wv, wh) in zip(got3, want3):
+        assert np.array_equal(v, wv) and np.array_equal(hh, wh)
+
+
+def test_queued_rccl_exchange_with_a_world_of_one():
+    """The queued exchange (fastmc_comm_gather_queued) on a real communicator, world of one, through dist.steps_pipelined:
+    identical to step_sharded step by step (the fall-back of a failed queued exchange is exercised on the CPU with stand-in
+    handles: tests/test_multi_deadline.py)."""
+    code = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, %r)
+os.environ["FASTMC_EXCHANGE_TIMEOUT"] = "1.5"
+from fast_amd import _lib, dist, rendezvous
+h = _lib.Handle(256, 40, "f64", 0)
+ps = np.full((256, 256), 1e-3); ps[128, 128] = 0.0
+h.set_spectrum(ps, 0.25); h.set_pupil(np.ones((40, 40)), 108, 0.01)
+rdzv = rendezvous.Rendezvous(0, 1, "unix", "fastmc-test-queued")
+tr = dist.make_transport(h, rdzv, rccl_timeout=60)
+assert tr.name == "rccl"
+steps = [(0, 50), (50, 50), (100, 50), (150, 50)]
+hr = (-40.0, 10.0, 16)
+want = [dist.step_sharded(h, tr, 4, b, n, 0.01, False, hr) for b, n in steps]
+got = list(dist.steps_pipelined(h, tr, 4, steps, 0.01, False, hr))
+for (v, hh, info), (wv, wh, _) in zip(got, want):
+    assert np.array_equal(v, wv) and np.array_equal(hh, wh) and info["exchange"] == "rccl" and info["exchange_device_ms"] >= 0
+print("ok")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout.splitlines(), r.stdout[-2000:] + r.stderr[-3000:]

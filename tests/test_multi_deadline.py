@@ -36,6 +36,23 @@ class FakeHandle:
         self.aborted += 1
         FakeHandle.wake.set()
 
+    # two steps in flight
+    def run_queued(self, seed, real0, n, logamp_var, coherent, slot, fetch=True):
+        q = self.__dict__.setdefault("_q", {})
+        assert slot not in q, "slot busy"
+        q[slot] = self._values(real0, n)
+        self._local = q[slot]
+
+    def histogram_queued(self, lo, hi, nbins, slot=0):
+        h = np.zeros(nbins + 2, dtype=np.int64)
+        h[0] = self._q[slot].size
+        self.__dict__.setdefault("_qh", {})[slot] = h
+
+    def queue_wait(self, slot, n_out=0, hist_bins=0):
+        v = self._q.pop(slot)
+        hh = self.__dict__.get("_qh", {}).pop(slot, None)
+        return (v if n_out else None), (hh if hist_bins else None)
+
     def last_exchange_ms(self):
         return 0.5
 
@@ -148,3 +165,46 @@ def test_left_behind_exchange_is_waited_for_with_a_bound(monkeypatch):
     never.set()
     time.sleep(0.1)
     dist._LEFT_BEHIND[:] = [t for t in dist._LEFT_BEHIND if t.is_alive()]
+
+
+def test_pipelined_steps_equal_the_blocking_ones_and_survive_a_dead_exchange(monkeypatch):
+    """DeviceGroup.run_pipelined: (1) host exchange, unequal shards, histograms; (2) with an RCCL clique whose queued exchange
+    never answers: the deadline passes, the clique is aborted, both slots are drained and the SAME steps come back through the
+    host path; later steps stay there."""
+    steps = [(0, 10), (10, 11), (21, 10), (31, 4)]
+    want = [np.concatenate([np.arange(r0, r0 + n) + 0.25, np.arange(r0, r0 + n) + 0.75]) for r0, n in steps]
+    grp = _group(3)
+    grp._rccl = False
+    got = list(grp.run_pipelined(1, steps, 0.0, False, (-10.0, 10.0, 4)))
+    for (v, hh), w, (_, n) in zip(got, want, steps):
+        assert np.array_equal(v, w) and hh[0] == 2 * n
+    assert all(not h._q for h in grp.handles)
+
+    grp = _group(2)
+    monkeypatch.setenv("FASTMC_EXCHANGE_TIMEOUT", "0.3")
+    monkeypatch.setenv("FASTMC_POST_ABORT_TIMEOUT", "2")
+    calls = {"n": 0}
+
+    def gather_all_queued(handles, n_local, hist_range=None, powers=True, slot=0):
+        calls["n"] += 1
+
+    monkeypatch.setattr(_lib, "comm_gather_all_queued", gather_all_queued)
+    real_wait = FakeHandle.queue_wait
+
+    def wait_that_hangs_on_rccl_steps(self, slot, n_out=0, hist_bins=0):
+        if grp._rccl and self is grp.handles[0] and n_out:       # the gathered landing buffer never arrives
+            FakeHandle.wake.wait()
+            raise _lib.FastMCError("aborted")
+        return real_wait(self, slot, n_out, hist_bins)
+    monkeypatch.setattr(FakeHandle, "queue_wait", wait_that_hangs_on_rccl_steps)
+    even = [(0, 10), (10, 10), (20, 10)]
+    want = [np.concatenate([np.arange(r0, r0 + n) + 0.25, np.arange(r0, r0 + n) + 0.75]) for r0, n in even]
+    t0 = time.perf_counter()
+    got = list(grp.run_pipelined(1, even, 0.0, False, None))
+    assert 0.25 < time.perf_counter() - t0 < 10
+    assert all(np.array_equal(v, w) for (v, _), w in zip(got, want))
+    assert calls["n"] == 2                                        # steps 0 and 1 were queued on the clique before it was given up
+    assert grp.exchange.startswith("host (RCCL exchange given up") and grp.last_exchange == "host"
+    assert all(h.aborted == 1 for h in grp.handles)
+    time.sleep(0.1)
+    assert not dist.stuck_threads()

@@ -72,6 +72,8 @@ struct QueueSlot {
   bool ex_recorded = false;
   bool pending = false;
   bool busy = false;              // enqueued and not waited for
+  bool stalled = false;           // FASTMC_TEST_STALL_GATHER=1: the queued exchange "never completes" (fastmc_queue_wait blocks until an abort)
+  int stall_gen = 0;              //   ... counted from the abort generation of the device when the exchange was queued
   hipEvent_t done = nullptr;      // after the last copy of the step
   double* pinned = nullptr;       // host landing buffer: the step's own vector, or the gathered vectors
   size_t pinned_cap = 0, landed = 0;   // doubles
@@ -501,7 +503,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   finish_pending(h);
-  for (QueueSlot& q : h->q) { q.busy = q.pending = q.ex_recorded = false; q.landed = q.hist_landed = 0; }
+  for (QueueSlot& q : h->q) { q.busy = q.pending = q.ex_recorded = q.stalled = false; q.landed = q.hist_landed = 0; }
   // back to the state fastmc_create leaves: problem unset, results forgotten, options at their defaults; buffers kept
   h->have_spec = h->have_pupil = h->have_sh = h->have_ps = false;
   h->last_n_iter = 0;
@@ -1608,6 +1610,8 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
 
 static int run_locked(fastmc_ctx* h, const RunSpec& S);
 static int histogram_device(fastmc_ctx* h, double lo, double hi, int nbins);
+static int stall_until_abort(const std::vector<int>& devices);
+static std::atomic<int> g_abort_gen[64];      // bumped by fastmc_comm_abort: wakes a stalled exchange of that device
 static int run_checked(fastmc_ctx* h, const RunSpec& S) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   FMC_LOCK(h);
@@ -1734,6 +1738,15 @@ extern "C" int fastmc_queue_wait(fastmc_t* h, int slot, double* out, int64_t out
   QueueSlot& q = h->q[slot];
   if (!q.busy) return fail(FASTMC_ESTATE, "nothing is queued on this slot");
   HIPCHK(hipSetDevice(h->device));
+  if (q.stalled) {               // the injected fault: an exchange that never completes, until the caller aborts
+    while (g_abort_gen[h->device & 63].load() == q.stall_gen) usleep(500);      // an abort since the exchange was queued ends the stall
+    const int rc = fail(FASTMC_ECOMM, "exchange aborted (FASTMC_TEST_STALL_GATHER)");
+    hipEventSynchronize(q.done);
+    { SlotScope sc(h, q); finish_pending(h); }
+    q.stalled = q.busy = false;
+    q.landed = q.hist_landed = 0;
+    return rc;
+  }
   HIPCHK(hipEventSynchronize(q.done));
   {
     SlotScope sc(h, q);
@@ -2238,7 +2251,6 @@ struct DeviceComm {
 };
 static DeviceComm g_comm[64];
 static std::mutex g_comm_mu;
-static std::atomic<int> g_abort_gen[64];      // bumped by fastmc_comm_abort: wakes a stalled exchange of that device
 // A device's communicator is handed to RCCL only under this lock (read g_comm -> enqueue the collectives), and
 // fastmc_comm_abort takes it (with a deadline of two seconds: enqueueing does not wait for peers) before ncclCommAbort frees
 // the communicator: no thread is ever between "copied the communicator" and "passed it to ncclAllGather" when it is freed.
@@ -2491,10 +2503,10 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
 extern "C" int fastmc_comm_gather_queued(fastmc_t* h, int64_t n_local, int want_powers, double lo_db, double hi_db, int nbins, int slot) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   if (slot < 0 || slot > 1) return fail(FASTMC_EINVAL, "slot must be 0 or 1");
-  if (stall_requested()) return stall_until_abort({h->device});
   FMC_LOCK(h);
   QueueSlot& q = h->q[slot];
   if (!q.busy) return fail(FASTMC_ESTATE, "fastmc_run_queued on this slot first");
+  if (stall_requested()) { q.stalled = true; q.stall_gen = g_abort_gen[h->device & 63].load(); return 0; }   // fault injection: enqueueing never blocks; the wait will
   std::lock_guard<std::timed_mutex> enq(g_enq_mu[h->device & 63]);
   const DeviceComm dc = device_comm(h->device);
   if (!dc.comm) return fail(FASTMC_ESTATE, "fastmc_comm_init not called for this device (or its communicator was aborted)");
@@ -2518,17 +2530,16 @@ extern "C" int fastmc_comm_gather_all_queued(fastmc_t* const* handles, int n, in
                                              int nbins, int slot) {
   if (!handles || n < 1 || n > 64) return fail(FASTMC_EINVAL, "bad argument");
   if (slot < 0 || slot > 1) return fail(FASTMC_EINVAL, "slot must be 0 or 1");
-  if (stall_requested()) {
-    std::vector<int> devs;
-    for (int i = 0; i < n; ++i) if (handles[i]) devs.push_back(handles[i]->device);
-    return stall_until_abort(devs);
-  }
   for (int i = 0; i < n; ++i) if (!handles[i]) return fail(FASTMC_EINVAL, "null handle");
   std::vector<std::unique_ptr<HandleLock>> hl;
   for (int i = 0; i < n; ++i) {
     hl.emplace_back(new HandleLock(handles[i]));
     if (!hl.back()->ok) return fail(FASTMC_ESTATE, "a handle is in use by another thread (an exchange that missed its deadline has not returned)");
     if (!handles[i]->q[slot].busy) return fail(FASTMC_ESTATE, "fastmc_run_queued on this slot of every handle first");
+  }
+  if (stall_requested()) {       // fault injection: enqueueing never blocks; the waits will
+    for (int i = 0; i < n; ++i) { handles[i]->q[slot].stalled = true; handles[i]->q[slot].stall_gen = g_abort_gen[handles[i]->device & 63].load(); }
+    return 0;
   }
   std::vector<std::unique_lock<std::timed_mutex>> enq;
   for (int i = 0; i < n; ++i) enq.emplace_back(g_enq_mu[handles[i]->device & 63]);

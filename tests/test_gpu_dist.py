@@ -176,7 +176,7 @@ def test_bench_two_threads_on_one_gpu_reports_what_ran():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["FASTMC_BENCH_DEVICES"] = "0,0"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, env=env, timeout=900)
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["workers"] == 2 and line["config"]["result_exchange"].startswith("host")
@@ -192,7 +192,7 @@ def test_bench_eight_workers_with_a_stalled_exchange_prints_its_line_and_says_wh
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update({"FASTMC_BENCH_DEVICES": ",".join(["0"] * 8), "FASTMC_TEST_STALL_GATHER": "1", "FASTMC_EXCHANGE_TIMEOUT": "3"})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-extras", "--no-sustained"], capture_output=True, text=True, env=env, timeout=900)
+                        "--no-cpu-baseline", "--no-extras", "--no-sustained"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["workers"] == 8 and line["config"]["rccl_ranks"] == 0
@@ -205,7 +205,7 @@ def test_bench_config3_strong_scaling_workload():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["FASTMC_BENCH_DEVICES"] = "0,0"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "config3",
-                        "--no-cpu-baseline", "--no-extras", "--no-sustained"], capture_output=True, text=True, env=env, timeout=900)
+                        "--no-cpu-baseline", "--no-extras", "--no-sustained"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["scaling"] == "strong" and "2048^2" in line["metric"] and line["config"]["iters_per_step_per_gpu"] == 50000

@@ -363,6 +363,7 @@ def main():
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained run after the timed steps")
     ap.add_argument("--iters-per-step", type=int, default=ITERS_PER_STEP, help="iterations per GPU and step of the configs[1] workload "
                     "(default 10000 = BASELINE configs[1]; other values are for overhead studies, the line says what ran)")
+    ap.add_argument("--no-host-cost-pass", action="store_true", help="skip the one-call reference run behind pipeline.host_ms_per_step")
     ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (enqueue, exchange, wait) instead of two steps in flight per device")
     ap.add_argument("--no-f64-generator-pass", action="store_true", help="skip the second timed pass with the float64 generator")
     ap.add_argument("--batch", type=int, default=0, help="realisations per launch (0 = library default)")
@@ -548,6 +549,26 @@ def main():
             dts = float(rdzv.all_reduce(np.array([dts]), "max")[0])
         sustained = {"seconds": dts, "steps": n_sus, "value": iters_worker * n_sus * workers / dts, "unit": "iterations/s"}
 
+    # What the host costs per step: the SAME realisations as the timed steps once more as ONE call per worker (args.steps times
+    # the iterations, one exchange) -- the device-limited time of the job; the timed steps' wall time beyond it is what issuing,
+    # exchanging and collecting K separate steps cost.  (The kernels' own event times cannot say it: with two steps in flight
+    # the events of consecutive launches overlap.)
+    host_cost = None
+    if not args.no_host_cost_pass:
+        keep_hist = hist_total
+        sync_all()
+        t0 = time.perf_counter()
+        if mode == "ranks":
+            dist.step_sharded(h, tr, p["SEED"], args.warmup * workers * n_real, args.steps * workers * n_real, lvar, False, HIST)
+        else:
+            grp.run(p["SEED"], args.warmup * workers * n_real, args.steps * workers * n_real, None, lvar, False, hist_range=HIST)
+        sync_all()
+        dt_one = time.perf_counter() - t0
+        if rdzv is not None:
+            dt_one = float(rdzv.all_reduce(np.array([dt_one]), "max")[0])
+        host_cost = {"one_call_ms_per_step": dt_one / args.steps * 1e3, "host_ms_per_step": (dt - dt_one) / args.steps * 1e3}
+        hist_total = keep_hist
+
     # The same job with the generator at the REFERENCE's precision (53-bit normals, float64 colouring: fast/funcs.py:352-356,
     # fast/fast.py:593-594), timed like the headline: same steps, same barriers, fresh realisation ranges.  Reported beside
     # `value` as `value_f64_generator` with its own roofline; `--rng-precision f64` makes it the headline instead.
@@ -615,9 +636,11 @@ def main():
                        "histogram_total": None if hist_total is None else int(np.sum(hist_total))},
             "roofline": roofline(args, N, Np, tim, args.steps, workers, iters_worker, kernels),
             "pipeline": {"steps_in_flight": 1 if args.no_pipeline else 2,
-                         # wall time of a step that is not kernel time of the busiest worker: launches, the exchange's host side, result
-                         # copies, Python -- hidden behind the device's work when two steps are in flight
-                         "host_ms_per_step": dt / args.steps * 1e3 - float(busy.mean(0).max()),
+                         # what K separate steps cost beyond the device-limited time of the same work: launches, the exchange's host side,
+                         # result copies, Python -- hidden behind the device's work when two steps are in flight
+                         "host_ms_per_step": None if host_cost is None else host_cost["host_ms_per_step"],
+                         "one_call_ms_per_step": None if host_cost is None else host_cost["one_call_ms_per_step"],
+                         "host_ms_note": "ms_per_step minus the time per step of the same realisations issued as ONE call per worker (device-limited)",
                          "gpu_busy_ms_per_step_per_worker": gpu_ms / args.steps / workers,
                          "gpu_busy_ms_per_step": {"min_worker": float(busy.mean(0).min()), "max_worker": float(busy.mean(0).max()),
                                                   "per_worker": [float(x) for x in busy.mean(0)]},

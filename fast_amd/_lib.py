@@ -27,6 +27,7 @@ EXPORTS = [
     "fastmc_run_async", "fastmc_wait", "fastmc_set_rng_precision", "fastmc_temporal_phases", "fastmc_last_kernels",
     "fastmc_precision", "fastmc_last_result_shape", "fastmc_run_queued", "fastmc_comm_gather_queued",
     "fastmc_comm_gather_all_queued", "fastmc_histogram_queued", "fastmc_queue_wait",
+    "fastmc_npstream_set_tables", "fastmc_npstream_normals", "fastmc_npstream_logamp", "fastmc_run_npstream",
 ]
 
 
@@ -99,6 +100,11 @@ def lib():
     L.fastmc_comm_gather_all_queued.argtypes = [C.POINTER(vp), C.c_int, i64, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
     L.fastmc_histogram_queued.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int]
     L.fastmc_queue_wait.argtypes = [vp, C.c_int, dp, i64, C.POINTER(i64), C.c_int]
+    u64p = C.POINTER(C.c_uint64)
+    L.fastmc_npstream_set_tables.argtypes = [C.c_int, dp, u64p, dp]
+    L.fastmc_npstream_normals.argtypes = [vp, u64p, i64, dp, u64p, u64p, C.POINTER(C.c_uint32)]
+    L.fastmc_npstream_logamp.argtypes = [vp, u64p, i64, C.c_double, dp, u64p, C.POINTER(C.c_uint32)]
+    L.fastmc_run_npstream.argtypes = [vp, u64p, i64, i64, i64, C.c_int, dp, u64p, C.POINTER(i64)]
     L.fastmc_set_rng_precision.argtypes = [vp, C.c_int]
     L.fastmc_powerspec.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp, dp, dp]
     L.fastmc_powerspec_terms.argtypes = [C.c_int, C.POINTER(PsParams), dp, dp, dp, dp]
@@ -162,6 +168,7 @@ def default_device():
 
 
 _PROMOTED = set()
+_NPS_DEVICES = set()      # devices whose library copy of numpy's ziggurat tables has been uploaded
 
 
 class Handle:
@@ -262,6 +269,47 @@ class Handle:
         n = _chk(lib().fastmc_queue_wait(self._h, int(slot), _dptr(out), int(n_out), None if hist is None else hist.ctypes.data_as(C.POINTER(C.c_int64)),
                                          0 if hist is None else hist.size))
         return (None if out is None else out[:n]), hist
+
+    # ---- numpy's normal stream on the device (fastmc.h: fastmc_npstream_*; fast_amd/npnormal.py)
+    def _npstream_ready(self):
+        if self.device not in _NPS_DEVICES:
+            from . import npnormal
+            wi, ki, fi = npnormal.get_tables()
+            wi, fi, ki = np.ascontiguousarray(wi, dtype=np.float64), np.ascontiguousarray(fi, dtype=np.float64), np.ascontiguousarray(ki, dtype=np.uint64)
+            _chk(lib().fastmc_npstream_set_tables(self.device, _dptr(wi), ki.ctypes.data_as(C.POINTER(C.c_uint64)), _dptr(fi)))
+            _NPS_DEVICES.add(self.device)
+
+    @staticmethod
+    def _u64p(a):
+        return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+    def npstream_normals(self, state_words, n, fetch=True):
+        """`Generator(PCG64 at state_words).normal(size=n)` drawn on the device -> (values | None, state after (lo, hi), words
+        consumed, overflow flags)."""
+        self._npstream_ready()
+        sw = np.ascontiguousarray(state_words, dtype=np.uint64)
+        out = np.empty(int(n)) if fetch else None
+        after, cons, ovf = np.zeros(2, dtype=np.uint64), C.c_uint64(0), C.c_uint32(0)
+        _chk(lib().fastmc_npstream_normals(self._h, self._u64p(sw), int(n), _dptr(out), self._u64p(after), C.byref(cons), C.byref(ovf)))
+        return out, after, cons.value, ovf.value
+
+    def npstream_logamp(self, state_words, n_iter, logamp_var):
+        self._npstream_ready()
+        sw = np.ascontiguousarray(state_words, dtype=np.uint64)
+        la = np.empty(int(n_iter))
+        after, ovf = np.zeros(2, dtype=np.uint64), C.c_uint32(0)
+        _chk(lib().fastmc_npstream_logamp(self._h, self._u64p(sw), int(n_iter), float(logamp_var), _dptr(la), self._u64p(after), C.byref(ovf)))
+        return la, after, ovf.value
+
+    def run_npstream(self, state_words, n_chunks, chunk_real, logamp_offset, coherent=False):
+        """Chunks of the Monte-Carlo loop with numpy-stream coefficients -> (I[n_chunks][2 chunk_real], state after, bad chunk | -1)."""
+        self._npstream_ready()
+        sw = np.ascontiguousarray(state_words, dtype=np.uint64)
+        out = np.empty((int(n_chunks), 2 * int(chunk_real) * (2 if coherent else 1)))
+        after, bad = np.zeros(2, dtype=np.uint64), C.c_int64(-1)
+        _chk(lib().fastmc_run_npstream(self._h, self._u64p(sw), int(n_chunks), int(chunk_real), int(logamp_offset), int(bool(coherent)),
+                                       _dptr(out), self._u64p(after), C.byref(bad)))
+        return (out.view(np.complex128) if coherent else out), after, bad.value
 
     def run_coeffs(self, coeff_re, coeff_im, logamp, coherent=False, sh_re=None, sh_im=None):
         cr, ci, la = _f64(coeff_re), _f64(coeff_im), _f64(logamp)

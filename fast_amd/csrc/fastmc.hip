@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -26,6 +27,9 @@
 #include "fmc_kernels.h"
 #if FMC_TU == 0
 #include "fmc_powerspec.h"
+#if FMC_TU == 0
+#include "fmc_npstream.h"
+#endif
 #endif
 
 using namespace fmc;
@@ -177,6 +181,7 @@ struct fastmc_ctx {
   char last_rows[96] = "", last_cols[96] = "";   // the row / column kernels of the last launch, as c++filt prints them (fastmc_last_kernels)
   bool pending = false;
   QueueSlot q[2];
+  struct NpsWork* nps = nullptr;   // workspace of the numpy-stream generator (GPU_RNG 'numpy'; fmc_npstream.h), created on first use
   size_t last_out_doubles = 0;    // size of the last run's result vector in `out`
   hipEvent_t ex_a = nullptr, ex_b = nullptr;   // around the collectives of the last exchange
   bool ex_recorded = false;
@@ -1395,6 +1400,10 @@ struct RunSpec {
   double* out;              // host
   double* phs;              // host
   bool async = false;       // fastmc_run_async: no host copy, no wait
+  // coefficients drawn on the device (numpy stream): called per batch to fill cre / cim (and the sub-harmonic inputs) for
+  // realisations [bs, bs + nb) of this run instead of the uploads of mode 1
+  std::function<int(int64_t, int)> fill;
+  const double* logamp_dev = nullptr;   // log-amplitudes already on the device, in output order, scaled
 };
 
 // Does this handle's row kernel draw the float64 generator itself (MODE 2)?  The P = 16 rows of the wave family: 1024, and
@@ -1466,14 +1475,16 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     TRY(dev_alloc(&h->sh_in_im, (size_t)B * 27));
     h->sh_cap = B;
   }
-  if (sh && S.mode == 1 && (!S.sh_re || !S.sh_im)) return fail(FASTMC_EINVAL, "sub-harmonics are set: sh_re / sh_im required");
+  if (sh && S.mode == 1 && !S.fill && (!S.sh_re || !S.sh_im)) return fail(FASTMC_EINVAL, "sub-harmonics are set: sh_re / sh_im required");
 
   RngKey key{(uint32_t)S.seed, (uint32_t)(S.seed >> 32)};
   timing_begin(h);
   int64_t fin_start = 0;
   for (int64_t bs = 0; bs < S.n_real; bs += B) {
     const int nb = (int)std::min<int64_t>(B, S.n_real - bs);
-    if (S.mode == 1) {
+    if (S.mode == 1 && S.fill) {
+      TRY(S.fill(bs, nb));
+    } else if (S.mode == 1) {
       HIPCHK(hipMemcpyAsync(h->cre, S.coeff_re + (size_t)bs * N2, (size_t)nb * N2 * 8, hipMemcpyHostToDevice, h->stream));
       HIPCHK(hipMemcpyAsync(h->cim, S.coeff_im + (size_t)bs * N2, (size_t)nb * N2 * 8, hipMemcpyHostToDevice, h->stream));
     } else if (gen64) {
@@ -1486,7 +1497,9 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       ShCoefArgs SA;
       SA.nb = nb; SA.key = key; SA.g0 = (uint64_t)(S.real0 + bs);
       SA.sh_re = SA.sh_im = nullptr;
-      if (S.mode == 1) {
+      if (S.mode == 1 && S.fill) {
+        SA.sh_re = h->sh_in_re; SA.sh_im = h->sh_in_im;          // filled on the device by S.fill
+      } else if (S.mode == 1) {
         HIPCHK(hipMemcpyAsync(h->sh_in_re, S.sh_re + (size_t)bs * 27, (size_t)nb * 27 * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->sh_in_im, S.sh_im + (size_t)bs * 27, (size_t)nb * 27 * 8, hipMemcpyHostToDevice, h->stream));
         SA.sh_re = h->sh_in_re; SA.sh_im = h->sh_in_im;
@@ -1580,7 +1593,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
         Span sp(h, 2);
         FinArgs FA;
         FA.nb = (int)(done - fin_start); FA.Np = Np; FA.coherent = S.coherent; FA.n_real = S.n_real; FA.j0 = fin_start;
-        FA.partial = h->partial; FA.logamp = S.logamp ? h->logamp : nullptr;
+        FA.partial = h->partial; FA.logamp = S.logamp_dev ? S.logamp_dev : (S.logamp ? h->logamp : nullptr);
         FA.logamp_sigma = std::sqrt(S.logamp_var); FA.rng_f64 = h->rng_f64; FA.key = key; FA.g0 = (uint64_t)(S.real0 + fin_start);
         FA.dx2 = h->dx * h->dx; FA.norm = h->wsum * (h->dx * h->dx); FA.out = h->out;
         hipLaunchKernelGGL(k_finalize, dim3((FA.nb + 3) / 4), dim3(256), 0, h->stream, FA);
@@ -1763,6 +1776,265 @@ extern "C" int fastmc_queue_wait(fastmc_t* h, int slot, double* out, int64_t out
     memcpy(hist, q.pinned_hist, q.hist_landed * 8);
   }
   return (int)q.landed;
+}
+#endif
+
+#if FMC_TU == 0
+// ------------------------------------------------------------------ numpy's normal stream on the device (fmc_npstream.h)
+struct NpsSegBuf {           // what classify / scan leave behind for emit, one per segment kept alive
+  NpsEvent* events = nullptr;
+  uint32_t* evcount = nullptr;
+  uint32_t* maps = nullptr;
+  uint8_t* tile_e = nullptr;
+  uint64_t* tile_base = nullptr;
+  int64_t cap_tiles = 0;
+};
+struct NpsWork {
+  NpsSegBuf seg[4];          // real parts, imaginary parts, sub-harmonic real / imaginary parts of the chunk in flight
+  u128* states = nullptr;    // [cap_states] chain of generator states: states[k] = before segment k of the call
+  uint64_t* consumed = nullptr;    // [cap_states]
+  uint32_t* overflow = nullptr;    // [cap_states] per segment
+  size_t cap_states = 0;
+  double* la = nullptr;      // log-amplitude normals of the run (device)
+  size_t la_cap = 0;
+  double* sh_re = nullptr;   // sub-harmonic draws of a chunk
+  double* sh_im = nullptr;
+  size_t sh_cap = 0;
+};
+static std::mutex g_nps_mu;
+static std::map<int, std::pair<NpsTables*, NpsJump*>> g_nps_dev;     // per device: ziggurat tables (from numpy), jump table
+
+static void nps_jump_table(NpsJump* J) {
+  const u128 mult = ((((u128)0x2360ED051FC65DA4ull) << 64) | 0x4385DF649FCCF645ull);
+  u128 a = mult, g = 1;        // a^(2^k) and 1 + a + ... + a^(2^k - 1)
+  for (int k = 0; k < 64; ++k) {
+    J->a[k] = a;
+    J->c[k] = g;
+    g = g * (a + 1);
+    a = a * a;
+  }
+}
+
+extern "C" int fastmc_npstream_set_tables(int device_id, const double* wi, const uint64_t* ki, const double* fi) {
+  if (!wi || !ki || !fi) return fail(FASTMC_EINVAL, "null table");
+  HIPCHK(hipSetDevice(device_id));
+  std::lock_guard<std::mutex> lk(g_nps_mu);
+  auto& e = g_nps_dev[device_id];
+  if (!e.first) {
+    HIPCHK(hipMalloc((void**)&e.first, sizeof(NpsTables)));
+    HIPCHK(hipMalloc((void**)&e.second, sizeof(NpsJump)));
+    NpsJump* J = new NpsJump;
+    nps_jump_table(J);
+    hipError_t r = hipMemcpy(e.second, J, sizeof(NpsJump), hipMemcpyHostToDevice);
+    delete J;
+    HIPCHK(r);
+  }
+  NpsTables T;
+  memcpy(T.wi, wi, sizeof(T.wi)); memcpy(T.ki, ki, sizeof(T.ki)); memcpy(T.fi, fi, sizeof(T.fi));
+  HIPCHK(hipMemcpy(e.first, &T, sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int64_t nps_tiles_for(uint64_t n) {       // upper bound of the words n normals consume (mean 1.0222 per normal), in tiles
+  const uint64_t words = n + n / 32 + 2 * (uint64_t)NPS_T;
+  return (int64_t)((words + NPS_T - 1) / NPS_T);
+}
+static int nps_seg_reserve(NpsSegBuf& b, int64_t tiles) {
+  if (b.cap_tiles >= tiles) return 0;
+  for (void* p : {(void*)b.events, (void*)b.evcount, (void*)b.maps, (void*)b.tile_e, (void*)b.tile_base}) if (p) hipFree(p);
+  b = NpsSegBuf();
+  HIPCHK(hipMalloc((void**)&b.events, (size_t)tiles * NPS_EVCAP * sizeof(NpsEvent)));
+  HIPCHK(hipMalloc((void**)&b.evcount, (size_t)tiles * 4));
+  HIPCHK(hipMalloc((void**)&b.maps, (size_t)tiles * NPS_K * 4));
+  HIPCHK(hipMalloc((void**)&b.tile_e, (size_t)tiles));
+  HIPCHK(hipMalloc((void**)&b.tile_base, (size_t)tiles * 8));
+  b.cap_tiles = tiles;
+  return 0;
+}
+static int nps_reserve_states(NpsWork* w, size_t n) {
+  if (w->cap_states >= n) return 0;
+  for (void* p : {(void*)w->states, (void*)w->consumed, (void*)w->overflow}) if (p) hipFree(p);
+  w->states = nullptr; w->consumed = nullptr; w->overflow = nullptr; w->cap_states = 0;
+  HIPCHK(hipMalloc((void**)&w->states, n * sizeof(u128)));
+  HIPCHK(hipMalloc((void**)&w->consumed, n * 8));
+  HIPCHK(hipMalloc((void**)&w->overflow, n * 4));
+  w->cap_states = n;
+  return 0;
+}
+// classify + scan of segment k of the call: n normals from states[k]; leaves states[k + 1]
+static int nps_segment(fastmc_ctx* h, NpsSegArgs& A, NpsSegBuf& b, size_t k, u128 inc, uint64_t n) {
+  NpsWork* w = h->nps;
+  const auto& dev = g_nps_dev[h->device];
+  const int64_t tiles = nps_tiles_for(n);
+  TRY(nps_seg_reserve(b, tiles));
+  A.state = w->states + k; A.inc = inc; A.n = n; A.ntiles = tiles; A.tab = dev.first; A.jump = dev.second;
+  A.events = b.events; A.evcount = b.evcount; A.maps = b.maps; A.tile_e = b.tile_e; A.tile_base = b.tile_base;
+  A.state_out = w->states + k + 1; A.consumed = w->consumed + k; A.overflow = w->overflow + k;
+  hipLaunchKernelGGL(k_nps_classify, dim3((unsigned)tiles), dim3(NPS_THREADS), 0, h->stream, A);
+  hipLaunchKernelGGL(k_nps_scan, dim3(1), dim3(NPS_THREADS), 0, h->stream, A);
+  return 0;
+}
+// normals [lo, hi) of a classified segment -> out[0 ... hi - lo)
+static void nps_emit(fastmc_ctx* h, const NpsSegArgs& A, uint64_t lo, uint64_t hi, double* out) {
+  // the tiles that can hold them: normal index i starts no earlier than word i and no later than word 1.05 i + 2 T
+  const int64_t t0 = (int64_t)(lo / NPS_T);
+  int64_t t1 = (int64_t)((hi + hi / 16) / NPS_T) + 3;
+  if (t1 > A.ntiles) t1 = A.ntiles;
+  if (t1 > t0) hipLaunchKernelGGL(k_nps_emit, dim3((unsigned)(t1 - t0)), dim3(NPS_THREADS), 0, h->stream, A, t0, lo, hi, out);
+}
+static int nps_prepare(fastmc_ctx* h, const uint64_t state_inc[4], size_t n_states, u128* inc) {
+  {
+    std::lock_guard<std::mutex> lk(g_nps_mu);
+    if (!g_nps_dev.count(h->device) || !g_nps_dev[h->device].first)
+      return fail(FASTMC_ESTATE, "fastmc_npstream_set_tables has not been called for this device");
+  }
+  if (!h->nps) h->nps = new NpsWork;
+  TRY(nps_reserve_states(h->nps, n_states));
+  const u128 st = ((u128)state_inc[1] << 64) | state_inc[0];
+  *inc = ((u128)state_inc[3] << 64) | state_inc[2];
+  HIPCHK(hipMemsetAsync(h->nps->overflow, 0, n_states * 4, h->stream));
+  HIPCHK(hipMemcpyAsync(h->nps->states, &st, sizeof(u128), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));          // (st is a stack variable)
+  return 0;
+}
+
+// One array of n normals, exactly `numpy.random.Generator(PCG64 at this state).normal(size=n)`: out (host, n doubles, may be
+// NULL), the generator state after it, the words it consumed, the overflow flags (0: the device's answer stands).
+extern "C" int fastmc_npstream_normals(fastmc_t* h, const uint64_t state_inc[4], int64_t n, double* out, uint64_t state_after[2],
+                                       uint64_t* consumed, uint32_t* overflow) {
+  if (!h || !state_inc || n < 1) return fail(FASTMC_EINVAL, "bad argument");
+  FMC_LOCK(h);
+  HIPCHK(hipSetDevice(h->device));
+  u128 inc;
+  TRY(nps_prepare(h, state_inc, 2, &inc));
+  NpsSegArgs A;
+  TRY(nps_segment(h, A, h->nps->seg[0], 0, inc, (uint64_t)n));
+  ScratchBuf d;
+  if (out) {
+    HIPCHK(hipMalloc((void**)&d.p, (size_t)n * 8));
+    nps_emit(h, A, 0, (uint64_t)n, d.p);
+    HIPCHK(hipMemcpyAsync(out, d.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  u128 st;
+  uint64_t cons = 0;
+  uint32_t ovf = 0;
+  HIPCHK(hipMemcpyAsync(&st, h->nps->states + 1, sizeof(u128), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&cons, h->nps->consumed, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&ovf, h->nps->overflow, 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  if (state_after) { state_after[0] = (uint64_t)st; state_after[1] = (uint64_t)(st >> 64); }
+  if (consumed) *consumed = cons;
+  if (overflow) *overflow = ovf;
+  return 0;
+}
+#endif
+
+#if FMC_TU == 0
+__global__ void k_nps_scale(double* x, int64_t n, double s) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= s;
+}
+
+// The log-amplitude draws of a run (fast/fast.py:123, 639-645; funcs.py:358-365): normal(n_iter) + 1j normal(n_iter), real part
+// kept and scaled -- two consecutive arrays of one stream = one array of 2 n_iter.
+extern "C" int fastmc_npstream_logamp(fastmc_t* h, const uint64_t state_inc[4], int64_t n_iter, double logamp_var, double* logamp,
+                                      uint64_t state_after[2], uint32_t* overflow) {
+  if (!h || !state_inc || n_iter < 1 || !(logamp_var >= 0.0)) return fail(FASTMC_EINVAL, "bad argument");
+  FMC_LOCK(h);
+  HIPCHK(hipSetDevice(h->device));
+  u128 inc;
+  TRY(nps_prepare(h, state_inc, 2, &inc));
+  NpsWork* w = h->nps;
+  TRY(grow(&w->la, &w->la_cap, (size_t)n_iter));
+  NpsSegArgs A;
+  TRY(nps_segment(h, A, w->seg[0], 0, inc, (uint64_t)(2 * n_iter)));
+  nps_emit(h, A, 0, (uint64_t)n_iter, w->la);
+  hipLaunchKernelGGL(k_nps_scale, dim3((unsigned)((n_iter + 255) / 256)), dim3(256), 0, h->stream, w->la, n_iter, std::sqrt(logamp_var));
+  u128 st;
+  uint32_t ovf = 0;
+  if (logamp) HIPCHK(hipMemcpyAsync(logamp, w->la, (size_t)n_iter * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&st, w->states + 1, sizeof(u128), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&ovf, w->overflow, 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  if (state_after) { state_after[0] = (uint64_t)st; state_after[1] = (uint64_t)(st >> 64); }
+  if (overflow) *overflow = ovf;
+  return 0;
+}
+
+// Chunks of the Monte-Carlo loop with the coefficients drawn from numpy's stream on the device.  Everything is enqueued
+// without a host round trip: the state chain, the draws, the kernels of every chunk; ONE synchronisation at the end.
+extern "C" int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int64_t n_chunks, int64_t chunk_real, int64_t logamp_offset,
+                                   int coherent, double* out, uint64_t state_after[2], int64_t* bad_chunk) {
+  if (!h || !state_inc || !out || n_chunks < 1 || chunk_real < 1 || logamp_offset < 0) return fail(FASTMC_EINVAL, "bad argument");
+  FMC_LOCK(h);
+  if (!h->have_spec || !h->have_pupil) return fail(FASTMC_ESTATE, "set_spectrum and set_pupil must be called first");
+  if (h->precision != FASTMC_F64) return fail(FASTMC_ESTATE, "the numpy-stream generator feeds the float64 pipeline");
+  HIPCHK(hipSetDevice(h->device));
+  const bool sh = h->have_sh;
+  const int segs = sh ? 4 : 2;
+  u128 inc;
+  TRY(nps_prepare(h, state_inc, (size_t)n_chunks * segs + 1, &inc));
+  NpsWork* w = h->nps;
+  if (!w->la || w->la_cap < (size_t)(logamp_offset + n_chunks * 2 * chunk_real))
+    return fail(FASTMC_ESTATE, "fastmc_npstream_logamp first (the run's log-amplitudes are drawn before its chunks)");
+  const size_t N2 = (size_t)h->N * h->N;
+  const size_t per_chunk = (size_t)2 * chunk_real * (coherent ? 2 : 1);
+  // results of all chunks land in one pinned buffer; copied out after the one synchronisation
+  double* pinned = nullptr;
+  HIPCHK(hipHostMalloc((void**)&pinned, per_chunk * n_chunks * 8, hipHostMallocDefault));
+  struct Free { double* p; ~Free() { if (p) hipHostFree(p); } } guard{pinned};
+  if (sh && w->sh_cap < (size_t)chunk_real * 27) {
+    if (w->sh_re) hipFree(w->sh_re);
+    if (w->sh_im) hipFree(w->sh_im);
+    w->sh_re = w->sh_im = nullptr; w->sh_cap = 0;
+    HIPCHK(hipMalloc((void**)&w->sh_re, (size_t)chunk_real * 27 * 8));
+    HIPCHK(hipMalloc((void**)&w->sh_im, (size_t)chunk_real * 27 * 8));
+    w->sh_cap = (size_t)chunk_real * 27;
+  }
+  for (int64_t c = 0; c < n_chunks; ++c) {
+    NpsSegArgs A[4];
+    const size_t k0 = (size_t)c * segs;
+    TRY(nps_segment(h, A[0], w->seg[0], k0, inc, (uint64_t)chunk_real * N2));          // real parts of the chunk
+    TRY(nps_segment(h, A[1], w->seg[1], k0 + 1, inc, (uint64_t)chunk_real * N2));      // imaginary parts
+    if (sh) {
+      TRY(nps_segment(h, A[2], w->seg[2], k0 + 2, inc, (uint64_t)chunk_real * 27));
+      TRY(nps_segment(h, A[3], w->seg[3], k0 + 3, inc, (uint64_t)chunk_real * 27));
+    }
+    RunSpec S{1, 0, 0, 0, chunk_real, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, coherent, nullptr, nullptr};
+    S.async = true;
+    S.logamp_dev = w->la + logamp_offset + (size_t)c * 2 * chunk_real;
+    S.fill = [&, h, sh, N2](int64_t bs, int nb) -> int {
+      nps_emit(h, A[0], (uint64_t)bs * N2, (uint64_t)(bs + nb) * N2, h->cre);
+      nps_emit(h, A[1], (uint64_t)bs * N2, (uint64_t)(bs + nb) * N2, h->cim);
+      if (sh) {
+        nps_emit(h, A[2], (uint64_t)bs * 27, (uint64_t)(bs + nb) * 27, h->sh_in_re);
+        nps_emit(h, A[3], (uint64_t)bs * 27, (uint64_t)(bs + nb) * 27, h->sh_in_im);
+      }
+      return 0;
+    };
+    h->pending = false;          // no wait between chunks: only the last chunk's kernel times are read (after the one sync below)
+    TRY(run_impl<double>(h, S));
+    HIPCHK(hipMemcpyAsync(pinned + per_chunk * c, h->out, per_chunk * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  std::vector<uint32_t> ovf((size_t)n_chunks * segs);
+  std::vector<u128> states((size_t)n_chunks * segs + 1);
+  HIPCHK(hipMemcpyAsync(ovf.data(), w->overflow, ovf.size() * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(states.data(), w->states, states.size() * sizeof(u128), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  finish_pending(h);
+  HIPCHK(hipGetLastError());
+  int64_t bad = -1;
+  for (int64_t c = 0; c < n_chunks && bad < 0; ++c)
+    for (int k = 0; k < segs; ++k)
+      if (ovf[(size_t)c * segs + k]) { bad = c; break; }
+  const int64_t good = bad < 0 ? n_chunks : bad;
+  memcpy(out, pinned, per_chunk * good * 8);
+  const u128 st = states[(size_t)good * segs];
+  if (state_after) { state_after[0] = (uint64_t)st; state_after[1] = (uint64_t)(st >> 64); }
+  if (bad_chunk) *bad_chunk = bad;
+  return 0;
 }
 #endif
 

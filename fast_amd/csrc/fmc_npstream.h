@@ -1,0 +1,366 @@
+// fmc_npstream.h -- numpy's Generator.normal stream, drawn on the device (GPU_RNG 'numpy').
+//
+// The reference draws every coefficient from ONE sequential stream, `funcs._R = numpy.random.default_rng(seed)`
+// (fast/funcs.py:21): `_R.normal(0, 1, shape) + 1j * _R.normal(0, 1, shape)` (funcs.py:352-356) after the log-amplitude draws
+// (fast.py:123, 639-645).  "Identical RNG seeds" therefore means reproducing that stream: PCG64 (128-bit LCG, XSL-RR output)
+// feeding numpy's 256-layer ziggurat, in which a normal consumes ONE 64-bit word 97.8 % of the time and two or more otherwise
+// (wedge test, tail loop, restarts) -- so the word a normal starts at depends on every earlier rejection.  Round 3 drew this
+// stream on the host (114 iterations/s end to end).  Here it is drawn on the device in three passes per array of n normals
+// (a "segment": the real parts of a chunk, its imaginary parts, the log-amplitudes ...), all enqueued without a host round trip:
+//
+//   classify  one workgroup per TILE of T = 16384 consecutive words.  A PCG64 state can be advanced by any distance in
+//             O(log) 128-bit multiply-adds, so every thread jumps to its own 8-word pieces and treats EVERY word as if a
+//             normal started there: fast (one word) or slow -- then it runs numpy's slow path to the end on a private copy of
+//             the generator and records an EVENT (position, words consumed f, value).  Events come out in position order
+//             (threads own consecutive pieces; a block scan assigns the slots).  Then the tile's transfer map: for each
+//             entry offset e < K (the first normal of the tile starts e words in, because the previous tile's last normal
+//             spilled over) the number of normals that start in the tile and the offset handed to the next tile.
+//   scan      one workgroup composes the maps of all tiles (two-level scan of functions on K values): every tile's true
+//             entry offset and the index of its first normal; the word after the n-th normal = the words this array consumed,
+//             and the generator state there (one more jump) for the next segment.
+//   emit      per tile, with its entry offset known: the words once more, the skipped ones masked (inside a slow normal's
+//             span), a prefix sum for the output index, value = rabs * wi[idx] (or the event's) -> out[], in the order numpy
+//             writes them.
+// A spill beyond K words, more events than a tile holds, or a stream longer than the launch allowed for raises an OVERFLOW flag
+// and the caller redoes that chunk with numpy's own draws (never observed: K = 16 is ~8 consecutive rejections).
+// The ziggurat tables are not in this source: fast_amd/npnormal.py reads them out of the numpy that is installed through a
+// crafted bit generator and checks the restatement against numpy's own stream before the device is trusted with it.
+// log1p / exp here are ocml's, numpy's are the host libm's: a tail value can differ in its last bit and an acceptance could flip
+// only when the two sides of the test agree to 2^-52 (probability ~1e-16 per slow normal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fmc {
+
+typedef unsigned __int128 u128;
+
+constexpr int NPS_T = 16384;          // words per tile
+constexpr int NPS_THREADS = 256;
+constexpr int NPS_WPT = 8;            // consecutive words per thread and sub-tile
+constexpr int NPS_SUB = NPS_THREADS * NPS_WPT;      // 2048 words per sub-tile
+constexpr int NPS_NSUB = NPS_T / NPS_SUB;           // 8
+constexpr int NPS_K = 16;             // entry offsets a tile's map covers
+constexpr int NPS_EVCAP = 1024;       // events per tile (expected 360, sigma 19)
+
+struct NpsEvent {
+  uint32_t pos;      // word in the tile at which the slow normal would start
+  uint32_t f;        // words it consumes
+  double v;          // its value
+};
+
+struct NpsTables {   // numpy's ziggurat (fast_amd/npnormal.py)
+  double wi[256];
+  uint64_t ki[256];
+  double fi[256];
+};
+
+struct NpsJump {     // a^(2^k) and the matching increments of the PCG64 LCG: state -> a state + c  applied 2^k times
+  u128 a[64];
+  u128 c[64];        // for increment 1 (scaled by the stream's increment at use: c_k(inc) = c_k(1) * inc)
+};
+
+struct NpsSegArgs {
+  const u128* state;        // generator state at the start of the segment (device)
+  u128 inc;
+  uint64_t n;               // normals wanted
+  int64_t ntiles;           // tiles classified (upper bound of the stream length)
+  const NpsTables* tab;
+  const NpsJump* jump;
+  NpsEvent* events;         // [ntiles][NPS_EVCAP]
+  uint32_t* evcount;        // [ntiles]
+  uint32_t* maps;           // [ntiles][NPS_K]: normals started | exit offset << 16
+  uint8_t* tile_e;          // [ntiles] entry offset (scan)
+  uint64_t* tile_base;      // [ntiles] index of the tile's first normal (scan)
+  u128* state_out;          // state after the segment (scan)
+  uint64_t* consumed;       // words the segment consumed (scan)
+  uint32_t* overflow;       // != 0: give up on the device for this chunk
+};
+
+__device__ __forceinline__ u128 nps_advance(u128 s, u128 inc, uint64_t dist, const NpsJump* J) {
+  for (int k = 0; dist; ++k, dist >>= 1)
+    if (dist & 1) s = J->a[k] * s + J->c[k] * inc;
+  return s;
+}
+__device__ __forceinline__ uint64_t nps_next(u128& s, u128 inc) {       // pcg64: step, then XSL-RR of the new state
+  s = s * ((((u128)0x2360ED051FC65DA4ull) << 64) | 0x4385DF649FCCF645ull) + inc;
+  const uint64_t hi = (uint64_t)(s >> 64), lo = (uint64_t)s, v = hi ^ lo;
+  const unsigned rot = (unsigned)(hi >> 58);
+  return (v >> rot) | (v << ((64u - rot) & 63u));
+}
+__device__ __forceinline__ double nps_double(u128& s, u128 inc) { return (double)(nps_next(s, inc) >> 11) * (1.0 / 9007199254740992.0); }
+
+// numpy/random/src/distributions/distributions.c: random_standard_normal, from the word `r` on, on the private generator (s, inc).
+// Returns the value; f = words consumed including r.  No FMA contraction in the acceptance tests (numpy's are plain C on x86-64).
+__device__ inline double nps_slow(uint64_t r, u128 s, u128 inc, const double* wi, const uint64_t* ki, const double* fi, uint32_t& f) {
+  const double R = 3.6541528853610087963519472518, INV_R = 0.27366123732975827203338247596;
+  f = 1;
+  for (;;) {
+    const int idx = (int)(r & 0xff);
+    const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
+    double x = __dmul_rn((double)rabs, wi[idx]);
+    if ((r >> 8) & 1) x = -x;
+    if (rabs < ki[idx]) return x;
+    if (idx == 0) {
+      for (;;) {
+        const double xx = __dmul_rn(-INV_R, log1p(-nps_double(s, inc)));
+        const double yy = -log1p(-nps_double(s, inc));
+        f += 2;
+        if (__dadd_rn(yy, yy) > __dmul_rn(xx, xx)) return ((rabs >> 8) & 1) ? -__dadd_rn(R, xx) : __dadd_rn(R, xx);
+        if (f > 4096) return 0.0;      // (cannot happen; keeps a corrupted table from hanging the device)
+      }
+    } else {
+      const double u = nps_double(s, inc);
+      f += 1;
+      if (__dadd_rn(__dmul_rn(fi[idx - 1] - fi[idx], u), fi[idx]) < exp(__dmul_rn(__dmul_rn(-0.5, x), x))) return x;
+    }
+    r = nps_next(s, inc);
+    f += 1;
+    if (f > 4096) return 0.0;
+  }
+}
+
+// exclusive block scan of one small integer per thread (256 threads, 4 waves); `total` = the sum
+__device__ __forceinline__ uint32_t nps_block_scan(uint32_t v, uint32_t* s_wave, uint32_t& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) s_wave[w] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int i = 0; i < w; ++i) base += s_wave[i];
+  total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+// ---------------------------------------------------------------- classify
+__global__ __launch_bounds__(NPS_THREADS) void k_nps_classify(NpsSegArgs A) {
+  __shared__ double s_wi[256];
+  __shared__ uint64_t s_ki[256];
+  __shared__ double s_fi[256];
+  __shared__ uint32_t s_ev[NPS_EVCAP];        // pos | f << 16 of the tile's events, in position order
+  __shared__ uint32_t s_wave[4];
+  __shared__ u128 s_base;
+  __shared__ uint32_t s_nev;
+  const int64_t tile = blockIdx.x;
+  const int t = threadIdx.x;
+  s_wi[t] = A.tab->wi[t]; s_ki[t] = A.tab->ki[t]; s_fi[t] = A.tab->fi[t];
+  if (t == 0) { s_base = nps_advance(*A.state, A.inc, (uint64_t)tile * NPS_T, A.jump); s_nev = 0; }
+  __syncthreads();
+  u128 st = nps_advance(s_base, A.inc, (uint64_t)t * NPS_WPT, A.jump);
+  NpsEvent* ev_out = A.events + (size_t)tile * NPS_EVCAP;
+  uint32_t nev = 0;
+  for (int sub = 0; sub < NPS_NSUB; ++sub) {
+    // this thread's eight words of the sub-tile
+    uint32_t lp[NPS_WPT], lf[NPS_WPT];
+    double lv[NPS_WPT];
+    uint32_t cnt = 0;
+    u128 s = st;
+#pragma unroll 1
+    for (int i = 0; i < NPS_WPT; ++i) {
+      const uint64_t r = nps_next(s, A.inc);
+      const int idx = (int)(r & 0xff);
+      const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
+      if (rabs >= s_ki[idx]) {
+        uint32_t f;
+        const double v = nps_slow(r, s, A.inc, s_wi, s_ki, s_fi, f);
+        lp[cnt] = (uint32_t)(sub * NPS_SUB + t * NPS_WPT + i); lf[cnt] = f; lv[cnt] = v;
+        ++cnt;
+      }
+    }
+    uint32_t total;
+    const uint32_t slot0 = nev + nps_block_scan(cnt, s_wave, total);
+    for (uint32_t k = 0; k < cnt; ++k) {
+      const uint32_t slot = slot0 + k;
+      if (slot < NPS_EVCAP) {
+        s_ev[slot] = lp[k] | (lf[k] << 16);
+        NpsEvent e; e.pos = lp[k]; e.f = lf[k]; e.v = lv[k];
+        ev_out[slot] = e;
+      }
+      if (lf[k] >= 0xffffu) atomicOr(A.overflow, 1u);
+    }
+    nev += total;
+    st = nps_advance(s, A.inc, (uint64_t)(NPS_SUB - NPS_WPT), A.jump);     // the same piece of the next sub-tile
+  }
+  if (nev > NPS_EVCAP) { if (t == 0) atomicOr(A.overflow, 2u); nev = NPS_EVCAP; }
+  if (t == 0) A.evcount[tile] = nev;
+  __syncthreads();
+  // transfer map: lane e walks the events from entry offset e
+  if (t < NPS_K) {
+    uint32_t cur = (uint32_t)t, count = 0;
+    for (uint32_t k = 0; k < nev; ++k) {
+      const uint32_t p = s_ev[k] & 0xffffu, f = s_ev[k] >> 16;
+      if (p < cur) continue;            // inside an earlier slow normal: not a start
+      count += p - cur + 1;             // the fast starts before it, and this one
+      cur = p + f;
+    }
+    uint32_t exit_off = 0;
+    if (cur < (uint32_t)NPS_T) count += NPS_T - cur; else exit_off = cur - NPS_T;
+    if (exit_off >= (uint32_t)NPS_K) { atomicOr(A.overflow, 4u); exit_off = 0; }
+    A.maps[(size_t)tile * NPS_K + t] = count | (exit_off << 16);
+  }
+}
+
+// ---------------------------------------------------------------- scan (one workgroup)
+__global__ __launch_bounds__(NPS_THREADS) void k_nps_scan(NpsSegArgs A) {
+  __shared__ uint32_t s_cnt[NPS_THREADS][NPS_K];
+  __shared__ uint8_t s_exit[NPS_THREADS][NPS_K];
+  __shared__ uint8_t s_be[NPS_THREADS];
+  __shared__ uint64_t s_bb[NPS_THREADS];
+  __shared__ int64_t s_end_tile;
+  __shared__ uint32_t s_ev[NPS_EVCAP];
+  const int t = threadIdx.x;
+  const int64_t per = (A.ntiles + NPS_THREADS - 1) / NPS_THREADS;
+  const int64_t j0 = (int64_t)t * per, j1 = min(j0 + per, A.ntiles);
+  {
+    // sixteen independent chains (one per entry offset) through this thread's tiles: their loads overlap
+    uint32_t cur[NPS_K], cnt[NPS_K];
+#pragma unroll
+    for (int e = 0; e < NPS_K; ++e) { cur[e] = (uint32_t)e; cnt[e] = 0; }
+    for (int64_t j = j0; j < j1; ++j) {
+      const uint32_t* mj = A.maps + (size_t)j * NPS_K;
+#pragma unroll
+      for (int e = 0; e < NPS_K; ++e) {
+        const uint32_t m = mj[cur[e]];
+        cnt[e] += m & 0xffffu;
+        cur[e] = m >> 16;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NPS_K; ++e) { s_cnt[t][e] = cnt[e]; s_exit[t][e] = (uint8_t)cur[e]; }
+  }
+  if (t == 0) s_end_tile = -1;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t e = 0;
+    uint64_t base = 0;
+    for (int i = 0; i < NPS_THREADS; ++i) {
+      s_be[i] = (uint8_t)e; s_bb[i] = base;
+      base += s_cnt[i][e];
+      e = s_exit[i][e];
+    }
+    if (base < A.n) atomicOr(A.overflow, 8u);          // the launch did not cover n normals
+  }
+  __syncthreads();
+  {
+    uint32_t cur = s_be[t];
+    uint64_t base = s_bb[t];
+    for (int64_t j = j0; j < j1; ++j) {
+      const uint32_t m = A.maps[(size_t)j * NPS_K + cur];
+      A.tile_e[j] = (uint8_t)cur;
+      A.tile_base[j] = base;
+      const uint64_t c = m & 0xffffu;
+      if (base < A.n && A.n <= base + c) s_end_tile = j;       // the tile the n-th normal starts in (exactly one)
+      base += c;
+      cur = m >> 16;
+    }
+  }
+  __syncthreads();
+  // the word after the n-th normal
+  const int64_t je = s_end_tile;
+  if (je < 0) {
+    if (t == 0) { *A.consumed = 0; *A.state_out = *A.state; if (A.n) atomicOr(A.overflow, 8u); }
+    return;
+  }
+  const uint32_t nev = A.evcount[je];
+  for (uint32_t k = t; k < nev; k += NPS_THREADS) {
+    const NpsEvent e = A.events[(size_t)je * NPS_EVCAP + k];
+    s_ev[k] = e.pos | (e.f << 16);
+  }
+  __syncthreads();
+  if (t == 0) {
+    const uint64_t want = A.n - A.tile_base[je];        // the want-th start of the tile (1-based)
+    uint64_t cur = A.tile_e[je], count = 0, end = 0;
+    bool done = false;
+    for (uint32_t k = 0; k < nev && !done; ++k) {
+      const uint64_t p = s_ev[k] & 0xffffu, f = s_ev[k] >> 16;
+      if (p < cur) continue;
+      if (count + (p - cur) >= want) { end = cur + (want - count); done = true; break; }      // a fast start
+      count += p - cur + 1;
+      cur = p + f;
+      if (count == want) { end = cur; done = true; }
+    }
+    if (!done) end = cur + (want - count);
+    const uint64_t consumed = (uint64_t)je * NPS_T + end;
+    *A.consumed = consumed;
+    *A.state_out = nps_advance(*A.state, A.inc, consumed, A.jump);
+  }
+}
+
+// ---------------------------------------------------------------- emit: normals [lo, hi) of the segment -> out[idx - lo]
+__global__ __launch_bounds__(NPS_THREADS) void k_nps_emit(NpsSegArgs A, int64_t tile0, uint64_t lo, uint64_t hi, double* out) {
+  __shared__ double s_wi[256];
+  __shared__ uint64_t s_ki[256];
+  __shared__ uint32_t s_skip[NPS_T / 32];     // bit p: word p is not the start of a normal
+  __shared__ uint32_t s_ev[NPS_EVCAP];
+  __shared__ uint32_t s_wave[4];
+  __shared__ u128 s_base;
+  const int64_t tile = tile0 + blockIdx.x;
+  if (tile >= A.ntiles) return;
+  const uint64_t base = A.tile_base[tile];
+  const uint32_t m = A.maps[(size_t)tile * NPS_K + A.tile_e[tile]];
+  if (base >= hi || base + (m & 0xffffu) <= lo) return;          // no normal of [lo, hi) starts here (uniform over the workgroup)
+  const int t = threadIdx.x;
+  s_wi[t] = A.tab->wi[t]; s_ki[t] = A.tab->ki[t];
+  for (int i = t; i < NPS_T / 32; i += NPS_THREADS) s_skip[i] = 0;
+  const uint32_t nev = A.evcount[tile];
+  const NpsEvent* ev = A.events + (size_t)tile * NPS_EVCAP;
+  for (uint32_t k = t; k < nev; k += NPS_THREADS) s_ev[k] = ev[k].pos | (ev[k].f << 16);
+  if (t == 0) s_base = nps_advance(*A.state, A.inc, (uint64_t)tile * NPS_T, A.jump);
+  __syncthreads();
+  if (t == 0) {
+    // the true path: mark what it skips (few hundred events; one lane)
+    uint32_t cur = A.tile_e[tile];
+    for (uint32_t p = 0; p < cur; ++p) s_skip[p >> 5] |= 1u << (p & 31);
+    for (uint32_t k = 0; k < nev; ++k) {
+      const uint32_t p = s_ev[k] & 0xffffu, f = s_ev[k] >> 16;
+      if (p < cur) continue;
+      for (uint32_t q = p + 1; q < p + f && q < (uint32_t)NPS_T; ++q) s_skip[q >> 5] |= 1u << (q & 31);
+      cur = p + f;
+    }
+  }
+  __syncthreads();
+  u128 st = nps_advance(s_base, A.inc, (uint64_t)t * NPS_WPT, A.jump);
+  uint64_t rank0 = base;         // index of the first normal of the current sub-tile
+  uint32_t nev_before = 0;       // events of the earlier sub-tiles
+  for (int sub = 0; sub < NPS_NSUB; ++sub) {
+    double val[NPS_WPT];
+    uint32_t slowmask = 0, startmask = 0, nslow = 0, nstart = 0;
+    u128 s = st;
+#pragma unroll
+    for (int i = 0; i < NPS_WPT; ++i) {
+      const uint64_t r = nps_next(s, A.inc);
+      const int idx = (int)(r & 0xff);
+      const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
+      const double x = __dmul_rn((double)rabs, s_wi[idx]);
+      val[i] = ((r >> 8) & 1) ? -x : x;
+      const uint32_t p = (uint32_t)(sub * NPS_SUB + t * NPS_WPT + i);
+      if (rabs >= s_ki[idx]) { slowmask |= 1u << i; ++nslow; }
+      if (!((s_skip[p >> 5] >> (p & 31)) & 1u)) { startmask |= 1u << i; ++nstart; }
+    }
+    uint32_t tot_slow, tot_start;
+    const uint32_t slow0 = nev_before + nps_block_scan(nslow, s_wave, tot_slow);      // the slots classify gave this thread's events
+    const uint32_t start0 = nps_block_scan(nstart, s_wave, tot_start);
+    uint32_t ks = slow0;
+    uint64_t o = rank0 + start0;
+#pragma unroll
+    for (int i = 0; i < NPS_WPT; ++i) {
+      const bool slow = (slowmask >> i) & 1u;
+      if ((startmask >> i) & 1u) {
+        if (o >= lo && o < hi) out[o - lo] = slow ? ev[min(ks, (uint32_t)NPS_EVCAP - 1)].v : val[i];
+        ++o;
+      }
+      if (slow) ++ks;
+    }
+    nev_before += tot_slow;
+    rank0 += tot_start;
+    st = nps_advance(s, A.inc, (uint64_t)(NPS_SUB - NPS_WPT), A.jump);
+  }
+}
+
+}  // namespace fmc

@@ -223,6 +223,33 @@ int fastmc_comm_gather_all_queued(fastmc_t* const* handles, int n, int64_t n_loc
 int fastmc_histogram_queued(fastmc_t* h, double lo_db, double hi_db, int nbins, int slot);   /* of the slot's own results, no exchange */
 int fastmc_queue_wait(fastmc_t* h, int slot, double* out, int64_t out_cap, int64_t* hist, int hist_cap);
 
+/* ---- numpy's normal stream on the device (GPU_RNG 'numpy'; round 4) ---------------------------------------------------
+ * The reference draws everything from one sequential stream, funcs._R = numpy.random.default_rng(seed) (fast/funcs.py:21,
+ * 352-365): PCG64 feeding numpy's ziggurat, where a normal consumes one 64-bit word or, 2.2 % of the time, more.  These
+ * entry points reproduce that stream on the device (fast_amd/csrc/fmc_npstream.h: classify every word as a potential start,
+ * compose the tiles' transfer maps, emit), so that a run with a given SEED returns the reference's own numbers at GPU speed.
+ *   fastmc_npstream_set_tables   the 256-entry ziggurat tables (wi, ki, fi) of the numpy that is installed, read out of it
+ *                                by fast_amd/npnormal.py (they are not in this library);
+ *   fastmc_npstream_normals      one array: out[0 ... n) = Generator(PCG64 at state_inc).normal(size = n); state_inc =
+ *                                {state lo, state hi, inc lo, inc hi} as numpy's bit_generator.state holds them; state_after
+ *                                (lo, hi), the words consumed, and *overflow != 0 when the device gave up (a normal spanning
+ *                                more than 16 words across a tile edge, ...: the caller then draws with numpy itself);
+ *   fastmc_run_npstream          chunks [0, n_chunks) of fast.Fast.run's loop (fast/fast.py:130-134): per chunk the real parts
+ *                                of chunk_real realisations, then their imaginary parts (funcs.py:352-356), then the
+ *                                sub-harmonic draws if sub-harmonics are set (fast.py:598-603); logamp_dev_scaled: the run's
+ *                                log-amplitudes as fastmc_npstream_logamp left them on the device.  out: [n_chunks][2 chunk_real]
+ *                                (x2 when coherent) as run_coeffs returns each chunk.  *bad_chunk = -1, or the first chunk whose
+ *                                draw overflowed: results before it stand, state_after is the state at ITS start.
+ *   fastmc_npstream_logamp       the 2 n_iter normals fast.py:639-645 draws before the chunks; keeps the first n_iter, scaled
+ *                                by sqrt(logamp_var), on the device for fastmc_run_npstream and copies them to logamp (host). */
+int fastmc_npstream_set_tables(int device_id, const double* wi, const uint64_t* ki, const double* fi);
+int fastmc_npstream_normals(fastmc_t* h, const uint64_t state_inc[4], int64_t n, double* out, uint64_t state_after[2],
+                            uint64_t* consumed, uint32_t* overflow);
+int fastmc_npstream_logamp(fastmc_t* h, const uint64_t state_inc[4], int64_t n_iter, double logamp_var, double* logamp,
+                           uint64_t state_after[2], uint32_t* overflow);
+int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int64_t n_chunks, int64_t chunk_real, int64_t logamp_offset,
+                        int coherent, double* out, uint64_t state_after[2], int64_t* bad_chunk);
+
 /* Names of the row and column kernels the handle launched last, as c++filt prints the instantiations (e.g.
  * "k_rows_wave<double, 16, 2, 0, 1, 4>"; empty before the first run): bench.py prices the instruction mix of what actually
  * ran (fast_amd/kernel_isa_stats.json is keyed by these names).  rows / cols: caller's buffers of `cap` bytes each. */

@@ -43,6 +43,8 @@ def test_bench_json_line_contract():
             assert hbm["rows"]["frac_counter"] <= 1.0
     assert d["value"] > 1e5 and abs(d["value"] - 10000 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-3 * d["value"]
     assert d["pipeline"]["powerspec_kernel_ms_warm"] < 2.0        # not the first-launch artefact
+    # two steps in flight: what the host costs a step beyond the device-limited time of the same work is small
+    assert d["pipeline"]["steps_in_flight"] == 2 and d["pipeline"]["host_ms_per_step"] is not None and d["pipeline"]["host_ms_per_step"] < 0.5
     # the kernel named is the one that ran, and the traffic figure belongs to a committed profile of that kernel
     assert r["kernel"] == "k_rows_wave<double, 16, 2, 0, 1, 4>" and r["cols_kernel"] == "k_cols_wave<double, 16, 2, 0, 1, 4>"
     assert r["traffic"] is not None and r["traffic"] < 1.5 * 16 * 1024 * 82 * r["realisations_per_launch"]

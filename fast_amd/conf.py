@@ -28,7 +28,8 @@ DEFAULTS = {
 # Keys of the MI355X backend (not in the reference).  Filled silently.
 GPU_DEFAULTS = {
     'GPU_PRECISION': 'f64',   # 'f64' (complex128 pipeline, reference precision) or 'f32'
-    'GPU_RNG': 'device',      # 'device': Philox on the GPU; 'host': numpy draws, reference order (parity mode)
+    'GPU_RNG': 'device',      # 'device': Philox on the GPU; 'host': numpy draws, reference order (parity mode);
+                              # 'numpy': the SAME stream as 'host' (the reference's numbers for its SEED) drawn on the GPU
     'GPU_RNG_PRECISION': 'f32',  # device generator: 'f32' (24-bit uniforms, hardware float32 Box-Muller, float32 colouring,
                               # fused into the row kernels) or 'f64' (53-bit normals and float64 colouring like the
                               # reference's funcs.py:352-356 / fast.py:594; ~4x slower)

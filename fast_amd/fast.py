@@ -10,10 +10,13 @@ Differences from the reference, all deliberate:
   * `GPU_RNG`: 'device' (default) draws the coefficients on the GPU with a counter-based
     generator -- results depend only on (SEED, iteration index), not on NCHUNKS, batch size or
     the number of GPUs; 'host' draws them with numpy in the reference's order, so the same
-    SEED reproduces the reference's `result._r` to ~1e-10 (parity mode, PCIe-bound);
+    SEED reproduces the reference's `result._r` to ~1e-10 (parity mode, PCIe-bound); 'numpy' draws
+    THAT stream -- numpy's PCG64 + ziggurat, word for word -- on the GPU: the reference's numbers
+    for its SEED without a host draw (fast_amd/npnormal.py, csrc/fmc_npstream.h);
   * `GPU_PRECISION`: 'f64' (default, complex128 like the reference) or 'f32';
   * `GPU_RNG_PRECISION`: 'f32' (default) or 'f64' -- the device generator's normals and the colouring multiply at the
-    reference's float64 precision (funcs.py:352-356, fast.py:594), ~4x slower;
+    reference's float64 precision (funcs.py:352-356, fast.py:594), fused into the row kernels at 1024 / 2048 / 4096 (half
+    the float32 generator's rate), staged through device memory on the other grids;
   * `TEMPORAL` (frozen-flow time series, fast.py:607-637): the layer screens, the bilinear shifts and
     the detector run on the GPU; its draws are always numpy's, in the reference's order (the
     series is sequential and tiny), so the same SEED reproduces the reference;
@@ -101,8 +104,8 @@ class Fast():
         self.rng_mode = p['GPU_RNG']
         if self.precision not in ('f64', 'f32'):
             raise Exception("GPU_PRECISION must be 'f64' or 'f32'")
-        if self.rng_mode not in ('device', 'host'):
-            raise Exception("GPU_RNG must be 'device' or 'host'")
+        if self.rng_mode not in ('device', 'host', 'numpy'):
+            raise Exception("GPU_RNG must be 'device', 'host' or 'numpy'")
         if p['GPU_RNG_PRECISION'] not in ('f32', 'f64'):
             raise Exception("GPU_RNG_PRECISION must be 'f32' or 'f64'")
         devs = p['GPU_DEVICES']
@@ -255,6 +258,8 @@ class Fast():
             self._run_temporal(I, coherent)
         elif self.rng_mode == 'host':
             self._run_host_rng(I, coherent)
+        elif self.rng_mode == 'numpy':
+            self._run_numpy_rng(I, coherent)
         else:
             seed = self.seed if self.seed is not None else int(numpy.random.SeedSequence().generate_state(2, numpy.uint32).view(numpy.uint64)[0])
             n_real = self.Niter // 2
@@ -281,7 +286,7 @@ class Fast():
         self.random_iters = I[-1]
         self.timing = self._handle.last_timing()
         self.result = FastResult(I.flatten(), self.diffraction_limit)
-        if self.temporal or self.rng_mode == 'host' or getattr(self, '_tr', None) is not None or self._group.world > 1:
+        if self.temporal or self.rng_mode in ('host', 'numpy') or getattr(self, '_tr', None) is not None or self._group.world > 1:
             # a run made of several library calls: hand the assembled vector back so that histogram(),
             # result_stats() and the fast_amd.comms reductions see all of it, not the last chunk / shard
             self._handle.set_results(self.result._r)
@@ -306,6 +311,60 @@ class Fast():
                 sr = _R.normal(0, 1, size=(half, 3, 3, 3))
                 si = _R.normal(0, 1, size=(half, 3, 3, 3))
             I[i] = self._handle.run_coeffs(cr, ci, self.logamp[i * M:(i + 1) * M], coherent, sr, si)
+
+    def _run_numpy_rng(self, I, coherent):
+        """The reference's numbers for the reference's SEED at GPU speed: numpy's own stream -- `funcs._R`, PCG64 + ziggurat, in the
+        reference's order (fast.py:123, 593, 600; funcs.py:352-365) -- drawn ON THE DEVICE (fast_amd/csrc/fmc_npstream.h,
+        fast_amd/npnormal.py).  The module generator `_R` is left exactly where the reference's would be after the run.  A chunk
+        the device gives up on (it says so; never observed) is drawn by numpy itself; a numpy whose normal() is not the ziggurat
+        restated here, or a generator that is not PCG64, makes the whole run fall back to `GPU_RNG: 'host'` with a warning."""
+        from . import npnormal
+        M, half, N = self.Niter_per_chunk, self.Niter_per_chunk // 2, self.Npxls
+        h = self._handle
+        try:
+            sw = npnormal.state_words(_R.bit_generator)
+            if self.precision != 'f64':
+                raise RuntimeError("the numpy-stream generator feeds the float64 pipeline")
+            la, after, ovf = h.npstream_logamp(sw, self.Niter, float(self.logamp_var))
+            if ovf:
+                raise RuntimeError(f"the device gave up on the log-amplitude draws (flags {ovf})")
+        except RuntimeError as e:          # incl. _lib.FastMCError
+            logger.warning(f"GPU_RNG 'numpy' is unavailable ({e}); drawing on the host (GPU_RNG 'host')")
+            return self._run_host_rng(I, coherent)
+        self.logamp[:] = la
+        inc = sw[2:]
+        sw = numpy.concatenate([after, inc])
+
+        def rstate(words):       # the dict numpy takes for a PCG64 at these state words
+            st = _R.bit_generator.state
+            st["state"]["state"] = (int(words[1]) << 64) | int(words[0])
+            st["has_uint32"], st["uinteger"] = 0, 0
+            return st
+        c, last = 0, self.Nchunks - 1
+        while c < self.Nchunks:
+            if c == last:
+                self._last_chunk_state = rstate(sw)           # `phs` re-draws the last chunk from here on demand
+            n = (last - c) if c < last else 1
+            out, after, bad = h.run_npstream(sw, n, half, c * M, coherent)
+            good = n if bad < 0 else bad
+            I[c:c + good] = out[:good]
+            c += good
+            sw = numpy.concatenate([after, inc])
+            if bad >= 0:
+                logger.warning(f"chunk {c}: the device gave up on numpy's stream; drawing this chunk with numpy")
+                _R.bit_generator.state = rstate(sw)
+                if c == last:
+                    self._last_chunk_state = _R.bit_generator.state
+                cr = _R.normal(0, 1, size=(half, N, N))
+                ci = _R.normal(0, 1, size=(half, N, N))
+                sr = si = None
+                if self.subharmonics:
+                    sr = _R.normal(0, 1, size=(half, 3, 3, 3))
+                    si = _R.normal(0, 1, size=(half, 3, 3, 3))
+                I[c] = h.run_coeffs(cr, ci, self.logamp[c * M:(c + 1) * M], coherent, sr, si)
+                c += 1
+                sw = npnormal.state_words(_R.bit_generator)
+        _R.bit_generator.state = rstate(sw)
 
     def _run_temporal(self, I, coherent):
         """Frozen-flow series (fast.py:607-637; funcs.py:367-375): numpy draws in the reference's
@@ -432,7 +491,7 @@ class Fast():
         half = self.Niter_per_chunk // 2
         if self.temporal:
             return self._handle.temporal_phases(*self._last_temporal)
-        if self.rng_mode == 'host':
+        if self.rng_mode in ('host', 'numpy'):
             N = self.Npxls
             rng = numpy.random.default_rng()
             rng.bit_generator.state = self._last_chunk_state

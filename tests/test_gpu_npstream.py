@@ -37,3 +37,56 @@ def test_consecutive_arrays_continue_the_stream():
         got, after, _, ovf = h.npstream_normals(sw, n)
         assert ovf == 0 and np.abs(got - want).max() < 1e-14
         sw = np.array([after[0], after[1], sw[2], sw[3]], dtype=np.uint64)
+
+
+# ------------------------------------------------------------------ Fast(config).run() with GPU_RNG 'numpy'
+from conftest import E2E_CASES, load_golden, params_from_json
+
+
+@pytest.mark.parametrize("case", E2E_CASES + ["default164"])
+def test_fast_run_reproduces_the_reference_for_its_seed_without_a_host_draw(case):
+    """Every end-to-end fixture of the reference (all AO modes, alias, noise, modal, sub-harmonics, coherent, downlink, odd
+    grids ...): `result._r`, the log-amplitudes, `phs` of the last chunk, AND the state the module generator is left in -- with
+    the draws made on the device."""
+    g = load_golden("e2e_" + case)
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_RNG": "numpy", "GPU_DEVICE": 0})
+    sim = fast_amd.Fast(p)
+    res = sim.run()
+    assert res._r.dtype == g["r"].dtype
+    np.testing.assert_allclose(res._r, g["r"], rtol=1e-9)
+    np.testing.assert_allclose(sim.logamp, g["logamp"], rtol=1e-9, atol=1e-300)
+    if "phs_last_chunk" in g.files and case != "numpy_branch":
+        np.testing.assert_allclose(sim.phs, g["phs_last_chunk"], rtol=1e-9, atol=1e-11 * np.abs(g["phs_last_chunk"]).max())
+    # the module generator is where the reference's would be: a host-mode run of the same config leaves it in the same state
+    after_dev = fast_amd.fast._R.bit_generator.state
+    p["GPU_RNG"] = "host"
+    sim2 = fast_amd.Fast(p)
+    res2 = sim2.run()
+    assert fast_amd.fast._R.bit_generator.state["state"] == after_dev["state"]
+    np.testing.assert_allclose(res._r, res2._r, rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["cfg1_256", "big_noao_1024", "big_noao_L0_1024", "big_ao_1024", "big_noao_L0_2048", "big_subharm_coherent_down_1024",
+                                  "big_ao_1000", "big_noao_1024_s2"])
+def test_fast_run_full_size_same_seed_on_the_device(name):
+    g = load_golden(name)
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_RNG": "numpy", "GPU_DEVICE": 0})
+    sim = fast_amd.Fast(p)
+    np.testing.assert_allclose(sim.run()._r, g["r"], rtol=1e-8)
+
+
+def test_numpy_mode_falls_back_to_host_draws_when_the_generator_is_not_pcg64(caplog):
+    g = load_golden("e2e_ao_alias")
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_RNG": "numpy", "GPU_DEVICE": 0})
+    sim = fast_amd.Fast(p)
+    fast_amd.fast._R = np.random.Generator(np.random.Philox(5))
+    import logging
+    with caplog.at_level(logging.WARNING):
+        r = sim.run()._r
+    assert any("drawing on the host" in m for m in caplog.messages)
+    want_rng = np.random.Generator(np.random.Philox(5))
+    assert np.isfinite(r).all() and r.size == g["r"].size
+    sim.set_seed(1)

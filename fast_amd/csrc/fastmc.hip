@@ -529,9 +529,15 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
 }
 #endif
 
+#if FMC_TU == 0
+static void nps_free(NpsWork* w);
+#endif
 static void destroy_now(fastmc_ctx* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+#if FMC_TU == 0
+  if (h->nps) { nps_free(h->nps); h->nps = nullptr; }
+#endif
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
   void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
@@ -1429,7 +1435,8 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
   const bool fused64 = S.mode == 0 && h->rng_f64 && fused_gen64<R>(h);
   const bool gen64 = S.mode == 0 && h->rng_f64 && !fused64;
   const int kmode = fused64 ? 2 : ((S.mode == 1 || gen64) ? 1 : 0);           // MODE of the row kernels
-  if (S.mode == 1) B = std::max(1, std::min<int>(B, (int)(256.0 * 1024 * 1024 / (N2 * 8.0))));
+  // host coefficients: 256 MB per upload; coefficients drawn on the device (S.fill): 2 GiB per array -- fewer, fuller launches
+  if (S.mode == 1) B = std::max(1, std::min<int>(B, (int)((S.fill ? 2048.0 : 256.0) * 1024 * 1024 / (N2 * 8.0))));
   if (gen64) B = std::max(1, std::min<int>(B, (int)(2048.0 * 1024 * 1024 / (N2 * 16.0))));
   if (S.epi == 1) B = std::max(1, std::min<int>(B, (int)(256.0 * 1024 * 1024 / (2.0 * Np * Np * 8.0))));
   B = (int)std::min<int64_t>(B, S.n_real);
@@ -1787,20 +1794,30 @@ struct NpsSegBuf {           // what classify / scan leave behind for emit, one 
   uint32_t* maps = nullptr;
   uint8_t* tile_e = nullptr;
   uint64_t* tile_base = nullptr;
+  u128* tile_state = nullptr;
   int64_t cap_tiles = 0;
 };
 struct NpsWork {
-  NpsSegBuf seg[4];          // real parts, imaginary parts, sub-harmonic real / imaginary parts of the chunk in flight
+  NpsSegBuf seg[4];          // [2 * set + k]: two sets (chunks alternate), k = 0 the coefficients of a chunk, 1 its sub-harmonic draws
+  hipStream_t gstream = nullptr;       // the generator chain (tile states, classify, scan) of chunk c + 1 runs here beside the
+  hipEvent_t ev_gen[2] = {nullptr, nullptr};   //   emit + Monte-Carlo kernels of chunk c on the handle's stream
+  hipEvent_t ev_used[2] = {nullptr, nullptr};
   u128* states = nullptr;    // [cap_states] chain of generator states: states[k] = before segment k of the call
   uint64_t* consumed = nullptr;    // [cap_states]
   uint32_t* overflow = nullptr;    // [cap_states] per segment
   size_t cap_states = 0;
   double* la = nullptr;      // log-amplitude normals of the run (device)
   size_t la_cap = 0;
-  double* sh_re = nullptr;   // sub-harmonic draws of a chunk
-  double* sh_im = nullptr;
-  size_t sh_cap = 0;
 };
+static void nps_free(NpsWork* w) {
+  if (w->gstream) hipStreamSynchronize(w->gstream);
+  for (NpsSegBuf& b : w->seg)
+    for (void* p : {(void*)b.events, (void*)b.evcount, (void*)b.maps, (void*)b.tile_e, (void*)b.tile_base, (void*)b.tile_state}) if (p) hipFree(p);
+  for (void* p : {(void*)w->states, (void*)w->consumed, (void*)w->overflow, (void*)w->la}) if (p) hipFree(p);
+  for (int i = 0; i < 2; ++i) { if (w->ev_gen[i]) hipEventDestroy(w->ev_gen[i]); if (w->ev_used[i]) hipEventDestroy(w->ev_used[i]); }
+  if (w->gstream) hipStreamDestroy(w->gstream);
+  delete w;
+}
 static std::mutex g_nps_mu;
 static std::map<int, std::pair<NpsTables*, NpsJump*>> g_nps_dev;     // per device: ziggurat tables (from numpy), jump table
 
@@ -1841,13 +1858,14 @@ static int64_t nps_tiles_for(uint64_t n) {       // upper bound of the words n n
 }
 static int nps_seg_reserve(NpsSegBuf& b, int64_t tiles) {
   if (b.cap_tiles >= tiles) return 0;
-  for (void* p : {(void*)b.events, (void*)b.evcount, (void*)b.maps, (void*)b.tile_e, (void*)b.tile_base}) if (p) hipFree(p);
+  for (void* p : {(void*)b.events, (void*)b.evcount, (void*)b.maps, (void*)b.tile_e, (void*)b.tile_base, (void*)b.tile_state}) if (p) hipFree(p);
   b = NpsSegBuf();
   HIPCHK(hipMalloc((void**)&b.events, (size_t)tiles * NPS_EVCAP * sizeof(NpsEvent)));
   HIPCHK(hipMalloc((void**)&b.evcount, (size_t)tiles * 4));
   HIPCHK(hipMalloc((void**)&b.maps, (size_t)tiles * NPS_K * 4));
   HIPCHK(hipMalloc((void**)&b.tile_e, (size_t)tiles));
   HIPCHK(hipMalloc((void**)&b.tile_base, (size_t)tiles * 8));
+  HIPCHK(hipMalloc((void**)&b.tile_state, (size_t)tiles * sizeof(u128)));
   b.cap_tiles = tiles;
   return 0;
 }
@@ -1862,25 +1880,39 @@ static int nps_reserve_states(NpsWork* w, size_t n) {
   return 0;
 }
 // classify + scan of segment k of the call: n normals from states[k]; leaves states[k + 1]
-static int nps_segment(fastmc_ctx* h, NpsSegArgs& A, NpsSegBuf& b, size_t k, u128 inc, uint64_t n) {
+static int nps_segment(fastmc_ctx* h, NpsSegArgs& A, NpsSegBuf& b, size_t k, u128 inc, uint64_t n, hipStream_t stream = nullptr) {
+  if (!stream) stream = h->stream;
   NpsWork* w = h->nps;
   const auto& dev = g_nps_dev[h->device];
   const int64_t tiles = nps_tiles_for(n);
   TRY(nps_seg_reserve(b, tiles));
   A.state = w->states + k; A.inc = inc; A.n = n; A.ntiles = tiles; A.tab = dev.first; A.jump = dev.second;
-  A.events = b.events; A.evcount = b.evcount; A.maps = b.maps; A.tile_e = b.tile_e; A.tile_base = b.tile_base;
+  A.events = b.events; A.evcount = b.evcount; A.maps = b.maps; A.tile_e = b.tile_e; A.tile_base = b.tile_base; A.tile_state = b.tile_state;
   A.state_out = w->states + k + 1; A.consumed = w->consumed + k; A.overflow = w->overflow + k;
-  hipLaunchKernelGGL(k_nps_classify, dim3((unsigned)tiles), dim3(NPS_THREADS), 0, h->stream, A);
-  hipLaunchKernelGGL(k_nps_scan, dim3(1), dim3(NPS_THREADS), 0, h->stream, A);
+  hipLaunchKernelGGL(k_nps_tilestates, dim3((unsigned)((tiles + NPS_THREADS - 1) / NPS_THREADS)), dim3(NPS_THREADS), 0, stream, A);
+  hipLaunchKernelGGL(k_nps_classify, dim3((unsigned)tiles), dim3(NPS_THREADS), 0, stream, A);
+  hipLaunchKernelGGL(k_nps_scan, dim3(1), dim3(NPS_THREADS), 0, stream, A);
   return 0;
 }
-// normals [lo, hi) of a classified segment -> out[0 ... hi - lo)
-static void nps_emit(fastmc_ctx* h, const NpsSegArgs& A, uint64_t lo, uint64_t hi, double* out) {
-  // the tiles that can hold them: normal index i starts no earlier than word i and no later than word 1.05 i + 2 T
-  const int64_t t0 = (int64_t)(lo / NPS_T);
+// normals [lo, hi) of a classified segment -> out[0 ... hi - lo); optionally a second range of the same segment in the same launch
+static NpsEmitRange nps_range(const NpsSegArgs& A, uint64_t lo, uint64_t hi, double* out) {
+  // the tiles that can hold them: normal index i starts no earlier than word i and no later than word 1.0625 i + 3 T
+  NpsEmitRange R;
+  R.tile0 = (int64_t)(lo / NPS_T);
   int64_t t1 = (int64_t)((hi + hi / 16) / NPS_T) + 3;
   if (t1 > A.ntiles) t1 = A.ntiles;
-  if (t1 > t0) hipLaunchKernelGGL(k_nps_emit, dim3((unsigned)(t1 - t0)), dim3(NPS_THREADS), 0, h->stream, A, t0, lo, hi, out);
+  R.ntiles = t1 > R.tile0 ? t1 - R.tile0 : 0;
+  R.lo = lo; R.hi = hi; R.out = out;
+  return R;
+}
+static void nps_emit2(fastmc_ctx* h, const NpsSegArgs& A, const NpsEmitRange& R0, const NpsEmitRange& R1) {
+  if (R0.ntiles + R1.ntiles > 0)
+    hipLaunchKernelGGL(k_nps_emit, dim3((unsigned)(R0.ntiles + R1.ntiles)), dim3(NPS_THREADS), 0, h->stream, A, R0, R1);
+}
+static void nps_emit(fastmc_ctx* h, const NpsSegArgs& A, uint64_t lo, uint64_t hi, double* out) {
+  NpsEmitRange none;
+  none.tile0 = 0; none.ntiles = 0; none.lo = none.hi = 0; none.out = nullptr;
+  nps_emit2(h, A, nps_range(A, lo, hi, out), none);
 }
 static int nps_prepare(fastmc_ctx* h, const uint64_t state_inc[4], size_t n_states, u128* inc) {
   {
@@ -1973,7 +2005,9 @@ extern "C" int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int
   if (h->precision != FASTMC_F64) return fail(FASTMC_ESTATE, "the numpy-stream generator feeds the float64 pipeline");
   HIPCHK(hipSetDevice(h->device));
   const bool sh = h->have_sh;
-  const int segs = sh ? 4 : 2;
+  // per chunk ONE array of the stream holds the real parts then the imaginary parts (two consecutive normal() calls are one
+  // longer one), a second one the sub-harmonic draws: one classify + scan each
+  const int segs = sh ? 2 : 1;
   u128 inc;
   TRY(nps_prepare(h, state_inc, (size_t)n_chunks * segs + 1, &inc));
   NpsWork* w = h->nps;
@@ -1985,39 +2019,53 @@ extern "C" int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int
   double* pinned = nullptr;
   HIPCHK(hipHostMalloc((void**)&pinned, per_chunk * n_chunks * 8, hipHostMallocDefault));
   struct Free { double* p; ~Free() { if (p) hipHostFree(p); } } guard{pinned};
-  if (sh && w->sh_cap < (size_t)chunk_real * 27) {
-    if (w->sh_re) hipFree(w->sh_re);
-    if (w->sh_im) hipFree(w->sh_im);
-    w->sh_re = w->sh_im = nullptr; w->sh_cap = 0;
-    HIPCHK(hipMalloc((void**)&w->sh_re, (size_t)chunk_real * 27 * 8));
-    HIPCHK(hipMalloc((void**)&w->sh_im, (size_t)chunk_real * 27 * 8));
-    w->sh_cap = (size_t)chunk_real * 27;
-  }
-  for (int64_t c = 0; c < n_chunks; ++c) {
-    NpsSegArgs A[4];
-    const size_t k0 = (size_t)c * segs;
-    TRY(nps_segment(h, A[0], w->seg[0], k0, inc, (uint64_t)chunk_real * N2));          // real parts of the chunk
-    TRY(nps_segment(h, A[1], w->seg[1], k0 + 1, inc, (uint64_t)chunk_real * N2));      // imaginary parts
-    if (sh) {
-      TRY(nps_segment(h, A[2], w->seg[2], k0 + 2, inc, (uint64_t)chunk_real * 27));
-      TRY(nps_segment(h, A[3], w->seg[3], k0 + 3, inc, (uint64_t)chunk_real * 27));
+  // Two streams: the generator chain of chunk c + 1 (tile states, classify, scan: sequential in the stream's state, latency-bound)
+  // runs beside the emit + Monte-Carlo kernels of chunk c (HBM-bound); the segment buffers alternate between two sets.
+  if (!w->gstream) {
+    HIPCHK(hipStreamCreateWithFlags(&w->gstream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(hipEventCreateWithFlags(&w->ev_gen[i], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&w->ev_used[i], hipEventDisableTiming));
     }
+  }
+  hipEvent_t ev0;      // the generator stream starts after what nps_prepare put on the handle's stream
+  HIPCHK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(ev0, h->stream));
+  HIPCHK(hipStreamWaitEvent(w->gstream, ev0, 0));
+  hipEventDestroy(ev0);
+  const uint64_t nc = (uint64_t)chunk_real * N2, ns = (uint64_t)chunk_real * 27;
+  std::vector<NpsSegArgs> AA((size_t)n_chunks * 2);
+  auto gen_chunk = [&](int64_t c) -> int {
+    const int set = (int)(c & 1);
+    if (c >= 2) HIPCHK(hipStreamWaitEvent(w->gstream, w->ev_used[set], 0));      // chunk c - 2 has read this set
+    TRY(nps_segment(h, AA[2 * c], w->seg[2 * set], (size_t)c * segs, inc, 2 * nc, w->gstream));      // real parts of the chunk, then its imaginary parts
+    if (sh) TRY(nps_segment(h, AA[2 * c + 1], w->seg[2 * set + 1], (size_t)c * segs + 1, inc, 2 * ns, w->gstream));
+    HIPCHK(hipEventRecord(w->ev_gen[set], w->gstream));
+    return 0;
+  };
+  TRY(gen_chunk(0));
+  for (int64_t c = 0; c < n_chunks; ++c) {
+    const int set = (int)(c & 1);
+    NpsSegArgs* A = &AA[2 * c];
+    HIPCHK(hipStreamWaitEvent(h->stream, w->ev_gen[set], 0));
+    if (c + 1 < n_chunks) TRY(gen_chunk(c + 1));
     RunSpec S{1, 0, 0, 0, chunk_real, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, coherent, nullptr, nullptr};
     S.async = true;
     S.logamp_dev = w->la + logamp_offset + (size_t)c * 2 * chunk_real;
-    S.fill = [&, h, sh, N2](int64_t bs, int nb) -> int {
-      nps_emit(h, A[0], (uint64_t)bs * N2, (uint64_t)(bs + nb) * N2, h->cre);
-      nps_emit(h, A[1], (uint64_t)bs * N2, (uint64_t)(bs + nb) * N2, h->cim);
-      if (sh) {
-        nps_emit(h, A[2], (uint64_t)bs * 27, (uint64_t)(bs + nb) * 27, h->sh_in_re);
-        nps_emit(h, A[3], (uint64_t)bs * 27, (uint64_t)(bs + nb) * 27, h->sh_in_im);
-      }
+    S.fill = [&, A, h, sh, N2, nc, ns](int64_t bs, int nb) -> int {
+      nps_emit2(h, A[0], nps_range(A[0], (uint64_t)bs * N2, (uint64_t)(bs + nb) * N2, h->cre),
+                nps_range(A[0], nc + (uint64_t)bs * N2, nc + (uint64_t)(bs + nb) * N2, h->cim));
+      if (sh)
+        nps_emit2(h, A[1], nps_range(A[1], (uint64_t)bs * 27, (uint64_t)(bs + nb) * 27, h->sh_in_re),
+                  nps_range(A[1], ns + (uint64_t)bs * 27, ns + (uint64_t)(bs + nb) * 27, h->sh_in_im));
       return 0;
     };
     h->pending = false;          // no wait between chunks: only the last chunk's kernel times are read (after the one sync below)
     TRY(run_impl<double>(h, S));
+    HIPCHK(hipEventRecord(w->ev_used[set], h->stream));
     HIPCHK(hipMemcpyAsync(pinned + per_chunk * c, h->out, per_chunk * 8, hipMemcpyDeviceToHost, h->stream));
   }
+  HIPCHK(hipStreamSynchronize(w->gstream));
   std::vector<uint32_t> ovf((size_t)n_chunks * segs);
   std::vector<u128> states((size_t)n_chunks * segs + 1);
   HIPCHK(hipMemcpyAsync(ovf.data(), w->overflow, ovf.size() * 4, hipMemcpyDeviceToHost, h->stream));

@@ -14,7 +14,9 @@
 //             the generator and records an EVENT (position, words consumed f, value).  Events come out in position order
 //             (threads own consecutive pieces; a block scan assigns the slots).  Then the tile's transfer map: for each
 //             entry offset e < K (the first normal of the tile starts e words in, because the previous tile's last normal
-//             spilled over) the number of normals that start in the tile and the offset handed to the next tile.
+//             spilled over) the number of normals that start in the tile and the offset handed to the next tile -- and, per
+//             event, for which entry offsets it is a start.  (The slow path diverges: the words of a sub-tile that need it
+//             are queued and evaluated one per lane.)
 //   scan      one workgroup composes the maps of all tiles (two-level scan of functions on K values): every tile's true
 //             entry offset and the index of its first normal; the word after the n-th normal = the words this array consumed,
 //             and the generator state there (one more jump) for the next segment.
@@ -35,16 +37,19 @@ namespace fmc {
 
 typedef unsigned __int128 u128;
 
-constexpr int NPS_T = 16384;          // words per tile
+#ifndef FMC_NPS_T
+#define FMC_NPS_T 8192
+#endif
+constexpr int NPS_T = FMC_NPS_T;      // words per tile
 constexpr int NPS_THREADS = 256;
 constexpr int NPS_WPT = 8;            // consecutive words per thread and sub-tile
 constexpr int NPS_SUB = NPS_THREADS * NPS_WPT;      // 2048 words per sub-tile
 constexpr int NPS_NSUB = NPS_T / NPS_SUB;           // 8
 constexpr int NPS_K = 16;             // entry offsets a tile's map covers
-constexpr int NPS_EVCAP = 1024;       // events per tile (expected 360, sigma 19)
+constexpr int NPS_EVCAP = NPS_T / 16; // events per tile (expected T / 45: 180 at T = 8192, sigma 13)
 
 struct NpsEvent {
-  uint32_t pos;      // word in the tile at which the slow normal would start
+  uint32_t pos;      // word in the tile at which the slow normal would start | (bit e: it IS a start when the tile is entered at offset e) << 16
   uint32_t f;        // words it consumes
   double v;          // its value
 };
@@ -70,6 +75,7 @@ struct NpsSegArgs {
   NpsEvent* events;         // [ntiles][NPS_EVCAP]
   uint32_t* evcount;        // [ntiles]
   uint32_t* maps;           // [ntiles][NPS_K]: normals started | exit offset << 16
+  u128* tile_state;         // [ntiles] generator state at the first word of each tile (k_nps_tilestates)
   uint8_t* tile_e;          // [ntiles] entry offset (scan)
   uint64_t* tile_base;      // [ntiles] index of the tile's first normal (scan)
   u128* state_out;          // state after the segment (scan)
@@ -121,14 +127,20 @@ __device__ inline double nps_slow(uint64_t r, u128 s, u128 inc, const double* wi
 }
 
 // exclusive block scan of one small integer per thread (256 threads, 4 waves); `total` = the sum
+// inclusive sum over the 64 lanes of a wave on the DPP crossbar (row shifts, then the two row broadcasts): VALU only
+__device__ __forceinline__ uint32_t nps_wave_scan(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);    // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);    // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);    // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);    // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2 and 3
+  return (uint32_t)x;
+}
 __device__ __forceinline__ uint32_t nps_block_scan(uint32_t v, uint32_t* s_wave, uint32_t& total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
-  }
+  const uint32_t inc = nps_wave_scan(v);
   if (lane == 63) s_wave[w] = inc;
   __syncthreads();
   uint32_t base = 0;
@@ -138,72 +150,135 @@ __device__ __forceinline__ uint32_t nps_block_scan(uint32_t v, uint32_t* s_wave,
   return base + inc - v;
 }
 
+// The jump table in the LDS with the stream's increment folded in: state -> a[k] state + cinc[k] is 2^k steps.  (Read from global
+// memory, the dependent loads of a jump cost a microsecond each.)
+struct NpsLdsJump {
+  u128 a[64];
+  u128 cinc[64];
+};
+__device__ __forceinline__ void nps_load_jump(NpsLdsJump* L, const NpsJump* J, u128 inc) {      // the caller's barrier follows
+  if (threadIdx.x < 64) { L->a[threadIdx.x] = J->a[threadIdx.x]; L->cinc[threadIdx.x] = J->c[threadIdx.x] * inc; }
+}
+__device__ __forceinline__ u128 nps_advance_lds(u128 s, uint64_t dist, const NpsLdsJump* L) {
+  for (int k = 0; dist; ++k, dist >>= 1)
+    if (dist & 1) s = L->a[k] * s + L->cinc[k];
+  return s;
+}
+
+// state at the first word of every tile of a segment (one thread per tile)
+__global__ __launch_bounds__(NPS_THREADS) void k_nps_tilestates(NpsSegArgs A) {
+  __shared__ NpsLdsJump s_jump;
+  nps_load_jump(&s_jump, A.jump, A.inc);
+  __syncthreads();
+  const int64_t tile = (int64_t)blockIdx.x * NPS_THREADS + threadIdx.x;
+  if (tile < A.ntiles) A.tile_state[tile] = nps_advance_lds(*A.state, (uint64_t)tile * NPS_T, &s_jump);
+}
+
 // ---------------------------------------------------------------- classify
+constexpr int NPS_QCAP = 256;          // slow words of one sub-tile (expected 45, sigma 7)
+struct NpsQueued {                     // a slow word waiting for numpy's slow path: the generator right after it, the word, where it was
+  u128 s;
+  uint64_t r;
+  uint32_t pos;                        // in the tile
+  uint32_t f;                          // out: words consumed
+  double v;                            // out: value
+};
+
 __global__ __launch_bounds__(NPS_THREADS) void k_nps_classify(NpsSegArgs A) {
   __shared__ double s_wi[256];
   __shared__ uint64_t s_ki[256];
   __shared__ double s_fi[256];
   __shared__ uint32_t s_ev[NPS_EVCAP];        // pos | f << 16 of the tile's events, in position order
+  __shared__ uint32_t s_mask[NPS_EVCAP];      // bit e: the event is a START on the path that enters the tile at offset e
+  __shared__ NpsQueued s_q[NPS_QCAP];
+  __shared__ uint16_t s_qidx[NPS_SUB];
   __shared__ uint32_t s_wave[4];
-  __shared__ u128 s_base;
-  __shared__ uint32_t s_nev;
+  __shared__ NpsLdsJump s_jump;
+  __shared__ uint32_t s_qn[2];                // queue length, double-buffered over the sub-tiles
   const int64_t tile = blockIdx.x;
   const int t = threadIdx.x;
   s_wi[t] = A.tab->wi[t]; s_ki[t] = A.tab->ki[t]; s_fi[t] = A.tab->fi[t];
-  if (t == 0) { s_base = nps_advance(*A.state, A.inc, (uint64_t)tile * NPS_T, A.jump); s_nev = 0; }
+  nps_load_jump(&s_jump, A.jump, A.inc);
+  if (t == 0) s_qn[0] = s_qn[1] = 0;
   __syncthreads();
-  u128 st = nps_advance(s_base, A.inc, (uint64_t)t * NPS_WPT, A.jump);
+  u128 piece = nps_advance_lds(A.tile_state[tile], (uint64_t)t * NPS_WPT, &s_jump);      // the generator before this thread's piece of the sub-tile
+  const u128 a_sub = s_jump.a[11], c_sub = s_jump.cinc[11];                     // 2^11 = NPS_SUB words on
+  static_assert(NPS_SUB == 2048, "the sub-tile stride is the 2^11 entry of the jump table");
   NpsEvent* ev_out = A.events + (size_t)tile * NPS_EVCAP;
   uint32_t nev = 0;
   for (int sub = 0; sub < NPS_NSUB; ++sub) {
-    // this thread's eight words of the sub-tile
-    uint32_t lp[NPS_WPT], lf[NPS_WPT];
-    double lv[NPS_WPT];
-    uint32_t cnt = 0;
-    u128 s = st;
-#pragma unroll 1
+    // the eight words of this thread's piece: only WHICH are slow (numpy's slow path diverges; it runs below, one queued word per lane)
+    uint32_t slowmask = 0, cnt = 0;
+    u128 s = piece;
+#pragma unroll
     for (int i = 0; i < NPS_WPT; ++i) {
       const uint64_t r = nps_next(s, A.inc);
       const int idx = (int)(r & 0xff);
       const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
       if (rabs >= s_ki[idx]) {
-        uint32_t f;
-        const double v = nps_slow(r, s, A.inc, s_wi, s_ki, s_fi, f);
-        lp[cnt] = (uint32_t)(sub * NPS_SUB + t * NPS_WPT + i); lf[cnt] = f; lv[cnt] = v;
-        ++cnt;
+        slowmask |= 1u << i; ++cnt;
+        const uint32_t q = atomicAdd(&s_qn[sub & 1], 1u);
+        if (q < (uint32_t)NPS_QCAP) {
+          s_q[q].s = s; s_q[q].r = r; s_q[q].pos = (uint32_t)(sub * NPS_SUB + t * NPS_WPT + i);
+          s_qidx[t * NPS_WPT + i] = (uint16_t)q;
+        }
       }
     }
     uint32_t total;
-    const uint32_t slot0 = nev + nps_block_scan(cnt, s_wave, total);
-    for (uint32_t k = 0; k < cnt; ++k) {
-      const uint32_t slot = slot0 + k;
-      if (slot < NPS_EVCAP) {
-        s_ev[slot] = lp[k] | (lf[k] << 16);
-        NpsEvent e; e.pos = lp[k]; e.f = lf[k]; e.v = lv[k];
-        ev_out[slot] = e;
-      }
-      if (lf[k] >= 0xffffu) atomicOr(A.overflow, 1u);
+    const uint32_t slot0 = nev + nps_block_scan(cnt, s_wave, total);           // (its barriers also publish the queue)
+    const uint32_t qn = min(s_qn[sub & 1], (uint32_t)NPS_QCAP);
+    if (t == 0) {
+      if (s_qn[sub & 1] > (uint32_t)NPS_QCAP) atomicOr(A.overflow, 2u);
+      s_qn[(sub + 1) & 1] = 0;           // the next sub-tile's queue (its pushes come after this iteration's last barrier)
     }
+    if ((uint32_t)t < qn) {
+      uint32_t f;
+      s_q[t].v = nps_slow(s_q[t].r, s_q[t].s, A.inc, s_wi, s_ki, s_fi, f);
+      s_q[t].f = f;
+      if (f >= 0xffffu) atomicOr(A.overflow, 1u);
+    }
+    __syncthreads();
+    uint32_t slot = slot0;
+#pragma unroll
+    for (int i = 0; i < NPS_WPT; ++i)
+      if ((slowmask >> i) & 1u) {
+        const uint32_t q = s_qidx[t * NPS_WPT + i];
+        if (slot < (uint32_t)NPS_EVCAP && q < (uint32_t)NPS_QCAP) {
+          s_ev[slot] = s_q[q].pos | (s_q[q].f << 16);
+          ev_out[slot].f = s_q[q].f;
+          ev_out[slot].v = s_q[q].v;
+        }
+        ++slot;
+      }
     nev += total;
-    st = nps_advance(s, A.inc, (uint64_t)(NPS_SUB - NPS_WPT), A.jump);     // the same piece of the next sub-tile
+    __syncthreads();
+    piece = a_sub * piece + c_sub;
   }
   if (nev > NPS_EVCAP) { if (t == 0) atomicOr(A.overflow, 2u); nev = NPS_EVCAP; }
   if (t == 0) A.evcount[tile] = nev;
   __syncthreads();
-  // transfer map: lane e walks the events from entry offset e
-  if (t < NPS_K) {
-    uint32_t cur = (uint32_t)t, count = 0;
+  // transfer map: lane e walks the events from entry offset e and marks the ones that are starts on its path
+  if (t < 64) {                         // (the whole first wave, in step: the ballot needs every lane at the same event)
+    uint32_t cur = (uint32_t)min(t, NPS_K - 1), count = 0;
     for (uint32_t k = 0; k < nev; ++k) {
-      const uint32_t p = s_ev[k] & 0xffffu, f = s_ev[k] >> 16;
-      if (p < cur) continue;            // inside an earlier slow normal: not a start
-      count += p - cur + 1;             // the fast starts before it, and this one
-      cur = p + f;
+      const uint32_t pf = s_ev[k], p = pf & 0xffffu, f = pf >> 16;
+      const bool on = p >= cur;         // else: inside an earlier slow normal, not a start
+      const uint64_t b = __ballot(on);
+      if (t == 0) s_mask[k] = (uint32_t)(b & ((1u << NPS_K) - 1u));
+      if (on) {
+        count += p - cur + 1;           // the fast starts before it, and this one
+        cur = p + f;
+      }
     }
+    if (t < NPS_K) {
     uint32_t exit_off = 0;
     if (cur < (uint32_t)NPS_T) count += NPS_T - cur; else exit_off = cur - NPS_T;
     if (exit_off >= (uint32_t)NPS_K) { atomicOr(A.overflow, 4u); exit_off = 0; }
     A.maps[(size_t)tile * NPS_K + t] = count | (exit_off << 16);
+    }
   }
+  __syncthreads();
+  for (uint32_t k = t; k < nev; k += NPS_THREADS) ev_out[k].pos = (s_ev[k] & 0xffffu) | (s_mask[k] << 16);
 }
 
 // ---------------------------------------------------------------- scan (one workgroup)
@@ -214,7 +289,9 @@ __global__ __launch_bounds__(NPS_THREADS) void k_nps_scan(NpsSegArgs A) {
   __shared__ uint64_t s_bb[NPS_THREADS];
   __shared__ int64_t s_end_tile;
   __shared__ uint32_t s_ev[NPS_EVCAP];
+  __shared__ NpsLdsJump s_jump;
   const int t = threadIdx.x;
+  nps_load_jump(&s_jump, A.jump, A.inc);
   const int64_t per = (A.ntiles + NPS_THREADS - 1) / NPS_THREADS;
   const int64_t j0 = (int64_t)t * per, j1 = min(j0 + per, A.ntiles);
   {
@@ -270,7 +347,7 @@ __global__ __launch_bounds__(NPS_THREADS) void k_nps_scan(NpsSegArgs A) {
   const uint32_t nev = A.evcount[je];
   for (uint32_t k = t; k < nev; k += NPS_THREADS) {
     const NpsEvent e = A.events[(size_t)je * NPS_EVCAP + k];
-    s_ev[k] = e.pos | (e.f << 16);
+    s_ev[k] = (e.pos & 0xffffu) | (e.f << 16);
   }
   __syncthreads();
   if (t == 0) {
@@ -288,78 +365,104 @@ __global__ __launch_bounds__(NPS_THREADS) void k_nps_scan(NpsSegArgs A) {
     if (!done) end = cur + (want - count);
     const uint64_t consumed = (uint64_t)je * NPS_T + end;
     *A.consumed = consumed;
-    *A.state_out = nps_advance(*A.state, A.inc, consumed, A.jump);
+    *A.state_out = nps_advance_lds(*A.state, consumed, &s_jump);
   }
 }
 
 // ---------------------------------------------------------------- emit: normals [lo, hi) of the segment -> out[idx - lo]
-__global__ __launch_bounds__(NPS_THREADS) void k_nps_emit(NpsSegArgs A, int64_t tile0, uint64_t lo, uint64_t hi, double* out) {
+struct NpsEmitRange {      // normals [lo, hi) -> out[0 ... hi - lo), looked for in tiles [tile0, tile0 + ntiles)
+  int64_t tile0, ntiles;
+  uint64_t lo, hi;
+  double* out;
+};
+__global__ __launch_bounds__(NPS_THREADS) void k_nps_emit(NpsSegArgs A, NpsEmitRange R0, NpsEmitRange R1) {
+  // two ranges per launch (the real and the imaginary parts of a batch): twice the workgroups in flight
+  const bool second = (int64_t)blockIdx.x >= R0.ntiles;
+  const NpsEmitRange R = second ? R1 : R0;
+  const int64_t tile0 = R.tile0 - (second ? R0.ntiles : 0);
+  const uint64_t lo = R.lo, hi = R.hi;
+  double* out = R.out;
   __shared__ double s_wi[256];
   __shared__ uint64_t s_ki[256];
   __shared__ uint32_t s_skip[NPS_T / 32];     // bit p: word p is not the start of a normal
-  __shared__ uint32_t s_ev[NPS_EVCAP];
+  __shared__ double s_out[NPS_SUB];           // the normals of one sub-tile, in order
   __shared__ uint32_t s_wave[4];
-  __shared__ u128 s_base;
+  __shared__ NpsLdsJump s_jump;
   const int64_t tile = tile0 + blockIdx.x;
   if (tile >= A.ntiles) return;
   const uint64_t base = A.tile_base[tile];
-  const uint32_t m = A.maps[(size_t)tile * NPS_K + A.tile_e[tile]];
+  const uint32_t e_in = A.tile_e[tile];
+  const uint32_t m = A.maps[(size_t)tile * NPS_K + e_in];
   if (base >= hi || base + (m & 0xffffu) <= lo) return;          // no normal of [lo, hi) starts here (uniform over the workgroup)
   const int t = threadIdx.x;
   s_wi[t] = A.tab->wi[t]; s_ki[t] = A.tab->ki[t];
-  for (int i = t; i < NPS_T / 32; i += NPS_THREADS) s_skip[i] = 0;
+  for (int i = t; i < NPS_T / 32; i += NPS_THREADS) s_skip[i] = (i == 0) ? ((1u << e_in) - 1u) : 0u;      // the words before the entry offset
+  nps_load_jump(&s_jump, A.jump, A.inc);
+  __syncthreads();
+  // the words inside the slow normals of the true path (classify marked which events start on it)
   const uint32_t nev = A.evcount[tile];
   const NpsEvent* ev = A.events + (size_t)tile * NPS_EVCAP;
-  for (uint32_t k = t; k < nev; k += NPS_THREADS) s_ev[k] = ev[k].pos | (ev[k].f << 16);
-  if (t == 0) s_base = nps_advance(*A.state, A.inc, (uint64_t)tile * NPS_T, A.jump);
-  __syncthreads();
-  if (t == 0) {
-    // the true path: mark what it skips (few hundred events; one lane)
-    uint32_t cur = A.tile_e[tile];
-    for (uint32_t p = 0; p < cur; ++p) s_skip[p >> 5] |= 1u << (p & 31);
-    for (uint32_t k = 0; k < nev; ++k) {
-      const uint32_t p = s_ev[k] & 0xffffu, f = s_ev[k] >> 16;
-      if (p < cur) continue;
-      for (uint32_t q = p + 1; q < p + f && q < (uint32_t)NPS_T; ++q) s_skip[q >> 5] |= 1u << (q & 31);
-      cur = p + f;
-    }
+  for (uint32_t k = t; k < nev; k += NPS_THREADS) {
+    const uint32_t pm = ev[k].pos, f = ev[k].f, p = pm & 0xffffu;
+    if ((pm >> (16 + e_in)) & 1u)
+      for (uint32_t q = p + 1; q < p + f && q < (uint32_t)NPS_T; ++q) atomicOr(&s_skip[q >> 5], 1u << (q & 31));
   }
   __syncthreads();
-  u128 st = nps_advance(s_base, A.inc, (uint64_t)t * NPS_WPT, A.jump);
+  u128 piece = nps_advance_lds(A.tile_state[tile], (uint64_t)t * NPS_WPT, &s_jump);
+  const u128 a_sub = s_jump.a[11], c_sub = s_jump.cinc[11];
   uint64_t rank0 = base;         // index of the first normal of the current sub-tile
   uint32_t nev_before = 0;       // events of the earlier sub-tiles
-  for (int sub = 0; sub < NPS_NSUB; ++sub) {
-    double val[NPS_WPT];
-    uint32_t slowmask = 0, startmask = 0, nslow = 0, nstart = 0;
-    u128 s = st;
+  static_assert(NPS_NSUB % 2 == 0, "sub-tiles are stepped in pairs");
+  for (int sub = 0; sub < NPS_NSUB; sub += 2) {
+    // TWO sub-tiles per pass: two independent generator chains per lane (a PCG64 step is a dependent chain of a dozen
+    // quarter-rate multiplies; with three or four waves per SIMD one chain per lane leaves the VALU idle two cycles in three)
+    double val[2][NPS_WPT];
+    uint32_t slowmask[2] = {0, 0};
+    u128 sc[2];
+    const u128 piece_b = a_sub * piece + c_sub;
+    sc[0] = piece;
+    sc[1] = piece_b;
 #pragma unroll
     for (int i = 0; i < NPS_WPT; ++i) {
-      const uint64_t r = nps_next(s, A.inc);
-      const int idx = (int)(r & 0xff);
-      const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
-      const double x = __dmul_rn((double)rabs, s_wi[idx]);
-      val[i] = ((r >> 8) & 1) ? -x : x;
-      const uint32_t p = (uint32_t)(sub * NPS_SUB + t * NPS_WPT + i);
-      if (rabs >= s_ki[idx]) { slowmask |= 1u << i; ++nslow; }
-      if (!((s_skip[p >> 5] >> (p & 31)) & 1u)) { startmask |= 1u << i; ++nstart; }
-    }
-    uint32_t tot_slow, tot_start;
-    const uint32_t slow0 = nev_before + nps_block_scan(nslow, s_wave, tot_slow);      // the slots classify gave this thread's events
-    const uint32_t start0 = nps_block_scan(nstart, s_wave, tot_start);
-    uint32_t ks = slow0;
-    uint64_t o = rank0 + start0;
 #pragma unroll
-    for (int i = 0; i < NPS_WPT; ++i) {
-      const bool slow = (slowmask >> i) & 1u;
-      if ((startmask >> i) & 1u) {
-        if (o >= lo && o < hi) out[o - lo] = slow ? ev[min(ks, (uint32_t)NPS_EVCAP - 1)].v : val[i];
-        ++o;
+      for (int c = 0; c < 2; ++c) {
+        const uint64_t r = nps_next(sc[c], A.inc);
+        const int idx = (int)(r & 0xff);
+        const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
+        const double x = __dmul_rn((double)rabs, s_wi[idx]);
+        val[c][i] = ((r >> 8) & 1) ? -x : x;
+        if (rabs >= s_ki[idx]) slowmask[c] |= 1u << i;
       }
-      if (slow) ++ks;
     }
-    nev_before += tot_slow;
-    rank0 += tot_start;
-    st = nps_advance(s, A.inc, (uint64_t)(NPS_SUB - NPS_WPT), A.jump);
+    piece = a_sub * piece_b + c_sub;     // this thread's piece of sub-tile sub + 2
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const uint32_t p0 = (uint32_t)((sub + c) * NPS_SUB + t * NPS_WPT);
+      const uint32_t startmask = ~(s_skip[p0 >> 5] >> (p0 & 31)) & 0xffu;        // eight consecutive bits of one word (p0 is a multiple of 8)
+      const uint32_t nslow = __popc(slowmask[c]), nstart = __popc(startmask);
+      // ONE scan for both counts (each sums to at most 2048 per sub-tile: 16 bits apiece)
+      uint32_t tot;
+      const uint32_t ex = nps_block_scan(nslow | (nstart << 16), s_wave, tot);
+      const uint32_t tot_slow = tot & 0xffffu, tot_start = tot >> 16;
+      // the sub-tile's normals are one contiguous run of the output (rank0 ...): gathered in the LDS in order, written coalesced
+      uint32_t ks = nev_before + (ex & 0xffffu), o = ex >> 16;
+#pragma unroll
+      for (int i = 0; i < NPS_WPT; ++i) {
+        const bool slow = (slowmask[c] >> i) & 1u;
+        if ((startmask >> i) & 1u) {
+          s_out[o] = slow ? ev[min(ks, (uint32_t)NPS_EVCAP - 1)].v : val[c][i];
+          ++o;
+        }
+        if (slow) ++ks;
+      }
+      __syncthreads();
+      for (uint32_t k = t; k < tot_start; k += NPS_THREADS) {
+        const uint64_t g = rank0 + k;
+        if (g >= lo && g < hi) out[g - lo] = s_out[k];
+      }
+      nev_before += tot_slow;
+      rank0 += tot_start;
+    }
   }
 }
 

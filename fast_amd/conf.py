@@ -28,6 +28,8 @@ DEFAULTS = {
 # Keys of the MI355X backend (not in the reference).  Filled silently.
 GPU_DEFAULTS = {
     'GPU_PRECISION': 'f64',   # 'f64' (complex128 pipeline, reference precision) or 'f32'
+    'GPU_FALLBACK': False,    # True: when libfastmc.so or a GPU is missing, warn (as fast/fast.py:107-110 does for pyfftw) and compute
+                              # on the host with numpy (fast_amd/hostpath.py); default: raise, nothing ever falls back silently
     'GPU_RNG': 'device',      # 'device': Philox on the GPU; 'host': numpy draws, reference order (parity mode);
                               # 'numpy': the SAME stream as 'host' (the reference's numbers for its SEED) drawn on the GPU
     'GPU_RNG_PRECISION': 'f32',  # device generator: 'f32' (24-bit uniforms, hardware float32 Box-Muller, float32 colouring,

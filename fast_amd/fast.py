@@ -115,13 +115,30 @@ class Fast():
                 raise Exception("GPU_DEVICES must name at least one device")
             if p['GPU_DEVICE'] is not None and int(p['GPU_DEVICE']) != devs[0]:
                 raise Exception("GPU_DEVICE and GPU_DEVICES disagree: give one of them")
-        self.device = (_lib.default_device() if p['GPU_DEVICE'] is None else int(p['GPU_DEVICE'])) if devs is None else devs[0]
-        self.devices = [self.device] if devs is None else devs
-        _warn_transform_branch(p['FFTW'])
-
-        # one handle per device, one thread each (fast_amd/multi.py); the first handle also serves everything that is
-        # not sharded (statistics, histogram of the assembled vector, TEMPORAL and host-generator modes)
-        self._group = multi.DeviceGroup(self.Npxls, self.Npxls_pup, self.precision, self.devices)
+        # The backend: libfastmc.so on a GPU -- or, ONLY when the caller opted in with GPU_FALLBACK and the library or a device is
+        # missing, numpy (fast_amd/hostpath.py), announced the way the reference announces its own fall-back (fast/fast.py:107-110)
+        self._be, self.backend = _lib, 'gpu'
+        if p['GPU_FALLBACK']:
+            from . import hostpath
+            why = hostpath.unavailable_reason()
+            if why is not None:
+                logger.warning(f"{why}, falling back to numpy (GPU_FALLBACK)")
+                self._be, self.backend = hostpath, 'host'
+                if self.rng_mode != 'host':
+                    logger.warning(f"GPU_RNG '{self.rng_mode}' needs a device: the draws are numpy's, in the reference's order (GPU_RNG 'host')")
+                    self.rng_mode = 'host'
+                self.precision = 'f64'
+        if self.backend == 'host':
+            self.device, self.devices = -1, [-1]
+            _warn_transform_branch(p['FFTW'])
+            self._group = multi.DeviceGroup(self.Npxls, self.Npxls_pup, 'f64', [-1], exchange="host", factory=lambda d: self._be.Handle(self.Npxls, self.Npxls_pup))
+        else:
+            self.device = (_lib.default_device() if p['GPU_DEVICE'] is None else int(p['GPU_DEVICE'])) if devs is None else devs[0]
+            self.devices = [self.device] if devs is None else devs
+            _warn_transform_branch(p['FFTW'])
+            # one handle per device, one thread each (fast_amd/multi.py); the first handle also serves everything that is
+            # not sharded (statistics, histogram of the assembled vector, TEMPORAL and host-generator modes)
+            self._group = multi.DeviceGroup(self.Npxls, self.Npxls_pup, self.precision, self.devices)
         self._handle = self._group.handles[0]
         self.precision = getattr(self._handle, 'precision', self.precision)     # what the handle computes in (see _lib.Handle)
         if p['GPU_BATCH']:
@@ -169,7 +186,7 @@ class Fast():
         args = (prob.dx, prob.wvl, p['L0'], p['l0'], prob.ao_mode, p['ALIAS'], p['NOISE'], prob.d_wfs, p['TLOOP'], p['TEXP'],
                 atm.dtheta, atm.cn2, atm.h, atm.wind_vector, prob.pup.pupil_filter, prob.simpson_w)
         kw = dict(lf_mask=None, modal=prob.modal, modal_mult=prob.modal_mult, zmax=prob.zmax, D_ground=p['D_GROUND'])
-        outs = self._group.each(lambda h, i: _lib.powerspec_set(h, prob.df, *args, pupil_filter_token=prob.pup.token, **kw))
+        outs = self._group.each(lambda h, i: self._be.powerspec_set(h, prob.df, *args, pupil_filter_token=prob.pup.token, **kw))
         out = outs[0]
         self._grids = {}
         for k in ("aniso_servo_error", "alias_error", "noise_error", "fitting_error", "phs_var", "logamp_var", "phs_var_weights"):
@@ -202,7 +219,7 @@ class Fast():
         """(L, N, N) per-layer grids by the stand-alone evaluation: the handles' colouring tables, the cached grids and the
         scalars on the object are left alone (a spectrum installed through the `powerspec` setter stays installed)."""
         args, kw = self._ps_args()
-        pl = _lib.powerspec(self._prob.N, *args, per_layer=True, device=self.device, **kw)["powerspec_per_layer"]
+        pl = self._be.powerspec(self._prob.N, *args, per_layer=True, device=self.device, **kw)["powerspec_per_layer"]
         pl.flags.writeable = False
         return pl
 
@@ -401,7 +418,7 @@ class Fast():
         the object: every run() of a time series needs it again."""
         if getattr(self, "_full", None) is None:
             N = self.Npxls
-            self._full = _lib.Handle(N, N, self.precision, self.device)
+            self._full = self._be.Handle(N, N, self.precision, self.device)
             self._full.set_pupil(numpy.ones((N, N)), 0, self.dx)
             self._full.set_spectrum(numpy.ones((N, N)), self._prob.df)
         return self._full
@@ -432,7 +449,7 @@ class Fast():
         """turb_powerspec, G_ao, alias_powerspec, noise_powerspec of fast.py:448-472, fetched from the GPU on first use."""
         if getattr(self, "_terms", None) is None:
             prob, p, atm = self._prob, self.params, self._prob.atm
-            t = _lib.powerspec_terms(prob.N, prob.dx, prob.wvl, p['L0'], p['l0'], prob.ao_mode, p['ALIAS'], p['NOISE'],
+            t = self._be.powerspec_terms(prob.N, prob.dx, prob.wvl, p['L0'], p['l0'], prob.ao_mode, p['ALIAS'], p['NOISE'],
                                      prob.d_wfs, p['TLOOP'], p['TEXP'], atm.dtheta, atm.cn2, atm.h, atm.wind_vector,
                                      prob.pup.pupil_filter, prob.simpson_w, lf_mask=None, modal=prob.modal,
                                      modal_mult=prob.modal_mult, zmax=prob.zmax, D_ground=p['D_GROUND'], device=self.device)
@@ -512,7 +529,7 @@ class Fast():
     def compute_mean_irradiance(self, onaxis=True):
         """Analytic (non Monte-Carlo) mean coupled flux, fast.py:736-761; its N x N transforms on the GPU."""
         return host.mean_irradiance(self.powerspec, self._prob.W, self.dx, self._prob.df, self.diffraction_limit, onaxis,
-                                    self.device)
+                                    self.device, backend=self._be)
 
     def make_header(self, params):
         """Result-file header cards (fast.py:771-807)."""

@@ -315,14 +315,15 @@ def pupils(p, N, Np, dx):
 
 
 # ----------------------------------------------------------------------------- analytic mean irradiance
-def mean_irradiance(powerspec, W, dx, df, diffraction_limit, onaxis=True, device=None):
+def mean_irradiance(powerspec, W, dx, df, diffraction_limit, onaxis=True, device=None, backend=None):
     """Fast.compute_mean_irradiance (fast.py:736-761): mean coupled flux from the optical transfer
     functions, no Monte Carlo.  Its three or four N x N transforms (aotools ft2 / ift2: centred DFTs
     scaled by delta^2 resp. (N delta_f)^2) run on the GPU (_lib.centred_fft2)."""
-    from . import _lib
+    if backend is None:
+        from . import _lib as backend
     N = powerspec.shape[0]
-    ft2 = lambda g, delta: _lib.centred_fft2(g, device) * delta ** 2
-    ift2 = lambda G, delta_f: _lib.centred_fft2(G, device, inverse=True) * (N * delta_f) ** 2
+    ft2 = lambda g, delta: backend.centred_fft2(g, device) * delta ** 2
+    ift2 = lambda G, delta_f: backend.centred_fft2(G, device, inverse=True) * (N * delta_f) ** 2
     pupil = np.zeros(powerspec.shape)
     pupil[:W.shape[0], :W.shape[1]] = W
     phs_otf = ift2(powerspec, df)

@@ -1,0 +1,67 @@
+"""CPU: the opt-in host path (`GPU_FALLBACK: True`; fast_amd/hostpath.py) against the reference's own fixtures -- this container
+has no GPU, so `fast_amd.Fast` takes it here exactly as a user on a login node would: a warning in the reference's style
+(fast/fast.py:107-110), then numpy.  BASELINE configs[0] ("CPU numpy FFT path, plumbing, no GPU") runs as written."""
+import logging
+
+import numpy as np
+import pytest
+
+from conftest import E2E_CASES, load_golden, params_from_json
+import fast_amd
+from fast_amd import _lib
+
+
+def _no_gpu():
+    try:
+        return _lib.device_count() == 0
+    except Exception:
+        return True
+
+
+needs_no_gpu = pytest.mark.skipif(not _no_gpu(), reason="a GPU is visible: GPU_FALLBACK does not fall back")
+
+
+def test_default_is_to_raise_without_a_gpu():
+    if not _no_gpu():
+        pytest.skip("a GPU is visible")
+    g = load_golden("e2e_ao_alias")
+    p = params_from_json(g["params_json"])
+    with pytest.raises(Exception):
+        fast_amd.Fast(p)
+
+
+@needs_no_gpu
+@pytest.mark.parametrize("case", E2E_CASES + ["default164"])
+def test_host_path_reproduces_the_reference(case, caplog):
+    g = load_golden("e2e_" + case)
+    p = params_from_json(g["params_json"])
+    p["GPU_FALLBACK"] = True
+    with caplog.at_level(logging.WARNING):
+        sim = fast_amd.Fast(p)
+    assert sim.backend == "host" and any("falling back to numpy" in m for m in caplog.messages)
+    res = sim.run()
+    assert res._r.dtype == g["r"].dtype
+    np.testing.assert_allclose(res._r, g["r"], rtol=1e-9)
+    np.testing.assert_allclose(sim.logamp, g["logamp"], rtol=1e-9, atol=1e-300)
+    for k in ("phs_var", "logamp_var", "fitting_error", "aniso_servo_error", "alias_error", "noise_error"):
+        if k in g.files:
+            np.testing.assert_allclose(getattr(sim, k), g[k], rtol=1e-9, atol=1e-300, err_msg=k)
+    if "powerspec" in g.files:
+        np.testing.assert_allclose(sim.powerspec, g["powerspec"], rtol=1e-10, atol=1e-13 * np.abs(g["powerspec"]).max())
+    if "phs_last_chunk" in g.files and case != "numpy_branch":
+        np.testing.assert_allclose(sim.phs, g["phs_last_chunk"], rtol=1e-9, atol=1e-11 * np.abs(g["phs_last_chunk"]).max())
+    assert np.isfinite(res.power).all() and np.isfinite(res.dB_rel).all()
+    h = sim.histogram(-40.0, 10.0, 16)
+    assert h.sum() == res._r.size and sim.result_stats([-3.0])["n"] == res._r.size
+
+
+@needs_no_gpu
+@pytest.mark.parametrize("name", ["temporal_default", "temporal_noao", "temporal_npxls100", "temporal_small"])
+def test_host_path_temporal_series(name):
+    """BASELINE configs[0]: the reference's shipped test/test_params.py (TEMPORAL, 100 iterations) as written, no GPU."""
+    g = load_golden(name)
+    p = params_from_json(g["params_json"])
+    p["GPU_FALLBACK"] = True
+    sim = fast_amd.Fast(p)
+    res = sim.run()
+    np.testing.assert_allclose(res._r, g["r"], rtol=1e-9)

@@ -260,7 +260,25 @@ def extras_unmeasured_rows(args, device):
         t0 = time.perf_counter()
         for i in range(3):
             h.run(1, (i + 1) * (n_it // 2), n_it // 2, None, float(sim.logamp_var), False)
-        out[tag] = {"iterations_per_s": 3 * n_it / (time.perf_counter() - t0)}
+        out[tag] = {"iterations_per_s": 3 * n_it / (time.perf_counter() - t0), "rows_kernel": h.last_kernels()[0]}
+    # same-seed modes (the reference's numbers for its SEED): numpy's stream drawn on the device (GPU_RNG 'numpy') against numpy's
+    # draws on the host (GPU_RNG 'host'), same chunking as BASELINE configs[1] (100 iterations per chunk), results compared
+    p = workload_params(copy.copy(args))
+    p.update({"GPU_DEVICE": device, "NITER": 200, "NCHUNKS": 2, "GPU_RNG": "host"})
+    t0 = time.perf_counter()
+    r_host = fast_amd.Fast(copy.copy(p)).run()._r
+    t_host = time.perf_counter() - t0
+    p["GPU_RNG"] = "numpy"
+    r_dev = fast_amd.Fast(copy.copy(p)).run()._r                       # (also warms the tables and buffers)
+    p.update({"NITER": 4000, "NCHUNKS": 40})
+    sim = fast_amd.Fast(copy.copy(p))
+    t0 = time.perf_counter()
+    sim.run()
+    t_dev = time.perf_counter() - t0
+    out["same_seed_1024"] = {"host_draws_iterations_per_s": 200 / t_host, "device_numpy_stream_iterations_per_s": 4000 / t_dev,
+                             "ratio": (4000 / t_dev) / (200 / t_host), "max_rel_diff_same_seed": float(np.abs(r_dev / r_host - 1).max()),
+                             "note": "GPU_RNG 'numpy': numpy's PCG64 + ziggurat stream reproduced on the device (fast_amd/csrc/fmc_npstream.h); "
+                                     "the host figure includes Fast() construction of a 200-iteration run"}
     return out
 
 

@@ -582,9 +582,18 @@ def main():
             grp.run(p["SEED"], args.warmup * workers * n_real, args.steps * workers * n_real, None, lvar, False, hist_range=HIST)
         sync_all()
         dt_one = time.perf_counter() - t0
+        # this pass's HIP events time the same launches with ONE run in the queue: with two steps in flight the events of
+        # consecutive launches overlap by a few per cent (the start marker of a launch is stamped while the previous step still
+        # drains), so the roofline's launch durations are taken from here
+        tim_one = dict.fromkeys(tim_keys, 0.0)
+        busy_keep2, busy = busy, []
+        add_timing(tim_one)
+        busy = busy_keep2
         if rdzv is not None:
             dt_one = float(rdzv.all_reduce(np.array([dt_one]), "max")[0])
-        host_cost = {"one_call_ms_per_step": dt_one / args.steps * 1e3, "host_ms_per_step": (dt - dt_one) / args.steps * 1e3}
+            for k in tim_keys:
+                tim_one[k] = float(rdzv.all_reduce(np.array([tim_one[k]]), "sum")[0])
+        host_cost = {"one_call_ms_per_step": dt_one / args.steps * 1e3, "host_ms_per_step": (dt - dt_one) / args.steps * 1e3, "tim": tim_one}
         hist_total = keep_hist
 
     # The same job with the generator at the REFERENCE's precision (53-bit normals, float64 colouring: fast/funcs.py:352-356,
@@ -603,13 +612,18 @@ def main():
         sync_all()
         dt64 = time.perf_counter() - t0
         kernels64 = h.last_kernels()
+        # launch durations for this pass's roofline from ONE more step issued on its own (see the host-cost pass above)
+        tim64_one = dict.fromkeys(tim_keys, 0.0)
+        step(first + 1 + args.steps)
+        add_timing(tim64_one)
         busy = busy_keep
         if rdzv is not None:
             dt64 = float(rdzv.all_reduce(np.array([dt64]), "max")[0])
             for k in tim_keys:
                 tim64[k] = float(rdzv.all_reduce(np.array([tim64[k]]), "sum")[0])
+                tim64_one[k] = float(rdzv.all_reduce(np.array([tim64_one[k]]), "sum")[0])
         assert np.isfinite(out64).all() and (out64 > 0).all()
-        gen64 = {"dt": dt64, "tim": tim64, "kernels": kernels64}
+        gen64 = {"dt": dt64, "tim": tim64, "tim_one": tim64_one, "kernels": kernels64}
         grp.each(lambda hh, i: hh.set_rng_precision("f32"))
 
     # GPUs that actually ran (one node: distinct device indices over all workers) and the communicator's own world size
@@ -652,13 +666,15 @@ def main():
                        "parallelism": f"realisations sharded over {workers} worker(s) on {n_devices} GPU(s)", "result_exchange": exchange_name(),
                        "rccl_ranks": rccl_ranks,
                        "histogram_total": None if hist_total is None else int(np.sum(hist_total))},
-            "roofline": roofline(args, N, Np, tim, args.steps, workers, iters_worker, kernels),
+            "roofline": roofline(args, N, Np, tim if (host_cost is None or args.no_pipeline) else host_cost["tim"], args.steps, workers, iters_worker, kernels),
             "pipeline": {"steps_in_flight": 1 if args.no_pipeline else 2,
                          # what K separate steps cost beyond the device-limited time of the same work: launches, the exchange's host side,
                          # result copies, Python -- hidden behind the device's work when two steps are in flight
                          "host_ms_per_step": None if host_cost is None else host_cost["host_ms_per_step"],
                          "one_call_ms_per_step": None if host_cost is None else host_cost["one_call_ms_per_step"],
-                         "host_ms_note": "ms_per_step minus the time per step of the same realisations issued as ONE call per worker (device-limited)",
+                         "host_ms_note": "ms_per_step minus the time per step of the same realisations issued as ONE call per worker (device-limited); "
+                                         "rows_ms / cols_ms below are HIP-event sums of the timed steps (with two steps in flight consecutive launches' "
+                                         "events overlap by a few per cent); roofline.avg_launch_ms is from the one-call pass",
                          "gpu_busy_ms_per_step_per_worker": gpu_ms / args.steps / workers,
                          "gpu_busy_ms_per_step": {"min_worker": float(busy.mean(0).min()), "max_worker": float(busy.mean(0).max()),
                                                   "per_worker": [float(x) for x in busy.mean(0)]},
@@ -673,7 +689,8 @@ def main():
                 "what": "the same steps with GPU_RNG_PRECISION 'f64': 53-bit normals (two xoshiro128+ streams), float64 log / sqrt / sincos "
                         "(fast_amd/csrc/fmc_gen64.h), float64 colouring, fused into the row kernel -- the reference's arithmetic end to end",
                 "rows_ms": gen64["tim"]["rows_ms"] / args.steps / workers, "cols_ms": gen64["tim"]["cols_ms"] / args.steps / workers,
-                "roofline": roofline(args, N, Np, gen64["tim"], args.steps, workers, iters_worker, gen64["kernels"])}
+                "roofline": roofline(args, N, Np, gen64["tim"] if args.no_pipeline else gen64["tim_one"], args.steps if args.no_pipeline else 1,
+                                     workers, iters_worker, gen64["kernels"])}
         if exchange is not None:
             line["exchange"] = exchange
         if sustained:

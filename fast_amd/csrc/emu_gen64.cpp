@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
   std::vector<uint32_t> w(4 * n);
   if (fread(w.data(), 16, n, f) != n) { fprintf(stderr, "short read\n"); return 1; }
   fclose(f);
-  std::vector<fmc::Gen64Entry> tab(fmc::GEN64_LOG_ENTRIES);
+  std::vector<fmc::Gen64Entry> tab(fmc::GEN64_LOG_ENTRIES + fmc::GEN64_TRIG_ENTRIES);
   fmc::gen64_build_table(tab.data());
   std::vector<double> out(2 * n);
   for (size_t i = 0; i < n; ++i)

@@ -181,6 +181,12 @@ struct fastmc_ctx {
   char last_rows[96] = "", last_cols[96] = "";   // the row / column kernels of the last launch, as c++filt prints them (fastmc_last_kernels)
   bool pending = false;
   QueueSlot q[2];
+  // the landing copies of a queued step run on a COPY stream behind an event of the compute stream, so that the next step's
+  // kernels do not queue up behind them; whatever overwrites what a copy may still be reading (out, hist, gather_buf) first
+  // waits for `copy_guard`, the completion event of the latest such copies
+  hipStream_t cstream = nullptr;
+  hipEvent_t copy_fence = nullptr;      // recorded on the compute stream before a slot's copies
+  hipEvent_t copy_guard = nullptr;
   struct NpsWork* nps = nullptr;   // workspace of the numpy-stream generator (GPU_RNG 'numpy'; fmc_npstream.h), created on first use
   size_t last_out_doubles = 0;    // size of the last run's result vector in `out`
   hipEvent_t ex_a = nullptr, ex_b = nullptr;   // around the collectives of the last exchange
@@ -219,6 +225,11 @@ static int grow(double** p, size_t* cap, size_t need) {
   HIPCHK(hipMalloc((void**)p, need * sizeof(double)));
   *cap = need;
   return 0;
+}
+
+// before anything writes out / hist / gather_buf: the copies of a queued step that may still be reading them (see cstream)
+static void guard_outputs(fastmc_ctx* h) {
+  if (h->copy_guard) hipStreamWaitEvent(h->stream, h->copy_guard, 0);
 }
 
 static hipEvent_t next_event(fastmc_ctx* h) {
@@ -508,6 +519,8 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   finish_pending(h);
+  if (h->cstream) hipStreamSynchronize(h->cstream);
+  h->copy_guard = nullptr;
   for (QueueSlot& q : h->q) { q.busy = q.pending = q.ex_recorded = q.stalled = false; q.landed = q.hist_landed = 0; }
   // back to the state fastmc_create leaves: problem unset, results forgotten, options at their defaults; buffers kept
   h->have_spec = h->have_pupil = h->have_sh = h->have_ps = false;
@@ -545,6 +558,8 @@ static void destroy_now(fastmc_ctx* h) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (auto e : h->pool) hipEventDestroy(e);
+  if (h->cstream) { hipStreamSynchronize(h->cstream); hipStreamDestroy(h->cstream); }
+  if (h->copy_fence) hipEventDestroy(h->copy_fence);
   for (QueueSlot& q : h->q) {
     for (auto e : q.pool) hipEventDestroy(e);
     for (hipEvent_t e : {q.ex_a, q.ex_b, q.done}) if (e) hipEventDestroy(e);
@@ -626,7 +641,7 @@ static const Gen64Entry* gen64_table(int device) {
   std::lock_guard<std::mutex> lk(mu);
   auto it = tabs.find(device);
   if (it != tabs.end()) return it->second;
-  Gen64Entry host[GEN64_LOG_ENTRIES];
+  Gen64Entry host[GEN64_LOG_ENTRIES + GEN64_TRIG_ENTRIES];
   gen64_build_table(host);
   Gen64Entry* d = nullptr;
   if (hipMalloc((void**)&d, GEN64_TABLE_BYTES) != hipSuccess) return nullptr;
@@ -1413,8 +1428,8 @@ struct RunSpec {
 };
 
 // Does this handle's row kernel draw the float64 generator itself (MODE 2)?  The P = 16 rows of the wave family: 1024, and
-// 2048 / 4096 as sub-rows, float64 pipeline, any window the family serves (every variant's tables + the 2 KB log table fit the
-// LDS: 151.5 KB + 64 omS <= 160 KB for the sixteen-wave variants, whose omS <= 128; 126 KB + 64 omS for the twelve-wave ones).
+// 2048 / 4096 as sub-rows, float64 pipeline, any window the family serves (every variant's tables + the 4 KB of generator tables fit the
+// LDS: 152 KB + 64 omS <= 160 KB for the sixteen-wave variants, whose omS <= 128; 128 KB + 64 omS for the twelve-wave ones, omS <= 512).
 template <class R>
 static bool fused_gen64(fastmc_ctx* h) {
   if constexpr (sizeof(R) != 8) return false;
@@ -1603,6 +1618,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
         FA.partial = h->partial; FA.logamp = S.logamp_dev ? S.logamp_dev : (S.logamp ? h->logamp : nullptr);
         FA.logamp_sigma = std::sqrt(S.logamp_var); FA.rng_f64 = h->rng_f64; FA.key = key; FA.g0 = (uint64_t)(S.real0 + fin_start);
         FA.dx2 = h->dx * h->dx; FA.norm = h->wsum * (h->dx * h->dx); FA.out = h->out;
+        guard_outputs(h);
         hipLaunchKernelGGL(k_finalize, dim3((FA.nb + 3) / 4), dim3(256), 0, h->stream, FA);
         fin_start = done;
       }
@@ -1689,18 +1705,29 @@ extern "C" int fastmc_wait(fastmc_t* h, double* out) {
 
 #if FMC_TU == 0
 // ---- two steps in flight (QueueSlot)
-static int slot_land(fastmc_ctx* h, QueueSlot& q, const double* dev, size_t n) {     // D2H into the slot's pinned buffer, on the stream
+static int slot_copies_begin(fastmc_ctx* h) {      // the copies that follow wait for everything enqueued on the compute stream so far
+  if (!h->cstream) {
+    HIPCHK(hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->copy_fence, hipEventDisableTiming));
+  }
+  HIPCHK(hipEventRecord(h->copy_fence, h->stream));
+  HIPCHK(hipStreamWaitEvent(h->cstream, h->copy_fence, 0));
+  return 0;
+}
+static int slot_land(fastmc_ctx* h, QueueSlot& q, const double* dev, size_t n) {     // D2H into the slot's pinned buffer, on the copy stream
+  TRY(slot_copies_begin(h));
   if (q.pinned_cap < n) {
     if (q.pinned) HIPCHK(hipHostFree(q.pinned));
     q.pinned = nullptr; q.pinned_cap = 0;
     HIPCHK(hipHostMalloc((void**)&q.pinned, n * 8, hipHostMallocDefault));
     q.pinned_cap = n;
   }
-  HIPCHK(hipMemcpyAsync(q.pinned, dev, n * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(q.pinned, dev, n * 8, hipMemcpyDeviceToHost, h->cstream));
   q.landed = n;
   return 0;
 }
 static int slot_land_hist(fastmc_ctx* h, QueueSlot& q, int nbins) {
+  TRY(slot_copies_begin(h));
   const size_t n = (size_t)nbins + 2;
   if (q.hist_cap < n) {
     if (q.pinned_hist) HIPCHK(hipHostFree(q.pinned_hist));
@@ -1708,13 +1735,15 @@ static int slot_land_hist(fastmc_ctx* h, QueueSlot& q, int nbins) {
     HIPCHK(hipHostMalloc((void**)&q.pinned_hist, n * 8, hipHostMallocDefault));
     q.hist_cap = n;
   }
-  HIPCHK(hipMemcpyAsync(q.pinned_hist, h->hist, n * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(q.pinned_hist, h->hist, n * 8, hipMemcpyDeviceToHost, h->cstream));
   q.hist_landed = n;
   return 0;
 }
 static int slot_mark_done(fastmc_ctx* h, QueueSlot& q) {
   if (!q.done) HIPCHK(hipEventCreateWithFlags(&q.done, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(q.done, h->stream));
+  TRY(slot_copies_begin(h));                             // the completion follows everything on the compute stream so far, copies or not
+  HIPCHK(hipEventRecord(q.done, h->cstream));
+  h->copy_guard = q.done;
   q.busy = true;
   return 0;
 }
@@ -2183,6 +2212,7 @@ static int temporal_impl(fastmc_ctx* h, const double* xs, const double* ys, cons
   A.N = h->N; A.Np = Np; A.L = L; A.M = M; A.coherent = coherent;
   A.screens = h->layers; A.xs = d.p; A.ys = d.p + o_ys; A.roll = (const int*)(d.p + o_roll); A.W = h->W; A.logamp = d.p + o_la;
   A.dx2 = h->dx * h->dx; A.norm = h->wsum * (h->dx * h->dx); A.out = out ? d.p + o_out : nullptr; A.phs = phs ? d.p + o_phs : nullptr;
+  guard_outputs(h);
   hipLaunchKernelGGL(k_temporal_detect, dim3(M), dim3(256), 0, h->stream, A);
   HIPCHK(hipGetLastError());
   if (out) HIPCHK(hipMemcpyAsync(out, d.p + o_out, (size_t)M * 8 * (coherent ? 2 : 1), hipMemcpyDeviceToHost, h->stream));
@@ -2211,6 +2241,7 @@ static int histogram_device(fastmc_ctx* h, double lo, double hi, int nbins) {
     HIPCHK(hipMalloc((void**)&h->hist, ((size_t)nbins + 2) * 8));
     h->hist_cap = (size_t)nbins + 2;
   }
+  guard_outputs(h);
   HIPCHK(hipMemsetAsync(h->hist, 0, ((size_t)nbins + 2) * 8, h->stream));
   const int64_t n = h->last_n_iter;
   hipLaunchKernelGGL(k_histogram, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->out, n, h->last_coherent, lo,
@@ -2225,6 +2256,7 @@ extern "C" int fastmc_set_results(fastmc_t* h, const double* values, int64_t n_i
   HIPCHK(hipSetDevice(h->device));
   const size_t need = (size_t)n_iter * (coherent ? 2 : 1);
   TRY(grow(&h->out, &h->out_cap, need));
+  guard_outputs(h);
   HIPCHK(hipMemcpyAsync(h->out, values, need * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->last_n_iter = n_iter;
@@ -2689,11 +2721,13 @@ extern "C" int fastmc_comm_world(fastmc_t* h, int* world_size, int* rank) {
 // process take part); the host copies follow on the same stream.
 static int comm_enqueue_gather(fastmc_ctx* h, const DeviceComm& dc, int64_t n_local, bool powers) {
   HIPCHK(hipSetDevice(h->device));
+  guard_outputs(h);
   if (powers) NCCLCHK(g_rccl.AllGather(h->out, h->gather_buf, (size_t)n_local, ncclDouble, dc.comm, h->stream));
   return 0;
 }
 static int comm_enqueue_hist(fastmc_ctx* h, const DeviceComm& dc, int nbins) {
   HIPCHK(hipSetDevice(h->device));
+  guard_outputs(h);
   NCCLCHK(g_rccl.AllReduce(h->hist, h->hist, (size_t)nbins + 2, ncclUint64, ncclSum, dc.comm, h->stream));
   return 0;
 }

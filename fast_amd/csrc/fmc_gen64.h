@@ -13,9 +13,9 @@
 //     exact up to one rounding, |r'| <= 2^-6, and  -2 ln(1 + r) = r' + r'^2 Q(r')  with a degree-5 near-minimax Q
 //     (tools/gen64_design.py: relative error of y < 2e-18 before rounding);
 //   * sqrt y: v_rsq_f32 seed (2^-22) and ONE cubic correction step in float64 (five instructions): ~1 ulp;
-//   * exp(2 pi i t): quadrant q = round(4 t) and x = (pi / 2)(4 t - q) in [-pi/4, pi/4] from the integer bits (one float64
-//     subtraction) -- the same x, bit for bit, as the restatement's 2 pi (t - q / 4) -- then the fdlibm kernel polynomials
-//     (each < 1 ulp) and the quadrant's swap / signs by three integer instructions on the angle word.
+//   * exp(2 pi i t): the top seven bits of t index a 128-entry table (cos, sin)(2 pi (j + 1/2) / 128) (2 KB more); the
+//     remainder x in [-pi/128, pi/128) comes EXACTLY out of the integer bits (one float64 subtraction), sin x and cos x - 1 from
+//     three-term polynomials, and the table entry (scaled by the radius) is rotated by x: seventeen float64 instructions.
 // Everything but the seed is plain IEEE float64 arithmetic with FMAs, so the host emulation (emu_gen64.cpp, tests/
 // test_emu_gen64.py) executes the kernels' arithmetic exactly; draws agree with the libm restatement to ~4e-16 relative
 // (bar in the tests: 2e-14 absolute).
@@ -31,7 +31,9 @@ struct Gen64Entry {
   double c2;   // -2 c_j
   double T;    // 2 ln c_j
 };
-constexpr size_t GEN64_TABLE_BYTES = GEN64_LOG_ENTRIES * sizeof(Gen64Entry);   // 2 KB
+constexpr int GEN64_TRIG_ENTRIES = 128;
+// entries [0, 128): the log table; [128, 256): (cos, sin)(2 pi (j + 1/2) / 128) in the same two-double layout
+constexpr size_t GEN64_TABLE_BYTES = (GEN64_LOG_ENTRIES + GEN64_TRIG_ENTRIES) * sizeof(Gen64Entry);   // 4 KB
 
 FMC_HD uint32_t g64_hi(double x) { uint64_t b; memcpy(&b, &x, 8); return (uint32_t)(b >> 32); }
 FMC_HD uint32_t g64_lo(double x) { uint64_t b; memcpy(&b, &x, 8); return (uint32_t)b; }
@@ -51,6 +53,13 @@ inline void gen64_build_table(Gen64Entry* t) {
     const double c = gen64_table_c(j);
     t[j].c2 = -2.0 * c;
     t[j].T = (double)(2.0L * logl((long double)c));
+  }
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  for (int j = 0; j < GEN64_TRIG_ENTRIES; ++j) {
+    // exact symmetries first (the table is symmetric about the octants), then long double
+    const long double a = two_pi * ((long double)(2 * j + 1) / (long double)(2 * GEN64_TRIG_ENTRIES));
+    t[GEN64_LOG_ENTRIES + j].c2 = (double)cosl(a);
+    t[GEN64_LOG_ENTRIES + j].T = (double)sinl(a);
   }
 }
 
@@ -115,48 +124,35 @@ FMC_HD uint32_t g64_xor_and(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 
-// (cos, sin)(2 pi t) scaled by R, t = B 2^-53, B = (b >> 9) 2^30 + (b2 >> 2).  In quarter turns 4 t = e / 2 + ..., e = b >> 29:
-// the quadrant q = (e + 1) >> 1 (round to nearest) and the signed remainder f = 4 t - q in [-1/2, 1/2) come from the integer
-// bits -- G = B mod 2^51 with bit 50 flipped, placed in the mantissa of 2^52, minus (2^52 + 2^50) is f 2^51 EXACTLY: one
-// float64 subtraction instead of two conversions, an ldexp, an FMA, a rint and a conversion back -- and
-//     swap sin / cos  <=>  q odd       <=>  bit 30 of b + 2^29
-//     sin negative    <=>  q in {2, 3} <=>  bit 31 of b + 2^29
-//     cos negative    <=>  q in {1, 2} <=>  bit 31 of b + 3 2^29      (all mod 2^32: e = 7 rounds up to q = 4 = 0)
-// x = (pi / 2) f is the restatement's 2 pi (t - rint(4 t) / 4) bit for bit, except on the ties of the quadrant rounding
-// (probability 2^-51: rint rounds them to even, this rounds them up; either is the same angle).
-FMC_HD void g64_sincos_scaled(uint32_t b, uint32_t b2, double R, double& re, double& im) {
-  // f 2^51 = G - (bit 50 of G) 2^51 = (G xor 2^50) - 2^50: the xor and the exponent of 2^52 are ONE constant on the hi word
+// (cos, sin)(2 pi t) scaled by R, t = B 2^-53, B = (b >> 9) 2^30 + (b2 >> 2).  The top seven bits of B pick the table angle
+// theta_j = 2 pi (j + 1/2) / 128; the low 46 bits G, placed in the mantissa of 2^52 and reduced by (2^52 + 2^45), are
+// (t - (j + 1/2) / 128) 2^53 EXACTLY (one float64 subtraction, no conversion), so x = 2 pi (t - theta_j / 2 pi) lies in
+// [-pi/128, pi/128) and  sin x = x + x^3 (S1 + S2 x^2 + S3 x^4),  cos x - 1 = x^2 (C1 + C2 x^2 + C3 x^4)  to < 1e-17; then the
+// rotation of the table entry (scaled by R first).  Seventeen float64 instructions and one 16-byte table read: no quadrant
+// selects, no sign logic (round 4b; the quadrant form with the two fdlibm polynomials cost twenty and eleven integer ones).
+template <class TabPtr>
+FMC_HD void g64_sincos_scaled(uint32_t b, uint32_t b2, double R, TabPtr tab, double& re, double& im) {
   const uint32_t glo = g64_alignbit(b >> 9, b2, 2);                              // ((b >> 9) << 30) | (b2 >> 2)
-  const double d = g64_mk(((b >> 11) & 0x0007FFFFu) ^ 0x43340000u, glo);         // 2^52 + (G xor 2^50)
-  const double x = (d - 0x1.4p+52) * 0x1.921fb54442d18p-51;                      // (pi / 2) 2^-51 (f 2^51)
+  const double d = g64_mk(0x43300000u | ((b >> 11) & 0x00003FFFu), glo);         // 2^52 + G,  G = B mod 2^46
+  const double x = (d - 0x1.02p+52) * 0x1.921fb54442d18p-51;                    // ((G - 2^45) 2^-53) 2 pi   (2 pi 2^-53 = (pi / 2) 2^-51)
+  const Gen64Entry e = tab[GEN64_LOG_ENTRIES + (b >> 25)];
   const double z = x * x;
-  // fdlibm __kernel_sin / __kernel_cos on [-pi/4, pi/4]
-  double ps = g64_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = g64_fma(z, ps, 2.75573137070700676789e-06);
-  ps = g64_fma(z, ps, -1.98412698298579493134e-04);
-  ps = g64_fma(z, ps, 8.33333333332248946124e-03);
-  ps = g64_fma(z, ps, -1.66666666666666324348e-01);
-  const double sn = g64_fma(z * x, ps, x);
-  double pc = g64_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = g64_fma(z, pc, -2.75573143513906633035e-07);
-  pc = g64_fma(z, pc, 2.48015872894767294178e-05);
-  pc = g64_fma(z, pc, -1.38888888888741095749e-03);
-  pc = g64_fma(z, pc, 4.16666666666666019037e-02);
-  const double cs = g64_fma(z * z, pc, g64_fma(z, -0.5, 1.0));
-  const uint32_t q1 = b + 0x20000000u, q3 = b + 0x60000000u;
-  const bool swap = (q1 & 0x40000000u) != 0u;
-  const double cv = swap ? sn : cs, sv = swap ? cs : sn;
-  // cos(2 pi t) = {cs, -sn, -cs, sn}[q & 3],  sin(2 pi t) = {sn, cs, -sn, -cs}[q & 3]: the signs go onto R's hi word
-  const uint32_t rh = g64_hi(R), rl = g64_lo(R);
-  re = g64_mk(g64_xor_and(rh, q3, 0x80000000u), rl) * cv;
-  im = g64_mk(g64_xor_and(rh, q1, 0x80000000u), rl) * sv;
+  double p = g64_fma(z, -1.0 / 5040.0, 1.0 / 120.0);
+  p = g64_fma(z, p, -1.0 / 6.0);
+  const double sn = g64_fma(x * z, p, x);
+  double q = g64_fma(z, -1.0 / 720.0, 1.0 / 24.0);
+  q = g64_fma(z, q, -0.5);
+  const double cm1 = z * q;                                                       // cos x - 1
+  const double tc = R * e.c2, ts = R * e.T;                                      // R (cos, sin) theta_j
+  re = g64_fma(-ts, sn, g64_fma(tc, cm1, tc));
+  im = g64_fma(tc, sn, g64_fma(ts, cm1, ts));
 }
 
 // One coloured coefficient: sqrt(-2 ln u) exp(2 pi i t) amp
 template <class TabPtr>
 FMC_HD void box_muller_f64_fast(uint32_t a, uint32_t b, uint32_t a2, uint32_t b2, double amp, TabPtr tab, double& re, double& im) {
   const double R = g64_sqrt(g64_neg2log(a, a2, tab)) * amp;
-  g64_sincos_scaled(b, b2, R, re, im);
+  g64_sincos_scaled(b, b2, R, tab, re, im);
 }
 
 }  // namespace fmc

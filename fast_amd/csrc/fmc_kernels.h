@@ -101,11 +101,11 @@ __device__ __forceinline__ cpx<double> draw_coloured_f64(xoshiro128p& s, xoshiro
   box_muller_f64_fast(a, b, a2, b2, amp, tab, c.x, c.y);
   return c;
 }
-// stage the log table of the float64 generator into the LDS (2 KB; the caller's barrier follows)
+// stage the tables of the float64 generator into the LDS (4 KB; the caller's barrier follows)
 __device__ __forceinline__ void load_gen64_table(Gen64Entry* s_tab, const Gen64Entry* g) {
   double* d = reinterpret_cast<double*>(s_tab);
   const double* sgl = reinterpret_cast<const double*>(g);
-  for (int i = threadIdx.x; i < 2 * GEN64_LOG_ENTRIES; i += blockDim.x) d[i] = sgl[i];
+  for (int i = threadIdx.x; i < (int)(GEN64_TABLE_BYTES / 8); i += blockDim.x) d[i] = sgl[i];
 }
 
 // both Box-Muller words of a coefficient from ONE state advance (9 instead of 16 integer operations)
@@ -455,7 +455,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = WaveGeom<R, P>;
   using E = typename Xch<R>::E;
-  // MODE 2 (float64 generator fused into the row): its 2 KB log table at the start of the LDS (a table offset IS the address)
+  // MODE 2 (float64 generator fused into the row): its 4 KB of tables (log, cos / sin) at the start of the LDS (a table offset IS the address)
   Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
   cpx<R>* s_om = s_tw + P * WAVE;
@@ -1665,7 +1665,7 @@ __global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, int rng_f64, const G
 // reference does (fast/fast.py:594).  One thread per stream, neighbouring threads neighbouring columns.  Only the kernel
 // families without a fused form (MODE 2 of the row kernels) take this detour through HBM.
 __global__ __launch_bounds__(256) void k_gen_coeffs_f64(RngKey key, uint64_t g0, int nb, int N, const Gen64Entry* g64, double* cre, double* cim) {
-  __shared__ Gen64Entry s_g64[GEN64_LOG_ENTRIES];
+  __shared__ Gen64Entry s_g64[GEN64_LOG_ENTRIES + GEN64_TRIG_ENTRIES];
   load_gen64_table(s_g64, g64);
   __syncthreads();
   const int SL = stream_lanes(N);

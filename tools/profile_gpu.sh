@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # one generator per profile: the headline (float32 draw) unless the arguments say --rng-precision f64
-BENCH="python3 $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-sustained --no-f64-generator-pass --no-host-cost-pass $*"
+BENCH="python3 $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-sustained --no-f64-generator-pass --no-host-cost-pass --no-pipeline $*"
 # 1) kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 # 2) PMC passes (separate runs; FETCH_SIZE and WRITE_SIZE do not fit one pass)

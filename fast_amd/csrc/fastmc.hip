@@ -1036,7 +1036,7 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
 template <class R, int L0, int D>
 static void launch_pk_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   using C = PkCfg<R, L0, D>;
-  const size_t lds = pk_lds_bytes<R, L0>(RA.omS, C::WPB), ldc = pk_lds_bytes<R, L0>(RA.omS, C::WPC);
+  const size_t lds = pk_lds_bytes<R, L0>(RA.omS, C::WPB) + (mode == 2 ? GEN64_TABLE_BYTES : 0), ldc = pk_lds_bytes<R, L0>(RA.omS, C::WPC);
   constexpr int LR = 128 / (int)sizeof(cpx<R>), LU = LR / C::G, BPG = ROWS_PER_WAVE * C::WPB / LU;
   const int blocks = (C::N / LR) * ((RA.nb + BPG - 1) / BPG);
   {
@@ -1045,6 +1045,12 @@ static void launch_pk_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>
       hipFuncSetAttribute((const void*)k_rows_pk<R, L0, 0, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_pk<R, L0, 0, D>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, RA);
       FMC_NOTE(h->last_rows, "k_rows_pk<%s, %d, %d, %d>", rname<R>(), L0, 0, D);
+    } else if (mode == 2) {
+      if constexpr (sizeof(R) == 8) {
+        hipFuncSetAttribute((const void*)k_rows_pk<R, L0, 2, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_rows_pk<R, L0, 2, D>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, RA);
+        FMC_NOTE(h->last_rows, "k_rows_pk<%s, %d, %d, %d>", rname<R>(), L0, 2, D);
+      }
     } else {
       hipFuncSetAttribute((const void*)k_rows_pk<R, L0, 1, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_pk<R, L0, 1, D>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, RA);
@@ -1433,8 +1439,9 @@ struct RunSpec {
 template <class R>
 static bool fused_gen64(fastmc_ctx* h) {
   if constexpr (sizeof(R) != 8) return false;
-  if (h->path != 1 || h->P != 16 || wave_rt_split(h->N)) return false;
   if (getenv("FASTMC_GEN64_STAGED")) return false;          // A/B: the round-3 form (k_gen_coeffs_f64 -> cre / cim -> MODE 1 rows)
+  if (h->path == 1 && pk_grid(h->N) && pk_variant<R>(h) >= 0) return true;      // 128 / 256 / 512: the packed rows draw it themselves too
+  if (h->path != 1 || h->P != 16 || wave_rt_split(h->N)) return false;
   int ns = 0, wpb = 0;
   wave_config<R>(h, &ns, &wpb);
   return ns == 2 || ns == 4 || ns == 8;      // not the whole-grid window (NS = P: its tables leave no room, and nothing draws into it)
@@ -1918,9 +1925,11 @@ static int nps_segment(fastmc_ctx* h, NpsSegArgs& A, NpsSegBuf& b, size_t k, u12
   A.state = w->states + k; A.inc = inc; A.n = n; A.ntiles = tiles; A.tab = dev.first; A.jump = dev.second;
   A.events = b.events; A.evcount = b.evcount; A.maps = b.maps; A.tile_e = b.tile_e; A.tile_base = b.tile_base; A.tile_state = b.tile_state;
   A.state_out = w->states + k + 1; A.consumed = w->consumed + k; A.overflow = w->overflow + k;
+  static const bool general_scan = [] { const char* e = getenv("FASTMC_NPS_GENERAL_SCAN"); return e && *e == '1'; }();      // (tests)
+  A.flags = general_scan ? NPS_SCAN_GENERAL : 0u;
   hipLaunchKernelGGL(k_nps_tilestates, dim3((unsigned)((tiles + NPS_THREADS - 1) / NPS_THREADS)), dim3(NPS_THREADS), 0, stream, A);
   hipLaunchKernelGGL(k_nps_classify, dim3((unsigned)tiles), dim3(NPS_THREADS), 0, stream, A);
-  hipLaunchKernelGGL(k_nps_scan, dim3(1), dim3(NPS_THREADS), 0, stream, A);
+  hipLaunchKernelGGL(k_nps_scan, dim3(1), dim3(NPS_SCAN_THREADS), 0, stream, A);
   return 0;
 }
 // normals [lo, hi) of a classified segment -> out[0 ... hi - lo); optionally a second range of the same segment in the same launch

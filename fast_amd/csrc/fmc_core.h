@@ -272,6 +272,31 @@ FMC_HD void dft_reg(cpx<R> (&v)[P]) {
           u[q] = cmul(y[q][a2], mk<R>((R)wr, (R)wi));
         }
       });
+      if constexpr (Q == 5) {
+        // radix-5 butterfly in 36 real operations instead of the 72 of the direct form (round 4: the 50-lane rows -- 1000 = 50 x 20 --
+        // spent a third of their float64 instructions in direct radix-5 butterflies):  t1 = u1 + u4, t2 = u2 + u3, t3 = u1 - u4,
+        // t4 = u2 - u3;  a1 = u0 + c1 t1 + c2 t2, a2 = u0 + c2 t1 + c1 t2, b1 = s1 t3 + s2 t4, b2 = s2 t3 - s1 t4;
+        // y0 = u0 + t1 + t2, y1 = a1 - i b1, y4 = a1 + i b1, y2 = a2 - i b2, y3 = a2 + i b2
+        constexpr R c1 = (R)cos_frac(1, 5), c2 = (R)cos_frac(2, 5), s1 = (R)sin_frac(1, 5), s2 = (R)sin_frac(2, 5);
+        const cpx<R> t1 = u[1] + u[4], t2 = u[2] + u[3], t3 = u[1] - u[4], t4 = u[2] - u[3];
+        const cpx<R> p1 = mk<R>(u[0].x + c1 * t1.x + c2 * t2.x, u[0].y + c1 * t1.y + c2 * t2.y);
+        const cpx<R> p2 = mk<R>(u[0].x + c2 * t1.x + c1 * t2.x, u[0].y + c2 * t1.y + c1 * t2.y);
+        const cpx<R> q1 = mk<R>(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+        const cpx<R> q2 = mk<R>(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+        v[a2 + M * 0] = u[0] + (t1 + t2);
+        v[a2 + M * 1] = mk<R>(p1.x + q1.y, p1.y - q1.x);
+        v[a2 + M * 4] = mk<R>(p1.x - q1.y, p1.y + q1.x);
+        v[a2 + M * 2] = mk<R>(p2.x + q2.y, p2.y - q2.x);
+        v[a2 + M * 3] = mk<R>(p2.x - q2.y, p2.y + q2.x);
+      } else if constexpr (Q == 3) {
+        // radix-3: t = u1 + u2, a = u0 - t / 2, b = (sqrt 3 / 2)(u1 - u2);  y0 = u0 + t, y1 = a - i b, y2 = a + i b
+        constexpr R s = (R)sin_frac(1, 3);
+        const cpx<R> t = u[1] + u[2], d = u[1] - u[2];
+        const cpx<R> a = mk<R>(u[0].x - (R)0.5 * t.x, u[0].y - (R)0.5 * t.y), b = mk<R>(s * d.x, s * d.y);
+        v[a2 + M * 0] = u[0] + t;
+        v[a2 + M * 1] = mk<R>(a.x + b.y, a.y - b.x);
+        v[a2 + M * 2] = mk<R>(a.x - b.y, a.y + b.x);
+      } else
       static_for<Q>([&](auto A1) {
         constexpr int a1 = decltype(A1)::value;
         cpx<R> acc = u[0];

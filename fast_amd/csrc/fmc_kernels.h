@@ -662,9 +662,12 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPB * 64)) void k_rows_pk(RowArgs
   using C = PkCfg<R, L0, D>;
   using E = typename Xch<R>::E;
   constexpr int L = C::L, G = C::G, N = C::N, WPB = C::WPB;
-  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  // MODE 2 (float64 generator fused into the rows, as in k_rows_wave): its 4 KB of tables at the start of the LDS
+  Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
   cpx<R>* s_om = s_tw + 16 * L;
   E* s_x = reinterpret_cast<E*>(s_om + C::OM_ROWS * A.omS);
+  if constexpr (MODE == 2) load_gen64_table(s_g64, A.g64);
   pk_load_tables<R, L0>(s_tw, s_om, A.tw, A.om, A.omS);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * D16_XELEMS;
@@ -691,6 +694,20 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPB * 64)) void k_rows_pk(RowArgs
       xoshiro128p rs = row_stream(A.key, g, ky0 + gl, q, L);
 #pragma unroll
       for (int j = 0; j < 16; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[lane_in + L * j]);
+    } else if constexpr (MODE == 2) {
+      static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
+      const R* amp = A.amp + (size_t)ky0 * N;
+      xoshiro128p rs = row_stream(A.key, g, ky0 + gl, q, L), rl = row_stream_lo(A.key, g, ky0 + gl, q, L);
+      double an = (double)amp[lane_in];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double a = an;
+        if (j + 1 < 16) an = (double)amp[lane_in + L * (j + 1)];
+        ex.loadfence();
+        regs.v[j] = draw_coloured_f64(rs, rl, a, s_g64);
+        asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3), "+v"(rl.s0), "+v"(rl.s1),
+                     "+v"(rl.s2), "+v"(rl.s3));
+      }
     } else {
       const R* amp = A.amp + (size_t)ky0 * N;
       const size_t base = ((size_t)b * N + ky0) * N;

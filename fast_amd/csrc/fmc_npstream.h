@@ -81,6 +81,7 @@ struct NpsSegArgs {
   u128* state_out;          // state after the segment (scan)
   uint64_t* consumed;       // words the segment consumed (scan)
   uint32_t* overflow;       // != 0: give up on the device for this chunk
+  uint32_t flags;           // NPS_SCAN_GENERAL
 };
 
 __device__ __forceinline__ u128 nps_advance(u128 s, u128 inc, uint64_t dist, const NpsJump* J) {
@@ -274,7 +275,8 @@ __global__ __launch_bounds__(NPS_THREADS) void k_nps_classify(NpsSegArgs A) {
     uint32_t exit_off = 0;
     if (cur < (uint32_t)NPS_T) count += NPS_T - cur; else exit_off = cur - NPS_T;
     if (exit_off >= (uint32_t)NPS_K) { atomicOr(A.overflow, 4u); exit_off = 0; }
-    A.maps[(size_t)tile * NPS_K + t] = count | (exit_off << 16);
+    const bool same = (__ballot(exit_off == (uint32_t)__builtin_amdgcn_readfirstlane((int)exit_off)) & 0xffffull) == 0xffffull;
+    A.maps[(size_t)tile * NPS_K + t] = count | (exit_off << 16) | (same ? 0x80000000u : 0u);      // (NPS_MAP_CONST: see the scan)
     }
   }
   __syncthreads();
@@ -282,59 +284,132 @@ __global__ __launch_bounds__(NPS_THREADS) void k_nps_classify(NpsSegArgs A) {
 }
 
 // ---------------------------------------------------------------- scan (one workgroup)
-__global__ __launch_bounds__(NPS_THREADS) void k_nps_scan(NpsSegArgs A) {
-  __shared__ uint32_t s_cnt[NPS_THREADS][NPS_K];
-  __shared__ uint8_t s_exit[NPS_THREADS][NPS_K];
-  __shared__ uint8_t s_be[NPS_THREADS];
-  __shared__ uint64_t s_bb[NPS_THREADS];
+// Entry offset and first-normal index of every tile.  A tile almost never remembers how it was entered (the paths from the K
+// entry offsets merge at the first word that is a start on all of them), which the classifier records in bit 31 of its map: then
+// the entry of tile j is the exit of tile j - 1 whatever came before, every load is independent of every other, and the indices
+// are a prefix sum (the "fast" path: three rounds of memory latency).  If any tile's exit depends on its entry, or the segment is
+// longer than the LDS holds, the maps are composed in order instead: each thread walks a contiguous run of tiles for all K
+// entries at once, the runs are chained, and a second walk fills in the tiles (the "general" path: one latency per tile of a run,
+// twice).  Both are exact; NPS_SCAN_GENERAL in A.flags forces the second (tests).
+constexpr int NPS_SCAN_THREADS = 1024;
+constexpr int NPS_SCAN_CAP = 16384;                    // tiles of the fast path (134 M words: a full-size chunk has 12.9 k)
+constexpr uint32_t NPS_SCAN_GENERAL = 1u;
+constexpr uint32_t NPS_MAP_CONST = 0x80000000u;        // map bit: the tile's exit offset is the same for all K entries
+__device__ __forceinline__ uint32_t nps_map_exit(uint32_t m) { return (m >> 16) & 0xffu; }
+
+__global__ __launch_bounds__(NPS_SCAN_THREADS) void k_nps_scan(NpsSegArgs A) {
+  constexpr int GENERAL_BYTES = NPS_K * NPS_SCAN_THREADS * 5, FAST_BYTES = NPS_SCAN_CAP * 3;
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[GENERAL_BYTES > FAST_BYTES ? GENERAL_BYTES : FAST_BYTES];
   __shared__ int64_t s_end_tile;
   __shared__ uint32_t s_ev[NPS_EVCAP];
   __shared__ NpsLdsJump s_jump;
+  __shared__ uint32_t s_entry[NPS_SCAN_THREADS];
+  __shared__ unsigned long long s_base[NPS_SCAN_THREADS];
+  __shared__ int s_general;
   const int t = threadIdx.x;
   nps_load_jump(&s_jump, A.jump, A.inc);
-  const int64_t per = (A.ntiles + NPS_THREADS - 1) / NPS_THREADS;
-  const int64_t j0 = (int64_t)t * per, j1 = min(j0 + per, A.ntiles);
-  {
-    // sixteen independent chains (one per entry offset) through this thread's tiles: their loads overlap
-    uint32_t cur[NPS_K], cnt[NPS_K];
+  const int64_t per = (A.ntiles + NPS_SCAN_THREADS - 1) / NPS_SCAN_THREADS;
+  const int64_t j0 = min((int64_t)t * per, A.ntiles), j1 = min(j0 + per, A.ntiles);
+  const bool general0 = A.ntiles > NPS_SCAN_CAP || (A.flags & NPS_SCAN_GENERAL);       // (uniform)
+  if (t == 0) { s_end_tile = -1; s_general = general0 ? 1 : 0; }
+  __syncthreads();
+  if (!general0) {
+    uint8_t* s_x = s_raw;                                              // exit offset of tile j
+    uint16_t* s_c = reinterpret_cast<uint16_t*>(s_raw + NPS_SCAN_CAP);  // normals started in tile j
+    const int nt = (int)A.ntiles;
+    bool all_const = true;
+    for (int j = t; j < nt; j += 4 * NPS_SCAN_THREADS) {               // four independent loads in flight per lane
+      uint32_t m[4];
 #pragma unroll
-    for (int e = 0; e < NPS_K; ++e) { cur[e] = (uint32_t)e; cnt[e] = 0; }
-    for (int64_t j = j0; j < j1; ++j) {
-      const uint32_t* mj = A.maps + (size_t)j * NPS_K;
+      for (int u = 0; u < 4; ++u) { const int ju = j + u * NPS_SCAN_THREADS; m[u] = ju < nt ? A.maps[(size_t)ju * NPS_K] : NPS_MAP_CONST; }
 #pragma unroll
-      for (int e = 0; e < NPS_K; ++e) {
-        const uint32_t m = mj[cur[e]];
-        cnt[e] += m & 0xffffu;
-        cur[e] = m >> 16;
+      for (int u = 0; u < 4; ++u) {
+        const int ju = j + u * NPS_SCAN_THREADS;
+        if (ju < nt) s_x[ju] = (uint8_t)nps_map_exit(m[u]);
+        all_const = all_const && (m[u] & NPS_MAP_CONST);
       }
     }
+    if (!all_const) s_general = 1;
+    __syncthreads();
+  }
+  if (!s_general) {
+    uint8_t* s_x = s_raw;
+    uint16_t* s_c = reinterpret_cast<uint16_t*>(s_raw + NPS_SCAN_CAP);
+    const int nt = (int)A.ntiles;
+    for (int j = t; j < nt; j += 4 * NPS_SCAN_THREADS) {
+      uint32_t m[4];
 #pragma unroll
-    for (int e = 0; e < NPS_K; ++e) { s_cnt[t][e] = cnt[e]; s_exit[t][e] = (uint8_t)cur[e]; }
-  }
-  if (t == 0) s_end_tile = -1;
-  __syncthreads();
-  if (t == 0) {
-    uint32_t e = 0;
-    uint64_t base = 0;
-    for (int i = 0; i < NPS_THREADS; ++i) {
-      s_be[i] = (uint8_t)e; s_bb[i] = base;
-      base += s_cnt[i][e];
-      e = s_exit[i][e];
+      for (int u = 0; u < 4; ++u) {
+        const int ju = j + u * NPS_SCAN_THREADS;
+        m[u] = ju < nt ? A.maps[(size_t)ju * NPS_K + (ju ? s_x[ju - 1] : 0u)] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int ju = j + u * NPS_SCAN_THREADS; if (ju < nt) s_c[ju] = (uint16_t)(m[u] & 0xffffu); }
     }
-    if (base < A.n) atomicOr(A.overflow, 8u);          // the launch did not cover n normals
-  }
-  __syncthreads();
-  {
-    uint32_t cur = s_be[t];
-    uint64_t base = s_bb[t];
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int64_t j = j0; j < j1; ++j) mine += s_c[j];
+    // exclusive prefix over the 1024 threads (at most CAP * T = 2^27 normals: 32 bits)
+    uint32_t* s_wave = s_entry;                                         // (free on this path)
+    const uint32_t inc = nps_wave_scan(mine);
+    if ((t & 63) == 63) s_wave[t >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < NPS_SCAN_THREADS / 64; ++w) { const uint32_t v = s_wave[w]; if (w < (t >> 6)) before += v; total += v; }
+    if (t == 0 && total < A.n) atomicOr(A.overflow, 8u);                // the launch did not cover n normals
+    uint64_t base = before + inc - mine;
+    for (int64_t j = j0; j < j1; ++j) {
+      const uint64_t c = s_c[j];
+      A.tile_e[j] = j ? s_x[j - 1] : (uint8_t)0;
+      A.tile_base[j] = base;
+      if (base < A.n && A.n <= base + c) s_end_tile = j;               // the tile the n-th normal starts in (exactly one)
+      base += c;
+    }
+  } else {
+    // maps of contiguous runs of tiles, one per thread: normals started and exit offset for each of the K entry offsets
+    auto s_cnt = reinterpret_cast<uint32_t(*)[NPS_SCAN_THREADS]>(s_raw);                                    // [entry offset][run]
+    auto s_exit = reinterpret_cast<uint8_t(*)[NPS_SCAN_THREADS]>(s_raw + NPS_K * NPS_SCAN_THREADS * 4);
+    __syncthreads();
+    {
+      // sixteen independent chains (one per entry offset) through this thread's tiles: their loads overlap
+      uint32_t cur[NPS_K], cnt[NPS_K];
+#pragma unroll
+      for (int e = 0; e < NPS_K; ++e) { cur[e] = (uint32_t)e; cnt[e] = 0; }
+      for (int64_t j = j0; j < j1; ++j) {
+        const uint32_t* mj = A.maps + (size_t)j * NPS_K;
+#pragma unroll
+        for (int e = 0; e < NPS_K; ++e) {
+          const uint32_t m = mj[cur[e]];
+          cnt[e] += m & 0xffffu;
+          cur[e] = nps_map_exit(m);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < NPS_K; ++e) { s_cnt[e][t] = cnt[e]; s_exit[e][t] = (uint8_t)cur[e]; }
+    }
+    __syncthreads();
+    if (t == 0) {                          // chain the runs (1024 steps in the LDS)
+      uint32_t e = 0;
+      unsigned long long base = 0;
+      for (int r = 0; r < NPS_SCAN_THREADS; ++r) {
+        s_entry[r] = e;
+        base += s_cnt[e][r];
+        s_base[r] = base;
+        e = s_exit[e][r];
+      }
+      if (base < A.n) atomicOr(A.overflow, 8u);
+    }
+    __syncthreads();
+    uint32_t cur = s_entry[t];
+    uint64_t base = t ? s_base[t - 1] : 0ull;
     for (int64_t j = j0; j < j1; ++j) {
       const uint32_t m = A.maps[(size_t)j * NPS_K + cur];
       A.tile_e[j] = (uint8_t)cur;
       A.tile_base[j] = base;
       const uint64_t c = m & 0xffffu;
-      if (base < A.n && A.n <= base + c) s_end_tile = j;       // the tile the n-th normal starts in (exactly one)
+      if (base < A.n && A.n <= base + c) s_end_tile = j;
       base += c;
-      cur = m >> 16;
+      cur = nps_map_exit(m);
     }
   }
   __syncthreads();
@@ -345,7 +420,7 @@ __global__ __launch_bounds__(NPS_THREADS) void k_nps_scan(NpsSegArgs A) {
     return;
   }
   const uint32_t nev = A.evcount[je];
-  for (uint32_t k = t; k < nev; k += NPS_THREADS) {
+  for (uint32_t k = t; k < nev; k += NPS_SCAN_THREADS) {
     const NpsEvent e = A.events[(size_t)je * NPS_EVCAP + k];
     s_ev[k] = (e.pos & 0xffffu) | (e.f << 16);
   }

@@ -90,3 +90,26 @@ def test_numpy_mode_falls_back_to_host_draws_when_the_generator_is_not_pcg64(cap
     want_rng = np.random.Generator(np.random.Philox(5))
     assert np.isfinite(r).all() and r.size == g["r"].size
     sim.set_seed(1)
+
+
+def test_general_scan_path_gives_the_same_stream():
+    """The scan's in-order composition of the tile maps (taken when a tile's exit offset depends on its entry, or a segment is
+    longer than the LDS holds) is never reached by real streams: force it and compare with numpy again."""
+    import os, subprocess, sys
+    code = r'''
+import numpy as np
+from fast_amd import _lib, npnormal
+h = _lib.Handle(256, 40, "f64", 0)
+for seed, n in ((1, 1), (2, 5000), (4, 16385), (6, 1_048_576), (9, 3_000_001)):
+    rng = np.random.default_rng(seed)
+    sw = npnormal.state_words(rng.bit_generator)
+    want = rng.normal(0, 1, n)
+    got, after, consumed, ovf = h.npstream_normals(sw, n)
+    assert ovf == 0 and np.abs(got - want).max() < 8e-15, (seed, n, ovf)
+    assert (int(after[1]) << 64) | int(after[0]) == rng.bit_generator.state["state"]["state"]
+print("ok")
+'''
+    env = dict(os.environ, FASTMC_NPS_GENERAL_SCAN="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout.splitlines(), r.stdout + r.stderr

@@ -1218,7 +1218,11 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (1024, 82, 0, "k_rows_wave<double, 16, 2, 2, 1, 7>"), (1024, 120, 904, "k_rows_wave<double, 16, 2, 2, 1, 7>"),
             (1024, 200, None, "k_rows_wave<double, 16, 4, 2, 1, 7>"), (1024, 400, None, "k_rows_wave<double, 16, 8, 2, 1, 7>"),
             (2048, 82, None, "k_rows_wave<double, 16, 2, 2, 2, 4>"), (2048, 122, None, "k_rows_wave<double, 16, 2, 2, 2, 6>"),
-            (2048, 402, None, "k_rows_wave<double, 16, 8, 2, 2, 7>"), (4096, 82, None, "k_rows_wave<double, 16, 2, 2, 4, 4>")]
+            (2048, 402, None, "k_rows_wave<double, 16, 8, 2, 2, 7>"), (4096, 82, None, "k_rows_wave<double, 16, 2, 2, 4, 4>"),
+            # packed rows (eight / four / two rows per wavefront): centred six planes and all planes
+            (128, 82, None, "k_rows_pk<double, 0, 2, 0>"), (128, 128, None, "k_rows_pk<double, 0, 2, 1>"),
+            (256, 82, None, "k_rows_pk<double, 1, 2, 0>"), (256, 200, None, "k_rows_pk<double, 1, 2, 1>"), (256, 82, 100, "k_rows_pk<double, 1, 2, 1>"),
+            (512, 96, None, "k_rows_pk<double, 2, 2, 0>"), (512, 250, 7, "k_rows_pk<double, 2, 2, 1>")]
 
 
 @pytest.mark.parametrize("N,Np,lo,kernel", _FUSED64)

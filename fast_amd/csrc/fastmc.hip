@@ -1431,6 +1431,12 @@ struct RunSpec {
   // realisations [bs, bs + nb) of this run instead of the uploads of mode 1
   std::function<int(int64_t, int)> fill;
   const double* logamp_dev = nullptr;   // log-amplitudes already on the device, in output order, scaled
+  // ... or the whole run's coefficients already on the device (numpy stream, one-pass generator): [n_real][N^2] each, and the
+  // sub-harmonic inputs [n_real][27] each; batches read them in place
+  const double* coef_dev_re = nullptr;
+  const double* coef_dev_im = nullptr;
+  const double* sh_dev_re = nullptr;
+  const double* sh_dev_im = nullptr;
 };
 
 // Does this handle's row kernel draw the float64 generator itself (MODE 2)?  The P = 16 rows of the wave family: 1024, and
@@ -1458,7 +1464,8 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
   const bool gen64 = S.mode == 0 && h->rng_f64 && !fused64;
   const int kmode = fused64 ? 2 : ((S.mode == 1 || gen64) ? 1 : 0);           // MODE of the row kernels
   // host coefficients: 256 MB per upload; coefficients drawn on the device (S.fill): 2 GiB per array -- fewer, fuller launches
-  if (S.mode == 1) B = std::max(1, std::min<int>(B, (int)((S.fill ? 2048.0 : 256.0) * 1024 * 1024 / (N2 * 8.0))));
+  const bool devcoef = S.mode == 1 && S.coef_dev_re != nullptr;
+  if (S.mode == 1) B = std::max(1, std::min<int>(B, (int)(((S.fill || devcoef) ? 2048.0 : 256.0) * 1024 * 1024 / (N2 * 8.0))));
   if (gen64) B = std::max(1, std::min<int>(B, (int)(2048.0 * 1024 * 1024 / (N2 * 16.0))));
   if (S.epi == 1) B = std::max(1, std::min<int>(B, (int)(256.0 * 1024 * 1024 / (2.0 * Np * Np * 8.0))));
   B = (int)std::min<int64_t>(B, S.n_real);
@@ -1484,7 +1491,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     TRY(grow(&h->logamp, &h->logamp_cap, (size_t)S.n_real * 2));
     HIPCHK(hipMemcpyAsync(h->logamp, S.logamp, (size_t)S.n_real * 16, hipMemcpyHostToDevice, h->stream));
   }
-  if (kmode == 1 && h->coef_cap < (size_t)B) {
+  if (kmode == 1 && !devcoef && h->coef_cap < (size_t)B) {
     if (h->cre) HIPCHK(hipFree(h->cre));
     if (h->cim) HIPCHK(hipFree(h->cim));
     h->cre = h->cim = nullptr; h->coef_cap = 0;
@@ -1504,14 +1511,17 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     TRY(dev_alloc(&h->sh_in_im, (size_t)B * 27));
     h->sh_cap = B;
   }
-  if (sh && S.mode == 1 && !S.fill && (!S.sh_re || !S.sh_im)) return fail(FASTMC_EINVAL, "sub-harmonics are set: sh_re / sh_im required");
+  if (sh && devcoef && (!S.sh_dev_re || !S.sh_dev_im)) return fail(FASTMC_EINVAL, "sub-harmonics are set: sh_dev_re / sh_dev_im required");
+  if (sh && S.mode == 1 && !S.fill && !devcoef && (!S.sh_re || !S.sh_im)) return fail(FASTMC_EINVAL, "sub-harmonics are set: sh_re / sh_im required");
 
   RngKey key{(uint32_t)S.seed, (uint32_t)(S.seed >> 32)};
   timing_begin(h);
   int64_t fin_start = 0;
   for (int64_t bs = 0; bs < S.n_real; bs += B) {
     const int nb = (int)std::min<int64_t>(B, S.n_real - bs);
-    if (S.mode == 1 && S.fill) {
+    if (devcoef) {
+      // in place
+    } else if (S.mode == 1 && S.fill) {
       TRY(S.fill(bs, nb));
     } else if (S.mode == 1) {
       HIPCHK(hipMemcpyAsync(h->cre, S.coeff_re + (size_t)bs * N2, (size_t)nb * N2 * 8, hipMemcpyHostToDevice, h->stream));
@@ -1526,7 +1536,9 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       ShCoefArgs SA;
       SA.nb = nb; SA.key = key; SA.g0 = (uint64_t)(S.real0 + bs);
       SA.sh_re = SA.sh_im = nullptr;
-      if (S.mode == 1 && S.fill) {
+      if (devcoef) {
+        SA.sh_re = S.sh_dev_re + (size_t)bs * 27; SA.sh_im = S.sh_dev_im + (size_t)bs * 27;
+      } else if (S.mode == 1 && S.fill) {
         SA.sh_re = h->sh_in_re; SA.sh_im = h->sh_in_im;          // filled on the device by S.fill
       } else if (S.mode == 1) {
         HIPCHK(hipMemcpyAsync(h->sh_in_re, S.sh_re + (size_t)bs * 27, (size_t)nb * 27 * 8, hipMemcpyHostToDevice, h->stream));
@@ -1543,7 +1555,9 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     RA.N = N; RA.Np = Np; RA.lo = h->lo; RA.nb = nb;
     RA.om = (const cpx<R>*)h->om; RA.omS = h->omS;
     RA.V = (cpx<R>*)h->V; RA.key = key; RA.g0 = (uint64_t)(S.real0 + bs);
-    RA.cre = h->cre; RA.cim = h->cim; RA.g64 = h->g64;
+    RA.cre = devcoef ? S.coef_dev_re + (size_t)bs * N2 : h->cre;
+    RA.cim = devcoef ? S.coef_dev_im + (size_t)bs * N2 : h->cim;
+    RA.g64 = h->g64;
     ColArgs<R> CA;
     CA.N = N; CA.Np = Np; CA.lo = h->lo; CA.nb = nb;
     CA.V = (const cpx<R>*)h->V; CA.om = RA.om; CA.omS = h->omS;
@@ -1833,7 +1847,17 @@ struct NpsSegBuf {           // what classify / scan leave behind for emit, one 
   u128* tile_state = nullptr;
   int64_t cap_tiles = 0;
 };
+struct NpsOneBuf {           // the one-pass generator's buffers for one segment: its normals and the look-back words
+  double* out = nullptr;
+  size_t cap_out = 0;
+  uint32_t* xexit = nullptr;
+  unsigned long long* agg = nullptr;
+  u128* tile_state = nullptr;
+  uint32_t* ticket = nullptr;
+  int64_t cap_tiles = 0;
+};
 struct NpsWork {
+  NpsOneBuf one[4];          // like seg[]
   NpsSegBuf seg[4];          // [2 * set + k]: two sets (chunks alternate), k = 0 the coefficients of a chunk, 1 its sub-harmonic draws
   hipStream_t gstream = nullptr;       // the generator chain (tile states, classify, scan) of chunk c + 1 runs here beside the
   hipEvent_t ev_gen[2] = {nullptr, nullptr};   //   emit + Monte-Carlo kernels of chunk c on the handle's stream
@@ -1849,6 +1873,8 @@ static void nps_free(NpsWork* w) {
   if (w->gstream) hipStreamSynchronize(w->gstream);
   for (NpsSegBuf& b : w->seg)
     for (void* p : {(void*)b.events, (void*)b.evcount, (void*)b.maps, (void*)b.tile_e, (void*)b.tile_base, (void*)b.tile_state}) if (p) hipFree(p);
+  for (NpsOneBuf& b : w->one)
+    for (void* p : {(void*)b.out, (void*)b.xexit, (void*)b.agg, (void*)b.tile_state, (void*)b.ticket}) if (p) hipFree(p);
   for (void* p : {(void*)w->states, (void*)w->consumed, (void*)w->overflow, (void*)w->la}) if (p) hipFree(p);
   for (int i = 0; i < 2; ++i) { if (w->ev_gen[i]) hipEventDestroy(w->ev_gen[i]); if (w->ev_used[i]) hipEventDestroy(w->ev_used[i]); }
   if (w->gstream) hipStreamDestroy(w->gstream);
@@ -1888,10 +1914,14 @@ extern "C" int fastmc_npstream_set_tables(int device_id, const double* wi, const
   return 0;
 }
 
-static int64_t nps_tiles_for(uint64_t n) {       // upper bound of the words n normals consume (mean 1.0222 per normal), in tiles
+static int64_t nps_tiles_for(uint64_t n, int tile_words = NPS_T) {       // upper bound of the words n normals consume (mean 1.0222 per normal), in tiles
   const uint64_t words = n + n / 32 + 2 * (uint64_t)NPS_T;
-  return (int64_t)((words + NPS_T - 1) / NPS_T);
+  return (int64_t)((words + tile_words - 1) / tile_words);
 }
+#ifndef FMC_NPS1_NSUB
+#define FMC_NPS1_NSUB 2
+#endif
+constexpr int NPS1_NSUB = FMC_NPS1_NSUB;          // the one-pass generator's tile: NSUB * 2048 words
 static int nps_seg_reserve(NpsSegBuf& b, int64_t tiles) {
   if (b.cap_tiles >= tiles) return 0;
   for (void* p : {(void*)b.events, (void*)b.evcount, (void*)b.maps, (void*)b.tile_e, (void*)b.tile_base, (void*)b.tile_state}) if (p) hipFree(p);
@@ -1930,6 +1960,44 @@ static int nps_segment(fastmc_ctx* h, NpsSegArgs& A, NpsSegBuf& b, size_t k, u12
   hipLaunchKernelGGL(k_nps_tilestates, dim3((unsigned)((tiles + NPS_THREADS - 1) / NPS_THREADS)), dim3(NPS_THREADS), 0, stream, A);
   hipLaunchKernelGGL(k_nps_classify, dim3((unsigned)tiles), dim3(NPS_THREADS), 0, stream, A);
   hipLaunchKernelGGL(k_nps_scan, dim3(1), dim3(NPS_SCAN_THREADS), 0, stream, A);
+  return 0;
+}
+// The one-pass form (fmc_npstream.h: k_nps_onepass) when the segment's normals fit a device buffer of their own: every word is
+// generated once.  FASTMC_NPS_ONEPASS_MAX_GB (default 16) bounds that buffer; FASTMC_NPS_THREEPASS=1 forces the three-pass form (tests).
+static bool nps_use_onepass(uint64_t n) {
+  static const bool three = [] { const char* e = getenv("FASTMC_NPS_THREEPASS"); return e && *e == '1'; }();
+  static const double max_gb = [] { const char* e = getenv("FASTMC_NPS_ONEPASS_MAX_GB"); return e ? atof(e) : 16.0; }();
+  return !three && (double)n * 8.0 <= max_gb * 1073741824.0;
+}
+// segment k of the call, n normals from states[k], written to b.out[0 ... n); leaves states[k + 1]
+static int nps_onepass(fastmc_ctx* h, NpsOneBuf& b, size_t k, u128 inc, uint64_t n, hipStream_t stream = nullptr) {
+  if (!stream) stream = h->stream;
+  NpsWork* w = h->nps;
+  const auto& dev = g_nps_dev[h->device];
+  const int64_t tiles = nps_tiles_for(n, NPS1_NSUB * NPS_SUB);
+  if (b.cap_tiles < tiles) {
+    for (void* p : {(void*)b.xexit, (void*)b.agg, (void*)b.tile_state}) if (p) hipFree(p);
+    b.xexit = nullptr; b.agg = nullptr; b.tile_state = nullptr; b.cap_tiles = 0;
+    HIPCHK(hipMalloc((void**)&b.xexit, (size_t)tiles * 4));
+    HIPCHK(hipMalloc((void**)&b.agg, (size_t)tiles * 8));
+    HIPCHK(hipMalloc((void**)&b.tile_state, (size_t)tiles * sizeof(u128)));
+    if (!b.ticket) HIPCHK(hipMalloc((void**)&b.ticket, 4));
+    b.cap_tiles = tiles;
+  }
+  if (b.cap_out < n) {
+    if (b.out) HIPCHK(hipFree(b.out));
+    b.out = nullptr; b.cap_out = 0;
+    HIPCHK(hipMalloc((void**)&b.out, (size_t)n * 8));
+    b.cap_out = n;
+  }
+  NpsSegArgs A{};
+  A.state = w->states + k; A.inc = inc; A.n = n; A.ntiles = tiles; A.tab = dev.first; A.jump = dev.second;
+  A.tile_state = b.tile_state;
+  A.state_out = w->states + k + 1; A.consumed = w->consumed + k; A.overflow = w->overflow + k;
+  NpsOneArgs O;
+  O.out = b.out; O.xexit = b.xexit; O.agg = b.agg; O.ticket = b.ticket;
+  hipLaunchKernelGGL(k_nps_tilestates1<NPS1_NSUB>, dim3((unsigned)((tiles + NPS_THREADS - 1) / NPS_THREADS)), dim3(NPS_THREADS), 0, stream, A, O);
+  hipLaunchKernelGGL(k_nps_onepass<NPS1_NSUB>, dim3((unsigned)tiles), dim3(NPS_THREADS), 0, stream, A, O);
   return 0;
 }
 // normals [lo, hi) of a classified segment -> out[0 ... hi - lo); optionally a second range of the same segment in the same launch
@@ -1977,13 +2045,19 @@ extern "C" int fastmc_npstream_normals(fastmc_t* h, const uint64_t state_inc[4],
   HIPCHK(hipSetDevice(h->device));
   u128 inc;
   TRY(nps_prepare(h, state_inc, 2, &inc));
-  NpsSegArgs A;
-  TRY(nps_segment(h, A, h->nps->seg[0], 0, inc, (uint64_t)n));
   ScratchBuf d;
-  if (out) {
-    HIPCHK(hipMalloc((void**)&d.p, (size_t)n * 8));
-    nps_emit(h, A, 0, (uint64_t)n, d.p);
-    HIPCHK(hipMemcpyAsync(out, d.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+  if (nps_use_onepass((uint64_t)n)) {
+    NpsOneBuf& b = h->nps->one[0];
+    TRY(nps_onepass(h, b, 0, inc, (uint64_t)n));
+    if (out) HIPCHK(hipMemcpyAsync(out, b.out, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+  } else {
+    NpsSegArgs A;
+    TRY(nps_segment(h, A, h->nps->seg[0], 0, inc, (uint64_t)n));
+    if (out) {
+      HIPCHK(hipMalloc((void**)&d.p, (size_t)n * 8));
+      nps_emit(h, A, 0, (uint64_t)n, d.p);
+      HIPCHK(hipMemcpyAsync(out, d.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    }
   }
   u128 st;
   uint64_t cons = 0;
@@ -1993,6 +2067,14 @@ extern "C" int fastmc_npstream_normals(fastmc_t* h, const uint64_t state_inc[4],
   HIPCHK(hipMemcpyAsync(&ovf, h->nps->overflow, 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
+#ifdef NPS1_EXP_TIMES
+  if (const char* path = getenv("FASTMC_NPS_DUMP")) {
+    const int64_t tiles = nps_tiles_for((uint64_t)n, NPS1_NSUB * NPS_SUB);
+    std::vector<u128> rec((size_t)tiles);
+    hipMemcpy(rec.data(), h->nps->one[0].tile_state, rec.size() * sizeof(u128), hipMemcpyDeviceToHost);
+    if (FILE* f = fopen(path, "wb")) { fwrite(rec.data(), sizeof(u128), rec.size(), f); fclose(f); }
+  }
+#endif
   if (state_after) { state_after[0] = (uint64_t)st; state_after[1] = (uint64_t)(st >> 64); }
   if (consumed) *consumed = cons;
   if (overflow) *overflow = ovf;
@@ -2017,9 +2099,14 @@ extern "C" int fastmc_npstream_logamp(fastmc_t* h, const uint64_t state_inc[4], 
   TRY(nps_prepare(h, state_inc, 2, &inc));
   NpsWork* w = h->nps;
   TRY(grow(&w->la, &w->la_cap, (size_t)n_iter));
-  NpsSegArgs A;
-  TRY(nps_segment(h, A, w->seg[0], 0, inc, (uint64_t)(2 * n_iter)));
-  nps_emit(h, A, 0, (uint64_t)n_iter, w->la);
+  if (nps_use_onepass((uint64_t)(2 * n_iter))) {
+    TRY(nps_onepass(h, w->one[0], 0, inc, (uint64_t)(2 * n_iter)));
+    HIPCHK(hipMemcpyAsync(w->la, w->one[0].out, (size_t)n_iter * 8, hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    NpsSegArgs A;
+    TRY(nps_segment(h, A, w->seg[0], 0, inc, (uint64_t)(2 * n_iter)));
+    nps_emit(h, A, 0, (uint64_t)n_iter, w->la);
+  }
   hipLaunchKernelGGL(k_nps_scale, dim3((unsigned)((n_iter + 255) / 256)), dim3(256), 0, h->stream, w->la, n_iter, std::sqrt(logamp_var));
   u128 st;
   uint32_t ovf = 0;
@@ -2073,9 +2160,16 @@ extern "C" int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int
   hipEventDestroy(ev0);
   const uint64_t nc = (uint64_t)chunk_real * N2, ns = (uint64_t)chunk_real * 27;
   std::vector<NpsSegArgs> AA((size_t)n_chunks * 2);
+  const bool onepass = nps_use_onepass(2 * nc);
   auto gen_chunk = [&](int64_t c) -> int {
     const int set = (int)(c & 1);
     if (c >= 2) HIPCHK(hipStreamWaitEvent(w->gstream, w->ev_used[set], 0));      // chunk c - 2 has read this set
+    if (onepass) {
+      TRY(nps_onepass(h, w->one[2 * set], (size_t)c * segs, inc, 2 * nc, w->gstream));
+      if (sh) TRY(nps_onepass(h, w->one[2 * set + 1], (size_t)c * segs + 1, inc, 2 * ns, w->gstream));
+      HIPCHK(hipEventRecord(w->ev_gen[set], w->gstream));
+      return 0;
+    }
     TRY(nps_segment(h, AA[2 * c], w->seg[2 * set], (size_t)c * segs, inc, 2 * nc, w->gstream));      // real parts of the chunk, then its imaginary parts
     if (sh) TRY(nps_segment(h, AA[2 * c + 1], w->seg[2 * set + 1], (size_t)c * segs + 1, inc, 2 * ns, w->gstream));
     HIPCHK(hipEventRecord(w->ev_gen[set], w->gstream));
@@ -2090,7 +2184,10 @@ extern "C" int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int
     RunSpec S{1, 0, 0, 0, chunk_real, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, coherent, nullptr, nullptr};
     S.async = true;
     S.logamp_dev = w->la + logamp_offset + (size_t)c * 2 * chunk_real;
-    S.fill = [&, A, h, sh, N2, nc, ns](int64_t bs, int nb) -> int {
+    if (onepass) {
+      S.coef_dev_re = w->one[2 * set].out; S.coef_dev_im = w->one[2 * set].out + nc;
+      if (sh) { S.sh_dev_re = w->one[2 * set + 1].out; S.sh_dev_im = w->one[2 * set + 1].out + ns; }
+    } else S.fill = [&, A, h, sh, N2, nc, ns](int64_t bs, int nb) -> int {
       nps_emit2(h, A[0], nps_range(A[0], (uint64_t)bs * N2, (uint64_t)(bs + nb) * N2, h->cre),
                 nps_range(A[0], nc + (uint64_t)bs * N2, nc + (uint64_t)(bs + nb) * N2, h->cim));
       if (sh)

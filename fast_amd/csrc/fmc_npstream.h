@@ -5,10 +5,11 @@
 // (fast.py:123, 639-645).  "Identical RNG seeds" therefore means reproducing that stream: PCG64 (128-bit LCG, XSL-RR output)
 // feeding numpy's 256-layer ziggurat, in which a normal consumes ONE 64-bit word 97.8 % of the time and two or more otherwise
 // (wedge test, tail loop, restarts) -- so the word a normal starts at depends on every earlier rejection.  Round 3 drew this
-// stream on the host (114 iterations/s end to end).  Here it is drawn on the device in three passes per array of n normals
-// (a "segment": the real parts of a chunk, its imaginary parts, the log-amplitudes ...), all enqueued without a host round trip:
+// stream on the host (114 iterations/s end to end).  Here it is drawn on the device, per array of n normals (a "segment": the
+// real parts of a chunk followed by its imaginary parts, the log-amplitudes ...), all enqueued without a host round trip.
+// The three-pass form, for segments of any length:
 //
-//   classify  one workgroup per TILE of T = 16384 consecutive words.  A PCG64 state can be advanced by any distance in
+//   classify  one workgroup per TILE of T = 8192 consecutive words.  A PCG64 state can be advanced by any distance in
 //             O(log) 128-bit multiply-adds, so every thread jumps to its own 8-word pieces and treats EVERY word as if a
 //             normal started there: fast (one word) or slow -- then it runs numpy's slow path to the end on a private copy of
 //             the generator and records an EVENT (position, words consumed f, value).  Events come out in position order
@@ -17,12 +18,16 @@
 //             spilled over) the number of normals that start in the tile and the offset handed to the next tile -- and, per
 //             event, for which entry offsets it is a start.  (The slow path diverges: the words of a sub-tile that need it
 //             are queued and evaluated one per lane.)
-//   scan      one workgroup composes the maps of all tiles (two-level scan of functions on K values): every tile's true
-//             entry offset and the index of its first normal; the word after the n-th normal = the words this array consumed,
-//             and the generator state there (one more jump) for the next segment.
+//   scan      one workgroup: every tile's true entry offset and the index of its first normal (see k_nps_scan); the word
+//             after the n-th normal = the words this array consumed, and the generator state there (one more jump) for the
+//             next segment.
 //   emit      per tile, with its entry offset known: the words once more, the skipped ones masked (inside a slow normal's
 //             span), a prefix sum for the output index, value = rabs * wi[idx] (or the event's) -> out[], in the order numpy
 //             writes them.
+//
+// and the ONE-PASS form (k_nps_onepass, at the end of this file) when the segment's normals fit a device buffer of their own:
+// the same classification, but each tile keeps its values in registers, learns its entry offset and first index from its
+// predecessors while they still run (decoupled look-back) and writes its normals itself -- every word generated once.
 // A spill beyond K words, more events than a tile holds, or a stream longer than the launch allowed for raises an OVERFLOW flag
 // and the caller redoes that chunk with numpy's own draws (never observed: K = 16 is ~8 consecutive rejections).
 // The ziggurat tables are not in this source: fast_amd/npnormal.py reads them out of the numpy that is installed through a
@@ -314,8 +319,7 @@ __global__ __launch_bounds__(NPS_SCAN_THREADS) void k_nps_scan(NpsSegArgs A) {
   if (t == 0) { s_end_tile = -1; s_general = general0 ? 1 : 0; }
   __syncthreads();
   if (!general0) {
-    uint8_t* s_x = s_raw;                                              // exit offset of tile j
-    uint16_t* s_c = reinterpret_cast<uint16_t*>(s_raw + NPS_SCAN_CAP);  // normals started in tile j
+    uint8_t* s_x = s_raw;                                              // exit offset of tile j (then, after it: normals started in tile j)
     const int nt = (int)A.ntiles;
     bool all_const = true;
     for (int j = t; j < nt; j += 4 * NPS_SCAN_THREADS) {               // four independent loads in flight per lane
@@ -538,6 +542,370 @@ __global__ __launch_bounds__(NPS_THREADS) void k_nps_emit(NpsSegArgs A, NpsEmitR
       nev_before += tot_slow;
       rank0 += tot_start;
     }
+  }
+}
+
+
+// ---------------------------------------------------------------- one pass: classify, chain and write a segment in ONE kernel
+// The three passes above generate every word twice (classify, emit: ~0.4 ms each per 2 x 10^8 words, the price of 128-bit LCG steps
+// at quarter rate).  When the whole segment fits a device buffer the words are generated ONCE: a workgroup keeps its tile's fast
+// values in registers (32 per lane), classifies as above, learns its entry offset and the index of its first normal from its
+// predecessors while they are still running (a decoupled look-back, Merrill & Garland 2016), and writes its normals.
+//   * tiles are handed out by a ticket in dispatch order, so a workgroup only ever waits for workgroups that already run;
+//   * entry offset: a tile whose exit offset is the same for all K entries (NPS_MAP_CONST: virtually all) publishes it straight
+//     after its map; a tile that does depend on its entry waits for its predecessor's first -- a chain only through such tiles;
+//   * index: with the entry known the tile's count is a number, and the index of its first normal a plain prefix sum:
+//     status << 62 | value per tile in one 64-bit word (1: the tile's count, 2: the sum up to and including the tile), looked
+//     back over 64 predecessors per step by the first wave.
+// Same overflow flags as the three-pass form, same results bit for bit (tests run both).
+struct NpsOneArgs {
+  double* out;                    // [n] the segment's normals
+  uint32_t* xexit;                // [ntiles] bit 31: published; low byte: the tile's exit offset on the stream's path
+  unsigned long long* agg;        // [ntiles] status << 62 | normals
+  uint32_t* ticket;
+};
+constexpr unsigned long long NPS_AGG_MASK = (1ull << 62) - 1ull;
+
+// tile states, and the look-back words cleared (one thread per tile)
+template <int NSUB>
+__global__ __launch_bounds__(NPS_THREADS) void k_nps_tilestates1(NpsSegArgs A, NpsOneArgs O) {
+  constexpr int TW = NSUB * NPS_SUB;
+  __shared__ NpsLdsJump s_jump;
+  nps_load_jump(&s_jump, A.jump, A.inc);
+  __syncthreads();
+  const int64_t tile = (int64_t)blockIdx.x * NPS_THREADS + threadIdx.x;
+  if (tile == 0) *O.ticket = 0u;
+  if (tile < A.ntiles) {
+    A.tile_state[tile] = nps_advance_lds(*A.state, (uint64_t)tile * TW, &s_jump);
+    O.xexit[tile] = 0u;
+    O.agg[tile] = 0ull;
+  }
+}
+
+__device__ __forceinline__ unsigned long long nps_wave_sum64(unsigned long long v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// Five workgroups per CU (96 registers -- five values spill -- and 30 KB of LDS): between generating its words and writing
+// them a tile mostly WAITS (its predecessors' words, 1 - 2 us per round trip through memory), and only other tiles fill the VALU.
+#ifndef NPS1_WAVES
+#define NPS1_WAVES 5
+#endif
+#if NPS1_WAVES
+#define NPS1_OCC __attribute__((amdgpu_waves_per_eu(NPS1_WAVES, NPS1_WAVES)))
+#else
+#define NPS1_OCC
+#endif
+#ifndef NPS1_QCAP
+#define NPS1_QCAP 192
+#endif
+template <int NSUB>      // tile = NSUB sub-tiles of 2048 words: 8 values per lane and sub-tile stay in registers
+__global__ __launch_bounds__(NPS_THREADS) NPS1_OCC void k_nps_onepass(NpsSegArgs A, NpsOneArgs O) {
+  static_assert(NSUB % 2 == 0 && NPS_WPT == 8, "passes of two sub-tiles; eight start bits of a lane lie in one skip word");
+  constexpr int TW = NSUB * NPS_SUB, EVCAP1 = TW / 16;
+  constexpr int QCAP = NPS1_QCAP;                   // slow words of TWO sub-tiles (expected 90, sigma 9.4)
+  __shared__ double s_wi[256];
+  __shared__ uint64_t s_ki[256];
+  __shared__ double s_fi[256];
+  __shared__ uint32_t s_ev[EVCAP1];          // pos | f << 16, in position order
+  __shared__ uint32_t s_mask[EVCAP1];        // bit e: a START on the path that enters at offset e
+  __shared__ double s_evv[EVCAP1];           // the slow normal's value
+  // the slow-word queue (while classifying) and the output staging (while writing) share their bytes
+  constexpr int Q_BYTES = QCAP * (int)sizeof(NpsQueued), QIDX_BYTES = 2 * NPS_SUB * 2, OUT_BYTES = NPS_SUB * 8;
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[(Q_BYTES + QIDX_BYTES) > OUT_BYTES ? (Q_BYTES + QIDX_BYTES) : OUT_BYTES];
+  NpsQueued* s_q = reinterpret_cast<NpsQueued*>(s_raw);
+  uint16_t* s_qidx = reinterpret_cast<uint16_t*>(s_raw + Q_BYTES);        // [2][NPS_SUB]
+  double* s_out = reinterpret_cast<double*>(s_raw);
+  __shared__ uint32_t s_skip[TW / 32];
+  __shared__ uint32_t s_wave[4];
+  __shared__ NpsLdsJump s_jump;
+  __shared__ uint32_t s_qn[2];
+  __shared__ uint32_t s_tile, s_ein, s_cnt;
+  __shared__ unsigned long long s_base;
+  const int t = threadIdx.x;
+  if (t == 0) { s_tile = atomicAdd(O.ticket, 1u); s_qn[0] = s_qn[1] = 0; }
+  s_wi[t] = A.tab->wi[t]; s_ki[t] = A.tab->ki[t]; s_fi[t] = A.tab->fi[t];
+  nps_load_jump(&s_jump, A.jump, A.inc);
+  __syncthreads();
+  const int64_t tile = s_tile;
+  u128 piece = nps_advance_lds(A.tile_state[tile], (uint64_t)t * NPS_WPT, &s_jump);
+  const u128 a_sub = s_jump.a[11], c_sub = s_jump.cinc[11];
+  static_assert(NPS_SUB == 2048, "the sub-tile stride is the 2^11 entry of the jump table");
+#ifdef NPS1_EXP_TIMES
+  const uint64_t T0 = wall_clock64();
+  uint64_t T1 = 0, T2 = 0, T3 = 0;
+  __shared__ uint64_t s_t1w;
+#endif
+
+  // ---- the words, once: fast values kept, slow words evaluated through the queue (two sub-tiles per pass: two chains per lane)
+  double val[NSUB][NPS_WPT];
+  uint32_t slowmask[NSUB];
+  uint32_t nev = 0;
+#pragma unroll
+  for (int pass = 0; pass < NSUB / 2; ++pass) {
+    u128 sc[2];
+    sc[0] = piece;
+    sc[1] = a_sub * piece + c_sub;
+    piece = a_sub * sc[1] + c_sub;
+    slowmask[2 * pass] = slowmask[2 * pass + 1] = 0;
+#pragma unroll
+    for (int i = 0; i < NPS_WPT; ++i) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint64_t r = nps_next(sc[c], A.inc);
+        const int idx = (int)(r & 0xff);
+        const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
+        const double x = __dmul_rn((double)rabs, s_wi[idx]);
+        val[2 * pass + c][i] = ((r >> 8) & 1) ? -x : x;
+        asm volatile("" : "+v"(val[2 * pass + c][i]));      // the VALUE stays (else the compiler keeps what it is made of: 255 registers)
+        if (rabs >= s_ki[idx]) {
+          slowmask[2 * pass + c] |= 1u << i;
+          const uint32_t q = atomicAdd(&s_qn[pass & 1], 1u);
+          if (q < (uint32_t)QCAP) {
+            s_q[q].s = sc[c]; s_q[q].r = r; s_q[q].pos = (uint32_t)((2 * pass + c) * NPS_SUB + t * NPS_WPT + i);
+            s_qidx[c * NPS_SUB + t * NPS_WPT + i] = (uint16_t)q;
+          }
+        }
+      }
+    }
+    const uint32_t na = __popc(slowmask[2 * pass]), nb = __popc(slowmask[2 * pass + 1]);
+    uint32_t tot;
+    const uint32_t ex = nps_block_scan(na | (nb << 16), s_wave, tot);         // (its barriers also publish the queue)
+    const uint32_t tot_a = tot & 0xffffu, tot_b = tot >> 16;
+    const uint32_t qn = min(s_qn[pass & 1], (uint32_t)QCAP);
+    if (t == 0) {
+      if (s_qn[pass & 1] > (uint32_t)QCAP) atomicOr(A.overflow, 2u);
+      s_qn[(pass + 1) & 1] = 0;
+    }
+    if ((uint32_t)t < qn) {
+      uint32_t f;
+      s_q[t].v = nps_slow(s_q[t].r, s_q[t].s, A.inc, s_wi, s_ki, s_fi, f);
+      s_q[t].f = f;
+      if (f >= 0xffffu) atomicOr(A.overflow, 1u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      uint32_t slot = nev + (c ? tot_a + (ex >> 16) : (ex & 0xffffu));
+#pragma unroll
+      for (int i = 0; i < NPS_WPT; ++i)
+        if ((slowmask[2 * pass + c] >> i) & 1u) {
+          const uint32_t q = s_qidx[c * NPS_SUB + t * NPS_WPT + i];
+          if (slot < (uint32_t)EVCAP1 && q < (uint32_t)QCAP) {
+            s_ev[slot] = s_q[q].pos | (s_q[q].f << 16);
+            s_evv[slot] = s_q[q].v;
+          }
+          ++slot;
+        }
+    }
+    nev += tot_a + tot_b;
+    __syncthreads();
+  }
+  if (nev > EVCAP1) { if (t == 0) atomicOr(A.overflow, 2u); nev = EVCAP1; }
+
+  // ---- first wave: the tile's transfer map, then its place in the stream from its predecessors
+  if (t < 64) {
+#ifdef NPS1_EXP_TIMES
+    T1 = wall_clock64();
+#endif
+    // Lane e walks the events from entry offset e (lanes 16 ... 63 repeat lane 15) until the K paths have merged -- at the first
+    // word that is a start on all of them, within an event or two.  From there the walk is ONE path, and no longer serial: an
+    // event at p is a start unless the last start's span reaches beyond p, which the running maximum M of ALL earlier spans
+    // decides for nearly every event at once (M <= p: a start whatever came before); the few with M > p (a slow word within a
+    // slow normal's span: 2 %) are settled in order on the scalar unit.  (A serial walk costs ~20 dependent instructions per
+    // event on a lone wave: 13 us per tile, as long as generating it.)
+    uint32_t cur = (uint32_t)min(t, NPS_K - 1), count = 0;
+    uint32_t km = 0;
+    bool merged = false;
+    for (; km < nev && !merged; ++km) {
+      const uint32_t pf = s_ev[km], p = pf & 0xffffu, f = pf >> 16;
+      const bool on = p >= cur;
+      const uint64_t b = __ballot(on);
+      if (t == 0) s_mask[km] = (uint32_t)(b & ((1u << NPS_K) - 1u));
+      if (on) { count += p - cur + 1; cur = p + f; }
+      merged = __ballot(cur == (uint32_t)__builtin_amdgcn_readfirstlane((int)cur)) == ~0ull;
+    }
+    if (merged) {
+      const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+      uint32_t R = cur0;              // where the path stands: the end of the last start's span
+      uint32_t skipped = 0;           // words of the tile inside the spans of the starts (not the starts themselves)
+      for (uint32_t k0 = km; k0 < nev; k0 += 64) {
+        const uint32_t k = k0 + t;
+        const bool valid = k < nev;
+        const uint32_t pf = valid ? s_ev[k] : 0xffffffffu, p = pf & 0xffffu, reach = p + (pf >> 16);
+        uint32_t incl = reach;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+          if (t >= d) incl = max(incl, o);
+        }
+        uint32_t M = (uint32_t)__shfl_up((int)incl, 1, 64);
+        M = t ? max(M, R) : R;
+        uint64_t onm = __ballot(valid && M <= p), amb = __ballot(valid && M > p);
+        while (amb) {
+          const int ka = __builtin_ctzll(amb);
+          amb &= amb - 1;
+          const uint64_t below = onm & ((1ull << ka) - 1ull);
+          const uint32_t Rk = below ? (uint32_t)__builtin_amdgcn_readlane((int)reach, 63 - __builtin_clzll(below)) : R;
+          if (Rk <= (uint32_t)__builtin_amdgcn_readlane((int)p, ka)) onm |= 1ull << ka;
+        }
+        const bool on = (onm >> t) & 1ull;
+        if (valid) s_mask[k] = on ? ((1u << NPS_K) - 1u) : 0u;
+        uint32_t sk = on ? min(reach, (uint32_t)TW) - p - 1u : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sk += (uint32_t)__shfl_xor((int)sk, d, 64);
+        skipped += sk;
+        if (onm) R = (uint32_t)__builtin_amdgcn_readlane((int)reach, 63 - __builtin_clzll(onm));
+      }
+      if (cur0 < (uint32_t)TW) count += (uint32_t)TW - cur0 - skipped;
+      cur = max(R, (uint32_t)TW);       // (every word up to the end of the tile accounted for)
+    }
+    uint32_t exit_off = 0;
+    if (cur < (uint32_t)TW) count += TW - cur; else exit_off = cur - TW;
+    if (exit_off >= (uint32_t)NPS_K) { atomicOr(A.overflow, 4u); exit_off = 0; }
+#if defined(NPS1_EXP_TIMES) && NPS1_EXP_TIMES == 2
+    if (t == 0) s_t1w = wall_clock64();
+#endif
+    const bool same = __ballot(exit_off == (uint32_t)__builtin_amdgcn_readfirstlane((int)exit_off)) == ~0ull;
+    uint32_t e_in = 0;
+#ifdef NPS1_EXP_NOWAIT
+    if (false) {
+#else
+    if (tile > 0) {
+#endif
+      if (same && t == 0) __hip_atomic_store(&O.xexit[tile], 0x80000000u | exit_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t x;
+      for (;;) {
+        x = __hip_atomic_load(&O.xexit[tile - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+        if (x >> 31) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      e_in = x & 0xffu;
+    }
+#ifdef NPS1_EXP_TIMES
+    T2 = wall_clock64();
+#endif
+    const uint32_t c_here = (uint32_t)__shfl((int)count, (int)e_in, 64);
+    const uint32_t x_here = (uint32_t)__shfl((int)exit_off, (int)e_in, 64);
+    if ((tile == 0 || !same) && t == 0) __hip_atomic_store(&O.xexit[tile], 0x80000000u | x_here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long base = 0;
+#ifdef NPS1_EXP_NOWAIT
+    base = (unsigned long long)tile * 8000ull;
+    if (false) {
+#else
+    if (tile > 0) {
+#endif
+      if (t == 0) __hip_atomic_store(&O.agg[tile], (1ull << 62) | c_here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t p = tile - 1;
+      for (;;) {
+        const int64_t idx = p - t;
+        const unsigned long long v = idx >= 0 ? __hip_atomic_load(&O.agg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+        const uint32_t st = (uint32_t)(v >> 62);
+        const uint64_t pm = __ballot(st == 2u), zm = __ballot(st == 0u);
+        if (pm) {
+          const int first = __builtin_ctzll(pm);                                   // the nearest predecessor that knows its prefix
+          const uint64_t upto = first == 63 ? ~0ull : ((1ull << (first + 1)) - 1ull);
+          if (zm & upto) { __builtin_amdgcn_s_sleep(2); continue; }
+          base += nps_wave_sum64(t <= first ? (v & NPS_AGG_MASK) : 0ull);
+          break;
+        }
+        if (zm) { __builtin_amdgcn_s_sleep(2); continue; }
+        base += nps_wave_sum64(v & NPS_AGG_MASK);
+        p -= 64;
+      }
+    }
+    if (t == 0) {
+      __hip_atomic_store(&O.agg[tile], (2ull << 62) | (base + c_here), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_ein = e_in; s_cnt = c_here; s_base = base;
+    }
+#ifdef NPS1_EXP_TIMES
+    T3 = wall_clock64();
+#endif
+  }
+  for (int i = t; i < TW / 32; i += NPS_THREADS) s_skip[i] = 0u;
+  __syncthreads();
+  const uint32_t e_in = s_ein, cnt_tile = s_cnt;
+  const uint64_t base = s_base;
+  if (tile == 0 && A.n == 0 && t == 0) { *A.consumed = 0; *A.state_out = *A.state; }
+  if (tile == A.ntiles - 1 && t == 0 && base + cnt_tile < A.n) atomicOr(A.overflow, 8u);          // the launch did not cover n normals
+  if (base >= A.n) return;                                                                         // (uniform) beyond the segment
+#ifdef NPS1_EXP_NOOUT
+  if (A.n) return;
+#endif
+
+  // ---- the words that are not starts: before the entry offset, and inside the slow normals of the stream's path
+  if (t == 0 && e_in) atomicOr(&s_skip[0], (1u << e_in) - 1u);
+  for (uint32_t k = t; k < nev; k += NPS_THREADS) {
+    const uint32_t pf = s_ev[k], p = pf & 0xffffu, f = pf >> 16;
+    if ((s_mask[k] >> e_in) & 1u)
+      for (uint32_t q = p + 1; q < p + f && q < (uint32_t)TW; ++q) atomicOr(&s_skip[q >> 5], 1u << (q & 31));
+  }
+  __syncthreads();
+
+  // ---- write: each sub-tile's normals are one contiguous run of the output, gathered in the LDS in order, stored coalesced
+  uint64_t rank0 = base;
+  uint32_t nev_before = 0;
+#pragma unroll
+  for (int c = 0; c < NSUB; ++c) {
+    const uint32_t p0 = (uint32_t)(c * NPS_SUB + t * NPS_WPT);
+    const uint32_t startmask = ~(s_skip[p0 >> 5] >> (p0 & 31)) & 0xffu;
+    const uint32_t nslow = __popc(slowmask[c]), nstart = __popc(startmask);
+    uint32_t tot;
+    const uint32_t ex = nps_block_scan(nslow | (nstart << 16), s_wave, tot);
+    const uint32_t tot_slow = tot & 0xffffu, tot_start = tot >> 16;
+    uint32_t ks = nev_before + (ex & 0xffffu), o = ex >> 16;
+#pragma unroll
+    for (int i = 0; i < NPS_WPT; ++i) {
+      const bool slow = (slowmask[c] >> i) & 1u;
+      if ((startmask >> i) & 1u) {
+        s_out[o] = slow ? s_evv[min(ks, (uint32_t)EVCAP1 - 1)] : val[c][i];
+        ++o;
+      }
+      if (slow) ++ks;
+    }
+    __syncthreads();
+    for (uint32_t k = t; k < tot_start; k += NPS_THREADS) {
+      const uint64_t g = rank0 + k;
+      if (g < A.n) O.out[g] = s_out[k];
+    }
+    nev_before += tot_slow;
+    rank0 += tot_start;
+  }
+
+#ifdef NPS1_EXP_TIMES
+  __syncthreads();
+  if (t == 0) {          // start | four 24-bit deltas (100 MHz ticks): generation done, entry offset known, index known, written
+    const uint64_t T4 = wall_clock64();
+#if NPS1_EXP_TIMES == 2     // generation done, walk done, entry offset known, index known
+    const uint64_t d1 = (T1 - T0) & 0xffffff, d2 = (s_t1w - T0) & 0xffffff, d3 = (T2 - T0) & 0xffffff, d4 = (T3 - T0) & 0xffffff;
+    (void)T4;
+#else
+    const uint64_t d1 = (T1 - T0) & 0xffffff, d2 = (T2 - T0) & 0xffffff, d3 = (T3 - T0) & 0xffffff, d4 = (T4 - T0) & 0xffffff;
+#endif
+    const u128 rec = (u128)(uint32_t)T0 | ((u128)d1 << 32) | ((u128)d2 << 56) | ((u128)d3 << 80) | ((u128)d4 << 104);
+    A.tile_state[tile] = rec;
+  }
+#endif
+  // ---- the tile the n-th normal starts in: the word after it = what the segment consumed, and the generator there
+  if (t == 0 && base < A.n && A.n <= base + cnt_tile) {
+    const uint64_t want = A.n - base;
+    uint64_t cur = e_in, count = 0, end = 0;
+    bool done = false;
+    for (uint32_t k = 0; k < nev && !done; ++k) {
+      const uint64_t p = s_ev[k] & 0xffffu, f = s_ev[k] >> 16;
+      if (p < cur) continue;
+      if (count + (p - cur) >= want) { end = cur + (want - count); done = true; break; }
+      count += p - cur + 1;
+      cur = p + f;
+      if (count == want) { end = cur; done = true; }
+    }
+    if (!done) end = cur + (want - count);
+    const uint64_t consumed = (uint64_t)tile * TW + end;
+    *A.consumed = consumed;
+    *A.state_out = nps_advance_lds(*A.state, consumed, &s_jump);
   }
 }
 

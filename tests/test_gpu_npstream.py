@@ -92,9 +92,10 @@ def test_numpy_mode_falls_back_to_host_draws_when_the_generator_is_not_pcg64(cap
     sim.set_seed(1)
 
 
-def test_general_scan_path_gives_the_same_stream():
-    """The scan's in-order composition of the tile maps (taken when a tile's exit offset depends on its entry, or a segment is
-    longer than the LDS holds) is never reached by real streams: force it and compare with numpy again."""
+def test_three_pass_form_gives_the_same_stream():
+    """Segments too long for a buffer of their own take the three-pass form (classify, scan, emit): force it and compare again --
+    also with the scan's in-order composition of the tile maps (taken when a tile's exit offset depends on its entry, which real
+    streams never reach)."""
     import os, subprocess, sys
     code = r'''
 import numpy as np
@@ -109,7 +110,7 @@ for seed, n in ((1, 1), (2, 5000), (4, 16385), (6, 1_048_576), (9, 3_000_001)):
     assert (int(after[1]) << 64) | int(after[0]) == rng.bit_generator.state["state"]["state"]
 print("ok")
 '''
-    env = dict(os.environ, FASTMC_NPS_GENERAL_SCAN="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "ok" in r.stdout.splitlines(), r.stdout + r.stderr
+    for extra in ({"FASTMC_NPS_THREEPASS": "1"}, {"FASTMC_NPS_THREEPASS": "1", "FASTMC_NPS_GENERAL_SCAN": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout.splitlines(), r.stdout + r.stderr

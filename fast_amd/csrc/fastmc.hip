@@ -2146,40 +2146,46 @@ extern "C" int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int
   struct Free { double* p; ~Free() { if (p) hipHostFree(p); } } guard{pinned};
   // Two streams: the generator chain of chunk c + 1 (tile states, classify, scan: sequential in the stream's state, latency-bound)
   // runs beside the emit + Monte-Carlo kernels of chunk c (HBM-bound); the segment buffers alternate between two sets.
-  if (!w->gstream) {
+  // (FASTMC_NPS_TWO_STREAMS=1: the generator of chunk c + 1 on a stream of its own beside the Monte-Carlo kernels of chunk c.
+  //  Both fill the device on their own, so nothing overlaps and the cross-stream events only add launch gaps: one stream.)
+  static const bool two = [] { const char* e = getenv("FASTMC_NPS_TWO_STREAMS"); return e && *e == '1'; }();
+  if (two && !w->gstream) {
     HIPCHK(hipStreamCreateWithFlags(&w->gstream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
       HIPCHK(hipEventCreateWithFlags(&w->ev_gen[i], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&w->ev_used[i], hipEventDisableTiming));
     }
   }
-  hipEvent_t ev0;      // the generator stream starts after what nps_prepare put on the handle's stream
-  HIPCHK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(ev0, h->stream));
-  HIPCHK(hipStreamWaitEvent(w->gstream, ev0, 0));
-  hipEventDestroy(ev0);
+  hipStream_t gs = two ? w->gstream : h->stream;
+  if (two) {
+    hipEvent_t ev0;      // the generator stream starts after what nps_prepare put on the handle's stream
+    HIPCHK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev0, h->stream));
+    HIPCHK(hipStreamWaitEvent(w->gstream, ev0, 0));
+    hipEventDestroy(ev0);
+  }
   const uint64_t nc = (uint64_t)chunk_real * N2, ns = (uint64_t)chunk_real * 27;
   std::vector<NpsSegArgs> AA((size_t)n_chunks * 2);
   const bool onepass = nps_use_onepass(2 * nc);
   auto gen_chunk = [&](int64_t c) -> int {
     const int set = (int)(c & 1);
-    if (c >= 2) HIPCHK(hipStreamWaitEvent(w->gstream, w->ev_used[set], 0));      // chunk c - 2 has read this set
+    if (two && c >= 2) HIPCHK(hipStreamWaitEvent(gs, w->ev_used[set], 0));      // chunk c - 2 has read this set
     if (onepass) {
-      TRY(nps_onepass(h, w->one[2 * set], (size_t)c * segs, inc, 2 * nc, w->gstream));
-      if (sh) TRY(nps_onepass(h, w->one[2 * set + 1], (size_t)c * segs + 1, inc, 2 * ns, w->gstream));
-      HIPCHK(hipEventRecord(w->ev_gen[set], w->gstream));
+      TRY(nps_onepass(h, w->one[2 * set], (size_t)c * segs, inc, 2 * nc, gs));
+      if (sh) TRY(nps_onepass(h, w->one[2 * set + 1], (size_t)c * segs + 1, inc, 2 * ns, gs));
+      if (two) HIPCHK(hipEventRecord(w->ev_gen[set], gs));
       return 0;
     }
-    TRY(nps_segment(h, AA[2 * c], w->seg[2 * set], (size_t)c * segs, inc, 2 * nc, w->gstream));      // real parts of the chunk, then its imaginary parts
-    if (sh) TRY(nps_segment(h, AA[2 * c + 1], w->seg[2 * set + 1], (size_t)c * segs + 1, inc, 2 * ns, w->gstream));
-    HIPCHK(hipEventRecord(w->ev_gen[set], w->gstream));
+    TRY(nps_segment(h, AA[2 * c], w->seg[2 * set], (size_t)c * segs, inc, 2 * nc, gs));      // real parts of the chunk, then its imaginary parts
+    if (sh) TRY(nps_segment(h, AA[2 * c + 1], w->seg[2 * set + 1], (size_t)c * segs + 1, inc, 2 * ns, gs));
+    if (two) HIPCHK(hipEventRecord(w->ev_gen[set], gs));
     return 0;
   };
   TRY(gen_chunk(0));
   for (int64_t c = 0; c < n_chunks; ++c) {
     const int set = (int)(c & 1);
     NpsSegArgs* A = &AA[2 * c];
-    HIPCHK(hipStreamWaitEvent(h->stream, w->ev_gen[set], 0));
+    if (two) HIPCHK(hipStreamWaitEvent(h->stream, w->ev_gen[set], 0));
     if (c + 1 < n_chunks) TRY(gen_chunk(c + 1));
     RunSpec S{1, 0, 0, 0, chunk_real, nullptr, nullptr, nullptr, nullptr, nullptr, 0.0, coherent, nullptr, nullptr};
     S.async = true;
@@ -2197,10 +2203,10 @@ extern "C" int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int
     };
     h->pending = false;          // no wait between chunks: only the last chunk's kernel times are read (after the one sync below)
     TRY(run_impl<double>(h, S));
-    HIPCHK(hipEventRecord(w->ev_used[set], h->stream));
+    if (two) HIPCHK(hipEventRecord(w->ev_used[set], h->stream));
     HIPCHK(hipMemcpyAsync(pinned + per_chunk * c, h->out, per_chunk * 8, hipMemcpyDeviceToHost, h->stream));
   }
-  HIPCHK(hipStreamSynchronize(w->gstream));
+  if (two) HIPCHK(hipStreamSynchronize(w->gstream));
   std::vector<uint32_t> ovf((size_t)n_chunks * segs);
   std::vector<u128> states((size_t)n_chunks * segs + 1);
   HIPCHK(hipMemcpyAsync(ovf.data(), w->overflow, ovf.size() * 4, hipMemcpyDeviceToHost, h->stream));

@@ -102,6 +102,18 @@ __device__ __forceinline__ uint64_t nps_next(u128& s, u128 inc) {       // pcg64
 }
 __device__ __forceinline__ double nps_double(u128& s, u128 inc) { return (double)(nps_next(s, inc) >> 11) * (1.0 / 9007199254740992.0); }
 
+// The fast-path value of the word r -- numpy's `x = rabs * wi[idx]; if (sign) x = -x` with rabs = bits 9 ... 60 -- in five
+// instructions: the 52 bits dropped under the exponent of 2^52 are the integer as a double (exact, no u64 -> f64 conversion),
+// and the sign bit (bit 8 of r) is XORed in.  rabs comes back for the ziggurat's `rabs < ki[idx]`.
+__device__ __forceinline__ double nps_fast_value(uint64_t r, const double* wi, uint64_t& rabs) {
+  const uint32_t lo = (uint32_t)r, hi = (uint32_t)(r >> 32);
+  const uint32_t mlo = __builtin_amdgcn_alignbit(hi, lo, 9), mhi = (hi >> 9) & 0xfffffu;
+  rabs = ((uint64_t)mhi << 32) | mlo;
+  const double d = __hiloint2double((int)(mhi | 0x43300000u), (int)mlo) - 4503599627370496.0;
+  const double x = __dmul_rn(d, wi[lo & 0xffu]);
+  return __hiloint2double(__double2hiint(x) ^ (int)((lo << 23) & 0x80000000u), __double2loint(x));
+}
+
 // numpy/random/src/distributions/distributions.c: random_standard_normal, from the word `r` on, on the private generator (s, inc).
 // Returns the value; f = words consumed including r.  No FMA contraction in the acceptance tests (numpy's are plain C on x86-64).
 __device__ inline double nps_slow(uint64_t r, u128 s, u128 inc, const double* wi, const uint64_t* ki, const double* fi, uint32_t& f) {
@@ -507,9 +519,8 @@ __global__ __launch_bounds__(NPS_THREADS) void k_nps_emit(NpsSegArgs A, NpsEmitR
       for (int c = 0; c < 2; ++c) {
         const uint64_t r = nps_next(sc[c], A.inc);
         const int idx = (int)(r & 0xff);
-        const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
-        const double x = __dmul_rn((double)rabs, s_wi[idx]);
-        val[c][i] = ((r >> 8) & 1) ? -x : x;
+        uint64_t rabs;
+        val[c][i] = nps_fast_value(r, s_wi, rabs);
         if (rabs >= s_ki[idx]) slowmask[c] |= 1u << i;
       }
     }
@@ -656,9 +667,8 @@ __global__ __launch_bounds__(NPS_THREADS) NPS1_OCC void k_nps_onepass(NpsSegArgs
       for (int c = 0; c < 2; ++c) {
         const uint64_t r = nps_next(sc[c], A.inc);
         const int idx = (int)(r & 0xff);
-        const uint64_t rabs = (r >> 9) & 0x000fffffffffffffull;
-        const double x = __dmul_rn((double)rabs, s_wi[idx]);
-        val[2 * pass + c][i] = ((r >> 8) & 1) ? -x : x;
+        uint64_t rabs;
+        val[2 * pass + c][i] = nps_fast_value(r, s_wi, rabs);
         asm volatile("" : "+v"(val[2 * pass + c][i]));      // the VALUE stays (else the compiler keeps what it is made of: 255 registers)
         if (rabs >= s_ki[idx]) {
           slowmask[2 * pass + c] |= 1u << i;

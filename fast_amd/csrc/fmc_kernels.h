@@ -528,11 +528,21 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
                        "+v"(rl.s2), "+v"(rl.s3));
         }
       } else {
+        // coefficients from HBM (three float64 loads per element: real part, imaginary part, colouring factor), eight elements
+        // at a time: all P at once are 6 P VGPRs of loads in flight on top of the 4 P of the row (P = 16: 68 B of scratch per lane)
         const size_t base = ((size_t)b * N + ky) * N;
+        constexpr int CH = (sizeof(R) == 8 && P > 8) ? 8 : P;
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
-          const int kx = sp + S * (lane + WAVE * j);
-          regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
+        for (int j0 = 0; j0 < P; j0 += CH) {
+#pragma unroll
+          for (int j = j0; j < (j0 + CH < P ? j0 + CH : P); ++j) {
+            const int kx = sp + S * (lane + WAVE * j);
+            regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
+          }
+          if constexpr (CH < P) {
+#pragma unroll
+            for (int j = j0; j < (j0 + CH < P ? j0 + CH : P); ++j) asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y));
+          }
         }
       }
       wave_row_fft<R, P, NS, D, OMC>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);

@@ -1,9 +1,5 @@
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_npstream.py -x -q 2>&1 | tail -2
-for rep in 1 2; do
-for v in 0 1; do
-  export FASTMC_NPS_TWO_STREAMS=$v
-  echo "== two streams: $v"
-  python3 tools/sameseed_rate.py 40000 400 2>&1 | grep numpy
-done
-done
+timeout 900 python -m pytest tests/test_gpu_npstream.py tests/test_gpu_parity.py -x -q 2>&1 | tail -2
+python3 tools/sameseed_rate.py 40000 400 2>&1 | grep numpy
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_nps14 -- python3 tools/sameseed_rate.py 10000 100 > gpurun_out/nps14.txt 2>&1
+cat gpurun_out/prof_nps14/*/*kernel_stats.csv | head -5 | cut -d, -f1-4,6,7

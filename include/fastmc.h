@@ -227,7 +227,11 @@ int fastmc_queue_wait(fastmc_t* h, int slot, double* out, int64_t out_cap, int64
  * The reference draws everything from one sequential stream, funcs._R = numpy.random.default_rng(seed) (fast/funcs.py:21,
  * 352-365): PCG64 feeding numpy's ziggurat, where a normal consumes one 64-bit word or, 2.2 % of the time, more.  These
  * entry points reproduce that stream on the device (fast_amd/csrc/fmc_npstream.h: classify every word as a potential start,
- * compose the tiles' transfer maps, emit), so that a run with a given SEED returns the reference's own numbers at GPU speed.
+ * chain the tiles' transfer maps, write -- in one kernel with a decoupled look-back when the array fits a device buffer of
+ * its own, in three passes otherwise), so that a run with a given SEED returns the reference's own numbers at GPU speed.
+ * Environment (A/B and tests; same results): FASTMC_NPS_ONEPASS_MAX_GB (default 16) bounds that buffer; FASTMC_NPS_THREEPASS=1
+ * forces the three-pass form, FASTMC_NPS_GENERAL_SCAN=1 its in-order scan; FASTMC_NPS_TWO_STREAMS=1 puts the generator of
+ * chunk c + 1 on a stream of its own; FASTMC_GEN64_STAGED=1 stages the float64 device generator through HBM.
  *   fastmc_npstream_set_tables   the 256-entry ziggurat tables (wi, ki, fi) of the numpy that is installed, read out of it
  *                                by fast_amd/npnormal.py (they are not in this library);
  *   fastmc_npstream_normals      one array: out[0 ... n) = Generator(PCG64 at state_inc).normal(size = n); state_inc =

@@ -18,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -948,15 +949,43 @@ extern "C" int fastmc_set_subharm(fastmc_t* h, const double* ps_sh, const double
 // ------------------------------------------------------------------ launches
 // every launch leaves the name of its kernel on the handle (fastmc_last_kernels: bench.py prices the instruction mix of what ran)
 template <class R> static const char* rname() { return sizeof(R) == 8 ? "double" : "float"; }
+static int device_cus(int device) {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cus.find(device);
+  if (it != cus.end()) return it->second;
+  hipDeviceProp_t prop;
+  const int n = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  cus[device] = n;
+  return n;
+}
 #define FMC_NOTE(dst, ...) snprintf(dst, sizeof(dst), __VA_ARGS__)
 template <class R, int P, int NS, int MODE, int S = 1, int D = 0>
 static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
   const size_t lds = wave_lds_bytes_d<R, P, NS, D>(A.omS) + (MODE == 2 ? GEN64_TABLE_BYTES : 0);   // fits for every P = 16 variant (fused_gen64)
   hipFuncSetAttribute((const void*)k_rows_wave<R, P, NS, MODE, S, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   constexpr int WPB = WCfg<R, P, NS, D>::WPB;
-  constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
+  constexpr int LR = 128 / (int)sizeof(cpx<R>);
+  // Rows per wave: ROWS_PER_WAVE (8) when the launch is many rounds of workgroups; a SMALL launch (a chunk of 50 realisations
+  // at 1024^2 is 400 workgroups' worth on 256 CUs, one workgroup per CU: two rounds for 1.56 of work) takes the divisor that
+  // wastes the least of its last round -- 7 % per halving is what the shorter walk costs (twiddle preload per wave).
+  RowArgs<R> B = A;
+  {
+    constexpr int step = LR / std::gcd(WPB, LR);                // rows per wave come in multiples of this (whole 128-byte lines)
+    const int cus = device_cus(h->device);
+    double best = 1e300;
+    for (int rpw = ROWS_PER_WAVE; rpw >= step; rpw /= 2) {
+      if (rpw % step) break;
+      const int bpg = rpw * WPB / LR;
+      const int64_t blocks = (int64_t)(A.N / LR) * ((A.nb + bpg - 1) / bpg);
+      const double cost = (double)((blocks + cus - 1) / cus) * rpw * (1.0 + 0.07 * std::log2((double)ROWS_PER_WAVE / rpw));
+      if (cost < best * 0.999) { best = cost; B.rpw = rpw; }
+    }
+  }
+  const int BPG = B.rpw * WPB / LR;
   const int blocks = (A.N / LR) * ((A.nb + BPG - 1) / BPG);
-  hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE, S, D>), dim3(blocks), dim3(WPB * 64), lds, h->stream, A);
+  hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE, S, D>), dim3(blocks), dim3(WPB * 64), lds, h->stream, B);
   FMC_NOTE(h->last_rows, "k_rows_wave<%s, %d, %d, %d, %d, %d>", rname<R>(), P, NS, MODE, S, D);
 }
 template <class R, int P, int NS, int EPI, int S = 1, int D = 0>

@@ -160,6 +160,7 @@ struct BluArgs {
 template <class R>
 struct RowArgs {
   int N, Np, lo, nb;            // grid size, window size, first window index, realisations in this launch
+  int rpw = 0;                  // k_rows_wave: rows per wave of this launch (0: ROWS_PER_WAVE); small launches take fewer (launch_rows_wave)
   const R* amp;                 // [N][N] sqrt(powerspec)*df  (wave family: with (-1)^(ky+kx) folded in); host-coefficient mode
   const float* ampf;            // the same table rounded to float32: colouring of the device generator's float32 normals
   const cpx<R>* tw;             // wave: tw1 [P*64];  direct: w_N^e, e < N
@@ -479,7 +480,8 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
   constexpr int WPB = WCfg<R, P, NS, D>::WPB;
   constexpr int LR = 128 / (int)sizeof(cpx<R>);
   static_assert((ROWS_PER_WAVE * WPB) % LR == 0, "tile must hold whole lines");
-  constexpr int BPG = ROWS_PER_WAVE * WPB / LR;          // realisations per workgroup
+  const int rpw = A.rpw ? A.rpw : ROWS_PER_WAVE;         // (a multiple of LR / gcd(WPB, LR): whole lines)
+  const int BPG = rpw * WPB / LR;                        // realisations per workgroup
   const int nbb = (A.nb + BPG - 1) / BPG;
   const int b0 = (blockIdx.x % nbb) * BPG;               // realisation block fastest: neighbours share amp rows
   const int row0 = (blockIdx.x / nbb) * LR;
@@ -490,7 +492,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 #pragma unroll
       for (int m = 1; m < 8; ++m) regs.omc[s2][m] = s_om[m * A.omS + min(lane + WAVE * s2, A.omS - 1)];
   }
-  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+  for (int rr = 0; rr < rpw; ++rr) {
     const int flat = rr * WPB + w;
     const int b = b0 + flat / LR;
     if (b >= A.nb) break;                                // wave-uniform
@@ -528,20 +530,41 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
                        "+v"(rl.s2), "+v"(rl.s3));
         }
       } else {
-        // coefficients from HBM (three float64 loads per element: real part, imaginary part, colouring factor), eight elements
-        // at a time: all P at once are 6 P VGPRs of loads in flight on top of the 4 P of the row (P = 16: 68 B of scratch per lane)
+        // coefficients from HBM: three float64 loads per element (real part, imaginary part, colouring factor).  All P at once are
+        // 6 P VGPRs of loads in flight on top of the 4 P of the row (P = 16: 68 B of scratch per lane); in two halves the second
+        // half's loads only start when the first has arrived.  So: chunks of four elements through two register buffers, chunk
+        // k + 2 requested as soon as chunk k is consumed -- loads are in flight for the whole of the load phase, 48 VGPRs of them.
         const size_t base = ((size_t)b * N + ky) * N;
-        constexpr int CH = (sizeof(R) == 8 && P > 8) ? 8 : P;
+        constexpr int CH = (sizeof(R) == 8 && P > 8 && P % 4 == 0) ? 4 : P, NCH = P / CH;
+        if constexpr (NCH == 1) {
 #pragma unroll
-        for (int j0 = 0; j0 < P; j0 += CH) {
-#pragma unroll
-          for (int j = j0; j < (j0 + CH < P ? j0 + CH : P); ++j) {
+          for (int j = 0; j < P; ++j) {
             const int kx = sp + S * (lane + WAVE * j);
             regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
           }
-          if constexpr (CH < P) {
+        } else {
+          R cr[2][CH], ci[2][CH], am[2][CH];
 #pragma unroll
-            for (int j = j0; j < (j0 + CH < P ? j0 + CH : P); ++j) asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y));
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+              const int kx = sp + S * (lane + WAVE * (k * CH + i));
+              cr[k][i] = (R)A.cre[base + kx]; ci[k][i] = (R)A.cim[base + kx]; am[k][i] = amp[kx];
+            }
+#pragma unroll
+          for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+              regs.v[k * CH + i] = cscale(mk<R>(cr[k & 1][i], ci[k & 1][i]), am[k & 1][i]);
+              asm volatile("" : "+v"(regs.v[k * CH + i].x), "+v"(regs.v[k * CH + i].y) : : "memory");      // (no later load moves above this)
+            }
+            if (k + 2 < NCH) {
+#pragma unroll
+              for (int i = 0; i < CH; ++i) {
+                const int kx = sp + S * (lane + WAVE * ((k + 2) * CH + i));
+                cr[k & 1][i] = (R)A.cre[base + kx]; ci[k & 1][i] = (R)A.cim[base + kx]; am[k & 1][i] = amp[kx];
+              }
+            }
           }
         }
       }

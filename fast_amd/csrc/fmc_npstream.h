@@ -663,21 +663,28 @@ __global__ __launch_bounds__(NPS_THREADS) NPS1_OCC void k_nps_onepass(NpsSegArgs
     slowmask[2 * pass] = slowmask[2 * pass + 1] = 0;
 #pragma unroll
     for (int i = 0; i < NPS_WPT; ++i) {
+      // both chains' steps in ONE basic block (their dependent multiplies interleave), one branch for the rare pushes
+      uint64_t r[2], rabs[2];
+      bool slow[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) r[c] = nps_next(sc[c], A.inc);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const uint64_t r = nps_next(sc[c], A.inc);
-        const int idx = (int)(r & 0xff);
-        uint64_t rabs;
-        val[2 * pass + c][i] = nps_fast_value(r, s_wi, rabs);
+        val[2 * pass + c][i] = nps_fast_value(r[c], s_wi, rabs[c]);
         asm volatile("" : "+v"(val[2 * pass + c][i]));      // the VALUE stays (else the compiler keeps what it is made of: 255 registers)
-        if (rabs >= s_ki[idx]) {
-          slowmask[2 * pass + c] |= 1u << i;
-          const uint32_t q = atomicAdd(&s_qn[pass & 1], 1u);
-          if (q < (uint32_t)QCAP) {
-            s_q[q].s = sc[c]; s_q[q].r = r; s_q[q].pos = (uint32_t)((2 * pass + c) * NPS_SUB + t * NPS_WPT + i);
-            s_qidx[c * NPS_SUB + t * NPS_WPT + i] = (uint16_t)q;
+        slow[c] = rabs[c] >= s_ki[(int)(r[c] & 0xff)];
+      }
+      if (slow[0] | slow[1]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          if (slow[c]) {
+            slowmask[2 * pass + c] |= 1u << i;
+            const uint32_t q = atomicAdd(&s_qn[pass & 1], 1u);
+            if (q < (uint32_t)QCAP) {
+              s_q[q].s = sc[c]; s_q[q].r = r[c]; s_q[q].pos = (uint32_t)((2 * pass + c) * NPS_SUB + t * NPS_WPT + i);
+              s_qidx[c * NPS_SUB + t * NPS_WPT + i] = (uint16_t)q;
+            }
           }
-        }
       }
     }
     const uint32_t na = __popc(slowmask[2 * pass]), nb = __popc(slowmask[2 * pass + 1]);
@@ -780,11 +787,7 @@ __global__ __launch_bounds__(NPS_THREADS) NPS1_OCC void k_nps_onepass(NpsSegArgs
 #endif
     const bool same = __ballot(exit_off == (uint32_t)__builtin_amdgcn_readfirstlane((int)exit_off)) == ~0ull;
     uint32_t e_in = 0;
-#ifdef NPS1_EXP_NOWAIT
-    if (false) {
-#else
     if (tile > 0) {
-#endif
       if (same && t == 0) __hip_atomic_store(&O.xexit[tile], 0x80000000u | exit_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       uint32_t x;
       for (;;) {
@@ -802,12 +805,7 @@ __global__ __launch_bounds__(NPS_THREADS) NPS1_OCC void k_nps_onepass(NpsSegArgs
     const uint32_t x_here = (uint32_t)__shfl((int)exit_off, (int)e_in, 64);
     if ((tile == 0 || !same) && t == 0) __hip_atomic_store(&O.xexit[tile], 0x80000000u | x_here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long base = 0;
-#ifdef NPS1_EXP_NOWAIT
-    base = (unsigned long long)tile * 8000ull;
-    if (false) {
-#else
     if (tile > 0) {
-#endif
       if (t == 0) __hip_atomic_store(&O.agg[tile], (1ull << 62) | c_here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int64_t p = tile - 1;
       for (;;) {
@@ -842,9 +840,6 @@ __global__ __launch_bounds__(NPS_THREADS) NPS1_OCC void k_nps_onepass(NpsSegArgs
   if (tile == 0 && A.n == 0 && t == 0) { *A.consumed = 0; *A.state_out = *A.state; }
   if (tile == A.ntiles - 1 && t == 0 && base + cnt_tile < A.n) atomicOr(A.overflow, 8u);          // the launch did not cover n normals
   if (base >= A.n) return;                                                                         // (uniform) beyond the segment
-#ifdef NPS1_EXP_NOOUT
-  if (A.n) return;
-#endif
 
   // ---- the words that are not starts: before the entry offset, and inside the slow normals of the stream's path
   if (t == 0 && e_in) atomicOr(&s_skip[0], (1u << e_in) - 1u);

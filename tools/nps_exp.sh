@@ -1,11 +1,5 @@
-RT=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
-ls -la $RT
-export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:verbosity=1
-LD_PRELOAD=$RT python3 -c "print('hello under asan')"; echo "rc=$?"
-export FASTMC_LIB=$PWD/build/asan/libfastmc_asan.so
-LD_PRELOAD=$RT python3 -c "
-import sys; sys.path.insert(0,'.')
-from fast_amd import _lib
-h=_lib.Handle(256,40,'f64',0)
-print('handle ok', h.last_kernels())
-"; echo "rc=$?"
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests/test_gpu_npstream.py tests/test_gpu_parity.py -x -q 2>&1 | grep -E "passed|failed"
+python3 tools/sameseed_rate.py 40000 400 2>&1 | grep numpy
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_nps16 -- python3 tools/sameseed_rate.py 10000 100 > gpurun_out/nps16.txt 2>&1
+cat gpurun_out/prof_nps16/*/*kernel_stats.csv | head -4 | cut -d, -f1-4

@@ -2243,6 +2243,14 @@ extern "C" int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int
   HIPCHK(hipStreamSynchronize(h->stream));
   finish_pending(h);
   HIPCHK(hipGetLastError());
+  {   // FASTMC_NPS_TEST_OVERFLOW=k (tests): the first call of the process with more than k chunks reports chunk k as given up
+    static std::atomic<int> armed{[] { const char* e = getenv("FASTMC_NPS_TEST_OVERFLOW"); return e ? atoi(e) : -1; }()};
+    int k = armed.load();
+    if (k >= 0 && n_chunks > k) {
+      int expect = k;
+      if (armed.compare_exchange_strong(expect, -1)) ovf[(size_t)k * segs] |= 0x80u;
+    }
+  }
   int64_t bad = -1;
   for (int64_t c = 0; c < n_chunks && bad < 0; ++c)
     for (int k = 0; k < segs; ++k)

@@ -231,7 +231,9 @@ int fastmc_queue_wait(fastmc_t* h, int slot, double* out, int64_t out_cap, int64
  * its own, in three passes otherwise), so that a run with a given SEED returns the reference's own numbers at GPU speed.
  * Environment (A/B and tests; same results): FASTMC_NPS_ONEPASS_MAX_GB (default 16) bounds that buffer; FASTMC_NPS_THREEPASS=1
  * forces the three-pass form, FASTMC_NPS_GENERAL_SCAN=1 its in-order scan; FASTMC_NPS_TWO_STREAMS=1 puts the generator of
- * chunk c + 1 on a stream of its own; FASTMC_GEN64_STAGED=1 stages the float64 device generator through HBM.
+ * chunk c + 1 on a stream of its own; FASTMC_NPS_TEST_OVERFLOW=k makes the first fastmc_run_npstream call of the process with
+ * more than k chunks report chunk k as given up (the caller's redo-with-numpy path); FASTMC_GEN64_STAGED=1 stages the float64
+ * device generator through HBM.
  *   fastmc_npstream_set_tables   the 256-entry ziggurat tables (wi, ki, fi) of the numpy that is installed, read out of it
  *                                by fast_amd/npnormal.py (they are not in this library);
  *   fastmc_npstream_normals      one array: out[0 ... n) = Generator(PCG64 at state_inc).normal(size = n); state_inc =

@@ -114,3 +114,37 @@ print("ok")
     for extra in ({"FASTMC_NPS_THREEPASS": "1"}, {"FASTMC_NPS_THREEPASS": "1", "FASTMC_NPS_GENERAL_SCAN": "1"}):
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "ok" in r.stdout.splitlines(), r.stdout + r.stderr
+
+
+def test_a_chunk_the_device_gives_up_on_is_redrawn_by_numpy_and_the_run_goes_on():
+    """An overflow flag (a normal spanning more than 16 words across a tile edge, ...) has never been raised by a real stream; the
+    library can be told to report one (FASTMC_NPS_TEST_OVERFLOW): the run must draw that chunk with numpy from the state at its
+    start, continue on the device, and end with the reference's numbers and generator state."""
+    import os, subprocess, sys
+    code = r'''
+import logging, sys
+import numpy as np
+sys.path.insert(0, "tests")
+import fast_amd
+from conftest import load_golden, params_from_json
+g = load_golden("e2e_ao_alias")
+p = params_from_json(g["params_json"])
+p.update({"GPU_RNG": "numpy", "GPU_DEVICE": 0, "LOGLEVEL": "WARNING"})
+msgs = []
+class H(logging.Handler):
+    def emit(self, rec): msgs.append(rec.getMessage())
+logging.getLogger("fast_amd").addHandler(H())
+sim = fast_amd.Fast(p)
+r = sim.run()._r
+assert any("gave up" in m for m in msgs), msgs
+assert np.allclose(r, g["r"], rtol=1e-9, atol=0), np.abs(r / g["r"] - 1).max()
+# ... and the module generator stands where a run without the incident leaves it
+end = fast_amd.fast._R.bit_generator.state["state"]["state"]
+p2 = dict(p, GPU_RNG="host")
+fast_amd.Fast(p2).run()
+assert fast_amd.fast._R.bit_generator.state["state"]["state"] == end
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, FASTMC_NPS_TEST_OVERFLOW="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout.splitlines(), r.stdout[-2000:] + r.stderr[-3000:]

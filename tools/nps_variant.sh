@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds a variant of libfastmc.so whose translation unit 0 (the numpy-stream kernels) is compiled with extra -D flags:
-#   tools/nps_variant.sh NAME "-DNPS1_EXP_NOWAIT"   ->  build/variants/libfastmc_NAME.so   (use: FASTMC_LIB=build/variants/libfastmc_NAME.so)
+#   tools/nps_variant.sh NAME "-DNPS1_WAVES=4 -DNPS1_EXP_TIMES=2"   ->  build/variants/libfastmc_NAME.so   (use: FASTMC_LIB=build/variants/libfastmc_NAME.so)
 # The other objects are the ones `make -C fast_amd/csrc all` left in fast_amd/csrc/obj.
 set -e
 NAME=$1; FLAGS=$2

@@ -1008,8 +1008,9 @@ static void launch_wave_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<
     if constexpr (S == 1 && pk_grid(64 * P)) launch_rows_wave<R, P, NS, 1, S, DR>(h, RA);
     else if (mode == 0) launch_rows_wave<R, P, NS, 0, S, DR>(h, RA);
     else if (mode == 2) {
-      // the float64 generator fused into the row (run_impl: fused_gen64): P = 16 only (1024, and 2048 / 4096 as sub-rows)
-      if constexpr (sizeof(R) == 8 && P == 16) launch_rows_wave<R, P, NS, 2, S, DR>(h, RA);
+      // the float64 generator fused into the row (run_impl: fused_gen64): every P = 16 variant (1024, and 2048 / 4096 as
+      // sub-rows), and the plain variant (D = 0) of the other one-row-per-wave grids (192 ... 1792)
+      if constexpr (sizeof(R) == 8 && (P == 16 || (DR == 0 && S == 1 && (NS == 2 || NS == 4)))) launch_rows_wave<R, P, NS, 2, S, DR>(h, RA);
     }
     else launch_rows_wave<R, P, NS, 1, S, DR>(h, RA);
   }
@@ -1468,7 +1469,8 @@ struct RunSpec {
   const double* sh_dev_im = nullptr;
 };
 
-// Does this handle's row kernel draw the float64 generator itself (MODE 2)?  The P = 16 rows of the wave family: 1024, and
+// Does this handle's row kernel draw the float64 generator itself (MODE 2)?  The one-row-per-wave grids of the wave family
+// (192 ... 1792: the plain variant, windows up to 256 pixels), the packed rows, and the P = 16 rows: 1024, and
 // 2048 / 4096 as sub-rows, float64 pipeline, any window the family serves (every variant's tables + the 4 KB of generator tables fit the
 // LDS: 152 KB + 64 omS <= 160 KB for the sixteen-wave variants, whose omS <= 128; 128 KB + 64 omS for the twelve-wave ones, omS <= 512).
 template <class R>
@@ -1476,10 +1478,36 @@ static bool fused_gen64(fastmc_ctx* h) {
   if constexpr (sizeof(R) != 8) return false;
   if (getenv("FASTMC_GEN64_STAGED")) return false;          // A/B: the round-3 form (k_gen_coeffs_f64 -> cre / cim -> MODE 1 rows)
   if (h->path == 1 && pk_grid(h->N) && pk_variant<R>(h) >= 0) return true;      // 128 / 256 / 512: the packed rows draw it themselves too
-  if (h->path != 1 || h->P != 16 || wave_rt_split(h->N)) return false;
+  if (h->path != 1 || wave_rt_split(h->N) || pk_grid(h->N)) return false;
   int ns = 0, wpb = 0;
   wave_config<R>(h, &ns, &wpb);
-  return ns == 2 || ns == 4 || ns == 8;      // not the whole-grid window (NS = P: its tables leave no room, and nothing draws into it)
+  if (h->P == 16) return ns == 2 || ns == 4 || ns == 8;      // not the whole-grid window (NS = P: its tables leave no room, and nothing draws into it)
+  // the other one-row-per-wave grids (192 ... 1792, S = 1): windows of up to 256 pixels, where the generator's 4 KB of tables fit the LDS
+  if (h->S != 1 || (ns != 2 && ns != 4)) return false;
+  if constexpr (sizeof(R) == 8) {
+    auto fits = [&](auto tag) {
+      constexpr int PP = decltype(tag)::value;
+      if (ns == 2) return wave_lds_bytes_d<R, PP, 2, 0>(h->omS) + GEN64_TABLE_BYTES <= LDS_MAX;
+      if constexpr (has_ns4(PP)) return wave_lds_bytes_d<R, PP, 4, 0>(h->omS) + GEN64_TABLE_BYTES <= LDS_MAX;
+      return false;
+    };
+    switch (h->P) {
+      case 3: return fits(std::integral_constant<int, 3>());
+      case 5: return fits(std::integral_constant<int, 5>());
+      case 6: return fits(std::integral_constant<int, 6>());
+      case 7: return fits(std::integral_constant<int, 7>());
+      case 9: return fits(std::integral_constant<int, 9>());
+      case 10: return fits(std::integral_constant<int, 10>());
+      case 12: return fits(std::integral_constant<int, 12>());
+      case 14: return fits(std::integral_constant<int, 14>());
+      case 18: return fits(std::integral_constant<int, 18>());
+      case 20: return fits(std::integral_constant<int, 20>());
+      case 24: return fits(std::integral_constant<int, 24>());
+      case 28: return fits(std::integral_constant<int, 28>());
+      default: return false;
+    }
+  }
+  return false;
 }
 
 template <class R>

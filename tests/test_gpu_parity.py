@@ -1212,7 +1212,7 @@ def test_float64_device_generator_matches_its_restatement(N, Np, sub):
 
 
 # every MODE 2 instantiation a dispatch reaches (fastmc.hip: dispatch_wave): dense six / eight planes, twelve-wave six / eight /
-# sixteen planes, NS = 4 / 8, split rows of 2048 / 4096, off-centre windows
+# sixteen planes, NS = 4 / 8, split rows of 2048 / 4096, off-centre windows; the packed rows; every other P of the family
 _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"),
             (1024, 97, None, "k_rows_wave<double, 16, 2, 2, 1, 8>"), (1024, 128, None, "k_rows_wave<double, 16, 2, 2, 1, 8>"),
             (1024, 82, 0, "k_rows_wave<double, 16, 2, 2, 1, 7>"), (1024, 120, 904, "k_rows_wave<double, 16, 2, 2, 1, 7>"),
@@ -1222,7 +1222,17 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             # packed rows (eight / four / two rows per wavefront): centred six planes and all planes
             (128, 82, None, "k_rows_pk<double, 0, 2, 0>"), (128, 128, None, "k_rows_pk<double, 0, 2, 1>"),
             (256, 82, None, "k_rows_pk<double, 1, 2, 0>"), (256, 200, None, "k_rows_pk<double, 1, 2, 1>"), (256, 82, 100, "k_rows_pk<double, 1, 2, 1>"),
-            (512, 96, None, "k_rows_pk<double, 2, 2, 0>"), (512, 250, 7, "k_rows_pk<double, 2, 2, 1>")]
+            (512, 96, None, "k_rows_pk<double, 2, 2, 0>"), (512, 250, 7, "k_rows_pk<double, 2, 2, 1>"),
+            # the other one-row-per-wave grids (192 ... 1792): the plain variant, windows of up to 128 / 256 pixels
+            (192, 30, None, "k_rows_wave<double, 3, 2, 2, 1, 0>"), (320, 82, 3, "k_rows_wave<double, 5, 2, 2, 1, 0>"),
+            (384, 60, None, "k_rows_wave<double, 6, 2, 2, 1, 0>"), (448, 128, None, "k_rows_wave<double, 7, 2, 2, 1, 0>"),
+            (576, 82, None, "k_rows_wave<double, 9, 2, 2, 1, 0>"), (576, 200, None, "k_rows_wave<double, 9, 4, 2, 1, 0>"),
+            (640, 82, None, "k_rows_wave<double, 10, 2, 2, 1, 0>"), (640, 250, 11, "k_rows_wave<double, 10, 4, 2, 1, 0>"),
+            (768, 82, None, "k_rows_wave<double, 12, 2, 2, 1, 0>"), (768, 256, None, "k_rows_wave<double, 12, 4, 2, 1, 0>"),
+            (896, 100, None, "k_rows_wave<double, 14, 2, 2, 1, 0>"), (1152, 82, None, "k_rows_wave<double, 18, 2, 2, 1, 0>"),
+            (1280, 82, None, "k_rows_wave<double, 20, 2, 2, 1, 0>"), (1280, 200, None, "k_rows_wave<double, 20, 4, 2, 1, 0>"),
+            (1536, 120, 1400, "k_rows_wave<double, 24, 2, 2, 1, 0>"), (1536, 222, None, "k_rows_wave<double, 24, 4, 2, 1, 0>"),
+            (1792, 82, None, "k_rows_wave<double, 28, 2, 2, 1, 0>")]
 
 
 @pytest.mark.parametrize("N,Np,lo,kernel", _FUSED64)

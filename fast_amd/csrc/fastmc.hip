@@ -1170,6 +1170,14 @@ static void launch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA,
       hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 0, SPLIT, LN, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_mr<R, P, NS, 0, SPLIT, LN, PR>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
       FMC_NOTE(h->last_rows, "k_rows_mr<%s, %d, %d, %d, %s, %d, %d>", rname<R>(), P, NS, 0, SPLIT ? "true" : "false", LN, PR);
+    } else if (mode == 2) {
+      // the float64 generator fused into the row (run_impl: fused_gen64 has checked that its tables fit)
+      if constexpr (PR == 0 && sizeof(R) == 8) {
+        const size_t lds2 = lds + GEN64_TABLE_BYTES;
+        hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 2, SPLIT, LN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipLaunchKernelGGL((k_rows_mr<R, P, NS, 2, SPLIT, LN, 0>), dim3(blocks), dim3(WPB * 64), lds2, h->stream, RA);
+        FMC_NOTE(h->last_rows, "k_rows_mr<%s, %d, %d, %d, %s, %d, %d>", rname<R>(), P, NS, 2, SPLIT ? "true" : "false", LN, 0);
+      }
     } else if constexpr (PR == 0) {
       hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 1, SPLIT, LN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_mr<R, P, NS, 1, SPLIT, LN, 0>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
@@ -1478,6 +1486,25 @@ static bool fused_gen64(fastmc_ctx* h) {
   if constexpr (sizeof(R) != 8) return false;
   if (getenv("FASTMC_GEN64_STAGED")) return false;          // A/B: the round-3 form (k_gen_coeffs_f64 -> cre / cim -> MODE 1 rows)
   if (h->path == 1 && pk_grid(h->N) && pk_variant<R>(h) >= 0) return true;      // 128 / 256 / 512: the packed rows draw it themselves too
+  if constexpr (sizeof(R) == 8) {
+    // 50-lane family (path 3) and the run-time-split wave grids: the kernels of fmc_mrfft.h, where their tables + 4 KB fit
+    const bool ws = h->path == 1 && wave_rt_split(h->N);
+    if (h->path == 3 || ws) {
+      const int ns2 = h->NS <= 2 ? 2 : 4, PP_ = ws ? h->P : h->mr_P;
+      const int omS = h->omS;
+#define FMC_G64_MR(PP, LNN)                                                                                     \
+      if (PP_ == PP) {                                                                                          \
+        if (ns2 == 2) return mr_lds_bytes<R, PP, 2, LNN>(omS) + GEN64_TABLE_BYTES <= LDS_MAX;                   \
+        if constexpr (LNN == MR_LN ? mr_has_ns4(PP) : has_ns4(PP)) return mr_lds_bytes<R, PP, 4, LNN>(omS) + GEN64_TABLE_BYTES <= LDS_MAX; \
+        return false;                                                                                           \
+      }
+      if (ws) { FMC_G64_MR(7, WAVE) FMC_G64_MR(9, WAVE) FMC_G64_MR(10, WAVE) FMC_G64_MR(14, WAVE) FMC_G64_MR(18, WAVE) FMC_G64_MR(20, WAVE) FMC_G64_MR(24, WAVE) }
+      else { FMC_G64_MR(2, MR_LN) FMC_G64_MR(3, MR_LN) FMC_G64_MR(4, MR_LN) FMC_G64_MR(5, MR_LN) FMC_G64_MR(6, MR_LN) FMC_G64_MR(7, MR_LN) FMC_G64_MR(8, MR_LN)
+             FMC_G64_MR(9, MR_LN) FMC_G64_MR(10, MR_LN) FMC_G64_MR(12, MR_LN) FMC_G64_MR(14, MR_LN) FMC_G64_MR(16, MR_LN) FMC_G64_MR(18, MR_LN) FMC_G64_MR(20, MR_LN) FMC_G64_MR(24, MR_LN) }
+#undef FMC_G64_MR
+      return false;
+    }
+  }
   if (h->path != 1 || wave_rt_split(h->N) || pk_grid(h->N)) return false;
   int ns = 0, wpb = 0;
   wave_config<R>(h, &ns, &wpb);

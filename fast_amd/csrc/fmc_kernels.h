@@ -1094,9 +1094,12 @@ __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_rows_mr(Row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = LaneFam<R, P, LN>;
   using E = typename Xch<R>::E;
-  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  // MODE 2 (float64 generator fused into the rows, as in k_rows_wave): its 4 KB of tables at the start of the LDS
+  Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
   cpx<R>* s_om = s_tw + P * WAVE;
   E* s_x = reinterpret_cast<E*>(s_om + G::L0 * A.omS);
+  if constexpr (MODE == 2) load_gen64_table(s_g64, A.g64);
   load_tables_mr<R, P, LN>(s_tw, s_om, A.tw, A.om, A.omS);
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1130,6 +1133,21 @@ __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_rows_mr(Row
         xoshiro128p rs = row_stream(A.key, g, ky, sp + S * li, LN * S);
 #pragma unroll
         for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[S * (li + LN * j)]);
+      } else if constexpr (MODE == 2) {
+        // the generator at the reference's precision, one coefficient at a time (see k_rows_wave)
+        static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
+        const R* amp = A.amp + (size_t)ky * N + sp;
+        xoshiro128p rs = row_stream(A.key, g, ky, sp + S * li, LN * S), rl = row_stream_lo(A.key, g, ky, sp + S * li, LN * S);
+        double an = (double)amp[S * li];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          const double a = an;
+          if (j + 1 < P) an = (double)amp[S * (li + LN * (j + 1))];
+          ex.loadfence();
+          regs.v[j] = draw_coloured_f64(rs, rl, a, s_g64);
+          asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3), "+v"(rl.s0), "+v"(rl.s1),
+                       "+v"(rl.s2), "+v"(rl.s3));
+        }
       } else {
         const size_t base = ((size_t)b * N + ky) * N + sp;
         const R* amp = A.amp + (size_t)ky * N + sp;

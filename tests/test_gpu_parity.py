@@ -1232,7 +1232,14 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (896, 100, None, "k_rows_wave<double, 14, 2, 2, 1, 0>"), (1152, 82, None, "k_rows_wave<double, 18, 2, 2, 1, 0>"),
             (1280, 82, None, "k_rows_wave<double, 20, 2, 2, 1, 0>"), (1280, 200, None, "k_rows_wave<double, 20, 4, 2, 1, 0>"),
             (1536, 120, 1400, "k_rows_wave<double, 24, 2, 2, 1, 0>"), (1536, 222, None, "k_rows_wave<double, 24, 4, 2, 1, 0>"),
-            (1792, 82, None, "k_rows_wave<double, 28, 2, 2, 1, 0>")]
+            (1792, 82, None, "k_rows_wave<double, 28, 2, 2, 1, 0>"),
+            # 50-lane family (N = 50 P S) and the run-time-split wave grids: the rows of fmc_mrfft.h
+            (100, 40, None, "k_rows_mr<double, 2, 2, 2, false, 50, 0>"), (300, 60, None, "k_rows_mr<double, 6, 2, 2, false, 50, 0>"),
+            (500, 82, None, "k_rows_mr<double, 10, 2, 2, false, 50, 0>"), (800, 96, 3, "k_rows_mr<double, 16, 2, 2, false, 50, 0>"),
+            (1000, 82, None, "k_rows_mr<double, 20, 2, 2, false, 50, 0>"), (1000, 200, None, "k_rows_mr<double, 20, 4, 2, false, 50, 0>"),
+            (1200, 100, None, "k_rows_mr<double, 24, 2, 2, false, 50, 0>"), (2000, 82, None, "k_rows_mr<double, 20, 2, 2, true, 50, 0>"),
+            (1750, 70, None, "k_rows_mr<double, 7, 2, 2, true, 50, 0>"), (1344, 82, None, "k_rows_mr<double, 7, 2, 2, true, 64, 0>"),
+            (2560, 120, None, "k_rows_mr<double, 20, 2, 2, true, 64, 0>")]
 
 
 @pytest.mark.parametrize("N,Np,lo,kernel", _FUSED64)

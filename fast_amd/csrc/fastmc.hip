@@ -1123,6 +1123,14 @@ static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
       hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 0, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_blu<R, P, NS, 0, BLK>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
       FMC_NOTE(h->last_rows, "k_rows_blu<%s, %d, %d, %d, %s>", rname<R>(), P, NS, 0, BLK ? "true" : "false");
+    } else if (mode == 2) {
+      // the float64 generator fused into the row (run_impl: fused_gen64 has checked that its tables fit)
+      if constexpr (sizeof(R) == 8) {
+        const size_t lds2 = lds + GEN64_TABLE_BYTES;
+        hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 2, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipLaunchKernelGGL((k_rows_blu<R, P, NS, 2, BLK>), dim3(blocks), dim3(WPB * 64), lds2, h->stream, RA);
+        FMC_NOTE(h->last_rows, "k_rows_blu<%s, %d, %d, %d, %s>", rname<R>(), P, NS, 2, BLK ? "true" : "false");
+      }
     } else {
       hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 1, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_blu<R, P, NS, 1, BLK>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
@@ -1487,6 +1495,15 @@ static bool fused_gen64(fastmc_ctx* h) {
   if (getenv("FASTMC_GEN64_STAGED")) return false;          // A/B: the round-3 form (k_gen_coeffs_f64 -> cre / cim -> MODE 1 rows)
   if (h->path == 1 && pk_grid(h->N) && pk_variant<R>(h) >= 0) return true;      // 128 / 256 / 512: the packed rows draw it themselves too
   if constexpr (sizeof(R) == 8) {
+    if (h->path == 2) {      // chirp-z family: its rows draw it too where the tables fit
+      const int ns2 = h->NS <= 2 ? 2 : 4;
+      const int omS = h->omS;
+#define FMC_G64_BLU(PP, NN) if (h->blu_P == PP && ns2 == NN) return blu_lds_bytes<R, PP, NN>(omS, BluCfg<R, PP, NN>::WPB) + GEN64_TABLE_BYTES <= LDS_MAX;
+      if (h->blu_SB > 1) { FMC_G64_BLU(16, 2) FMC_G64_BLU(16, 4) return false; }
+      FMC_G64_BLU(4, 2) FMC_G64_BLU(8, 2) FMC_G64_BLU(8, 4) FMC_G64_BLU(16, 2) FMC_G64_BLU(16, 4) FMC_G64_BLU(24, 2) FMC_G64_BLU(24, 4) FMC_G64_BLU(32, 2)
+#undef FMC_G64_BLU
+      return false;
+    }
     // 50-lane family (path 3) and the run-time-split wave grids: the kernels of fmc_mrfft.h, where their tables + 4 KB fit
     const bool ws = h->path == 1 && wave_rt_split(h->N);
     if (h->path == 3 || ws) {

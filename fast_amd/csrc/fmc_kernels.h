@@ -887,11 +887,14 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using BG = BluGeom<R, P>;
   using E = typename Xch<R>::E;
-  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  // MODE 2 (float64 generator fused into the rows, as in k_rows_wave): its 4 KB of tables at the start of the LDS
+  Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
   cpx<R>* s_om = s_tw + P * WAVE;
   cpx<R>* s_twf = s_om + 8 * A.omS;
   E* s_x = reinterpret_cast<E*>(s_twf + 64);
   for (int i = threadIdx.x; i < 64; i += blockDim.x) s_twf[i] = A.blu.twf[i];
+  if constexpr (MODE == 2) load_gen64_table(s_g64, A.g64);
   load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -929,6 +932,8 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
       const R* amp = A.amp + (size_t)ky * N;
       const size_t base = ((size_t)b * N + ky) * N;
       xoshiro128p rs = row_stream(A.key, g, ky, lane, WAVE);
+      xoshiro128p rl = rs;
+      if constexpr (MODE == 2) rl = row_stream_lo(A.key, g, ky, lane, WAVE);
       const int nj = A.blu.B / WAVE;                     // values per lane and block
 #pragma unroll 1
       for (int jb = 0; jb < A.blu.SB; ++jb) {
@@ -938,6 +943,13 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
           const int kx = k0 + lane + WAVE * j;
           const bool in = j < nj && kx < N;              // draws only for coefficients of the row, in stream order
           if (MODE == 0) regs.v[j] = in ? cmul(draw_coloured<R>(rs, ampf[kx]), pre[kx]) : mk<R>((R)0, (R)0);
+          else if constexpr (MODE == 2) {
+            if constexpr (sizeof(R) == 8) {
+              regs.v[j] = in ? cmul(draw_coloured_f64(rs, rl, (double)amp[kx], s_g64), pre[kx]) : mk<R>((R)0, (R)0);
+              asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3), "+v"(rl.s0), "+v"(rl.s1),
+                           "+v"(rl.s2), "+v"(rl.s3));
+            }
+          }
           else regs.v[j] = in ? cmul(cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]), pre[kx]) : mk<R>((R)0, (R)0);
         }
         bluestein_row<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, s_twf, vhat + (size_t)jb * (WAVE * P), A.Np);
@@ -954,6 +966,18 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
       for (int j = 0; j < P; ++j) {
         const int kx = lane + WAVE * j;
         regs.v[j] = kx < N ? cmul(draw_coloured<R>(rs, ampf[kx]), pre[kx]) : mk<R>((R)0, (R)0);
+      }
+    } else if constexpr (MODE == 2) {
+      // the generator at the reference's precision, one coefficient at a time (see k_rows_wave)
+      static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
+      const R* amp = A.amp + (size_t)ky * N;
+      xoshiro128p rs = row_stream(A.key, g, ky, lane, WAVE), rl = row_stream_lo(A.key, g, ky, lane, WAVE);
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int kx = lane + WAVE * j;
+        regs.v[j] = kx < N ? cmul(draw_coloured_f64(rs, rl, (double)amp[kx], s_g64), pre[kx]) : mk<R>((R)0, (R)0);
+        asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3), "+v"(rl.s0), "+v"(rl.s1),
+                     "+v"(rl.s2), "+v"(rl.s3));
       }
     } else {
       const size_t base = ((size_t)b * N + ky) * N;

@@ -1239,12 +1239,16 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (1000, 82, None, "k_rows_mr<double, 20, 2, 2, false, 50, 0>"), (1000, 200, None, "k_rows_mr<double, 20, 4, 2, false, 50, 0>"),
             (1200, 100, None, "k_rows_mr<double, 24, 2, 2, false, 50, 0>"), (2000, 82, None, "k_rows_mr<double, 20, 2, 2, true, 50, 0>"),
             (1750, 70, None, "k_rows_mr<double, 7, 2, 2, true, 50, 0>"), (1344, 82, None, "k_rows_mr<double, 7, 2, 2, true, 64, 0>"),
-            (2560, 120, None, "k_rows_mr<double, 20, 2, 2, true, 64, 0>")]
+            (2560, 120, None, "k_rows_mr<double, 20, 2, 2, true, 64, 0>"),
+            # chirp-z family (any other N): one transform of length 64 P, and rows in input blocks beyond 2048
+            (164, 60, None, "k_rows_blu<double, 4, 2, 2, false>"), (291, 82, 5, "k_rows_blu<double, 8, 2, 2, false>"),
+            (722, 200, None, "k_rows_blu<double, 16, 4, 2, false>"), (1111, 82, None, "k_rows_blu<double, 24, 2, 2, false>"),
+            (1901, 82, None, "k_rows_blu<double, 32, 2, 2, false>"), (3901, 82, None, "k_rows_blu<double, 16, 2, 2, true>")]
 
 
 @pytest.mark.parametrize("N,Np,lo,kernel", _FUSED64)
 def test_fused_float64_generator_rows_match_the_oracle_on_restated_draws(N, Np, lo, kernel):
-    """MODE 2 of the P = 16 row kernels (fmc_kernels.h): the float64 generator drawn inside the row.  Powers against the
+    """MODE 2 of the row kernels of every FFT family (fmc_kernels.h): the float64 generator drawn inside the row.  Powers against the
     oracle on oracle/devrng.py's float64 restatement at the float64 pipeline's bar (1e-9: nothing float32 is left in the
     path), the kernel that ran is the fused one, and the staged form (FASTMC_GEN64_STAGED: k_gen_coeffs_f64 -> MODE 1 rows)
     is covered by test_float64_device_generator_matches_its_restatement on the other families."""

@@ -424,7 +424,7 @@ class Handle:
 
     def set_rng_precision(self, precision):
         """Device generator: 'f32' (default) or 'f64' (the reference's 53-bit normals and float64 colouring: fused into the
-        row kernels at 1024 / 2048 / 4096, staged in device memory on the other grids)."""
+        row kernels of every FFT family where its 4 KB of tables fit the LDS, staged in device memory otherwise)."""
         _chk(lib().fastmc_set_rng_precision(self._h, {"f64": F64, "f32": F32}[precision]))
 
     # ---- RCCL (the communicator belongs to the handle's DEVICE and outlives the handle)

@@ -15,8 +15,8 @@ Differences from the reference, all deliberate:
     for its SEED without a host draw (fast_amd/npnormal.py, csrc/fmc_npstream.h);
   * `GPU_PRECISION`: 'f64' (default, complex128 like the reference) or 'f32';
   * `GPU_RNG_PRECISION`: 'f32' (default) or 'f64' -- the device generator's normals and the colouring multiply at the
-    reference's float64 precision (funcs.py:352-356, fast.py:594), fused into the row kernels at 1024 / 2048 / 4096 (half
-    the float32 generator's rate), staged through device memory on the other grids;
+    reference's float64 precision (funcs.py:352-356, fast.py:594), fused into the row kernels of every FFT family (half to
+    three quarters of the float32 generator's rate), staged through device memory by the direct kernels;
   * `TEMPORAL` (frozen-flow time series, fast.py:607-637): the layer screens, the bilinear shifts and
     the detector run on the GPU; its draws are always numpy's, in the reference's order (the
     series is sequential and tiny), so the same SEED reproduces the reference;

@@ -279,9 +279,10 @@ int fastmc_set_batch(fastmc_t* h, int batch);
  * colouring, fused into the row kernels.  FASTMC_F64: the reference's precision (fast/funcs.py:352-356 draws 53-bit normals,
  * fast/fast.py:594 colours in float64): the same streams with the low bits from a second stream, float64 log / sqrt /
  * sincos in ~90 instructions per coefficient (fast_amd/csrc/fmc_gen64.h: table-driven log, seeded Newton square root,
- * fdlibm kernels; draws within 3e-15 of the libm restatement), FUSED into the row kernels of the 1024 / 2048 / 4096 grids
- * (no coefficient passes through device memory: about half the float32 generator's rate) and staged through device memory
- * for the other kernel families (coloured in float64 by the host-coefficient kernels).  Both restated in oracle/devrng.py.  fastmc_rng_coeffs / fastmc_rng_logamp return the draws of the precision in force. */
+ * fdlibm kernels; draws within 3e-15 of the libm restatement), FUSED into the row kernels of every FFT family (wave, packed,
+ * 50-lane, run-time-split, chirp-z) wherever its 4 KB of tables fit the LDS (no coefficient passes through device memory: half
+ * to three quarters of the float32 generator's rate) and staged through device memory otherwise (the direct kernels; coloured
+ * in float64 by the host-coefficient kernels).  Both restated in oracle/devrng.py.  fastmc_rng_coeffs / fastmc_rng_logamp return the draws of the precision in force. */
 int fastmc_set_rng_precision(fastmc_t* h, int precision);
 
 /* ---- AO-residual power spectrum (Fast.compute_powerspec, fast/fast.py:445-492) ---- */

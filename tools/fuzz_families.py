@@ -37,12 +37,21 @@ for c in range(cases):
     h.set_pupil(np.ones((Np, Np)), lo, 0.01)
     a = h.screens_coeffs(cr, ci)
     ra = h.run(c + 1, 3, 2, None, 0.01)              # device generator, detector, finalize
+    g64 = prec == "f64" and os.environ.get("FUZZ_GEN64", "1") != "0"
+    if g64:                                          # ... and the float64 generator, fused into the family's rows (MODE 2) where it has the form
+        h.set_rng_precision("f64")
+        ra64 = h.run(c + 1, 3, 2, None, 0.01)
+        h.set_rng_precision("f32")
     path = h.kernel_path()
     h.kernel_path(0)
     b = h.screens_coeffs(cr, ci)
     rb = h.run(c + 1, 3, 2, None, 0.01)
-    h.close()
     err = max(np.abs(a - b).max() / np.abs(b).max(), np.abs(ra - rb).max() / np.abs(rb).max() * (1e-2 if prec == "f32" else 1e-1))
+    if g64:                                          # the direct family stages the same draws (k_gen_coeffs_f64): float64 end to end
+        h.set_rng_precision("f64")
+        rb64 = h.run(c + 1, 3, 2, None, 0.01)
+        err = max(err, np.abs(ra64 - rb64).max() / np.abs(rb64).max() * 1e-1)
+    h.close()
     ref_err = float("nan")
     if N <= 1024:
         z = np.fft.fftshift(np.fft.fft2(np.fft.fftshift((cr[0] + 1j * ci[0]) * np.sqrt(ps) * 0.37)))[lo:lo + Np, lo:lo + Np]

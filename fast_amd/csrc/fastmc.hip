@@ -960,6 +960,26 @@ static int device_cus(int device) {
   cus[device] = n;
   return n;
 }
+// Rows per wave of a row-kernel launch: ROWS_PER_WAVE (8) when the launch is many rounds of workgroups; a SMALL launch (a chunk
+// of 50 realisations at 1024^2 is 400 workgroups' worth on 256 CUs, one workgroup per CU: two rounds for 1.56 of work) takes the
+// divisor that wastes the least of its last round -- 7 % per halving is what the shorter walk costs (table preloads per wave).
+template <class R>
+static int pick_rpw(fastmc_ctx* h, int N, int nb, int WPB) {
+  constexpr int LR = 128 / (int)sizeof(cpx<R>);
+  const int step = LR / std::gcd(WPB, LR);                // rows per wave come in multiples of this (whole 128-byte lines)
+  const int cus = device_cus(h->device);
+  const int64_t row_blocks = (N + LR - 1) / LR;
+  double best = 1e300;
+  int pick = ROWS_PER_WAVE;
+  for (int rpw = ROWS_PER_WAVE; rpw >= step; rpw /= 2) {
+    if (rpw % step) break;
+    const int bpg = rpw * WPB / LR;
+    const int64_t blocks = row_blocks * ((nb + bpg - 1) / bpg);
+    const double cost = (double)((blocks + cus - 1) / cus) * rpw * (1.0 + 0.07 * std::log2((double)ROWS_PER_WAVE / rpw));
+    if (cost < best * 0.999) { best = cost; pick = rpw; }
+  }
+  return pick;
+}
 #define FMC_NOTE(dst, ...) snprintf(dst, sizeof(dst), __VA_ARGS__)
 template <class R, int P, int NS, int MODE, int S = 1, int D = 0>
 static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
@@ -967,22 +987,8 @@ static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
   hipFuncSetAttribute((const void*)k_rows_wave<R, P, NS, MODE, S, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   constexpr int WPB = WCfg<R, P, NS, D>::WPB;
   constexpr int LR = 128 / (int)sizeof(cpx<R>);
-  // Rows per wave: ROWS_PER_WAVE (8) when the launch is many rounds of workgroups; a SMALL launch (a chunk of 50 realisations
-  // at 1024^2 is 400 workgroups' worth on 256 CUs, one workgroup per CU: two rounds for 1.56 of work) takes the divisor that
-  // wastes the least of its last round -- 7 % per halving is what the shorter walk costs (twiddle preload per wave).
   RowArgs<R> B = A;
-  {
-    constexpr int step = LR / std::gcd(WPB, LR);                // rows per wave come in multiples of this (whole 128-byte lines)
-    const int cus = device_cus(h->device);
-    double best = 1e300;
-    for (int rpw = ROWS_PER_WAVE; rpw >= step; rpw /= 2) {
-      if (rpw % step) break;
-      const int bpg = rpw * WPB / LR;
-      const int64_t blocks = (int64_t)(A.N / LR) * ((A.nb + bpg - 1) / bpg);
-      const double cost = (double)((blocks + cus - 1) / cus) * rpw * (1.0 + 0.07 * std::log2((double)ROWS_PER_WAVE / rpw));
-      if (cost < best * 0.999) { best = cost; B.rpw = rpw; }
-    }
-  }
+  B.rpw = pick_rpw<R>(h, A.N, A.nb, WPB);
   const int BPG = B.rpw * WPB / LR;
   const int blocks = (A.N / LR) * ((A.nb + BPG - 1) / BPG);
   hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE, S, D>), dim3(blocks), dim3(WPB * 64), lds, h->stream, B);
@@ -1115,25 +1121,28 @@ template <class R, int P, int NS, bool BLK = false>
 static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   constexpr int WPB = BluCfg<R, P, NS>::WPB, WPC = BLK ? BluCfg<R, P, NS>::WPB : BluCfg<R, P, NS>::WPB_COLS;
   const size_t lds = blu_lds_bytes<R, P, NS>(RA.omS, WPB), ldc = blu_lds_bytes<R, P, NS>(RA.omS, WPC);
-  constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
+  constexpr int LR = 128 / (int)sizeof(cpx<R>);
+  RowArgs<R> RB = RA;
+  RB.rpw = pick_rpw<R>(h, RA.N, RA.nb, WPB);
+  const int BPG = RB.rpw * WPB / LR;
   const int blocks = ((RA.N + LR - 1) / LR) * ((RA.nb + BPG - 1) / BPG);
   {
     Span s(h, 0);
     if (mode == 0) {
       hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 0, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_blu<R, P, NS, 0, BLK>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      hipLaunchKernelGGL((k_rows_blu<R, P, NS, 0, BLK>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RB);
       FMC_NOTE(h->last_rows, "k_rows_blu<%s, %d, %d, %d, %s>", rname<R>(), P, NS, 0, BLK ? "true" : "false");
     } else if (mode == 2) {
       // the float64 generator fused into the row (run_impl: fused_gen64 has checked that its tables fit)
       if constexpr (sizeof(R) == 8) {
         const size_t lds2 = lds + GEN64_TABLE_BYTES;
         hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 2, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        hipLaunchKernelGGL((k_rows_blu<R, P, NS, 2, BLK>), dim3(blocks), dim3(WPB * 64), lds2, h->stream, RA);
+        hipLaunchKernelGGL((k_rows_blu<R, P, NS, 2, BLK>), dim3(blocks), dim3(WPB * 64), lds2, h->stream, RB);
         FMC_NOTE(h->last_rows, "k_rows_blu<%s, %d, %d, %d, %s>", rname<R>(), P, NS, 2, BLK ? "true" : "false");
       }
     } else {
       hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 1, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_blu<R, P, NS, 1, BLK>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      hipLaunchKernelGGL((k_rows_blu<R, P, NS, 1, BLK>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RB);
       FMC_NOTE(h->last_rows, "k_rows_blu<%s, %d, %d, %d, %s>", rname<R>(), P, NS, 1, BLK ? "true" : "false");
     }
   }
@@ -1170,25 +1179,28 @@ template <class R, int P, int NS, bool SPLIT, int LN, int PR>
 static void launch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   constexpr int WPB = MrCfg<R, P, NS, LN>::WPB;
   const size_t lds = mr_lds_bytes<R, P, NS, LN>(RA.omS);
-  constexpr int LR = 128 / (int)sizeof(cpx<R>), BPG = ROWS_PER_WAVE * WPB / LR;
+  constexpr int LR = 128 / (int)sizeof(cpx<R>);
+  RowArgs<R> RB = RA;
+  RB.rpw = pick_rpw<R>(h, RA.N, RA.nb, WPB);
+  const int BPG = RB.rpw * WPB / LR;
   const int blocks = ((RA.N + LR - 1) / LR) * ((RA.nb + BPG - 1) / BPG);
   {
     Span s(h, 0);
     if (mode == 0) {
       hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 0, SPLIT, LN, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 0, SPLIT, LN, PR>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 0, SPLIT, LN, PR>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RB);
       FMC_NOTE(h->last_rows, "k_rows_mr<%s, %d, %d, %d, %s, %d, %d>", rname<R>(), P, NS, 0, SPLIT ? "true" : "false", LN, PR);
     } else if (mode == 2) {
       // the float64 generator fused into the row (run_impl: fused_gen64 has checked that its tables fit)
       if constexpr (PR == 0 && sizeof(R) == 8) {
         const size_t lds2 = lds + GEN64_TABLE_BYTES;
         hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 2, SPLIT, LN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        hipLaunchKernelGGL((k_rows_mr<R, P, NS, 2, SPLIT, LN, 0>), dim3(blocks), dim3(WPB * 64), lds2, h->stream, RA);
+        hipLaunchKernelGGL((k_rows_mr<R, P, NS, 2, SPLIT, LN, 0>), dim3(blocks), dim3(WPB * 64), lds2, h->stream, RB);
         FMC_NOTE(h->last_rows, "k_rows_mr<%s, %d, %d, %d, %s, %d, %d>", rname<R>(), P, NS, 2, SPLIT ? "true" : "false", LN, 0);
       }
     } else if constexpr (PR == 0) {
       hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 1, SPLIT, LN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 1, SPLIT, LN, 0>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RA);
+      hipLaunchKernelGGL((k_rows_mr<R, P, NS, 1, SPLIT, LN, 0>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RB);
       FMC_NOTE(h->last_rows, "k_rows_mr<%s, %d, %d, %d, %s, %d, %d>", rname<R>(), P, NS, 1, SPLIT ? "true" : "false", LN, 0);
     }
   }

@@ -160,7 +160,7 @@ struct BluArgs {
 template <class R>
 struct RowArgs {
   int N, Np, lo, nb;            // grid size, window size, first window index, realisations in this launch
-  int rpw = 0;                  // k_rows_wave: rows per wave of this launch (0: ROWS_PER_WAVE); small launches take fewer (launch_rows_wave)
+  int rpw = 0;                  // k_rows_wave / _mr / _blu: rows per wave of this launch (0: ROWS_PER_WAVE); small launches take fewer (pick_rpw)
   const R* amp;                 // [N][N] sqrt(powerspec)*df  (wave family: with (-1)^(ky+kx) folded in); host-coefficient mode
   const float* ampf;            // the same table rounded to float32: colouring of the device generator's float32 normals
   const cpx<R>* tw;             // wave: tw1 [P*64];  direct: w_N^e, e < N
@@ -905,11 +905,12 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
   constexpr int WPB = BluCfg<R, P, NS>::WPB;
   constexpr int LR = 128 / (int)sizeof(cpx<R>);
   static_assert((ROWS_PER_WAVE * WPB) % LR == 0, "tile must hold whole lines");
-  constexpr int BPG = ROWS_PER_WAVE * WPB / LR;
+  const int rpw = A.rpw ? A.rpw : ROWS_PER_WAVE;         // (launch: pick_rpw)
+  const int BPG = rpw * WPB / LR;
   const int nbb = (A.nb + BPG - 1) / BPG;
   const int b0 = (blockIdx.x % nbb) * BPG;
   const int row0 = (blockIdx.x / nbb) * LR;
-  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+  for (int rr = 0; rr < rpw; ++rr) {
     const int flat = rr * WPB + w;
     const int b = b0 + flat / LR;
     if (b >= A.nb) break;                                // wave-uniform
@@ -1136,11 +1137,12 @@ __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_rows_mr(Row
   constexpr int WPB = MrCfg<R, P, NS, LN>::WPB;
   constexpr int LR = 128 / (int)sizeof(cpx<R>);
   static_assert((ROWS_PER_WAVE * WPB) % LR == 0, "tile must hold whole lines");
-  constexpr int BPG = ROWS_PER_WAVE * WPB / LR;
+  const int rpw = A.rpw ? A.rpw : ROWS_PER_WAVE;         // (launch: pick_rpw)
+  const int BPG = rpw * WPB / LR;
   const int nbb = (A.nb + BPG - 1) / BPG;
   const int b0 = (blockIdx.x % nbb) * BPG;
   const int row0 = (blockIdx.x / nbb) * LR;
-  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+  for (int rr = 0; rr < rpw; ++rr) {
     const int flat = rr * WPB + w;
     const int b = b0 + flat / LR;
     if (b >= A.nb) break;                                // wave-uniform

@@ -428,7 +428,12 @@ static HandleCache g_handles;
 extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int precision) {
   if (!out) return fail(FASTMC_EINVAL, "handle pointer is NULL");
   *out = nullptr;
-  if (N < 4 || N > 4096) return fail(FASTMC_EINVAL, "N must be in [4, 4096]");
+  // Every N <= 4096 has a kernel family.  Beyond it the grids with a run-time sub-row count go on: N = 64 P S (wave_rt_split:
+  // 4608, 5120, 6144, 6400, 7168, 7680, 8192 ...) and N = 50 P S (mr_split: 4200, 4500, 4800, 5000, 6000, 7000, 8000 ...), S <= 8
+  // sub-rows of P <= 24 values per lane -- nothing in their kernels depends on the size.  The cap of 8192 is memory and test
+  // coverage, not the kernels (the spectrum tables alone are 12 B per pixel: 0.8 GB at 8192^2).
+  if (N < 4 || (N > 4096 && !(N <= 8192 && (wave_rt_split(N) || mr_supported(N)))))
+    return fail(FASTMC_EINVAL, "N must be in [4, 4096], or a grid of S <= 8 sub-rows N = 64 P S / 50 P S (P <= 24) up to 8192");
   if (Np < 1 || Np > N) return fail(FASTMC_EINVAL, "Np must be in [1, N]");
   if (precision != FASTMC_F64 && precision != FASTMC_F32) return fail(FASTMC_EINVAL, "precision must be FASTMC_F64 or FASTMC_F32");
   int count = 0;
@@ -1276,7 +1281,7 @@ int dispatch_ws(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int m
     if (ns == 2) { dispatch_mr_pn<R, PP, 2, true, WAVE>(h, RA, CA, mode, epi); return 0; }                                   \
     if constexpr (has_ns4(PP)) { if (ns == 4) { dispatch_mr_pn<R, PP, 4, true, WAVE>(h, RA, CA, mode, epi); return 0; } }     \
   }
-  FMC_WS(7) FMC_WS(9) FMC_WS(10) FMC_WS(14) FMC_WS(18) FMC_WS(20) FMC_WS(24)
+  FMC_WS(7) FMC_WS(9) FMC_WS(10) FMC_WS(14) FMC_WS(16) FMC_WS(18) FMC_WS(20) FMC_WS(24)      // (16: 7168 and 8192 only)
 #undef FMC_WS
   return fail(FASTMC_ESTATE, "no run-time-split instantiation for this grid / window");
 }
@@ -1527,7 +1532,7 @@ static bool fused_gen64(fastmc_ctx* h) {
         if constexpr (LNN == MR_LN ? mr_has_ns4(PP) : has_ns4(PP)) return mr_lds_bytes<R, PP, 4, LNN>(omS) + GEN64_TABLE_BYTES <= LDS_MAX; \
         return false;                                                                                           \
       }
-      if (ws) { FMC_G64_MR(7, WAVE) FMC_G64_MR(9, WAVE) FMC_G64_MR(10, WAVE) FMC_G64_MR(14, WAVE) FMC_G64_MR(18, WAVE) FMC_G64_MR(20, WAVE) FMC_G64_MR(24, WAVE) }
+      if (ws) { FMC_G64_MR(7, WAVE) FMC_G64_MR(9, WAVE) FMC_G64_MR(10, WAVE) FMC_G64_MR(14, WAVE) FMC_G64_MR(16, WAVE) FMC_G64_MR(18, WAVE) FMC_G64_MR(20, WAVE) FMC_G64_MR(24, WAVE) }
       else { FMC_G64_MR(2, MR_LN) FMC_G64_MR(3, MR_LN) FMC_G64_MR(4, MR_LN) FMC_G64_MR(5, MR_LN) FMC_G64_MR(6, MR_LN) FMC_G64_MR(7, MR_LN) FMC_G64_MR(8, MR_LN)
              FMC_G64_MR(9, MR_LN) FMC_G64_MR(10, MR_LN) FMC_G64_MR(12, MR_LN) FMC_G64_MR(14, MR_LN) FMC_G64_MR(16, MR_LN) FMC_G64_MR(18, MR_LN) FMC_G64_MR(20, MR_LN) FMC_G64_MR(24, MR_LN) }
 #undef FMC_G64_MR

@@ -405,7 +405,8 @@ FMC_HD constexpr int wave_rt_split(int N) {
   if (N % 64 != 0 || N == 2048 || N == 4096) return 0;
   const int q = N / 64;
   if (mr_supported_P(q)) return 0;
-  for (int S = 2; S <= 4; ++S)
+  const int smax = N > 4096 ? 8 : 4;        // beyond 4096: up to eight sub-rows (8192 = 8 x 1024, 7168 = 7 x 1024, 6400 = 5 x 1280, ...)
+  for (int S = 2; S <= smax; ++S)
     if (q % S == 0 && q / S >= 7 && q / S <= 24 && mr_supported_P(q / S)) return S;
   return 0;
 }
@@ -421,7 +422,8 @@ FMC_HD constexpr int mr_split(int N) {       // 0: not a size of the family
   if (N == 2048 || N == 4096 || (N % 64 == 0 && (mr_supported_P(N / 64) || wave_rt_split(N)))) return 0;
   const int q = N / MR_LN;
   if (q <= 24) return mr_supported_P(q) ? 1 : 0;
-  for (int S = 2; S <= 5; ++S)
+  const int smax = N > 4096 ? 8 : 5;        // beyond 4096: up to eight sub-rows (6400 = 8 x 800, 7000 = 7 x 1000, 8000 = 8 x 1000, ...)
+  for (int S = 2; S <= smax; ++S)
     if (q % S == 0 && q / S >= 7 && q / S <= 24 && mr_supported_P(q / S)) return S;
   return 0;
 }

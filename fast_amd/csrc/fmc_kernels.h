@@ -1281,9 +1281,9 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_rows_direct(RowArgs<R> A) {
     for (int i = threadIdx.x; i < N; i += blockDim.x) s_lds[i] = A.tw[i];
   if (MODE == 0) {
     const int SL = stream_lanes(N);
-    if ((int)threadIdx.x < SL && (int)threadIdx.x < N) {   // one sequential stream per stream index
-      xoshiro128p rs = row_stream(A.key, g, ky, threadIdx.x, SL);
-      for (int kx = threadIdx.x; kx < N; kx += SL) s_row[kx] = draw_coloured<R>(rs, A.ampf[(size_t)ky * N + kx]);
+    for (int L = threadIdx.x; L < SL && L < N; L += blockDim.x) {   // one sequential stream per stream index (SL > blockDim beyond 4096)
+      xoshiro128p rs = row_stream(A.key, g, ky, L, SL);
+      for (int kx = L; kx < N; kx += SL) s_row[kx] = draw_coloured<R>(rs, A.ampf[(size_t)ky * N + kx]);
     }
   } else {
     const size_t base = ((size_t)b * N + ky) * N;

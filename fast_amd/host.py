@@ -20,7 +20,30 @@ TWO_PI = 2 * np.pi
 # grid sizes served by the wave-FFT kernels: 64 * 2^k * {1, 3, 5, 7, 9}, 128 ... 2048 (fmc_wavefft.h), and 4096
 # (4 interleaved sub-rows of 1024; 2048 runs as 2)
 WAVE_FFT_SIZES = sorted(64 * q * 2 ** k for q in (1, 3, 5, 7, 9) for k in range(6) if 2 <= q * 2 ** k <= 32) + [4096]
-MAX_NPXLS = 4096          # libfastmc: N <= 4096 (fastmc_create)
+MAX_NPXLS = 4096          # libfastmc: every N <= 4096 has a kernel family (fastmc_create) ...
+MAX_NPXLS_SUBROWS = 8192  # ... and the grids N = 64 P S / 50 P S of S <= 8 sub-rows (P <= 24 values per lane) go on to 8192
+
+
+def _radix_ok(q):
+    if q < 2 or q > 32:
+        return False
+    while q % 2 == 0:
+        q //= 2
+    return q in (1, 3, 5, 7, 9)
+
+
+def big_grid_supported(N):
+    """Grids beyond 4096 that libfastmc serves (fmc_core.h: wave_rt_split / mr_split with up to eight sub-rows): N = 64 P S or
+    50 P S, S <= 8, 7 <= P <= 24, P = 2^k times 1, 3, 5, 7 or 9 -- 4608, 4800, 5000, 5120, 6000, 6144, 6400, 7000, 7168, 7680,
+    8000, 8192 ..."""
+    if N <= MAX_NPXLS or N > MAX_NPXLS_SUBROWS:
+        return False
+    for unit in (64, 50):
+        if N % unit == 0:
+            q = N // unit
+            if any(q % S == 0 and 7 <= q // S <= 24 and _radix_ok(q // S) for S in range(2, 9)):
+                return True
+    return False
 # Measured float64 throughput [k iterations/s, Np = 82, device generator] of every grid size that has an FFT kernel family
 # (tools/sizesweep.sh on one MI355X; profiles/r01k_sizesweep_f64.txt, r02g_sizesweep_lanes50_f64.txt, r03_packed_rows_rates.txt for
 # 128 / 256 / 512, DESIGN.md section 4):
@@ -134,11 +157,12 @@ def grid_size(p, atm):
         N = p['NPXLS']
     if N > 2048:
         logger.warning(f"NPXLS is large ({N}) and may cause very high memory usage")
-    if N > MAX_NPXLS:
+    if N > MAX_NPXLS and not big_grid_supported(N):
         # fail before any O(N^2) host work; a TEMPORAL series auto-sizes to half its total wind
         # displacement (fast.py:201-206), which outgrows the kernels quickly
         hint = " (TEMPORAL: fewer steps per object, a shorter DT or a coarser DX)" if p['TEMPORAL'] else ""
-        raise Exception(f"NPXLS = {N} exceeds the GPU kernels' limit of {MAX_NPXLS}{hint}")
+        raise Exception(f"NPXLS = {N} exceeds the GPU kernels' limit of {MAX_NPXLS} (beyond it only grids of up to eight sub-rows, "
+                        f"N = 64 P S or 50 P S up to {MAX_NPXLS_SUBROWS}: 4608, 5000, 5120, 6000, 6144, 7000, 8000, 8192 ...){hint}")
     Np = int(np.ceil(D / dx)) + 2
     return dx, int(N), Np
 

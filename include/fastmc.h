@@ -17,7 +17,8 @@
  *     with a deadline (FASTMC_HANDLE_BUSY_TIMEOUT seconds, default 30): a second caller waits its turn and then fails with
  *     FASTMC_ESTATE instead of racing the first -- the case that matters is an exchange a deadline thread is still inside
  *     while its caller, having called fastmc_comm_abort (which takes no handle lock), goes on with the handle;
- *   - N <= 4096, Np <= N; fastmc_destroy() parks ONE retired handle per device, whole (stream, buffers), and
+ *   - N <= 4096 (every N has a kernel family; beyond it the grids N = 64 P S / 50 P S of S <= 8 sub-rows, P <= 24, up to 8192:
+ *     4608, 5000, 5120, 6000, 6144, 7000, 7168, 8000, 8192 ...), Np <= N; fastmc_destroy() parks ONE retired handle per device, whole (stream, buffers), and
  *     fastmc_create() of the same (N, Np, precision) on that device takes it back, reset to the state of a new
  *     handle (sweeps build one short-lived handle per geometry sample); a handle it displaces is freed, except
  *     for the largest work buffer of the device, which is kept for the next handle;

@@ -109,7 +109,7 @@ def wave_rt_split(N):
     q = N // 64
     if _radix_ok(q):
         return 0
-    for S in (2, 3, 4):
+    for S in range(2, (8 if N > 4096 else 4) + 1):          # beyond 4096: up to eight sub-rows (8192 = 8 x 1024)
         if q % S == 0 and 7 <= q // S <= 24 and _radix_ok(q // S):
             return S
     return 0
@@ -132,7 +132,7 @@ def mr_split(N):
     q = N // 50
     if q <= 24:
         return 1 if ok(q) else 0
-    for S in range(2, 6):
+    for S in range(2, (8 if N > 4096 else 5) + 1):          # beyond 4096: up to eight sub-rows (8000 = 8 x 1000)
         if q % S == 0 and 7 <= q // S <= 24 and ok(q // S):
             return S
     return 0

@@ -1407,3 +1407,40 @@ def test_dense_sixteen_wave_kernels_equal_the_twelve_wave_kernels():
     np.testing.assert_allclose(outs[0], outs[1], rtol=1e-12)
     h, ps, df, W = _small_problem(1024, 82)
     np.testing.assert_array_equal(h.run(17, 2, 40, None, 0.02), outs[0 if not os.environ.get("FASTMC_NO_DENSE16") else 1])
+
+
+# ------------------------------------------------------------------ grids beyond 4096 (the reference has no upper limit, fast.py:176-211)
+@pytest.mark.parametrize("N,Np,kernel", [(4608, 60, "k_rows_mr<double, 24, 2, 0, true, 64, 2>"), (5000, 82, "k_rows_mr<double, 20, 2, 0, true, 50, 1>"),
+                                         (7168, 100, "k_rows_mr<double, 16, 2, 0, true, 64, 0>"), (8192, 82, "k_rows_mr<double, 16, 2, 0, true, 64, 2>")])
+def test_grids_beyond_4096_run_as_up_to_eight_sub_rows(N, Np, kernel):
+    """N = 64 P S / 50 P S with a run-time sub-row count S <= 8 (fmc_core.h: wave_rt_split / mr_split) up to 8192: screens from
+    host coefficients against numpy's FFT; the device generator through the family's rows against the oracle on the restated
+    draws (one size: the restatement is Python) and against the direct family on the same seed; the float64 generator fused in
+    the rows against the direct family's staged draws."""
+    rng = np.random.default_rng(N)
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    ps = ps * 0.02
+    lo = (N - Np) // 2
+    W = _window_W(Np)
+    h = _lib.Handle(N, Np, "f64", 0)
+    h.set_spectrum(ps, df)
+    h.set_pupil(W, lo, 0.01)
+    cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
+    a = h.screens_coeffs(cr, ci)
+    z = np.fft.fftshift(np.fft.fft2(np.fft.fftshift((cr[0] + 1j * ci[0]) * np.sqrt(ps) * df)))[lo:lo + Np, lo:lo + Np]
+    assert max(np.abs(a[0] - z.real).max(), np.abs(a[1] - z.imag).max()) < 1e-12 * np.abs(z).max()
+    del cr, ci, z
+    seed, real0 = 5, 2 ** 32 + 1
+    got = h.run(seed, real0, 1, None, 0.01)
+    assert h.last_kernels()[0] == kernel
+    if N == 4608:
+        want = _oracle_powers_from_restated_draws(seed, real0, 1, ps, df, W, lo, 0.01, 0.01)
+        np.testing.assert_allclose(got, want, rtol=1e-5)
+    h.set_rng_precision("f64")
+    got64 = h.run(seed, real0, 1, None, 0.01)
+    assert ", 2, true," in h.last_kernels()[0]                  # MODE 2: the float64 generator inside the row
+    h.kernel_path(0)
+    np.testing.assert_allclose(got64, h.run(seed, real0, 1, None, 0.01), rtol=1e-9)
+    h.set_rng_precision("f32")
+    np.testing.assert_allclose(got, h.run(seed, real0, 1, None, 0.01), rtol=1e-9)
+    h.close()

@@ -242,3 +242,17 @@ def test_grid_beyond_the_kernels_limit_is_a_clear_exception():
     q.update({"NITER": 200000, "NCHUNKS": 10, "DT": 0.01})        # 32.6 m/s x 0.01 s x 200 000 steps / 1 cm / 2 = 3.3e6 columns
     with pytest.raises(Exception, match="limit of 4096.*TEMPORAL"):
         fast_amd.Fast(q)
+
+
+def test_grids_beyond_4096_that_the_kernels_serve():
+    """host.big_grid_supported restates fastmc_create's rule: N = 64 P S or 50 P S, S <= 8 sub-rows of 7 <= P <= 24 values per
+    lane (P = 2^k times 1, 3, 5, 7 or 9), up to 8192."""
+    from fast_amd import host
+    yes = [4608, 4800, 5000, 5120, 6000, 6144, 6400, 7000, 7168, 7680, 8000, 8192]
+    no = [4096, 4098, 4100, 5632, 8193, 8256, 9000, 9600, 12288]
+    assert all(host.big_grid_supported(n) for n in yes) and not any(host.big_grid_supported(n) for n in no)
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from oracle import devrng
+    for n in yes:      # the restated stream layout knows them too (sub-rows x lanes)
+        assert devrng.stream_lanes(n) in (64 * devrng.spec_split(n), 50 * devrng.mr_split(n)) and devrng.stream_lanes(n) > 64

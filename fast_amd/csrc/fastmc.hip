@@ -354,9 +354,10 @@ static int blu_pick_P(int N, int Np, int* SB = nullptr, int* B = nullptr) {
     if (ns > 2 && !(P == 8 || P == 16 || P == 24)) continue;
     return P;
   }
-  // rows beyond the largest M: input blocks on the M = 1024 pipeline (2200, 2816, ... 4095)
+  // rows beyond the largest M: input blocks on the M = 1024 pipeline (2200, 2816, ... 4095: up to six blocks; beyond 4096 up to
+  // eleven: 8192 / 768 at Np = 256)
   const int nblk = blu_blocks(N, Np);
-  if (nblk >= 2 && nblk <= 8) {
+  if (nblk >= 2 && nblk <= 12) {
     if (SB) *SB = nblk;
     if (B) *B = blu_block_len(Np);
     return 16;
@@ -432,8 +433,10 @@ extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int p
   // 4608, 5120, 6144, 6400, 7168, 7680, 8192 ...) and N = 50 P S (mr_split: 4200, 4500, 4800, 5000, 6000, 7000, 8000 ...), S <= 8
   // sub-rows of P <= 24 values per lane -- nothing in their kernels depends on the size.  The cap of 8192 is memory and test
   // coverage, not the kernels (the spectrum tables alone are 12 B per pixel: 0.8 GB at 8192^2).
-  if (N < 4 || (N > 4096 && !(N <= 8192 && (wave_rt_split(N) || mr_supported(N)))))
-    return fail(FASTMC_EINVAL, "N must be in [4, 4096], or a grid of S <= 8 sub-rows N = 64 P S / 50 P S (P <= 24) up to 8192");
+  // ... and any other N <= 8192 through the chirp-z kernels with its rows in input blocks (blu_pick_P), for windows of up to 256 pixels.
+  if (N < 4 || (N > 4096 && !(N <= 8192 && (wave_rt_split(N) || mr_supported(N) || (Np >= 1 && Np <= N && blu_pick_P(N, Np))))))
+    return fail(FASTMC_EINVAL, "N must be in [4, 8192]; beyond 4096 the window must be at most 256 pixels unless N is a grid of S <= 8 sub-rows, "
+                               "N = 64 P S / 50 P S with 7 <= P <= 24");
   if (Np < 1 || Np > N) return fail(FASTMC_EINVAL, "Np must be in [1, N]");
   if (precision != FASTMC_F64 && precision != FASTMC_F32) return fail(FASTMC_EINVAL, "precision must be FASTMC_F64 or FASTMC_F32");
   int count = 0;

@@ -157,12 +157,13 @@ def grid_size(p, atm):
         N = p['NPXLS']
     if N > 2048:
         logger.warning(f"NPXLS is large ({N}) and may cause very high memory usage")
-    if N > MAX_NPXLS and not big_grid_supported(N):
+    if N > MAX_NPXLS_SUBROWS or (N > MAX_NPXLS and not big_grid_supported(N) and int(np.ceil(D / dx)) + 2 > 256):
         # fail before any O(N^2) host work; a TEMPORAL series auto-sizes to half its total wind
         # displacement (fast.py:201-206), which outgrows the kernels quickly
         hint = " (TEMPORAL: fewer steps per object, a shorter DT or a coarser DX)" if p['TEMPORAL'] else ""
-        raise Exception(f"NPXLS = {N} exceeds the GPU kernels' limit of {MAX_NPXLS} (beyond it only grids of up to eight sub-rows, "
-                        f"N = 64 P S or 50 P S up to {MAX_NPXLS_SUBROWS}: 4608, 5000, 5120, 6000, 6144, 7000, 8000, 8192 ...){hint}")
+        raise Exception(f"NPXLS = {N} exceeds the GPU kernels' limit of {MAX_NPXLS_SUBROWS if N > MAX_NPXLS_SUBROWS else MAX_NPXLS} "
+                        f"(every N <= {MAX_NPXLS}; up to {MAX_NPXLS_SUBROWS} with a pupil window of at most 256 pixels, or as a grid of "
+                        f"up to eight sub-rows, N = 64 P S or 50 P S: 4608, 5000, 5120, 6000, 6144, 7000, 8000, 8192 ...){hint}")
     Np = int(np.ceil(D / dx)) + 2
     return dx, int(N), Np
 

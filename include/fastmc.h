@@ -17,8 +17,9 @@
  *     with a deadline (FASTMC_HANDLE_BUSY_TIMEOUT seconds, default 30): a second caller waits its turn and then fails with
  *     FASTMC_ESTATE instead of racing the first -- the case that matters is an exchange a deadline thread is still inside
  *     while its caller, having called fastmc_comm_abort (which takes no handle lock), goes on with the handle;
- *   - N <= 4096 (every N has a kernel family; beyond it the grids N = 64 P S / 50 P S of S <= 8 sub-rows, P <= 24, up to 8192:
- *     4608, 5000, 5120, 6000, 6144, 7000, 7168, 8000, 8192 ...), Np <= N; fastmc_destroy() parks ONE retired handle per device, whole (stream, buffers), and
+ *   - N <= 8192: every N <= 4096 has a kernel family; beyond it the grids N = 64 P S / 50 P S of S <= 8 sub-rows (7 <= P <= 24:
+ *     4608, 5000, 5120, 6000, 6144, 7000, 7168, 8000, 8192 ...) for any window, every other N for windows of up to 256 pixels
+ *     (chirp-z kernels, rows in input blocks); Np <= N; fastmc_destroy() parks ONE retired handle per device, whole (stream, buffers), and
  *     fastmc_create() of the same (N, Np, precision) on that device takes it back, reset to the state of a new
  *     handle (sweeps build one short-lived handle per geometry sample); a handle it displaces is freed, except
  *     for the largest work buffer of the device, which is kept for the next handle;
@@ -197,7 +198,7 @@ int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches);
  *       row on these grids, whichever family transforms them;
  *   2 = chirp-z (any other N, odd included, with 64 P >= N + Np - 1 for P in {4, 8, 16, 24, 32} and Np <= 256: every 1-D
  *       transform as a Bluestein convolution on the same pipeline; default for N >= 96);
- *   0 = direct O(N^2 Np) pruned DFT (any N <= 4096; tiny grids, huge windows, cross-check of the other three).
+ *   0 = direct O(N^2 Np) pruned DFT (any N the LDS holds; tiny grids, huge windows, cross-check of the other three).
  * force: -1 query only, 0 / 1 / 2 / 3 select (fails with EINVAL if the family does not serve this (N, Np)). */
 int fastmc_kernel_path(fastmc_t* h, int force);
 

@@ -1411,12 +1411,14 @@ def test_dense_sixteen_wave_kernels_equal_the_twelve_wave_kernels():
 
 # ------------------------------------------------------------------ grids beyond 4096 (the reference has no upper limit, fast.py:176-211)
 @pytest.mark.parametrize("N,Np,kernel", [(4608, 60, "k_rows_mr<double, 24, 2, 0, true, 64, 2>"), (5000, 82, "k_rows_mr<double, 20, 2, 0, true, 50, 1>"),
-                                         (7168, 100, "k_rows_mr<double, 16, 2, 0, true, 64, 0>"), (8192, 82, "k_rows_mr<double, 16, 2, 0, true, 64, 2>")])
+                                         (7168, 100, "k_rows_mr<double, 16, 2, 0, true, 64, 0>"), (8192, 82, "k_rows_mr<double, 16, 2, 0, true, 64, 2>"),
+                                         (4100, 82, "k_rows_blu<double, 16, 2, 0, true>"), (7003, 200, "k_rows_blu<double, 16, 4, 0, true>")])
 def test_grids_beyond_4096_run_as_up_to_eight_sub_rows(N, Np, kernel):
-    """N = 64 P S / 50 P S with a run-time sub-row count S <= 8 (fmc_core.h: wave_rt_split / mr_split) up to 8192: screens from
-    host coefficients against numpy's FFT; the device generator through the family's rows against the oracle on the restated
-    draws (one size: the restatement is Python) and against the direct family on the same seed; the float64 generator fused in
-    the rows against the direct family's staged draws."""
+    """N = 64 P S / 50 P S with a run-time sub-row count S <= 8 (fmc_core.h: wave_rt_split / mr_split) up to 8192, and any other
+    N <= 8192 on the chirp-z kernels with its rows in up to eleven input blocks: screens from host coefficients against numpy's
+    FFT; the device generator through the family's rows against the oracle on the restated draws (one size: the restatement is
+    Python) and against the direct family on the same seed; the float64 generator fused in the rows against the direct family's
+    staged draws."""
     rng = np.random.default_rng(N)
     ps, df = _vk_spectrum(N, 0.01, 30.0)
     ps = ps * 0.02
@@ -1438,7 +1440,7 @@ def test_grids_beyond_4096_run_as_up_to_eight_sub_rows(N, Np, kernel):
         np.testing.assert_allclose(got, want, rtol=1e-5)
     h.set_rng_precision("f64")
     got64 = h.run(seed, real0, 1, None, 0.01)
-    assert ", 2, true," in h.last_kernels()[0]                  # MODE 2: the float64 generator inside the row
+    assert ", 2, true" in h.last_kernels()[0]                   # MODE 2: the float64 generator inside the row
     h.kernel_path(0)
     np.testing.assert_allclose(got64, h.run(seed, real0, 1, None, 0.01), rtol=1e-9)
     h.set_rng_precision("f32")

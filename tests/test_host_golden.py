@@ -230,17 +230,20 @@ def test_theta0_is_in_arcseconds_like_aotools():
 
 
 def test_grid_beyond_the_kernels_limit_is_a_clear_exception():
-    """The reference has no upper limit on NPXLS (fast.py:176-211); the GPU kernels stop at 4096.  A larger grid -- explicit, or
+    """The reference has no upper limit on NPXLS (fast.py:176-211); the GPU kernels stop at 8192 (beyond 4096: windows of up to
+    256 pixels, or the sub-row grids).  A larger grid -- explicit, or
     auto-sized by a long TEMPORAL series (fast.py:201-206: half the total wind displacement) -- fails in the host set-up with an
     Exception that names the limit, before any O(N^2) work and without touching the GPU."""
     import fast_amd
     from conftest import load_golden, params_from_json
     p = params_from_json(load_golden("e2e_ao_alias")["params_json"])
-    with pytest.raises(Exception, match="exceeds the GPU kernels' limit of 4096"):
-        fast_amd.Fast(dict(p, NPXLS=4098))
+    with pytest.raises(Exception, match="exceeds the GPU kernels' limit of 8192"):
+        fast_amd.Fast(dict(p, NPXLS=8194))
+    with pytest.raises(Exception, match="exceeds the GPU kernels' limit of 4096.*window of at most 256"):
+        fast_amd.Fast(dict(p, NPXLS=4098, D_GROUND=3.0, DX=0.01))          # a 302-pixel pupil window on a grid without sub-rows
     q = params_from_json(load_golden("temporal_default")["params_json"])
     q.update({"NITER": 200000, "NCHUNKS": 10, "DT": 0.01})        # 32.6 m/s x 0.01 s x 200 000 steps / 1 cm / 2 = 3.3e6 columns
-    with pytest.raises(Exception, match="limit of 4096.*TEMPORAL"):
+    with pytest.raises(Exception, match="limit of 8192.*TEMPORAL"):
         fast_amd.Fast(q)
 
 

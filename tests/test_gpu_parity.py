@@ -407,7 +407,9 @@ def test_histogram_matches_numpy():
 # ------------------------------------------------------------------ error behaviour
 def test_errors_are_reported_not_fatal():
     with pytest.raises(fast_amd.FastMCError):
-        _lib.Handle(8192, 10)
+        _lib.Handle(8194, 10)
+    with pytest.raises(fast_amd.FastMCError):
+        _lib.Handle(4100, 300)              # beyond 4096 a window above 256 pixels needs a sub-row grid
     with pytest.raises(fast_amd.FastMCError):
         _lib.Handle(64, 65)
     h = _lib.Handle(64, 22, "f64", 0)

@@ -22,10 +22,14 @@ for c in range(cases):
     if c % 4 == 3:                                      # every fourth: N = 50 P -> 50-lane family
         N = int(rng.choice([100, 150, 200, 250, 300, 350, 400, 450, 500, 600, 700, 800, 900, 1000, 1200, 1350, 1400, 1500, 1600, 1750, 1800, 2000,
                           1344, 1728, 1920, 2304, 2560]))
+    if c % 32 == 9:                                     # rarely a grid beyond 4096: sub-rows (64 P S, 50 P S) or chirp-z blocks
+        N = int(rng.choice([4608, 5000, 5120, 6000, 6144, 6400, 7000, 7168, 7680, 8000, 8192, int(rng.integers(4097, 8192)), int(rng.integers(4097, 8192))]))
     if only:
         N = int(rng.choice(only))
     Np = int(rng.integers(1, min(N, 300 if c % 2 == 0 else 256) + 1))
     if N > 2048 and c % 16 == 5:
+        Np = int(rng.integers(1, 200))
+    if N > 4096:
         Np = int(rng.integers(1, 200))
     lo = int(rng.choice([0, N - Np, (N - Np) // 2, rng.integers(0, N - Np + 1)]))
     prec = "f64" if rng.random() < 0.7 else "f32"

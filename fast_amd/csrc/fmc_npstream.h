@@ -576,6 +576,7 @@ struct NpsOneArgs {
   uint32_t* ticket;
 };
 constexpr unsigned long long NPS_AGG_MASK = (1ull << 62) - 1ull;
+constexpr uint32_t NPS1_SPIN_LIMIT = 1u << 20;        // polls of a look-back wait before the tile gives up (each a memory round trip: ~1 s)
 
 // tile states, and the look-back words cleared (one thread per tile)
 template <int NSUB>
@@ -789,11 +790,15 @@ __global__ __launch_bounds__(NPS_THREADS) NPS1_OCC void k_nps_onepass(NpsSegArgs
     uint32_t e_in = 0;
     if (tile > 0) {
       if (same && t == 0) __hip_atomic_store(&O.xexit[tile], 0x80000000u | exit_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      uint32_t x;
+      // (Every wait below is bounded: a predecessor that never publishes -- a fault, not a state this protocol reaches -- must
+      // not hang the device.  After NPS1_SPIN_LIMIT polls, ~1 s, the tile raises overflow flag 32, goes on with what it has and
+      // publishes, so that its successors end too; the caller redoes the chunk with numpy as for every other flag.)
+      uint32_t x, spins = 0;
       for (;;) {
         x = __hip_atomic_load(&O.xexit[tile - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
         if (x >> 31) break;
+        if (++spins > NPS1_SPIN_LIMIT) { if (t == 0) atomicOr(A.overflow, 32u); x = 0x80000000u; break; }
         __builtin_amdgcn_s_sleep(4);
       }
       e_in = x & 0xffu;
@@ -808,7 +813,9 @@ __global__ __launch_bounds__(NPS_THREADS) NPS1_OCC void k_nps_onepass(NpsSegArgs
     if (tile > 0) {
       if (t == 0) __hip_atomic_store(&O.agg[tile], (1ull << 62) | c_here, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int64_t p = tile - 1;
+      uint32_t spins = 0;
       for (;;) {
+        if (++spins > NPS1_SPIN_LIMIT) { if (t == 0) atomicOr(A.overflow, 32u); break; }
         const int64_t idx = p - t;
         const unsigned long long v = idx >= 0 ? __hip_atomic_load(&O.agg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
         const uint32_t st = (uint32_t)(v >> 62);

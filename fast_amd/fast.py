@@ -73,7 +73,12 @@ class Fast():
             self.set_seed(self.seed)
         self.init_logging()
 
-        prob = host.build_problem(p)          # raises the reference's config Exceptions
+        # (the size limit belongs to the GPU kernels: a run that has opted into the numpy path and gets it has none, like the reference)
+        host_only = False
+        if p['GPU_FALLBACK']:
+            from . import hostpath
+            host_only = hostpath.unavailable_reason() is not None
+        prob = host.build_problem(p, size_limit=not host_only)          # raises the reference's config Exceptions
         self._prob = prob
         self.Niter_per_chunk = prob.M
         atm, pup = prob.atm, prob.pup

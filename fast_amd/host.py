@@ -117,7 +117,7 @@ def atmosphere(p):
     return a
 
 
-def grid_size(p, atm):
+def grid_size(p, atm, size_limit=True):
     """Pixel scale, grid size and pupil-window size (Fast.init_frequency_grid, fast.py:147-211)."""
     D = p['D_GROUND']
     if p['DX'] == 'auto':
@@ -157,7 +157,7 @@ def grid_size(p, atm):
         N = p['NPXLS']
     if N > 2048:
         logger.warning(f"NPXLS is large ({N}) and may cause very high memory usage")
-    if N > MAX_NPXLS_SUBROWS or (N > MAX_NPXLS and not big_grid_supported(N) and int(np.ceil(D / dx)) + 2 > 256):
+    if size_limit and (N > MAX_NPXLS_SUBROWS or (N > MAX_NPXLS and not big_grid_supported(N) and int(np.ceil(D / dx)) + 2 > 256)):
         # fail before any O(N^2) host work; a TEMPORAL series auto-sizes to half its total wind
         # displacement (fast.py:201-206), which outgrows the kernels quickly
         hint = " (TEMPORAL: fewer steps per object, a shorter DT or a coarser DX)" if p['TEMPORAL'] else ""
@@ -524,7 +524,7 @@ def _shifted(axes, k, l, d):
 
 
 # ----------------------------------------------------------------------------- the whole host init
-def build_problem(params):
+def build_problem(params, size_limit=True):
     """Everything `Fast.__init__` computes on the host before the GPU is needed
     (fast.py:71-103 minus compute_powerspec)."""
     p = params
@@ -538,7 +538,7 @@ def build_problem(params):
     prob.atm = atmosphere(p)
     prob.wvl = p['WVL']
     prob.k = TWO_PI / prob.wvl
-    prob.dx, prob.N, prob.Np = grid_size(p, prob.atm)
+    prob.dx, prob.N, prob.Np = grid_size(p, prob.atm, size_limit)
     prob.axis = freq_axis(prob.N, prob.dx)
     prob.df = prob.axis[1] - prob.axis[0]
     prob.subharm = bool(p['SUBHARM']) and not p['TEMPORAL']

@@ -65,3 +65,18 @@ def test_host_path_temporal_series(name):
     sim = fast_amd.Fast(p)
     res = sim.run()
     np.testing.assert_allclose(res._r, g["r"], rtol=1e-9)
+
+
+def test_the_numpy_path_has_no_grid_size_limit():
+    """The limit of 8192 (windows of up to 256 pixels beyond 4096) belongs to the GPU kernels; a run that opted into the numpy path
+    (GPU_FALLBACK) and gets it has none, like the reference (fast.py:176-211).  Only the set-up is exercised: the O(N^2) power
+    spectrum of a 8200^2 grid is not a CPU-suite test."""
+    from fast_amd import host
+    from conftest import load_golden, params_from_json
+    p = params_from_json(load_golden("e2e_ao_alias")["params_json"])
+    import fast_amd.conf as conf
+    cfg = conf.ConfigParser(dict(p, NPXLS=8200)).config
+    with pytest.raises(Exception, match="exceeds the GPU kernels' limit"):
+        host.grid_size(cfg, host.atmosphere(cfg))
+    dx, N, Np = host.grid_size(cfg, host.atmosphere(cfg), size_limit=False)
+    assert N == 8200

@@ -58,6 +58,7 @@ FAST_SIZE_RATE = {
     800: 820, 900: 590, 1000: 580, 1200: 455, 1400: 227, 1500: 249, 1600: 198, 2000: 124, 2500: 91, 3000: 57, 4000: 32,
 }
 ROUND_UP_SIZES = sorted(FAST_SIZE_RATE)
+_ROUND_WARNED = False
 
 
 def round_up_size(N):
@@ -145,8 +146,14 @@ def grid_size(p, atm, size_limit=True):
             # example; 256 on the packed-row kernels is faster than anything in between); the next size of the
             # fast kernel family samples the spectrum slightly finer
             bigger = round_up_size(N)
-            if bigger:
-                logger.info(f"GPU_ROUND_NPXLS: auto NPXLS {N} -> {bigger}")
+            if bigger and bigger != N:
+                # a drop-in user comparing headers with the reference's would trip on a silent change: said once per process as a
+                # warning (the reference's own auto rule would give N), afterwards at INFO
+                global _ROUND_WARNED
+                (logger.info if _ROUND_WARNED else logger.warning)(
+                    f"GPU_ROUND_NPXLS: auto NPXLS {N} (the reference's rule) -> {bigger} (the next fast kernel size; "
+                    f"GPU_ROUND_NPXLS: False keeps {N})")
+                _ROUND_WARNED = True
                 N = bigger
         logger.info(f"Auto set NPXLS to {N}")
         if p['AO_MODE'] == 'NOAO' and not np.isinf(p['L0']):

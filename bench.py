@@ -66,7 +66,7 @@ def workload_params(args):
         "D_SAT": 0.1, "H_SAT": 36e6, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w,
         "WIND_DIR": np.array([0., 90., 180., 270.]), "L0": np.inf, "l0": 1e-6, "ZENITH_ANGLE": 55,
         "DTHETA": [4, 0], "AO_MODE": args.ao_mode, "DSUBAP": 0.1, "TLOOP": 1e-3, "TEXP": 1e-3, "ALIAS": True,
-        "NOISE": 0, "GPU_PRECISION": args.precision, "GPU_RNG": "device", "GPU_RNG_PRECISION": getattr(args, "rng_precision", "f32"),
+        "NOISE": 0, "GPU_PRECISION": args.precision, "GPU_RNG": "device", "GPU_RNG_PRECISION": getattr(args, "rng_precision", "f64"),
         "FFTW": True, "GPU_SHARD": False,
     }
 
@@ -367,10 +367,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--rng-precision", default="f32", choices=["f32", "f64"],
-                    help="device generator of the TIMED steps: f32 (default: float32 normals and colouring, the headline) or f64 (the "
-                         "reference's 53-bit normals and float64 colouring, fast/funcs.py:352-356; without this flag the same job is "
-                         "timed a second time at f64 and reported as value_f64_generator)")
+    ap.add_argument("--rng-precision", default="f64", choices=["f32", "f64"],
+                    help="device generator of the TIMED steps: f64 (default, the headline: the reference's 53-bit normals and float64 "
+                         "colouring, fast/funcs.py:352-356, fast/fast.py:593-594) or f32 (the opt-in shortcut GPU_RNG_PRECISION 'f32': "
+                         "float32 normals and colouring); without this flag the same job is timed a second time with the f32 draw and "
+                         "reported as the extra value_f32_draw")
     ap.add_argument("--npxls", type=int, default=None, help="grid size (default: 1024, or 2048 with --workload config3)")
     ap.add_argument("--ao-mode", default="NOAO")
     ap.add_argument("--workload", default="config1", choices=["config1", "config3"],
@@ -383,7 +384,8 @@ def main():
                     "(default 10000 = BASELINE configs[1]; other values are for overhead studies, the line says what ran)")
     ap.add_argument("--no-host-cost-pass", action="store_true", help="skip the one-call reference run behind pipeline.host_ms_per_step")
     ap.add_argument("--no-pipeline", action="store_true", help="one step at a time (enqueue, exchange, wait) instead of two steps in flight per device")
-    ap.add_argument("--no-f64-generator-pass", action="store_true", help="skip the second timed pass with the float64 generator")
+    ap.add_argument("--no-f32-draw-pass", "--no-f64-generator-pass", dest="no_other_precision_pass", action="store_true",
+                    help="skip the second timed pass with the other generator precision")
     ap.add_argument("--batch", type=int, default=0, help="realisations per launch (0 = library default)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -596,35 +598,37 @@ def main():
         host_cost = {"one_call_ms_per_step": dt_one / args.steps * 1e3, "host_ms_per_step": (dt - dt_one) / args.steps * 1e3, "tim": tim_one}
         hist_total = keep_hist
 
-    # The same job with the generator at the REFERENCE's precision (53-bit normals, float64 colouring: fast/funcs.py:352-356,
-    # fast/fast.py:593-594), timed like the headline: same steps, same barriers, fresh realisation ranges.  Reported beside
-    # `value` as `value_f64_generator` with its own roofline; `--rng-precision f64` makes it the headline instead.
-    gen64 = None
-    if args.rng_precision == "f32" and args.precision == "f64" and not args.no_f64_generator_pass:
-        grp.each(lambda hh, i: hh.set_rng_precision("f64"))
+    # The same job with the OTHER generator precision, timed like the headline: same steps, same barriers, fresh realisation
+    # ranges.  The headline draws at the REFERENCE's precision (53-bit normals, float64 colouring: fast/funcs.py:352-356,
+    # fast/fast.py:593-594); the extra pass is the opt-in float32 draw (`value_f32_draw`).  With `--rng-precision f32` the roles
+    # swap (`value_f64_generator`).
+    other = None
+    other_prec = "f32" if args.rng_precision == "f64" else "f64"
+    if args.precision == "f64" and not args.no_other_precision_pass:
+        grp.each(lambda hh, i: hh.set_rng_precision(other_prec))
         first = args.warmup + args.steps + 100000
         run_steps(first, 1)
         busy_keep, busy = busy, []
-        tim64 = dict.fromkeys(tim_keys, 0.0)
+        tim2 = dict.fromkeys(tim_keys, 0.0)
         sync_all()
         t0 = time.perf_counter()
-        out64 = run_steps(first + 1, args.steps, tim64)
+        out2 = run_steps(first + 1, args.steps, tim2)
         sync_all()
-        dt64 = time.perf_counter() - t0
-        kernels64 = h.last_kernels()
+        dt2 = time.perf_counter() - t0
+        kernels2 = h.last_kernels()
         # launch durations for this pass's roofline from ONE more step issued on its own (see the host-cost pass above)
-        tim64_one = dict.fromkeys(tim_keys, 0.0)
+        tim2_one = dict.fromkeys(tim_keys, 0.0)
         step(first + 1 + args.steps)
-        add_timing(tim64_one)
+        add_timing(tim2_one)
         busy = busy_keep
         if rdzv is not None:
-            dt64 = float(rdzv.all_reduce(np.array([dt64]), "max")[0])
+            dt2 = float(rdzv.all_reduce(np.array([dt2]), "max")[0])
             for k in tim_keys:
-                tim64[k] = float(rdzv.all_reduce(np.array([tim64[k]]), "sum")[0])
-                tim64_one[k] = float(rdzv.all_reduce(np.array([tim64_one[k]]), "sum")[0])
-        assert np.isfinite(out64).all() and (out64 > 0).all()
-        gen64 = {"dt": dt64, "tim": tim64, "tim_one": tim64_one, "kernels": kernels64}
-        grp.each(lambda hh, i: hh.set_rng_precision("f32"))
+                tim2[k] = float(rdzv.all_reduce(np.array([tim2[k]]), "sum")[0])
+                tim2_one[k] = float(rdzv.all_reduce(np.array([tim2_one[k]]), "sum")[0])
+        assert np.isfinite(out2).all() and (out2 > 0).all()
+        other = {"dt": dt2, "tim": tim2, "tim_one": tim2_one, "kernels": kernels2}
+        grp.each(lambda hh, i: hh.set_rng_precision(args.rng_precision))
 
     # GPUs that actually ran (one node: distinct device indices over all workers) and the communicator's own world size
     if mode == "ranks":
@@ -656,7 +660,7 @@ def main():
                                      + ("; the device generator draws 53-bit normals and colours in float64 like the reference (fast/funcs.py:352-356, "
                                         "fast/fast.py:593-594), fused into the row kernel" if args.rng_precision == "f64" else
                                         "; the device generator's normals are float32 (24-bit uniforms, hardware log/sqrt/sin/cos), "
-                                        "coloured in float32 and widened: `value_f64_generator` is the same job at the reference's precision")
+                                        "coloured in float32 and widened (opt-in shortcut, NOT the reference's arithmetic)")
                                      + "; host-coefficient (parity) mode is float64 throughout",
                        "rng_precision": args.rng_precision,
                        "iters_per_step_per_gpu": iters_worker, "kernel_path": {0: "direct", 1: "wave-fft", 2: "chirp-z", 3: "lanes50-fft"}[h.kernel_path()],
@@ -682,15 +686,19 @@ def main():
                          "cols_ms": tim["cols_ms"] / args.steps / workers, "finalize_ms": tim["finalize_ms"] / args.steps / workers,
                          "init_s": init_s, "powerspec_kernel_ms_warm": sim.powerspec_kernel_ms},
         }
-        if gen64:
-            line["value_f64_generator"] = total_iters / gen64["dt"]
-            line["f64_generator"] = {
-                "dtype": "f64", "ms_per_step": gen64["dt"] / args.steps * 1e3, "ratio_to_value": (total_iters / gen64["dt"]) / value,
-                "what": "the same steps with GPU_RNG_PRECISION 'f64': 53-bit normals (two xoshiro128+ streams), float64 log / sqrt / sincos "
-                        "(fast_amd/csrc/fmc_gen64.h), float64 colouring, fused into the row kernel -- the reference's arithmetic end to end",
-                "rows_ms": gen64["tim"]["rows_ms"] / args.steps / workers, "cols_ms": gen64["tim"]["cols_ms"] / args.steps / workers,
-                "roofline": roofline(args, N, Np, gen64["tim"] if args.no_pipeline else gen64["tim_one"], args.steps if args.no_pipeline else 1,
-                                     workers, iters_worker, gen64["kernels"])}
+        if other:
+            key, obj = ("value_f32_draw", "f32_draw") if other_prec == "f32" else ("value_f64_generator", "f64_generator")
+            line[key] = total_iters / other["dt"]
+            line[obj] = {
+                "dtype": "f64 (f32 draw)" if other_prec == "f32" else "f64", "ms_per_step": other["dt"] / args.steps * 1e3,
+                "ratio_to_value": (total_iters / other["dt"]) / value,
+                "what": ("the same steps with GPU_RNG_PRECISION 'f32' (opt-in): float32 normals (24-bit uniforms, hardware log / sqrt / sin / cos), "
+                         "float32 colouring, widened -- NOT the reference's arithmetic; complex128 transform as the headline" if other_prec == "f32" else
+                         "the same steps with GPU_RNG_PRECISION 'f64': 53-bit normals, float64 log / sqrt / sincos (fast_amd/csrc/fmc_gen64.h), "
+                         "float64 colouring, fused into the row kernel -- the reference's arithmetic end to end"),
+                "rows_ms": other["tim"]["rows_ms"] / args.steps / workers, "cols_ms": other["tim"]["cols_ms"] / args.steps / workers,
+                "roofline": roofline(args, N, Np, other["tim"] if args.no_pipeline else other["tim_one"], args.steps if args.no_pipeline else 1,
+                                     workers, iters_worker, other["kernels"])}
         if exchange is not None:
             line["exchange"] = exchange
         if sustained:

@@ -32,9 +32,10 @@ GPU_DEFAULTS = {
                               # on the host with numpy (fast_amd/hostpath.py); default: raise, nothing ever falls back silently
     'GPU_RNG': 'device',      # 'device': Philox on the GPU; 'host': numpy draws, reference order (parity mode);
                               # 'numpy': the SAME stream as 'host' (the reference's numbers for its SEED) drawn on the GPU
-    'GPU_RNG_PRECISION': 'f32',  # device generator: 'f32' (24-bit uniforms, hardware float32 Box-Muller, float32 colouring,
-                              # fused into the row kernels) or 'f64' (53-bit normals and float64 colouring like the
-                              # reference's funcs.py:352-356 / fast.py:594; ~4x slower)
+    'GPU_RNG_PRECISION': 'auto',  # device generator: 'auto' = the pipeline's precision (GPU_PRECISION; 'f64' unless that says otherwise);
+                              # 'f64': 53-bit normals and float64 colouring like the reference's funcs.py:352-356 / fast.py:594,
+                              # fused into the row kernels; 'f32' (opt-in shortcut, ~1.7x the rate at 1024^2): 24-bit uniforms,
+                              # hardware float32 Box-Muller, float32 colouring -- NOT the reference's arithmetic
     'GPU_DEVICE': None,       # HIP device index; None -> LOCAL_RANK or 0
     'GPU_DEVICES': None,      # list of HIP device indices driven by THIS process (one thread each, fast_amd/multi.py);
                               # None -> [GPU_DEVICE]

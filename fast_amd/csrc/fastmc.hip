@@ -642,7 +642,7 @@ extern "C" int fastmc_set_batch(fastmc_t* h, int batch) {
 }
 #endif
 
-// The 128-entry log table of the float64 generator (fmc_gen64.h), one copy per device, uploaded on first use and kept.
+// The tables of the float64 generator (fmc_gen64.h: 256 (cos, sin) entries, 128 log entries), one copy per device, uploaded on first use and kept.
 #if FMC_TU == 0
 static const Gen64Entry* gen64_table(int device) {
   static std::mutex mu;
@@ -1545,7 +1545,18 @@ static bool fused_gen64(fastmc_ctx* h) {
   if (h->path != 1 || wave_rt_split(h->N) || pk_grid(h->N)) return false;
   int ns = 0, wpb = 0;
   wave_config<R>(h, &ns, &wpb);
-  if (h->P == 16) return ns == 2 || ns == 4 || ns == 8;      // not the whole-grid window (NS = P: its tables leave no room, and nothing draws into it)
+  if (h->P == 16) {      // not the whole-grid window (NS = P: its tables leave no room, and nothing draws into it)
+    // every variant dispatch_wave can pick for this window must hold the generator's tables beside its own (they all do for the
+    // windows the family serves -- sixteen waves: 153 KB + 48 omS, omS <= 128; twelve waves: 133 KB + 48 omS, omS <= 512 -- but
+    // the launch must never be the place that finds out)
+    if constexpr (sizeof(R) == 8) {
+      const size_t g = GEN64_TABLE_BYTES;
+      if (ns == 2) return wave_lds_bytes_d<R, 16, 2, 7>(h->omS) + g <= LDS_MAX && (!dense16r_fits<R>(h) || wave_lds_bytes_d<R, 16, 2, 8>(h->omS) + g <= LDS_MAX);
+      if (ns == 4) return wave_lds_bytes_d<R, 16, 4, 7>(h->omS) + g <= LDS_MAX;
+      if (ns == 8) return wave_lds_bytes_d<R, 16, 8, 7>(h->omS) + g <= LDS_MAX;
+    }
+    return false;
+  }
   // the other one-row-per-wave grids (192 ... 1792, S = 1): windows of up to 256 pixels, where the generator's 4 KB of tables fit the LDS
   if (h->S != 1 || (ns != 2 && ns != 4)) return false;
   if constexpr (sizeof(R) == 8) {

@@ -66,37 +66,39 @@ __device__ __forceinline__ xoshiro128p row_stream(RngKey key, uint64_t g, int ky
   s.seed(philox4x32<FMC_SEED_ROUNDS>((uint32_t)(ky * SL + L), STREAM_SCREEN, (uint32_t)g, (uint32_t)(g >> 32), key.k0, key.k1));
   return s;
 }
-// ---- the generator at the reference's precision (GPU_RNG_PRECISION 'f64'; fast/funcs.py:352-356 draws 53-bit normals)
-// The SAME two words (a, b) of stream (g, ky, L) give the leading bits, a second stream (counter word 1 = STREAM_SCREEN_LO,
-// otherwise seeded alike) the rest:  u = (a 2^21 + (a' >> 11) + 1/2) 2^-53,  turns t = ((b >> 9) 2^30 + (b' >> 2)) 2^-53,
-// (re, im) = sqrt(-2 ln u) (cos, sin)(2 pi t) in float64 (libm log / sqrt / sincospi).  The float32 generator is this draw
-// with u and t cut to their first 24 / 23 bits, so the two modes see the same normals to ~2^-24 (tests bound what the
-// float32 shortcut changes in the powers).  Tails reach 8.6 sigma.
-constexpr uint32_t STREAM_SCREEN_LO = 3;
+// ---- the generator at the reference's precision (GPU_RNG_PRECISION 'f64', the default; fast/funcs.py:352-356 draws 53-bit
+// normals).  Four words make one complex normal (fmc_gen64.h has the definition and its fast form):
+//     u = RNE(a 2^32 + (a2 | 1)) 2^-64,   turns t = (b 2^24 + (b2 >> 8)) 2^-56,   (re, im) = sqrt(-2 ln u) (cos, sin)(2 pi t)
+// in float64.  (a, b) are the words of the float32 draw, whose u and t are this draw's cut to their first 24 / 23 bits: the two
+// precisions see the same normals to ~2^-24.  The coefficient streams take (a2, b2) from the SAME xoshiro128+ state as (a, b)
+// (xoshiro128p::next4: the "++" scrambler on both halves of the state) -- round 4 ran a second stream per lane for them.  Tails
+// reach 9.4 sigma.
 constexpr uint32_t STREAM_SUBHARM_LO = 4;
-__device__ __forceinline__ xoshiro128p row_stream_lo(RngKey key, uint64_t g, int ky, int L, int SL) {
-  xoshiro128p s;
-  s.seed(philox4x32<FMC_SEED_ROUNDS>((uint32_t)(ky * SL + L), STREAM_SCREEN_LO, (uint32_t)g, (uint32_t)(g >> 32), key.k0, key.k1));
-  return s;
-}
+// the definition, with libm (log-amplitude and sub-harmonic draws: a handful per realisation; the coefficient draws run
+// box_muller_f64_fast, which agrees with this to ~4e-16)
 __device__ __forceinline__ void box_muller_f64(uint32_t a, uint32_t b, uint32_t a2, uint32_t b2, double& re, double& im) {
-  const double u = ((double)(((uint64_t)a << 21) | (uint64_t)(a2 >> 11)) + 0.5) * 0x1p-53;
-  const double t = (double)(((uint64_t)(b >> 9) << 30) | (uint64_t)(b2 >> 2)) * 0x1p-53;
+  const double u = __builtin_fma((double)a, 0x1p32, (double)(a2 | 1u)) * 0x1p-64;
   const double r = sqrt(-2.0 * log(u));
+  // the 56-bit angle reduced EXACTLY to the nearest quarter turn: |rem| <= 2^53 is a float64, x carries one rounding
+  const uint64_t T = ((uint64_t)b << 24) | (uint64_t)(b2 >> 8);
+  const uint64_t q = (T + (1ull << 53)) >> 54;
+  const double x = (double)(int64_t)(T - (q << 54)) * 0x1.921fb54442d18p-54;      // 2 pi 2^-56 rem
   double sn, cs;
-  sincospi(2.0 * t, &sn, &cs);
-  re = r * cs;
-  im = r * sn;
+  sincos(x, &sn, &cs);
+  const int qi = (int)(q & 3);
+  const double c = qi == 0 ? cs : (qi == 1 ? -sn : (qi == 2 ? -cs : sn));
+  const double si = qi == 0 ? sn : (qi == 1 ? cs : (qi == 2 ? -sn : -cs));
+  re = r * c;
+  im = r * si;
 }
 
-// The same draw in ~90 instructions (fmc_gen64.h): table-driven log, v_rsq_f32-seeded Newton sqrt, fdlibm kernels for the
-// angle -- what the row kernels run in MODE 2, the staging kernel and the read-back.  `tab`: the 128-entry log table, in the
-// LDS (row kernels) or in global memory.
-template <class TabPtr>
-__device__ __forceinline__ cpx<double> draw_coloured_f64(xoshiro128p& s, xoshiro128p& slo, double amp, TabPtr tab) {
+// The same draw in ~60 instructions (fmc_gen64.h): table-driven log, v_rsq_f32-seeded cubic sqrt, table + rotation for the
+// angle -- what the row kernels run in MODE 2, the staging kernel and the read-back.  `tab`: the tables as a pointer (global
+// memory, or generic into the LDS) or Gen64Lds0 (staged at LDS address 0: the row kernels).
+template <class Tab>
+__device__ __forceinline__ cpx<double> draw_coloured_f64(xoshiro128p& s, double amp, Tab tab) {
   uint32_t a, b, a2, b2;
-  s.next2(a, b);
-  slo.next2(a2, b2);
+  s.next4(a, b, a2, b2);
   cpx<double> c;
   box_muller_f64_fast(a, b, a2, b2, amp, tab, c.x, c.y);
   return c;
@@ -423,19 +425,45 @@ __device__ __forceinline__ void load_tables(cpx<R>* s_tw, cpx<R>* s_om, const cp
   for (int i = threadIdx.x; i < OM_ROWS * omS; i += blockDim.x) s_om[i] = om[i];    // the 16 x 4 row reads rows 1 ... 3 only
   __syncthreads();
 }
+// The wave family stages neither table's row 0 (w^0 = 1: no row reads it -- fmc_wavefft.h multiplies by tw1[a][.] for a >= 1 and
+// by om[m][.] for m >= 1): 1 KB + 16 omS bytes (float64) that the float64 generator's tables need beside sixteen exchange
+// buffers.  `s_tw` / `s_om` are the tables' VIRTUAL bases (row 0 would start there): WaveLds carves them.
+template <class R, int P, int OM_ROWS = 8>
+__device__ __forceinline__ void load_tables_skip0(cpx<R>* s_tw, cpx<R>* s_om, const cpx<R>* tw, const cpx<R>* om, int omS) {
+  for (int i = WAVE + threadIdx.x; i < P * WAVE; i += blockDim.x) s_tw[i] = tw[i];
+  for (int i = omS + threadIdx.x; i < OM_ROWS * omS; i += blockDim.x) s_om[i] = om[i];
+  __syncthreads();
+}
+template <class R, int P>
+__host__ __device__ constexpr size_t wave_table_bytes(int om_rows, int omS) {
+  return (size_t)((P - 1) * WAVE + (om_rows - 1) * omS) * sizeof(cpx<R>);
+}
+// [generator tables (MODE 2)][tw1 rows 1 ... P-1][om rows 1 ... OM_ROWS-1][exchange buffers]
+template <class R, int P, int OM_ROWS>
+struct WaveLds {
+  cpx<R>* s_tw;
+  cpx<R>* s_om;
+  typename Xch<R>::E* s_x;
+  __device__ __forceinline__ WaveLds(unsigned char* smem, size_t gen_bytes, int omS) {
+    cpx<R>* t = reinterpret_cast<cpx<R>*>(smem + gen_bytes);
+    s_tw = t - WAVE;
+    s_om = t + (P - 1) * WAVE - omS;
+    s_x = reinterpret_cast<typename Xch<R>::E*>(t + (P - 1) * WAVE + (OM_ROWS - 1) * omS);
+  }
+};
 
-// LDS carve (dynamic): [tw1 P*64 cpx][om 8*omS cpx][xbuf WPB*XELEMS 8-byte]
+// LDS carve (dynamic): [tw1 rows 1 ... P-1][om rows 1 ... 7][xbuf WPB*XELEMS 8-byte]
 template <class R, int P, int NS>
 __host__ __device__ constexpr size_t wave_lds_bytes(int omS) {
-  return (size_t)(P * WAVE + 8 * omS) * sizeof(cpx<R>) + (size_t)WaveCfg<R, P, NS>::WPB * WaveGeom<R, P>::XELEMS * 8;
+  return wave_table_bytes<R, P>(8, omS) + (size_t)WaveCfg<R, P, NS>::WPB * WaveGeom<R, P>::XELEMS * 8;
 }
 template <class R, int P, int NS, int D>
 __host__ __device__ constexpr size_t wave_lds_bytes_cols(int omS) {
-  return (size_t)(P * WAVE + WCfg<R, P, NS, D>::OM_ROWS * omS) * sizeof(cpx<R>) + (size_t)WCfg<R, P, NS, D>::WPB_COLS * WCfg<R, P, NS, D>::XELEMS * 8;
+  return wave_table_bytes<R, P>(WCfg<R, P, NS, D>::OM_ROWS, omS) + (size_t)WCfg<R, P, NS, D>::WPB_COLS * WCfg<R, P, NS, D>::XELEMS * 8;
 }
 template <class R, int P, int NS, int D>
 __host__ __device__ constexpr size_t wave_lds_bytes_d(int omS) {
-  return (size_t)(P * WAVE + WCfg<R, P, NS, D>::OM_ROWS * omS) * sizeof(cpx<R>) + (size_t)WCfg<R, P, NS, D>::WPB * WCfg<R, P, NS, D>::XELEMS * 8;
+  return wave_table_bytes<R, P>(WCfg<R, P, NS, D>::OM_ROWS, omS) + (size_t)WCfg<R, P, NS, D>::WPB * WCfg<R, P, NS, D>::XELEMS * 8;
 }
 
 // S > 1: the row of NF = S * 64 P points is transformed as S interleaved sub-rows (kx = s mod S), each by
@@ -458,11 +486,12 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
   using E = typename Xch<R>::E;
   // MODE 2 (float64 generator fused into the row): its 4 KB of tables (log, cos / sin) at the start of the LDS (a table offset IS the address)
   Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
-  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
-  cpx<R>* s_om = s_tw + P * WAVE;
-  E* s_x = reinterpret_cast<E*>(s_om + WCfg<R, P, NS, D>::OM_ROWS * A.omS);
-  if constexpr (MODE == 2) load_gen64_table(s_g64, A.g64);
-  load_tables<R, P, WCfg<R, P, NS, D>::OM_ROWS>(s_tw, s_om, A.tw, A.om, A.omS);
+  const WaveLds<R, P, WCfg<R, P, NS, D>::OM_ROWS> lds(smem, MODE == 2 ? GEN64_TABLE_BYTES : 0, A.omS);
+  cpx<R>* s_tw = lds.s_tw;
+  cpx<R>* s_om = lds.s_om;
+  E* s_x = lds.s_x;
+  if constexpr (MODE == 2) { gen64_lds0_check(s_g64); load_gen64_table(s_g64, A.g64); }
+  load_tables_skip0<R, P, WCfg<R, P, NS, D>::OM_ROWS>(s_tw, s_om, A.tw, A.om, A.omS);
 
   // the wave index is wave-uniform: in an SGPR, so that row / realisation indices and the table base addresses
   // derived from it are scalar and the loads use the scalar-base + lane-offset form
@@ -514,7 +543,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
         // the generator at the reference's precision (fast/funcs.py:352-356, fast/fast.py:593-594): 53-bit normals, float64
         // colouring; the low bits from the second stream of the same (g, ky, L)
         static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
-        xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S), rl = row_stream_lo(A.key, g, ky, sp + S * lane, WAVE * S);
+        xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
         // one coefficient at a time, its colouring factor loaded one draw ahead: left alone the compiler issues the sixteen
         // float64 table loads (32 VGPRs) before the first draw and spills
         double an = (double)amp[sp + S * lane];
@@ -523,11 +552,10 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
           const double a = an;
           if (j + 1 < P) an = (double)amp[sp + S * (lane + WAVE * (j + 1))];
           ex.loadfence();
-          regs.v[j] = draw_coloured_f64(rs, rl, a, s_g64);
+          regs.v[j] = draw_coloured_f64(rs, a, Gen64Lds0{});
           // the draws one after the other: a finished coefficient and the two stream states are pinned here, so that no
           // arithmetic of draw j + 1 starts (and holds registers) before draw j has retired its temporaries
-          asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3), "+v"(rl.s0), "+v"(rl.s1),
-                       "+v"(rl.s2), "+v"(rl.s3));
+          asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
         }
       } else {
         // coefficients from HBM: three float64 loads per element (real part, imaginary part, colouring factor).  All P at once are
@@ -608,9 +636,10 @@ void k_cols_wave(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using G = WaveGeom<R, P>;
   using E = typename Xch<R>::E;
-  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
-  cpx<R>* s_om = s_tw + P * WAVE;
-  E* s_x = reinterpret_cast<E*>(s_om + WCfg<R, P, NS, D>::OM_ROWS * A.omS);
+  const WaveLds<R, P, WCfg<R, P, NS, D>::OM_ROWS> lds(smem, 0, A.omS);
+  cpx<R>* s_tw = lds.s_tw;
+  cpx<R>* s_om = lds.s_om;
+  E* s_x = lds.s_x;
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * WCfg<R, P, NS, D>::XELEMS;
@@ -624,7 +653,7 @@ void k_cols_wave(ColArgs<R> A) {
   LaneRegs<R, P, NS> regs;
   GpuExec<R, P, NS> ex{lane, regs};
   const cpx<R>* col = A.V + ((size_t)b * A.Np + xi) * N;
-  load_tables<R, P, WCfg<R, P, NS, D>::OM_ROWS>(s_tw, s_om, A.tw, A.om, A.omS);
+  load_tables_skip0<R, P, WCfg<R, P, NS, D>::OM_ROWS>(s_tw, s_om, A.tw, A.om, A.omS);
   if (!valid) return;   // whole wave exits; no block barrier follows
   if (S == 1) {
 #pragma unroll
@@ -700,7 +729,7 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPB * 64)) void k_rows_pk(RowArgs
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
   cpx<R>* s_om = s_tw + 16 * L;
   E* s_x = reinterpret_cast<E*>(s_om + C::OM_ROWS * A.omS);
-  if constexpr (MODE == 2) load_gen64_table(s_g64, A.g64);
+  if constexpr (MODE == 2) { gen64_lds0_check(s_g64); load_gen64_table(s_g64, A.g64); }
   pk_load_tables<R, L0>(s_tw, s_om, A.tw, A.om, A.omS);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * D16_XELEMS;
@@ -730,16 +759,15 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPB * 64)) void k_rows_pk(RowArgs
     } else if constexpr (MODE == 2) {
       static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
       const R* amp = A.amp + (size_t)ky0 * N;
-      xoshiro128p rs = row_stream(A.key, g, ky0 + gl, q, L), rl = row_stream_lo(A.key, g, ky0 + gl, q, L);
+      xoshiro128p rs = row_stream(A.key, g, ky0 + gl, q, L);
       double an = (double)amp[lane_in];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const double a = an;
         if (j + 1 < 16) an = (double)amp[lane_in + L * (j + 1)];
         ex.loadfence();
-        regs.v[j] = draw_coloured_f64(rs, rl, a, s_g64);
-        asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3), "+v"(rl.s0), "+v"(rl.s1),
-                     "+v"(rl.s2), "+v"(rl.s3));
+        regs.v[j] = draw_coloured_f64(rs, a, Gen64Lds0{});
+        asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
       }
     } else {
       const R* amp = A.amp + (size_t)ky0 * N;
@@ -894,7 +922,7 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
   cpx<R>* s_twf = s_om + 8 * A.omS;
   E* s_x = reinterpret_cast<E*>(s_twf + 64);
   for (int i = threadIdx.x; i < 64; i += blockDim.x) s_twf[i] = A.blu.twf[i];
-  if constexpr (MODE == 2) load_gen64_table(s_g64, A.g64);
+  if constexpr (MODE == 2) { gen64_lds0_check(s_g64); load_gen64_table(s_g64, A.g64); }
   load_tables<R, P>(s_tw, s_om, A.tw, A.om, A.omS);
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -933,8 +961,6 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
       const R* amp = A.amp + (size_t)ky * N;
       const size_t base = ((size_t)b * N + ky) * N;
       xoshiro128p rs = row_stream(A.key, g, ky, lane, WAVE);
-      xoshiro128p rl = rs;
-      if constexpr (MODE == 2) rl = row_stream_lo(A.key, g, ky, lane, WAVE);
       const int nj = A.blu.B / WAVE;                     // values per lane and block
 #pragma unroll 1
       for (int jb = 0; jb < A.blu.SB; ++jb) {
@@ -946,9 +972,8 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
           if (MODE == 0) regs.v[j] = in ? cmul(draw_coloured<R>(rs, ampf[kx]), pre[kx]) : mk<R>((R)0, (R)0);
           else if constexpr (MODE == 2) {
             if constexpr (sizeof(R) == 8) {
-              regs.v[j] = in ? cmul(draw_coloured_f64(rs, rl, (double)amp[kx], s_g64), pre[kx]) : mk<R>((R)0, (R)0);
-              asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3), "+v"(rl.s0), "+v"(rl.s1),
-                           "+v"(rl.s2), "+v"(rl.s3));
+              regs.v[j] = in ? cmul(draw_coloured_f64(rs, (double)amp[kx], Gen64Lds0{}), pre[kx]) : mk<R>((R)0, (R)0);
+              asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
             }
           }
           else regs.v[j] = in ? cmul(cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]), pre[kx]) : mk<R>((R)0, (R)0);
@@ -972,13 +997,12 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
       // the generator at the reference's precision, one coefficient at a time (see k_rows_wave)
       static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
       const R* amp = A.amp + (size_t)ky * N;
-      xoshiro128p rs = row_stream(A.key, g, ky, lane, WAVE), rl = row_stream_lo(A.key, g, ky, lane, WAVE);
+      xoshiro128p rs = row_stream(A.key, g, ky, lane, WAVE);
 #pragma unroll
       for (int j = 0; j < P; ++j) {
         const int kx = lane + WAVE * j;
-        regs.v[j] = kx < N ? cmul(draw_coloured_f64(rs, rl, (double)amp[kx], s_g64), pre[kx]) : mk<R>((R)0, (R)0);
-        asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3), "+v"(rl.s0), "+v"(rl.s1),
-                     "+v"(rl.s2), "+v"(rl.s3));
+        regs.v[j] = kx < N ? cmul(draw_coloured_f64(rs, (double)amp[kx], Gen64Lds0{}), pre[kx]) : mk<R>((R)0, (R)0);
+        asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
       }
     } else {
       const size_t base = ((size_t)b * N + ky) * N;
@@ -1124,7 +1148,7 @@ __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_rows_mr(Row
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
   cpx<R>* s_om = s_tw + P * WAVE;
   E* s_x = reinterpret_cast<E*>(s_om + G::L0 * A.omS);
-  if constexpr (MODE == 2) load_gen64_table(s_g64, A.g64);
+  if constexpr (MODE == 2) { gen64_lds0_check(s_g64); load_gen64_table(s_g64, A.g64); }
   load_tables_mr<R, P, LN>(s_tw, s_om, A.tw, A.om, A.omS);
 
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1163,16 +1187,15 @@ __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_rows_mr(Row
         // the generator at the reference's precision, one coefficient at a time (see k_rows_wave)
         static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
         const R* amp = A.amp + (size_t)ky * N + sp;
-        xoshiro128p rs = row_stream(A.key, g, ky, sp + S * li, LN * S), rl = row_stream_lo(A.key, g, ky, sp + S * li, LN * S);
+        xoshiro128p rs = row_stream(A.key, g, ky, sp + S * li, LN * S);
         double an = (double)amp[S * li];
 #pragma unroll
         for (int j = 0; j < P; ++j) {
           const double a = an;
           if (j + 1 < P) an = (double)amp[S * (li + LN * (j + 1))];
           ex.loadfence();
-          regs.v[j] = draw_coloured_f64(rs, rl, a, s_g64);
-          asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3), "+v"(rl.s0), "+v"(rl.s1),
-                       "+v"(rl.s2), "+v"(rl.s3));
+          regs.v[j] = draw_coloured_f64(rs, a, Gen64Lds0{});
+          asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
         }
       } else {
         const size_t base = ((size_t)b * N + ky) * N + sp;
@@ -1741,11 +1764,11 @@ __global__ void k_rng_coeffs(RngKey key, uint64_t g, int N, int rng_f64, const G
   if (idx >= N * SL) return;
   const int ky = idx / SL, l = idx % SL;
   if (l >= N) return;
-  xoshiro128p rs = row_stream(key, g, ky, l, SL), rlo = row_stream_lo(key, g, ky, l, SL);
+  xoshiro128p rs = row_stream(key, g, ky, l, SL);
   for (int kx = l; kx < N; kx += SL) {
     cpx<double> c;
     if (rng_f64) {
-      c = draw_coloured_f64(rs, rlo, 1.0, g64);     // the arithmetic of the fused rows (MODE 2), bit for bit
+      c = draw_coloured_f64(rs, 1.0, g64);     // the arithmetic of the fused rows (MODE 2), bit for bit
     } else {
       c = draw_coeff<double>(rs);
     }
@@ -1768,10 +1791,10 @@ __global__ __launch_bounds__(256) void k_gen_coeffs_f64(RngKey key, uint64_t g0,
   const int l = (int)(idx % SL), ky = (int)((idx / SL) % N), b = (int)(idx / ((int64_t)SL * N));
   if (l >= N) return;
   const uint64_t g = g0 + (uint64_t)b;
-  xoshiro128p rs = row_stream(key, g, ky, l, SL), rlo = row_stream_lo(key, g, ky, l, SL);
+  xoshiro128p rs = row_stream(key, g, ky, l, SL);
   const size_t base = ((size_t)b * N + ky) * N;
   for (int kx = l; kx < N; kx += SL) {
-    const cpx<double> c = draw_coloured_f64(rs, rlo, 1.0, s_g64);
+    const cpx<double> c = draw_coloured_f64(rs, 1.0, s_g64);
     cre[base + kx] = c.x;
     cim[base + kx] = c.y;
   }

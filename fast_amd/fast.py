@@ -14,9 +14,10 @@ Differences from the reference, all deliberate:
     THAT stream -- numpy's PCG64 + ziggurat, word for word -- on the GPU: the reference's numbers
     for its SEED without a host draw (fast_amd/npnormal.py, csrc/fmc_npstream.h);
   * `GPU_PRECISION`: 'f64' (default, complex128 like the reference) or 'f32';
-  * `GPU_RNG_PRECISION`: 'f32' (default) or 'f64' -- the device generator's normals and the colouring multiply at the
-    reference's float64 precision (funcs.py:352-356, fast.py:594), fused into the row kernels of every FFT family (half to
-    three quarters of the float32 generator's rate), staged through device memory by the direct kernels;
+  * `GPU_RNG_PRECISION`: 'auto' (default: the pipeline's precision, i.e. 'f64' unless GPU_PRECISION is 'f32'), 'f64' -- the
+    device generator's normals and the colouring multiply at the reference's float64 precision (funcs.py:352-356, fast.py:594),
+    fused into the row kernels of every FFT family, staged through device memory by the direct kernels -- or 'f32', the opt-in
+    shortcut (float32 normals and colouring into the complex128 transform: ~1.7 x the rate at 1024^2, not the reference's arithmetic);
   * `TEMPORAL` (frozen-flow time series, fast.py:607-637): the layer screens, the bilinear shifts and
     the detector run on the GPU; its draws are always numpy's, in the reference's order (the
     series is sequential and tiny), so the same SEED reproduces the reference;
@@ -111,8 +112,8 @@ class Fast():
             raise Exception("GPU_PRECISION must be 'f64' or 'f32'")
         if self.rng_mode not in ('device', 'host', 'numpy'):
             raise Exception("GPU_RNG must be 'device', 'host' or 'numpy'")
-        if p['GPU_RNG_PRECISION'] not in ('f32', 'f64'):
-            raise Exception("GPU_RNG_PRECISION must be 'f32' or 'f64'")
+        if p['GPU_RNG_PRECISION'] not in ('auto', 'f32', 'f64'):
+            raise Exception("GPU_RNG_PRECISION must be 'auto', 'f32' or 'f64'")
         devs = p['GPU_DEVICES']
         if devs is not None:
             devs = [int(d) for d in (devs if isinstance(devs, (list, tuple, numpy.ndarray)) else [devs])]
@@ -148,8 +149,9 @@ class Fast():
         self.precision = getattr(self._handle, 'precision', self.precision)     # what the handle computes in (see _lib.Handle)
         if p['GPU_BATCH']:
             self._group.set_batch(p['GPU_BATCH'])
-        if p['GPU_RNG_PRECISION'] == 'f64':
-            self._group.each(lambda h, i: h.set_rng_precision('f64'))
+        # the generator at the reference's precision unless the caller chose the float32 pipeline or the float32 draw
+        self.rng_precision = p['GPU_RNG_PRECISION'] if p['GPU_RNG_PRECISION'] != 'auto' else ('f64' if self.precision == 'f64' else 'f32')
+        self._group.each(lambda h, i: h.set_rng_precision(self.rng_precision))
         if p['GPU_KERNELS'] != 'auto':
             if p['GPU_KERNELS'] not in _lib.KERNEL_PATHS:
                 raise Exception("GPU_KERNELS must be 'auto', 'wave', 'lanes50', 'chirpz' or 'direct'")

@@ -23,7 +23,7 @@ M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 W0, W1 = 0x9E3779B9, 0xBB67AE85
 MASK = np.uint64(0xFFFFFFFF)
 STREAM_SCREEN, STREAM_LOGAMP, STREAM_SUBHARM = 0, 1, 2
-STREAM_SCREEN_LO, STREAM_SUBHARM_LO = 3, 4      # second streams: the low bits of the float64 generator (fmc_kernels.h)
+STREAM_SUBHARM_LO = 4      # second Philox blocks of the sub-harmonic draws at float64 precision (fmc_kernels.h)
 
 
 SEED_ROUNDS = 7   # fmc_kernels.h: FMC_SEED_ROUNDS -- Philox rounds of the block that seeds a coefficient stream
@@ -56,17 +56,21 @@ def box_muller(a, b):
 
 
 def box_muller_f64(a, b, a2, b2):
-    """fmc_kernels.h: box_muller_f64 -- the float64 generator (GPU_RNG_PRECISION 'f64'): the words (a, b) of the float32
-    draw lead, (a2, b2) of the second stream supply the low bits:
-      u = (a 2^21 + (a2 >> 11) + 1/2) 2^-53,  t = ((b >> 9) 2^30 + (b2 >> 2)) 2^-53,  sqrt(-2 ln u) exp(2 pi i t)."""
+    """fmc_kernels.h: box_muller_f64 -- the float64 generator (GPU_RNG_PRECISION 'f64', round-5 definition): four 32-bit
+    words make one complex normal,
+      u = RNE(a 2^32 + (a2 | 1)) 2^-64,   t = (b 2^24 + (b2 >> 8)) 2^-56 turns,   sqrt(-2 ln u) exp(2 pi i t):
+    53 significant bits of the uniform at every magnitude down to 2^-64, a 56-bit angle; the leading 32 bits of both are the
+    words (a, b) of the float32 draw (`box_muller`)."""
     a, b, a2, b2 = (np.asarray(w).astype(np.uint64) for w in (a, b, a2, b2))
-    k = (a << np.uint64(21)) | (a2 >> np.uint64(11))
-    u = (k.astype(np.float64) + 0.5) * 2.0 ** -53
-    t = (((b >> np.uint64(9)) << np.uint64(30)) | (b2 >> np.uint64(2))).astype(np.float64) * 2.0 ** -53
+    v = ((a << np.uint64(32)) | (a2 | np.uint64(1))).astype(np.float64)         # uint64 -> float64: round to nearest even
+    u = v * 2.0 ** -64
     r = np.sqrt(-2.0 * np.log(u))
-    # sin / cos of 2 pi t by quadrant reduction (t is exact; 2 pi (t - q / 4) carries one rounding of a small angle)
-    q = np.rint(4.0 * t)
-    x = 2 * np.pi * (t - q / 4.0)
+    # sin / cos of 2 pi t: the 56-bit angle reduced EXACTLY to the nearest quarter turn (|rem| <= 2^53 is a float64; x = 2 pi
+    # 2^-56 rem carries one rounding of a small angle)
+    T = (b << np.uint64(24)) | (b2 >> np.uint64(8))
+    q = (T + (np.uint64(1) << np.uint64(53))) >> np.uint64(54)
+    rem = (T - (q << np.uint64(54))).astype(np.int64)                            # wraps to the signed remainder
+    x = rem.astype(np.float64) * (2 * np.pi * 2.0 ** -56)
     sn, cs = np.sin(x), np.cos(x)
     qi = q.astype(np.int64) & 3
     cos_t = np.where(qi == 0, cs, np.where(qi == 1, -sn, np.where(qi == 2, -cs, sn)))
@@ -94,6 +98,21 @@ def xoshiro128p_next2(s):
     b = (s[1] + s[2]).astype(np.uint32)
     xoshiro128p_next(s)
     return a, b
+
+
+def _rotl32(x, k):
+    return ((x << np.uint32(k)) | (x >> np.uint32(32 - k))).astype(np.uint32)
+
+
+def xoshiro128p_next4(s):
+    """Four words from ONE state advance (fmc_core.h: xoshiro128p::next4): (a, b) as next2, a2 = (rotl(a, 7) ^ s0) | 1,
+    b2 = rotl(b, 13) + s1 (a rotation of each sum combined with one of its terms, in the manner of xoshiro128++)."""
+    a = (s[0] + s[3]).astype(np.uint32)
+    b = (s[1] + s[2]).astype(np.uint32)
+    a2 = ((_rotl32(a, 7) ^ s[0]) | np.uint32(1)).astype(np.uint32)
+    b2 = (_rotl32(b, 13) + s[1]).astype(np.uint32)
+    xoshiro128p_next(s)
+    return a, b, a2, b2
 
 
 def _radix_ok(P):
@@ -168,16 +187,14 @@ def _stream_states(seed, g, N, stream):
 
 def device_coefficients_f64(seed, g, N):
     """(N, N) complex coefficients of realisation g with the generator at float64 precision (fastmc_set_rng_precision
-    FASTMC_F64; == fastmc_rng_coeffs then): the streams of `device_coefficients` plus, for the low bits, the streams seeded
-    with counter word 1 = STREAM_SCREEN_LO, combined by `box_muller_f64`."""
+    FASTMC_F64; == fastmc_rng_coeffs then): the SAME streams as `device_coefficients`, four words per state advance
+    (`xoshiro128p_next4`) combined by `box_muller_f64`."""
     SL = stream_lanes(N)
-    s, lo = _stream_states(seed, g, N, STREAM_SCREEN), _stream_states(seed, g, N, STREAM_SCREEN_LO)
+    s = _stream_states(seed, g, N, STREAM_SCREEN)
     out = np.empty((N, N), dtype=complex)
     with np.errstate(over="ignore"):
         for j in range((N + SL - 1) // SL):
-            a, b = xoshiro128p_next2(s)
-            a2, b2 = xoshiro128p_next2(lo)
-            c = box_muller_f64(a, b, a2, b2)
+            c = box_muller_f64(*xoshiro128p_next4(s))
             w = min(SL, N - SL * j)
             out[:, SL * j:SL * j + w] = c[:, :w]
     return out

@@ -1281,14 +1281,19 @@ def test_fused_float64_generator_rows_match_the_oracle_on_restated_draws(N, Np, 
 
 
 def test_fast_object_with_the_float64_generator():
-    """`GPU_RNG_PRECISION: 'f64'` through Fast(config).run(): same distribution as the float32 generator's run of the same
-    seed (the same normals to 2^-24: the vectors agree to ~1e-6 here), sharded over two handles identical to one."""
+    """The DEFAULT of `Fast(config).run()` on a float64 handle is the generator at the reference's precision (GPU_RNG_PRECISION
+    'auto' = 'f64'); the opt-in float32 draw of the same seed has the same distribution (the same normals to
+    2^-24: the vectors agree to ~1e-6 here); sharded over two handles identical to one; a float32 pipeline draws in float32."""
     g = load_golden("e2e_ao_alias")
     p = params_from_json(g["params_json"])
     p.update({"GPU_DEVICE": 0, "NITER": 400, "NCHUNKS": 4, "SEED": 5, "GPU_RNG": "device"})
-    r32 = fast_amd.Fast(dict(p)).run()._r
-    sim = fast_amd.Fast(dict(p, GPU_RNG_PRECISION="f64"))
+    s32 = fast_amd.Fast(dict(p, GPU_RNG_PRECISION="f32"))
+    r32 = s32.run()._r
+    sim = fast_amd.Fast(dict(p))
+    assert sim.rng_precision == "f64" and s32.rng_precision == "f32"
     r64 = sim.run()._r
+    assert np.array_equal(fast_amd.Fast(dict(p, GPU_RNG_PRECISION="f64")).run()._r, r64)
+    assert fast_amd.Fast(dict(p, GPU_PRECISION="f32")).rng_precision == "f32"
     assert np.isfinite(r64).all() and not np.array_equal(r32, r64)
     np.testing.assert_allclose(r32, r64, rtol=1e-4)
     p2 = dict(p, GPU_RNG_PRECISION="f64", GPU_DEVICES=[0, 0])

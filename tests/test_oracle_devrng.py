@@ -154,8 +154,64 @@ def test_float64_generator_restatement_extends_the_float32_one():
     assert np.abs(la32 - la64).max() < 2e-5 and abs(la64.std() - 1) < 0.1
     s32, s64 = devrng.device_subharm_coefficients(3, 7), devrng.device_subharm_coefficients(3, 7, f64=True)
     assert s64.shape == (3, 3, 3) and np.abs(s32 - s64).max() < 2e-5
-    # extremes of the words stay finite: u in (0, 1), tails to 8.6 sigma
+    # extremes of the words stay finite: u in (0, 1], tails to 9.4 sigma (u >= 2^-64)
     top = np.array([0xFFFFFFFF], dtype=np.uint32)
     zero = np.array([0], dtype=np.uint32)
-    assert np.isfinite(devrng.box_muller_f64(zero, zero, zero, zero)).all() and abs(devrng.box_muller_f64(zero, zero, zero, zero)[0]) > 8.6
+    assert np.isfinite(devrng.box_muller_f64(zero, zero, zero, zero)).all() and abs(devrng.box_muller_f64(zero, zero, zero, zero)[0]) > 9.4
     assert np.isfinite(devrng.box_muller_f64(top, top, top, top)).all() and abs(devrng.box_muller_f64(top, top, top, top)[0]) < 1e-7
+
+
+def test_four_words_of_one_state_advance():
+    """fmc_core.h: xoshiro128p::next4 -- the float64 generator takes (a, b, a2, b2) from ONE state advance: a2 and b2 (the bits
+    below the 32 leading ones of the uniform and of the angle) must be uniform, independent of (a, b), of each other and of the
+    neighbouring steps' words; a2 is odd by construction.  Known answers first (hand-evaluated from the definition)."""
+    s = [np.array([w], dtype=np.uint32) for w in (1, 2, 3, 4)]
+    a, b, a2, b2 = (int(w[0]) for w in devrng.xoshiro128p_next4(s))
+    assert (a, b) == (5, 5)
+    assert a2 == ((5 << 7) ^ 1) | 1 and b2 == (5 << 13) + 2
+    assert [int(w[0]) for w in s] == [int(w[0]) for w in _advance_by_hand(1, 2, 3, 4)]
+    # statistics over the streams of two realisations at 512^2 (2 x 512 rows x 64 streams x 8 steps)
+    N, SL = 512, 64
+    words = []
+    for g in range(2):
+        st = devrng._stream_states(2025, g, N, devrng.STREAM_SCREEN)
+        with np.errstate(over="ignore"):
+            words.append(np.stack([np.stack(devrng.xoshiro128p_next4(st)) for _ in range(N // SL)]))      # (steps, 4, N, SL)
+    w = np.concatenate(words, axis=2).astype(np.float64) / 2.0 ** 32                                      # (steps, 4, 2N, SL) in [0, 1)
+    a, b, a2, b2 = (w[:, i] for i in range(4))
+    assert (np.concatenate(words, axis=2)[:, 2] & 1).all()
+    from scipy import stats
+    for x in (a, b, a2, b2):
+        assert stats.kstest(x.ravel()[::7], "uniform").pvalue > 1e-3
+
+    def chi2_z(x, y, bins=32):
+        H, _, _ = np.histogram2d(x.ravel(), y.ravel(), bins=bins, range=[[0, 1], [0, 1]])
+        e = x.size / bins ** 2
+        dof = bins ** 2 - 1
+        return (((H - e) ** 2 / e).sum() - dof) / np.sqrt(2 * dof)
+    pairs = [(a, a2), (b, b2), (a, b2), (b, a2), (a2, b2), (a2[:-1], a2[1:]), (b2[:-1], b2[1:]), (a2[:-1], a[1:]), (b2[:-1], b[1:]),
+             (a[:-1], a2[1:]), (b[:-1], b2[1:])]
+    for x, y in pairs:
+        assert abs(chi2_z(x, y)) < 5
+    # the low HALF of each extra word too (bits 8 ... 15 of b2 feed the angle below 2^-32, bits 1 ... 15 of a2 the uniform below 2^-48)
+    lo = lambda x: (x * 2.0 ** 16) % 1.0      # noqa: E731
+    for x, y in ((a, lo(a2)), (b, lo(b2)), (lo(a2), lo(b2)), (lo(a2)[:-1], lo(a2)[1:]), (lo(b2)[:-1], lo(b2)[1:])):
+        assert abs(chi2_z(x, y)) < 5
+    # the float64 uniform and angle as the generator forms them: the part BELOW the float32 draw's bits is uniform and independent of it
+    wi = np.concatenate(words, axis=2).astype(np.uint64)
+    u_lo = wi[:, 2].astype(np.float64) / 2.0 ** 32                       # bits 33 ... 64 of u
+    t_lo = (wi[:, 3] >> np.uint64(8)).astype(np.float64) / 2.0 ** 24     # bits 33 ... 56 of t
+    assert abs(chi2_z(a, u_lo)) < 5 and abs(chi2_z(b, t_lo)) < 5 and abs(chi2_z(u_lo, t_lo)) < 5
+
+
+def _advance_by_hand(s0, s1, s2, s3):
+    """xoshiro128 state transition written out (Blackman & Vigna's reference formulation)."""
+    M = 0xFFFFFFFF
+    t = (s1 << 9) & M
+    s2 ^= s0
+    s3 ^= s1
+    s1 ^= s2
+    s0 ^= s3
+    s2 ^= t
+    s3 = ((s3 << 11) | (s3 >> 21)) & M
+    return [np.array([x], dtype=np.uint32) for x in (s0, s1, s2, s3)]

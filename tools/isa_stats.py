@@ -126,6 +126,8 @@ def main_loop(lines):
         m = re.match(r"\s+s_c?branch\w*\s+(\.LBB\w+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             span = (labels[m.group(1)], i)
+            if span[0] < 16 and span[1] > len(lines) - 16:
+                continue      # a branch from the kernel's last block back over its whole body (a cold block placed last): not a loop
             if best is None or span[1] - span[0] > best[1] - best[0]:
                 best = span
     return best if best and best[1] - best[0] > 200 else (0, len(lines) - 1)

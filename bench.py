@@ -387,6 +387,9 @@ def main():
     ap.add_argument("--no-f32-draw-pass", "--no-f64-generator-pass", dest="no_other_precision_pass", action="store_true",
                     help="skip the second timed pass with the other generator precision")
     ap.add_argument("--batch", type=int, default=0, help="realisations per launch (0 = library default)")
+    ap.add_argument("--require-rccl", action="store_true",
+                    help="with N > 1: exit non-zero unless every timed step's exchange ran over RCCL with a communicator of N ranks "
+                         "(a host fall-back must not pass for a scaling point)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
@@ -536,6 +539,9 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     kernels = h.last_kernels()                                            # what the timed steps launched
+    # effective shader clock INSIDE the last row launch of the timed steps (fastmc_last_clock: shader-clock ticks per constant-rate
+    # tick over one workgroup's life in the middle of the launch), per local worker
+    clocks = [c for c in (grp.each(lambda hh, i: hh.last_clock()) if mode != "ranks" else [h.last_clock()]) if c]
     busy = np.asarray(busy, dtype=float).reshape(args.steps, -1)          # (steps, local workers)
     ex_dev = np.asarray(acc["exchange_device_ms"], dtype=float)
     ex_dev = ex_dev.reshape(len(acc["exchange_device_ms"]), -1) if ex_dev.size else np.zeros((0, 1))
@@ -637,6 +643,12 @@ def main():
     else:
         n_devices = len(set(devices))
         rccl_ranks = grp.rccl_ranks if (mode == "threads" and grp.exchange == "rccl") else 0
+    rccl_problem = None
+    if args.require_rccl and workers > 1:
+        if rccl_ranks != workers:
+            rccl_problem = f"--require-rccl: the communicator reports {rccl_ranks} rank(s), {workers} wanted ({exchange_name()})"
+        elif acc["host_steps"] or acc["rccl_steps"] != args.steps:
+            rccl_problem = f"--require-rccl: {acc['rccl_steps']} of {args.steps} timed steps exchanged over RCCL, {acc['host_steps']} on the host ({exchange_name()})"
     if rank == 0:
         total_iters = iters_worker * args.steps * workers
         value = total_iters / dt
@@ -669,6 +681,7 @@ def main():
                        "workers": workers, "devices": devices if mode != "ranks" else "LOCAL_RANK per process",
                        "parallelism": f"realisations sharded over {workers} worker(s) on {n_devices} GPU(s)", "result_exchange": exchange_name(),
                        "rccl_ranks": rccl_ranks,
+                       "rccl_required": (rccl_problem or "met") if args.require_rccl else None,
                        "histogram_total": None if hist_total is None else int(np.sum(hist_total))},
             "roofline": roofline(args, N, Np, tim if (host_cost is None or args.no_pipeline) else host_cost["tim"], args.steps, workers, iters_worker, kernels),
             "pipeline": {"steps_in_flight": 1 if args.no_pipeline else 2,
@@ -686,6 +699,17 @@ def main():
                          "cols_ms": tim["cols_ms"] / args.steps / workers, "finalize_ms": tim["finalize_ms"] / args.steps / workers,
                          "init_s": init_s, "powerspec_kernel_ms_warm": sim.powerspec_kernel_ms},
         }
+        if clocks:
+            ghz = float(np.mean([c[0] for c in clocks]))
+            line["clock"] = {"effective_GHz": ghz, "per_worker_GHz": [c[0] for c in clocks], "stamp_span_us": float(np.mean([c[1] for c in clocks])),
+                             "nominal_GHz": NOMINAL_GHZ,
+                             "how": "fastmc_last_clock: s_memtime against s_memrealtime inside one workgroup in the middle of the last row-kernel "
+                                    "launch of the timed steps (every CU busy with the same kernel)"}
+            rl = line["roofline"]
+            if rl.get("frac") is not None:
+                rl["frac_at_effective_clock"] = rl["frac"] * NOMINAL_GHZ / ghz
+            if rl.get("issue"):
+                rl["issue"]["measured_cycles_per_row_at_effective_clock"] = rl["issue"]["measured_cycles_per_row_at_2.4GHz"] * ghz / NOMINAL_GHZ
         if other:
             key, obj = ("value_f32_draw", "f32_draw") if other_prec == "f32" else ("value_f64_generator", "f64_generator")
             line[key] = total_iters / other["dt"]
@@ -715,6 +739,9 @@ def main():
             pass
         print(json.dumps(line), flush=True)
     sync_all()
+    if rccl_problem:
+        dist.mark_clean_exit()
+        raise SystemExit(rccl_problem if rank == 0 else 3)
     # the line is out: if a thread is still blocked inside RCCL although its communicator was aborted, fast_amd.dist's exit hook
     # skips the runtime teardown -- with status 0 only because the run got here (an exception on the way exits non-zero)
     dist.mark_clean_exit()

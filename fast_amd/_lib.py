@@ -25,7 +25,7 @@ EXPORTS = [
     "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_init_all", "fastmc_comm_world", "fastmc_comm_gather",
     "fastmc_comm_gather_all", "fastmc_comm_destroy", "fastmc_comm_abort", "fastmc_last_exchange_ms",
     "fastmc_run_async", "fastmc_wait", "fastmc_set_rng_precision", "fastmc_temporal_phases", "fastmc_last_kernels",
-    "fastmc_precision", "fastmc_last_result_shape", "fastmc_run_queued", "fastmc_comm_gather_queued",
+    "fastmc_precision", "fastmc_last_result_shape", "fastmc_last_clock", "fastmc_run_queued", "fastmc_comm_gather_queued",
     "fastmc_comm_gather_all_queued", "fastmc_histogram_queued", "fastmc_queue_wait",
     "fastmc_npstream_set_tables", "fastmc_npstream_normals", "fastmc_npstream_logamp", "fastmc_run_npstream",
 ]
@@ -95,6 +95,7 @@ def lib():
     L.fastmc_last_kernels.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
     L.fastmc_precision.argtypes = [vp]
     L.fastmc_last_result_shape.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_int)]
+    L.fastmc_last_clock.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.fastmc_run_queued.argtypes = [vp, u64, i64, i64, C.c_double, C.c_int, C.c_int, C.c_int]
     L.fastmc_comm_gather_queued.argtypes = [vp, i64, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
     L.fastmc_comm_gather_all_queued.argtypes = [C.POINTER(vp), C.c_int, i64, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
@@ -126,6 +127,11 @@ def lib():
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+def last_error():
+    """The message of the calling thread's last failed library call (fastmc_last_error)."""
+    return lib().fastmc_last_error().decode()
 
 
 def _chk(rc):
@@ -421,6 +427,16 @@ class Handle:
 
     def set_batch(self, batch):
         _chk(lib().fastmc_set_batch(self._h, int(batch)))
+
+    def last_clock(self):
+        """(GHz, span in microseconds) of the shader clock inside the last row-kernel launch (fastmc_last_clock), or None when no
+        launch of this handle has stamped it (only the wave family's row kernel does)."""
+        g, us = C.c_double(0.0), C.c_double(0.0)
+        rc = lib().fastmc_last_clock(self._h, C.byref(g), C.byref(us))
+        if rc == -4:           # FASTMC_ESTATE: nothing stamped yet
+            return None
+        _chk(rc)
+        return g.value, us.value
 
     def set_rng_precision(self, precision):
         """Device generator: 'f32' (default) or 'f64' (the reference's 53-bit normals and float64 colouring: fused into the

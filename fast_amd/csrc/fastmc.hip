@@ -179,6 +179,8 @@ struct fastmc_ctx {
   // (HandleLock), with a deadline, so that an exchange a deadline thread is still inside and the caller that gave up on it
   // (fastmc_comm_abort takes no lock) never run on the handle together, and neither can wait for ever
   std::timed_mutex use_mu;
+  unsigned long long* clk = nullptr;   // device: clock stamps of the last k_rows_wave launch (fastmc_last_clock)
+  int comm_slot = -1;      // slot of the communicator tables; -1: the device's (the only form outside the fake-RCCL tests, cslot())
   char last_rows[96] = "", last_cols[96] = "";   // the row / column kernels of the last launch, as c++filt prints them (fastmc_last_kernels)
   bool pending = false;
   QueueSlot q[2];
@@ -539,6 +541,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   h->last_rows[0] = h->last_cols[0] = 0;
   h->batch = 0;
   h->rng_f64 = 0;
+  if (h->comm_slot >= 0) { fastmc_comm_abort(h); h->comm_slot = -1; }     // (fake-RCCL tests: the slot belonged to this handle, not to a device)
   h->path = default_path(h->N, h->blu_P, h->mr_P);
   h->lo = 0;
   h->df = h->dx = h->wsum = 0;
@@ -563,7 +566,7 @@ static void destroy_now(fastmc_ctx* h) {
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
   void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
-                  h->sh_in_im, h->hist, h->gather_buf, h->layers, h->ps_dev};
+                  h->sh_in_im, h->hist, h->gather_buf, h->layers, h->ps_dev, (void*)h->clk};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (auto e : h->pool) hipEventDestroy(e);
@@ -616,6 +619,27 @@ extern "C" int fastmc_last_kernels(fastmc_t* h, char* rows, char* cols, int cap)
   if (!h || !rows || !cols || cap < 1) return fail(FASTMC_EINVAL, "null handle / buffers");
   snprintf(rows, (size_t)cap, "%s", h->last_rows);
   snprintf(cols, (size_t)cap, "%s", h->last_cols);
+  return 0;
+}
+
+// Effective shader clock of the last row-kernel launch that stamped it (k_rows_wave: the wave family): shader-clock ticks per
+// constant-rate tick inside one workgroup in the middle of the launch.  *ghz: the clock in GHz; *span_us: how long the stamping
+// workgroup ran.  Blocks until the handle's stream is idle.  FASTMC_ESTATE when no launch has stamped yet.
+extern "C" int fastmc_last_clock(fastmc_t* h, double* ghz, double* span_us) {
+  if (!h || !ghz || !span_us) return fail(FASTMC_EINVAL, "null handle / outputs");
+  FMC_LOCK(h);
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->clk) return fail(FASTMC_ESTATE, "no row kernel has stamped the clock on this handle yet");
+  unsigned long long c[4] = {0, 0, 0, 0};
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(c, h->clk, sizeof(c), hipMemcpyDeviceToHost));
+  if (c[3] <= c[1] || c[2] <= c[0]) return fail(FASTMC_ESTATE, "no row kernel has stamped the clock on this handle yet");
+  int wall_khz = 0;
+  HIPCHK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, h->device));
+  if (wall_khz <= 0) wall_khz = 100000;                       // gfx9: s_memrealtime counts at 100 MHz
+  const double wall_s = (double)(c[3] - c[1]) / ((double)wall_khz * 1e3);
+  *ghz = (double)(c[2] - c[0]) / wall_s * 1e-9;
+  *span_us = wall_s * 1e6;
   return 0;
 }
 
@@ -1595,6 +1619,10 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
   const bool fused64 = S.mode == 0 && h->rng_f64 && fused_gen64<R>(h);
   const bool gen64 = S.mode == 0 && h->rng_f64 && !fused64;
   const int kmode = fused64 ? 2 : ((S.mode == 1 || gen64) ? 1 : 0);           // MODE of the row kernels
+  if (!h->clk) {       // four words for the row kernel's clock stamps (fastmc_last_clock)
+    HIPCHK(hipMalloc((void**)&h->clk, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(h->clk, 0, 4 * sizeof(unsigned long long), h->stream));
+  }
   // host coefficients: 256 MB per upload; coefficients drawn on the device (S.fill): 2 GiB per array -- fewer, fuller launches
   const bool devcoef = S.mode == 1 && S.coef_dev_re != nullptr;
   if (S.mode == 1) B = std::max(1, std::min<int>(B, (int)(((S.fill || devcoef) ? 2048.0 : 256.0) * 1024 * 1024 / (N2 * 8.0))));
@@ -1690,6 +1718,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     RA.cre = devcoef ? S.coef_dev_re + (size_t)bs * N2 : h->cre;
     RA.cim = devcoef ? S.coef_dev_im + (size_t)bs * N2 : h->cim;
     RA.g64 = h->g64;
+    RA.clk = h->clk;
     ColArgs<R> CA;
     CA.N = N; CA.Np = Np; CA.lo = h->lo; CA.nb = nb;
     CA.V = (const cpx<R>*)h->V; CA.om = RA.om; CA.omS = h->omS;
@@ -1801,6 +1830,7 @@ static int run_locked(fastmc_ctx* h, const RunSpec& S);
 static int histogram_device(fastmc_ctx* h, double lo, double hi, int nbins);
 static int stall_until_abort(const std::vector<int>& devices);
 static std::atomic<int> g_abort_gen[64];      // bumped by fastmc_comm_abort: wakes a stalled exchange of that device
+static int cslot(const fastmc_ctx* h);        // slot of a handle in the communicator tables (its device's, see the definition)
 static int run_checked(fastmc_ctx* h, const RunSpec& S) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   FMC_LOCK(h);
@@ -1941,7 +1971,7 @@ extern "C" int fastmc_queue_wait(fastmc_t* h, int slot, double* out, int64_t out
   if (!q.busy) return fail(FASTMC_ESTATE, "nothing is queued on this slot");
   HIPCHK(hipSetDevice(h->device));
   if (q.stalled) {               // the injected fault: an exchange that never completes, until the caller aborts
-    while (g_abort_gen[h->device & 63].load() == q.stall_gen) usleep(500);      // an abort since the exchange was queued ends the stall
+    while (g_abort_gen[cslot(h)].load() == q.stall_gen) usleep(500);      // an abort since the exchange was queued ends the stall
     const int rc = fail(FASTMC_ECOMM, "exchange aborted (FASTMC_TEST_STALL_GATHER)");
     hipEventSynchronize(q.done);
     { SlotScope sc(h, q); finish_pending(h); }
@@ -2831,7 +2861,15 @@ static int load_rccl() {
   if (g_rccl.lib) return 0;
   if (const char* off = getenv("FASTMC_DISABLE_RCCL"))
     if (off[0] && off[0] != '0') return fail(FASTMC_ECOMM, "RCCL disabled by FASTMC_DISABLE_RCCL");
-  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  // FASTMC_RCCL_LIB: the library to load instead (a path; the tests' stand-in, or an RCCL build that is not on the loader's path)
+  void* lib = nullptr;
+  if (const char* path = getenv("FASTMC_RCCL_LIB")) {
+    if (path[0]) {
+      lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) return fail(FASTMC_ECOMM, std::string("cannot load FASTMC_RCCL_LIB: ") + dlerror());
+    }
+  }
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!lib) return fail(FASTMC_ECOMM, std::string("cannot load librccl: ") + dlerror());
 #define SYM(n)                                                        \
@@ -2860,6 +2898,16 @@ static std::mutex g_comm_mu;
 // the communicator: no thread is ever between "copied the communicator" and "passed it to ncclAllGather" when it is freed.
 // What blocks when a peer is gone is the hipStreamSynchronize AFTER the enqueue, outside this lock.
 static std::timed_mutex g_enq_mu[64];
+// A communicator belongs to a DEVICE: slot device & 63 of the tables above (and of g_abort_gen).  The fake-RCCL tests
+// (FASTMC_RCCL_LIB + FASTMC_TEST_VIRTUAL_RANKS=1: tests/stubs/fake_rccl.cpp) put several ranks on the one device a test box has;
+// their handles carry a slot of their own (32 + rank) so that the group / stream / ordering code below runs with a world of up
+// to 8 where RCCL itself cannot.  Never set with the real library.
+static int cslot(const fastmc_ctx* h) { return h->comm_slot >= 0 ? h->comm_slot : (h->device & 63); }
+static bool virtual_ranks_allowed() {
+  const char* a = getenv("FASTMC_RCCL_LIB");
+  const char* b = getenv("FASTMC_TEST_VIRTUAL_RANKS");
+  return a && a[0] && b && b[0] && b[0] != '0';
+}
 
 // FASTMC_TEST_STALL_GATHER=1: the exchange entry points block, without touching RCCL, until fastmc_comm_abort is called for
 // one of the devices, and then fail -- the fault that the deadline / fall-back tests inject.  =2: the same AFTER the
@@ -2892,9 +2940,9 @@ static int exchange_end(fastmc_ctx* h) {
   h->ex_recorded = true;
   return 0;
 }
-static DeviceComm device_comm(int device) {
+static DeviceComm device_comm(int slot) {
   std::lock_guard<std::mutex> g(g_comm_mu);
-  return g_comm[device & 63];
+  return g_comm[slot & 63];
 }
 
 #if FMC_TU == 0
@@ -2913,21 +2961,21 @@ extern "C" int fastmc_comm_unique_id(uint8_t id128[128]) {
 extern "C" int fastmc_comm_init(fastmc_t* h, const uint8_t id128[128], int world_size, int rank) {
   if (!h || !id128 || world_size < 1 || rank < 0 || rank >= world_size) return fail(FASTMC_EINVAL, "bad argument");
   TRY(load_rccl());
-  if (device_comm(h->device).comm) return fail(FASTMC_ESTATE, "this device already has a communicator (fastmc_comm_destroy first)");
+  if (device_comm(cslot(h)).comm) return fail(FASTMC_ESTATE, "this device already has a communicator (fastmc_comm_destroy first)");
   HIPCHK(hipSetDevice(h->device));
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   ncclComm_t c = nullptr;
-  const int gen = g_abort_gen[h->device & 63].load();
+  const int gen = g_abort_gen[cslot(h)].load();
   NCCLCHK(g_rccl.CommInitRank(&c, world_size, id, rank));
-  if (g_abort_gen[h->device & 63].load() != gen) {
+  if (g_abort_gen[cslot(h)].load() != gen) {
     // fastmc_comm_abort was called while the clique was being built (the caller's deadline passed and it took the host
     // path): the communicator must not appear now
     g_rccl.CommAbort(c);
     return fail(FASTMC_ECOMM, "communicator aborted while it was being initialised");
   }
   std::lock_guard<std::mutex> g(g_comm_mu);
-  g_comm[h->device & 63] = DeviceComm{c, world_size, rank};
+  g_comm[cslot(h)] = DeviceComm{c, world_size, rank};
   return 0;
 }
 #endif
@@ -2936,25 +2984,33 @@ extern "C" int fastmc_comm_init(fastmc_t* h, const uint8_t id128[128], int world
 extern "C" int fastmc_comm_init_all(fastmc_t* const* handles, int n) {
   if (!handles || n < 1 || n > 64) return fail(FASTMC_EINVAL, "bad argument");
   std::vector<int> devs(n);
+  bool shared = false;
   for (int i = 0; i < n; ++i) {
     if (!handles[i]) return fail(FASTMC_EINVAL, "null handle");
     devs[i] = handles[i]->device;
-    for (int j = 0; j < i; ++j)
-      if (devs[j] == devs[i]) return fail(FASTMC_ECOMM, "two handles on one device: RCCL needs one device per rank (use the host exchange)");
-    if (device_comm(devs[i]).comm) return fail(FASTMC_ESTATE, "a device already has a communicator (fastmc_comm_destroy first)");
+    for (int j = 0; j < i; ++j) shared = shared || devs[j] == devs[i];
   }
+  if (shared) {
+    // RCCL needs one device per rank.  Only the stand-in library of the tests takes several ranks on one device: their handles
+    // then get slots of their own in the communicator tables (see cslot)
+    if (!virtual_ranks_allowed() || n > 32)
+      return fail(FASTMC_ECOMM, "two handles on one device: RCCL needs one device per rank (use the host exchange)");
+    for (int i = 0; i < n; ++i) handles[i]->comm_slot = 32 + i;
+  }
+  for (int i = 0; i < n; ++i)
+    if (device_comm(cslot(handles[i])).comm) return fail(FASTMC_ESTATE, "a device already has a communicator (fastmc_comm_destroy first)");
   TRY(load_rccl());
   std::vector<ncclComm_t> comms(n, nullptr);
   std::vector<int> gen(n);
-  for (int i = 0; i < n; ++i) gen[i] = g_abort_gen[devs[i] & 63].load();
+  for (int i = 0; i < n; ++i) gen[i] = g_abort_gen[cslot(handles[i])].load();
   NCCLCHK(g_rccl.CommInitAll(comms.data(), n, devs.data()));
   for (int i = 0; i < n; ++i)
-    if (g_abort_gen[devs[i] & 63].load() != gen[i]) {       // aborted meanwhile (see fastmc_comm_init)
+    if (g_abort_gen[cslot(handles[i])].load() != gen[i]) {       // aborted meanwhile (see fastmc_comm_init)
       for (int j = 0; j < n; ++j) g_rccl.CommAbort(comms[j]);
       return fail(FASTMC_ECOMM, "communicators aborted while they were being initialised");
     }
   std::lock_guard<std::mutex> g(g_comm_mu);
-  for (int i = 0; i < n; ++i) g_comm[devs[i] & 63] = DeviceComm{comms[i], n, i};
+  for (int i = 0; i < n; ++i) g_comm[cslot(handles[i])] = DeviceComm{comms[i], n, i};
   return 0;
 }
 #endif
@@ -2962,7 +3018,7 @@ extern "C" int fastmc_comm_init_all(fastmc_t* const* handles, int n) {
 #if FMC_TU == 0
 extern "C" int fastmc_comm_world(fastmc_t* h, int* world_size, int* rank) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
-  const DeviceComm dc = device_comm(h->device);
+  const DeviceComm dc = device_comm(cslot(h));
   if (world_size) *world_size = dc.comm ? dc.world : 0;
   if (rank) *rank = dc.comm ? dc.rank : -1;
   return 0;
@@ -2988,13 +3044,13 @@ static int comm_enqueue_hist(fastmc_ctx* h, const DeviceComm& dc, int nbins) {
 extern "C" int fastmc_comm_gather(fastmc_t* h, int64_t n_local, double* all_powers, int64_t* hist, double lo_db,
                                   double hi_db, int nbins) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
-  if (stall_requested()) return stall_until_abort({h->device});
+  if (stall_requested()) return stall_until_abort({cslot(h)});
   FMC_LOCK(h);
   int world = 0;
-  const int gen = g_abort_gen[h->device & 63].load();
+  const int gen = g_abort_gen[cslot(h)].load();
   {
-    std::lock_guard<std::timed_mutex> enq(g_enq_mu[h->device & 63]);
-    const DeviceComm dc = device_comm(h->device);
+    std::lock_guard<std::timed_mutex> enq(g_enq_mu[cslot(h)]);
+    const DeviceComm dc = device_comm(cslot(h));
     if (!dc.comm) return fail(FASTMC_ESTATE, "fastmc_comm_init not called for this device (or its communicator was aborted)");
     if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds the last run");
     world = dc.world;
@@ -3007,7 +3063,7 @@ extern "C" int fastmc_comm_gather(fastmc_t* h, int64_t n_local, double* all_powe
     TRY(exchange_end(h));
   }
   if (stall_mode() == 2) {        // fault injection: the collectives are on the stream, the exchange "never completes"
-    while (g_abort_gen[h->device & 63].load() == gen) usleep(500);
+    while (g_abort_gen[cslot(h)].load() == gen) usleep(500);
     hipStreamSynchronize(h->stream);
     finish_pending(h);
     return fail(FASTMC_ECOMM, "exchange aborted after its collectives were enqueued (FASTMC_TEST_STALL_GATHER=2)");
@@ -3016,7 +3072,7 @@ extern "C" int fastmc_comm_gather(fastmc_t* h, int64_t n_local, double* all_powe
   if (hist) HIPCHK(hipMemcpyAsync(hist, h->hist, ((size_t)nbins + 2) * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   finish_pending(h);
-  if (g_abort_gen[h->device & 63].load() != gen) return fail(FASTMC_ECOMM, "the communicator was aborted during the exchange");
+  if (g_abort_gen[cslot(h)].load() != gen) return fail(FASTMC_ECOMM, "the communicator was aborted during the exchange");
   return 0;
 }
 #endif
@@ -3027,7 +3083,7 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
   if (!handles || n < 1 || n > 64) return fail(FASTMC_EINVAL, "bad argument");
   if (stall_requested()) {
     std::vector<int> devs;
-    for (int i = 0; i < n; ++i) if (handles[i]) devs.push_back(handles[i]->device);
+    for (int i = 0; i < n; ++i) if (handles[i]) devs.push_back(cslot(handles[i]));
     return stall_until_abort(devs);
   }
   for (int i = 0; i < n; ++i) if (!handles[i]) return fail(FASTMC_EINVAL, "null handle");
@@ -3039,13 +3095,13 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
     if (!hl.back()->ok) return fail(FASTMC_ESTATE, "a handle is in use by another thread (an exchange that missed its deadline has not returned)");
   }
   std::vector<int> gens(n);
-  for (int i = 0; i < n; ++i) gens[i] = g_abort_gen[handles[i]->device & 63].load();
+  for (int i = 0; i < n; ++i) gens[i] = g_abort_gen[cslot(handles[i])].load();
   std::vector<std::unique_lock<std::timed_mutex>> enq;
-  for (int i = 0; i < n; ++i) enq.emplace_back(g_enq_mu[handles[i]->device & 63]);
+  for (int i = 0; i < n; ++i) enq.emplace_back(g_enq_mu[cslot(handles[i])]);
   std::vector<DeviceComm> dcs(n);
   for (int i = 0; i < n; ++i) {
     fastmc_ctx* h = handles[i];
-    dcs[i] = device_comm(h->device);
+    dcs[i] = device_comm(cslot(h));
     if (!dcs[i].comm || dcs[i].world != n || dcs[i].rank != i)
       return fail(FASTMC_ESTATE, "handles do not match the communicators of fastmc_comm_init_all (same handles, same order)");
     if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds a handle's last run");
@@ -3080,7 +3136,7 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
   if (stall_mode() == 2) {
     for (;;) {
       bool aborted = false;
-      for (int i = 0; i < n; ++i) aborted = aborted || g_abort_gen[handles[i]->device & 63].load() != gens[i];
+      for (int i = 0; i < n; ++i) aborted = aborted || g_abort_gen[cslot(handles[i])].load() != gens[i];
       if (aborted) break;
       usleep(500);
     }
@@ -3098,7 +3154,7 @@ extern "C" int fastmc_comm_gather_all(fastmc_t* const* handles, int n, int64_t n
     finish_pending(handles[i]);
   }
   for (int i = 0; i < n; ++i)
-    if (g_abort_gen[handles[i]->device & 63].load() != gens[i]) return fail(FASTMC_ECOMM, "a communicator was aborted during the exchange");
+    if (g_abort_gen[cslot(handles[i])].load() != gens[i]) return fail(FASTMC_ECOMM, "a communicator was aborted during the exchange");
   return 0;
 }
 #endif
@@ -3112,9 +3168,9 @@ extern "C" int fastmc_comm_gather_queued(fastmc_t* h, int64_t n_local, int want_
   FMC_LOCK(h);
   QueueSlot& q = h->q[slot];
   if (!q.busy) return fail(FASTMC_ESTATE, "fastmc_run_queued on this slot first");
-  if (stall_requested()) { q.stalled = true; q.stall_gen = g_abort_gen[h->device & 63].load(); return 0; }   // fault injection: enqueueing never blocks; the wait will
-  std::lock_guard<std::timed_mutex> enq(g_enq_mu[h->device & 63]);
-  const DeviceComm dc = device_comm(h->device);
+  if (stall_requested()) { q.stalled = true; q.stall_gen = g_abort_gen[cslot(h)].load(); return 0; }   // fault injection: enqueueing never blocks; the wait will
+  std::lock_guard<std::timed_mutex> enq(g_enq_mu[cslot(h)]);
+  const DeviceComm dc = device_comm(cslot(h));
   if (!dc.comm) return fail(FASTMC_ESTATE, "fastmc_comm_init not called for this device (or its communicator was aborted)");
   if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds the last run");
   HIPCHK(hipSetDevice(h->device));
@@ -3144,15 +3200,15 @@ extern "C" int fastmc_comm_gather_all_queued(fastmc_t* const* handles, int n, in
     if (!handles[i]->q[slot].busy) return fail(FASTMC_ESTATE, "fastmc_run_queued on this slot of every handle first");
   }
   if (stall_requested()) {       // fault injection: enqueueing never blocks; the waits will
-    for (int i = 0; i < n; ++i) { handles[i]->q[slot].stalled = true; handles[i]->q[slot].stall_gen = g_abort_gen[handles[i]->device & 63].load(); }
+    for (int i = 0; i < n; ++i) { handles[i]->q[slot].stalled = true; handles[i]->q[slot].stall_gen = g_abort_gen[cslot(handles[i])].load(); }
     return 0;
   }
   std::vector<std::unique_lock<std::timed_mutex>> enq;
-  for (int i = 0; i < n; ++i) enq.emplace_back(g_enq_mu[handles[i]->device & 63]);
+  for (int i = 0; i < n; ++i) enq.emplace_back(g_enq_mu[cslot(handles[i])]);
   std::vector<DeviceComm> dcs(n);
   for (int i = 0; i < n; ++i) {
     fastmc_ctx* h = handles[i];
-    dcs[i] = device_comm(h->device);
+    dcs[i] = device_comm(cslot(h));
     if (!dcs[i].comm || dcs[i].world != n || dcs[i].rank != i)
       return fail(FASTMC_ESTATE, "handles do not match the communicators of fastmc_comm_init_all (same handles, same order)");
     if (n_local <= 0 || n_local > h->last_n_iter * (h->last_coherent ? 2 : 1)) return fail(FASTMC_EINVAL, "n_local exceeds a handle's last run");
@@ -3205,14 +3261,14 @@ extern "C" int fastmc_comm_abort(fastmc_t* h) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   ncclComm_t c = nullptr;
   // not while another thread is handing this communicator to RCCL (see g_enq_mu); never longer than two seconds
-  std::unique_lock<std::timed_mutex> enq(g_enq_mu[h->device & 63], std::defer_lock);
+  std::unique_lock<std::timed_mutex> enq(g_enq_mu[cslot(h)], std::defer_lock);
   (void)enq.try_lock_for(std::chrono::seconds(2));
   {
     std::lock_guard<std::mutex> g(g_comm_mu);
-    c = g_comm[h->device & 63].comm;
-    g_comm[h->device & 63] = DeviceComm();
+    c = g_comm[cslot(h)].comm;
+    g_comm[cslot(h)] = DeviceComm();
   }
-  g_abort_gen[h->device & 63].fetch_add(1);
+  g_abort_gen[cslot(h)].fetch_add(1);
   if (c && g_rccl.lib) {
     hipSetDevice(h->device);
     ncclResult_t r = g_rccl.CommAbort(c);
@@ -3232,12 +3288,12 @@ extern "C" int fastmc_last_exchange_ms(fastmc_t* h, double* ms) {
 extern "C" int fastmc_comm_destroy(fastmc_t* h) {
   if (!h) return fail(FASTMC_EINVAL, "null handle");
   ncclComm_t c = nullptr;
-  std::unique_lock<std::timed_mutex> enq(g_enq_mu[h->device & 63], std::defer_lock);
+  std::unique_lock<std::timed_mutex> enq(g_enq_mu[cslot(h)], std::defer_lock);
   (void)enq.try_lock_for(std::chrono::seconds(2));
   {
     std::lock_guard<std::mutex> g(g_comm_mu);
-    c = g_comm[h->device & 63].comm;
-    g_comm[h->device & 63] = DeviceComm();
+    c = g_comm[cslot(h)].comm;
+    g_comm[cslot(h)] = DeviceComm();
   }
   if (c && g_rccl.lib) {
     hipSetDevice(h->device);

@@ -385,22 +385,18 @@ struct xoshiro128p {
     advance();
   }
   // Four words from ONE state advance (the float64 generator, round 5): (a, b) as next2 -- the float32 draw's words -- and
-  //   a2 = (rotl(a, 7) ^ s0) | 1,   b2 = rotl(b, 13) + s1
-  // (scramblers in the manner of xoshiro128++ on both halves of the state: a rotation of the sum combined with one of its terms).
-  // (a, a2 >> 1) <-> (s0, s3 up to one bit) and (b, b2) <-> (s1, s2) are bijections, so the four words are jointly equidistributed
-  // over the period like the state itself; a2 and b2 only supply the bits BELOW the 32 leading ones of the uniform and of the angle
-  // (fmc_gen64.h), and a2 comes out odd because the uniform wants it so (one v_bitop3_b32 for xor and or).  Five plain
-  // instructions instead of the second stream's eight + the splice, and no second Philox block per lane and row.
+  //   a2 = ((a mod 2^24) 0x9E3779 + s0) | 1,   b2 = (b mod 2^24) 0x85EBCB + s1          (mod 2^32)
+  // -- each sum scrambled once more by a 24-bit multiply and combined with one of its terms (one v_mad_u32_u24 each: a 24-bit
+  // multiply-add issues faster than the rotate of a "++" scrambler; tools/ubench).  (a, a2 >> 1) <-> (s0 up to one bit, s3) and
+  // (b, b2) <-> (s1, s2) are bijections, so the four words are jointly equidistributed over the period like the state itself;
+  // a2 and b2 only supply the bits BELOW the 32 / 24 leading ones of the uniform and of the angle (fmc_gen64.h), and a2 comes out
+  // odd because the uniform wants it so.  Three plain instructions instead of the second stream's eight + the splice, and no
+  // second Philox block per lane and row.
   FMC_HD void next4(uint32_t& a, uint32_t& b, uint32_t& a2, uint32_t& b2) {
     a = s0 + s3;
     b = s1 + s2;
-    const uint32_t ra = (a << 7) | (a >> 25);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FMC_NO_BITOP3)
-    a2 = __builtin_amdgcn_bitop3_b32(ra, s0, 1u, 0xBE);      // (A ^ B) | C: truth table (0xF0 ^ 0xCC) | 0xAA
-#else
-    a2 = (ra ^ s0) | 1u;
-#endif
-    b2 = ((b << 13) | (b >> 19)) + s1;
+    a2 = ((a & 0x00FFFFFFu) * 0x009E3779u + s0) | 1u;
+    b2 = (b & 0x00FFFFFFu) * 0x0085EBCBu + s1;
     advance();
   }
 };

@@ -3,9 +3,9 @@
 // The reference draws 53-bit normals and colours them in float64 (fast/funcs.py:352-356, fast/fast.py:593-594).  Our float64
 // generator turns FOUR 32-bit words into one complex normal (definition: box_muller_f64 below, libm; restated in
 // oracle/devrng.py: box_muller_f64):
-//     u = RNE(a 2^32 + (a2 | 1)) 2^-64,     t = (b 2^24 + (b2 >> 8)) 2^-56 turns,     sqrt(-2 ln u) exp(2 pi i t)
-// -- a uniform with 53 significant bits at every magnitude down to 2^-64 (tails to 9.4 sigma), a 56-bit angle; the leading 32 bits
-// of both are the words (a, b) of the float32 draw, so the two precisions see the same normals to ~2^-24.  The coefficient
+//     u = RNE(a 2^32 + (a2 | 1)) 2^-64,     t = ((b >> 8) 2^32 + b2) 2^-56 turns,     sqrt(-2 ln u) exp(2 pi i t)
+// -- a uniform with 53 significant bits at every magnitude down to 2^-64 (tails to 9.4 sigma), a 56-bit angle; their leading 32 /
+// 24 bits are the words (a, b >> 8) of the float32 draw, so the two precisions see the same normals to ~2^-24.  The coefficient
 // streams take the four words from ONE xoshiro128+ state (fmc_core.h: xoshiro128p::next4); the log-amplitude and sub-harmonic
 // draws from Philox blocks.  (Round 4's definition spliced 53 + 53 bits out of two streams: 14 more integer instructions per
 // coefficient and a second Philox block per lane and row.)
@@ -18,11 +18,11 @@
 //     one rounding, |r'| <= 2^-7, and  -2 ln(1 + r) = r' + r'^2 Q(r')  with a degree-4 near-minimax Q
 //     (tools/gen64_design.py: relative error of y < 4e-17 before rounding);
 //   * sqrt y: v_rsq_f32 seed (2^-22) and ONE cubic correction step in float64 (five instructions): ~1 ulp;
-//   * exp(2 pi i t): the top byte of b indexes a 256-entry table (cos, sin)(2 pi (j + 1/2) / 256); the other 48 bits G, placed
-//     in the mantissa of 2^52 by one v_perm_b32 and one v_alignbit_b32 and reduced by (2^52 + 2^47), are the remainder EXACTLY
+//   * exp(2 pi i t): the top byte of b indexes a 256-entry table (cos, sin)(2 pi (j + 1/2) / 256); the other 48 bits G = (bits 8 ...
+//     23 of b, b2), placed in the mantissa of 2^52 by ONE v_perm_b32 and reduced by (2^52 + 2^47), are the remainder EXACTLY
 //     (one float64 subtraction, no conversion): x = 2 pi 2^-56 (G - 2^47) in [-pi/256, pi/256), sin x and cos x - 1 from two- and
 //     three-term polynomials in w = G - 2^47 (the scale folded into the coefficients), and the table entry (scaled by the
-//     radius) is rotated by x: fourteen float64 instructions, three integer ones.
+//     radius) is rotated by x: fourteen float64 instructions, two integer ones.
 // Everything but the seed is plain IEEE float64 arithmetic with FMAs, so the host emulation (emu_gen64.cpp, tests/
 // test_emu_gen64.py) executes the kernels' arithmetic exactly; draws agree with the libm restatement to ~4e-16 relative
 // (bar in the tests: 2e-14 absolute).
@@ -107,6 +107,7 @@ __device__ __forceinline__ Gen64Entry g64_lds_at(uint32_t byte_off) {
   return e;
 }
 __device__ __forceinline__ Gen64Entry g64_trig_entry(Gen64Lds0, uint32_t b) {
+
   uint32_t off;      // 16 (b >> 24): the top byte selected by SDWA, shifted by four
   asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(4u), "v"(b));
   return g64_lds_at(off);
@@ -131,9 +132,10 @@ FMC_HD float g64_rsq_seed(float x) {
 #endif
 }
 
-// y = -2 ln(V 2^-64), V = RNE(a 2^32 + (a2 | 1)) -- odd before rounding, so never 0.  V = 2^64 (a = 2^32 - 1 and a2 >= 2^32 - 2^10:
-// probability 2^-54) reduces to K = 0, m = 1, interval 64, whose T the table sets to MINUS the polynomial's value at m = 1
-// (gen64_build_table), so that y is exactly 0 there and never negative anywhere.
+// y = -2 ln(V 2^-64), V = RNE(a 2^32 + (a2 | 1)) -- odd before rounding, so never 0 -- is evaluated in g64_pre / g64_post below:
+// u = 2^K m, table entry by the top mantissa bits, r' = fma(m, -2 c_j, 2), y = K (-2 ln 2) + 2 ln c_j + g64_log_poly(r').
+// V = 2^64 (a = 2^32 - 1 and a2 >= 2^32 - 2^10: probability 2^-54) reduces to K = 0, m = 1, interval 64, whose T the table sets
+// to MINUS the polynomial's value at m = 1 (gen64_build_table), so that y is exactly 0 there and never negative anywhere.
 // hi word of m: (hx & 0xFFFFF) + 0x3FE80000 (hipcc, left alone, splits the mask in two and ORs a byte back in: three instructions)
 FMC_HD uint32_t g64_m_hi(uint32_t hx) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -144,17 +146,6 @@ FMC_HD uint32_t g64_m_hi(uint32_t hx) {
   return (hx & 0x000FFFFFu) + 0x3FE80000u;
 #endif
 }
-template <class Tab>
-FMC_HD double g64_neg2log(uint32_t a, uint32_t a2_odd, Tab tab) {
-  const double v = g64_fma((double)a, 0x1p32, (double)a2_odd);     // ONE rounding of the exact 64-bit integer a 2^32 + (a2 | 1)
-  const uint32_t hx = g64_hi(v) + 0x00080000u;            // mantissas >= 1.5 carry into the exponent: m in [0.75, 1.5)
-  const int K = (int)(hx >> 20) - (1023 + 64);              // u = v 2^-64 = 2^K m
-  const double m = g64_mk(g64_m_hi(hx), g64_lo(v));
-  const Gen64Entry e = g64_log_entry(tab, hx);
-  const double p = g64_log_poly(g64_fma(m, e.c2, 2.0));    // r' = -2 (m c_j - 1)
-  return g64_fma((double)K, -0x1.62e42fefa39efp+0, e.T) + p;      // K (-2 ln 2) + 2 ln c_j + p
-}
-
 // sqrt(y), y >= 0
 FMC_HD double g64_sqrt(double y) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(FMC_G64_RSQ64)     // A/B: the float64 estimate instruction instead of cvt + v_rsq_f32 + cvt
@@ -177,7 +168,7 @@ FMC_HD uint32_t g64_alignbit(uint32_t hi, uint32_t lo, int sh) {      // ({hi, l
   return (hi << (32 - sh)) | (lo >> sh);
 #endif
 }
-// 0x43300000 | ((b >> 8) & 0xFFFF): the hi word of 2^52 + G, G = (b & 0xFFFFFF) 2^24 + (b2 >> 8) -- bytes (0x43, 0x30, b.2, b.1)
+// 0x43300000 | ((b >> 8) & 0xFFFF): the hi word of 2^52 + G, G = ((b >> 8) & 0xFFFF) 2^32 + b2 -- bytes (0x43, 0x30, b.2, b.1)
 FMC_HD uint32_t g64_angle_hi(uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t r;      // (as asm: hipcc takes the builtin apart and puts it together again in four instructions)
@@ -188,12 +179,12 @@ FMC_HD uint32_t g64_angle_hi(uint32_t b) {
 #endif
 }
 
-// (cos, sin)(2 pi t) scaled by R, t = (b 2^24 + (b2 >> 8)) 2^-56.  The top byte of b picks the table angle
+// (cos, sin)(2 pi t) scaled by R, t = ((b >> 8) 2^32 + b2) 2^-56.  The top byte of b picks the table angle
 // theta_j = 2 pi (j + 1/2) / 256; the other 48 bits G give w = G - 2^47 exactly and x = 2 pi 2^-56 w in [-pi/256, pi/256):
 //   sin x = w (k1 + z (k3 + z k5)),   cos x - 1 = z (c2 + z (c4 + z c6)),   z = w^2     (truncation < 1e-17; tools/gen64_design.py)
 // then the rotation of the table entry (scaled by R first).
 FMC_HD void g64_sincos_scaled(uint32_t b, uint32_t b2, double R, Gen64Entry e, double& re, double& im) {      // e = g64_trig_entry(tab, b)
-  const double d = g64_mk(g64_angle_hi(b), g64_alignbit(b, b2, 8));              // 2^52 + G
+  const double d = g64_mk(g64_angle_hi(b), b2);                                   // 2^52 + G
   const double w = d - 0x1.08p+52;                                                // G - 2^47
   const double z = w * w;
   double p = g64_fma(z, 0x1.466bc6775aae2p-274, -0x1.4abbce625be53p-163);
@@ -207,14 +198,36 @@ FMC_HD void g64_sincos_scaled(uint32_t b, uint32_t b2, double R, Gen64Entry e, d
   im = g64_fma(tc, sn, g64_fma(ts, cm1, ts));
 }
 
-// One coloured coefficient: sqrt(-2 ln u) exp(2 pi i t) amp.  `a2_odd`: the word a2 with its lowest bit set (the coefficient
-// streams deliver it so: xoshiro128p::next4).  The table entry of the angle is asked for first: its address needs one instruction,
-// and the read is back long before the radius is.
+// One coloured coefficient: sqrt(-2 ln u) exp(2 pi i t) amp, in two halves so that a row kernel can ask for draw j + 1's table
+// entries before it does draw j's arithmetic (g64_pre: the words' integer work and the two table reads; g64_post: everything
+// else).  `a2_odd`: the word a2 with its lowest bit set (the coefficient streams deliver it so: xoshiro128p::next4).
+struct Gen64Pre {
+  double v;            // a 2^32 + a2_odd, rounded once
+  uint32_t hx;         // its hi word + 2^19
+  uint32_t b, b2;
+  Gen64Entry el, et;   // log entry, angle entry
+};
+template <class Tab>
+FMC_HD Gen64Pre g64_pre(uint32_t a, uint32_t b, uint32_t a2_odd, uint32_t b2, Tab tab) {
+  Gen64Pre p;
+  p.et = g64_trig_entry(tab, b);            // asked for first: its address needs one instruction
+  p.v = g64_fma((double)a, 0x1p32, (double)a2_odd);
+  p.hx = g64_hi(p.v) + 0x00080000u;
+  p.el = g64_log_entry(tab, p.hx);
+  p.b = b; p.b2 = b2;
+  return p;
+}
+FMC_HD void g64_post(const Gen64Pre& p, double amp, double& re, double& im) {
+  const int K = (int)(p.hx >> 20) - (1023 + 64);
+  const double m = g64_mk(g64_m_hi(p.hx), g64_lo(p.v));
+  const double pl = g64_log_poly(g64_fma(m, p.el.c2, 2.0));
+  const double y = g64_fma((double)K, -0x1.62e42fefa39efp+0, p.el.T) + pl;
+  const double R = g64_sqrt(y) * amp;
+  g64_sincos_scaled(p.b, p.b2, R, p.et, re, im);
+}
 template <class Tab>
 FMC_HD void box_muller_f64_fast(uint32_t a, uint32_t b, uint32_t a2_odd, uint32_t b2, double amp, Tab tab, double& re, double& im) {
-  const Gen64Entry e = g64_trig_entry(tab, b);
-  const double R = g64_sqrt(g64_neg2log(a, a2_odd, tab)) * amp;
-  g64_sincos_scaled(b, b2, R, e, re, im);
+  g64_post(g64_pre(a, b, a2_odd, b2, tab), amp, re, im);
 }
 
 }  // namespace fmc

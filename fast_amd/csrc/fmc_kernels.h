@@ -68,10 +68,10 @@ __device__ __forceinline__ xoshiro128p row_stream(RngKey key, uint64_t g, int ky
 }
 // ---- the generator at the reference's precision (GPU_RNG_PRECISION 'f64', the default; fast/funcs.py:352-356 draws 53-bit
 // normals).  Four words make one complex normal (fmc_gen64.h has the definition and its fast form):
-//     u = RNE(a 2^32 + (a2 | 1)) 2^-64,   turns t = (b 2^24 + (b2 >> 8)) 2^-56,   (re, im) = sqrt(-2 ln u) (cos, sin)(2 pi t)
+//     u = RNE(a 2^32 + (a2 | 1)) 2^-64,   turns t = ((b >> 8) 2^32 + b2) 2^-56,   (re, im) = sqrt(-2 ln u) (cos, sin)(2 pi t)
 // in float64.  (a, b) are the words of the float32 draw, whose u and t are this draw's cut to their first 24 / 23 bits: the two
 // precisions see the same normals to ~2^-24.  The coefficient streams take (a2, b2) from the SAME xoshiro128+ state as (a, b)
-// (xoshiro128p::next4: the "++" scrambler on both halves of the state) -- round 4 ran a second stream per lane for them.  Tails
+// (xoshiro128p::next4: a 24-bit multiply-add on both halves of the state) -- round 4 ran a second stream per lane for them.  Tails
 // reach 9.4 sigma.
 constexpr uint32_t STREAM_SUBHARM_LO = 4;
 // the definition, with libm (log-amplitude and sub-harmonic draws: a handful per realisation; the coefficient draws run
@@ -80,7 +80,7 @@ __device__ __forceinline__ void box_muller_f64(uint32_t a, uint32_t b, uint32_t 
   const double u = __builtin_fma((double)a, 0x1p32, (double)(a2 | 1u)) * 0x1p-64;
   const double r = sqrt(-2.0 * log(u));
   // the 56-bit angle reduced EXACTLY to the nearest quarter turn: |rem| <= 2^53 is a float64, x carries one rounding
-  const uint64_t T = ((uint64_t)b << 24) | (uint64_t)(b2 >> 8);
+  const uint64_t T = ((uint64_t)(b >> 8) << 32) | (uint64_t)b2;
   const uint64_t q = (T + (1ull << 53)) >> 54;
   const double x = (double)(int64_t)(T - (q << 54)) * 0x1.921fb54442d18p-54;      // 2 pi 2^-56 rem
   double sn, cs;
@@ -176,7 +176,8 @@ struct RowArgs {
   const double* cre;            // host-coefficient mode: [nb][N][N] real parts
   const double* cim;
   BluArgs<R> blu;               // chirp-z family only
-  const Gen64Entry* g64;        // float64 generator (MODE 2): its 128-entry log table (fmc_gen64.h)
+  const Gen64Entry* g64;        // float64 generator (MODE 2): its tables (fmc_gen64.h)
+  unsigned long long* clk = nullptr;   // k_rows_wave: four words for the launch's clock stamps (fastmc_last_clock), or null
 };
 
 struct SubharmArgs {
@@ -496,6 +497,11 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
   // the wave index is wave-uniform: in an SGPR, so that row / realisation indices and the table base addresses
   // derived from it are scalar and the loads use the scalar-base + lane-offset form
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Effective shader clock of THIS launch (fastmc_last_clock): the first lane of the middle workgroup stamps the shader-clock
+  // counter (s_memtime) and the constant-rate counter (s_memrealtime) before and after its rows -- about a hundred
+  // microseconds in the middle of the launch, every CU busy with the same kernel: the clock the row time was paid in.
+  const bool stamp = A.clk != nullptr && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0;
+  if (stamp) { A.clk[0] = (unsigned long long)clock64(); A.clk[1] = (unsigned long long)wall_clock64(); }
   E* xbuf = s_x + w * WCfg<R, P, NS, D>::XELEMS;
   const int N = S * G::N;           // full row length
   LaneRegs<R, P, NS> regs;
@@ -541,7 +547,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
         for (int j = 0; j < P; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[sp + S * (lane + WAVE * j)]);
       } else if constexpr (MODE == 2) {
         // the generator at the reference's precision (fast/funcs.py:352-356, fast/fast.py:593-594): 53-bit normals, float64
-        // colouring; the low bits from the second stream of the same (g, ky, L)
+        // colouring; four words per coefficient from one advance of the stream (g, ky, L)
         static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
         xoshiro128p rs = row_stream(A.key, g, ky, sp + S * lane, WAVE * S);
         // one coefficient at a time, its colouring factor loaded one draw ahead: left alone the compiler issues the sixteen
@@ -553,7 +559,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
           if (j + 1 < P) an = (double)amp[sp + S * (lane + WAVE * (j + 1))];
           ex.loadfence();
           regs.v[j] = draw_coloured_f64(rs, a, Gen64Lds0{});
-          // the draws one after the other: a finished coefficient and the two stream states are pinned here, so that no
+          // the draws one after the other: a finished coefficient and the stream state are pinned here, so that no
           // arithmetic of draw j + 1 starts (and holds registers) before draw j has retired its temporaries
           asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
         }
@@ -622,6 +628,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
       if (oi < A.Np) out[(size_t)oi * N] = mk<R>(regs.xr[s], regs.xi[s]);
     }
   }
+  if (stamp) { A.clk[2] = (unsigned long long)clock64(); A.clk[3] = (unsigned long long)wall_clock64(); }
 }
 
 // EPI 0: detector partial sums; EPI 1: write the cropped screens.

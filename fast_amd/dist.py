@@ -44,11 +44,14 @@ def call_with_deadline(fn, timeout):
             box["value"] = fn()
         except BaseException as e:
             box["err"] = f"{type(e).__name__}: {e}"
+    _EXIT["code"] = None          # an exit code recorded earlier did not end the process (see the exit hooks below)
     th = threading.Thread(target=work, daemon=True, name="fastmc-deadline")
     th.start()
     th.join(timeout)
     if th.is_alive():
         _LEFT_BEHIND.append(th)
+        _EXIT["clean"] = False
+        _install_exit_hooks()     # from here on the process may have to leave through os._exit: record how it meant to exit
         return False, f"no answer within {timeout:g} s"
     if "err" in box:
         return False, box["err"]
@@ -72,7 +75,11 @@ def join_left_behind(timeout):
     t_end = time.monotonic() + timeout
     for th in list(_LEFT_BEHIND):
         th.join(max(0.0, t_end - time.monotonic()))
-    return not stuck_threads()
+    if stuck_threads():
+        return False
+    del _LEFT_BEHIND[:]
+    _remove_exit_hooks()          # nobody is left inside the library: the interpreter can end the ordinary way again
+    return True
 
 
 def post_abort_timeout():
@@ -87,28 +94,58 @@ class ExchangeStuck(RuntimeError):
 
 # ---- exit status when a thread is stuck inside RCCL at interpreter exit
 # Interpreter / runtime teardown would wait for ever for such a thread, so the exit hook leaves through os._exit -- with the
-# status the process was going to exit with: an uncaught exception (sys.excepthook) or sys.exit(n) is recorded here, a run that
-# finished says so with mark_clean_exit(); with neither the status is EX_SOFTWARE (70), never a silent 0.
+# status the process was going to exit with.  Nothing is patched at import: the hooks that record that status (sys.excepthook for
+# an uncaught exception, sys.exit for an exit code) are installed when the FIRST thread is left behind by a
+# deadline and removed again when none is left (join_left_behind); a process that never loses a thread never sees them.
+#   * an uncaught exception -> 1, sys.exit(n) -> n (a bare `raise SystemExit(n)` at top level passes no hook Python offers: it
+#     counts as "nobody said", below -- replacing builtins.SystemExit would break `except SystemExit` around sys.exit);
+#   * a step that FINISHED after its exchange was given up (host fall-back of Fast.run / DeviceGroup / step_sharded) marks the
+#     exit clean itself (mark_clean_exit), so a program that simply ends after it exits 0; bench.py marks it when its line is out;
+#   * none of these (a caller of call_with_deadline that never said its work was done) -> EX_SOFTWARE (70), never a silent 0.
+# A recorded code that did not end the process (a SystemExit somebody caught: argparse inside a framework) is forgotten by the next
+# deadline call or mark_clean_exit.
 _EXIT = {"code": None, "clean": False}
-_orig_excepthook, _orig_exit = sys.excepthook, sys.exit
+_HOOKS = {"on": False, "excepthook": None, "exit": None}
 
 
-def _excepthook(tp, val, tb):
-    _EXIT["code"] = (val.code if isinstance(val.code, int) else (0 if val.code is None else 1)) if isinstance(val, SystemExit) else 1
-    _orig_excepthook(tp, val, tb)
+def _code_of(code):
+    return code if isinstance(code, int) else (0 if code is None else 1)
 
 
-def _exit(code=0):
-    _EXIT["code"] = code if isinstance(code, int) else (0 if code is None else 1)
-    _orig_exit(code)
+def _install_exit_hooks():
+    if _HOOKS["on"]:
+        return
+    _HOOKS.update(on=True, excepthook=sys.excepthook, exit=sys.exit)
+    prev_hook, prev_exit = sys.excepthook, sys.exit
+
+    def excepthook(tp, val, tb):
+        _EXIT["code"] = _code_of(val.code) if isinstance(val, SystemExit) else 1
+        prev_hook(tp, val, tb)
+
+    def exit_(code=0):
+        _EXIT["code"] = _code_of(code)
+        prev_exit(code)
+    _HOOKS["ours"] = (excepthook, exit_)
+    sys.excepthook, sys.exit = excepthook, exit_
 
 
-sys.excepthook, sys.exit = _excepthook, _exit
+def _remove_exit_hooks():
+    if not _HOOKS["on"]:
+        return
+    ours = _HOOKS.get("ours", (None, None))
+    if sys.excepthook is ours[0]:          # (somebody who hooked in after us keeps their hook; ours then just chains)
+        sys.excepthook = _HOOKS["excepthook"]
+    if sys.exit is ours[1]:
+        sys.exit = _HOOKS["exit"]
+    _HOOKS["on"] = False
 
 
 def mark_clean_exit():
-    """The program's work is done and reported: a thread left inside RCCL may be abandoned with exit status 0."""
+    """The program's work is done (and reported): a thread left inside RCCL may be abandoned with exit status 0.  Called by the
+    library itself when a step finished on the host path after its device exchange was given up, and by bench.py when its line
+    is out; an exit code recorded earlier that did not end the process is forgotten."""
     _EXIT["clean"] = True
+    _EXIT["code"] = None
 
 
 def exit_status():
@@ -344,6 +381,8 @@ def step_sharded(handle, transport, seed, real_base, n_real_total, logamp_var=0.
     hist = None if hist_range is None else transport.reduce_hist(handle.histogram(*hist_range))
     info["exchange_host_ms"] = (time.perf_counter() - t1) * 1e3
     info["wall_ms"] = (time.perf_counter() - t0) * 1e3
+    if getattr(transport, "why", ""):
+        mark_clean_exit()          # the step finished on the host path after the device exchange was given up (see the exit hooks)
     return assemble(parts, complex_out=coherent), hist, info
 
 
@@ -376,41 +415,54 @@ def steps_pipelined(handle, transport, seed, steps, logamp_var=0.0, coherent=Fal
                 pass
 
     mode = {}
-    if steps:
-        mode[0] = enqueue(0)
-    i = 0
-    while i < len(steps):
-        if i + 1 < len(steps) and (i + 1) not in mode:
-            mode[i + 1] = enqueue(i + 1)
-        base, n_total = steps[i]
-        real0, n_local = shard_range(n_total, world, rank)
-        nval = 2 * n_local * (2 if coherent else 1)
-        info = {"exchange": "rccl" if mode[i] else "host", "exchange_device_ms": 0.0}
-        t0 = time.perf_counter()
-        if mode[i]:
-            ok, val = call_with_deadline(lambda: handle.queue_wait(i & 1, nval * world, nbins), exchange_timeout())
-            flags = transport.rdzv.all_gather_array(np.array([1 if ok else 0], dtype=np.int32)).ravel()
-            if not flags.all():
-                bad = np.flatnonzero(flags == 0).tolist()
-                transport.degrade(handle, val if not ok else f"rank(s) {bad} reported a failed exchange")
-                ok2, why2 = call_with_deadline(drain, post_abort_timeout())
-                if not ok2:
-                    raise ExchangeStuck(f"queued steps did not drain after the RCCL exchange was aborted: {why2}")
-                mode = {i: enqueue(i)}
-                continue
-            allp, hist = val
-            allp = allp.reshape(world, nval)
-            parts = [allp[r].view(np.complex128) if coherent else allp[r] for r in range(world)]
-            info["exchange_device_ms"] = handle.last_exchange_ms()
-        else:
-            local, lh = handle.queue_wait(i & 1, nval, nbins)
-            t1 = time.perf_counter()
-            parts = transport.gather(local.view(np.complex128) if coherent else local, handle)
-            hist = None if hist_range is None else transport.reduce_hist(lh)
-            info["exchange_host_ms"] = (time.perf_counter() - t1) * 1e3
-        info["wall_ms"] = (time.perf_counter() - t0) * 1e3
-        yield assemble(parts, complex_out=coherent), hist, info
-        i += 1
+    done = False
+    try:
+        if steps:
+            mode[0] = enqueue(0)
+        i = 0
+        while i < len(steps):
+            if i + 1 < len(steps) and (i + 1) not in mode:
+                mode[i + 1] = enqueue(i + 1)
+            base, n_total = steps[i]
+            real0, n_local = shard_range(n_total, world, rank)
+            nval = 2 * n_local * (2 if coherent else 1)
+            info = {"exchange": "rccl" if mode[i] else "host", "exchange_device_ms": 0.0}
+            t0 = time.perf_counter()
+            if mode[i]:
+                ok, val = call_with_deadline(lambda: handle.queue_wait(i & 1, nval * world, nbins), exchange_timeout())
+                flags = transport.rdzv.all_gather_array(np.array([1 if ok else 0], dtype=np.int32)).ravel()
+                if not flags.all():
+                    bad = np.flatnonzero(flags == 0).tolist()
+                    transport.degrade(handle, val if not ok else f"rank(s) {bad} reported a failed exchange")
+                    ok2, why2 = call_with_deadline(drain, post_abort_timeout())
+                    if not ok2:
+                        raise ExchangeStuck(f"queued steps did not drain after the RCCL exchange was aborted: {why2}")
+                    mode = {i: enqueue(i)}
+                    continue
+                allp, hist = val
+                allp = allp.reshape(world, nval)
+                parts = [allp[r].view(np.complex128) if coherent else allp[r] for r in range(world)]
+                info["exchange_device_ms"] = handle.last_exchange_ms()
+            else:
+                local, lh = handle.queue_wait(i & 1, nval, nbins)
+                t1 = time.perf_counter()
+                parts = transport.gather(local.view(np.complex128) if coherent else local, handle)
+                hist = None if hist_range is None else transport.reduce_hist(lh)
+                info["exchange_host_ms"] = (time.perf_counter() - t1) * 1e3
+            info["wall_ms"] = (time.perf_counter() - t0) * 1e3
+            mode.pop(i, None)
+            if getattr(transport, "why", ""):
+                mark_clean_exit()          # finished on the host path after the device exchange was given up
+            yield assemble(parts, complex_out=coherent), hist, info
+            i += 1
+        done = True
+    finally:
+        # a consumer that stops early leaves step i + 1 enqueued (slot busy, on the RCCL path a collective on the stream): empty
+        # both slots under the post-abort deadline, so that the next pass over this handle does not find "slot still in flight"
+        if not done and mode:
+            ok3, why3 = call_with_deadline(drain, post_abort_timeout())
+            if not ok3:
+                logger.warning(f"queued steps did not drain when the pipelined pass was abandoned: {why3}")
 
 
 def histogram_sharded(local_hist, transport):

@@ -169,6 +169,9 @@ class HostHandle:
     def last_kernels(self):
         return "numpy.fft (host path)", "numpy (host path)"
 
+    def last_clock(self):
+        return None
+
     def effective_precision(self):
         return "f64"
 

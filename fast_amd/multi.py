@@ -68,6 +68,13 @@ def run_threads(fns, pool=None):
 call_with_deadline, exchange_timeout = dist.call_with_deadline, dist.exchange_timeout
 
 
+def _virtual_ranks():
+    """The tests' stand-in for librccl.so (FASTMC_RCCL_LIB) takes several ranks on ONE device when FASTMC_TEST_VIRTUAL_RANKS=1
+    (tests/stubs/fake_rccl.cpp; fastmc.hip: cslot): the group / stream / ordering code of the RCCL path then runs with a world of
+    2 ... 8 on the single GPU of a test box.  Never with the real library."""
+    return bool(os.environ.get("FASTMC_RCCL_LIB")) and os.environ.get("FASTMC_TEST_VIRTUAL_RANKS", "0") not in ("", "0")
+
+
 class DeviceGroup:
     """N handles of one (N_grid, Np, precision) problem on N devices.
 
@@ -105,7 +112,7 @@ class DeviceGroup:
 
     def _try_rccl(self, timeout):
         timeout = float(os.environ.get("FASTMC_RCCL_TIMEOUT", "90")) if timeout is None else timeout
-        if len(set(self.devices)) < self.world:
+        if len(set(self.devices)) < self.world and not _virtual_ranks():
             self.exchange = "host (several handles share a device: RCCL needs one device per rank)"
             return
         # the communicators belong to the devices and outlive the handles: a clique left by an earlier group of the
@@ -176,6 +183,8 @@ class DeviceGroup:
             self.last_hist = np.sum([x for x in hs if not np.isscalar(x)], axis=0)
         out = dist.assemble(parts, complex_out=coherent)
         self.last_exchange_wall_ms = (time.perf_counter() - t0) * 1e3
+        if self.degraded is not None:
+            dist.mark_clean_exit()      # a group that gave its clique up finished a step on the host path (dist: exit hooks)
         return out
 
     def _run_rccl(self, seed, real0, ranges, logamp_var, coherent, hist_range):
@@ -207,6 +216,7 @@ class DeviceGroup:
             self.last_hist = np.sum(hs, axis=0)
         self.last_exchange = "host"
         self.last_exchange_wall_ms = (time.perf_counter() - t0) * 1e3
+        dist.mark_clean_exit()          # the step finished on the host path after its device exchange was given up
         return dist.assemble(parts, complex_out=coherent)
 
     # ---- the same steps with TWO in flight: the device never waits for the host between steps
@@ -278,30 +288,44 @@ class DeviceGroup:
                         pass
 
         mode = {}
-        if steps:
-            mode[0] = enqueue(0)
-        i = 0
-        while i < len(steps):
-            if i + 1 < len(steps) and (i + 1) not in mode:
-                mode[i + 1] = enqueue(i + 1)
-            t0 = time.perf_counter()
-            if mode[i]:
-                ok, val = call_with_deadline(lambda: collect(i, True), exchange_timeout())
-            else:
-                ok, val = True, collect(i, False)
-            self.last_exchange_wall_ms = (time.perf_counter() - t0) * 1e3
-            if not ok:
-                # the device exchange gave no result: abort, wait for whatever is still inside the library, empty both slots
-                # and redo this step and the queued one on the host path (same realisations, same numbers)
-                self._degrade(val)
-                ok2, why2 = call_with_deadline(drain, dist.post_abort_timeout())
-                if not ok2:
-                    raise dist.ExchangeStuck(f"queued steps did not drain after the RCCL exchange was aborted: {why2}")
-                mode = {i: enqueue(i)}
-                continue
-            self.last_hist = val[1]
-            yield val
-            i += 1
+        done = False
+        try:
+            if steps:
+                mode[0] = enqueue(0)
+            i = 0
+            while i < len(steps):
+                if i + 1 < len(steps) and (i + 1) not in mode:
+                    mode[i + 1] = enqueue(i + 1)
+                t0 = time.perf_counter()
+                if mode[i]:
+                    ok, val = call_with_deadline(lambda: collect(i, True), exchange_timeout())
+                else:
+                    ok, val = True, collect(i, False)
+                self.last_exchange_wall_ms = (time.perf_counter() - t0) * 1e3
+                if not ok:
+                    # the device exchange gave no result: abort, wait for whatever is still inside the library, empty both slots
+                    # and redo this step and the queued one on the host path (same realisations, same numbers)
+                    self._degrade(val)
+                    ok2, why2 = call_with_deadline(drain, dist.post_abort_timeout())
+                    if not ok2:
+                        raise dist.ExchangeStuck(f"queued steps did not drain after the RCCL exchange was aborted: {why2}")
+                    mode = {i: enqueue(i)}
+                    continue
+                self.last_hist = val[1]
+                mode.pop(i, None)
+                if self.degraded is not None:
+                    dist.mark_clean_exit()
+                yield val
+                i += 1
+            done = True
+        finally:
+            # A consumer that stops early (break, an exception in its loop body, the generator collected) leaves step i + 1
+            # enqueued with its slot busy -- and on the RCCL path a collective on the stream: the next pass over these handles
+            # would find "this slot is still in flight".  Empty both slots of every handle, under the post-abort deadline.
+            if not done and mode:
+                ok3, why3 = call_with_deadline(drain, dist.post_abort_timeout())
+                if not ok3:
+                    logger.warning(f"queued steps did not drain when the pipelined pass was abandoned: {why3}")
 
     def _degrade(self, why):
         """Give the clique up for good: abort every communicator (wakes a blocked exchange) and take the host path."""

@@ -58,16 +58,16 @@ def box_muller(a, b):
 def box_muller_f64(a, b, a2, b2):
     """fmc_kernels.h: box_muller_f64 -- the float64 generator (GPU_RNG_PRECISION 'f64', round-5 definition): four 32-bit
     words make one complex normal,
-      u = RNE(a 2^32 + (a2 | 1)) 2^-64,   t = (b 2^24 + (b2 >> 8)) 2^-56 turns,   sqrt(-2 ln u) exp(2 pi i t):
-    53 significant bits of the uniform at every magnitude down to 2^-64, a 56-bit angle; the leading 32 bits of both are the
-    words (a, b) of the float32 draw (`box_muller`)."""
+      u = RNE(a 2^32 + (a2 | 1)) 2^-64,   t = ((b >> 8) 2^32 + b2) 2^-56 turns,   sqrt(-2 ln u) exp(2 pi i t):
+    53 significant bits of the uniform at every magnitude down to 2^-64, a 56-bit angle; their leading 32 / 24 bits are the
+    words (a, b >> 8) of the float32 draw (`box_muller`)."""
     a, b, a2, b2 = (np.asarray(w).astype(np.uint64) for w in (a, b, a2, b2))
     v = ((a << np.uint64(32)) | (a2 | np.uint64(1))).astype(np.float64)         # uint64 -> float64: round to nearest even
     u = v * 2.0 ** -64
     r = np.sqrt(-2.0 * np.log(u))
     # sin / cos of 2 pi t: the 56-bit angle reduced EXACTLY to the nearest quarter turn (|rem| <= 2^53 is a float64; x = 2 pi
     # 2^-56 rem carries one rounding of a small angle)
-    T = (b << np.uint64(24)) | (b2 >> np.uint64(8))
+    T = ((b >> np.uint64(8)) << np.uint64(32)) | b2
     q = (T + (np.uint64(1) << np.uint64(53))) >> np.uint64(54)
     rem = (T - (q << np.uint64(54))).astype(np.int64)                            # wraps to the signed remainder
     x = rem.astype(np.float64) * (2 * np.pi * 2.0 ** -56)
@@ -100,17 +100,14 @@ def xoshiro128p_next2(s):
     return a, b
 
 
-def _rotl32(x, k):
-    return ((x << np.uint32(k)) | (x >> np.uint32(32 - k))).astype(np.uint32)
-
-
 def xoshiro128p_next4(s):
-    """Four words from ONE state advance (fmc_core.h: xoshiro128p::next4): (a, b) as next2, a2 = (rotl(a, 7) ^ s0) | 1,
-    b2 = rotl(b, 13) + s1 (a rotation of each sum combined with one of its terms, in the manner of xoshiro128++)."""
+    """Four words from ONE state advance (fmc_core.h: xoshiro128p::next4): (a, b) as next2,
+    a2 = ((a mod 2^24) 0x9E3779 + s0) | 1, b2 = (b mod 2^24) 0x85EBCB + s1 (mod 2^32)."""
     a = (s[0] + s[3]).astype(np.uint32)
     b = (s[1] + s[2]).astype(np.uint32)
-    a2 = ((_rotl32(a, 7) ^ s[0]) | np.uint32(1)).astype(np.uint32)
-    b2 = (_rotl32(b, 13) + s[1]).astype(np.uint32)
+    m24 = np.uint64(0xFFFFFF)
+    a2 = (((a.astype(np.uint64) & m24) * np.uint64(0x9E3779) + s[0]) & MASK).astype(np.uint32) | np.uint32(1)
+    b2 = (((b.astype(np.uint64) & m24) * np.uint64(0x85EBCB) + s[1]) & MASK).astype(np.uint32)
     xoshiro128p_next(s)
     return a, b, a2, b2
 

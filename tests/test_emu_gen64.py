@@ -51,7 +51,7 @@ def test_edges_of_the_reductions(emu, tmp_path):
         for a2 in (0, 0xFFFFFFFF, 0x3FF, 0x400, 0x401, 0xFFFFFC00, 0xFFFFFBFF, 0x7FF, 0x800, 0x80000000):
             for b in (0, 0xFFFFFFFF, 0x40000000, 0x3FFFFFFF, 0x80000000, 0x7FFFFFFF, 0xC0000000, 0xBFFFFFFF, 0x20000000, 0xE0000000,
                       0x01000000, 0x00FFFFFF, 0x00800000, 0x007FFFFF, 0xFF800000, 0x3F800000, 0x40800000):
-                for b2 in (0, 0xFFFFFFFF, 0xFF, 0x100):
+                for b2 in (0, 0xFFFFFFFF, 1, 0x80000000, 0x7FFFFFFF):
                     edge.append((a, b, a2, b2))
     w = np.array(edge, dtype=np.uint32)
     got = run(emu, w, tmp_path)

@@ -139,10 +139,37 @@ def test_a_stuck_thread_never_turns_an_error_exit_into_success():
     rc, err = _rc("raise RuntimeError('the run died after an exchange timed out')")
     assert rc == 1 and "the run died" in err
     assert _rc("sys.exit(3)")[0] == 3
-    assert _rc("raise SystemExit(4)")[0] == 4 or _rc("raise SystemExit(4)")[0] == 70     # not via sys.exit: at least not 0
+    assert _rc("raise SystemExit(4)")[0] in (4, 70)   # not via sys.exit: no hook sees it -- "nobody said the run finished", not 0
+    assert _rc("try:\n    sys.exit(5)\nexcept SystemExit:\n    pass\ndist.mark_clean_exit()")[0] == 0     # a caught exit is history
     assert _rc("pass")[0] == 70                       # nobody said the run finished: EX_SOFTWARE, not 0
     assert _rc("dist.mark_clean_exit()")[0] == 0      # the work is done and reported: the stuck thread is abandoned quietly
     assert _rc("dist.mark_clean_exit(); raise ValueError('late failure')")[0] == 1
+
+
+def test_exit_hooks_exist_only_while_a_thread_is_left_behind():
+    """importing fast_amd patches nothing; the hooks appear when a deadline leaves a thread behind and go away when the
+    thread has come back (join_left_behind)."""
+    code = """
+import sys, threading
+hook, ex = sys.excepthook, sys.exit
+sys.path.insert(0, {root!r})
+import fast_amd
+from fast_amd import dist
+assert sys.excepthook is hook and sys.exit is ex
+gate = threading.Event()
+ok, why = dist.call_with_deadline(gate.wait, 0.2)
+assert not ok and dist.stuck_threads()
+assert sys.excepthook is not hook and sys.exit is not ex
+try:
+    sys.exit(9)
+except SystemExit as e:
+    assert e.code == 9
+gate.set()
+assert dist.join_left_behind(5.0) and not dist.stuck_threads()
+assert sys.excepthook is hook and sys.exit is ex
+"""
+    r = subprocess.run([sys.executable, "-c", code.format(root=_ROOT)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
 
 
 def test_left_behind_exchange_is_waited_for_with_a_bound(monkeypatch):

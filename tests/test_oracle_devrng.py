@@ -168,7 +168,7 @@ def test_four_words_of_one_state_advance():
     s = [np.array([w], dtype=np.uint32) for w in (1, 2, 3, 4)]
     a, b, a2, b2 = (int(w[0]) for w in devrng.xoshiro128p_next4(s))
     assert (a, b) == (5, 5)
-    assert a2 == ((5 << 7) ^ 1) | 1 and b2 == (5 << 13) + 2
+    assert a2 == (5 * 0x9E3779 + 1) | 1 and b2 == 5 * 0x85EBCB + 2
     assert [int(w[0]) for w in s] == [int(w[0]) for w in _advance_by_hand(1, 2, 3, 4)]
     # statistics over the streams of two realisations at 512^2 (2 x 512 rows x 64 streams x 8 steps)
     N, SL = 512, 64
@@ -193,14 +193,14 @@ def test_four_words_of_one_state_advance():
              (a[:-1], a2[1:]), (b[:-1], b2[1:])]
     for x, y in pairs:
         assert abs(chi2_z(x, y)) < 5
-    # the low HALF of each extra word too (bits 8 ... 15 of b2 feed the angle below 2^-32, bits 1 ... 15 of a2 the uniform below 2^-48)
+    # the low HALF of each extra word too (bits 0 ... 15 of b2 feed the angle below 2^-40, bits 1 ... 15 of a2 the uniform below 2^-48)
     lo = lambda x: (x * 2.0 ** 16) % 1.0      # noqa: E731
     for x, y in ((a, lo(a2)), (b, lo(b2)), (lo(a2), lo(b2)), (lo(a2)[:-1], lo(a2)[1:]), (lo(b2)[:-1], lo(b2)[1:])):
         assert abs(chi2_z(x, y)) < 5
     # the float64 uniform and angle as the generator forms them: the part BELOW the float32 draw's bits is uniform and independent of it
     wi = np.concatenate(words, axis=2).astype(np.uint64)
     u_lo = wi[:, 2].astype(np.float64) / 2.0 ** 32                       # bits 33 ... 64 of u
-    t_lo = (wi[:, 3] >> np.uint64(8)).astype(np.float64) / 2.0 ** 24     # bits 33 ... 56 of t
+    t_lo = wi[:, 3].astype(np.float64) / 2.0 ** 32                       # bits 25 ... 56 of t
     assert abs(chi2_z(a, u_lo)) < 5 and abs(chi2_z(b, t_lo)) < 5 and abs(chi2_z(u_lo, t_lo)) < 5
 
 

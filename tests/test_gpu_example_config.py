@@ -42,17 +42,19 @@ VARIANTS = [
 def check_result(sim, niter, complex_result=False):
     res = sim.result
     raw = np.asarray(res._r)
-    if not complex_result:
-        assert np.array_equal(np.asarray(sim.I), np.asarray(res.power))      # `I`: the powers, kept for old callers (fast/fast.py:137)
     assert raw.shape == (niter,) and raw.dtype == (np.complex128 if complex_result else np.float64)
     assert np.isfinite(raw).all()
+    if complex_result:          # COHERENT: complex amplitudes relative to the diffraction limit; the unit conversions are for powers
+        assert (np.abs(raw) > 0).all()
+        return
+    assert np.array_equal(np.asarray(sim.I), np.asarray(res.power))      # `I`: the powers, kept for old callers (fast/fast.py:137)
     power = np.asarray(res.power)
     assert power.shape == (niter,) and np.isfinite(power).all() and (power > 0).all()
     # unit conversions of FastResult (fast/fast.py:949-983): dB relative to the diffraction limit, dB of the launched power, dBm
-    np.testing.assert_allclose(res.dB_rel, 10 * np.log10(np.abs(raw) ** 2 if complex_result else raw), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(res.dB_rel, 10 * np.log10(raw), rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(10 ** (np.asarray(res.dB_abs) / 10), power, rtol=1e-11)
     np.testing.assert_allclose(10 ** (np.asarray(res.dBm) / 10) * 1e-3, power, rtol=1e-11)
-    np.testing.assert_allclose(power, (np.abs(raw) ** 2 if complex_result else raw) * sim.diffraction_limit, rtol=1e-12)
+    np.testing.assert_allclose(power, raw * sim.diffraction_limit, rtol=1e-12)
 
 
 @pytest.mark.parametrize("change, grid", VARIANTS, ids=["-".join(f"{k}={v}" for k, v in c.items()) for c, _ in VARIANTS])

@@ -1293,7 +1293,12 @@ def test_fast_object_with_the_float64_generator():
     assert sim.rng_precision == "f64" and s32.rng_precision == "f32"
     r64 = sim.run()._r
     assert np.array_equal(fast_amd.Fast(dict(p, GPU_RNG_PRECISION="f64")).run()._r, r64)
-    assert fast_amd.Fast(dict(p, GPU_PRECISION="f32")).rng_precision == "f32"
+    # 'auto' follows the precision the handle COMPUTES in: a float32 pipeline draws in float32 where the grid has float32 kernels
+    # (NPXLS 256); a grid without them is promoted to float64 (fastmc_create) and then draws in float64 too
+    f32 = fast_amd.Fast(dict(p, GPU_PRECISION="f32", NPXLS=256))
+    assert f32.precision == "f32" and f32.rng_precision == "f32"
+    promoted = fast_amd.Fast(dict(p, GPU_PRECISION="f32"))
+    assert promoted.rng_precision == ("f32" if promoted.precision == "f32" else "f64")
     assert np.isfinite(r64).all() and not np.array_equal(r32, r64)
     np.testing.assert_allclose(r32, r64, rtol=1e-4)
     p2 = dict(p, GPU_RNG_PRECISION="f64", GPU_DEVICES=[0, 0])

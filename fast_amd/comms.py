@@ -89,15 +89,15 @@ def ber_qam(M, EbN0, samples=None):
 
 
 def Q(x):
-    """comms.py:258-262, through the same device code: Q(x) = ber_ook at snr = x with no atmosphere."""
+    """comms.py:258-262, through the same device code: Q(x) = ber_ook at snr = x with no atmosphere.  ONE library call for the
+    whole array (the queries of every non-zero element together; Q(-x) = 1 - Q(x), Q(0) = 1/2)."""
     x = numpy.asarray(x, dtype=float)
     flat = numpy.atleast_1d(x).ravel()
-    out = numpy.empty(flat.shape)
-    for i, v in enumerate(flat):
-        if v > 0:
-            out[i] = ber_ook(20 * numpy.log10(v))
-        elif v == 0:
-            out[i] = 0.5
-        else:
-            out[i] = 1.0 - ber_ook(20 * numpy.log10(-v))
+    out = numpy.full(flat.shape, 0.5)
+    nz = numpy.flatnonzero(flat != 0)
+    if nz.size:
+        queries = [(_lib.LM_BER_OOK, float(20 * numpy.log10(abs(v))), 0.0) for v in flat[nz]]
+        res = _metrics(queries, numpy.ones(1))
+        q = numpy.array([r[0] / r[2] for r in res])
+        out[nz] = numpy.where(flat[nz] > 0, q, 1.0 - q)
     return out.reshape(x.shape) if x.ndim else float(out[0])

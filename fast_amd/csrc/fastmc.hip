@@ -2030,6 +2030,10 @@ struct NpsWork {
   size_t cap_states = 0;
   double* la = nullptr;      // log-amplitude normals of the run (device)
   size_t la_cap = 0;
+  // the device's ziggurat tables and jump table, looked up ONCE per call under g_nps_mu (nps_prepare): the launches below never
+  // touch the map, which fastmc_npstream_set_tables of another thread / device may be inserting into
+  NpsTables* tab = nullptr;
+  NpsJump* jump = nullptr;
 };
 static void nps_free(NpsWork* w) {
   if (w->gstream) hipStreamSynchronize(w->gstream);
@@ -2111,10 +2115,9 @@ static int nps_reserve_states(NpsWork* w, size_t n) {
 static int nps_segment(fastmc_ctx* h, NpsSegArgs& A, NpsSegBuf& b, size_t k, u128 inc, uint64_t n, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
   NpsWork* w = h->nps;
-  const auto& dev = g_nps_dev[h->device];
   const int64_t tiles = nps_tiles_for(n);
   TRY(nps_seg_reserve(b, tiles));
-  A.state = w->states + k; A.inc = inc; A.n = n; A.ntiles = tiles; A.tab = dev.first; A.jump = dev.second;
+  A.state = w->states + k; A.inc = inc; A.n = n; A.ntiles = tiles; A.tab = w->tab; A.jump = w->jump;
   A.events = b.events; A.evcount = b.evcount; A.maps = b.maps; A.tile_e = b.tile_e; A.tile_base = b.tile_base; A.tile_state = b.tile_state;
   A.state_out = w->states + k + 1; A.consumed = w->consumed + k; A.overflow = w->overflow + k;
   static const bool general_scan = [] { const char* e = getenv("FASTMC_NPS_GENERAL_SCAN"); return e && *e == '1'; }();      // (tests)
@@ -2135,7 +2138,7 @@ static bool nps_use_onepass(uint64_t n) {
 static int nps_onepass(fastmc_ctx* h, NpsOneBuf& b, size_t k, u128 inc, uint64_t n, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
   NpsWork* w = h->nps;
-  const auto& dev = g_nps_dev[h->device];
+  const std::pair<NpsTables*, NpsJump*> dev(w->tab, w->jump);
   const int64_t tiles = nps_tiles_for(n, NPS1_NSUB * NPS_SUB);
   if (b.cap_tiles < tiles) {
     for (void* p : {(void*)b.xexit, (void*)b.agg, (void*)b.tile_state}) if (p) hipFree(p);
@@ -2183,12 +2186,17 @@ static void nps_emit(fastmc_ctx* h, const NpsSegArgs& A, uint64_t lo, uint64_t h
   nps_emit2(h, A, nps_range(A, lo, hi, out), none);
 }
 static int nps_prepare(fastmc_ctx* h, const uint64_t state_inc[4], size_t n_states, u128* inc) {
+  NpsTables* tab = nullptr;
+  NpsJump* jump = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_nps_mu);
-    if (!g_nps_dev.count(h->device) || !g_nps_dev[h->device].first)
+    auto it = g_nps_dev.find(h->device);
+    if (it == g_nps_dev.end() || !it->second.first)
       return fail(FASTMC_ESTATE, "fastmc_npstream_set_tables has not been called for this device");
+    tab = it->second.first; jump = it->second.second;
   }
   if (!h->nps) h->nps = new NpsWork;
+  h->nps->tab = tab; h->nps->jump = jump;
   TRY(nps_reserve_states(h->nps, n_states));
   const u128 st = ((u128)state_inc[1] << 64) | state_inc[0];
   *inc = ((u128)state_inc[3] << 64) | state_inc[2];

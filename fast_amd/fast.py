@@ -94,9 +94,9 @@ class Fast():
         self.subharmonics = prob.subharm
         self.ao_mode, self.Dsubap, self.tloop, self.texp = prob.ao_mode, prob.d_wfs, p['TLOOP'], p['TEXP']
         self.Zmax, self.alias, self.noise, self.modal, self.modal_mult = prob.zmax, p['ALIAS'], p['NOISE'], prob.modal, prob.modal_mult
-        self.dx_sat, self.pupil, self.pupil_sat = pup.dx_sat, pup.pupil, pup.pupil_sat
-        self.pupil_mode, self.pupil_mode_sat, self.W0, self.W0_sat = pup.pupil_mode, pup.pupil_mode_sat, pup.W0, pup.W0_sat
-        self.pupil_filter, self.pup_coords = pup.pupil_filter, pup.pup_coords
+        self.dx_sat, self.pupil_sat = pup.dx_sat, pup.pupil_sat           # (pupil, pupil_mode, pupil_filter: properties below)
+        self.pupil_mode_sat, self.W0, self.W0_sat = pup.pupil_mode_sat, pup.W0, pup.W0_sat
+        self.pup_coords = pup.pup_coords
         self.link_budget, self.diffraction_limit = prob.link_budget, prob.diffraction_limit
         self.logamp = numpy.zeros((self.Niter))
         # bookkeeping names of the reference object that a caller may read (fast.py:78-80, 106, 245-257, 528-531)
@@ -239,6 +239,52 @@ class Fast():
             self._grids[which] = g
         return self._grids[which]
 
+    # ---- pupil weights: plain attributes of the reference object, read where they are used -- `pupil * pupil_mode` in every
+    # compute_detector (fast.py:647-649), `pupil_filter` in compute_powerspec (fast.py:488-492) -- so a caller may replace them
+    # after construction.  Here the weights live on the devices: a replacement is uploaded; a new pupil_filter takes effect at
+    # the next compute_powerspec(), as in the reference.  (The arrays of a geometry are shared between objects and read-only:
+    # the first replacement gives this object a description of its own.)
+    def _own_pupil(self):
+        import copy
+        if not getattr(self, "_pupil_owned", False):
+            self._prob.pup = copy.copy(self._prob.pup)
+            self._pupil_owned = True
+        return self._prob.pup
+
+    def _set_weights(self, pupil=None, mode=None):
+        pup = self._own_pupil()
+        Np = self.Npxls_pup
+        for name, a in (("pupil", pupil), ("pupil_mode", mode)):
+            if a is not None:
+                a = numpy.array(a, dtype=float)
+                if a.shape != (Np, Np):
+                    raise ValueError(f"{name} must be ({Np}, {Np})")
+                a.flags.writeable = False
+                setattr(pup, name, a)
+        self._prob.W = pup.pupil * pup.pupil_mode
+        self._group.set_pupil(self._prob.W, pup.crop_lo, self.dx)
+
+    pupil = property(lambda self: self._prob.pup.pupil, lambda self, v: self._set_weights(pupil=v),
+                     doc="(Np, Np) aperture on the pupil grid (fast.py:379-392); assignable")
+    pupil_mode = property(lambda self: self._prob.pup.pupil_mode, lambda self, v: self._set_weights(mode=v),
+                          doc="(Np, Np) fibre / launch mode on the pupil grid; assignable")
+
+    @property
+    def pupil_filter(self):
+        """(N, N) |FT(pupil x mode)|^2-type filter of the log-amplitude spectrum (funcs.py:300-312); assignable -- an (N, N)
+        array or a scalar -- and read by the next compute_powerspec()."""
+        return self._prob.pup.pupil_filter
+
+    @pupil_filter.setter
+    def pupil_filter(self, value):
+        pup = self._own_pupil()
+        N = self.Npxls
+        a = numpy.array(numpy.broadcast_to(numpy.asarray(value, dtype=float), (N, N)))
+        a.flags.writeable = False
+        pup.pupil_filter = a
+        host._PUPIL_TOKEN += 1
+        pup.token = host._PUPIL_TOKEN          # a new array: the device-side cache must not serve the old one
+
     @property
     def powerspec(self):
         """(N, N) residual phase PSD, fft-shifted layout (fast.py:481); fetched from the GPU on first use."""
@@ -362,8 +408,7 @@ class Fast():
         def rstate(words):       # the dict numpy takes for a PCG64 at these state words
             st = _R.bit_generator.state
             st["state"]["state"] = (int(words[1]) << 64) | int(words[0])
-            st["has_uint32"], st["uinteger"] = 0, 0
-            return st
+            return st          # (has_uint32 / uinteger -- a buffered 32-bit half-word -- stay as they are: normal() never touches them)
         c, last = 0, self.Nchunks - 1
         while c < self.Nchunks:
             if c == last:

@@ -189,8 +189,9 @@ def state_words(bit_generator):
 
 
 def set_state(bit_generator, lo_hi):
-    """Put a PCG64 at the 128-bit state (lo, hi) the library returned (its increment is unchanged)."""
+    """Put a PCG64 at the 128-bit state (lo, hi) the library returned.  Its increment is unchanged, and so is the 32-bit half-word
+    an earlier integers() draw may have left buffered (has_uint32 / uinteger): Generator.normal() never reads or clears it, so
+    the reference's generator would still hold it after the same draws."""
     st = bit_generator.state
     st["state"]["state"] = (int(lo_hi[1]) << 64) | int(lo_hi[0])
-    st["has_uint32"], st["uinteger"] = 0, 0
     bit_generator.state = st

@@ -30,7 +30,10 @@
  *     tests inject (tests/test_gpu_dist.py); =2 blocks the same way AFTER the collectives of a real communicator have been
  *     enqueued, holding the handle (the abort then meets a thread with RCCL work on its stream);
  *   - environment: FASTMC_DISABLE_RCCL=1 makes the communicator entry points fail with FASTMC_ECOMM (callers exchange
- *     through the host); FASTMC_NO_DENSE16=1 (read by fastmc_create) keeps the twelve-wave kernels where the
+ *     through the host); FASTMC_RCCL_LIB=<path> names the library to load in place of librccl.so.1 (an RCCL build off the
+ *     loader's path, or the tests' stand-in tests/stubs/fake_rccl.cpp -- with which, and only with which,
+ *     FASTMC_TEST_VIRTUAL_RANKS=1 lets fastmc_comm_init_all take several handles of ONE device as ranks of a clique, so that
+ *     the grouped collectives run on a one-GPU box: tests/test_fake_rccl.py); FASTMC_NO_DENSE16=1 (read by fastmc_create) keeps the twelve-wave kernels where the
  *     sixteen-wave dense-image kernels would run (A/B timing; same results).
  */
 #ifndef FASTMC_H
@@ -207,8 +210,11 @@ int fastmc_kernel_path(fastmc_t* h, int force);
  * the next one.  A handle has two SLOTS (0 and 1), each with its own timing events, pinned host landing buffers and a
  * completion event, so that a caller can keep the stream fed:
  *     run_queued(step 0, slot 0);  for i = 0, 1, ...: { run_queued(step i + 1, slot (i + 1) & 1);  queue_wait(slot i & 1) }
- * Everything is ordered by the handle's one stream (kernels of step i, the exchange of step i, the copy of its results to
- * the slot's pinned buffer, kernels of step i + 1 ...), so the device buffers need no copies of their own.
+ * The kernels and the exchange of step i, then the kernels of step i + 1 ..., are ordered by the handle's compute stream.  The
+ * copies that land a step's results on its slot run on a second, COPY stream behind an event of the compute stream, so that the
+ * next step's kernels do not queue up behind them; the device buffers they read (the result vector, the histogram, the gather
+ * buffer) are single, so every later writer of those buffers first waits for the completion event of the latest landing copies
+ * (fastmc.hip: copy_guard / guard_outputs -- the invariant a new writer of `out`, `hist` or `gather_buf` must keep).
  *   fastmc_run_queued          as fastmc_run_async; fetch != 0 also lands the step's own result vector on the slot;
  *   fastmc_comm_gather_queued  after run_queued on the same slot: enqueue the all-gather of the n_local values per rank
  *                              (want_powers != 0) and / or the all-reduced dB histogram (nbins > 0) and land them on the slot;
@@ -284,14 +290,20 @@ int fastmc_precision(fastmc_t* h);
 int fastmc_set_batch(fastmc_t* h, int batch);
 
 /* Precision of the DEVICE generator (fastmc_run / fastmc_run_async / fastmc_screens; not of the transform, which
- * fastmc_create fixes).  FASTMC_F32 (default): 24-bit uniforms, hardware float32 log / sqrt / sin / cos, float32
- * colouring, fused into the row kernels.  FASTMC_F64: the reference's precision (fast/funcs.py:352-356 draws 53-bit normals,
- * fast/fast.py:594 colours in float64): the same streams with the low bits from a second stream, float64 log / sqrt /
- * sincos in ~90 instructions per coefficient (fast_amd/csrc/fmc_gen64.h: table-driven log, seeded Newton square root,
- * fdlibm kernels; draws within 3e-15 of the libm restatement), FUSED into the row kernels of every FFT family (wave, packed,
- * 50-lane, run-time-split, chirp-z) wherever its 4 KB of tables fit the LDS (no coefficient passes through device memory: half
- * to three quarters of the float32 generator's rate) and staged through device memory otherwise (the direct kernels; coloured
- * in float64 by the host-coefficient kernels).  Both restated in oracle/devrng.py.  fastmc_rng_coeffs / fastmc_rng_logamp return the draws of the precision in force. */
+ * fastmc_create fixes).
+ *   FASTMC_F64: the reference's precision (fast/funcs.py:352-356 draws 53-bit normals, fast/fast.py:594 colours in float64).  Four
+ *     32-bit words per coefficient from ONE advance of its xoshiro128+ stream (round 5; fmc_core.h: next4) make a uniform with 53
+ *     significant bits down to 2^-64 and a 56-bit angle; float64 log / sqrt / sincos in ~60 instructions per coefficient
+ *     (fast_amd/csrc/fmc_gen64.h: table-driven log, seeded cubic square root, table + rotation for the angle; draws within 3e-15
+ *     of the libm restatement), FUSED into the row kernels of every FFT family (wave, packed, 50-lane, run-time-split, chirp-z)
+ *     wherever its 6 KB of tables fit the LDS (no coefficient passes through device memory) and staged through device memory
+ *     otherwise (the direct kernels; coloured in float64 by the host-coefficient kernels).  What `fast_amd.Fast` selects on a
+ *     float64 handle (GPU_RNG_PRECISION 'auto'), what bench.py times, and what a C caller that wants the reference's arithmetic
+ *     end to end must select after fastmc_create.
+ *   FASTMC_F32 (the state fastmc_create leaves, kept for the callers of rounds 1-4): the opt-in shortcut -- 24-bit uniforms,
+ *     hardware float32 log / sqrt / sin / cos, float32 colouring, fused into the row kernels; ~1.7 x the rate at 1024^2.
+ * Both restated in oracle/devrng.py; the leading 32 / 24 bits of the float64 draw's uniform and angle are the float32 draw's words.
+ * fastmc_rng_coeffs / fastmc_rng_logamp return the draws of the precision in force. */
 int fastmc_set_rng_precision(fastmc_t* h, int precision);
 
 /* ---- AO-residual power spectrum (Fast.compute_powerspec, fast/fast.py:445-492) ---- */

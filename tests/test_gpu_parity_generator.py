@@ -1,0 +1,543 @@
+"""GPU parity, device generator: the device's draws (both precisions) against oracle/devrng.py, every row variant a dispatch can
+reach against the oracle on restated draws, family against family, the statistical battery.  (Split out of test_gpu_parity.py in round 5.)"""
+from _parity import *      # noqa: F401,F403 (numpy, pytest, fixtures, fast_amd, the oracle, the shared helpers)
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ generator
+@pytest.mark.parametrize("N", [16, 33, 128, 256, 512, 1024, 2048, 4096, 200, 1000, 1500, 2000])
+def test_device_generator_matches_oracle_restatement(N):
+    h = _lib.Handle(N, max(1, N // 4), "f64", 0)
+    for seed, g in ((1, 0), (0xDEADBEEFCAFE, 5), (7, 2 ** 33 + 3)):
+        got = h.rng_coeffs(seed, g)
+        want = devrng.device_coefficients(seed, g, N)
+        err = np.abs(got - want)
+        # float32 hardware log / sqrt / sin / cos against float64: ~1e-7 typically; the radius loses relative
+        # accuracy where u -> 1 (|ln u| tiny), which 16.8 M draws at 4096^2 do reach
+        assert err.max() < 1e-3 and np.quantile(err, 0.9999) < 1e-5
+    la = h.rng_logamp(9, 2 ** 32 - 4, 16)
+    assert np.abs(la - devrng.device_logamp_normals(9, 2 ** 32 - 4, 16)).max() < 1e-4
+    big = h.rng_coeffs(3, 1)
+    if N >= 512:
+        assert abs(big.real.mean()) < 0.01 and abs(big.real.std() - 1) < 0.01 and abs(big.imag.std() - 1) < 0.01
+        assert abs(np.mean(big.real * big.imag)) < 0.01
+
+
+@pytest.mark.parametrize("N", [64, 128, 256, 512, 1000, 1024, 2048, 4096])
+def test_device_rng_run_matches_oracle_with_restated_generator(N):
+    """2048 and 4096 run as 2 resp. 4 interleaved sub-rows of 1024 (split wave kernels), with 128 resp. 256
+    generator streams per row; 128 / 256 / 512 as packed rows with 8 / 16 / 32 streams per row; the device result must
+    follow the restated generator there too."""
+    Np = 22 if N == 64 else 82
+    h, ps, df, W = _small_problem(N, Np)
+    seed, real0, n = 42, 5, (4 if N <= 512 else 2)
+    got = h.run(seed, real0, n, None, 0.01)
+    coeffs = np.stack([devrng.device_coefficients(seed, real0 + j, N) for j in range(n)])
+    it = 2 * real0
+    chi = devrng.device_logamp_normals(seed, it, 2 * n) * 0.1
+    la = np.concatenate([chi[0::2], chi[1::2]])
+    want = R.powers_from_coefficients(coeffs, ps, df, W, 0.01, la)
+    np.testing.assert_allclose(got, want, rtol=DEVICE_RTOL)
+    if N in (128, 256, 512, 2048):
+        h.kernel_path(0)                               # the direct family draws the same streams
+        np.testing.assert_allclose(h.run(seed, real0, n, None, 0.01), got, rtol=1e-9)
+
+
+def test_device_rng_invariant_to_batch_and_split():
+    h, ps, df, W = _small_problem()
+    ref = h.run(7, 0, 24, None, 0.02)
+    h.set_batch(5)
+    np.testing.assert_array_equal(h.run(7, 0, 24, None, 0.02), ref)
+    h.set_batch(0)
+    a = h.run(7, 0, 10, None, 0.02)
+    b = h.run(7, 10, 14, None, 0.02)
+    np.testing.assert_array_equal(np.r_[a[:10], b[:14], a[10:], b[14:]], ref)
+    h.kernel_path(0)   # direct family: same generator, same answers to rounding
+    np.testing.assert_allclose(h.run(7, 0, 4, None, 0.02), np.r_[ref[:4], ref[24:28]], rtol=1e-9)
+
+
+def test_device_rng_statistics_match_host_mode():
+    """Same distribution as numpy-drawn coefficients: mean dB within 3 sigma, KS p > 0.01."""
+    from scipy import stats
+    N, Np, n = 512, 82, 600
+    h, ps, df, W = _small_problem(N, Np, "f32")
+    dev = h.run(123, 0, n, None, 0.01)
+    rng = np.random.default_rng(0)
+    host = []
+    for _ in range(n // 50):
+        cr, ci = rng.normal(size=(50, N, N)), rng.normal(size=(50, N, N))
+        host.append(h.run_coeffs(cr, ci, rng.normal(scale=0.1, size=100)))
+    host = np.concatenate(host)
+    d1, d2 = 10 * np.log10(dev), 10 * np.log10(host)
+    se = np.sqrt(d1.var() / len(d1) + d2.var() / len(d2))
+    assert abs(d1.mean() - d2.mean()) < 4 * se
+    assert stats.ks_2samp(d1, d2).pvalue > 0.01
+    si1, si2 = (dev / dev.mean()).var(), (host / host.mean()).var()
+    assert abs(si1 / si2 - 1) < 0.25
+
+
+def test_fast_device_mode_end_to_end():
+    g = load_golden("e2e_ao_alias")
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_DEVICE": 0, "NITER": 400, "NCHUNKS": 4, "SEED": 5})
+    sim = fast_amd.Fast(dict(p))
+    r1 = sim.run()._r
+    assert r1.shape == (400,) and np.isfinite(r1).all() and (r1 > 0).all()
+    p2 = dict(p)
+    p2["NCHUNKS"] = 2
+    r2 = fast_amd.Fast(p2).run()._r   # chunking only reorders [Re block | Im block] per chunk
+    np.testing.assert_allclose(np.sort(r1), np.sort(r2), rtol=0, atol=0)
+    ref = g["r"]
+    assert abs(10 * np.log10(r1.mean()) - 10 * np.log10(ref.mean())) < 1.0
+
+
+def test_device_generator_statistical_quality():
+    """Moments, tails, uniformity of phase and independence across lanes / rows / realisations of the
+    device generator (Philox-seeded xoshiro128+ streams + hardware Box-Muller), 4 x 1024^2 draws."""
+    from scipy import stats
+    h = _lib.Handle(1024, 8, "f64", 0)
+    c = np.stack([h.rng_coeffs(2024, g) for g in range(4)])          # (4, 1024, 1024) complex
+    z = np.concatenate([c.real.ravel(), c.imag.ravel()])
+    n = z.size
+    assert abs(z.mean()) < 5 / np.sqrt(n)
+    assert abs(z.var() - 1) < 5 * np.sqrt(2 / n)
+    assert abs(stats.skew(z)) < 5 * np.sqrt(6 / n)
+    assert abs(stats.kurtosis(z)) < 5 * np.sqrt(24 / n)
+    # tails against the normal law: expected counts beyond 3, 4, 5 sigma
+    for k in (3.0, 4.0, 5.0):
+        expect = n * 2 * stats.norm.sf(k)
+        got = np.count_nonzero(np.abs(z) > k)
+        assert abs(got - expect) < 6 * np.sqrt(expect) + 3
+    # |c|^2 / 2 is Exp(1), the phase is uniform
+    assert stats.kstest((np.abs(c[0]) ** 2 / 2).ravel()[::7], "expon").pvalue > 1e-3
+    assert stats.kstest((np.angle(c[1]).ravel()[::7] + np.pi) / (2 * np.pi), "uniform").pvalue > 1e-3
+    # independence: neighbouring lanes, neighbouring stream positions (kx, kx+64), rows, realisations
+    def corr(a, b):
+        return abs(np.mean(a * b)) * np.sqrt(a.size)
+    re = c.real
+    assert corr(re[:, :, :-1], re[:, :, 1:]) < 5
+    assert corr(re[:, :, :-64], re[:, :, 64:]) < 5
+    assert corr(re[:, :-1, :], re[:, 1:, :]) < 5
+    assert corr(re[0], re[1]) < 5 and corr(re[0], c.imag[0]) < 5
+    # different seeds decorrelate
+    assert corr(re[0], h.rng_coeffs(2025, 0).real) < 5
+
+
+@pytest.mark.parametrize("key,pkey", [("r_ao", "params_json"), ("r_noao", "params2_json")])
+def test_device_mode_distribution_matches_reference_output(key, pkey):
+    """4000 GPU iterations with the device generator vs 2000 iterations of the REFERENCE itself
+    (numpy PCG64 draws) on the same configuration: same distribution (two-sample KS), same mean
+    power within 4 standard errors, same scintillation index within 25 %."""
+    from scipy import stats
+    g = load_golden("stat_ref_256")
+    ref = g[key]
+    p = params_from_json(g[pkey])
+    p.update({"GPU_DEVICE": 0, "NITER": 4000, "NCHUNKS": 20, "SEED": 1234, "GPU_RNG": "device"})
+    r = fast_amd.Fast(p).run()._r
+    d1, d2 = 10 * np.log10(r), 10 * np.log10(ref)
+    assert stats.ks_2samp(d1, d2).pvalue > 0.01
+    se = np.sqrt(r.var() / r.size + ref.var() / ref.size)
+    assert abs(r.mean() - ref.mean()) < 4 * se
+    si1, si2 = (r / r.mean()).var(), (ref / ref.mean()).var()
+    assert abs(si1 / si2 - 1) < 0.25
+
+
+@pytest.mark.parametrize("N", [256, 1024, 2048])
+def test_f32_pipeline_tracks_f64_on_the_same_device_draws(N):
+    """Same seed -> same generator words in both precisions; only the transform arithmetic differs.
+    Full-size check of the float32 pipeline against the float64 one (phases of tens of radians)."""
+    ps, df = _vk_spectrum(N, 0.01, 25.0)
+    W = _window_W(82)
+    out = {}
+    for prec in ("f64", "f32"):
+        h = _lib.Handle(N, 82, prec, 0)
+        h.set_spectrum(ps, df)
+        h.set_pupil(W, (N - 82) // 2, 0.01)
+        out[prec] = h.run(77, 3, 16, None, 0.01)
+        scr = h.screens(77, 3, 1)
+        out[prec + "_rms"] = scr.std()
+    assert out["f64_rms"] > 0.5                      # radians rms over the window of one screen (piston-dominated: varies per draw)
+    np.testing.assert_allclose(out["f32"], out["f64"], rtol=5e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("N,Np", [(164, 82), (1002, 82), (302, 150), (2200, 82), (2816, 140)])
+def test_chirpz_device_generator_equals_direct_family(N, Np):
+    h, ps, df, W = _small_problem(N, Np)
+    assert h.kernel_path() == 2
+    a = h.run(7, 3, 6, None, 0.02)
+    coh = h.run(7, 3, 6, None, 0.02, coherent=True)
+    np.testing.assert_allclose(np.abs(coh) ** 2, a, rtol=1e-12)
+    h.set_batch(4)
+    np.testing.assert_array_equal(h.run(7, 3, 6, None, 0.02), a)
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.run(7, 3, 6, None, 0.02), a, rtol=1e-9)
+    # and the restated generator + oracle
+    coeffs = np.stack([devrng.device_coefficients(7, 3 + j, N) for j in range(6)])
+    chi = devrng.device_logamp_normals(7, 6, 12) * np.sqrt(0.02)
+    la = np.concatenate([chi[0::2], chi[1::2]])
+    np.testing.assert_allclose(a, R.powers_from_coefficients(coeffs, ps, df, W, 0.01, la), rtol=DEVICE_RTOL)
+
+
+@pytest.mark.parametrize("N,Np", [(100, 50), (500, 82), (1000, 82), (600, 150), (1400, 82), (2500, 82)])
+def test_lanes50_device_generator_equals_direct_family(N, Np):
+    h, ps, df, W = _small_problem(N, Np)
+    assert h.kernel_path() == 3
+    a = h.run(7, 3, 6, None, 0.02)
+    coh = h.run(7, 3, 6, None, 0.02, coherent=True)
+    np.testing.assert_allclose(np.abs(coh) ** 2, a, rtol=1e-12)
+    h.set_batch(4)
+    np.testing.assert_array_equal(h.run(7, 3, 6, None, 0.02), a)
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.run(7, 3, 6, None, 0.02), a, rtol=1e-9)
+    # and the restated generator (50 streams per row) + oracle
+    coeffs = np.stack([devrng.device_coefficients(7, 3 + j, N) for j in range(6)])
+    chi = devrng.device_logamp_normals(7, 6, 12) * np.sqrt(0.02)
+    la = np.concatenate([chi[0::2], chi[1::2]])
+    np.testing.assert_allclose(a, R.powers_from_coefficients(coeffs, ps, df, W, 0.01, la), rtol=DEVICE_RTOL)
+
+
+@pytest.mark.parametrize("N,Np,lo", [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, None), (1024, 128, None),
+                                     (1024, 200, None), (1024, 256, None), (1024, 400, None), (1024, 82, 0), (1024, 82, 500),
+                                     (1024, 120, 904), (2048, 82, None), (2048, 122, None), (2048, 402, None), (4096, 82, None)])
+def test_p16_row_variants_equal_the_direct_family(N, Np, lo):
+    """P = 16 grids pick their row by window: the 16 x 4 lane factorisation with six of sixteen planes (centred, <= 96 pixels; dense
+    at 1024^2), eight planes (97-128), all planes (anything else, NS = 2 / 4 / 8).  Each against the direct family on the same
+    device draws, and the screens of host coefficients against numpy."""
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    lo = (N - Np) // 2 if lo is None else lo
+    h = _lib.Handle(N, Np, "f64", 0)
+    h.set_spectrum(ps * 0.02, df)
+    h.set_pupil(_window_W(Np), lo, 0.01)
+    assert h.kernel_path() == 1
+    n = 2 if N <= 2048 else 1
+    a = h.run(11, 5, n, None, 0.02)
+    h.set_batch(1)
+    np.testing.assert_array_equal(h.run(11, 5, n, None, 0.02), a)
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.run(11, 5, n, None, 0.02), a, rtol=1e-9)
+    if N == 1024:
+        h.kernel_path(1)
+        rng = np.random.default_rng(Np)
+        cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
+        z = np.fft.fftshift(np.fft.fft2(np.fft.fftshift((cr[0] + 1j * ci[0]) * np.sqrt(ps * 0.02) * df)))[lo:lo + Np, lo:lo + Np]
+        got = h.screens_coeffs(cr, ci)
+        assert max(np.abs(got[0] - z.real).max(), np.abs(got[1] - z.imag).max()) <= 1e-11 * np.abs(z).max()
+
+
+# Every device-generator instantiation a dispatch can reach, each DIRECTLY against the oracle (not through another HIP
+# kernel): fastmc.hip:dispatch_wave picks the row by (P, window): at P = 16 the 16 x 4 lane factorisation with six planes
+# (centred window <= 96 pixels; dense sixteen-wave kernels at 1024^2 -- the BENCHMARKED instantiation
+# k_rows_wave<double,16,2,0,1,4> --, twelve-wave / split rows at 2048^2 and 4096^2), eight planes (97-128 pixels), all
+# sixteen planes (any other window: NS = 2, 4, 8), the dense 8 x 8 row with all eight / six of eight planes for off-centre
+# windows; P = 18, 20, 24, 28 without the planes a centred window never reads; the 50-lane and run-time-split rows with and
+# without pruned planes; chirp-z and the general rows of the other sizes.
+_VARIANTS = [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, None), (1024, 128, None), (1024, 200, None),
+             (1024, 256, None), (1024, 400, None), (1024, 82, 0), (1024, 82, 340), (1024, 82, 500), (1024, 120, 904),
+             (2048, 82, None), (2048, 122, None), (2048, 402, None), (4096, 82, None),
+             (1152, 82, None), (1280, 82, None), (1536, 82, None), (1792, 82, None), (512, 82, None), (256, 82, None), (768, 152, None),
+             (1000, 82, None), (2000, 82, None), (1200, 82, None), (500, 82, None), (3072, 82, None), (1344, 82, None),
+             (164, 82, None), (943, 82, None),
+             # packed rows (eight / four / two rows per wavefront): six centred planes, all planes, off-centre and wide windows, the whole
+             # grid, and a window beyond the packed kernels (512, 300: device draws go to the direct family)
+             (128, 82, None), (128, 96, None), (128, 97, None), (128, 40, 0), (128, 128, None), (128, 60, 68),
+             (256, 96, None), (256, 97, None), (256, 40, 0), (256, 82, 100), (256, 200, None), (256, 256, None),
+             (512, 96, None), (512, 128, None), (512, 82, 3), (512, 250, 7), (512, 256, 256), (512, 300, None)]
+
+
+@pytest.mark.parametrize("N,Np,lo", _VARIANTS)
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_every_device_mode_row_variant_matches_the_oracle(N, Np, lo, prec):
+    if prec == "f32" and (N > 2048 or (N, Np, lo) not in [(1024, 82, None), (1024, 128, None), (1024, 200, None), (2048, 82, None), (1000, 82, None), (512, 82, None),
+                                                         (256, 82, None), (256, 200, None), (512, 250, 7), (128, 82, None), (128, 128, None)]):
+        pytest.skip("float32 pipeline: the benchmarked shapes only")
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    ps = ps * 0.02
+    lo = (N - Np) // 2 if lo is None else lo
+    W = _window_W(Np)
+    h = _lib.Handle(N, Np, prec, 0)
+    h.set_spectrum(ps, df)
+    h.set_pupil(W, lo, 0.01)
+    seed, real0, n = 2026, 7, (2 if N <= 1536 else 1)
+    got = h.run(seed, real0, n, None, 0.01)
+    # (1) against the RESTATEMENT of the generator: nothing in `want` comes from the device, so a variant whose fused draw and
+    #     read-back agreed with each other and both differed from the definition would fail here
+    want = _oracle_powers_from_restated_draws(seed, real0, n, ps, df, W, lo, 0.01, 0.01)
+    assert (want > 1e-3).all()                                  # few-radian screens: no deep fade amplifies the rounding
+    np.testing.assert_allclose(got, want, rtol=DEVICE_RTOL if prec == "f64" else 2e-4)
+    # (2) against the oracle on the device's own read-back draws (fastmc_rng_coeffs, float32 colouring as the kernels colour):
+    #     tighter, because the hardware transcendentals' ~1e-7 cancels
+    want_rb = _oracle_powers_from_device_draws(h, seed, real0, n, ps, df, W, lo, 0.01, 0.01)
+    np.testing.assert_allclose(got, want_rb, rtol=DEVICE_RTOL if prec == "f64" else 2e-4)
+    if prec == "f64":
+        assert np.abs(got / want_rb - 1).max() < 2e-6           # what is actually observed: ~1e-7
+
+
+def test_benchmarked_instantiation_at_baseline_size_matches_the_oracle():
+    """BASELINE configs[1] as bench.py runs it (1024^2, Np = 82, NOAO von Karman spectrum of the HV5/7 profile at 55 deg,
+    L0 = inf: 13 rad rms screens, deep fades included): 16 iterations of k_rows_wave<double,16,2,0,1,4> + its column kernel
+    against the oracle on the device's own draws.  Bar 1e-5 relative to the MEAN power (a fade of 1e-4 of the mean amplifies
+    any rounding 1e4-fold in relative terms) and 1e-4 on every single power."""
+    g = load_golden("big_noao_1024")
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_DEVICE": 0, "GPU_RNG": "device", "NITER": 16, "NCHUNKS": 1, "SEED": 77})
+    sim = fast_amd.Fast(p)
+    assert sim.Npxls == 1024 and sim.Npxls_pup == 82 and sim._handle.kernel_path() == 1
+    r = sim.run()._r
+    h = sim._handle
+    lo = int(sim._prob.pup.crop_lo)
+    want = _oracle_powers_from_device_draws(h, 77, 0, 8, sim.powerspec, sim._prob.df, sim._prob.W, lo, sim.dx, float(sim.logamp_var))
+    assert np.abs(r - want).max() < 1e-5 * want.mean()
+    np.testing.assert_allclose(r, want, rtol=1e-4)
+
+
+@pytest.mark.parametrize("N,Np,sub", [(512, 82, False), (1024, 82, False), (1000, 82, False), (2048, 82, False), (164, 82, False), (256, 40, True),
+                                      (128, 40, True), (512, 82, True), (256, 200, True), (128, 128, False)])
+def test_float64_device_generator_matches_its_restatement(N, Np, sub):
+    """GPU_RNG_PRECISION 'f64' (fastmc_set_rng_precision): 53-bit normals, float64 log / sqrt / sincospi, float64 colouring
+    -- the reference's precision (funcs.py:352-356, fast.py:594).  Its draws equal oracle/devrng.py's restatement to a few
+    ulp, the powers equal the oracle's on those draws to the float64 pipeline's bar (1e-9), on every kernel family, whatever
+    the batch; and the float32 generator's powers for the same seed differ from it by what the float32 shortcut costs."""
+    h, ps, df, W = _small_problem(N, Np)
+    h.set_rng_precision("f64")
+    seed, real0, n = 31, 4, (3 if N <= 1024 else 1)
+    for g in (real0, 2 ** 33 + 1):
+        assert np.abs(h.rng_coeffs(seed, g) - devrng.device_coefficients_f64(seed, g, N)).max() < 2e-14
+    la_n = h.rng_logamp(seed, 2 * real0, 2 * n)
+    assert np.abs(la_n - devrng.device_logamp_normals(seed, 2 * real0, 2 * n, f64=True)).max() < 2e-14
+    sub_args = None
+    if sub:
+        grid = R.subharm_grid(N, 0.01)
+        ps_lo = np.random.default_rng(1).uniform(0.5, 2.0, size=(3, 3, 3)) * 1e-3
+        h.set_subharm(ps_lo, grid.fx, grid.fy, grid.df)
+        rand_lo = np.stack([devrng.device_subharm_coefficients(seed, real0 + j, f64=True) for j in range(n)])
+        sub_args = (rand_lo, ps_lo, grid)
+    got = h.run(seed, real0, n, None, 0.01)
+    coeffs = np.stack([devrng.device_coefficients_f64(seed, real0 + j, N) for j in range(n)])
+    chi = devrng.device_logamp_normals(seed, 2 * real0, 2 * n, f64=True) * 0.1
+    la = np.concatenate([chi[0::2], chi[1::2]])
+    want = R.powers_from_coefficients(coeffs, ps, df, W, 0.01, la, sub=sub_args)
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    h.set_batch(2)
+    np.testing.assert_array_equal(h.run(seed, real0, n, None, 0.01), got)
+    h.set_batch(0)
+    h.run_async(seed, real0, n, 0.01)
+    np.testing.assert_array_equal(h.wait(), got)
+    fam = h.kernel_path()
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.run(seed, real0, n, None, 0.01), got, rtol=1e-9)
+    h.kernel_path(fam)
+    scr = h.screens(seed, real0, 1)
+    z = R.screens_fftw(coeffs[:1] * np.sqrt(ps), df)
+    lo = (N - Np) // 2
+    if not sub:
+        assert np.abs(scr[0] - z[0].real[lo:lo + Np, lo:lo + Np]).max() < 1e-10 * np.abs(z).max()
+    # the float32 generator on the same seed: the same normals to ~2^-24
+    h.set_rng_precision("f32")
+    f32 = h.run(seed, real0, n, None, 0.01)
+    assert np.abs(f32 / got - 1).max() < DEVICE_RTOL
+    err = np.abs(h.rng_coeffs(seed, real0) - coeffs[0])          # 24-bit u: the radius loses relative accuracy where u -> 1
+    assert err.max() < 1e-3 and np.quantile(err, 0.9999) < 1e-5
+
+
+# every MODE 2 instantiation a dispatch reaches (fastmc.hip: dispatch_wave): dense six / eight planes, twelve-wave six / eight /
+# sixteen planes, NS = 4 / 8, split rows of 2048 / 4096, off-centre windows; the packed rows; every other P of the family
+_FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"),
+            (1024, 97, None, "k_rows_wave<double, 16, 2, 2, 1, 8>"), (1024, 128, None, "k_rows_wave<double, 16, 2, 2, 1, 8>"),
+            (1024, 82, 0, "k_rows_wave<double, 16, 2, 2, 1, 7>"), (1024, 120, 904, "k_rows_wave<double, 16, 2, 2, 1, 7>"),
+            (1024, 200, None, "k_rows_wave<double, 16, 4, 2, 1, 7>"), (1024, 400, None, "k_rows_wave<double, 16, 8, 2, 1, 7>"),
+            (2048, 82, None, "k_rows_wave<double, 16, 2, 2, 2, 4>"), (2048, 122, None, "k_rows_wave<double, 16, 2, 2, 2, 6>"),
+            (2048, 402, None, "k_rows_wave<double, 16, 8, 2, 2, 7>"), (4096, 82, None, "k_rows_wave<double, 16, 2, 2, 4, 4>"),
+            # packed rows (eight / four / two rows per wavefront): centred six planes and all planes
+            (128, 82, None, "k_rows_pk<double, 0, 2, 0>"), (128, 128, None, "k_rows_pk<double, 0, 2, 1>"),
+            (256, 82, None, "k_rows_pk<double, 1, 2, 0>"), (256, 200, None, "k_rows_pk<double, 1, 2, 1>"), (256, 82, 100, "k_rows_pk<double, 1, 2, 1>"),
+            (512, 96, None, "k_rows_pk<double, 2, 2, 0>"), (512, 250, 7, "k_rows_pk<double, 2, 2, 1>"),
+            # the other one-row-per-wave grids (192 ... 1792): the plain variant, windows of up to 128 / 256 pixels
+            (192, 30, None, "k_rows_wave<double, 3, 2, 2, 1, 0>"), (320, 82, 3, "k_rows_wave<double, 5, 2, 2, 1, 0>"),
+            (384, 60, None, "k_rows_wave<double, 6, 2, 2, 1, 0>"), (448, 128, None, "k_rows_wave<double, 7, 2, 2, 1, 0>"),
+            (576, 82, None, "k_rows_wave<double, 9, 2, 2, 1, 0>"), (576, 200, None, "k_rows_wave<double, 9, 4, 2, 1, 0>"),
+            (640, 82, None, "k_rows_wave<double, 10, 2, 2, 1, 0>"), (640, 250, 11, "k_rows_wave<double, 10, 4, 2, 1, 0>"),
+            (768, 82, None, "k_rows_wave<double, 12, 2, 2, 1, 0>"), (768, 256, None, "k_rows_wave<double, 12, 4, 2, 1, 0>"),
+            (896, 100, None, "k_rows_wave<double, 14, 2, 2, 1, 0>"), (1152, 82, None, "k_rows_wave<double, 18, 2, 2, 1, 0>"),
+            (1280, 82, None, "k_rows_wave<double, 20, 2, 2, 1, 0>"), (1280, 200, None, "k_rows_wave<double, 20, 4, 2, 1, 0>"),
+            (1536, 120, 1400, "k_rows_wave<double, 24, 2, 2, 1, 0>"), (1536, 222, None, "k_rows_wave<double, 24, 4, 2, 1, 0>"),
+            (1792, 82, None, "k_rows_wave<double, 28, 2, 2, 1, 0>"),
+            # 50-lane family (N = 50 P S) and the run-time-split wave grids: the rows of fmc_mrfft.h
+            (100, 40, None, "k_rows_mr<double, 2, 2, 2, false, 50, 0>"), (300, 60, None, "k_rows_mr<double, 6, 2, 2, false, 50, 0>"),
+            (500, 82, None, "k_rows_mr<double, 10, 2, 2, false, 50, 0>"), (800, 96, 3, "k_rows_mr<double, 16, 2, 2, false, 50, 0>"),
+            (1000, 82, None, "k_rows_mr<double, 20, 2, 2, false, 50, 0>"), (1000, 200, None, "k_rows_mr<double, 20, 4, 2, false, 50, 0>"),
+            (1200, 100, None, "k_rows_mr<double, 24, 2, 2, false, 50, 0>"), (2000, 82, None, "k_rows_mr<double, 20, 2, 2, true, 50, 0>"),
+            (1750, 70, None, "k_rows_mr<double, 7, 2, 2, true, 50, 0>"), (1344, 82, None, "k_rows_mr<double, 7, 2, 2, true, 64, 0>"),
+            (2560, 120, None, "k_rows_mr<double, 20, 2, 2, true, 64, 0>"),
+            # chirp-z family (any other N): one transform of length 64 P, and rows in input blocks beyond 2048
+            (164, 60, None, "k_rows_blu<double, 4, 2, 2, false>"), (291, 82, 5, "k_rows_blu<double, 8, 2, 2, false>"),
+            (722, 200, None, "k_rows_blu<double, 16, 4, 2, false>"), (1111, 82, None, "k_rows_blu<double, 24, 2, 2, false>"),
+            (1901, 82, None, "k_rows_blu<double, 32, 2, 2, false>"), (3901, 82, None, "k_rows_blu<double, 16, 2, 2, true>")]
+
+
+@pytest.mark.parametrize("N,Np,lo,kernel", _FUSED64)
+def test_fused_float64_generator_rows_match_the_oracle_on_restated_draws(N, Np, lo, kernel):
+    """MODE 2 of the row kernels of every FFT family (fmc_kernels.h): the float64 generator drawn inside the row.  Powers against the
+    oracle on oracle/devrng.py's float64 restatement at the float64 pipeline's bar (1e-9: nothing float32 is left in the
+    path), the kernel that ran is the fused one, and the staged form (FASTMC_GEN64_STAGED: k_gen_coeffs_f64 -> MODE 1 rows)
+    is covered by test_float64_device_generator_matches_its_restatement on the other families."""
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    ps = ps * 0.02
+    lo = (N - Np) // 2 if lo is None else lo
+    W = _window_W(Np)
+    h = _lib.Handle(N, Np, "f64", 0)
+    h.set_spectrum(ps, df)
+    h.set_pupil(W, lo, 0.01)
+    h.set_rng_precision("f64")
+    seed, real0, n = 99, 2 ** 33 + 6, (2 if N <= 1024 else 1)
+    got = h.run(seed, real0, n, None, 0.01)
+    assert h.last_kernels()[0] == kernel
+    amp = np.sqrt(ps) * df
+    re, im = [], []
+    for j in range(n):
+        z = R.screens_fftw(devrng.device_coefficients_f64(seed, real0 + j, N) * amp, 1.0)[lo:lo + Np, lo:lo + Np]
+        re.append(z.real)
+        im.append(z.imag)
+    chi = devrng.device_logamp_normals(seed, 2 * real0, 2 * n, f64=True) * 0.1
+    want = R.detector(np.stack(re + im), W, 0.01, np.concatenate([chi[0::2], chi[1::2]]))
+    assert (want > 1e-3).all()
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    # the read-back is the fused rows' arithmetic bit for bit: direct family (staged draws) on the same seed agrees to rounding
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.run(seed, real0, n, None, 0.01), got, rtol=1e-10)
+
+
+def test_fast_object_with_the_float64_generator():
+    """The DEFAULT of `Fast(config).run()` on a float64 handle is the generator at the reference's precision (GPU_RNG_PRECISION
+    'auto' = 'f64'); the opt-in float32 draw of the same seed has the same distribution (the same normals to
+    2^-24: the vectors agree to ~1e-6 here); sharded over two handles identical to one; a float32 pipeline draws in float32."""
+    g = load_golden("e2e_ao_alias")
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_DEVICE": 0, "NITER": 400, "NCHUNKS": 4, "SEED": 5, "GPU_RNG": "device"})
+    s32 = fast_amd.Fast(dict(p, GPU_RNG_PRECISION="f32"))
+    r32 = s32.run()._r
+    sim = fast_amd.Fast(dict(p))
+    assert sim.rng_precision == "f64" and s32.rng_precision == "f32"
+    r64 = sim.run()._r
+    assert np.array_equal(fast_amd.Fast(dict(p, GPU_RNG_PRECISION="f64")).run()._r, r64)
+    # 'auto' follows the precision the handle COMPUTES in: a float32 pipeline draws in float32 where the grid has float32 kernels
+    # (NPXLS 256); a grid without them is promoted to float64 (fastmc_create) and then draws in float64 too
+    f32 = fast_amd.Fast(dict(p, GPU_PRECISION="f32", NPXLS=256))
+    assert f32.precision == "f32" and f32.rng_precision == "f32"
+    promoted = fast_amd.Fast(dict(p, GPU_PRECISION="f32"))
+    assert promoted.rng_precision == ("f32" if promoted.precision == "f32" else "f64")
+    assert np.isfinite(r64).all() and not np.array_equal(r32, r64)
+    np.testing.assert_allclose(r32, r64, rtol=1e-4)
+    p2 = dict(p, GPU_RNG_PRECISION="f64", GPU_DEVICES=[0, 0])
+    p2.pop("GPU_DEVICE")
+    assert np.array_equal(fast_amd.Fast(p2).run()._r, r64)
+    # the log-amplitudes on the object are the float64 draws
+    chi = devrng.device_logamp_normals(5, 0, 400, f64=True) * np.sqrt(sim.logamp_var)
+    half = 50
+    la = np.empty((4, 100))
+    la[:, :half], la[:, half:] = chi[0::2].reshape(4, half), chi[1::2].reshape(4, half)
+    np.testing.assert_allclose(sim.logamp, la.ravel(), rtol=1e-12, atol=1e-15)
+    with pytest.raises(Exception, match="GPU_RNG_PRECISION"):
+        fast_amd.Fast(dict(p, GPU_RNG_PRECISION="f16"))
+
+
+def test_float32_generator_shortcut_is_bounded_on_identical_draws():
+    """What the float32 draws + float32 colouring of device mode cost in accuracy, isolated from the generator: the SAME numpy
+    draws through the float64 pipeline once as float64 coefficients (the reference's arithmetic, fast.py:594) and once rounded
+    to float32 and coloured in float32 (what fmc_kernels.h:draw_coloured does with its own draws), at BASELINE configs[1]
+    (1024^2, NOAO, L0 = 25 m: 26 rad rms).  Recorded in DESIGN.md section 2."""
+    g = load_golden("big_noao_L0_1024")
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_DEVICE": 0})
+    sim = fast_amd.Fast(p)
+    N, h = sim.Npxls, sim._handle
+    ps, df = sim.powerspec, sim._prob.df
+    rng = np.random.default_rng(5)
+    B = 8
+    cr, ci = rng.normal(size=(B, N, N)), rng.normal(size=(B, N, N))
+    la = np.zeros(2 * B)
+    p64 = h.run_coeffs(cr, ci, la)
+    # float32 draws, float32 colouring, widened: fed as "coefficients" of a unit spectrum so that nothing else multiplies them
+    amp32 = (np.sqrt(ps) * df).astype(np.float32)
+    c32r = (cr.astype(np.float32) * amp32).astype(np.float64) / df
+    c32i = (ci.astype(np.float32) * amp32).astype(np.float64) / df
+    h.set_spectrum(np.ones((N, N)), df)
+    p32 = h.run_coeffs(c32r, c32i, la)
+    rel = np.abs(p32 / p64 - 1)
+    scr = sim._handle.screens_coeffs(c32r[:1], c32i[:1])
+    assert np.abs(scr).max() > 10.0                              # tens of radians: the hard case
+    print(f"float32 draw + colouring vs float64 on identical draws: max rel {rel.max():.2e}, median {np.median(rel):.2e}, "
+          f"max abs / mean power {np.abs(p32 - p64).max() / p64.mean():.2e}")
+    assert np.abs(p32 - p64).max() < 2e-5 * p64.mean() and np.median(rel) < 2e-5
+
+
+def test_wide_windows_on_split_grids_use_the_wave_family():
+    """Windows of 257-512 pixels (a 2.6-5 m aperture at 1 cm) at 2048^2 stay on the wave kernels (eight output slots per
+    lane) with the device generator, and agree with the direct family."""
+    h, ps, df, W = _small_problem(2048, 402)
+    assert h.kernel_path() == 1
+    a = h.run(5, 0, 2, None, 0.01)
+    assert h.last_timing()["rows_launches"] == 1 and np.isfinite(a).all()
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.run(5, 0, 2, None, 0.01), a, rtol=1e-9)
+
+
+def test_dense_sixteen_wave_kernels_equal_the_twelve_wave_kernels():
+    """1024^2 with a window of up to 96 pixels runs the dense-image kernels (sixteen waves per workgroup); with
+    FASTMC_NO_DENSE16=1 the same library keeps the twelve-wave kernels: same arithmetic, same results."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from tests.test_gpu_parity import _small_problem; "
+            "h, ps, df, W = _small_problem(1024, 82); np.save(sys.argv[1], h.run(17, 2, 40, None, 0.02))") % ROOT
+    outs = []
+    for flag in ("0", "1"):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"fastmc_dense_{flag}_{os.getpid()}.npy")
+        env = dict(os.environ, FASTMC_NO_DENSE16=flag, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
+        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+        os.remove(path)
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-12)
+    h, ps, df, W = _small_problem(1024, 82)
+    np.testing.assert_array_equal(h.run(17, 2, 40, None, 0.02), outs[0 if not os.environ.get("FASTMC_NO_DENSE16") else 1])
+
+
+# ------------------------------------------------------------------ grids beyond 4096 (the reference has no upper limit, fast.py:176-211)
+@pytest.mark.parametrize("N,Np,kernel", [(4608, 60, "k_rows_mr<double, 24, 2, 0, true, 64, 2>"), (5000, 82, "k_rows_mr<double, 20, 2, 0, true, 50, 1>"),
+                                         (7168, 100, "k_rows_mr<double, 16, 2, 0, true, 64, 0>"), (8192, 82, "k_rows_mr<double, 16, 2, 0, true, 64, 2>"),
+                                         (4100, 82, "k_rows_blu<double, 16, 2, 0, true>"), (7003, 200, "k_rows_blu<double, 16, 4, 0, true>")])
+def test_grids_beyond_4096_run_as_up_to_eight_sub_rows(N, Np, kernel):
+    """N = 64 P S / 50 P S with a run-time sub-row count S <= 8 (fmc_core.h: wave_rt_split / mr_split) up to 8192, and any other
+    N <= 8192 on the chirp-z kernels with its rows in up to eleven input blocks: screens from host coefficients against numpy's
+    FFT; the device generator through the family's rows against the oracle on the restated draws (one size: the restatement is
+    Python) and against the direct family on the same seed; the float64 generator fused in the rows against the direct family's
+    staged draws."""
+    rng = np.random.default_rng(N)
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    ps = ps * 0.02
+    lo = (N - Np) // 2
+    W = _window_W(Np)
+    h = _lib.Handle(N, Np, "f64", 0)
+    h.set_spectrum(ps, df)
+    h.set_pupil(W, lo, 0.01)
+    cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
+    a = h.screens_coeffs(cr, ci)
+    z = np.fft.fftshift(np.fft.fft2(np.fft.fftshift((cr[0] + 1j * ci[0]) * np.sqrt(ps) * df)))[lo:lo + Np, lo:lo + Np]
+    assert max(np.abs(a[0] - z.real).max(), np.abs(a[1] - z.imag).max()) < 1e-12 * np.abs(z).max()
+    del cr, ci, z
+    seed, real0 = 5, 2 ** 32 + 1
+    got = h.run(seed, real0, 1, None, 0.01)
+    assert h.last_kernels()[0] == kernel
+    if N == 4608:
+        want = _oracle_powers_from_restated_draws(seed, real0, 1, ps, df, W, lo, 0.01, 0.01)
+        np.testing.assert_allclose(got, want, rtol=1e-5)
+    h.set_rng_precision("f64")
+    got64 = h.run(seed, real0, 1, None, 0.01)
+    assert ", 2, true" in h.last_kernels()[0]                   # MODE 2: the float64 generator inside the row
+    h.kernel_path(0)
+    np.testing.assert_allclose(got64, h.run(seed, real0, 1, None, 0.01), rtol=1e-9)
+    h.set_rng_precision("f32")
+    np.testing.assert_allclose(got, h.run(seed, real0, 1, None, 0.01), rtol=1e-9)
+    h.close()

@@ -80,3 +80,20 @@ def test_the_numpy_path_has_no_grid_size_limit():
         host.grid_size(cfg, host.atmosphere(cfg))
     dx, N, Np = host.grid_size(cfg, host.atmosphere(cfg), size_limit=False)
     assert N == 8200
+
+
+@needs_no_gpu
+@pytest.mark.parametrize("name", ["e2e_explicit_pupil", "e2e_explicit_pupil_noao"])
+def test_assigned_pupil_weights_reproduce_the_stand_in_free_fixtures(name):
+    """`sim.pupil`, `sim.pupil_mode`, `sim.pupil_filter` are assignable as on the reference object; with the fixture's explicit
+    weights the run reproduces a reference run that had no aotools stand-in between its config and `result._r`."""
+    from conftest import run_with_explicit_pupil, check_explicit_pupil_run
+    g, sim, res = run_with_explicit_pupil(name, GPU_FALLBACK=True)
+    check_explicit_pupil_run(g, sim, res)
+    # the shared description of the geometry was not touched: a second object starts from the computed pupil again
+    p = params_from_json(g["params_json"])
+    p["GPU_FALLBACK"] = True
+    other = fast_amd.Fast(p)
+    assert other.pupil.shape == g["W"].shape and not np.array_equal(other.pupil * other.pupil_mode, g["W"])
+    with pytest.raises(ValueError):
+        other.pupil = np.ones((3, 3))

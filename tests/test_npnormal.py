@@ -44,3 +44,19 @@ def test_state_round_trip():
     assert np.array_equal(rng.normal(size=5), ref.normal(size=5)) and int(w[0]) == st["state"] & npnormal.M64
     with pytest.raises(RuntimeError):
         npnormal.state_words(np.random.Generator(np.random.MT19937(1)).bit_generator)
+
+
+def test_set_state_keeps_a_buffered_half_word():
+    """Generator.normal() never touches the 32-bit half-word an earlier integers() draw left buffered, so writing the
+    state the device returned back must not clear it either -- the stream after run() is then the reference's."""
+    from fast_amd import npnormal
+    ref = np.random.default_rng(5)
+    ref.integers(0, 10, dtype=np.uint32)             # buffers the other half of a 64-bit word
+    assert ref.bit_generator.state["has_uint32"] == 1
+    ours = np.random.default_rng(5)
+    ours.integers(0, 10, dtype=np.uint32)
+    ref.normal(size=1000)                            # the reference draws ...
+    sw = npnormal.state_words(ref.bit_generator)     # ... and where it stands is what the device reports for the same draws
+    npnormal.set_state(ours.bit_generator, sw[:2])
+    assert ours.bit_generator.state == ref.bit_generator.state
+    assert np.array_equal(ours.integers(0, 2 ** 32, size=5, dtype=np.uint32), ref.integers(0, 2 ** 32, size=5, dtype=np.uint32))

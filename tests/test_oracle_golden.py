@@ -191,3 +191,37 @@ def test_default_numpy_branch_fixture_and_its_relation_to_the_fftw_branch():
     np.testing.assert_allclose(zn, want, rtol=1e-10, atol=1e-13 * np.abs(want).max())
     # consequence for the results: the default branch's phases are (B/N)^2 smaller -> powers near the no-turbulence value
     assert g["r"].mean() > g["r_fftw"].mean()
+
+
+# ------------------------------------------------------------------ fixtures with no aotools stand-in in the chain
+def test_detector_with_explicit_weights():
+    """SURVEY 8 row a5 pinned with NOTHING of ours in the fixture's making: the weights were written out in numpy by the capture
+    script (tools/capture_golden/capture.py: explicit_weights), the phase cube is random, the arithmetic is the reference's."""
+    g = load_golden("kat_detector_explicit_W")
+    M, c = int(g["M"]), int(g["chunk"])
+    la = g["logamp"][c * M:(c + 1) * M]
+    np.testing.assert_allclose(R.detector(g["phs"], g["W"], float(g["dx"]), la), g["incoherent"], rtol=1e-13)
+    np.testing.assert_allclose(R.detector(g["phs"], g["W"], float(g["dx"]), la, coherent=True), g["coherent"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["e2e_explicit_pupil", "e2e_explicit_pupil_noao"])
+def test_end_to_end_with_explicit_pupil_weights(name):
+    """Rows a6-a10 and a1-a5b end to end: residual spectrum, log-amplitude variance (pupil_filter = 1) and the same-seed powers
+    against a reference run whose pupil, fibre mode and pupil filter were explicit arrays."""
+    g = load_golden(name)
+    p = params_from_json(g["params_json"])
+    N, dx = int(g["Npxls"]), float(g["dx"])
+    ao_mode = p["AO_MODE"]
+    out = R.residual_powerspec(N=N, dx=dx, cn2=g["cn2"], h=g["h"], wind=g["wind_vector"], L0=p["L0"], l0=p["l0"], wvl=p["WVL"],
+                               ao_mode=ao_mode, d_wfs=p["DSUBAP"], dtheta=p["DTHETA"], D_ground=p["D_GROUND"], zmax=None,
+                               t_loop=p["TLOOP"], t_exp=p["TEXP"], alias=p["ALIAS"], noise=p["NOISE"], lf_mask=g["lf_mask"],
+                               pupil_filter=np.ones((N, N)))
+    tiny = 1e-13 * np.abs(g["powerspec"]).max()
+    np.testing.assert_allclose(out["powerspec"], g["powerspec"], rtol=1e-11, atol=tiny)
+    np.testing.assert_allclose(out["logamp_powerspec"], g["logamp_powerspec"], rtol=1e-11, atol=1e-13 * np.abs(g["logamp_powerspec"]).max())
+    for k in ("logamp_var", "phs_var", "fitting_error", "aniso_servo_error", "alias_error", "noise_error"):
+        np.testing.assert_allclose(out[k], g[k], rtol=1e-10, atol=1e-300, err_msg=k)
+    r = R.monte_carlo(p["SEED"], p["NITER"], p["NCHUNKS"], g["powerspec"], float(g["df"]), g["W"], dx, float(g["logamp_var"]),
+                      coherent=p["COHERENT"])
+    np.testing.assert_allclose(r, g["r"], rtol=1e-10)
+    assert r.dtype == g["r"].dtype

@@ -11,6 +11,7 @@ are data -- inputs and the outputs the reference computed for them.
 Fixture families (see tests/golden/MANIFEST.md, written by this script):
   kat_fft_*      reference funcs.make_phase_fft (FFTW branch) on explicit coefficients
   kat_detector   reference Fast.compute_detector on explicit phase cubes
+  kat_detector_explicit_W, e2e_explicit_pupil*   the same and whole runs with the pupil weights written out here: no aotools stand-in in the chain
   kat_vk / kat_subharm / kat_simpson   small function-level known answers
   e2e_*          full fast.Fast(config).run(): every init product + result._r
   big_*          1024^2 runs: scalars, strided spectrum sample, first powers
@@ -109,6 +110,59 @@ def kat_detector():
     save("kat_detector", "Fast.compute_detector on an explicit phase cube (chunk=1)", True,
          phs=phs, W=sim.pupil * sim.pupil_mode, dx=sim.dx, logamp=sim.logamp.copy(), chunk=1,
          M=M, incoherent=inc, coherent=coh)
+
+
+def explicit_weights(Np, dx, D):
+    """Pupil weights written out in numpy (no aotools stand-in in their making): a disc of diameter D sampled at pixel centres
+    (x_i = (i - (Np - 1) / 2) dx) times a Gaussian mode of 1/e^2 half-width 0.45 D, both on the Np x Np pupil grid."""
+    x = (np.arange(Np) - (Np - 1) / 2.0) * dx
+    r2 = x[:, None] ** 2 + x[None, :] ** 2
+    disc = (r2 <= (D / 2.0) ** 2).astype(float)
+    mode = np.exp(-r2 / (0.45 * D) ** 2)
+    return disc, mode
+
+
+def standin_free():
+    """Fixtures for SURVEY 8 rows a5 / a10 with NO stand-in in the chain.  The reference object is built as
+    usual (its __init__ runs the aotools stand-ins), then everything the Monte-Carlo path reads that came from a stand-in is
+    replaced by arrays written out here -- pupil, fibre mode, pupil_filter = 1 -- and the products that depend on them are
+    recomputed by the reference's own code (compute_powerspec: zonal AO + alias, scipy and numpy only).  What is left of the
+    stand-ins is pyfftw's: FFTW.__call__ as numpy.fft.fft2 over the planned axes, i.e. the unnormalised forward DFT FFTW computes."""
+    # 1. the detector on an explicit phase cube with explicit weights
+    sim = fast.Fast(base_params())
+    Np = sim.Npxls_pup
+    disc, mode = explicit_weights(Np, sim.dx, 0.2)
+    sim.pupil, sim.pupil_mode = disc, mode
+    rng = np.random.default_rng(123)
+    M = sim.Niter_per_chunk
+    phs = rng.normal(scale=5.0, size=(M, Np, Np))
+    sim.phs[:] = phs
+    sim.logamp[:] = rng.normal(scale=0.15, size=sim.Niter)
+    inc = sim.compute_detector(chunk=0).copy()
+    sim.params["COHERENT"] = True
+    coh = sim.compute_detector(chunk=0).copy()
+    save("kat_detector_explicit_W", "Fast.compute_detector on an explicit phase cube with weights written out in numpy (chunk=0)", False,
+         phs=phs, W=disc * mode, dx=sim.dx, logamp=sim.logamp.copy(), chunk=0, M=M, incoherent=inc, coherent=coh)
+    # 2. end to end: AO zonal + alias, 40 iterations, explicit weights, pupil_filter = 1
+    for name, over, note in (("e2e_explicit_pupil", dict(NITER=40, NCHUNKS=4, SEED=21), "AO zonal + ALIAS"),
+                             ("e2e_explicit_pupil_noao", dict(NITER=40, NCHUNKS=4, SEED=22, AO_MODE="NOAO", L0=30.0, COHERENT=True),
+                              "NOAO, L0 = 30 m, COHERENT")):
+        p = base_params(**over)
+        sim = fast.Fast(p)
+        disc, mode = explicit_weights(sim.Npxls_pup, sim.dx, p["D_GROUND"])
+        sim.pupil, sim.pupil_mode = disc, mode
+        sim.pupil_filter = np.ones((sim.Npxls, sim.Npxls))
+        sim.compute_powerspec()
+        res = sim.run()
+        save(name, note + ": Fast.run() with pupil, fibre mode and pupil_filter replaced by explicit arrays after __init__ and "
+             "compute_powerspec() run again -- no aotools stand-in between the config and result._r", False,
+             params_json=np.array(params_to_json(p)), W=disc * mode, dx=np.array(sim.dx), df=np.array(sim.freq.df), Npxls=np.array(sim.Npxls),
+             Npxls_pup=np.array(sim.Npxls_pup), h=sim.h, cn2=sim.cn2, wind_vector=sim.wind_vector,
+             lf_mask=np.asarray(sim.lf_mask, dtype=float), powerspec=sim.powerspec, powerspec_per_layer=sim.powerspec_per_layer,
+             logamp_powerspec=sim.logamp_powerspec, logamp_var=np.array(sim.logamp_var), phs_var=np.array(sim.phs_var),
+             fitting_error=np.array(sim.fitting_error), aniso_servo_error=np.array(sim.aniso_servo_error),
+             alias_error=np.array(sim.alias_error), noise_error=np.array(sim.noise_error),
+             r=res._r, logamp=sim.logamp.copy(), phs_last_chunk=sim.phs.copy())
 
 
 def kat_small():
@@ -505,12 +559,14 @@ def main():
         else:
             {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref,
              "--only-comms": comms_metrics, "--only-big2048": big2048, "--only-big-modes": big_modes,
-             "--only-zenith": zenith, "--only-numpy-branch": numpy_branch, "--only-decimal": decimal, "--only-big-seeds": big_seeds}[only[0]]()
+             "--only-zenith": zenith, "--only-numpy-branch": numpy_branch, "--only-decimal": decimal, "--only-big-seeds": big_seeds,
+             "--only-standin-free": standin_free}[only[0]]()
         for name, size, st, note in MANIFEST:
             print(f"| {name}.npz | {size} | {st} | {note} |")
         return
     kat_fft()
     kat_detector()
+    standin_free()
     kat_small()
     e2e()
     temporal()

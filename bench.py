@@ -159,7 +159,7 @@ def extras(args, device):
     import fast_amd
     from fast_amd import sweep
     out = {}
-    for tag, over in (("f32_same_job", {"GPU_PRECISION": "f32"}), ("config2_AO_alias_f64", {"AO_MODE": "AO", "ALIAS": True}),
+    for tag, over in (("f32_same_job", {"GPU_PRECISION": "f32", "GPU_RNG_PRECISION": "f32"}), ("config2_AO_alias_f64", {"AO_MODE": "AO", "ALIAS": True}),
                       ("npxls1000_f64_lanes50_kernels", {"NPXLS": 1000})):
         p = workload_params(copy.copy(args))
         p.update(over)
@@ -208,8 +208,8 @@ def extras(args, device):
 def extras_unmeasured_rows(args, device):
     """The rows of SURVEY section 8 that the headline does not exercise, each timed here so that they are on the record:
     BASELINE configs[0] exactly as stated (the reference's shipped test/test_params.py: NPXLS 256, TEMPORAL on, 100 iterations)
-    on the GPU and on the CPU oracle; a TEMPORAL run at 1024^2; SUBHARM on; 128^2, 256^2 and 512^2 device-mode rates (packed rows); and the device
-    generator at the reference's float64 precision (GPU_RNG_PRECISION 'f64': what the float32 shortcut buys)."""
+    on the GPU and on the CPU oracle; a TEMPORAL run at 1024^2; SUBHARM on; 128^2, 256^2 and 512^2 device-mode rates (packed rows); and the
+    opt-in float32 draw (GPU_RNG_PRECISION 'f32': what the shortcut buys over the default, the reference's float64 precision)."""
     import copy
     import fast_amd
     from oracle import fastref as R
@@ -249,7 +249,7 @@ def extras_unmeasured_rows(args, device):
     out["temporal_1024_2000_steps"] = {"init_s": t1 - t0, "run_s": t2 - t1, "iterations_per_s": 2000 / (t2 - t1)}
     # device-mode rates: sub-harmonics on, small grids, float64 generator
     for tag, over in (("subharm_on_1024_f64", {"SUBHARM": True, "L0": 25.0}), ("npxls128_f64", {"NPXLS": 128}), ("npxls256_f64", {"NPXLS": 256}), ("npxls512_f64", {"NPXLS": 512}),
-                      ("generator_f64_1024_f64", {"GPU_RNG_PRECISION": "f64"})):
+                      ("f32_draw_1024_f64", {"GPU_RNG_PRECISION": "f32"})):
         p = workload_params(copy.copy(args))
         p.update(over)
         p["GPU_DEVICE"] = device

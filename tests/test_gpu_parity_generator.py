@@ -489,7 +489,7 @@ def test_dense_sixteen_wave_kernels_equal_the_twelve_wave_kernels():
     import subprocess
     import sys
     from conftest import ROOT
-    code = ("import numpy as np, sys; sys.path.insert(0, %r); from tests.test_gpu_parity import _small_problem; "
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from _parity import _small_problem; "
             "h, ps, df, W = _small_problem(1024, 82); np.save(sys.argv[1], h.run(17, 2, 40, None, 0.02))") % ROOT
     outs = []
     for flag in ("0", "1"):

@@ -1,5 +1,9 @@
 #!/bin/bash
-# f64 iterations/s over grid sizes on one box: tools/sizesweep.sh [sizes...]
-for n in "${@:-128 164 192 256 320 384 448 512 576 640 768 896 1000 1024 1152 1280 1536 1792 2048}"; do for s in $n; do
-python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --npxls $s 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print($s, d['config']['kernel_path'], round(d['value']), 'it/s  rows', round(d['pipeline']['rows_ms'],3), 'cols', round(d['pipeline']['cols_ms'],3))"
-done; done
+# iterations/s over grid sizes on one box, both generator precisions: tools/sizesweep.sh [sizes...]
+# (10 000 iterations per step, Np = 82, float64 pipeline; per size: it/s, it/s x N^2 relative to the 1024^2 figure comes from the table)
+for n in "${@:-128 192 256 320 384 448 512 576 640 768 896 1000 1024 1152 1280 1536 1792 2000 2048}"; do for s in $n; do for prec in f64 f32; do
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-sustained --no-f32-draw-pass --no-host-cost-pass --rng-precision $prec --npxls $s 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print($s, '$prec-gen', round(d['value']), 'it/s', 'x N^2 = %.3g' % (d['value'] * $s * $s), d['roofline']['kernel'], 'rows', round(d['pipeline']['rows_ms'],2), 'cols', round(d['pipeline']['cols_ms'],2))"
+done; done; done

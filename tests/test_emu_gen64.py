@@ -1,7 +1,7 @@
 """The float64 device generator's FAST arithmetic (fast_amd/csrc/fmc_gen64.h: table-driven log, seeded cubic square root,
 table + rotation for the angle) executed on the host by fast_amd/emu_gen64 and compared with the libm restatement of
 the same definition (oracle/devrng.box_muller_f64).  Not a GPU test: everything in that header except the float32 1/sqrt
-seed is plain IEEE float64 + FMA, which g++ reproduces exactly; tests/test_gpu_parity.py holds the device against the same
+seed is plain IEEE float64 + FMA, which g++ reproduces exactly; tests/test_gpu_parity_generator.py holds the device against the same
 restatement (test_float64_device_generator_matches_its_restatement, bar 2e-14)."""
 import os
 import subprocess

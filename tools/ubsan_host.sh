@@ -3,7 +3,7 @@
 # the device code is the normal gfx950 code (-fno-gpu-sanitize).  (AddressSanitizer is not an option here: ROCm's ASan runtime
 # intercepts hsa_amd_memory_pool_allocate and needs XNACK, which this pool does not offer -- tried, the first hipMalloc fails.)
 #   build (here or on the box, ~2 min):   tools/ubsan_host.sh build
-#   run   (GPU box):                      tools/ubsan_host.sh tests/test_gpu_parity.py -q     -> reports go to stderr, run continues
+#   run   (GPU box):                      tools/ubsan_host.sh tests/test_gpu_parity_generator.py -q     -> reports go to stderr, run continues
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 if [ "${1:-}" == "build" ]; then

@@ -10,7 +10,9 @@ device path can be checked deterministically, not only statistically:
   SL = stream_lanes(N) (64 for most grids)
   coefficient (ky, l + SL j) = BM(a_j, b_j), (a_j, b_j) = (s0 + s3, s1 + s2) of the state after j advances
   (two words per state advance; jointly equidistributed over the period)
-  BM(a, b) = sqrt(-2 ln((a+.5)/2^32)) * exp(2 pi i (b >> 9)/2^23)
+  float32 draw (opt-in since round 5):  BM(a, b) = sqrt(-2 ln((a+.5)/2^32)) * exp(2 pi i (b >> 9)/2^23)
+  float64 generator (the default):      four words per advance (xoshiro128p_next4: a, b and two multiply-add scrambles a2, b2),
+                                        BM64 = sqrt(-2 ln(RNE(a 2^32 + (a2|1)) 2^-64)) * exp(2 pi i ((b >> 8) 2^32 + b2) 2^-56)
   (log-amplitude and sub-harmonic draws use Philox blocks directly)
 
 Philox4x32-10 is the published Random123 algorithm (Salmon et al., SC'11); `tests/test_oracle_devrng.py`

@@ -439,8 +439,9 @@ class Handle:
         return g.value, us.value
 
     def set_rng_precision(self, precision):
-        """Device generator: 'f32' (default) or 'f64' (the reference's 53-bit normals and float64 colouring: fused into the
-        row kernels of every FFT family where its 4 KB of tables fit the LDS, staged in device memory otherwise)."""
+        """Device generator: 'f64' (the reference's 53-bit normals and float64 colouring: what fastmc_create leaves on a float64
+        handle; fused into the row kernels of every FFT family where its 6 KB of tables fit the LDS, staged in device memory
+        otherwise) or 'f32' (the opt-in float32 draw; what a float32 handle starts with)."""
         _chk(lib().fastmc_set_rng_precision(self._h, {"f64": F64, "f32": F32}[precision]))
 
     # ---- RCCL (the communicator belongs to the handle's DEVICE and outlives the handle)

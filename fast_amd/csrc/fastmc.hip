@@ -463,6 +463,9 @@ extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int p
   // (chirp-z, 50-lane, run-time sub-rows, tiny) computes in float64 whatever was asked for
   if (precision == FASTMC_F32 && (!wave_supported(N) || wave_rt_split(N))) precision = FASTMC_F64;
   h->precision = precision;
+  // the device generator starts at the precision the handle computes in: a float64 handle draws the reference's 53-bit normals
+  // and colours in float64 (fast/funcs.py:352-356, fast/fast.py:594); fastmc_set_rng_precision(FASTMC_F32) opts into the float32 draw
+  h->rng_f64 = precision == FASTMC_F64;
   h->rsz = precision == FASTMC_F64 ? 8 : 4;
   h->blu_P = blu_pick_P(N, Np, &h->blu_SB, &h->blu_B);
   if (const char* e = getenv("FASTMC_NO_DENSE16")) h->no_dense = e[0] && e[0] != '0';
@@ -540,7 +543,7 @@ extern "C" void fastmc_destroy(fastmc_t* h) {
   h->last_coherent = 0;
   h->last_rows[0] = h->last_cols[0] = 0;
   h->batch = 0;
-  h->rng_f64 = 0;
+  h->rng_f64 = h->precision == FASTMC_F64;      // the state fastmc_create leaves
   if (h->comm_slot >= 0) { fastmc_comm_abort(h); h->comm_slot = -1; }     // (fake-RCCL tests: the slot belonged to this handle, not to a device)
   h->path = default_path(h->N, h->blu_P, h->mr_P);
   h->lo = 0;
@@ -667,7 +670,7 @@ extern "C" int fastmc_set_batch(fastmc_t* h, int batch) {
 #endif
 
 // The tables of the float64 generator (fmc_gen64.h: 256 (cos, sin) entries, 128 log entries), one copy per device, uploaded on first use and kept.
-#if FMC_TU == 0
+// (Host helpers of every translation unit -- run_locked below refers to them -- but only unit 0's entry points ever call them.)
 static const Gen64Entry* gen64_table(int device) {
   static std::mutex mu;
   static std::map<int, Gen64Entry*> tabs;
@@ -682,18 +685,19 @@ static const Gen64Entry* gen64_table(int device) {
   tabs[device] = d;
   return d;
 }
-#endif
-
-#if FMC_TU == 0
-extern "C" int fastmc_set_rng_precision(fastmc_t* h, int precision) {
-  if (!h || (precision != FASTMC_F64 && precision != FASTMC_F32)) return fail(FASTMC_EINVAL, "precision must be FASTMC_F64 or FASTMC_F32");
-  h->rng_f64 = precision == FASTMC_F64;
+static int ensure_gen64_table(fastmc_ctx* h) {       // the float64 generator's tables on this handle's device (uploaded once per device)
   if (h->rng_f64 && !h->g64) {
     HIPCHK(hipSetDevice(h->device));
     h->g64 = gen64_table(h->device);
     if (!h->g64) return fail(FASTMC_EHIP, "could not upload the float64 generator's table");
   }
   return 0;
+}
+#if FMC_TU == 0
+extern "C" int fastmc_set_rng_precision(fastmc_t* h, int precision) {
+  if (!h || (precision != FASTMC_F64 && precision != FASTMC_F32)) return fail(FASTMC_EINVAL, "precision must be FASTMC_F64 or FASTMC_F32");
+  h->rng_f64 = precision == FASTMC_F64;
+  return ensure_gen64_table(h);
 }
 #endif
 
@@ -1846,6 +1850,7 @@ static int run_locked(fastmc_ctx* h, const RunSpec& S) {      // the caller hold
   if (S.n_real <= 0) return fail(FASTMC_EINVAL, "n_real must be positive");
   if (S.real0 < 0) return fail(FASTMC_EINVAL, "real0 must be non-negative");
   HIPCHK(hipSetDevice(h->device));
+  TRY(ensure_gen64_table(h));         // (a float64 handle draws at float64 precision from fastmc_create on)
 #ifdef FMC_ONLY_F64   // experiment builds (make variant ... DEFS="-DFMC_ONLY_F64 ..."): half the compile time
   if (h->precision != FASTMC_F64) return fail(FASTMC_ESTATE, "this build has no float32 kernels (FMC_ONLY_F64)");
   return run_impl<double>(h, S);
@@ -2438,6 +2443,7 @@ extern "C" int fastmc_rng_coeffs(fastmc_t* h, uint64_t seed, int64_t real, doubl
   HIPCHK(hipSetDevice(h->device));
   if (real < 0) return fail(FASTMC_EINVAL, "realisation index must be non-negative");
   const int N = h->N;
+  TRY(ensure_gen64_table(h));
   ScratchBuf d;
   HIPCHK(hipMalloc((void**)&d.p, (size_t)N * N * 16));
   RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32)};

@@ -297,11 +297,11 @@ int fastmc_set_batch(fastmc_t* h, int batch);
  *     (fast_amd/csrc/fmc_gen64.h: table-driven log, seeded cubic square root, table + rotation for the angle; draws within 3e-15
  *     of the libm restatement), FUSED into the row kernels of every FFT family (wave, packed, 50-lane, run-time-split, chirp-z)
  *     wherever its 6 KB of tables fit the LDS (no coefficient passes through device memory) and staged through device memory
- *     otherwise (the direct kernels; coloured in float64 by the host-coefficient kernels).  What `fast_amd.Fast` selects on a
- *     float64 handle (GPU_RNG_PRECISION 'auto'), what bench.py times, and what a C caller that wants the reference's arithmetic
- *     end to end must select after fastmc_create.
- *   FASTMC_F32 (the state fastmc_create leaves, kept for the callers of rounds 1-4): the opt-in shortcut -- 24-bit uniforms,
- *     hardware float32 log / sqrt / sin / cos, float32 colouring, fused into the row kernels; ~1.7 x the rate at 1024^2.
+ *     otherwise (the direct kernels; coloured in float64 by the host-coefficient kernels).  THE STATE fastmc_create LEAVES ON A
+ *     FLOAT64 HANDLE (round 5: a handle draws at the precision it computes in), what `fast_amd.Fast` selects (GPU_RNG_PRECISION
+ *     'auto') and what bench.py times.
+ *   FASTMC_F32 (what a float32 handle starts with; on a float64 handle the opt-in shortcut): 24-bit uniforms, hardware float32
+ *     log / sqrt / sin / cos, float32 colouring, fused into the row kernels; ~1.7 x the rate at 1024^2.
  * Both restated in oracle/devrng.py; the leading 32 / 24 bits of the float64 draw's uniform and angle are the float32 draw's words.
  * fastmc_rng_coeffs / fastmc_rng_logamp return the draws of the precision in force. */
 int fastmc_set_rng_precision(fastmc_t* h, int precision);

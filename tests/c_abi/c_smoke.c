@@ -84,6 +84,36 @@ int main(void) {
   CHECK(fastmc_create(&h2, 0, 200, 40, FASTMC_F64));
   const int path200 = fastmc_kernel_path(h2, -1);
   fastmc_destroy(h2);
+  /* the generator at the reference's precision (what fast_amd.Fast selects) on a 1024-point row, and the clock the row kernel ran in */
+  {
+    const int NB = 1024, NpB = 82;
+    fastmc_t* hb = NULL;
+    double* psb = malloc(sizeof(double) * NB * NB);
+    double* Wb = malloc(sizeof(double) * NpB * NpB);
+    double r64[16], r32[16], ghz = 0.0, span_us = 0.0;
+    for (int i = 0; i < NB * NB; ++i) psb[i] = 1e-4;
+    for (int i = 0; i < NpB * NpB; ++i) Wb[i] = 1.0;
+    CHECK(fastmc_create(&hb, 0, NB, NpB, FASTMC_F64));
+    if (fastmc_last_clock(hb, &ghz, &span_us) != FASTMC_ESTATE) { fprintf(stderr, "a clock before any launch\n"); return 9; }
+    CHECK(fastmc_set_spectrum(hb, psb, 0.1));
+    CHECK(fastmc_set_pupil(hb, Wb, (NB - NpB) / 2, 0.01));
+    CHECK(fastmc_run(hb, 7, 0, 8, NULL, 0.0, 0, r64));                 /* a float64 handle draws at float64 precision as created */
+    CHECK(fastmc_last_clock(hb, &ghz, &span_us));
+    CHECK(fastmc_set_rng_precision(hb, FASTMC_F32));                   /* the opt-in float32 draw */
+    CHECK(fastmc_run(hb, 7, 0, 8, NULL, 0.0, 0, r32));
+    {
+      double again[16];
+      CHECK(fastmc_set_rng_precision(hb, FASTMC_F64));
+      CHECK(fastmc_run(hb, 7, 0, 8, NULL, 0.0, 0, again));
+      for (int i = 0; i < 16; ++i) if (again[i] != r64[i]) { fprintf(stderr, "the default generator is not FASTMC_F64\n"); return 9; }
+    }
+    double d = 0.0;
+    for (int i = 0; i < 16; ++i) d = fmax(d, fabs(r64[i] / r32[i] - 1.0));
+    printf("float64 generator vs float32 draw, same seed: max rel diff %.3g; row-kernel clock %.3f GHz over %.1f us\n", d, ghz, span_us);
+    if (!(d > 0.0 && d < 1e-3) || !(ghz > 1.0 && ghz < 2.6) || !(span_us > 1.0)) return 9;
+    fastmc_destroy(hb);
+    free(psb); free(Wb);
+  }
   printf("families: wave-vs-direct %.3g, path(200)=%d; comm rc=%d world=%d rank=%d gathered_diff=%.3g hist=%lld\n", famdiff, path200,
          rc_comm, world, rank, gathered_diff, gtotal);
   if (famdiff > 1e-9 || path200 != 3) return 7;

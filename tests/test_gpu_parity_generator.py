@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 # ------------------------------------------------------------------ generator
 @pytest.mark.parametrize("N", [16, 33, 128, 256, 512, 1024, 2048, 4096, 200, 1000, 1500, 2000])
 def test_device_generator_matches_oracle_restatement(N):
-    h = _lib.Handle(N, max(1, N // 4), "f64", 0)
+    h = f32_draw_handle(N, max(1, N // 4), "f64", 0)
     for seed, g in ((1, 0), (0xDEADBEEFCAFE, 5), (7, 2 ** 33 + 3)):
         got = h.rng_coeffs(seed, g)
         want = devrng.device_coefficients(seed, g, N)
@@ -96,7 +96,7 @@ def test_device_generator_statistical_quality():
     """Moments, tails, uniformity of phase and independence across lanes / rows / realisations of the
     device generator (Philox-seeded xoshiro128+ streams + hardware Box-Muller), 4 x 1024^2 draws."""
     from scipy import stats
-    h = _lib.Handle(1024, 8, "f64", 0)
+    h = f32_draw_handle(1024, 8, "f64", 0)
     c = np.stack([h.rng_coeffs(2024, g) for g in range(4)])          # (4, 1024, 1024) complex
     z = np.concatenate([c.real.ravel(), c.imag.ravel()])
     n = z.size
@@ -151,7 +151,7 @@ def test_f32_pipeline_tracks_f64_on_the_same_device_draws(N):
     W = _window_W(82)
     out = {}
     for prec in ("f64", "f32"):
-        h = _lib.Handle(N, 82, prec, 0)
+        h = f32_draw_handle(N, 82, prec, 0)
         h.set_spectrum(ps, df)
         h.set_pupil(W, (N - 82) // 2, 0.01)
         out[prec] = h.run(77, 3, 16, None, 0.01)
@@ -206,7 +206,7 @@ def test_p16_row_variants_equal_the_direct_family(N, Np, lo):
     device draws, and the screens of host coefficients against numpy."""
     ps, df = _vk_spectrum(N, 0.01, 30.0)
     lo = (N - Np) // 2 if lo is None else lo
-    h = _lib.Handle(N, Np, "f64", 0)
+    h = f32_draw_handle(N, Np, "f64", 0)
     h.set_spectrum(ps * 0.02, df)
     h.set_pupil(_window_W(Np), lo, 0.01)
     assert h.kernel_path() == 1
@@ -255,7 +255,7 @@ def test_every_device_mode_row_variant_matches_the_oracle(N, Np, lo, prec):
     ps = ps * 0.02
     lo = (N - Np) // 2 if lo is None else lo
     W = _window_W(Np)
-    h = _lib.Handle(N, Np, prec, 0)
+    h = f32_draw_handle(N, Np, prec, 0)
     h.set_spectrum(ps, df)
     h.set_pupil(W, lo, 0.01)
     seed, real0, n = 2026, 7, (2 if N <= 1536 else 1)
@@ -385,7 +385,7 @@ def test_fused_float64_generator_rows_match_the_oracle_on_restated_draws(N, Np, 
     ps = ps * 0.02
     lo = (N - Np) // 2 if lo is None else lo
     W = _window_W(Np)
-    h = _lib.Handle(N, Np, "f64", 0)
+    h = f32_draw_handle(N, Np, "f64", 0)
     h.set_spectrum(ps, df)
     h.set_pupil(W, lo, 0.01)
     h.set_rng_precision("f64")
@@ -519,7 +519,7 @@ def test_grids_beyond_4096_run_as_up_to_eight_sub_rows(N, Np, kernel):
     ps = ps * 0.02
     lo = (N - Np) // 2
     W = _window_W(Np)
-    h = _lib.Handle(N, Np, "f64", 0)
+    h = f32_draw_handle(N, Np, "f64", 0)
     h.set_spectrum(ps, df)
     h.set_pupil(W, lo, 0.01)
     cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
@@ -541,3 +541,27 @@ def test_grids_beyond_4096_run_as_up_to_eight_sub_rows(N, Np, kernel):
     h.set_rng_precision("f32")
     np.testing.assert_allclose(got, h.run(seed, real0, 1, None, 0.01), rtol=1e-9)
     h.close()
+
+
+def test_handle_default_generator_is_the_reference_precision():
+    """Round 5: `fastmc_create` leaves a handle drawing at the precision it computes in -- a float64 handle draws the reference's
+    53-bit normals (fast/funcs.py:352-356), fused into its row kernel, with no call to fastmc_set_rng_precision; a float32
+    handle the float32 draw.  The state survives the handle cache (a parked handle comes back reset to it)."""
+    N, Np = 1024, 82
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    for round_ in range(2):                      # second pass: the handle parked by close() is taken back by fastmc_create
+        h = _lib.Handle(N, Np, "f64", 0)
+        got = h.rng_coeffs(3, 1)
+        assert np.abs(got - devrng.device_coefficients_f64(3, 1, N)).max() < 2e-14
+        h.set_spectrum(ps * 0.02, df)
+        h.set_pupil(_window_W(Np), (N - Np) // 2, 0.01)
+        h.run(3, 0, 2, None, 0.01)
+        assert h.last_kernels()[0] == "k_rows_wave<double, 16, 2, 2, 1, 4>"
+        h.set_rng_precision("f32")               # the opt-in: must not leak into the next handle of this shape
+        assert np.abs(h.rng_coeffs(3, 1) - devrng.device_coefficients(3, 1, N)).max() < 1e-3
+        h.close()
+    h32 = _lib.Handle(N, Np, "f32", 0)
+    assert h32.precision == "f32"
+    assert np.abs(h32.rng_coeffs(3, 1) - devrng.device_coefficients(3, 1, N)).max() < 1e-3
+    assert np.abs(h32.rng_coeffs(3, 1) - devrng.device_coefficients_f64(3, 1, N)).max() > 1e-9
+    h32.close()

@@ -18,7 +18,7 @@ def test_powers_match_oracle(N, Np, prec, rtol, coherent):
     la = rng.normal(scale=0.1, size=2 * B)
     W = _window_W(Np)
     want = R.powers_from_coefficients(cr + 1j * ci, ps, df, W, 0.01, la, coherent)
-    h = _lib.Handle(N, Np, prec, 0)
+    h = f32_draw_handle(N, Np, prec, 0)
     h.set_spectrum(ps, df)
     h.set_pupil(W, (N - Np) // 2, 0.01)
     got = h.run_coeffs(cr, ci, la, coherent)
@@ -45,7 +45,7 @@ def test_detector_kat_from_reference():
         screen[0, r0:r0 + Np, c0:c0 + Np] = phs[j]
     xs = np.stack([r0 + np.arange(Np, dtype=float) for r0, _ in corners])[None]       # (L=1, M, Np) rows
     ys = np.stack([c0 + np.arange(Np, dtype=float) for _, c0 in corners])[None]
-    h = _lib.Handle(N, Np, "f64", 0)
+    h = f32_draw_handle(N, Np, "f64", 0)
     h.set_pupil(W, (N - Np) // 2, float(g["dx"]))
     h.set_layer_screens(screen)
     inc = h.temporal_chunk(xs, ys, np.zeros((1, 2, M), dtype=np.int32), la, coherent=False)
@@ -333,7 +333,7 @@ def test_detector_kat_with_explicit_weights():
         screen[0, r0:r0 + Np, c0:c0 + Np] = phs[j]
     xs = np.stack([r0 + np.arange(Np, dtype=float) for r0, _ in corners])[None]
     ys = np.stack([c0 + np.arange(Np, dtype=float) for _, c0 in corners])[None]
-    h = _lib.Handle(N, Np, "f64", 0)
+    h = f32_draw_handle(N, Np, "f64", 0)
     h.set_pupil(W, (N - Np) // 2, float(g["dx"]))
     h.set_layer_screens(screen)
     inc = h.temporal_chunk(xs, ys, np.zeros((1, 2, M), dtype=np.int32), la, coherent=False)

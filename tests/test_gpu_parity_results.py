@@ -10,7 +10,7 @@ def test_full_size_properties_1024():
     N, Np = 1024, 82
     ps, df = _vk_spectrum(N, 0.01, 25.0)
     W = _window_W(Np)
-    h = _lib.Handle(N, Np, "f64", 0)
+    h = f32_draw_handle(N, Np, "f64", 0)
     h.set_pupil(W, (N - Np) // 2, 0.01)
     # zero spectrum: every power is exactly exp(2 chi)
     h.set_spectrum(np.zeros((N, N)), df)
@@ -53,7 +53,7 @@ def test_errors_are_reported_not_fatal():
         _lib.Handle(4100, 300)              # beyond 4096 a window above 256 pixels needs a sub-row grid
     with pytest.raises(fast_amd.FastMCError):
         _lib.Handle(64, 65)
-    h = _lib.Handle(64, 22, "f64", 0)
+    h = f32_draw_handle(64, 22, "f64", 0)
     with pytest.raises(fast_amd.FastMCError, match="set_spectrum"):
         h.run(1, 0, 2)
     with pytest.raises(fast_amd.FastMCError):
@@ -165,7 +165,7 @@ def test_many_realisations_cross_finalize_span():
     """More than 32768 realisations in one call: detector partials are finalised in several spans."""
     N, Np = 64, 10
     ps, df = _vk_spectrum(N, 0.01, 30.0)
-    h = _lib.Handle(N, Np, "f32", 0)
+    h = f32_draw_handle(N, Np, "f32", 0)
     h.set_spectrum(ps * 0.02, df)
     h.set_pupil(_window_W(Np), (N - Np) // 2, 0.01)
     n = 33000

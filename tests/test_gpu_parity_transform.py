@@ -12,7 +12,7 @@ def test_screens_match_reference_fft_kat(N, prec, tol):
     g = load_golden(f"kat_fft_N{N}")
     for Np in (N, max(1, N // 3), 5):
         lo = (N - Np) // 2
-        h = _lib.Handle(N, Np, prec, 0)
+        h = f32_draw_handle(N, Np, prec, 0)
         h.set_spectrum(g["powerspec"], float(g["df"]))
         h.set_pupil(np.ones((Np, Np)), lo, float(g["dx"]))
         phs = h.screens_coeffs(g["coeffs"].real, g["coeffs"].imag)
@@ -35,7 +35,7 @@ def test_wave_kernels_match_oracle_fft(N, Np, prec, tol):
     cr, ci = rng.normal(size=(B, N, N)), rng.normal(size=(B, N, N))
     lo = (N - Np) // 2
     want = R.crop(R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df)), N, Np)
-    h = _lib.Handle(N, Np, prec, 0)
+    h = f32_draw_handle(N, Np, prec, 0)
     assert h.kernel_path() == 1
     h.set_spectrum(ps, df)
     h.set_pupil(np.ones((Np, Np)), lo, 0.01)
@@ -55,7 +55,7 @@ def test_wave_window_not_centred():
     cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
     full = R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df))
     for lo in (0, 3, N - Np):
-        h = _lib.Handle(N, Np, "f64", 0)
+        h = f32_draw_handle(N, Np, "f64", 0)
         h.set_spectrum(ps, df)
         h.set_pupil(np.ones((Np, Np)), lo, 0.01)
         got = h.screens_coeffs(cr, ci)
@@ -96,7 +96,7 @@ def test_subharmonic_screens_separable_and_general_grids(N, Np, rotate):
     want = R.crop(R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df))
                   + R.subharm_screens((sr + 1j * si) * np.sqrt(ps_lo), grid, N, dx), N, Np)
     for path in ([1, 0] if N % 64 == 0 else [0]):
-        h = _lib.Handle(N, Np, "f64", 0)
+        h = f32_draw_handle(N, Np, "f64", 0)
         h.kernel_path(path)
         h.set_spectrum(ps, df)
         h.set_pupil(np.ones((Np, Np)), lo, dx)
@@ -149,7 +149,7 @@ def test_chirpz_kernels_match_oracle_fft(N, Np, prec, tol):
     cr, ci = rng.normal(size=(nb, N, N)), rng.normal(size=(nb, N, N))
     want = R.crop(R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df)), N, Np)
     for lo in ((N - Np) // 2, 0, N - Np):
-        h = _lib.Handle(N, Np, prec, 0)
+        h = f32_draw_handle(N, Np, prec, 0)
         assert h.kernel_path() == (2 if N >= 96 else 0)
         h.kernel_path(2)
         h.set_spectrum(ps, df)
@@ -183,7 +183,7 @@ def test_lanes50_kernels_match_oracle_fft(N, Np, prec, tol):
     cr, ci = rng.normal(size=(nb, N, N)), rng.normal(size=(nb, N, N))
     full = R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df))
     for lo in sorted({(N - Np) // 2, 0, N - Np}):
-        h = _lib.Handle(N, Np, prec, 0)
+        h = f32_draw_handle(N, Np, prec, 0)
         assert h.kernel_path() == 3
         h.set_spectrum(ps, df)
         h.set_pupil(np.ones((Np, Np)), lo, 0.01)
@@ -207,7 +207,7 @@ def test_wave_family_with_run_time_sub_rows(N, Np):
     cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
     full = R.double_screens(R.screens_fftw((cr + 1j * ci) * np.sqrt(ps), df))
     for lo in sorted({(N - Np) // 2, 0, N - Np}):
-        h = _lib.Handle(N, Np, "f64", 0)
+        h = f32_draw_handle(N, Np, "f64", 0)
         assert h.kernel_path() == 1
         h.set_spectrum(ps * 0.02, df)
         h.set_pupil(_window_W(Np), lo, 0.01)

@@ -37,6 +37,7 @@ for c in range(cases):
     ps = rng.uniform(0.0, 1.0, size=(N, N)) ** 4 * 1e-3
     cr, ci = rng.normal(size=(1, N, N)), rng.normal(size=(1, N, N))
     h = _lib.Handle(N, Np, prec, 0)
+    h.set_rng_precision("f32")                       # the float32 draw first (fastmc_create leaves a float64 handle at the float64 generator)
     h.set_spectrum(ps, 0.37)
     h.set_pupil(np.ones((Np, Np)), lo, 0.01)
     a = h.screens_coeffs(cr, ci)

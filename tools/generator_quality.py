@@ -19,6 +19,8 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 SEED = int(sys.argv[3]) if len(sys.argv) > 3 else 20261003
 h = _lib.Handle(N, 8, "f64", 0)
+if len(sys.argv) > 4 and sys.argv[4] == "f32":      # default: the float64 generator (what a float64 handle draws since round 5)
+    h.set_rng_precision("f32")
 worst = 0.0
 
 

@@ -34,8 +34,8 @@ for (N, Np, lo, prec) in [(1000, 82, 459, "f64"), (500, 82, 209, "f64"), (250, 6
 sys.path.insert(0, "/root/repo")
 from oracle import devrng
 h = _lib.Handle(200, 64, "f64", 0)
-c = h.rng_coeffs(1234, 7)
-o = devrng.device_coefficients(1234, 7, 200)
+c = h.rng_coeffs(1234, 7)                              # a float64 handle draws the float64 generator (round 5)
+o = devrng.device_coefficients_f64(1234, 7, 200)
 print("rng 200 vs oracle", np.abs(c - o).max())
 h.close()
 print("failures", bad)

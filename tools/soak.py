@@ -10,10 +10,10 @@ p = {"NPXLS": 256, "DX": 0.01, "NITER": 2000, "NCHUNKS": 10, "SEED": 1, "LOGLEVE
 m0 = None
 for i in range(150):
     p["SEED"] = i; p["GPU_PRECISION"] = "f32" if i % 3 == 0 else "f64"
-    # every fifth object draws numpy's stream on the device (one-pass generator and its buffers), every seventh the float64 generator,
+    # every fifth object draws numpy's stream on the device (one-pass generator and its buffers), every seventh the opt-in float32 draw,
     # now and then another grid family (50-lane, chirp-z)
     p["GPU_RNG"] = "numpy" if (i % 5 == 1 and p["GPU_PRECISION"] == "f64") else "device"
-    p["GPU_RNG_PRECISION"] = "f64" if (i % 7 == 2 and p["GPU_PRECISION"] == "f64") else "f32"
+    p["GPU_RNG_PRECISION"] = "f32" if i % 7 == 2 else "auto"     # every seventh the opt-in float32 draw, else the default
     p["NPXLS"] = (256, 256, 300, 256, 291)[i % 5] if p["GPU_PRECISION"] == "f64" else 256
     sim = fast_amd.Fast(dict(p)); r = sim.run()._r; st = sim.result_stats([-3.0]); hs = sim.histogram()
     assert np.isfinite(r).all() and hs.sum() == 2000

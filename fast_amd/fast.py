@@ -246,6 +246,10 @@ class Fast():
     # the first replacement gives this object a description of its own.)
     def _own_pupil(self):
         import copy
+        if self.temporal:
+            # (the frozen-flow set-up -- high-resolution pupil-filter spline, temporal log-amplitude spectrum -- was built from the
+            # computed pupil at construction, as the reference builds it in __init__: fast.py:394-405, 538-587)
+            logger.warning("pupil weights replaced on a TEMPORAL object: the temporal log-amplitude spectrum keeps the pupil it was built with")
         if not getattr(self, "_pupil_owned", False):
             self._prob.pup = copy.copy(self._prob.pup)
             self._pupil_owned = True

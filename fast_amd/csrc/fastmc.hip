@@ -1026,7 +1026,21 @@ static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
   RowArgs<R> B = A;
   B.rpw = pick_rpw<R>(h, A.N, A.nb, WPB);
   const int BPG = B.rpw * WPB / LR;
-  const int blocks = (A.N / LR) * ((A.nb + BPG - 1) / BPG);
+  int blocks = (A.N / LR) * ((A.nb + BPG - 1) / BPG);
+  // A launch of many rounds keeps its workgroups: as many as the device holds at once walk the launch's tiles (k_rows_wave:
+  // A.tiles), so the tables are staged once per CU instead of once per tile (round 5, 1024^2 float64 generator: +1.2 %,
+  // profiles/r05_ab_generator_tables.txt section 6).  A small launch (a chunk of the same-seed / host modes) keeps one tile per
+  // workgroup with pick_rpw's tile height.  FASTMC_ROWS_PERSIST=0 switches the walk off (A/B).
+  static const int persist = getenv("FASTMC_ROWS_PERSIST") ? atoi(getenv("FASTMC_ROWS_PERSIST")) : 1;
+  if (persist && B.rpw == ROWS_PER_WAVE) {
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_rows_wave<R, P, NS, MODE, S, D>, WPB * 64, lds) != hipSuccess || per_cu < 1) {
+      (void)hipGetLastError();
+      per_cu = 1;
+    }
+    const int resident = device_cus(h->device) * per_cu;
+    if (blocks >= 8 * resident) { B.tiles = blocks; blocks = resident; }
+  }
   hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE, S, D>), dim3(blocks), dim3(WPB * 64), lds, h->stream, B);
   FMC_NOTE(h->last_rows, "k_rows_wave<%s, %d, %d, %d, %d, %d>", rname<R>(), P, NS, MODE, S, D);
 }

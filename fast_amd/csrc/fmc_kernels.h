@@ -162,6 +162,7 @@ struct BluArgs {
 template <class R>
 struct RowArgs {
   int N, Np, lo, nb;            // grid size, window size, first window index, realisations in this launch
+  int tiles = 0;                // k_rows_wave: tiles of the launch when its workgroups walk them (0: one tile per workgroup)
   int rpw = 0;                  // k_rows_wave / _mr / _blu: rows per wave of this launch (0: ROWS_PER_WAVE); small launches take fewer (pick_rpw)
   const R* amp;                 // [N][N] sqrt(powerspec)*df  (wave family: with (-1)^(ky+kx) folded in); host-coefficient mode
   const float* ampf;            // the same table rounded to float32: colouring of the device generator's float32 normals
@@ -518,8 +519,6 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
   const int rpw = A.rpw ? A.rpw : ROWS_PER_WAVE;         // (a multiple of LR / gcd(WPB, LR): whole lines)
   const int BPG = rpw * WPB / LR;                        // realisations per workgroup
   const int nbb = (A.nb + BPG - 1) / BPG;
-  const int b0 = (blockIdx.x % nbb) * BPG;               // realisation block fastest: neighbours share amp rows
-  const int row0 = (blockIdx.x / nbb) * LR;
   constexpr bool OMC = row_omc<P, NS, S, D>();
   if constexpr (OMC) {
 #pragma unroll
@@ -527,6 +526,14 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 #pragma unroll
       for (int m = 1; m < 8; ++m) regs.omc[s2][m] = s_om[m * A.omS + min(lane + WAVE * s2, A.omS - 1)];
   }
+  // the workgroups of a launch stay: each walks the launch's tiles from its own index in steps of the grid
+  // (launch_rows_wave: as many workgroups as the device holds at once), so the tables are staged once per CU
+  const int tiles = A.tiles ? A.tiles : (int)gridDim.x;
+#pragma unroll 1
+  for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
+  const int b0 = (vb % nbb) * BPG;                       // realisation block fastest: neighbours share amp rows
+  const int row0 = (vb / nbb) * LR;
+#pragma unroll 1
   for (int rr = 0; rr < rpw; ++rr) {
     const int flat = rr * WPB + w;
     const int b = b0 + flat / LR;
@@ -627,6 +634,8 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
       const int oi = lane + WAVE * s;
       if (oi < A.Np) out[(size_t)oi * N] = mk<R>(regs.xr[s], regs.xi[s]);
     }
+  }
+  if (A.tiles) __syncthreads();      // the waves of a workgroup stay within one tile of each other: the pieces of a V line leave together
   }
   if (stamp) { A.clk[2] = (unsigned long long)clock64(); A.clk[3] = (unsigned long long)wall_clock64(); }
 }

@@ -34,7 +34,9 @@
  *     loader's path, or the tests' stand-in tests/stubs/fake_rccl.cpp -- with which, and only with which,
  *     FASTMC_TEST_VIRTUAL_RANKS=1 lets fastmc_comm_init_all take several handles of ONE device as ranks of a clique, so that
  *     the grouped collectives run on a one-GPU box: tests/test_fake_rccl.py); FASTMC_NO_DENSE16=1 (read by fastmc_create) keeps the twelve-wave kernels where the
- *     sixteen-wave dense-image kernels would run (A/B timing; same results).
+ *     sixteen-wave dense-image kernels would run (A/B timing; same results); FASTMC_ROWS_PERSIST=0 (read at the first row launch)
+ *     gives every tile of a large row launch a workgroup of its own instead of letting the resident workgroups walk the tiles
+ *     (A/B timing; same results).
  */
 #ifndef FASTMC_H
 #define FASTMC_H

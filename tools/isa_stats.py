@@ -150,6 +150,10 @@ def inner_loop(lines, a, b):
     return best if best and best[1] - best[0] > 200 else None
 
 
+def n_instr(lines):
+    return sum(1 for l in lines if re.match(r"^\s+[a-z]", l) and not l.strip().startswith((";", ".", "//")))
+
+
 def count(lines):
     mix, by_class, flops, flops32 = collections.Counter(), collections.Counter(), 0, 0
     for l in lines:
@@ -197,6 +201,12 @@ def main():
             continue
         lines = bodies[hit[0]]
         a, b = main_loop(lines)
+        if tag.startswith("rows"):
+            # k_rows_wave walks tiles (round 5: the workgroups of a large launch stay): the tile loop holds the row loop plus a
+            # few dozen instructions of index arithmetic and a barrier per tile of 8 rows per wave -- the row loop is the unit
+            row = inner_loop(lines, a, b)
+            if row and n_instr(lines[a:row[0]] + lines[row[1] + 1:b + 1]) <= 80:
+                a, b = row
         if tag.startswith("cols"):
             a, b = 0, len(lines) - 1          # one column per wave: the whole body (its small loops are the table load)
         S = SUB_ROWS.get(tag, 1)

@@ -1016,6 +1016,27 @@ static int pick_rpw(fastmc_ctx* h, int N, int nb, int WPB) {
   }
   return pick;
 }
+// Workgroups of `kernel` (threads, dynamic LDS bytes) the device holds at once: what a launch whose workgroups stay and walk its
+// tiles is sized to (launch_rows_wave, launch_cols_wave).  Asked of the runtime once per (kernel, LDS size).
+static int resident_workgroups(fastmc_ctx* h, const void* kernel, int threads, size_t lds) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, size_t>, int> per_cu_of;
+  int per_cu;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = per_cu_of.find({kernel, lds});
+    if (it == per_cu_of.end()) {
+      int n = 1;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 1;
+      }
+      it = per_cu_of.emplace(std::make_pair(kernel, lds), n).first;
+    }
+    per_cu = it->second;
+  }
+  return device_cus(h->device) * per_cu;
+}
 #define FMC_NOTE(dst, ...) snprintf(dst, sizeof(dst), __VA_ARGS__)
 template <class R, int P, int NS, int MODE, int S = 1, int D = 0>
 static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
@@ -1033,12 +1054,7 @@ static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
   // workgroup with pick_rpw's tile height.  FASTMC_ROWS_PERSIST=0 switches the walk off (A/B).
   static const int persist = getenv("FASTMC_ROWS_PERSIST") ? atoi(getenv("FASTMC_ROWS_PERSIST")) : 1;
   if (persist && B.rpw == ROWS_PER_WAVE) {
-    int per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_rows_wave<R, P, NS, MODE, S, D>, WPB * 64, lds) != hipSuccess || per_cu < 1) {
-      (void)hipGetLastError();
-      per_cu = 1;
-    }
-    const int resident = device_cus(h->device) * per_cu;
+    const int resident = resident_workgroups(h, (const void*)k_rows_wave<R, P, NS, MODE, S, D>, WPB * 64, lds);
     if (blocks >= 8 * resident) { B.tiles = blocks; blocks = resident; }
   }
   hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE, S, D>), dim3(blocks), dim3(WPB * 64), lds, h->stream, B);
@@ -1050,7 +1066,13 @@ static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
   hipFuncSetAttribute((const void*)k_cols_wave<R, P, NS, EPI, S, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   constexpr int WPB = WCfg<R, P, NS, D>::WPB_COLS;
   const int items = A.nb * A.Np;
-  hipLaunchKernelGGL((k_cols_wave<R, P, NS, EPI, S, D>), dim3((items + WPB - 1) / WPB), dim3(WPB * 64), lds, h->stream, A);
+  int blocks = (items + WPB - 1) / WPB;
+  static const int persist = getenv("FASTMC_COLS_PERSIST") ? atoi(getenv("FASTMC_COLS_PERSIST")) : 1;
+  if (persist && cols_walk<P, NS, S>()) {          // as launch_rows_wave: a launch of many rounds keeps its workgroups (each wave walks the columns in steps of the grid)
+    const int resident = resident_workgroups(h, (const void*)k_cols_wave<R, P, NS, EPI, S, D>, WPB * 64, lds);
+    if (blocks >= 8 * resident) blocks = resident;
+  }
+  hipLaunchKernelGGL((k_cols_wave<R, P, NS, EPI, S, D>), dim3(blocks), dim3(WPB * 64), lds, h->stream, A);
   FMC_NOTE(h->last_cols, "k_cols_wave<%s, %d, %d, %d, %d, %d>", rname<R>(), P, NS, EPI, S, D);
 }
 

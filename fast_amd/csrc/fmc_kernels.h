@@ -646,6 +646,8 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 // 128^2 / 256^2, -17 % at 512^2.  (The same hint on the rows kernel spills and gains nothing.)
 // (Tried: the column's global loads issued before the table staging and its barrier: +20 % at 1024^2 -- the table copy queues
 // behind 16 KB of column loads per wave.)
+// the column kernels whose workgroups stay and walk the launch's columns (launch_cols_wave): the 1024-point pipeline, whole or two sub-rows
+template <int P, int NS, int S> constexpr bool cols_walk() { return P == 16 && NS == 2 && S <= 2; }
 template <class R, int P, int NS, int EPI, int S = 1, int D = 0>
 __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB_COLS * 64), ((P <= 8 && P != 7 && NS == 2 && WaveCfg<R, P, NS>::WPB == 12) ? 6 : 1))
 void k_cols_wave(ColArgs<R> A) {
@@ -660,17 +662,27 @@ void k_cols_wave(ColArgs<R> A) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * WCfg<R, P, NS, D>::XELEMS;
   // work item = (realisation b, window column xi), xi fastest: adjacent waves read adjacent columns
-  const int item = blockIdx.x * WCfg<R, P, NS, D>::WPB_COLS + w;
-  const bool valid = item < A.nb * A.Np;
+  // (launch_cols_wave: the workgroups of a large launch stay and each wave walks the items in steps of the grid -- the
+  // tables are staged once per CU; the waves need nothing from each other after the staging barrier)
+  const int N = S * G::N;
+  LaneRegs<R, P, NS> regs;
+  load_tables_skip0<R, P, WCfg<R, P, NS, D>::OM_ROWS>(s_tw, s_om, A.tw, A.om, A.omS);
+  const int items = A.nb * A.Np;
+  const int lane0 = lane;
+  // (instantiations outside cols_walk: one item per wave, no loop -- the walk costs the tighter register budgets of the small
+  // grids and the four-sub-row columns 100+ bytes of scratch)
+  int item = blockIdx.x * WCfg<R, P, NS, D>::WPB_COLS + w;
+  if (item >= items) return;   // whole wave exits; no block barrier follows
+#pragma unroll 1
+  do {
+  // the lane index is made opaque per item: nothing lane-dependent is hoisted over the walk (hoisted table values and offsets
+  // cost 240 bytes of scratch per lane otherwise)
+  int lane = lane0;
+  if constexpr (cols_walk<P, NS, S>()) asm volatile("" : "+v"(lane));
+  GpuExec<R, P, NS> ex{lane, regs};
   const int b = item / A.Np;
   const int xi = item % A.Np;
-  const int N = S * G::N;
-
-  LaneRegs<R, P, NS> regs;
-  GpuExec<R, P, NS> ex{lane, regs};
   const cpx<R>* col = A.V + ((size_t)b * A.Np + xi) * N;
-  load_tables_skip0<R, P, WCfg<R, P, NS, D>::OM_ROWS>(s_tw, s_om, A.tw, A.om, A.omS);
-  if (!valid) return;   // whole wave exits; no block barrier follows
   if (S == 1) {
 #pragma unroll
     for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
@@ -698,6 +710,8 @@ void k_cols_wave(ColArgs<R> A) {
     for (int s2 = 0; s2 < NS; ++s2) { regs.xr[s2] = accr[s2]; regs.xi[s2] = acci[s2]; }
   }
   column_epilogue<R, NS, EPI>(A.sh, A.W, A.partial, A.phs, A.nb, A.Np, b, xi, lane, regs.xr, regs.xi);
+  item += (int)gridDim.x * WCfg<R, P, NS, D>::WPB_COLS;
+  } while (cols_walk<P, NS, S>() && item < items);
 }
 
 // ================================================================== packed rows: N = 128 (L0 = 0), 256 (L0 = 1), 512 (L0 = 2)

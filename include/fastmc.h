@@ -36,7 +36,7 @@
  *     the grouped collectives run on a one-GPU box: tests/test_fake_rccl.py); FASTMC_NO_DENSE16=1 (read by fastmc_create) keeps the twelve-wave kernels where the
  *     sixteen-wave dense-image kernels would run (A/B timing; same results); FASTMC_ROWS_PERSIST=0 (read at the first row launch)
  *     gives every tile of a large row launch a workgroup of its own instead of letting the resident workgroups walk the tiles
- *     (A/B timing; same results).
+ *     (A/B timing; same results); FASTMC_COLS_PERSIST=0: the same for the column launches of the 1024-point pipeline.
  */
 #ifndef FASTMC_H
 #define FASTMC_H

@@ -504,6 +504,31 @@ def test_dense_sixteen_wave_kernels_equal_the_twelve_wave_kernels():
     np.testing.assert_array_equal(h.run(17, 2, 40, None, 0.02), outs[0 if not os.environ.get("FASTMC_NO_DENSE16") else 1])
 
 
+@pytest.mark.parametrize("N,n", [(1024, 420), (2048, 320)])
+def test_tile_walk_equals_one_tile_per_workgroup(N, n):
+    """A launch of at least eight rounds of workgroups keeps as many workgroups as the device holds and lets them walk the launch's
+    tiles (k_rows_wave: RowArgs::tiles; k_cols_wave of the 1024-point pipeline: each wave walks the columns); FASTMC_ROWS_PERSIST=0 /
+    FASTMC_COLS_PERSIST=0 give every tile a workgroup of its own.  Same arithmetic per row and column, partial sums per column:
+    the results are the same BITS, with both generators."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from _parity import _small_problem; "
+            "h, ps, df, W = _small_problem(%d, 82); a = h.run(23, 1, %d, None, 0.02); h.set_rng_precision('f64'); "
+            "np.save(sys.argv[1], np.stack([a, h.run(23, 1, %d, None, 0.02)]))") % (ROOT, N, n, n)
+    outs = []
+    for flag in ("0", "1"):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"fastmc_walk_{flag}_{os.getpid()}.npy")
+        env = dict(os.environ, FASTMC_ROWS_PERSIST=flag, FASTMC_COLS_PERSIST=flag, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
+        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+        os.remove(path)
+    assert np.isfinite(outs[0]).all() and outs[0].shape[0] == 2 and not np.array_equal(outs[0][0], outs[0][1])
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
 # ------------------------------------------------------------------ grids beyond 4096 (the reference has no upper limit, fast.py:176-211)
 @pytest.mark.parametrize("N,Np,kernel", [(4608, 60, "k_rows_mr<double, 24, 2, 0, true, 64, 2>"), (5000, 82, "k_rows_mr<double, 20, 2, 0, true, 50, 1>"),
                                          (7168, 100, "k_rows_mr<double, 16, 2, 0, true, 64, 0>"), (8192, 82, "k_rows_mr<double, 16, 2, 0, true, 64, 2>"),

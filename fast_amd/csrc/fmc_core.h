@@ -296,21 +296,35 @@ FMC_HD void dft_reg(cpx<R> (&v)[P]) {
         v[a2 + M * 0] = u[0] + t;
         v[a2 + M * 1] = mk<R>(a.x + b.y, a.y - b.x);
         v[a2 + M * 2] = mk<R>(a.x - b.y, a.y + b.x);
-      } else
-      static_for<Q>([&](auto A1) {
-        constexpr int a1 = decltype(A1)::value;
-        cpx<R> acc = u[0];
-        static_for<Q - 1>([&](auto Qm) {
-          constexpr int q = decltype(Qm)::value + 1;
-          constexpr int e = (q * a1) % Q;
-          if constexpr (e == 0) acc = acc + u[q];
-          else {
-            constexpr double wr = cos_frac(e, Q), wi = -sin_frac(e, Q);
-            acc = cfma(u[q], mk<R>((R)wr, (R)wi), acc);
-          }
+      } else {
+        // radix-7 / radix-9 (round 5; the direct form costs Q (Q - 1) complex multiply-adds = 168 / 288 real operations, the rows of
+        // 448 / 896 / 1792 and 576 / 1152 spent a third of their float64 instructions there): the same symmetric form as the
+        // radix-5 butterfly -- t_k = u_k + u_{Q-k}, d_k = u_k - u_{Q-k} (k = 1 ... H = (Q - 1) / 2); a_j = u0 + sum_k cos(2 pi j k / Q) t_k,
+        // b_j = sum_k sin(2 pi j k / Q) d_k;  y0 = u0 + sum_k t_k, y_j = a_j - i b_j, y_{Q-j} = a_j + i b_j: 66 / 104 real operations
+        constexpr int H = (Q - 1) / 2;
+        cpx<R> t[H], d[H];
+        static_for<H>([&](auto K) {
+          constexpr int k = decltype(K)::value + 1;
+          t[k - 1] = u[k] + u[Q - k];
+          d[k - 1] = u[k] - u[Q - k];
         });
-        v[a2 + M * a1] = acc;
-      });
+        cpx<R> y0 = u[0];
+        static_for<H>([&](auto K) { y0 = y0 + t[decltype(K)::value]; });
+        v[a2 + M * 0] = y0;
+        static_for<H>([&](auto J) {
+          constexpr int j = decltype(J)::value + 1;
+          cpx<R> a = u[0], b = mk<R>((R)0, (R)0);
+          static_for<H>([&](auto K) {
+            constexpr int k = decltype(K)::value + 1;
+            constexpr R c = (R)cos_frac((j * k) % Q, Q), sn = (R)sin_frac((j * k) % Q, Q);
+            a = mk<R>(a.x + c * t[k - 1].x, a.y + c * t[k - 1].y);
+            if constexpr (k == 1) b = mk<R>(sn * d[0].x, sn * d[0].y);
+            else b = mk<R>(b.x + sn * d[k - 1].x, b.y + sn * d[k - 1].y);
+          });
+          v[a2 + M * j] = mk<R>(a.x + b.y, a.y - b.x);
+          v[a2 + M * (Q - j)] = mk<R>(a.x - b.y, a.y + b.x);
+        });
+      }
     });
   }
 }

@@ -1050,10 +1050,11 @@ static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
   int blocks = (A.N / LR) * ((A.nb + BPG - 1) / BPG);
   // A launch of many rounds keeps its workgroups: as many as the device holds at once walk the launch's tiles (k_rows_wave:
   // A.tiles), so the tables are staged once per CU instead of once per tile (round 5, 1024^2 float64 generator: +1.2 %,
-  // profiles/r05_ab_generator_tables.txt section 6).  A small launch (a chunk of the same-seed / host modes) keeps one tile per
-  // workgroup with pick_rpw's tile height.  FASTMC_ROWS_PERSIST=0 switches the walk off (A/B).
+  // profiles/r05_ab_generator_tables.txt section 6).  Whatever tile height pick_rpw chose: a chunk of 50 realisations of the
+  // same-seed mode (3200 tiles of one row per wave) walks too, +1.6 % end to end there.  A launch of fewer than 8 rounds keeps one tile
+  // per workgroup.  FASTMC_ROWS_PERSIST=0 switches the walk off (A/B).
   static const int persist = getenv("FASTMC_ROWS_PERSIST") ? atoi(getenv("FASTMC_ROWS_PERSIST")) : 1;
-  if (persist && B.rpw == ROWS_PER_WAVE) {
+  if (persist) {
     const int resident = resident_workgroups(h, (const void*)k_rows_wave<R, P, NS, MODE, S, D>, WPB * 64, lds);
     if (blocks >= 8 * resident) { B.tiles = blocks; blocks = resident; }
   }

@@ -640,6 +640,25 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
   if (stamp) { A.clk[2] = (unsigned long long)clock64(); A.clk[3] = (unsigned long long)wall_clock64(); }
 }
 
+// One element of a V column for the column pass of the one-pass wave kernels and the packed kernels.  V is written once by the row
+// pass and read once here, a slab of 1-7 GB that no cache holds: the loads carry the non-temporal hint (round 5; 1024^2: columns
+// 1.41 -> 1.26 ms per step, step +0.3 ... +1.1 % by box; 256^2 +2.5 %, 512^2 +1 %).  NOT where a line is read more than once (the split
+// columns of 2048 / 4096 read every line in S passes: +9 % there), and never on the ROW pass's stores (-20 %: the L2 no longer
+// combines the eight 16-byte pieces of a line).  profiles/r05_ab_generator_tables.txt section 13.
+#ifndef FMC_V_NT_LOAD
+#define FMC_V_NT_LOAD 1
+#endif
+template <class R>
+__device__ __forceinline__ cpx<R> load_v(const cpx<R>* p) {
+#if FMC_V_NT_LOAD
+  typedef R vec2 __attribute__((ext_vector_type(2)));
+  const vec2 t = __builtin_nontemporal_load(reinterpret_cast<const vec2*>(p));
+  return mk<R>(t.x, t.y);
+#else
+  return *p;
+#endif
+}
+
 // EPI 0: detector partial sums; EPI 1: write the cropped screens.
 // Small grids (P <= 8): each wave is short-lived (one column, a few microseconds of mostly latency), so
 // two workgroups per CU are worth a tighter register budget (6 waves per SIMD): column time -26 % at
@@ -685,7 +704,7 @@ void k_cols_wave(ColArgs<R> A) {
   const cpx<R>* col = A.V + ((size_t)b * A.Np + xi) * N;
   if (S == 1) {
 #pragma unroll
-    for (int j = 0; j < P; ++j) regs.v[j] = col[lane + WAVE * j];
+    for (int j = 0; j < P; ++j) regs.v[j] = load_v(col + lane + WAVE * j);
     wave_row_fft<R, P, NS, D>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
   } else {
     R accr[NS], acci[NS];
@@ -694,7 +713,7 @@ void k_cols_wave(ColArgs<R> A) {
 #pragma unroll 1
     for (int sp = 0; sp < S; ++sp) {
 #pragma unroll
-      for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (lane + WAVE * j)];
+      for (int j = 0; j < P; ++j) regs.v[j] = col[sp + S * (lane + WAVE * j)];      // (every line is read by S passes: no hint)
       wave_row_fft<R, P, NS, D>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) {
@@ -842,7 +861,7 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPC * 64), (PkCfg<R, L0, D>::CMIN
     const cpx<R>* col = A.V + ((size_t)b * A.Np + (item % ngrp) * G) * N;
     const uint32_t lane_in = (live ? gl : 0) * N + q;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) regs.v[j] = col[lane_in + L * j];
+    for (int j = 0; j < 16; ++j) regs.v[j] = load_v(col + lane_in + L * j);
     packed_row_fft<R, L0, C::NSL, C::B0M>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     auto pixel = [&](int yi, R p1, R p2) {

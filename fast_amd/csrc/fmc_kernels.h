@@ -481,6 +481,9 @@ __device__ __forceinline__ void wave_row_fft(Exec& ex, typename Xch<R>::E* xbuf,
   else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF), OMC>(ex, xbuf, s_tw, s_om, omS, lo, Np);
 }
 
+// MODE 1 coefficients (host draws, numpy's stream drawn on the device): 16 bytes per element read once from a buffer of up to 1.7 GB --
+// non-temporal loads (round 5: same-seed mode 96.6 -> 100.1 k it/s; profiles/r05_ab_generator_tables.txt section 14)
+#define FMC_LDC(p) __builtin_nontemporal_load(p)
 template <class R, int P, int NS, int MODE, int S = 1, int D = 0>
 __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -581,7 +584,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 #pragma unroll
           for (int j = 0; j < P; ++j) {
             const int kx = sp + S * (lane + WAVE * j);
-            regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
+            regs.v[j] = cscale(mk<R>((R)FMC_LDC(A.cre + base + kx), (R)FMC_LDC(A.cim + base + kx)), amp[kx]);
           }
         } else {
           R cr[2][CH], ci[2][CH], am[2][CH];
@@ -590,7 +593,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
               const int kx = sp + S * (lane + WAVE * (k * CH + i));
-              cr[k][i] = (R)A.cre[base + kx]; ci[k][i] = (R)A.cim[base + kx]; am[k][i] = amp[kx];
+              cr[k][i] = (R)FMC_LDC(A.cre + base + kx); ci[k][i] = (R)FMC_LDC(A.cim + base + kx); am[k][i] = amp[kx];
             }
 #pragma unroll
           for (int k = 0; k < NCH; ++k) {
@@ -603,7 +606,7 @@ __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(Row
 #pragma unroll
               for (int i = 0; i < CH; ++i) {
                 const int kx = sp + S * (lane + WAVE * ((k + 2) * CH + i));
-                cr[k & 1][i] = (R)A.cre[base + kx]; ci[k & 1][i] = (R)A.cim[base + kx]; am[k & 1][i] = amp[kx];
+                cr[k & 1][i] = (R)FMC_LDC(A.cre + base + kx); ci[k & 1][i] = (R)FMC_LDC(A.cim + base + kx); am[k & 1][i] = amp[kx];
               }
             }
           }

@@ -468,6 +468,9 @@ __host__ __device__ constexpr size_t wave_lds_bytes_d(int omS) {
   return wave_table_bytes<R, P>(WCfg<R, P, NS, D>::OM_ROWS, omS) + (size_t)WCfg<R, P, NS, D>::WPB * WCfg<R, P, NS, D>::XELEMS * 8;
 }
 
+// MODE 1 coefficients (host draws, numpy's stream drawn on the device): 16 bytes per element read once from a buffer of up to 1.7 GB --
+// non-temporal loads (round 5: same-seed mode 96.6 -> 100.1 k it/s; profiles/r05_ab_generator_tables.txt section 14)
+#define FMC_LDC(p) __builtin_nontemporal_load(p)
 // S > 1: the row of NF = S * 64 P points is transformed as S interleaved sub-rows (kx = s mod S), each by
 // the same P-per-lane pipeline, and the window outputs are combined, X[x] = sum_s w_NF^{s x} Y_s[x mod 64 P]
 // (decimation in time, evaluated only for the window).  2048 = 2 x 1024 and 4096 = 4 x 1024 run the
@@ -481,9 +484,6 @@ __device__ __forceinline__ void wave_row_fft(Exec& ex, typename Xch<R>::E* xbuf,
   else pruned_row_fft<R, P, NS, (D == 3 ? centre_planes(P, 8, 0) : 0xFF), OMC>(ex, xbuf, s_tw, s_om, omS, lo, Np);
 }
 
-// MODE 1 coefficients (host draws, numpy's stream drawn on the device): 16 bytes per element read once from a buffer of up to 1.7 GB --
-// non-temporal loads (round 5: same-seed mode 96.6 -> 100.1 k it/s; profiles/r05_ab_generator_tables.txt section 14)
-#define FMC_LDC(p) __builtin_nontemporal_load(p)
 template <class R, int P, int NS, int MODE, int S = 1, int D = 0>
 __global__ __launch_bounds__((WCfg<R, P, NS, D>::WPB * 64)) void k_rows_wave(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -826,7 +826,7 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPB * 64)) void k_rows_pk(RowArgs
       const size_t base = ((size_t)b * N + ky0) * N;
 #pragma unroll
       for (int j = 0; j < 16; ++j)
-        regs.v[j] = cscale(mk<R>((R)A.cre[base + lane_in + L * j], (R)A.cim[base + lane_in + L * j]), amp[lane_in + L * j]);
+        regs.v[j] = cscale(mk<R>((R)FMC_LDC(A.cre + base + lane_in + L * j), (R)FMC_LDC(A.cim + base + lane_in + L * j)), amp[lane_in + L * j]);
     }
     packed_row_fft<R, L0, C::NSL, C::B0M>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np);
     cpx<R>* out = A.V + (size_t)b * A.Np * N + ky0;      // V[b][oi][ky]
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
               asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
             }
           }
-          else regs.v[j] = in ? cmul(cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]), pre[kx]) : mk<R>((R)0, (R)0);
+          else regs.v[j] = in ? cmul(cscale(mk<R>((R)FMC_LDC(A.cre + base + kx), (R)FMC_LDC(A.cim + base + kx)), amp[kx]), pre[kx]) : mk<R>((R)0, (R)0);
         }
         bluestein_row<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, s_twf, vhat + (size_t)jb * (WAVE * P), A.Np);
 #pragma unroll
@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__((BluCfg<R, P, NS>::WPB * 64)) void k_rows_blu(RowAr
 #pragma unroll
       for (int j = 0; j < P; ++j) {
         const int kx = lane + WAVE * j;
-        regs.v[j] = kx < N ? cmul(cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]), pre[kx]) : mk<R>((R)0, (R)0);
+        regs.v[j] = kx < N ? cmul(cscale(mk<R>((R)FMC_LDC(A.cre + base + kx), (R)FMC_LDC(A.cim + base + kx)), amp[kx]), pre[kx]) : mk<R>((R)0, (R)0);
       }
     }
     bluestein_row<R, P, NS>(ex, xbuf, s_tw, s_om, A.omS, s_twf, vhat, A.Np);
@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__((MrCfg<R, P, NS, LN>::WPB * 64)) void k_rows_mr(Row
 #pragma unroll
         for (int j = 0; j < P; ++j) {
           const int kx = S * (li + LN * j);
-          regs.v[j] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
+          regs.v[j] = cscale(mk<R>((R)FMC_LDC(A.cre + base + kx), (R)FMC_LDC(A.cim + base + kx)), amp[kx]);
         }
       }
       G::template fft<NS, PR>(ex, xbuf, s_tw, s_om, A.omS, A.lo, A.Np, G::osign(N));
@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_rows_direct(RowArgs<R> A) {
   } else {
     const size_t base = ((size_t)b * N + ky) * N;
     for (int kx = threadIdx.x; kx < N; kx += blockDim.x)
-      s_row[kx] = cscale(mk<R>((R)A.cre[base + kx], (R)A.cim[base + kx]), amp[kx]);
+      s_row[kx] = cscale(mk<R>((R)FMC_LDC(A.cre + base + kx), (R)FMC_LDC(A.cim + base + kx)), amp[kx]);
   }
   __syncthreads();
   // Every window output is a length-N sum; with Np < blockDim the sum is cut into S segments so

@@ -419,6 +419,7 @@ static void wave_config(const fastmc_ctx* h, int* ns, int* wpb) {
 // One retired handle per device is kept whole (stream, events, every device buffer) and handed to the next
 // fastmc_create of the same (N, Np, precision): a sweep builds one short-lived handle per geometry sample
 // (fast/complete_orbit_simulation.py:217-228) and ~15 hipMalloc / hipFree pairs per object cost more than its spectrum.
+#if FMC_TU == 0
 struct HandleCache {
   std::mutex mu;
   fastmc_ctx* dev[64] = {};
@@ -427,7 +428,6 @@ struct HandleCache {
 };
 static HandleCache g_handles;
 
-#if FMC_TU == 0
 extern "C" int fastmc_create(fastmc_t** out, int device_id, int N, int Np, int precision) {
   if (!out) return fail(FASTMC_EINVAL, "handle pointer is NULL");
   *out = nullptr;

@@ -356,6 +356,27 @@ def stat_ref():
          params_json=np.array(params_to_json(p)), params2_json=np.array(params_to_json(p2)), r_ao=r_ao, r_noao=r_no)
 
 
+def stat_ref_1024():
+    """4000 iterations of the reference at the BENCHMARKED size (BASELINE configs[1]: 1024^2, NOAO, L0 = 25 m -- the hard
+    26 rad case -- and configs[2]: AO + alias): only the result vectors, for distribution tests of the default (float64
+    device generator) path at the size the bench line is quoted on.  ~5 min each at 13.8 it/s."""
+    h, cn2, w = turbulence_models.HV57_Bufton_profile(4)
+    p = dict(fast.conf.DEFAULTS)
+    p.update({"NPXLS": 1024, "DX": 0.01, "NITER": 4000, "NCHUNKS": 400, "TEMPORAL": False, "FFTW": True, "SEED": 21,
+              "W0": "opt", "D_GROUND": 0.8, "H_TURB": h, "CN2_TURB": cn2, "WIND_SPD": w, "WIND_DIR": [0, 90, 180, 270],
+              "ZENITH_ANGLE": 55, "DSUBAP": 0.1, "LOGLEVEL": "ERROR", "H_SAT": 36e6, "AO_MODE": "NOAO", "L0": 25.0})
+    t0 = time.time()
+    r_no = fast.Fast(p).run()._r
+    t1 = time.time()
+    p2 = dict(p)
+    p2.update({"AO_MODE": "AO", "ALIAS": True, "L0": np.inf, "SEED": 22, "NOISE": 0.0, "DTHETA": [4, 0], "TLOOP": 1e-3, "TEXP": 1e-3})
+    r_ao = fast.Fast(p2).run()._r
+    t2 = time.time()
+    print(f"  reference: NOAO {t1 - t0:.0f} s, AO {t2 - t1:.0f} s")
+    save("stat_ref_1024", "result._r of 4000 reference iterations at 1024^2: configs[1] NOAO L0=25, and configs[2] AO+alias", True,
+         params_json=np.array(params_to_json(p)), params2_json=np.array(params_to_json(p2)), r_noao=r_no, r_ao=r_ao)
+
+
 def comms_metrics():
     """Reference fade statistics and BER / SEP integrals (comms.py:171-262) on explicit sample vectors:
     a correlated log-normal series with many fades, its edge-case slices, and the stat_ref NOAO powers."""
@@ -557,7 +578,7 @@ def main():
         if only[0].startswith("--only-e2e="):
             e2e(only[0].split("=", 1)[1].split(","))
         else:
-            {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref,
+            {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref, "--only-stat-ref-1024": stat_ref_1024,
              "--only-comms": comms_metrics, "--only-big2048": big2048, "--only-big-modes": big_modes,
              "--only-zenith": zenith, "--only-numpy-branch": numpy_branch, "--only-decimal": decimal, "--only-big-seeds": big_seeds,
              "--only-standin-free": standin_free}[only[0]]()
@@ -582,6 +603,7 @@ def main():
         zenith()
         decimal()
         big_seeds()
+        stat_ref_1024()
     with open(os.path.join(OUT, "MANIFEST.md"), "w") as f:
         f.write("# Golden fixtures captured from the reference (tools/capture_golden/capture.py)\n\n")
         f.write(f"numpy {np.__version__}; reference snapshot /root/reference (2025-04-04).\n")

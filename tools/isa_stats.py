@@ -55,6 +55,10 @@ PACKED_KERNELS = {
     "cols_f64_256_packed": "void fmc::k_cols_pk<double, 1, 0, 0>(",
     "rows_f64_512_packed": "void fmc::k_rows_pk<double, 2, 0, 0>(",
     "cols_f64_512_packed": "void fmc::k_cols_pk<double, 2, 0, 0>(",
+    # the float64 generator fused into the packed rows (MODE 2)
+    "rows_f64_128_packed_gen64": "void fmc::k_rows_pk<double, 0, 2, 0>(",
+    "rows_f64_256_packed_gen64": "void fmc::k_rows_pk<double, 1, 2, 0>(",
+    "rows_f64_512_packed_gen64": "void fmc::k_rows_pk<double, 2, 2, 0>(",
 }
 
 TRANS = re.compile(r"^v_(log|sqrt|sin|cos|exp|rcp|rsq)_(f32|f16|f64)")

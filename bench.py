@@ -744,8 +744,12 @@ def main():
         print(json.dumps(line), flush=True)
     sync_all()
     if rccl_problem:
-        dist.mark_clean_exit()
-        raise SystemExit(rccl_problem if rank == 0 else 3)
+        # NOT a clean exit: with a thread still inside RCCL the exit hook of fast_amd.dist leaves through os._exit with the status
+        # recorded here (a raised SystemExit passes none of its hooks and used to come out as 0: ADVICE r5)
+        if rank == 0:
+            print(rccl_problem, file=sys.stderr, flush=True)
+        dist.mark_exit(3)
+        sys.exit(3)
     # the line is out: if a thread is still blocked inside RCCL although its communicator was aborted, fast_amd.dist's exit hook
     # skips the runtime teardown -- with status 0 only because the run got here (an exception on the way exits non-zero)
     dist.mark_clean_exit()

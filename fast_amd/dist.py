@@ -97,8 +97,11 @@ class ExchangeStuck(RuntimeError):
 # status the process was going to exit with.  Nothing is patched at import: the hooks that record that status (sys.excepthook for
 # an uncaught exception, sys.exit for an exit code) are installed when the FIRST thread is left behind by a
 # deadline and removed again when none is left (join_left_behind); a process that never loses a thread never sees them.
-#   * an uncaught exception -> 1, sys.exit(n) -> n (a bare `raise SystemExit(n)` at top level passes no hook Python offers: it
-#     counts as "nobody said", below -- replacing builtins.SystemExit would break `except SystemExit` around sys.exit);
+#   * an uncaught exception -> 1, sys.exit(n) -> n, mark_exit(n) -> n (a bare `raise SystemExit(n)` at top level passes no hook
+#     Python offers -- not sys.excepthook, not the patched sys.exit, and the status is a C local by the time atexit runs: it
+#     counts as "nobody said", below, or as "clean" when a finished step marked the exit so.  A failure path that must not be
+#     mistaken for success therefore calls mark_exit(n) / sys.exit(n); replacing builtins.SystemExit would break
+#     `except SystemExit` around sys.exit);
 #   * a step that FINISHED after its exchange was given up (host fall-back of Fast.run / DeviceGroup / step_sharded) marks the
 #     exit clean itself (mark_clean_exit), so a program that simply ends after it exits 0; bench.py marks it when its line is out;
 #   * none of these (a caller of call_with_deadline that never said its work was done) -> EX_SOFTWARE (70), never a silent 0.
@@ -146,6 +149,15 @@ def mark_clean_exit():
     is out; an exit code recorded earlier that did not end the process is forgotten."""
     _EXIT["clean"] = True
     _EXIT["code"] = None
+
+
+def mark_exit(code):
+    """The program is about to end with this status although a thread may still sit inside RCCL: record it, so that the exit
+    hook leaves with it whatever form the exit then takes (`sys.exit(n)` passes the hook by itself once it is installed; a
+    top-level `raise SystemExit(n)` passes NO hook Python offers -- a failure path that ends that way must say so here
+    first).  bench.py --require-rccl does, after a run that degraded to the host exchange."""
+    _EXIT["code"] = _code_of(code)
+    _EXIT["clean"] = False
 
 
 def exit_status():

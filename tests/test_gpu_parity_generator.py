@@ -124,23 +124,51 @@ def test_device_generator_statistical_quality():
     assert corr(re[0], h.rng_coeffs(2025, 0).real) < 5
 
 
-@pytest.mark.parametrize("key,pkey", [("r_ao", "params_json"), ("r_noao", "params2_json")])
-def test_device_mode_distribution_matches_reference_output(key, pkey):
-    """4000 GPU iterations with the device generator vs 2000 iterations of the REFERENCE itself
-    (numpy PCG64 draws) on the same configuration: same distribution (two-sample KS), same mean
-    power within 4 standard errors, same scintillation index within 25 %."""
+def _distribution_bars(r, ref, fade_dB):
+    """The bars of VERDICT r5 item 3, the same at 256^2 and at the benchmarked 1024^2: two-sample KS p > 0.01 on the dB values,
+    mean power within 3 standard errors, scintillation index within 10 %, fade probability (power below `fade_dB` relative to
+    the reference's mean) within 3 sigma binomial."""
     from scipy import stats
-    g = load_golden("stat_ref_256")
-    ref = g[key]
-    p = params_from_json(g[pkey])
-    p.update({"GPU_DEVICE": 0, "NITER": 4000, "NCHUNKS": 20, "SEED": 1234, "GPU_RNG": "device"})
-    r = fast_amd.Fast(p).run()._r
     d1, d2 = 10 * np.log10(r), 10 * np.log10(ref)
     assert stats.ks_2samp(d1, d2).pvalue > 0.01
     se = np.sqrt(r.var() / r.size + ref.var() / ref.size)
-    assert abs(r.mean() - ref.mean()) < 4 * se
+    assert abs(r.mean() - ref.mean()) < 3 * se, (r.mean(), ref.mean(), se)
     si1, si2 = (r / r.mean()).var(), (ref / ref.mean()).var()
-    assert abs(si1 / si2 - 1) < 0.25
+    assert abs(si1 / si2 - 1) < 0.10, (si1, si2)
+    thr = ref.mean() * 10 ** (fade_dB / 10)
+    p1, p2 = np.mean(r < thr), np.mean(ref < thr)
+    pp = (np.sum(r < thr) + np.sum(ref < thr)) / (r.size + ref.size)
+    assert pp * ref.size > 30, "the threshold must leave the reference a countable number of fades"
+    assert abs(p1 - p2) < 3 * np.sqrt(pp * (1 - pp) * (1 / r.size + 1 / ref.size)), (p1, p2)
+
+
+@pytest.mark.parametrize("key,pkey,fade_dB", [("r_ao", "params_json", -3.0), ("r_noao", "params2_json", -10.0)])
+def test_device_mode_distribution_matches_reference_output(key, pkey, fade_dB):
+    """20 000 GPU iterations with the DEFAULT device generator (float64 on a float64 handle) vs 10 000 iterations of the REFERENCE
+    itself (numpy PCG64 draws; stat_ref_256 + stat_ref_256b, fast/fast.py:115-140, 949-983) on the same configuration at 256^2."""
+    g, gb = load_golden("stat_ref_256"), load_golden("stat_ref_256b")
+    ref = np.concatenate([g[key], gb[key]])
+    p = params_from_json(g[pkey])
+    p.update({"GPU_DEVICE": 0, "NITER": 20000, "NCHUNKS": 20, "SEED": 1234, "GPU_RNG": "device"})
+    sim = fast_amd.Fast(p)
+    r = sim.run()._r
+    assert sim._handle.last_kernels()[0] == "k_rows_pk<double, 1, 2, 0>"        # MODE 2: the float64 generator drew in the row
+    _distribution_bars(r, ref, fade_dB)
+
+
+@pytest.mark.parametrize("key,pkey,fade_dB", [("r_noao", "params_json", -10.0), ("r_ao", "params2_json", -3.0)])
+def test_default_generator_distribution_at_the_benchmarked_size(key, pkey, fade_dB):
+    """the mode the bench line is quoted on (float64 device generator, the kernel k_rows_wave<double, 16, 2, 2, 1, 4>)
+    at the size it is quoted on.  20 000 GPU iterations at 1024^2 vs 4000 iterations of the reference (stat_ref_1024: BASELINE
+    configs[1] NOAO with L0 = 25 m -- 26 rad rms, deep fades -- and configs[2] AO + alias)."""
+    g = load_golden("stat_ref_1024")
+    ref = g[key]
+    p = params_from_json(g[pkey])
+    p.update({"GPU_DEVICE": 0, "NITER": 20000, "NCHUNKS": 20, "SEED": 4321, "GPU_RNG": "device"})
+    sim = fast_amd.Fast(p)
+    r = sim.run()._r
+    assert sim._handle.last_kernels()[0] == "k_rows_wave<double, 16, 2, 2, 1, 4>"   # the headline kernel, MODE 2
+    _distribution_bars(r, ref, fade_dB)
 
 
 @pytest.mark.parametrize("N", [256, 1024, 2048])

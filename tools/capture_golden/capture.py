@@ -356,6 +356,22 @@ def stat_ref():
          params_json=np.array(params_to_json(p)), params2_json=np.array(params_to_json(p2)), r_ao=r_ao, r_noao=r_no)
 
 
+def stat_ref_256b():
+    """8000 more iterations of each stat_ref configuration (other seeds): with stat_ref_256 a reference sample of 10 000 per
+    configuration, so that the 256^2 distribution test can hold the scintillation index to 10 % (bootstrap s.e. of 2000: 3.9 %)."""
+    g = np.load(os.path.join(OUT, "stat_ref_256.npz"))
+    out = {}
+    for key, pkey, seed in (("r_ao", "params_json", 111), ("r_noao", "params2_json", 112)):
+        raw = json.loads(str(g[pkey]))
+        p = dict(fast.conf.DEFAULTS)
+        for k, v in raw.items():
+            p[k] = np.array(v["__ndarray__"]) if isinstance(v, dict) and "__ndarray__" in v else (
+                float(v["__float__"]) if isinstance(v, dict) and "__float__" in v else v)
+        p.update({"NITER": 8000, "NCHUNKS": 80, "SEED": seed})
+        out[key] = fast.Fast(p).run()._r
+    save("stat_ref_256b", "8000 more reference iterations of each stat_ref_256 configuration (SEED 111 / 112)", True, **out)
+
+
 def stat_ref_1024():
     """4000 iterations of the reference at the BENCHMARKED size (BASELINE configs[1]: 1024^2, NOAO, L0 = 25 m -- the hard
     26 rad case -- and configs[2]: AO + alias): only the result vectors, for distribution tests of the default (float64
@@ -578,7 +594,7 @@ def main():
         if only[0].startswith("--only-e2e="):
             e2e(only[0].split("=", 1)[1].split(","))
         else:
-            {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref, "--only-stat-ref-1024": stat_ref_1024,
+            {"--only-temporal": temporal, "--only-mean-irradiance": mean_irradiance, "--only-stat-ref": stat_ref, "--only-stat-ref-1024": stat_ref_1024, "--only-stat-ref-256b": stat_ref_256b,
              "--only-comms": comms_metrics, "--only-big2048": big2048, "--only-big-modes": big_modes,
              "--only-zenith": zenith, "--only-numpy-branch": numpy_branch, "--only-decimal": decimal, "--only-big-seeds": big_seeds,
              "--only-standin-free": standin_free}[only[0]]()
@@ -593,6 +609,7 @@ def main():
     temporal()
     mean_irradiance()
     stat_ref()
+    stat_ref_256b()
     comms_metrics()
     p = default_cfg()
     numpy_branch()

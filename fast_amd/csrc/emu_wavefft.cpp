@@ -360,8 +360,78 @@ static int sweep_pk(const char* name, double tol) {
   return bad;
 }
 
+// Packed sub-rows (fmc_wavefft.h: pks_accumulate): G rows of N = S * M points per wave, S passes, against the naive DFT.
+template <class R, int L0, int S>
+static double run_pks_case(int Np, int shift, unsigned seed) {
+  constexpr int L = pk_lanes(L0), M = 16 * L, N = S * M, G = WAVE / L, FIRST = pks_first_plane(L0, S);
+  using E = typename Xch<R>::E;
+  std::mt19937_64 gen(seed);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  std::vector<double> inr(G * N), ini(G * N);
+  for (auto& v : inr) v = nd(gen);
+  for (auto& v : ini) v = nd(gen);
+  const int lo = (N - Np) / 2 + shift;
+  std::vector<cpx<R>> tw1((size_t)16 * L), pcw((size_t)S * PKS_SPAN);
+  build_tw1_pk<R>(tw1.data(), L, cs_turns);
+  build_pcw<R>(pcw.data(), N, S, cs_turns);
+  std::vector<E> xbuf(D16_XELEMS);
+  static HostExec<R, 16, pks_nm<L0>()> ex;
+  pks_clear<R, L0>(ex);
+  for (int sp = 0; sp < S; ++sp) {
+    for (int l = 0; l < WAVE; ++l)
+      for (int j = 0; j < 16; ++j) {
+        const int g = l / L, k = sp + S * (l % L + L * j);
+        const double sg = (k & 1) ? -1.0 : 1.0;        // the input-side fftshift sign, folded into the colouring table on the device
+        ex.regs[l].v[j] = mk<R>((R)(sg * inr[g * N + k]), (R)(sg * ini[g * N + k]));
+      }
+    packed_row_fft<R, L0, pks_nm<L0>(), pks_plane_mask(L0, S)>(ex, xbuf.data(), tw1.data(), (const cpx<R>*)nullptr, 0, 0, Np);
+    pks_accumulate<R, L0, FIRST>(ex, pcw.data() + sp * PKS_SPAN);
+  }
+  std::vector<double> gr((size_t)G * Np, 1e300), gi((size_t)G * Np, 1e300);
+  for (int l = 0; l < WAVE; ++l)
+    pks_outputs<R, L0>(l, ex.regs[l], N, lo, Np, [&](int oi, R re, R im) { gr[(l / L) * Np + oi] = re; gi[(l / L) * Np + oi] = im; });
+  double worst = 0.0, scale = 0.0;
+  const int h = N / 2;
+  for (int g = 0; g < G; ++g)
+    for (int oi = 0; oi < Np; ++oi) {
+      const int p = lo + oi;
+      long double sr = 0, si = 0;
+      for (int k = 0; k < N; ++k) {
+        const long long e = (((long long)(p - h) * (k + h)) % N + N) % N;
+        const long double a = -2.0L * M_PIl * (long double)e / N;
+        const long double c = cosl(a), sn = sinl(a);
+        sr += inr[g * N + k] * c - ini[g * N + k] * sn;
+        si += inr[g * N + k] * sn + ini[g * N + k] * c;
+      }
+      worst = std::fmax(worst, std::fmax(std::fabs(gr[g * Np + oi] - (double)sr), std::fabs(gi[g * Np + oi] - (double)si)));
+      scale = std::fmax(scale, std::fmax(std::fabs((double)sr), std::fabs((double)si)));
+    }
+  return worst / scale;
+}
+template <class R, int L0, int S>
+static int sweep_pks(const char* name, double tol) {
+  int bad = 0;
+  for (int Np : {82, 96, 23, 1, 64, 95, 40})
+    for (int shift : {0, Np < 90 ? 3 : 0, Np < 80 ? -5 : 0}) {
+      const double err = run_pks_case<R, L0, S>(Np, shift, 777u + Np + shift + S);
+      const bool ok = err <= tol;
+      std::printf("%s packed sub-rows N=%d (S=%d) shift=%d Np=%d relerr=%.3e %s\n", name, S * 16 * pk_lanes(L0), S, shift, Np, err, ok ? "ok" : "FAIL");
+      bad += !ok;
+    }
+  return bad;
+}
+
 int main() {
   int bad = 0;
+  bad += sweep_pks<double, 1, 3>("f64", 1e-13);
+  bad += sweep_pks<double, 1, 5>("f64", 1e-13);
+  bad += sweep_pks<double, 1, 6>("f64", 1e-13);
+  bad += sweep_pks<double, 1, 7>("f64", 1e-13);
+  bad += sweep_pks<double, 0, 5>("f64", 1e-13);
+  bad += sweep_pks<double, 0, 7>("f64", 1e-13);
+  bad += sweep_pks<double, 0, 9>("f64", 1e-13);
+  bad += sweep_pks<float, 1, 5>("f32", 2e-5);
+  bad += sweep_pks<float, 0, 7>("f32", 2e-5);
   bad += sweep_pk<double, 0>("f64", 1e-13);
   bad += sweep_pk<float, 0>("f32", 2e-5);
   bad += sweep_pk<double, 1>("f64", 1e-13);

@@ -129,6 +129,8 @@ struct fastmc_ctx {
   void* omg = nullptr;     //   host coefficients: TEMPORAL layer screens, centred_fft2)
   void* pk_tw1 = nullptr;  // N = 256, 512: tables of the packed rows (fmc_wavefft.h: build_tw1_pk / build_om_pk)
   void* pk_om = nullptr;
+  void* pks_tw1 = nullptr; // N = 640 ... 1792 (fmc_core.h: pks_split): tables of the packed sub-rows (fmc_wavefft.h: build_tw1_pk for M = 256, build_pcw)
+  void* pks_cw = nullptr;
   double* W = nullptr;
   void* V = nullptr;
   size_t V_cap = 0;        // realisations
@@ -567,7 +569,7 @@ static void destroy_now(fastmc_ctx* h) {
   if (h->nps) { nps_free(h->nps); h->nps = nullptr; }
 #endif
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
-  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->pks_tw1, h->pks_cw, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers, h->ps_dev, (void*)h->clk};
   for (void* p : ptrs)
@@ -838,6 +840,14 @@ static int upload_wave_tables(fastmc_ctx* h) {
     TRY(upload_table<R>(&h->pk_tw1, tw));
     TRY(upload_table<R>(&h->pk_om, omp));
   }
+  if (pks_grid(h->N) && !h->pks_tw1) {          // (both tables depend on N only)
+    const int Sp = pks_split(h->N), L = pk_lanes(pks_L0(h->N));
+    std::vector<cpx<R>> tw((size_t)16 * L), pcw((size_t)Sp * PKS_SPAN);
+    build_tw1_pk<R>(tw.data(), L, cs_turns);
+    build_pcw<R>(pcw.data(), h->N, Sp, cs_turns);
+    TRY(upload_table<R>(&h->pks_tw1, tw));
+    TRY(upload_table<R>(&h->pks_cw, pcw));
+  }
   return 0;
 }
 
@@ -851,6 +861,19 @@ static int pk_variant(const fastmc_ctx* h) {
   if (h->Np <= 96 && (window_planes(h->lo, h->Np, 16, h->N == 128 ? 8 : 16) & ~centre) == 0) return 0;
   if (h->Np <= 256) return 1;     // tables + sixteen exchange buffers fit the LDS for every such window
   return -1;
+}
+
+// Do the packed sub-rows serve this handle's window (fmc_kernels.h: k_rows_pks)?  0: yes -- a window of up to 96 pixels inside the
+// six centred planes of the sub-transforms; -1: no (host coefficients and the column pass always go to the one-row-per-wave
+// kernels; device draws with any other window are staged (float64 generator) or go to the direct family (float32 draw): the
+// P = 12 / 20 / 28 rows of fmc_wavefft.h do not know the N / 16-stream generator layout of these grids).
+template <class R>
+static int pks_variant(const fastmc_ctx* h) {
+  if (!pks_grid(h->N) || h->path != 1) return -1;
+  static const bool off = getenv("FASTMC_PKS") && atoi(getenv("FASTMC_PKS")) == 0;     // A/B: staged / direct instead
+  if (off) return -1;
+  // the six planes of a sub-transform hold x = N / 2 - 48 ... N / 2 + 47 (fmc_wavefft.h: pks_accumulate)
+  return (h->lo >= h->N / 2 - 48 && h->lo + h->Np <= h->N / 2 + 48) ? 0 : -1;
 }
 
 template <class R>
@@ -1080,11 +1103,12 @@ static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
 // rows with MODE = mode, columns with EPI = epi of one (P, NS, S, D) variant
 template <class R, int P, int NS, int S, int DR, int DC = DR>
 static void launch_wave_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
-  {
+  if (mode >= 0) {        // (-1: the packed sub-rows have written V already -- dispatch_pks_rows -- and only the column pass is wanted)
     Span s(h, 0);
     // 256 / 512 draw 16 / 32 streams per row (fmc_core.h: stream_lanes): their device-generator rows are the packed kernels
-    // (dispatch_pk) or the direct family, never the one-row-per-wave kernels, so MODE 0 is not instantiated for them
-    if constexpr (S == 1 && pk_grid(64 * P)) launch_rows_wave<R, P, NS, 1, S, DR>(h, RA);
+    // (dispatch_pk) or the direct family, never the one-row-per-wave kernels, so MODE 0 is not instantiated for them; the same
+    // for 768 / 1280 / 1792 (N / 16 streams per row: the packed sub-rows, staged draws or the direct family)
+    if constexpr (S == 1 && (pk_grid(64 * P) || pks_grid(64 * P))) launch_rows_wave<R, P, NS, 1, S, DR>(h, RA);
     else if (mode == 0) launch_rows_wave<R, P, NS, 0, S, DR>(h, RA);
     else if (mode == 2) {
       // the float64 generator fused into the row (run_impl: fused_gen64): every P = 16 variant (1024, and 2048 / 4096 as
@@ -1132,8 +1156,8 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
     launch_wave_pair<R, 16, NS, S, 7>(h, RA, CA, mode, epi);      // any other window: all sixteen planes
   } else {
     if constexpr (NS == 2 && P > 16 && prune_pays(P, 8, 0)) {
-      if (mode == 0 && epi == 0 && (window_planes(h->lo, h->Np, P, 8) & ~centre_planes(P, 8, 0)) == 0) {
-        launch_wave_pair<R, P, 2, S, 3>(h, RA, CA, 0, 0);
+      if ((mode == 0 || mode == -1) && epi == 0 && (window_planes(h->lo, h->Np, P, 8) & ~centre_planes(P, 8, 0)) == 0) {
+        launch_wave_pair<R, P, 2, S, 3>(h, RA, CA, mode, 0);
         return;
       }
     }
@@ -1188,6 +1212,40 @@ int dispatch_pk(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int m
   else if (h->N == 256) { if (v == 0) launch_pk_pair<R, 1, 0>(h, RA, CA, mode, epi); else launch_pk_pair<R, 1, 1>(h, RA, CA, mode, epi); }
   else                  { if (v == 0) launch_pk_pair<R, 2, 0>(h, RA, CA, mode, epi); else launch_pk_pair<R, 2, 1>(h, RA, CA, mode, epi); }
   return 0;
+}
+
+// Row pass of the packed sub-rows (640 ... 1792; fmc_kernels.h: k_rows_pks); the column pass follows from dispatch_wave_part with
+// mode -1.
+template <class R, int L0, int S, int MODE>
+static void launch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
+  using C = PksCfg<R, L0, S>;
+  const size_t lds = pks_lds_bytes<R, L0, S>() + (MODE == 2 ? GEN64_TABLE_BYTES : 0);
+  constexpr int LR = 128 / (int)sizeof(cpx<R>), LU = LR / C::G, BPG = ROWS_PER_WAVE * C::WPB / LU;
+  int blocks = (C::N / LR) * ((RA.nb + BPG - 1) / BPG);
+  RowArgs<R> B = RA;
+  hipFuncSetAttribute((const void*)k_rows_pks<R, L0, S, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static const int persist = getenv("FASTMC_ROWS_PERSIST") ? atoi(getenv("FASTMC_ROWS_PERSIST")) : 1;
+  if (persist) {        // as launch_rows_wave: a launch of many rounds keeps its workgroups, which walk its tiles
+    const int resident = resident_workgroups(h, (const void*)k_rows_pks<R, L0, S, MODE>, C::WPB * 64, lds);
+    if (blocks >= 8 * resident) { B.tiles = blocks; blocks = resident; }
+  }
+  hipLaunchKernelGGL((k_rows_pks<R, L0, S, MODE>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, B);
+  FMC_NOTE(h->last_rows, "k_rows_pks<%s, %d, %d, %d>", rname<R>(), L0, S, MODE);
+}
+template <class R>
+int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode, int) {
+  Span s(h, 0);
+  const int S = pks_split(h->N), L0 = pks_L0(h->N);
+  RowArgs<R> RA = RA_in;      // the family's own tables; the colouring tables with the input-side fftshift sign folded in
+  RA.amp = (const R*)h->amp_s; RA.ampf = h->ampf_s; RA.tw = (const cpx<R>*)h->pks_tw1; RA.cw = (const cpx<R>*)h->pks_cw;
+#define FMC_PKS(LL, SS)                                                                                   \
+  if (L0 == LL && S == SS) {                                                                              \
+    if (mode == 0) { launch_pks_rows<R, LL, SS, 0>(h, RA); return 0; }                                    \
+    if constexpr (sizeof(R) == 8) { if (mode == 2) { launch_pks_rows<R, LL, SS, 2>(h, RA); return 0; } }  \
+  }
+  FMC_PKS(1, 3) FMC_PKS(1, 5) FMC_PKS(1, 6) FMC_PKS(1, 7) FMC_PKS(0, 5) FMC_PKS(0, 7) FMC_PKS(0, 9)
+#undef FMC_PKS
+  return fail(FASTMC_ESTATE, "no packed sub-row kernel for this grid / mode");
 }
 
 template <class R, int P, int NS, bool BLK = false>
@@ -1467,6 +1525,7 @@ int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA
 
 // ------------------------------------------------------------------ translation units (see the top of the file)
 #define FMC_FAMILY_SIG(R) fastmc_ctx*, const RowArgs<R>&, const ColArgs<R>&, int, int
+#define FMC_PKS_SIG(R) fastmc_ctx*, const RowArgs<R>&, int, int
 #define FMC_WAVE_SIG(R) fastmc_ctx*, RowArgs<R>&, ColArgs<R>&, int, int, bool
 // unit -> what it instantiates.  The float32 pipeline exists for the wave and direct families; chirp-z, 50-lane and
 // run-time-split grids run the float64 kernels whatever precision was asked for (fastmc_create).
@@ -1508,6 +1567,8 @@ extern template int dispatch_mr_part<double, 1>(FMC_FAMILY_SIG(double));
 #if FMC_TU != 10
 extern template int dispatch_pk<double>(FMC_FAMILY_SIG(double));
 extern template int dispatch_pk<float>(FMC_FAMILY_SIG(float));
+extern template int dispatch_pks_rows<double>(FMC_PKS_SIG(double));
+extern template int dispatch_pks_rows<float>(FMC_PKS_SIG(float));
 #endif
 #endif
 #if FMC_TU == 1
@@ -1529,8 +1590,10 @@ template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
 template int dispatch_mr_part<double, 1>(FMC_FAMILY_SIG(double));
 #elif FMC_TU == 10
 template int dispatch_pk<double>(FMC_FAMILY_SIG(double));
+template int dispatch_pks_rows<double>(FMC_PKS_SIG(double));
 #ifndef FMC_ONLY_F64
 template int dispatch_pk<float>(FMC_FAMILY_SIG(float));
+template int dispatch_pks_rows<float>(FMC_PKS_SIG(float));
 #endif
 #elif !defined(FMC_ONLY_F64)
 #if FMC_TU == 4
@@ -1579,6 +1642,7 @@ static bool fused_gen64(fastmc_ctx* h) {
   if constexpr (sizeof(R) != 8) return false;
   if (getenv("FASTMC_GEN64_STAGED")) return false;          // A/B: the round-3 form (k_gen_coeffs_f64 -> cre / cim -> MODE 1 rows)
   if (h->path == 1 && pk_grid(h->N) && pk_variant<R>(h) >= 0) return true;      // 128 / 256 / 512: the packed rows draw it themselves too
+  if (h->path == 1 && pks_grid(h->N)) return pks_variant<R>(h) >= 0;            // 640 ... 1792 (pks_split): the packed sub-rows, else staged
   if constexpr (sizeof(R) == 8) {
     if (h->path == 2) {      // chirp-z family: its rows draw it too where the tables fit
       const int ns2 = h->NS <= 2 ? 2 : 4;
@@ -1797,7 +1861,11 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       CA.tw = RA.tw; CA.om = RA.om; CA.cw = nullptr; CA.tw_global = 0;
       TRY(dispatch_pk<R>(h, RA, CA, kmode, S.epi));
     } else {
-    bool wave_ok = h->path == 1 && !(pk_grid(h->N) && kmode == 0);    // packed grids beyond the packed windows: see pk_variant
+    // packed sub-rows (640 ... 1792, fmc_core.h: pks_split): the device generator's rows, then the column pass of the one-row-per-wave family
+    const bool pks = kmode != 1 && pks_variant<R>(h) >= 0;
+    bool wave_ok = h->path == 1 && !(pk_grid(h->N) && kmode == 0) && !(pks_grid(h->N) && kmode == 0 && !pks);    // packed grids beyond the packed windows: see pk_variant, pks_variant
+    if (pks) TRY(dispatch_pks_rows<R>(h, RA, kmode, 0));
+    const int wmode = pks ? -1 : kmode;
     bool general_2048 = false;   // N = 2048, window > 256 pixels, host coefficients: single-pass P = 32 kernels
     if (wave_ok) {
       int ns, wpb_unused;
@@ -1821,11 +1889,11 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
         if constexpr (sizeof(R) == 8) { TRY(dispatch_ws<R>(h, RA, CA, kmode, S.epi)); }
         else return fail(FASTMC_ESTATE, "run-time-split grids run the float64 kernels (fastmc_create)");
       } else if (general_2048 || (h->S == 1 && h->P >= 14 && h->P != 16)) {
-        TRY((dispatch_wave_part<R, 2>(h, RA, CA, kmode, S.epi, general_2048)));
+        TRY((dispatch_wave_part<R, 2>(h, RA, CA, wmode, S.epi, general_2048)));
       } else if (h->P == 16) {
         TRY((dispatch_wave_part<R, 1>(h, RA, CA, kmode, S.epi, false)));
       } else {
-        TRY((dispatch_wave_part<R, 0>(h, RA, CA, kmode, S.epi, false)));
+        TRY((dispatch_wave_part<R, 0>(h, RA, CA, wmode, S.epi, false)));
       }
     } else {
       TRY(dispatch_direct<R>(h, RA, CA, kmode, S.epi));

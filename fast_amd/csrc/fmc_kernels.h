@@ -939,6 +939,99 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPC * 64), (PkCfg<R, L0, D>::CMIN
   }
 }
 
+// ================================================================== packed SUB-ROWS: N = S x 256 (768, 1280, 1536, 1792), S x 128 (640, 896, 1152)
+// The row pass of the grids whose one-row-per-wave kernel holds 10 ... 28 values per lane (fmc_wavefft.h: pks_accumulate has the
+// arithmetic): a wavefront owns G = 4 / 8 consecutive rows and transforms them one sub-row index s at a time on the packed
+// pipeline of the 256 / 128-point grid -- sixteen draws per lane and pass from ONE generator stream (t = s + S q of SL = S L =
+// N / 16: fmc_core.h stream_lanes), six planes accumulated in registers, V written once per row.  Centred windows of up to 96
+// pixels, device generator (MODE 0 float32 draw, MODE 2 float64 generator); the column pass and every other window / mode stay
+// with the one-row-per-wave kernels (same V layout).  Tile walk as k_rows_wave.
+#ifndef FMC_PKS_WPB
+#define FMC_PKS_WPB 12
+#endif
+#ifndef FMC_PKS_WPB0
+#define FMC_PKS_WPB0 8
+#endif
+template <class R, int L0_, int S> struct PksCfg {
+  static constexpr int L0 = L0_, L = pk_lanes(L0), G = WAVE / L, M = 16 * L, N = S * M, NM = pks_nm<L0>();
+  static constexpr int B0M = pks_plane_mask(L0, S), FIRST = pks_first_plane(L0, S);
+  // 256-point sub-rows: 155 registers with the float64 generator, twelve waves; 128-point sub-rows carry twelve accumulators (48
+  // more registers for float64): eight waves
+  static constexpr int WPB = L0 == 1 ? FMC_PKS_WPB : (sizeof(R) == 8 ? FMC_PKS_WPB0 : 12);
+};
+// LDS carve (dynamic): [generator tables (MODE 2)][tw1 16 L cpx][pcw S x 96 cpx][xbuf WPB * D16_XELEMS 8-byte]
+template <class R, int L0, int S>
+__host__ __device__ constexpr size_t pks_lds_bytes() {
+  return (size_t)(16 * PksCfg<R, L0, S>::L + S * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksCfg<R, L0, S>::WPB * D16_XELEMS * 8;
+}
+template <class R, int L0, int S, int MODE>
+__global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using C = PksCfg<R, L0, S>;
+  using E = typename Xch<R>::E;
+  constexpr int L = C::L, G = C::G, N = C::N, WPB = C::WPB;
+  Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
+  cpx<R>* s_cw = s_tw + 16 * L;
+  E* s_x = reinterpret_cast<E*>(s_cw + S * PKS_SPAN);
+  if constexpr (MODE == 2) { gen64_lds0_check(s_g64); load_gen64_table(s_g64, A.g64); }
+  for (int i = threadIdx.x; i < 16 * L; i += blockDim.x) s_tw[i] = A.tw[i];
+  for (int i = threadIdx.x; i < S * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  E* xbuf = s_x + w * D16_XELEMS;
+  LaneRegs<R, 16, C::NM> regs;
+  GpuExec<R, 16, C::NM> ex{lane, regs};
+  constexpr int LR = 128 / (int)sizeof(cpx<R>), LU = LR / G;
+  static_assert(LR % G == 0 && (ROWS_PER_WAVE * WPB) % LU == 0, "tile must hold whole lines");
+  constexpr int BPG = ROWS_PER_WAVE * WPB / LU;
+  const int nbb = (A.nb + BPG - 1) / BPG;
+  const int q = lane & (L - 1), gl = lane / L;
+  const int lane_in = gl * N + S * q;                    // this lane's first input of sub-row 0 (the G rows of a unit are contiguous)
+  const int tiles = A.tiles ? A.tiles : (int)gridDim.x;
+#pragma unroll 1
+  for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
+  const int b0 = (vb % nbb) * BPG;
+  const int row0 = (vb / nbb) * LR;
+#pragma unroll 1
+  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+    const int flat = rr * WPB + w;
+    const int b = b0 + flat / LU;
+    if (b >= A.nb) break;                                // wave-uniform
+    const int ky0 = row0 + (flat % LU) * G;
+    const uint64_t g = A.g0 + (uint64_t)b;
+    pks_clear<R, L0>(ex);
+#pragma unroll 1
+    for (int sp = 0; sp < S; ++sp) {
+      // sub-row sp of the G rows: kx = sp + S (q + L j), stream t = sp + S q of SL = S L
+      xoshiro128p rs = row_stream(A.key, g, ky0 + gl, sp + S * q, S * L);
+      if (MODE == 0) {
+        const float* ampf = A.ampf + (size_t)ky0 * N + sp;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[lane_in + S * L * j]);
+      } else if constexpr (MODE == 2) {
+        static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
+        const R* amp = A.amp + (size_t)ky0 * N + sp;
+        double an = (double)amp[lane_in];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const double a = an;
+          if (j + 1 < 16) an = (double)amp[lane_in + S * L * (j + 1)];
+          ex.loadfence();
+          regs.v[j] = draw_coloured_f64(rs, a, Gen64Lds0{});
+          asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
+        }
+      }
+      packed_row_fft<R, L0, C::NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
+      pks_accumulate<R, L0, C::FIRST>(ex, s_cw + sp * PKS_SPAN);
+    }
+    cpx<R>* out = A.V + (size_t)b * A.Np * N + ky0;      // V[b][oi][ky]
+    pks_outputs<R, L0>(lane, regs, N, A.lo, A.Np, [&](int oi, R re, R im) { out[(uint32_t)(oi * N + gl)] = mk<R>(re, im); });
+  }
+  if (A.tiles) __syncthreads();      // (as k_rows_wave: the waves of a workgroup stay within one tile of each other)
+  }
+}
+
 // ================================================================== chirp-z family (any N with 64 P >= N + Np - 1)
 // The row / column passes of the wave family for grid sizes that are not 64 P: every 1-D transform is a chirp-z
 // (Bluestein) transform on the same pipeline (fmc_bluestein.h), window outputs only.  Same generator streams as the

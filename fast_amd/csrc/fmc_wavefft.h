@@ -609,6 +609,78 @@ FMC_HD void packed_outputs(int lane, const LaneRegs<R, 16, NSL>& r, int lo, int 
     }
   }
 }
+// ---------------------------------------------------------------- N = S x 256 / S x 128: packed SUB-ROWS (round 6)
+// A row of N = S M points (M = 16 L: the packed 256-point pipeline, L0 = 1, or the 128-point one, L0 = 0) as S interleaved
+// sub-rows c_s[m] = c[s + S m]:
+//     X[x] = sum_{s < S} w_N^{s x} Y_s[x mod M],      Y_s = DFT_M(c_s)            (decimation in time)
+// evaluated for the window only.  A wavefront transforms the G = 4 / 8 rows of a unit one sub-row index s at a time with
+// packed_row_fft -- sixteen values per lane whatever N, where the one-row-per-wave form holds N / 64 = 10 ... 28.  The window's
+// centre N / 2 falls on M / 2 of every sub-transform when S is odd and on 0 when S is even, so six planes of the
+// sub-transform ARE the outputs of a centred window of up to 96 pixels -- x = N / 2 - 48 + e, e < 96, whatever S:
+//   L0 = 1: lane (g, a) holds e = a + 16 p in plane b0 = (FIRST + p) mod 16, FIRST = 5 (S odd) or 13 (S even);
+//   L0 = 0: lane (g, i) holds e = i + 8 m + 16 p, m < 2, in r.v[8 m + FIRST + p], FIRST = 1 (S odd)
+// and the sum over s runs in the lane's own registers: no exchange between sub-rows, no second image.  The accumulators live
+// in r.omc[m][p] (the one-row kernels' register table is unused here).  Twiddles: pcw[s * 96 + e] = w_N^{s x} -- 96 entries per
+// sub-row that depend on N only (build_pcw); the G groups of a wavefront read the same sixteen.
+constexpr int PKS_SPAN = 96;                                         // outputs of a sub-transform the six planes hold
+template <int L0> constexpr int pks_nm() { return L0 == 0 ? 2 : 1; }        // butterflies (a values) per lane
+constexpr int pks_first_plane(int L0, int S) { return L0 == 0 ? ((S & 1) ? 1 : 5) : ((S & 1) ? 5 : 13); }
+constexpr int pks_plane_mask(int L0, int S) {
+  int m = 0;
+  for (int p = 0; p < 6; ++p) m |= 1 << ((pks_first_plane(L0, S) + p) & (L0 == 0 ? 7 : 15));
+  return m;
+}
+static_assert(pks_plane_mask(1, 3) == pk_centre_mask<1>() && pks_plane_mask(0, 5) == pk_centre_mask<0>() && pks_plane_mask(1, 6) == D16R_CENTRE_MASK,
+              "the centred planes of the 256 / 128-point grids, and the planes around 0");
+template <class R, int L0, class Exec>
+FMC_HD void pks_clear(Exec& ex) {
+  ex.each([&](int, LaneRegs<R, 16, pks_nm<L0>()>& r) {
+#pragma unroll
+    for (int m = 0; m < pks_nm<L0>(); ++m)
+#pragma unroll
+      for (int p = 0; p < 6; ++p) r.omc[m][p] = mk<R>((R)0, (R)0);
+  });
+}
+// after packed_row_fft of sub-row s (its planes in r.v, output-side sign applied): acc[m][p] += w_N^{s x} Y_s[x mod M]
+template <class R, int L0, int FIRST, class Exec>
+FMC_HD void pks_accumulate(Exec& ex, const cpx<R>* pcw_s) {
+  ex.each([&](int lane, LaneRegs<R, 16, pks_nm<L0>()>& r) {
+    if constexpr (L0 == 1) {
+      const cpx<R>* w = pcw_s + (lane & 15);
+#pragma unroll
+      for (int p = 0; p < 6; ++p) r.omc[0][p] = cfma(ex.ld(w + 16 * p), r.v[(FIRST + p) & 15], r.omc[0][p]);
+    } else {
+      const cpx<R>* w = pcw_s + (lane & 7);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int p = 0; p < 6; ++p) r.omc[m][p] = cfma(ex.ld(w + 8 * m + 16 * p), r.v[8 * m + ((FIRST + p) & 7)], r.omc[m][p]);
+    }
+  });
+}
+// f(oi, re, im) for every window output this lane holds after the last pks_accumulate; N the full row length
+template <class R, int L0, class F>
+FMC_HD void pks_outputs(int lane, const LaneRegs<R, 16, pks_nm<L0>()>& r, int N, int lo, int Np, F f) {
+  const int a = lane & (L0 == 0 ? 7 : 15);
+#pragma unroll
+  for (int p = 0; p < 6; ++p)
+#pragma unroll
+    for (int m = 0; m < pks_nm<L0>(); ++m) {
+      const int oi = N / 2 - 48 + a + 8 * m + 16 * p - lo;
+      if (oi >= 0 && oi < Np) f(oi, r.omc[m][p].x, r.omc[m][p].y);
+    }
+}
+template <class R, class CosSin>
+inline void build_pcw(cpx<R>* pcw, int N, int S, CosSin cs) {
+  for (int sp = 0; sp < S; ++sp)
+    for (int e = 0; e < PKS_SPAN; ++e) {
+      const long long x = N / 2 - 48 + e;
+      double c, sn;
+      cs((double)((sp * x) % N) / N, &c, &sn);
+      pcw[sp * PKS_SPAN + e] = mk<R>((R)c, (R)(-sn));
+    }
+}
+
 // tw1[a * L + q] = w_N^{q a}, N = 16 L (16 L entries);  om[1 * omS + oi] = w_L^{b}, b = ((lo + oi) / 16) mod L  (L0 = 2
 // only; row 0 is never read)
 template <class R, class CosSin>

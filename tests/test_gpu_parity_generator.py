@@ -264,6 +264,8 @@ _VARIANTS = [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, No
              (1024, 256, None), (1024, 400, None), (1024, 82, 0), (1024, 82, 340), (1024, 82, 500), (1024, 120, 904),
              (2048, 82, None), (2048, 122, None), (2048, 402, None), (4096, 82, None),
              (1152, 82, None), (1280, 82, None), (1536, 82, None), (1792, 82, None), (512, 82, None), (256, 82, None), (768, 152, None),
+             (768, 82, None), (768, 96, 333), (1280, 40, None), (1792, 82, 857), (1280, 82, 100),     # packed sub-rows; (768, 152) and (1280, 82, 100): beyond them
+             (640, 82, None), (896, 82, None), (896, 96, 401), (1152, 64, None), (1536, 82, 730), (640, 82, 0),
              (1000, 82, None), (2000, 82, None), (1200, 82, None), (500, 82, None), (3072, 82, None), (1344, 82, None),
              (164, 82, None), (943, 82, None),
              # packed rows (eight / four / two rows per wavefront): six centred planes, all planes, off-centre and wide windows, the whole
@@ -277,7 +279,7 @@ _VARIANTS = [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, No
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_every_device_mode_row_variant_matches_the_oracle(N, Np, lo, prec):
     if prec == "f32" and (N > 2048 or (N, Np, lo) not in [(1024, 82, None), (1024, 128, None), (1024, 200, None), (2048, 82, None), (1000, 82, None), (512, 82, None),
-                                                         (256, 82, None), (256, 200, None), (512, 250, 7), (128, 82, None), (128, 128, None)]):
+                                                         (256, 82, None), (256, 200, None), (512, 250, 7), (128, 82, None), (128, 128, None), (768, 82, None), (1792, 82, None), (896, 82, None), (1536, 82, None)]):
         pytest.skip("float32 pipeline: the benchmarked shapes only")
     ps, df = _vk_spectrum(N, 0.01, 30.0)
     ps = ps * 0.02
@@ -384,12 +386,18 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (192, 30, None, "k_rows_wave<double, 3, 2, 2, 1, 0>"), (320, 82, 3, "k_rows_wave<double, 5, 2, 2, 1, 0>"),
             (384, 60, None, "k_rows_wave<double, 6, 2, 2, 1, 0>"), (448, 128, None, "k_rows_wave<double, 7, 2, 2, 1, 0>"),
             (576, 82, None, "k_rows_wave<double, 9, 2, 2, 1, 0>"), (576, 200, None, "k_rows_wave<double, 9, 4, 2, 1, 0>"),
-            (640, 82, None, "k_rows_wave<double, 10, 2, 2, 1, 0>"), (640, 250, 11, "k_rows_wave<double, 10, 4, 2, 1, 0>"),
-            (768, 82, None, "k_rows_wave<double, 12, 2, 2, 1, 0>"), (768, 256, None, "k_rows_wave<double, 12, 4, 2, 1, 0>"),
-            (896, 100, None, "k_rows_wave<double, 14, 2, 2, 1, 0>"), (1152, 82, None, "k_rows_wave<double, 18, 2, 2, 1, 0>"),
-            (1280, 82, None, "k_rows_wave<double, 20, 2, 2, 1, 0>"), (1280, 200, None, "k_rows_wave<double, 20, 4, 2, 1, 0>"),
-            (1536, 120, 1400, "k_rows_wave<double, 24, 2, 2, 1, 0>"), (1536, 222, None, "k_rows_wave<double, 24, 4, 2, 1, 0>"),
-            (1792, 82, None, "k_rows_wave<double, 28, 2, 2, 1, 0>"),
+            (640, 82, None, "k_rows_pks<double, 0, 5, 2>"), (640, 96, 272, "k_rows_pks<double, 0, 5, 2>"), (640, 250, 11, "k_rows_wave<double, 10, 4, 1, 1, 0>"),
+            # 640, 768, 896, 1152, 1280, 1536, 1792 (round 6): the packed sub-rows for centred windows of up to 96 pixels (also shifted inside the six planes);
+            # any other window is STAGED (k_gen_coeffs_f64 -> MODE 1 rows: these grids draw N / 16 streams per row)
+            (768, 82, None, "k_rows_pks<double, 1, 3, 2>"), (768, 40, None, "k_rows_pks<double, 1, 3, 2>"), (768, 256, None, "k_rows_wave<double, 12, 4, 1, 1, 0>"),
+            (768, 82, 0, "k_rows_wave<double, 12, 2, 1, 1, 0>"),
+            (896, 100, None, "k_rows_wave<double, 14, 2, 1, 1, 0>"), (896, 82, None, "k_rows_pks<double, 0, 7, 2>"), (1152, 82, None, "k_rows_pks<double, 0, 9, 2>"),
+            (1152, 30, 545, "k_rows_pks<double, 0, 9, 2>"), (1152, 82, 500, "k_rows_wave<double, 18, 2, 1, 1, 0>"),
+            (1280, 82, None, "k_rows_pks<double, 1, 5, 2>"), (1280, 96, None, "k_rows_pks<double, 1, 5, 2>"), (1280, 82, 602, "k_rows_pks<double, 1, 5, 2>"),
+            (1280, 200, None, "k_rows_wave<double, 20, 4, 1, 1, 0>"),
+            (1536, 120, 1400, "k_rows_wave<double, 24, 2, 1, 1, 0>"), (1536, 222, None, "k_rows_wave<double, 24, 4, 1, 1, 0>"), (1536, 82, None, "k_rows_pks<double, 1, 6, 2>"),
+            (1536, 96, 720, "k_rows_pks<double, 1, 6, 2>"),
+            (1792, 82, None, "k_rows_pks<double, 1, 7, 2>"), (1792, 60, 860, "k_rows_pks<double, 1, 7, 2>"), (1792, 97, None, "k_rows_wave<double, 28, 2, 1, 1, 0>"),
             # 50-lane family (N = 50 P S) and the run-time-split wave grids: the rows of fmc_mrfft.h
             (100, 40, None, "k_rows_mr<double, 2, 2, 2, false, 50, 0>"), (300, 60, None, "k_rows_mr<double, 6, 2, 2, false, 50, 0>"),
             (500, 82, None, "k_rows_mr<double, 10, 2, 2, false, 50, 0>"), (800, 96, 3, "k_rows_mr<double, 16, 2, 2, false, 50, 0>"),

@@ -144,6 +144,12 @@ def test_a_stuck_thread_never_turns_an_error_exit_into_success():
     assert _rc("pass")[0] == 70                       # nobody said the run finished: EX_SOFTWARE, not 0
     assert _rc("dist.mark_clean_exit()")[0] == 0      # the work is done and reported: the stuck thread is abandoned quietly
     assert _rc("dist.mark_clean_exit(); raise ValueError('late failure')")[0] == 1
+    # a failure path that ends in a raised SystemExit after a step marked the exit clean (bench.py --require-rccl did)
+    # came out as 0.  No hook Python offers sees a top-level `raise SystemExit(n)`, so such a path records its status first:
+    assert _rc("dist.mark_clean_exit(); dist.mark_exit(4); raise SystemExit(4)")[0] == 4
+    assert _rc("dist.mark_clean_exit(); dist.mark_exit('degraded to the host exchange'); raise SystemExit('degraded')")[0] == 1
+    assert _rc("dist.mark_clean_exit(); dist.mark_exit(3); sys.exit(3)")[0] == 3
+    assert _rc("dist.mark_exit(3); dist.mark_clean_exit()")[0] == 0       # ... and a later clean mark is the last word
 
 
 def test_exit_hooks_exist_only_while_a_thread_is_left_behind():

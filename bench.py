@@ -205,6 +205,77 @@ def extras(args, device):
     return out
 
 
+def extras_multi(args, mode, devices, rank, world, rdzv):
+    """N > 1, EVERY rank calls this (its exchanges are collective): BASELINE configs[3] (2048^2, 100 000 iterations in total, sharded
+    over ALL the GPUs of the launch: strong scaling, gather + dB histogram) and configs[4] (32 zenith angles x 4096 iterations at
+    1024^2, AO + alias, dealt 32 / N per GPU), in the launch form of the headline: one process with a worker thread per device
+    (`GPU_DEVICES`, `sweep.zenith_scan(devices=...)`) or one process per GPU (`GPU_SHARD` auto, `zenith_scan(rank, world)` +
+    `gather_records`).  The reference's pattern: fast/complete_orbit_simulation.py:217-228 (one Fast object per geometry sample)."""
+    import copy
+    import fast_amd
+    from fast_amd import sweep
+    workers = len(devices) if mode == "threads" else world
+    out = {}
+
+    def wall_max(dt):
+        return dt if rdzv is None else float(rdzv.all_reduce(np.array([dt]), "max")[0])
+
+    # configs[3]
+    p = workload_params(copy.copy(args))
+    p.update({"NPXLS": 2048, "NITER": 100000, "NCHUNKS": 100, "AO_MODE": "NOAO"})
+    if mode == "threads":
+        p["GPU_DEVICES"] = devices
+    else:
+        p["GPU_DEVICE"] = devices[0]
+        p["GPU_SHARD"] = True                                # one process per GPU: Fast.run shards over the ranks and exchanges once
+    if 50000 % workers == 0:
+        t0 = time.perf_counter()
+        sim = fast_amd.Fast(p)
+        sim.run()                                            # first run: allocations, module load of the 2048 kernels
+        t1 = time.perf_counter()
+        if rdzv is not None:
+            rdzv.barrier()
+        t2 = time.perf_counter()
+        r = sim.run()._r
+        run_s = wall_max(time.perf_counter() - t2)
+        hist = sim.histogram(*HIST)
+        if mode == "threads":
+            exch, ranks = sim._group.exchange, (sim._group.rccl_ranks if sim._group.exchange == "rccl" else 0)
+        else:
+            tr = sim._transport()
+            exch, ranks = tr.name, (tr.rccl_ranks if tr.name == "rccl" else 0)
+        out["config3_2048_100k_all_gpus"] = {"iterations_per_s": 100000 / run_s, "run_s": run_s, "init_and_first_run_s": t1 - t0, "workers": workers,
+                                             "scaling": "strong", "histogram_total": int(hist.sum()), "result_exchange": exch, "rccl_ranks": int(ranks),
+                                             "mean_dB_rel": float(10 * np.log10(r.mean()))}
+        del sim
+    else:
+        out["config3_2048_100k_all_gpus"] = {"skipped": f"{workers} workers do not divide 50 000 realisations"}
+    # configs[4]
+    base = workload_params(copy.copy(args))
+    base.update({"AO_MODE": "AO", "ALIAS": True, "NPXLS": 1024, "GPU_DEVICE": devices[0]})
+    angles = np.linspace(0, 70, 32)
+    devs = devices if mode == "threads" else None
+    r_, w_ = (0, 1) if mode == "threads" else (rank, world)
+    sweep.zenith_scan(base, angles[:2 * workers], niter=4096, rank=r_, world=w_, devices=devs)      # warm: pupil / module caches, handle caches
+    if rdzv is not None:
+        rdzv.barrier()
+    t0 = time.perf_counter()
+    recs = sweep.zenith_scan(base, angles, niter=4096, rank=r_, world=w_, devices=devs)
+    if mode == "ranks":
+        recs = sweep.gather_records(recs)
+    wall = wall_max(time.perf_counter() - t0)
+    per_dev = {}
+    for rec in recs:
+        per_dev[rec["device"]] = per_dev.get(rec["device"], 0) + 1
+    out["config5_zenith_scan_32x4096_all_gpus"] = {
+        "wall_s": wall, "iterations_per_s_end_to_end": 32 * 4096 / wall, "samples": len(recs), "workers": workers,
+        "samples_per_worker": 32 / workers, "samples_by_device_index": {str(k): v for k, v in sorted(per_dev.items())},
+        "init_s_sum": sum(r["init_s"] for r in recs), "run_s_sum": sum(r["run_s"] for r in recs),
+        "mean_dB_rel_first_last": [recs[0]["mean_dB_rel"], recs[-1]["mean_dB_rel"]],
+        "note": "no result exchange but the per-sample records (JSON over the rendezvous between processes); device indices are per process"}
+    return out
+
+
 def extras_unmeasured_rows(args, device):
     """The rows of SURVEY section 8 that the headline does not exercise, each timed here so that they are on the record:
     BASELINE configs[0] exactly as stated (the reference's shipped test/test_params.py: NPXLS 256, TEMPORAL on, 100 iterations)
@@ -736,6 +807,18 @@ def main():
         if mode == "single" and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sim)
             line["speedup_vs_cpu_1core"] = value / line["cpu_baseline"]["value"]
+    sync_all()
+    # N > 1: configs[3] over all the GPUs (strong scaling) and the configs[4] sweep dealt over them, in this launch form.  Collective:
+    # every rank runs it; rank 0 holds the line back until it is done.
+    multi_extras = None
+    if workers > 1 and not args.no_extras and not strong:
+        try:
+            multi_extras = extras_multi(args, mode, devices, rank, world, rdzv)
+        except Exception as e:      # the headline is measured: a side measurement must not lose it
+            multi_extras = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        if multi_extras is not None:
+            line["extras_multi_gpu"] = multi_extras
         try:      # RCCL prints a version banner through C stdio: flush it first so that the JSON line is the last line
             import ctypes
             ctypes.CDLL(None).fflush(None)

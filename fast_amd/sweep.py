@@ -7,7 +7,8 @@ complete_orbit_simulation.py:227) and its init is dominated by `compute_powerspe
 1024^2).  Here the power spectrum is one GPU kernel (< 1 ms), the pupil /
 fibre-mode products are cached across samples that share the aperture (host.pupils cache), and
 samples are dealt round-robin to the ranks of a multi-process launch (one process per GPU:
-`zenith_scan(..., rank, world)`); only the per-sample summary statistics are gathered, as JSON --
+`zenith_scan(..., rank, world)`) and, inside a process that drives several GPUs, to one thread per device
+(`devices=[...]`); only the per-sample summary statistics are gathered, as JSON --
 nothing received from another rank is ever unpickled.
 """
 import base64
@@ -21,17 +22,27 @@ import numpy
 from .fast import Fast
 
 
-def zenith_scan(base_params, zenith_angles, niter=4096, nchunks=1, keep_power=False, rank=0, world=1):
+def zenith_scan(base_params, zenith_angles, niter=4096, nchunks=1, keep_power=False, rank=0, world=1, devices=None):
     """Run `Fast` for each zenith angle owned by this rank (angles[rank::world]).
+
+    `devices`: the GPUs this process drives.  With several (one process, N devices: `bench.py --gpus N` without a launcher,
+    `GPU_DEVICES` of the caller) the rank's samples are dealt round-robin to one thread per device -- BASELINE configs[4]
+    is "4 configs per GPU" on 8 GPUs in either launch form; ctypes releases the GIL inside the library, every handle has
+    its own stream and the library's per-device state is locked.  None / one entry: `GPU_DEVICE` of base_params (or that entry).
 
     L_SAT is recomputed from H_SAT for each angle (funcs.l_path via Fast.init_atmos,
     fast.py:237-241) because base_params['L_SAT'] is left None.  Returns a list of dicts
-    (zenith, mean dB_rel, scintillation index, phs_var, logamp_var, timings)."""
-    out = []
-    for idx in range(rank, len(zenith_angles), world):
+    (zenith, mean dB_rel, scintillation index, phs_var, logamp_var, timings, device), ordered by sample index."""
+    mine = list(range(rank, len(zenith_angles), world))
+    devs = None if devices is None else [int(d) for d in devices]
+
+    def one(idx, device):
         p = copy.copy(base_params)
         p.update({"ZENITH_ANGLE": float(zenith_angles[idx]), "NITER": niter, "NCHUNKS": nchunks, "TEMPORAL": False,
                   "GPU_SHARD": False})
+        if device is not None:
+            p["GPU_DEVICE"] = device
+            p["GPU_DEVICES"] = None
         if p.get("SEED") is not None:
             p["SEED"] = int(p["SEED"]) + idx
         t0 = time.perf_counter()
@@ -42,11 +53,30 @@ def zenith_scan(base_params, zenith_angles, niter=4096, nchunks=1, keep_power=Fa
         rec = {"index": idx, "zenith": float(zenith_angles[idx]), "mean_dB_rel": float(res.avg_power_dB_rel),
                "scintillation_index": float(res.scintillation_index), "phs_var": float(sim.phs_var),
                "logamp_var": float(sim.logamp_var), "r0_los": float(sim.r0_los), "L": float(sim.L),
-               "init_s": t1 - t0, "run_s": t2 - t1, "powerspec_kernel_ms": sim.powerspec_kernel_ms}
+               "init_s": t1 - t0, "run_s": t2 - t1, "powerspec_kernel_ms": sim.powerspec_kernel_ms, "device": int(sim.device)}
         if keep_power:
             rec["r"] = res._r
-        out.append(rec)
-    return out
+        return rec
+
+    if not devs or len(devs) == 1:
+        return [one(idx, devs[0] if devs else None) for idx in mine]
+    import threading
+    out, errs = [], []
+
+    def worker(k):
+        try:
+            for idx in mine[k::len(devs)]:
+                out.append(one(idx, devs[k]))          # (list.append is atomic under the GIL)
+        except BaseException as e:                     # noqa: BLE001 -- re-raised in the caller's thread
+            errs.append(e)
+    ths = [threading.Thread(target=worker, args=(k,), name=f"fastmc-sweep-{k}") for k in range(len(devs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+    return sorted(out, key=lambda r: r["index"])
 
 
 def _encode(records):

@@ -200,6 +200,48 @@ def test_bench_eight_workers_with_a_stalled_exchange_prints_its_line_and_says_wh
     assert line["exchange"]["steps_host"] == 2 and line["config"]["histogram_total"] == 8 * 10000
 
 
+def test_bench_multi_gpu_line_carries_config3_and_the_config5_sweep_over_all_workers():
+    """one `bench.py --gpus N` line (one process, N worker threads -- here four on device 0) carries the weak-scaling
+    headline AND configs[3] over all N workers (strong scaling, gather + histogram) AND the 32-angle configs[4] sweep dealt 32 / N per
+    worker, each with its exchange named."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FASTMC_BENCH_DEVICES"] = "0,0,0,0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-sustained", "--no-f32-draw-pass", "--no-host-cost-pass"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "weak" and line["config"]["workers"] == 4
+    x = line["extras_multi_gpu"]
+    assert "error" not in x, x
+    c3, c5 = x["config3_2048_100k_all_gpus"], x["config5_zenith_scan_32x4096_all_gpus"]
+    assert c3["workers"] == 4 and c3["histogram_total"] == 100000 and c3["scaling"] == "strong" and c3["iterations_per_s"] > 1e4
+    assert c3["result_exchange"].startswith("host") and c3["rccl_ranks"] == 0          # four workers share one device here
+    assert c5["samples"] == 32 and c5["workers"] == 4 and c5["samples_per_worker"] == 8 and c5["iterations_per_s_end_to_end"] > 1e4
+    assert c5["samples_by_device_index"] == {"0": 32}
+    assert c5["mean_dB_rel_first_last"][0] > c5["mean_dB_rel_first_last"][1]
+
+
+def test_bench_two_ranks_line_carries_the_multi_gpu_extras():
+    """The launcher form (one process per GPU: how the driver starts bench.py for N > 1), two ranks on the one GPU of a test box:
+    configs[3] sharded over the ranks (GPU_SHARD auto) and the configs[4] sweep dealt angles[rank::world], records gathered."""
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29591", FASTMC_BENCH_DEVICE="0", FASTMC_DISABLE_RCCL="1", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                                       "--no-sustained", "--no-f32-draw-pass", "--no-host-cost-pass"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:] + e[-3000:]
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert line["config"]["workers"] == 2 and "processes" in line["config"]["launch"]
+    x = line["extras_multi_gpu"]
+    assert "error" not in x, x
+    assert x["config3_2048_100k_all_gpus"]["histogram_total"] == 100000 and x["config3_2048_100k_all_gpus"]["result_exchange"] == "host"
+    assert x["config5_zenith_scan_32x4096_all_gpus"]["samples"] == 32 and x["config5_zenith_scan_32x4096_all_gpus"]["samples_per_worker"] == 16
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]            # rank 0 alone prints the line
+
+
 def test_bench_config3_strong_scaling_workload():
     """--workload config3: BASELINE configs[3] (2048^2, 100 000 iterations per step in total) split over the workers."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}

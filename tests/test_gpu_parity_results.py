@@ -92,6 +92,29 @@ def test_zenith_scan_sweep():
     assert half[0]["mean_dB_rel"] == recs[1]["mean_dB_rel"]
 
 
+def test_zenith_scan_dealt_over_devices_equals_the_single_device_scan():
+    """`sweep.zenith_scan(devices=[...])` deals a process's samples to one thread per device (bench.py --gpus N
+    without a launcher: BASELINE configs[4] is 4 configs per GPU on 8 GPUs).  With GPU_DEVICES=[0, 0, 0, 0] on the one GPU of a
+    test box every record -- the per-iteration powers too -- equals the single-device scan's, and each worker served its share."""
+    from fast_amd import sweep
+    g = load_golden("e2e_ao_alias")
+    p = params_from_json(g["params_json"])
+    p.update({"GPU_DEVICE": 0, "NPXLS": 512, "SEED": 3})
+    angles = np.linspace(0, 60, 10)
+    one = sweep.zenith_scan(p, angles, niter=64, keep_power=True)
+    four = sweep.zenith_scan(p, angles, niter=64, keep_power=True, devices=[0, 0, 0, 0])
+    assert [r["index"] for r in four] == list(range(10)) and all(r["device"] == 0 for r in four)
+    for a, b in zip(one, four):
+        assert a["zenith"] == b["zenith"] and a["phs_var"] == b["phs_var"] and a["mean_dB_rel"] == b["mean_dB_rel"]
+        np.testing.assert_array_equal(a["r"], b["r"])
+    # ... and combined with a rank's share of a multi-process launch: rank 1 of 2 owns the odd samples, dealt over two devices
+    half = sweep.zenith_scan(p, angles, niter=64, rank=1, world=2, devices=[0, 0])
+    assert [r["index"] for r in half] == [1, 3, 5, 7, 9] and half[2]["mean_dB_rel"] == one[5]["mean_dB_rel"]
+    # a worker's exception reaches the caller
+    with pytest.raises(Exception):
+        sweep.zenith_scan(dict(p, NPXLS=-5), angles[:4], niter=64, devices=[0, 0])
+
+
 def test_config5_zenith_scan_full_size():
     """BASELINE configs[4] at size: 32 zenith angles x 4096 iterations at 1024^2, AO + alias, through
     sweep.zenith_scan (one Fast object per angle, spectrum evaluated and kept on the GPU).  Two of the angles are

@@ -724,6 +724,18 @@ def main():
             rccl_problem = f"--require-rccl: the communicator reports {rccl_ranks} rank(s), {workers} wanted ({exchange_name()})"
         elif acc["host_steps"] or acc["rccl_steps"] != args.steps:
             rccl_problem = f"--require-rccl: {acc['rccl_steps']} of {args.steps} timed steps exchanged over RCCL, {acc['host_steps']} on the host ({exchange_name()})"
+    # every row-kernel launch of worker 0 in issue order, as calls of n realisations (a call is n // batch launches of `batch` and
+    # one of the remainder): tools/summarise_profile.py reads a profile's per-dispatch times against it
+    B_launch = h.get_batch()
+    calls = [["warmup", n_real, args.warmup], ["timed", n_real, args.steps]]
+    if sustained:
+        calls.append(["sustained", n_real, sustained["steps"]])
+    if host_cost is not None:
+        calls.append(["one_call", args.steps * n_real, 1])
+    launch_plan = {"batch": B_launch, "kernel": kernels[0], "calls": calls, "launches_per_step": -(-n_real // B_launch),
+                   "launches_of_one_step": [B_launch] * (n_real // B_launch) + ([n_real % B_launch] if n_real % B_launch else []),
+                   "note": "realisations per call and worker; the other-precision pass and the extras launch other kernels"}
+    clean = host_cost["tim"] if (host_cost is not None and not args.no_pipeline) else tim
     if rank == 0:
         total_iters = iters_worker * args.steps * workers
         value = total_iters / dt
@@ -759,6 +771,7 @@ def main():
                        "rccl_required": (rccl_problem or "met") if args.require_rccl else None,
                        "histogram_total": None if hist_total is None else int(np.sum(hist_total))},
             "roofline": roofline(args, N, Np, tim if (host_cost is None or args.no_pipeline) else host_cost["tim"], args.steps, workers, iters_worker, kernels),
+            "launch_plan": launch_plan,
             "pipeline": {"steps_in_flight": 1 if args.no_pipeline else 2,
                          # what K separate steps cost beyond the device-limited time of the same work: launches, the exchange's host side,
                          # result copies, Python -- hidden behind the device's work when two steps are in flight
@@ -770,8 +783,14 @@ def main():
                          "gpu_busy_ms_per_step_per_worker": gpu_ms / args.steps / workers,
                          "gpu_busy_ms_per_step": {"min_worker": float(busy.mean(0).min()), "max_worker": float(busy.mean(0).max()),
                                                   "per_worker": [float(x) for x in busy.mean(0)]},
-                         "rows_ms": tim["rows_ms"] / args.steps / workers,
-                         "cols_ms": tim["cols_ms"] / args.steps / workers, "finalize_ms": tim["finalize_ms"] / args.steps / workers,
+                         # per step and worker, from the ONE-CALL pass when there is one (nothing else in the queue: the sum of
+                         # its launches' HIP-event times IS the kernels' time; profiles/*summary.md reproduces it launch by launch);
+                         # the timed steps' own event sums, which overlap with two steps in flight, are kept beside them
+                         "rows_ms": clean["rows_ms"] / args.steps / workers,
+                         "cols_ms": clean["cols_ms"] / args.steps / workers, "finalize_ms": clean["finalize_ms"] / args.steps / workers,
+                         "kernel_ms_from": "one-call pass" if (host_cost is not None and not args.no_pipeline) else "timed steps",
+                         "rows_ms_timed_steps_event_sum": tim["rows_ms"] / args.steps / workers,
+                         "cols_ms_timed_steps_event_sum": tim["cols_ms"] / args.steps / workers,
                          "init_s": init_s, "powerspec_kernel_ms_warm": sim.powerspec_kernel_ms},
         }
         if clocks:

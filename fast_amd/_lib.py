@@ -19,7 +19,7 @@ EXPORTS = [
     "fastmc_version", "fastmc_last_error", "fastmc_device_count", "fastmc_create", "fastmc_destroy",
     "fastmc_set_spectrum", "fastmc_set_pupil", "fastmc_set_subharm", "fastmc_run", "fastmc_run_coeffs",
     "fastmc_screens_coeffs", "fastmc_screens", "fastmc_rng_coeffs", "fastmc_rng_logamp", "fastmc_histogram",
-    "fastmc_result_stats", "fastmc_last_timing", "fastmc_kernel_path", "fastmc_set_batch", "fastmc_powerspec",
+    "fastmc_result_stats", "fastmc_last_timing", "fastmc_kernel_path", "fastmc_set_batch", "fastmc_get_batch", "fastmc_powerspec",
     "fastmc_set_layer_screens", "fastmc_temporal_chunk", "fastmc_link_metrics", "fastmc_set_results",
     "fastmc_powerspec_terms", "fastmc_powerspec_set", "fastmc_powerspec_get",
     "fastmc_comm_unique_id", "fastmc_comm_init", "fastmc_comm_init_all", "fastmc_comm_world", "fastmc_comm_gather",
@@ -92,6 +92,7 @@ def lib():
     L.fastmc_last_timing.argtypes = [vp, dp, C.POINTER(i64)]
     L.fastmc_kernel_path.argtypes = [vp, C.c_int]
     L.fastmc_set_batch.argtypes = [vp, C.c_int]
+    L.fastmc_get_batch.argtypes = [vp, C.POINTER(C.c_int)]
     L.fastmc_last_kernels.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
     L.fastmc_precision.argtypes = [vp]
     L.fastmc_last_result_shape.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_int)]
@@ -427,6 +428,13 @@ class Handle:
 
     def set_batch(self, batch):
         _chk(lib().fastmc_set_batch(self._h, int(batch)))
+
+    def get_batch(self):
+        """Realisations per launch of this handle's runs as it stands (fastmc_get_batch): a run of n is n // batch launches of
+        `batch` and one of the remainder."""
+        b = C.c_int(0)
+        _chk(lib().fastmc_get_batch(self._h, C.byref(b)))
+        return int(b.value)
 
     def last_clock(self):
         """(GHz, span in microseconds) of the shader clock inside the last row-kernel launch (fastmc_last_clock), or None when no

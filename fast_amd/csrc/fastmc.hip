@@ -671,6 +671,15 @@ extern "C" int fastmc_set_batch(fastmc_t* h, int batch) {
 }
 #endif
 
+static int default_batch(const fastmc_ctx* h);
+#if FMC_TU == 0
+extern "C" int fastmc_get_batch(fastmc_t* h, int* batch) {
+  if (!h || !batch) return fail(FASTMC_EINVAL, "null argument");
+  *batch = default_batch(h);
+  return 0;
+}
+#endif
+
 // The tables of the float64 generator (fmc_gen64.h: 256 (cos, sin) entries, 128 log entries), one copy per device, uploaded on first use and kept.
 // (Host helpers of every translation unit -- run_locked below refers to them -- but only unit 0's entry points ever call them.)
 static const Gen64Entry* gen64_table(int device) {

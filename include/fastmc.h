@@ -290,6 +290,11 @@ int fastmc_precision(fastmc_t* h);
 
 /* Realisations in flight per launch (batch).  0 = library default. */
 int fastmc_set_batch(fastmc_t* h, int batch);
+/* The batch a run of this handle uses as it stands (the value set, or the library's default for its grid and window: a `V`
+ * slab of up to 2 GiB in whole workgroup rounds): a run of n realisations is n / batch launches of `batch` and one of the
+ * remainder.  Measurement hook: bench.py prints its launch plan with it, so that a profile's per-dispatch times can be read
+ * against the realisations each dispatch held. */
+int fastmc_get_batch(fastmc_t* h, int* batch);
 
 /* Precision of the DEVICE generator (fastmc_run / fastmc_run_async / fastmc_screens; not of the transform, which
  * fastmc_create fixes).

@@ -20,6 +20,59 @@ for f in find("trace", "*kernel_stats.csv"):
         print(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | "
               f"{float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |")
     print()
+def per_launch_table():
+    """The row kernel's dispatches of the trace run, one by one, against bench.py's launch plan (roofline.launch_plan of the line
+    the profiled command printed): which call each dispatch belongs to and how many realisations it held -- so that an average
+    is only ever taken over EQUAL launches."""
+    import json
+    try:
+        line = json.loads(open(os.path.join(out, "bench_line_under_rocprof.json")).read())
+        plan = line["launch_plan"]
+    except Exception as e:
+        print(f"(no launch plan in the profiled bench line: {e})\n")
+        return
+    kernel, B = plan["kernel"], int(plan["batch"])
+    seq = []                                  # (phase, realisations) per dispatch, in issue order
+    for phase, n, count in plan["calls"]:
+        one = [B] * (n // B) + ([n % B] if n % B else [])
+        seq += [(phase, r) for _ in range(int(count)) for r in one]
+    files = find("trace", "*kernel_trace.csv")
+    if not files:
+        return
+    disp = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(files[0]))
+                   if short(r["Kernel_Name"]) == short(kernel)), key=lambda t: t[0])
+    N = int(line["metric"].split("(")[1].split("^")[0])
+    ghz = (line.get("clock") or {}).get("effective_GHz")
+    steps = int(line["steps"])
+    print(f"## the row kernel launch by launch ({short(kernel)}, batch {B}, N = {N}; clock stamped in this run: {ghz and round(ghz, 3)} GHz)\n")
+    if len(disp) != len(seq):
+        print(f"(the trace holds {len(disp)} dispatches of this kernel, the plan {len(seq)}: not matched one to one)\n")
+        return
+    groups = collections.OrderedDict()
+    for (phase, r), (t0, t1) in zip(seq, disp):
+        groups.setdefault((phase, r), []).append((t1 - t0) / 1e3)
+    print("| call | realisations in the launch | launches | mean us | min us | max us | us per realisation | cycles per row and SIMD at the stamped clock |")
+    print("|---|---|---|---|---|---|---|---|")
+    for (phase, r), us in groups.items():
+        m = sum(us) / len(us)
+        # a launch of r realisations is r N rows over 1024 SIMDs: cycles per row = time x clock x 1024 / (r N)
+        cyc = m * 1e-6 * ghz * 1e9 * 1024 / (r * N) if ghz else float("nan")
+        print(f"| {phase} | {r} | {len(us)} | {m:.1f} | {min(us):.1f} | {max(us):.1f} | {m / r:.4f} | {cyc:.0f} |")
+    tot = collections.defaultdict(float)
+    for (phase, r), us in groups.items():
+        tot[phase] += sum(us)
+    print()
+    if "timed" in tot:
+        print(f"rows per step, timed steps (sum of their launches / {steps} steps): **{tot['timed'] / steps / 1e3:.3f} ms**")
+    if "one_call" in tot:
+        print(f"rows per step, one-call pass (the same realisations as ONE call / {steps}): **{tot['one_call'] / steps / 1e3:.3f} ms**")
+    pl = line.get("pipeline", {})
+    print(f"the bench line of this very run: pipeline.rows_ms = {pl.get('rows_ms'):.3f} ms ({pl.get('kernel_ms_from')}; HIP events), "
+          f"timed steps' event sum {pl.get('rows_ms_timed_steps_event_sum'):.3f} ms, ms_per_step {line['ms_per_step']:.3f}, "
+          f"value {line['value']:.0f} it/s under the profiler\n")
+
+
+per_launch_table()
 for f in find("trace", "*kernel_trace.csv")[:1]:
     rows = list(csv.DictReader(open(f)))
     seen = {}
@@ -34,7 +87,7 @@ for f in find("trace", "*kernel_trace.csv")[:1]:
         print(f"| {k} | {r.get('Grid_Size_X','?')} | {r.get('Workgroup_Size_X','?')} | {r.get('VGPR_Count','?')} | "
               f"{r.get('Accum_VGPR_Count','?')} | {r.get('SGPR_Count','?')} | {r.get('LDS_Block_Size','?')} | {r.get('Scratch_Size','?')} |")
     print()
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_sq4"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_sq4"):  # (pmc_sq3: the matrix-pipe counters)
     files = find(sub, "*counter_collection.csv")
     if not files:
         continue

@@ -175,6 +175,7 @@ struct fastmc_ctx {
   double* gather_buf = nullptr;
   size_t gather_cap = 0;
   // fastmc_run_async: kernels enqueued, events not read yet (fastmc_wait / the exchange finish the bookkeeping)
+  bool light_rows = false; // fastmc_run_npstream on two streams: the MODE 1 rows as four-wave workgroups (WCfg D = 9)
   int rng_f64 = 0;        // fastmc_set_rng_precision: the device generator at float64 precision (fused into the P = 16 rows, else staged in cre / cim)
   const Gen64Entry* g64 = nullptr;   // its log table on this device (gen64_table)
   // ONE caller at a time on a handle's stream, events and result bookkeeping: the entry points that use them take this lock
@@ -1147,6 +1148,13 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
         // (EPI 1).  Split rows: sixteen-wave workgroups where the tables fit (A/B at 2048^2: rows 37.4 -> 35.7 ms per 5000
         // realisations; 4096^2: -1 %); the split column kernel loses 6 % there at 4096^2 and stays on twelve waves.
         if constexpr (S == 1) {
+          if constexpr (sizeof(R) == 8) {
+            if (dense && mode == 1 && epi == 0 && h->light_rows) {      // same-seed mode on two streams (fastmc_run_npstream): WCfg D = 9
+              { Span s(h, 0); launch_rows_wave<R, 16, 2, 1, 1, 9>(h, RA); }
+              { Span s(h, 1); launch_cols_wave<R, 16, 2, 0, 1, 4>(h, CA); }
+              return;
+            }
+          }
           if (dense) { launch_wave_pair<R, 16, 2, 1, 4>(h, RA, CA, mode, epi); return; }
         } else {
           if (dense && mode != 1) { launch_wave_pair<R, 16, 2, S, 4, 5>(h, RA, CA, mode, epi); return; }
@@ -1640,6 +1648,7 @@ struct RunSpec {
   const double* coef_dev_im = nullptr;
   const double* sh_dev_re = nullptr;
   const double* sh_dev_im = nullptr;
+  double* out_dev = nullptr;            // write the results here instead of h->out (the chunks of fastmc_run_npstream: one copy back per call, not per chunk)
 };
 
 // Does this handle's row kernel draw the float64 generator itself (MODE 2)?  The one-row-per-wave grids of the wave family
@@ -1917,7 +1926,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
         FA.nb = (int)(done - fin_start); FA.Np = Np; FA.coherent = S.coherent; FA.n_real = S.n_real; FA.j0 = fin_start;
         FA.partial = h->partial; FA.logamp = S.logamp_dev ? S.logamp_dev : (S.logamp ? h->logamp : nullptr);
         FA.logamp_sigma = std::sqrt(S.logamp_var); FA.rng_f64 = h->rng_f64; FA.key = key; FA.g0 = (uint64_t)(S.real0 + fin_start);
-        FA.dx2 = h->dx * h->dx; FA.norm = h->wsum * (h->dx * h->dx); FA.out = h->out;
+        FA.dx2 = h->dx * h->dx; FA.norm = h->wsum * (h->dx * h->dx); FA.out = S.out_dev ? S.out_dev : h->out;
         guard_outputs(h);
         hipLaunchKernelGGL(k_finalize, dim3((FA.nb + 3) / 4), dim3(256), 0, h->stream, FA);
         fin_start = done;
@@ -2149,6 +2158,8 @@ struct NpsWork {
   size_t cap_states = 0;
   double* la = nullptr;      // log-amplitude normals of the run (device)
   size_t la_cap = 0;
+  double* res = nullptr;     // results of all chunks of one fastmc_run_npstream call (device): copied back once
+  size_t res_cap = 0;
   // the device's ziggurat tables and jump table, looked up ONCE per call under g_nps_mu (nps_prepare): the launches below never
   // touch the map, which fastmc_npstream_set_tables of another thread / device may be inserting into
   NpsTables* tab = nullptr;
@@ -2160,7 +2171,7 @@ static void nps_free(NpsWork* w) {
     for (void* p : {(void*)b.events, (void*)b.evcount, (void*)b.maps, (void*)b.tile_e, (void*)b.tile_base, (void*)b.tile_state}) if (p) hipFree(p);
   for (NpsOneBuf& b : w->one)
     for (void* p : {(void*)b.out, (void*)b.xexit, (void*)b.agg, (void*)b.tile_state, (void*)b.ticket}) if (p) hipFree(p);
-  for (void* p : {(void*)w->states, (void*)w->consumed, (void*)w->overflow, (void*)w->la}) if (p) hipFree(p);
+  for (void* p : {(void*)w->states, (void*)w->consumed, (void*)w->overflow, (void*)w->la, (void*)w->res}) if (p) hipFree(p);
   for (int i = 0; i < 2; ++i) { if (w->ev_gen[i]) hipEventDestroy(w->ev_gen[i]); if (w->ev_used[i]) hipEventDestroy(w->ev_used[i]); }
   if (w->gstream) hipStreamDestroy(w->gstream);
   delete w;
@@ -2433,11 +2444,25 @@ extern "C" int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int
   double* pinned = nullptr;
   HIPCHK(hipHostMalloc((void**)&pinned, per_chunk * n_chunks * 8, hipHostMallocDefault));
   struct Free { double* p; ~Free() { if (p) hipHostFree(p); } } guard{pinned};
+  if (w->res_cap < per_chunk * (size_t)n_chunks) {
+    if (w->res) HIPCHK(hipFree(w->res));
+    w->res = nullptr; w->res_cap = 0;
+    HIPCHK(hipMalloc((void**)&w->res, per_chunk * n_chunks * 8));
+    w->res_cap = per_chunk * (size_t)n_chunks;
+  }
   // Two streams: the generator chain of chunk c + 1 (tile states, classify, scan: sequential in the stream's state, latency-bound)
   // runs beside the emit + Monte-Carlo kernels of chunk c (HBM-bound); the segment buffers alternate between two sets.
   // (FASTMC_NPS_TWO_STREAMS=1: the generator of chunk c + 1 on a stream of its own beside the Monte-Carlo kernels of chunk c.
-  //  Both fill the device on their own, so nothing overlaps and the cross-stream events only add launch gaps: one stream.)
+  //  Nothing overlaps -- round 6 ran the two streams FREE of each other (no events: timing only) and a chunk still took the SUM of
+  //  the two, also with the rows as light four-wave workgroups that would fit a CU beside three of the generator's: the generator's
+  //  26 000 small workgroups refill every slot the moment it frees, so a row workgroup finds room only when the generator's queue
+  //  is empty.  The cross-stream events only add launch gaps: one stream.  profiles/r06_ab_same_seed_mode.txt)
   static const bool two = [] { const char* e = getenv("FASTMC_NPS_TWO_STREAMS"); return e && *e == '1'; }();
+  // The chunks' MODE 1 rows (50 realisations each: HBM-bound coefficient reads) as FOUR-wave workgroups (WCfg D = 9): 197-202 us per
+  // chunk against 247 for the sixteen-wave form, same-seed mode +3.3 % (profiles/r06_ab_same_seed_mode.txt); FASTMC_NPS_LIGHT_ROWS=0: A/B
+  static const bool light = [] { const char* e = getenv("FASTMC_NPS_LIGHT_ROWS"); return !(e && *e == '0'); }();
+  h->light_rows = light;
+  struct Unlight { fastmc_ctx* h; ~Unlight() { h->light_rows = false; } } unlight{h};
   if (two && !w->gstream) {
     HIPCHK(hipStreamCreateWithFlags(&w->gstream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
@@ -2470,6 +2495,8 @@ extern "C" int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int
     if (two) HIPCHK(hipEventRecord(w->ev_gen[set], gs));
     return 0;
   };
+  static const bool times = getenv("FASTMC_NPS_TIMES") != nullptr;     // stderr: how long the host took to ENQUEUE the chunks, and the whole call
+  const auto t_enq0 = std::chrono::steady_clock::now();
   TRY(gen_chunk(0));
   for (int64_t c = 0; c < n_chunks; ++c) {
     const int set = (int)(c & 1);
@@ -2491,16 +2518,24 @@ extern "C" int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int
       return 0;
     };
     h->pending = false;          // no wait between chunks: only the last chunk's kernel times are read (after the one sync below)
+    S.out_dev = w->res + per_chunk * c;      // every chunk's results stay on the device until the one copy below (round 6: one launch gap less per chunk)
     TRY(run_impl<double>(h, S));
     if (two) HIPCHK(hipEventRecord(w->ev_used[set], h->stream));
-    HIPCHK(hipMemcpyAsync(pinned + per_chunk * c, h->out, per_chunk * 8, hipMemcpyDeviceToHost, h->stream));
   }
+  HIPCHK(hipMemcpyAsync(pinned, w->res, per_chunk * n_chunks * 8, hipMemcpyDeviceToHost, h->stream));
+  const auto t_enq1 = std::chrono::steady_clock::now();
   if (two) HIPCHK(hipStreamSynchronize(w->gstream));
   std::vector<uint32_t> ovf((size_t)n_chunks * segs);
   std::vector<u128> states((size_t)n_chunks * segs + 1);
   HIPCHK(hipMemcpyAsync(ovf.data(), w->overflow, ovf.size() * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(states.data(), w->states, states.size() * sizeof(u128), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (times) {
+    const auto t_end = std::chrono::steady_clock::now();
+    fprintf(stderr, "fastmc_run_npstream: %lld chunks enqueued in %.3f ms (%.1f us per chunk), call %.3f ms (%.1f us per chunk)\n", (long long)n_chunks,
+            std::chrono::duration<double, std::milli>(t_enq1 - t_enq0).count(), std::chrono::duration<double, std::micro>(t_enq1 - t_enq0).count() / n_chunks,
+            std::chrono::duration<double, std::milli>(t_end - t_enq0).count(), std::chrono::duration<double, std::micro>(t_end - t_enq0).count() / n_chunks);
+  }
   finish_pending(h);
   HIPCHK(hipGetLastError());
   {   // FASTMC_NPS_TEST_OVERFLOW=k (tests): the first call of the process with more than k chunks reports chunk k as given up

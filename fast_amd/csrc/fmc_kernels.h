@@ -407,13 +407,15 @@ template <class R, int P, int NS> struct WaveCfg {
 //   5  six planes in the twelve-wave kernels (split columns of 2048 / 4096, host coefficients / screens of the split rows);
 //   6  eight planes, twelve waves (97-128 pixels on the split grids, or where the dense tables do not fit);
 //   7  all sixteen planes, twelve waves: any other window (NS = 2, 4, 8) -- the 4-term sums alone pay for the larger butterfly.
+//   9  (rows, MODE 1 only) the row of 4 in FOUR-wave workgroups (59 KB of LDS): the HBM-bound coefficient rows of the same-seed mode
+//      as a light workgroup that fits a CU BESIDE three workgroups of the numpy-stream generator (fastmc_run_npstream on two streams)
 template <class R, int P, int NS, int D> struct WCfg {
   static constexpr int OM_ROWS = (D >= 4) ? 4 : 8;     // stage-2b table rows in the LDS: the 16 x 4 row reads rows 1 ... 3
-  static constexpr bool DENSE = (D == 4 || D == 8);
-  static_assert(D == 0 || (D == 3 && NS == 2 && P > 16) || (P == 16 && NS == 2 && D >= 4 && D <= 8) || (D == 7 && P == 16),
+  static constexpr bool DENSE = (D == 4 || D == 8 || D == 9);
+  static_assert(D == 0 || (D == 3 && NS == 2 && P > 16) || (P == 16 && NS == 2 && D >= 4 && D <= 9) || (D == 7 && P == 16),
                 "pruned planes for NS = 2; the 16 x 4 row for P = 16");
   static_assert(WaveGeom<R, 16>::XELEMS >= D16_XELEMS, "the 16 x 4 row (D = 5) runs in the twelve-wave exchange buffer");
-  static constexpr int WPB = DENSE ? 16 : WaveCfg<R, P, NS>::WPB_ROWS;
+  static constexpr int WPB = D == 9 ? 4 : (DENSE ? 16 : WaveCfg<R, P, NS>::WPB_ROWS);
   // the column kernel: sixteen waves as the rows (A/B at 1024^2: two six-wave workgroups per CU -1 %, one of eight +18 %)
   static constexpr int WPB_COLS = DENSE ? 16 : WaveCfg<R, P, NS>::WPB;
   static constexpr int XELEMS = DENSE ? D16_XELEMS : WaveGeom<R, P>::XELEMS;

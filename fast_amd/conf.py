@@ -43,8 +43,10 @@ GPU_DEFAULTS = {
     'GPU_KERNELS': 'auto',    # kernel family: 'auto' (wave FFT where NPXLS = 64 P, 50-lane FFT where NPXLS = 50 P S, chirp-z for
                               # other sizes, direct for tiny grids / huge windows) | 'wave' | 'lanes50' | 'chirpz' | 'direct'
                               # (O(N^2 Np) cross-check)
-    'GPU_ROUND_NPXLS': 'auto', # with NPXLS 'auto': round the auto-sized grid up to the next fast-kernel size: True | False |
-                               # 'auto' = when nothing ties the run to the reference's exact grid (GPU_RNG 'device', not TEMPORAL)
+    'GPU_ROUND_NPXLS': False, # with NPXLS 'auto': False (default since round 6) = the reference's own auto-sized grid (fast/fast.py:167-189:
+                               # 164 for the shipped example -- a drop-in keeps the user's grid; the chirp-z kernels serve any size);
+                               # True = round it up to the next fast-kernel size (opt-in, logged); 'auto' = round when nothing ties the
+                               # run to the reference's exact grid (GPU_RNG 'device', not TEMPORAL: the default of rounds 3-5)
     'GPU_SHARD': 'auto',      # shard iterations over the ranks of a multi-process launch (RANK / WORLD_SIZE in the
                               # environment; fast_amd/rendezvous.py): 'auto' | True | False
 }

@@ -183,6 +183,7 @@ struct fastmc_ctx {
   // (fastmc_comm_abort takes no lock) never run on the handle together, and neither can wait for ever
   std::timed_mutex use_mu;
   unsigned long long* clk = nullptr;   // device: clock stamps of the last k_rows_wave launch (fastmc_last_clock)
+  bool clk_fresh = false;  // the LAST row launch of this handle was a stamping one (k_rows_wave): stamps of an earlier launch are never reported
   int comm_slot = -1;      // slot of the communicator tables; -1: the device's (the only form outside the fake-RCCL tests, cslot())
   char last_rows[96] = "", last_cols[96] = "";   // the row / column kernels of the last launch, as c++filt prints them (fastmc_last_kernels)
   bool pending = false;
@@ -635,7 +636,7 @@ extern "C" int fastmc_last_clock(fastmc_t* h, double* ghz, double* span_us) {
   if (!h || !ghz || !span_us) return fail(FASTMC_EINVAL, "null handle / outputs");
   FMC_LOCK(h);
   HIPCHK(hipSetDevice(h->device));
-  if (!h->clk) return fail(FASTMC_ESTATE, "no row kernel has stamped the clock on this handle yet");
+  if (!h->clk || !h->clk_fresh) return fail(FASTMC_ESTATE, "the last row kernel of this handle did not stamp the clock (only k_rows_wave does)");
   unsigned long long c[4] = {0, 0, 0, 0};
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy(c, h->clk, sizeof(c), hipMemcpyDeviceToHost));
@@ -1093,6 +1094,7 @@ static void launch_rows_wave(fastmc_ctx* h, const RowArgs<R>& A) {
   }
   hipLaunchKernelGGL((k_rows_wave<R, P, NS, MODE, S, D>), dim3(blocks), dim3(WPB * 64), lds, h->stream, B);
   FMC_NOTE(h->last_rows, "k_rows_wave<%s, %d, %d, %d, %d, %d>", rname<R>(), P, NS, MODE, S, D);
+  h->clk_fresh = B.clk != nullptr;
 }
 template <class R, int P, int NS, int EPI, int S = 1, int D = 0>
 static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
@@ -1842,6 +1844,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     RA.cim = devcoef ? S.coef_dev_im + (size_t)bs * N2 : h->cim;
     RA.g64 = h->g64;
     RA.clk = h->clk;
+    h->clk_fresh = false;        // set again by the launch that stamps (launch_rows_wave): another family's row never reports old stamps
     ColArgs<R> CA;
     CA.N = N; CA.Np = Np; CA.lo = h->lo; CA.nb = nb;
     CA.V = (const cpx<R>*)h->V; CA.om = RA.om; CA.omS = h->omS;
@@ -3066,10 +3069,14 @@ static std::timed_mutex g_enq_mu[64];
 // their handles carry a slot of their own (32 + rank) so that the group / stream / ordering code below runs with a world of up
 // to 8 where RCCL itself cannot.  Never set with the real library.
 static int cslot(const fastmc_ctx* h) { return h->comm_slot >= 0 ? h->comm_slot : (h->device & 63); }
+// ... and only when the library that was loaded IS the tests' stand-in: it exports `fake_rccl_marker`; a real RCCL named by
+// FASTMC_RCCL_LIB (a build off the loader's path) never takes several ranks on one device whatever the environment says
 static bool virtual_ranks_allowed() {
   const char* a = getenv("FASTMC_RCCL_LIB");
   const char* b = getenv("FASTMC_TEST_VIRTUAL_RANKS");
-  return a && a[0] && b && b[0] && b[0] != '0';
+  if (!(a && a[0] && b && b[0] && b[0] != '0')) return false;
+  if (load_rccl() != 0) return false;
+  return dlsym(g_rccl.lib, "fake_rccl_marker") != nullptr;
 }
 
 // FASTMC_TEST_STALL_GATHER=1: the exchange entry points block, without touching RCCL, until fastmc_comm_abort is called for
@@ -3158,8 +3165,16 @@ extern "C" int fastmc_comm_init_all(fastmc_t* const* handles, int n) {
     // then get slots of their own in the communicator tables (see cslot)
     if (!virtual_ranks_allowed() || n > 32)
       return fail(FASTMC_ECOMM, "two handles on one device: RCCL needs one device per rank (use the host exchange)");
-    for (int i = 0; i < n; ++i) handles[i]->comm_slot = 32 + i;
   }
+  // The private slots of the virtual ranks hold for this call and are KEPT only when the clique is up: on every failure below the
+  // handles go back to their device's slot (a handle left on slot 32 + i addressed the wrong communicator afterwards)
+  std::vector<int> old_slot(n);
+  for (int i = 0; i < n; ++i) old_slot[i] = handles[i]->comm_slot;
+  struct Rollback {
+    fastmc_t* const* hs; const std::vector<int>& old; int n; bool keep = false;
+    ~Rollback() { if (!keep) for (int i = 0; i < n; ++i) hs[i]->comm_slot = old[i]; }
+  } rollback{handles, old_slot, n};
+  if (shared) for (int i = 0; i < n; ++i) handles[i]->comm_slot = 32 + i;
   for (int i = 0; i < n; ++i)
     if (device_comm(cslot(handles[i])).comm) return fail(FASTMC_ESTATE, "a device already has a communicator (fastmc_comm_destroy first)");
   TRY(load_rccl());
@@ -3174,6 +3189,7 @@ extern "C" int fastmc_comm_init_all(fastmc_t* const* handles, int n) {
     }
   std::lock_guard<std::mutex> g(g_comm_mu);
   for (int i = 0; i < n; ++i) g_comm[cslot(handles[i])] = DeviceComm{comms[i], n, i};
+  rollback.keep = true;
   return 0;
 }
 #endif

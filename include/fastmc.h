@@ -271,11 +271,14 @@ int fastmc_run_npstream(fastmc_t* h, const uint64_t state_inc[4], int64_t n_chun
  * ran (fast_amd/kernel_isa_stats.json is keyed by these names).  rows / cols: caller's buffers of `cap` bytes each. */
 int fastmc_last_kernels(fastmc_t* h, char* rows, char* cols, int cap);
 
-/* Effective shader clock of the handle's last row-kernel launch (wave family): inside one workgroup in the middle of the launch the
- * kernel reads the shader-clock counter and the constant-rate counter before and after its rows; *ghz = shader ticks per second
- * in GHz, *span_us = the time between the two readings.  bench.py reports it as `clock.effective_GHz`, so that a row time can be
- * told apart from a box's clock (MI355X throttles under sustained float64 work: ~2.0-2.15 GHz against the nominal 2.4).  Blocks
- * until the handle's stream is idle; FASTMC_ESTATE when no launch has stamped yet.  No counterpart in the reference. */
+/* Effective shader clock of the handle's last row-kernel launch (wave family, k_rows_wave): the first lane of the launch's middle
+ * workgroup reads the shader-clock counter and the constant-rate counter before and after its rows; *ghz = shader ticks per second
+ * in GHz, *span_us = the time between the two readings -- that workgroup's life: the whole launch when the launch's workgroups stay
+ * and walk its tiles (large launches: milliseconds), one tile otherwise (tens of microseconds).  bench.py reports it as
+ * `clock.effective_GHz`, so that a row time can be told apart from a box's clock (MI355X throttles under sustained float64 work:
+ * 2.0-2.3 GHz against the nominal 2.4).  Blocks until the handle's stream is idle.  FASTMC_ESTATE when the handle's LAST row launch
+ * was not a stamping one (another kernel family, or none yet): stamps of an earlier launch are never reported.  No counterpart in the
+ * reference. */
 int fastmc_last_clock(fastmc_t* h, double* ghz, double* span_us);
 
 /* Shape of the result vector resident on the device -- what fastmc_wait copies out: *n_iter iterations (0: no results yet),

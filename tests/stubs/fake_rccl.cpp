@@ -149,6 +149,8 @@ ncclResult_t enqueue(FakeComm* comm, const Call& c) {
 }  // namespace
 
 extern "C" {
+// what tells libfastmc that this is the tests' stand-in, not an RCCL build: only then may several ranks share a device
+int fake_rccl_marker = 1;
 ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
   if (!id) return ncclInvalidArgument;
   static uint64_t serial = 0x0123456789abcdefULL;

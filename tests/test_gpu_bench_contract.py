@@ -59,6 +59,14 @@ def test_bench_json_line_contract():
     assert 1.5 < c["effective_GHz"] <= 2.45 and c["nominal_GHz"] == 2.4 and c["stamp_span_us"] > 5
     assert abs(r["frac_at_effective_clock"] - r["frac"] * 2.4 / c["effective_GHz"]) < 1e-12 and r["frac_at_effective_clock"] <= 1.0
     assert abs(iss["measured_cycles_per_row_at_effective_clock"] - iss["measured_cycles_per_row_at_2.4GHz"] * c["effective_GHz"] / 2.4) < 1e-6
+    # the launch plan: every row-kernel launch of the run as calls of n realisations, so that a profile's per-dispatch
+    # times can be read against the realisations each dispatch held; pipeline.rows_ms comes from the one-call pass (nothing else in flight)
+    lp = d["launch_plan"]
+    assert lp["kernel"] == r["kernel"] and lp["batch"] > 0 and sum(lp["launches_of_one_step"]) == 5000 and lp["launches_per_step"] == len(lp["launches_of_one_step"])
+    assert [c_[0] for c_ in lp["calls"]][:2] == ["warmup", "timed"] and lp["calls"][-1] == ["one_call", 5000 * d["steps"], 1]
+    pl = d["pipeline"]
+    assert pl["kernel_ms_from"] == "one-call pass" and 0 < pl["rows_ms"] <= d["ms_per_step"] and pl["rows_ms"] + pl["cols_ms"] + pl["finalize_ms"] <= 1.02 * d["ms_per_step"]
+    assert abs(pl["rows_ms"] - r["avg_launch_ms"] * r["iterations_per_launch"] ** -1 * 10000) < 0.05 * pl["rows_ms"]      # the same pass, per step
     # the opt-in float32 draw (GPU_RNG_PRECISION 'f32'): its own value and roofline, faster, and NOT the headline
     g = d["f32_draw"]
     assert d["value_f32_draw"] > d["value"] and g["dtype"] == "f64 (f32 draw)" and 1.0 < g["ratio_to_value"] < 3.0

@@ -29,13 +29,13 @@ def shipped_example(**over):
 
 
 # (one-key changes of the reference's smoke script, as data) -> the grid this repo must end up on.  The shipped example auto-sizes
-# to 164 (fast/fast.py:167-189); TEMPORAL keeps the reference's grid (its draws are numpy's), a Monte-Carlo run with the device
-# generator rounds it up to the next fast-kernel size (GPU_ROUND_NPXLS 'auto'), host draws keep 164 again.
+# to 164 (fast/fast.py:167-189) and so does this repo by default (GPU_ROUND_NPXLS False since round 6: a drop-in keeps the reference's
+# grid; chirp-z kernels); GPU_ROUND_NPXLS 'auto' / True round a device-generator Monte-Carlo run up to the next fast-kernel size.
 VARIANTS = [
-    (dict(FFTW=True), 164), (dict(TEMPORAL=False), 256), (dict(SUBHARM=True, TEMPORAL=False), 256), (dict(OBSC_GROUND=0.1), 164),
+    (dict(FFTW=True), 164), (dict(TEMPORAL=False), 164), (dict(TEMPORAL=False, GPU_ROUND_NPXLS="auto"), 256), (dict(SUBHARM=True, TEMPORAL=False), 164), (dict(OBSC_GROUND=0.1), 164),
     (dict(OBSC_SAT=0.05), 164), (dict(W0=0.1, AXICON=True, OBSC_GROUND=0.1), 164), (dict(L0=25), None), (dict(PROP_DIR="down"), 164),
     (dict(AO_MODE="NOAO"), None), (dict(AO_MODE="TT"), 164), (dict(NOISE=1), 164), (dict(MODAL=True), 164),
-    (dict(TEMPORAL=False, GPU_PRECISION="f32"), 256), (dict(TEMPORAL=False, GPU_RNG="host"), 164), (dict(TEMPORAL=False, NPXLS=256), 256),
+    (dict(TEMPORAL=False, GPU_PRECISION="f32"), 164), (dict(TEMPORAL=False, GPU_PRECISION="f32", GPU_ROUND_NPXLS=True), 256), (dict(TEMPORAL=False, GPU_RNG="host"), 164), (dict(TEMPORAL=False, NPXLS=256), 256),
 ]
 
 
@@ -135,7 +135,7 @@ def test_save_and_load_round_trip(tmp_path):
     back = fast.load(f)
     np.testing.assert_array_equal(back.power, sim.result.power)
     np.testing.assert_allclose(back.dB_rel, sim.result.dB_rel, rtol=1e-12)
-    assert back.hdr["NPXLS"] == 256 and back.hdr["AO_MODE"] == "AO" and back.hdr["SEED"] == 4     # auto 164, rounded up (GPU_ROUND_NPXLS 'auto')
+    assert back.hdr["NPXLS"] == 164 and back.hdr["AO_MODE"] == "AO" and back.hdr["SEED"] == 4     # the reference's auto-sized grid (GPU_ROUND_NPXLS False)
 
 
 def test_error_rate_integrals_on_resident_results_equal_the_host_reductions():

@@ -92,6 +92,26 @@ def test_zenith_scan_sweep():
     assert half[0]["mean_dB_rel"] == recs[1]["mean_dB_rel"]
 
 
+def test_last_clock_never_reports_the_stamps_of_an_earlier_launch():
+    """only k_rows_wave stamps the clock.  After another kernel family ran last on the handle, fastmc_last_clock says so
+    (None here) instead of handing out the previous launch's stamps; the next stamping launch brings it back."""
+    from fast_amd import _lib
+    h = _lib.Handle(1024, 82, "f64", 0)
+    h.set_spectrum(np.ones((1024, 1024)) * 1e-4, 0.5)
+    h.set_pupil(np.ones((82, 82)), (1024 - 82) // 2, 0.01)
+    assert h.last_clock() is None
+    h.run(1, 0, 64, None, 0.01)
+    ghz, span = h.last_clock()
+    assert 1.2 < ghz < 2.5 and span > 1
+    h.kernel_path(0)                      # the direct family: no stamps
+    h.run(1, 0, 2, None, 0.01)
+    assert h.last_kernels()[0].startswith("k_rows_direct") and h.last_clock() is None
+    h.kernel_path(1)
+    h.run(1, 0, 64, None, 0.01)
+    assert h.last_clock() is not None
+    h.close()
+
+
 def test_zenith_scan_dealt_over_devices_equals_the_single_device_scan():
     """`sweep.zenith_scan(devices=[...])` deals a process's samples to one thread per device (bench.py --gpus N
     without a launcher: BASELINE configs[4] is 4 configs per GPU on 8 GPUs).  With GPU_DEVICES=[0, 0, 0, 0] on the one GPU of a

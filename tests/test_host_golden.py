@@ -141,11 +141,12 @@ def test_fits_round_trip(tmp_path):
 def test_optional_rounding_of_auto_grid_size():
     g = load_golden("e2e_default164")
     p = fast_amd.conf.ConfigParser(dict(params_from_json(g["params_json"]))).config
+    assert fast_amd.conf.GPU_DEFAULTS["GPU_ROUND_NPXLS"] is False and host.build_problem(dict(p)).N == 164      # default (round 6): the reference's grid
     p["GPU_ROUND_NPXLS"] = False
     assert host.build_problem(dict(p)).N == 164                      # the reference's auto rule
     p["GPU_ROUND_NPXLS"] = True
     assert host.build_problem(dict(p)).N == 256                      # four rows per wavefront: faster than 192 .. 250
-    p["GPU_ROUND_NPXLS"] = "auto"                                    # default: round unless the grid is tied to the reference's
+    p["GPU_ROUND_NPXLS"] = "auto"                                    # (the default of rounds 3-5) round unless the grid is tied to the reference's
     for rng_mode, temporal, n in (("device", False, 256), ("host", False, 164), ("device", True, None)):
         q = dict(p, GPU_RNG=rng_mode, TEMPORAL=temporal)
         if n is not None:

@@ -1252,7 +1252,7 @@ static void launch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
   FMC_NOTE(h->last_rows, "k_rows_pks<%s, %d, %d, %d>", rname<R>(), L0, S, MODE);
 }
 template <class R>
-int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode, int) {
+int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode) {
   Span s(h, 0);
   const int S = pks_split(h->N), L0 = pks_L0(h->N);
   RowArgs<R> RA = RA_in;      // the family's own tables; the colouring tables with the input-side fftshift sign folded in
@@ -1544,7 +1544,7 @@ int dispatch_direct(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA
 
 // ------------------------------------------------------------------ translation units (see the top of the file)
 #define FMC_FAMILY_SIG(R) fastmc_ctx*, const RowArgs<R>&, const ColArgs<R>&, int, int
-#define FMC_PKS_SIG(R) fastmc_ctx*, const RowArgs<R>&, int, int
+#define FMC_PKS_SIG(R) fastmc_ctx*, const RowArgs<R>&, int
 #define FMC_WAVE_SIG(R) fastmc_ctx*, RowArgs<R>&, ColArgs<R>&, int, int, bool
 // unit -> what it instantiates.  The float32 pipeline exists for the wave and direct families; chirp-z, 50-lane and
 // run-time-split grids run the float64 kernels whatever precision was asked for (fastmc_create).
@@ -1885,8 +1885,12 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     // packed sub-rows (640 ... 1792, fmc_core.h: pks_split): the device generator's rows, then the column pass of the one-row-per-wave family
     const bool pks = kmode != 1 && pks_variant<R>(h) >= 0;
     bool wave_ok = h->path == 1 && !(pk_grid(h->N) && kmode == 0) && !(pks_grid(h->N) && kmode == 0 && !pks);    // packed grids beyond the packed windows: see pk_variant, pks_variant
-    if (pks) TRY(dispatch_pks_rows<R>(h, RA, kmode, 0));
+    if (pks) TRY(dispatch_pks_rows<R>(h, RA, kmode));
     const int wmode = pks ? -1 : kmode;
+    // the one-row-per-wave kernels of the N / 16-stream grids exist for host coefficients only (launch_wave_pair): a device draw must
+    // never reach them (it would transform whatever `cre` / `cim` hold)
+    if (wave_ok && (pk_grid(h->N) || pks_grid(h->N)) && wmode != 1 && wmode != -1)
+      return fail(FASTMC_ESTATE, "internal: device draws routed to a host-coefficient row kernel");
     bool general_2048 = false;   // N = 2048, window > 256 pixels, host coefficients: single-pass P = 32 kernels
     if (wave_ok) {
       int ns, wpb_unused;

@@ -443,6 +443,26 @@ def test_fused_float64_generator_rows_match_the_oracle_on_restated_draws(N, Np, 
     np.testing.assert_allclose(h.run(seed, real0, n, None, 0.01), got, rtol=1e-10)
 
 
+@pytest.mark.parametrize("N,Np,kernel", [(1280, 82, "k_rows_pks<double, 1, 5, 2>"), (896, 60, "k_rows_pks<double, 0, 7, 2>"), (1536, 96, "k_rows_pks<double, 1, 6, 2>")])
+def test_device_generator_screens_on_the_packed_subrow_grids(N, Np, kernel):
+    """`fastmc_screens` (EPI 1: the cropped screens themselves) on the grids of the packed sub-rows: the rows are k_rows_pks, the column
+    pass the one-row-per-wave kernel launched alone (dispatch mode -1).  Against the oracle's transform of the restated float64 draws,
+    and against the direct family on the same seed."""
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    ps = ps * 0.02
+    lo = (N - Np) // 2
+    h = f32_draw_handle(N, Np, "f64", 0)
+    h.set_spectrum(ps, df)
+    h.set_pupil(_window_W(Np), lo, 0.01)
+    h.set_rng_precision("f64")
+    scr = h.screens(5, 11, 1)
+    assert h.last_kernels()[0] == kernel
+    z = R.screens_fftw(devrng.device_coefficients_f64(5, 11, N) * (np.sqrt(ps) * df), 1.0)[lo:lo + Np, lo:lo + Np]
+    assert np.abs(scr[0] - z.real).max() < 1e-11 * np.abs(z).max() and np.abs(scr[1] - z.imag).max() < 1e-11 * np.abs(z).max()
+    h.kernel_path(0)
+    np.testing.assert_allclose(h.screens(5, 11, 1), scr, rtol=0, atol=1e-11 * np.abs(z).max())
+
+
 def test_fast_object_with_the_float64_generator():
     """The DEFAULT of `Fast(config).run()` on a float64 handle is the generator at the reference's precision (GPU_RNG_PRECISION
     'auto' = 'f64'); the opt-in float32 draw of the same seed has the same distribution (the same normals to

@@ -1190,24 +1190,25 @@ static void launch_pk_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>
   using C = PkCfg<R, L0, D>;
   const size_t lds = pk_lds_bytes<R, L0>(RA.omS, C::WPB) + (mode == 2 ? GEN64_TABLE_BYTES : 0), ldc = pk_lds_bytes<R, L0>(RA.omS, C::WPC);
   constexpr int LR = 128 / (int)sizeof(cpx<R>), LU = LR / C::G, BPG = ROWS_PER_WAVE * C::WPB / LU;
-  const int blocks = (C::N / LR) * ((RA.nb + BPG - 1) / BPG);
+  const int tiles_all = (C::N / LR) * ((RA.nb + BPG - 1) / BPG);
+  static const int persist = getenv("FASTMC_ROWS_PERSIST") ? atoi(getenv("FASTMC_ROWS_PERSIST")) : 1;
+  auto rows = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    hipFuncSetAttribute((const void*)k_rows_pk<R, L0, MODE, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    RowArgs<R> B = RA;
+    int blocks = tiles_all;
+    if (persist) {        // as launch_rows_wave: a launch of many rounds keeps its workgroups, which walk its tiles (round 6)
+      const int resident = resident_workgroups(h, (const void*)k_rows_pk<R, L0, MODE, D>, C::WPB * 64, lds);
+      if (blocks >= 8 * resident) { B.tiles = blocks; blocks = resident; }
+    }
+    hipLaunchKernelGGL((k_rows_pk<R, L0, MODE, D>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, B);
+    FMC_NOTE(h->last_rows, "k_rows_pk<%s, %d, %d, %d>", rname<R>(), L0, MODE, D);
+  };
   {
     Span s(h, 0);
-    if (mode == 0) {
-      hipFuncSetAttribute((const void*)k_rows_pk<R, L0, 0, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_pk<R, L0, 0, D>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, RA);
-      FMC_NOTE(h->last_rows, "k_rows_pk<%s, %d, %d, %d>", rname<R>(), L0, 0, D);
-    } else if (mode == 2) {
-      if constexpr (sizeof(R) == 8) {
-        hipFuncSetAttribute((const void*)k_rows_pk<R, L0, 2, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_rows_pk<R, L0, 2, D>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, RA);
-        FMC_NOTE(h->last_rows, "k_rows_pk<%s, %d, %d, %d>", rname<R>(), L0, 2, D);
-      }
-    } else {
-      hipFuncSetAttribute((const void*)k_rows_pk<R, L0, 1, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_rows_pk<R, L0, 1, D>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, RA);
-      FMC_NOTE(h->last_rows, "k_rows_pk<%s, %d, %d, %d>", rname<R>(), L0, 1, D);
-    }
+    if (mode == 0) rows(std::integral_constant<int, 0>());
+    else if (mode == 2) { if constexpr (sizeof(R) == 8) rows(std::integral_constant<int, 2>()); }
+    else rows(std::integral_constant<int, 1>());
   }
   {
     Span s(h, 1);

@@ -795,10 +795,15 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPB * 64)) void k_rows_pk(RowArgs
   static_assert(LR % G == 0 && (ROWS_PER_WAVE * WPB) % LU == 0, "tile must hold whole lines");
   constexpr int BPG = ROWS_PER_WAVE * WPB / LU;
   const int nbb = (A.nb + BPG - 1) / BPG;
-  const int b0 = (blockIdx.x % nbb) * BPG;
-  const int row0 = (blockIdx.x / nbb) * LR;
   const int q = lane & (L - 1), gl = lane / L;
   const int lane_in = gl * N + q;                        // this lane's first input of the G rows of a unit (rows are contiguous)
+  // (round 6) the workgroups of a large launch stay and walk its tiles, as k_rows_wave's do: tables staged once per CU
+  const int tiles = A.tiles ? A.tiles : (int)gridDim.x;
+#pragma unroll 1
+  for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
+  const int b0 = (vb % nbb) * BPG;
+  const int row0 = (vb / nbb) * LR;
+#pragma unroll 1
   for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
     const int flat = rr * WPB + w;
     const int b = b0 + flat / LU;
@@ -834,6 +839,8 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPB * 64)) void k_rows_pk(RowArgs
     cpx<R>* out = A.V + (size_t)b * A.Np * N + ky0;      // V[b][oi][ky]
     packed_outputs<R, L0, C::NSL, C::B0M>(lane, regs, A.lo, A.Np,
                                           [&](int oi, R re, R im) { out[(uint32_t)(oi * N + gl)] = mk<R>(re, im); });   // scalar base + 32-bit lane offset
+  }
+  if (A.tiles) __syncthreads();      // the waves of a workgroup stay within one tile of each other
   }
 }
 

@@ -421,8 +421,73 @@ static int sweep_pks(const char* name, double tol) {
   return bad;
 }
 
+// Packed sub-rows of SIXTY-FOUR points (pks64_pass): sixteen rows of N = S * 64 points per wave, S passes, against the naive DFT.
+template <class R, int S>
+static double run_pks64_case(int Np, int shift, unsigned seed) {
+  constexpr int M = 64, N = S * M, G = 16;
+  using E = typename Xch<R>::E;
+  std::mt19937_64 gen(seed);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  std::vector<double> inr(G * N), ini(G * N);
+  for (auto& v : inr) v = nd(gen);
+  for (auto& v : ini) v = nd(gen);
+  const int lo = (N - Np) / 2 + shift;
+  std::vector<cpx<R>> tw(64), pcw((size_t)S * PKS_SPAN);
+  build_tw64<R>(tw.data(), cs_turns);
+  build_pcw<R>(pcw.data(), N, S, cs_turns);
+  std::vector<E> xbuf(D16_XELEMS);
+  static HostExec<R, 16, 4> ex;
+  pks64_clear<R>(ex);
+  for (int sp = 0; sp < S; ++sp) {
+    for (int l = 0; l < WAVE; ++l)
+      for (int j = 0; j < 16; ++j) {
+        const int g = l / 4, k = sp + S * (l % 4 + 4 * j);
+        const double sg = (k & 1) ? -1.0 : 1.0;
+        ex.regs[l].v[j] = mk<R>((R)(sg * inr[g * N + k]), (R)(sg * ini[g * N + k]));
+      }
+    pks64_pass<R>(ex, xbuf.data(), tw.data(), pcw.data() + sp * PKS_SPAN);
+  }
+  std::vector<double> gr((size_t)G * Np, 1e300), gi((size_t)G * Np, 1e300);
+  for (int l = 0; l < WAVE; ++l)
+    pks64_outputs<R>(l, ex.regs[l], N, lo, Np, [&](int oi, R re, R im) { gr[(l / 4) * Np + oi] = re; gi[(l / 4) * Np + oi] = im; });
+  double worst = 0.0, scale = 0.0;
+  const int h = N / 2;
+  for (int g = 0; g < G; ++g)
+    for (int oi = 0; oi < Np; ++oi) {
+      const int p = lo + oi;
+      long double sr = 0, si = 0;
+      for (int k = 0; k < N; ++k) {
+        const long long e = (((long long)(p - h) * (k + h)) % N + N) % N;
+        const long double a = -2.0L * M_PIl * (long double)e / N;
+        const long double c = cosl(a), sn = sinl(a);
+        sr += inr[g * N + k] * c - ini[g * N + k] * sn;
+        si += inr[g * N + k] * sn + ini[g * N + k] * c;
+      }
+      worst = std::fmax(worst, std::fmax(std::fabs(gr[g * Np + oi] - (double)sr), std::fabs(gi[g * Np + oi] - (double)si)));
+      scale = std::fmax(scale, std::fmax(std::fabs((double)sr), std::fabs((double)si)));
+    }
+  return worst / scale;
+}
+template <class R, int S>
+static int sweep_pks64(const char* name, double tol) {
+  int bad = 0;
+  for (int Np : {82, 96, 23, 1, 64, 95, 40})
+    for (int shift : {0, Np < 90 ? 3 : 0, Np < 80 ? -5 : 0}) {
+      const double err = run_pks64_case<R, S>(Np, shift, 4242u + Np + shift + S);
+      const bool ok = err <= tol;
+      std::printf("%s packed sub-rows of 64 N=%d (S=%d) shift=%d Np=%d relerr=%.3e %s\n", name, S * 64, S, shift, Np, err, ok ? "ok" : "FAIL");
+      bad += !ok;
+    }
+  return bad;
+}
+
 int main() {
   int bad = 0;
+  bad += sweep_pks64<double, 9>("f64", 1e-13);
+  bad += sweep_pks64<double, 3>("f64", 1e-13);
+  bad += sweep_pks64<double, 5>("f64", 1e-13);
+  bad += sweep_pks64<double, 7>("f64", 1e-13);
+  bad += sweep_pks64<float, 9>("f32", 2e-5);
   bad += sweep_pks<double, 1, 3>("f64", 1e-13);
   bad += sweep_pks<double, 1, 5>("f64", 1e-13);
   bad += sweep_pks<double, 1, 6>("f64", 1e-13);

@@ -852,9 +852,10 @@ static int upload_wave_tables(fastmc_ctx* h) {
     TRY(upload_table<R>(&h->pk_om, omp));
   }
   if (pks_grid(h->N) && !h->pks_tw1) {          // (both tables depend on N only)
-    const int Sp = pks_split(h->N), L = pk_lanes(pks_L0(h->N));
+    const int Sp = pks_split(h->N), L = pks_L0(h->N) < 0 ? 4 : pk_lanes(pks_L0(h->N));
     std::vector<cpx<R>> tw((size_t)16 * L), pcw((size_t)Sp * PKS_SPAN);
-    build_tw1_pk<R>(tw.data(), L, cs_turns);
+    if (pks_L0(h->N) < 0) build_tw64<R>(tw.data(), cs_turns);
+    else build_tw1_pk<R>(tw.data(), L, cs_turns);
     build_pcw<R>(pcw.data(), h->N, Sp, cs_turns);
     TRY(upload_table<R>(&h->pks_tw1, tw));
     TRY(upload_table<R>(&h->pks_cw, pcw));
@@ -1252,6 +1253,22 @@ static void launch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
   hipLaunchKernelGGL((k_rows_pks<R, L0, S, MODE>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, B);
   FMC_NOTE(h->last_rows, "k_rows_pks<%s, %d, %d, %d>", rname<R>(), L0, S, MODE);
 }
+template <class R, int S, int MODE>
+static void launch_pks64_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
+  using C = Pks64Cfg<R, S>;
+  const size_t lds = pks64_lds_bytes<R, S>() + (MODE == 2 ? GEN64_TABLE_BYTES : 0);
+  constexpr int BPG = ROWS_PER_WAVE * C::WPB;
+  int blocks = (C::N / C::G) * ((RA.nb + BPG - 1) / BPG);
+  RowArgs<R> B = RA;
+  hipFuncSetAttribute((const void*)k_rows_pks64<R, S, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static const int persist = getenv("FASTMC_ROWS_PERSIST") ? atoi(getenv("FASTMC_ROWS_PERSIST")) : 1;
+  if (persist) {
+    const int resident = resident_workgroups(h, (const void*)k_rows_pks64<R, S, MODE>, C::WPB * 64, lds);
+    if (blocks >= 8 * resident) { B.tiles = blocks; blocks = resident; }
+  }
+  hipLaunchKernelGGL((k_rows_pks64<R, S, MODE>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, B);
+  FMC_NOTE(h->last_rows, "k_rows_pks64<%s, %d, %d>", rname<R>(), S, MODE);
+}
 template <class R>
 int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode) {
   Span s(h, 0);
@@ -1265,6 +1282,13 @@ int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode) {
   }
   FMC_PKS(1, 3) FMC_PKS(1, 5) FMC_PKS(1, 6) FMC_PKS(1, 7) FMC_PKS(0, 5) FMC_PKS(0, 7) FMC_PKS(0, 9)
 #undef FMC_PKS
+#define FMC_PKS64(SS)                                                                                  \
+  if (L0 < 0 && S == SS) {                                                                             \
+    if (mode == 0) { launch_pks64_rows<R, SS, 0>(h, RA); return 0; }                                   \
+    if constexpr (sizeof(R) == 8) { if (mode == 2) { launch_pks64_rows<R, SS, 2>(h, RA); return 0; } } \
+  }
+  FMC_PKS64(3) FMC_PKS64(5) FMC_PKS64(7) FMC_PKS64(9)
+#undef FMC_PKS64
   return fail(FASTMC_ESTATE, "no packed sub-row kernel for this grid / mode");
 }
 

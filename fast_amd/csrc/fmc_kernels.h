@@ -1041,6 +1041,83 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
   }
 }
 
+// Sub-rows of SIXTY-FOUR points (192, 320, 448, 576; fmc_wavefft.h: pks64_pass): SIXTEEN rows per wavefront, four lanes per sub-row, 24
+// accumulators per lane (every output of a sub-transform is needed, a third of them for two window positions).  A unit's sixteen rows
+// are two whole 128-byte lines of every V column; a workgroup owns them for ROWS_PER_WAVE * WPB consecutive realisations.
+#ifndef FMC_PKS64_WPB
+#define FMC_PKS64_WPB 8
+#endif
+template <class R, int S> struct Pks64Cfg {
+  static constexpr int M = 64, N = S * M, G = 16;
+  static constexpr int WPB = sizeof(R) == 8 ? FMC_PKS64_WPB : 12;
+};
+template <class R, int S>
+__host__ __device__ constexpr size_t pks64_lds_bytes() {
+  return (size_t)(64 + S * PKS_SPAN) * sizeof(cpx<R>) + (size_t)Pks64Cfg<R, S>::WPB * D16_XELEMS * 8;
+}
+template <class R, int S, int MODE>
+__global__ __launch_bounds__((Pks64Cfg<R, S>::WPB * 64)) void k_rows_pks64(RowArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using C = Pks64Cfg<R, S>;
+  using E = typename Xch<R>::E;
+  constexpr int N = C::N, WPB = C::WPB, G = C::G;
+  Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
+  cpx<R>* s_cw = s_tw + 64;
+  E* s_x = reinterpret_cast<E*>(s_cw + S * PKS_SPAN);
+  if constexpr (MODE == 2) { gen64_lds0_check(s_g64); load_gen64_table(s_g64, A.g64); }
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) s_tw[i] = A.tw[i];
+  for (int i = threadIdx.x; i < S * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  E* xbuf = s_x + w * D16_XELEMS;
+  LaneRegs<R, 16, 4> regs;
+  GpuExec<R, 16, 4> ex{lane, regs};
+  constexpr int BPG = ROWS_PER_WAVE * WPB;               // realisations per tile
+  const int nbb = (A.nb + BPG - 1) / BPG;
+  const int q = lane & 3, gl = lane >> 2;
+  const int lane_in = gl * N + S * q;                    // this lane's first input of sub-row 0
+  const int tiles = A.tiles ? A.tiles : (int)gridDim.x;
+#pragma unroll 1
+  for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
+  const int b0 = (vb % nbb) * BPG;
+  const int ky0 = (vb / nbb) * G;
+#pragma unroll 1
+  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+    const int b = b0 + rr * WPB + w;
+    if (b >= A.nb) break;                                // wave-uniform
+    const uint64_t g = A.g0 + (uint64_t)b;
+    pks64_clear<R>(ex);
+#pragma unroll 1
+    for (int sp = 0; sp < S; ++sp) {
+      // sub-row sp of the sixteen rows: kx = sp + S (q + 4 j), stream t = sp + S q of SL = 4 S = N / 16
+      xoshiro128p rs = row_stream(A.key, g, ky0 + gl, sp + S * q, 4 * S);
+      if (MODE == 0) {
+        const float* ampf = A.ampf + (size_t)ky0 * N + sp;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[lane_in + 4 * S * j]);
+      } else if constexpr (MODE == 2) {
+        static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
+        const R* amp = A.amp + (size_t)ky0 * N + sp;
+        double an = (double)amp[lane_in];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const double a = an;
+          if (j + 1 < 16) an = (double)amp[lane_in + 4 * S * (j + 1)];
+          ex.loadfence();
+          regs.v[j] = draw_coloured_f64(rs, a, Gen64Lds0{});
+          asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
+        }
+      }
+      pks64_pass<R>(ex, xbuf, s_tw, s_cw + sp * PKS_SPAN);
+    }
+    cpx<R>* out = A.V + (size_t)b * A.Np * N + ky0;      // V[b][oi][ky]
+    pks64_outputs<R>(lane, regs, N, A.lo, A.Np, [&](int oi, R re, R im) { out[(uint32_t)(oi * N + gl)] = mk<R>(re, im); });
+  }
+  if (A.tiles) __syncthreads();
+  }
+}
+
 // ================================================================== chirp-z family (any N with 64 P >= N + Np - 1)
 // The row / column passes of the wave family for grid sizes that are not 64 P: every 1-D transform is a chirp-z
 // (Bluestein) transform on the same pipeline (fmc_bluestein.h), window outputs only.  Same generator streams as the

@@ -166,14 +166,14 @@ def pk_grid(N):
 
 
 def pks_split(N):
-    """fmc_core.h: pks_split -- grids of the packed SUB-ROWS (round 6): N = S * 256 (S = 3, 5, 6, 7) or S * 128 (S = 5, 7, 9);
-    0 otherwise."""
-    return {768: 3, 1280: 5, 1536: 6, 1792: 7, 640: 5, 896: 7, 1152: 9}.get(N, 0)
+    """fmc_core.h: pks_split -- grids of the packed SUB-ROWS (round 6): N = S * 256 (S = 3, 5, 6, 7), S * 128 (S = 5, 7, 9) or
+    S * 64 (S = 3, 5, 7, 9); 0 otherwise."""
+    return {768: 3, 1280: 5, 1536: 6, 1792: 7, 640: 5, 896: 7, 1152: 9, 576: 9, 448: 7, 320: 5, 192: 3}.get(N, 0)
 
 
 def stream_lanes(N):
     """fmc_core.h: stream_lanes -- generator streams per row: N / 16 on the packed grids (128, 256, 512) and on the grids of
-    the packed sub-rows (640, 768, 896, 1152, 1280, 1536, 1792): sixteen draws per stream; 50 S on the 50-lane grids, else 64 * spec_split(N)."""
+    the packed sub-rows (192, 320, 448, 576, 640, 768, 896, 1152, 1280, 1536, 1792): sixteen draws per stream; 50 S on the 50-lane grids, else 64 * spec_split(N)."""
     if pk_grid(N) or pks_split(N):
         return N // 16
     return 50 * mr_split(N) if mr_supported(N) else 64 * spec_split(N)
@@ -208,7 +208,7 @@ def device_coefficients_f64(seed, g, N):
 def device_coefficients(seed, g, N):
     """(N, N) complex coefficients of realisation g (== fastmc_rng_coeffs).
 
-    SL = stream_lanes(N) streams per row (64; 128 / 256 at 2048 / 4096; 8 / 16 / 32 at 128 / 256 / 512; N / 16 at 640, 768, 896, 1152, 1280, 1536, 1792; 50 S on the 50 P S grids).  Stream (g, ky, L = kx mod SL): state = Philox4x32-7(ctr =
+    SL = stream_lanes(N) streams per row (64; 128 / 256 at 2048 / 4096; 8 / 16 / 32 at 128 / 256 / 512; N / 16 at 192, 320, 448, 576, 640, 768, 896, 1152, 1280, 1536, 1792; 50 S on the 50 P S grids).  Stream (g, ky, L = kx mod SL): state = Philox4x32-7(ctr =
     (ky*SL + L, STREAM_SCREEN, g_lo, g_hi), key = seed) (s0 := 1 if the block is all zero); coefficient
     (ky, L + SL j) = BM(s0 + s3, s1 + s2) of the xoshiro128+ state after j advances (fmc_core.h: xoshiro128p::next2,
     fmc_kernels.h: row_stream / draw_words).  The device colours these float32 normals with sqrt(powerspec) * df

@@ -266,6 +266,7 @@ _VARIANTS = [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, No
              (1152, 82, None), (1280, 82, None), (1536, 82, None), (1792, 82, None), (512, 82, None), (256, 82, None), (768, 152, None),
              (768, 82, None), (768, 96, 333), (1280, 40, None), (1792, 82, 857), (1280, 82, 100),     # packed sub-rows; (768, 152) and (1280, 82, 100): beyond them
              (640, 82, None), (896, 82, None), (896, 96, 401), (1152, 64, None), (1536, 82, 730), (640, 82, 0),
+             (576, 82, None), (576, 40, 250), (448, 82, None), (320, 96, None), (192, 82, None), (576, 82, 100),     # sub-rows of 64 points; the last: beyond them
              (1000, 82, None), (2000, 82, None), (1200, 82, None), (500, 82, None), (3072, 82, None), (1344, 82, None),
              (164, 82, None), (943, 82, None),
              # packed rows (eight / four / two rows per wavefront): six centred planes, all planes, off-centre and wide windows, the whole
@@ -279,7 +280,7 @@ _VARIANTS = [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, No
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_every_device_mode_row_variant_matches_the_oracle(N, Np, lo, prec):
     if prec == "f32" and (N > 2048 or (N, Np, lo) not in [(1024, 82, None), (1024, 128, None), (1024, 200, None), (2048, 82, None), (1000, 82, None), (512, 82, None),
-                                                         (256, 82, None), (256, 200, None), (512, 250, 7), (128, 82, None), (128, 128, None), (768, 82, None), (1792, 82, None), (896, 82, None), (1536, 82, None)]):
+                                                         (256, 82, None), (256, 200, None), (512, 250, 7), (128, 82, None), (128, 128, None), (768, 82, None), (1792, 82, None), (896, 82, None), (1536, 82, None), (576, 82, None), (320, 96, None)]):
         pytest.skip("float32 pipeline: the benchmarked shapes only")
     ps, df = _vk_spectrum(N, 0.01, 30.0)
     ps = ps * 0.02
@@ -383,9 +384,12 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (256, 82, None, "k_rows_pk<double, 1, 2, 0>"), (256, 200, None, "k_rows_pk<double, 1, 2, 1>"), (256, 82, 100, "k_rows_pk<double, 1, 2, 1>"),
             (512, 96, None, "k_rows_pk<double, 2, 2, 0>"), (512, 250, 7, "k_rows_pk<double, 2, 2, 1>"),
             # the other one-row-per-wave grids (192 ... 1792): the plain variant, windows of up to 128 / 256 pixels
-            (192, 30, None, "k_rows_wave<double, 3, 2, 2, 1, 0>"), (320, 82, 3, "k_rows_wave<double, 5, 2, 2, 1, 0>"),
-            (384, 60, None, "k_rows_wave<double, 6, 2, 2, 1, 0>"), (448, 128, None, "k_rows_wave<double, 7, 2, 2, 1, 0>"),
-            (576, 82, None, "k_rows_wave<double, 9, 2, 2, 1, 0>"), (576, 200, None, "k_rows_wave<double, 9, 4, 2, 1, 0>"),
+            # 192 / 320 / 448 / 576 (round 6): sub-rows of SIXTY-FOUR points, sixteen rows per wavefront (k_rows_pks64); windows the 96
+            # centred outputs do not hold are staged (MODE 1 rows)
+            (192, 30, None, "k_rows_pks64<double, 3, 2>"), (192, 96, None, "k_rows_pks64<double, 3, 2>"), (320, 82, 3, "k_rows_wave<double, 5, 2, 1, 1, 0>"),
+            (320, 82, None, "k_rows_pks64<double, 5, 2>"), (448, 60, 200, "k_rows_pks64<double, 7, 2>"),
+            (384, 60, None, "k_rows_wave<double, 6, 2, 2, 1, 0>"), (448, 128, None, "k_rows_wave<double, 7, 2, 1, 1, 0>"),
+            (576, 82, None, "k_rows_pks64<double, 9, 2>"), (576, 96, 240, "k_rows_pks64<double, 9, 2>"), (576, 200, None, "k_rows_wave<double, 9, 4, 1, 1, 0>"),
             (640, 82, None, "k_rows_pks<double, 0, 5, 2>"), (640, 96, 272, "k_rows_pks<double, 0, 5, 2>"), (640, 250, 11, "k_rows_wave<double, 10, 4, 1, 1, 0>"),
             # 640, 768, 896, 1152, 1280, 1536, 1792 (round 6): the packed sub-rows for centred windows of up to 96 pixels (also shifted inside the six planes);
             # any other window is STAGED (k_gen_coeffs_f64 -> MODE 1 rows: these grids draw N / 16 streams per row)
@@ -443,7 +447,8 @@ def test_fused_float64_generator_rows_match_the_oracle_on_restated_draws(N, Np, 
     np.testing.assert_allclose(h.run(seed, real0, n, None, 0.01), got, rtol=1e-10)
 
 
-@pytest.mark.parametrize("N,Np,kernel", [(1280, 82, "k_rows_pks<double, 1, 5, 2>"), (896, 60, "k_rows_pks<double, 0, 7, 2>"), (1536, 96, "k_rows_pks<double, 1, 6, 2>")])
+@pytest.mark.parametrize("N,Np,kernel", [(1280, 82, "k_rows_pks<double, 1, 5, 2>"), (896, 60, "k_rows_pks<double, 0, 7, 2>"), (1536, 96, "k_rows_pks<double, 1, 6, 2>"),
+                                         (576, 82, "k_rows_pks64<double, 9, 2>")])
 def test_device_generator_screens_on_the_packed_subrow_grids(N, Np, kernel):
     """`fastmc_screens` (EPI 1: the cropped screens themselves) on the grids of the packed sub-rows: the rows are k_rows_pks, the column
     pass the one-row-per-wave kernel launched alone (dispatch mode -1).  Against the oracle's transform of the restated float64 draws,

@@ -829,12 +829,14 @@ def main():
     sync_all()
     # N > 1: configs[3] over all the GPUs (strong scaling) and the configs[4] sweep dealt over them, in this launch form.  Collective:
     # every rank runs it; rank 0 holds the line back until it is done.
-    multi_extras = None
+    multi_extras, extras_stuck = None, False
     if workers > 1 and not args.no_extras and not strong:
-        try:
-            multi_extras = extras_multi(args, mode, devices, rank, world, rdzv)
-        except Exception as e:      # the headline is measured: a side measurement must not lose it
-            multi_extras = {"error": f"{type(e).__name__}: {e}"}
+        # the headline is measured: a side measurement must neither lose it nor hang the run -- it runs under a deadline, and when
+        # it does not come back the line goes out without it and the process leaves (the other ranks' deadlines do the same)
+        ok, val = dist.call_with_deadline(lambda: extras_multi(args, mode, devices, rank, world, rdzv),
+                                          float(os.environ.get("FASTMC_BENCH_EXTRAS_TIMEOUT", "300")))
+        multi_extras = val if ok else {"error": str(val)}
+        extras_stuck = (not ok) and bool(dist.stuck_threads())
     if rank == 0:
         if multi_extras is not None:
             line["extras_multi_gpu"] = multi_extras
@@ -844,7 +846,8 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
-    sync_all()
+    if not extras_stuck:            # (a rank whose side measurement is stuck inside a collective cannot meet the others again)
+        sync_all()
     if rccl_problem:
         # NOT a clean exit: with a thread still inside RCCL the exit hook of fast_amd.dist leaves through os._exit with the status
         # recorded here (a raised SystemExit passes none of its hooks and used to come out as 0: ADVICE r5)

@@ -50,6 +50,11 @@ static double run_case(int lo, int Np, unsigned seed) {
   std::vector<cpx<R>> tw1((size_t)P * WAVE), om((size_t)8 * omS);
   build_tw1<R>(tw1.data(), P, cs_turns);
   build_om<R>(om.data(), omS, P, lo, Np, cs_turns);
+  // The GPU kernels do not stage row 0 of either table (w^0 = 1; fmc_kernels.h: WaveLds hands the rows VIRTUAL bases one row below
+  // the LDS block): the invariant "no row reads tw1[0][.] or om[0][.]" is checked here, where the same code runs on the host --
+  // row 0 poisoned with NaN must leave every output finite
+  for (int l = 0; l < WAVE; ++l) tw1[l] = mk<R>((R)NAN, (R)NAN);
+  for (int oi = 0; oi < omS; ++oi) om[oi] = mk<R>((R)NAN, (R)NAN);
   std::vector<E> xbuf(G::XELEMS);
 
   static HostExec<R, P, NS> ex;

@@ -107,6 +107,9 @@ struct LaneRegs {
   cpx<R> omc[NS][8];   // stage-2b table values of this lane's outputs kept in registers (OMC kernels only; untouched otherwise)
 };
 
+// ROW-0 INVARIANT: no row function of this file reads tw1[0 * 64 + .] or om[0 * omS + .] (w^0 = 1: the first term of every product /
+// sum is taken as it is).  The GPU kernels rely on it -- they do not stage row 0 and address the tables through bases one row
+// BELOW the LDS block (fmc_kernels.h: WaveLds) -- and emu_wavefft.cpp checks it on the host by poisoning row 0 with NaN.
 // Tables (precomputed on the host in float64, stored as R):
 //   tw1[a*64 + l]  = w_N^{l a}                                   (P*64 complex)
 //   om[m*omS + oi] = w_64^{m * b(oi)},  m < 8                    (8*omS complex), b(oi) = (lo+oi) / P; row m = 0 (= 1) is

@@ -82,11 +82,22 @@ m1, m2, m3, m4 = (acc[k] / n for k in ("s1", "s2", "s3", "s4"))
 print(f"{n:.3e} normals from {R} realisations of {N}^2 complex coefficients, seed {SEED}")
 report("mean", m1 * np.sqrt(n))
 report("variance", (m2 - m1 ** 2 - 1) / np.sqrt(2 / n))
-report("skewness", m3 / np.sqrt(6 / n))
-report("excess kurtosis", (m4 - 3) / np.sqrt(24 / n))
+# standardised CENTRAL moments, whose standard errors under normality are sqrt(6 / n) and sqrt(24 / n).  (Rounds 2-5 divided the RAW
+# third / fourth moments by these: the raw ones have variances 15 / n and 96 / n, so those z-scores read 1.58 x / 2 x too large --
+# a "skewness z = -4.35" of round 6 was a raw-moment z of -2.75.)
+c2 = m2 - m1 ** 2
+c3 = m3 - 3 * m1 * m2 + 2 * m1 ** 3
+c4 = m4 - 4 * m1 * m3 + 6 * m1 ** 2 * m2 - 3 * m1 ** 4
+report("skewness", c3 / c2 ** 1.5 / np.sqrt(6 / n))
+report("excess kurtosis", (c4 / c2 ** 2 - 3) / np.sqrt(24 / n))
 for k, got in tails.items():
     e = n * 2 * stats.norm.sf(k)
-    report(f"count beyond {k:.0f} sigma: {got} (expected {e:.1f})", (got - e) / np.sqrt(e))
+    if e >= 30:
+        zt = (got - e) / np.sqrt(e)
+    else:       # few expected counts: the exact Poisson tail as a two-sided z (a count of 2 where 0.13 is expected is p = 0.8 %, not "5 sigma")
+        pt = min(1.0, 2 * min(stats.poisson.cdf(got, e), stats.poisson.sf(got - 1, e)))
+        zt = np.sign(got - e) * stats.norm.isf(pt / 2)
+    report(f"count beyond {k:.0f} sigma: {got} (expected {e:.1f})", zt)
 for name, hh in (("radius: exp(-|c|^2/2) uniform, 4096 bins", hist_u), ("phase uniform, 4096 bins", hist_t)):
     e = hh.sum() / 4096
     report(name, (((hh - e) ** 2 / e).sum() - 4095) / np.sqrt(2 * 4095))

@@ -43,7 +43,8 @@ PY
     nps-profile) bash tools/profile_numpy_stream.sh ${TAG}_nps > $OUT/profile_nps.log 2>&1; tail -5 $OUT/profile_nps.log ;;
     sweep) bash tools/sizesweep.sh ${arg//,/ } > $OUT/sizesweep.txt 2>&1; cat $OUT/sizesweep.txt ;;
     trace) bash tools/trace_sizes.sh $TAG ${arg//,/ } > $OUT/trace_sizes.txt 2>&1; cat $OUT/trace_sizes.txt ;;
-    ubsan) bash tools/ubsan_host.sh tests -m gpu -q -x > $OUT/ubsan_suite.txt 2> $OUT/ubsan_stderr.txt; tail -3 $OUT/ubsan_suite.txt; grep -c "runtime error" $OUT/ubsan_stderr.txt $OUT/ubsan_suite.txt ;;
+    ubsan) [ -f build/ubsan/libfastmc_ubsan.so ] || bash tools/ubsan_host.sh build > $OUT/ubsan_build.log 2>&1   # (build/ does not travel: built on the box, ~2 min)
+           bash tools/ubsan_host.sh tests -m gpu -q -x > $OUT/ubsan_suite.txt 2> $OUT/ubsan_stderr.txt; tail -3 $OUT/ubsan_suite.txt; grep -c "runtime error" $OUT/ubsan_stderr.txt $OUT/ubsan_suite.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done

@@ -1269,6 +1269,35 @@ static void launch_pks64_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
   hipLaunchKernelGGL((k_rows_pks64<R, S, MODE>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, B);
   FMC_NOTE(h->last_rows, "k_rows_pks64<%s, %d, %d>", rname<R>(), S, MODE);
 }
+template <class R> int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode);
+template <class R, int L0, int S, int EPI>
+static void launch_pks_cols(fastmc_ctx* h, const ColArgs<R>& CA) {
+  using C = PksCfg<R, L0, S>;
+  constexpr int WPC = PksColCfg<R, L0, S>::WPC;
+  const size_t lds = pks_cols_lds_bytes<R, L0, S>();
+  const int items = CA.nb * ((CA.Np + C::G - 1) / C::G);
+  hipFuncSetAttribute((const void*)k_cols_pks<R, L0, S, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_cols_pks<R, L0, S, EPI>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), lds, h->stream, CA);
+  FMC_NOTE(h->last_cols, "k_cols_pks<%s, %d, %d, %d>", rname<R>(), L0, S, EPI);
+}
+// rows (device generator) and columns of the packed sub-rows: the pair keeps V permuted along ky (fmc_kernels.h: k_rows_pks)
+template <class R>
+int dispatch_pks(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in, int mode, int epi) {
+  TRY(dispatch_pks_rows<R>(h, RA_in, mode));
+  if (pks_L0(h->N) < 0) return 0;      // sub-rows of 64 points: standard V, the caller launches the one-row-per-wave column pass (mode -1)
+  Span s(h, 1);
+  ColArgs<R> CA = CA_in;
+  CA.tw = (const cpx<R>*)h->pks_tw1; CA.cw = (const cpx<R>*)h->pks_cw;
+  const int S = pks_split(h->N), L0 = pks_L0(h->N);
+#define FMC_PKSC(LL, SS)                                                                  \
+  if (L0 == LL && S == SS) {                                                              \
+    if (epi == 0) launch_pks_cols<R, LL, SS, 0>(h, CA); else launch_pks_cols<R, LL, SS, 1>(h, CA); \
+    return 0;                                                                             \
+  }
+  FMC_PKSC(1, 3) FMC_PKSC(1, 5) FMC_PKSC(1, 6) FMC_PKSC(1, 7) FMC_PKSC(0, 5) FMC_PKSC(0, 7) FMC_PKSC(0, 9)
+#undef FMC_PKSC
+  return fail(FASTMC_ESTATE, "no packed sub-row column kernel for this grid");
+}
 template <class R>
 int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode) {
   Span s(h, 0);
@@ -1611,8 +1640,8 @@ extern template int dispatch_mr_part<double, 1>(FMC_FAMILY_SIG(double));
 #if FMC_TU != 10
 extern template int dispatch_pk<double>(FMC_FAMILY_SIG(double));
 extern template int dispatch_pk<float>(FMC_FAMILY_SIG(float));
-extern template int dispatch_pks_rows<double>(FMC_PKS_SIG(double));
-extern template int dispatch_pks_rows<float>(FMC_PKS_SIG(float));
+extern template int dispatch_pks<double>(FMC_FAMILY_SIG(double));
+extern template int dispatch_pks<float>(FMC_FAMILY_SIG(float));
 #endif
 #endif
 #if FMC_TU == 1
@@ -1634,10 +1663,10 @@ template int dispatch_ws<double>(FMC_FAMILY_SIG(double));
 template int dispatch_mr_part<double, 1>(FMC_FAMILY_SIG(double));
 #elif FMC_TU == 10
 template int dispatch_pk<double>(FMC_FAMILY_SIG(double));
-template int dispatch_pks_rows<double>(FMC_PKS_SIG(double));
+template int dispatch_pks<double>(FMC_FAMILY_SIG(double));
 #ifndef FMC_ONLY_F64
 template int dispatch_pk<float>(FMC_FAMILY_SIG(float));
-template int dispatch_pks_rows<float>(FMC_PKS_SIG(float));
+template int dispatch_pks<float>(FMC_FAMILY_SIG(float));
 #endif
 #elif !defined(FMC_ONLY_F64)
 #if FMC_TU == 4
@@ -1910,11 +1939,11 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     // packed sub-rows (640 ... 1792, fmc_core.h: pks_split): the device generator's rows, then the column pass of the one-row-per-wave family
     const bool pks = kmode != 1 && pks_variant<R>(h) >= 0;
     bool wave_ok = h->path == 1 && !(pk_grid(h->N) && kmode == 0) && !(pks_grid(h->N) && kmode == 0 && !pks);    // packed grids beyond the packed windows: see pk_variant, pks_variant
-    if (pks) TRY(dispatch_pks_rows<R>(h, RA, kmode));
-    const int wmode = pks ? -1 : kmode;
+    const bool pks64 = pks && pks_L0(h->N) < 0;            // sub-rows of 64 points: their column pass is the one-row-per-wave kernel's
+    const int wmode = pks64 ? -1 : kmode;
     // the one-row-per-wave kernels of the N / 16-stream grids exist for host coefficients only (launch_wave_pair): a device draw must
     // never reach them (it would transform whatever `cre` / `cim` hold)
-    if (wave_ok && (pk_grid(h->N) || pks_grid(h->N)) && wmode != 1 && wmode != -1)
+    if (!pks && wave_ok && (pk_grid(h->N) || pks_grid(h->N)) && wmode != 1)
       return fail(FASTMC_ESTATE, "internal: device draws routed to a host-coefficient row kernel");
     bool general_2048 = false;   // N = 2048, window > 256 pixels, host coefficients: single-pass P = 32 kernels
     if (wave_ok) {
@@ -1934,7 +1963,13 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     RA.tw_global = 0;
     CA.tw_global = 0;
     CA.cw = RA.cw;
-    if (general_2048 || wave_ok) {
+    if (pks) {
+      // rows with the device generator and -- 128 / 256-point sub-rows -- the column pass, V permuted along ky between them
+      // (fmc_kernels.h: k_rows_pks / k_cols_pks)
+      TRY(dispatch_pks<R>(h, RA, CA, kmode, S.epi));
+    }
+    if (pks && !pks64) {
+    } else if (general_2048 || wave_ok) {
       if (!general_2048 && wave_rt_split(h->N)) {
         if constexpr (sizeof(R) == 8) { TRY(dispatch_ws<R>(h, RA, CA, kmode, S.epi)); }
         else return fail(FASTMC_ESTATE, "run-time-split grids run the float64 kernels (fastmc_create)");

@@ -953,8 +953,8 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPC * 64), (PkCfg<R, L0, D>::CMIN
 // arithmetic): a wavefront owns G = 4 / 8 consecutive rows and transforms them one sub-row index s at a time on the packed
 // pipeline of the 256 / 128-point grid -- sixteen draws per lane and pass from ONE generator stream (t = s + S q of SL = S L =
 // N / 16: fmc_core.h stream_lanes), six planes accumulated in registers, V written once per row.  Centred windows of up to 96
-// pixels, device generator (MODE 0 float32 draw, MODE 2 float64 generator); the column pass and every other window / mode stay
-// with the one-row-per-wave kernels (same V layout).  Tile walk as k_rows_wave.
+// pixels, device generator (MODE 0 float32 draw, MODE 2 float64 generator); every other window / mode stays with the one-row-per-wave
+// kernels.  The pair k_rows_pks / k_cols_pks keeps V permuted along ky (sub-row major).  Tile walk as k_rows_wave.
 #ifndef FMC_PKS_WPB
 #define FMC_PKS_WPB 12
 #endif
@@ -996,24 +996,31 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
   constexpr int BPG = ROWS_PER_WAVE * WPB / LU;
   const int nbb = (A.nb + BPG - 1) / BPG;
   const int q = lane & (L - 1), gl = lane / L;
-  const int lane_in = gl * N + S * q;                    // this lane's first input of sub-row 0 (the G rows of a unit are contiguous)
+  // V of these grids is stored PERMUTED along ky so that the column pass (k_cols_pks) reads its sub-rows contiguously: row
+  // ky = s + S m lives at position s M + m of its window column.  A unit's G rows are therefore S apart (ky = kyb + S g: G
+  // consecutive POSITIONS, a half / whole 128-byte line), a tile the LR positions of one line of one row class s.
+  constexpr int M = C::M, TPS = M / LR;
+  static_assert(M % LR == 0, "whole lines per row class");
+  const int lane_in = gl * S * N + S * q;                // this lane's first input of sub-row 0
   const int tiles = A.tiles ? A.tiles : (int)gridDim.x;
 #pragma unroll 1
   for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
   const int b0 = (vb % nbb) * BPG;
-  const int row0 = (vb / nbb) * LR;
+  const int tr = vb / nbb;
+  const int s_r = tr / TPS, m0 = (tr % TPS) * LR;
 #pragma unroll 1
   for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
     const int flat = rr * WPB + w;
     const int b = b0 + flat / LU;
     if (b >= A.nb) break;                                // wave-uniform
-    const int ky0 = row0 + (flat % LU) * G;
+    const int mu = m0 + (flat % LU) * G;                 // position of the unit's first row within its class
+    const int ky0 = s_r + S * mu;                        // ... and that row
     const uint64_t g = A.g0 + (uint64_t)b;
     pks_clear<R, L0>(ex);
 #pragma unroll 1
     for (int sp = 0; sp < S; ++sp) {
       // sub-row sp of the G rows: kx = sp + S (q + L j), stream t = sp + S q of SL = S L
-      xoshiro128p rs = row_stream(A.key, g, ky0 + gl, sp + S * q, S * L);
+      xoshiro128p rs = row_stream(A.key, g, ky0 + S * gl, sp + S * q, S * L);
       if (MODE == 0) {
         const float* ampf = A.ampf + (size_t)ky0 * N + sp;
 #pragma unroll
@@ -1034,16 +1041,110 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
       packed_row_fft<R, L0, C::NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
       pks_accumulate<R, L0, C::FIRST>(ex, s_cw + sp * PKS_SPAN);
     }
-    cpx<R>* out = A.V + (size_t)b * A.Np * N + ky0;      // V[b][oi][ky]
+    cpx<R>* out = A.V + (size_t)b * A.Np * N + s_r * M + mu;      // V[b][oi][position of ky]
     pks_outputs<R, L0>(lane, regs, N, A.lo, A.Np, [&](int oi, R re, R im) { out[(uint32_t)(oi * N + gl)] = mk<R>(re, im); });
   }
   if (A.tiles) __syncthreads();      // (as k_rows_wave: the waves of a workgroup stay within one tile of each other)
   }
 }
 
+// The column pass of the same grids: G window columns per wavefront, S passes over a column's sub-rows (contiguous in the permuted V),
+// the detector as k_cols_pk's rolled loop over the lane's accumulators, the sums reduced over the L lanes of a column by DPP.
+template <class R, int L0, int S> struct PksColCfg {
+  // 122 registers (M = 256) / 152 (M = 128: twelve accumulators) with float64: four / three waves per SIMD; the exchange buffers and
+  // the tables of sixteen / twelve waves fit the LDS (150 KB / 117 KB at most)
+  static constexpr int WPC = (L0 == 1 || sizeof(R) == 4) ? 16 : 12;
+};
+template <class R, int L0, int S>
+__host__ __device__ constexpr size_t pks_cols_lds_bytes() {
+  return (size_t)(16 * PksCfg<R, L0, S>::L + S * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksColCfg<R, L0, S>::WPC * D16_XELEMS * 8;
+}
+template <class R, int L0, int S, int EPI>
+__global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(ColArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using C = PksCfg<R, L0, S>;
+  using E = typename Xch<R>::E;
+  constexpr int L = C::L, G = C::G, N = C::N, M = C::M, NM = C::NM, WPC = PksColCfg<R, L0, S>::WPC;
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  cpx<R>* s_cw = s_tw + 16 * L;
+  E* s_x = reinterpret_cast<E*>(s_cw + S * PKS_SPAN);
+  for (int i = threadIdx.x; i < 16 * L; i += blockDim.x) s_tw[i] = A.tw[i];
+  for (int i = threadIdx.x; i < S * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  E* xbuf = s_x + w * D16_XELEMS;
+  const int q = lane & (L - 1), gl = lane / L;
+  LaneRegs<R, 16, NM> regs;
+  GpuExec<R, 16, NM> ex{lane, regs};
+  const int ngrp = (A.Np + G - 1) / G;
+  const int item = blockIdx.x * WPC + w;
+  if (item >= A.nb * ngrp) return;                         // wave-uniform; no block barrier follows
+  const int b = item / ngrp;
+  const int xi = (item % ngrp) * G + gl;
+  const bool live = xi < A.Np;                             // the last group of a realisation may be short
+  const cpx<R>* col = A.V + ((size_t)b * A.Np + (item % ngrp) * G) * N;
+  const uint32_t lane_in = (live ? gl : 0) * N + q;
+  pks_clear<R, L0>(ex);
+#pragma unroll 1
+  for (int sp = 0; sp < S; ++sp) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) regs.v[j] = load_v(col + sp * M + lane_in + L * j);
+    packed_row_fft<R, L0, NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
+    pks_accumulate<R, L0, C::FIRST>(ex, s_cw + sp * PKS_SPAN);
+  }
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  auto pixel = [&](int yi, R p1, R p2) {
+    pixel_phase<R>(A.sh, b, A.Np, yi, xi, p1, p2);
+    if (EPI == 1) {
+      const size_t plane = (size_t)A.Np * A.Np;
+      A.phs[((size_t)b) * plane + (size_t)yi * A.Np + xi] = (double)p1;
+      A.phs[((size_t)(A.nb + b)) * plane + (size_t)yi * A.Np + xi] = (double)p2;
+    } else {
+      const double wgt = A.W[(size_t)yi * A.Np + xi];
+      double s1, c1, s2, c2;
+      sincos_r(p1, s1, c1);
+      sincos_r(p2, s2, c2);
+      acc[0] += wgt * c1; acc[1] += wgt * s1; acc[2] += wgt * c2; acc[3] += wgt * s2;
+    }
+  };
+  cpx<R>* ob = reinterpret_cast<cpx<R>*>(xbuf) + lane;
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+#pragma unroll
+    for (int p = 0; p < 6; ++p) ob[WAVE * p] = regs.omc[m][p];
+    ex.sync();
+    const int y0 = N / 2 - 48 + q + 8 * m - A.lo;          // (L0 = 1: m = 0, q = a; L0 = 0: a = q + 8 m)
+#pragma unroll 1
+    for (int p = 0; p < 6; ++p) {
+      const int yi = y0 + 16 * p;
+      if (live && yi >= 0 && yi < A.Np) {
+        const cpx<R> v = ob[WAVE * p];
+        pixel(yi, v.x, v.y);
+      }
+    }
+    ex.sync();
+  }
+  if (EPI == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double v = acc[k];
+      v += dpp_copy<0xB1>(v);     // quad_perm [1,0,3,2]
+      v += dpp_copy<0x4E>(v);     // quad_perm [2,3,0,1]
+      v += dpp_copy<0x141>(v);    // row_half_mirror: every lane holds the sum of its 8 lanes
+      if (L0 >= 1) v += dpp_copy<0x140>(v);    // row_mirror: ... of its 16-lane row
+      acc[k] = v;
+    }
+    if (q == 0 && live) {
+      double* o = A.partial + ((size_t)b * A.Np + xi) * 4;
+      o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+    }
+  }
+}
+
 // Sub-rows of SIXTY-FOUR points (192, 320, 448, 576; fmc_wavefft.h: pks64_pass): SIXTEEN rows per wavefront, four lanes per sub-row, 24
 // accumulators per lane (every output of a sub-transform is needed, a third of them for two window positions).  A unit's sixteen rows
-// are two whole 128-byte lines of every V column; a workgroup owns them for ROWS_PER_WAVE * WPB consecutive realisations.
+// are two whole 128-byte lines of every V column; a workgroup owns them for ROWS_PER_WAVE * WPB consecutive realisations.  V in the
+// standard layout: the column pass stays with the one-row-per-wave kernels (dispatch mode -1).
 #ifndef FMC_PKS64_WPB
 #define FMC_PKS64_WPB 8
 #endif
@@ -1111,7 +1212,8 @@ __global__ __launch_bounds__((Pks64Cfg<R, S>::WPB * 64)) void k_rows_pks64(RowAr
       }
       pks64_pass<R>(ex, xbuf, s_tw, s_cw + sp * PKS_SPAN);
     }
-    cpx<R>* out = A.V + (size_t)b * A.Np * N + ky0;      // V[b][oi][ky]
+    cpx<R>* out = A.V + (size_t)b * A.Np * N + ky0;      // V[b][oi][ky] (the standard layout: the column pass is the one-row-per-wave kernel's --
+                                                         // a sixteen-column form of k_cols_pks with its 24 accumulators ran SLOWER: profiles/r06_ab_packed_subrows.txt section 5)
     pks64_outputs<R>(lane, regs, N, A.lo, A.Np, [&](int oi, R re, R im) { out[(uint32_t)(oi * N + gl)] = mk<R>(re, im); });
   }
   if (A.tiles) __syncthreads();

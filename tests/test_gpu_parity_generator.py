@@ -323,7 +323,9 @@ def test_benchmarked_instantiation_at_baseline_size_matches_the_oracle():
 
 
 @pytest.mark.parametrize("N,Np,sub", [(512, 82, False), (1024, 82, False), (1000, 82, False), (2048, 82, False), (164, 82, False), (256, 40, True),
-                                      (128, 40, True), (512, 82, True), (256, 200, True), (128, 128, False)])
+                                      (128, 40, True), (512, 82, True), (256, 200, True), (128, 128, False),
+                                      # packed sub-rows (round 6): rows AND columns in S passes (768, 896), rows only (576); sub-harmonics in their epilogues
+                                      (768, 82, True), (896, 60, True), (576, 82, True), (1280, 82, False)])
 def test_float64_device_generator_matches_its_restatement(N, Np, sub):
     """GPU_RNG_PRECISION 'f64' (fastmc_set_rng_precision): 53-bit normals, float64 log / sqrt / sincospi, float64 colouring
     -- the reference's precision (funcs.py:352-356, fast.py:594).  Its draws equal oracle/devrng.py's restatement to a few

@@ -426,10 +426,10 @@ static int sweep_pks(const char* name, double tol) {
   return bad;
 }
 
-// Packed sub-rows of SIXTY-FOUR points (pks64_pass): sixteen rows of N = S * 64 points per wave, S passes, against the naive DFT.
+// Packed sub-rows of SIXTY-FOUR points (pks64_pass): eight rows of N = S * 64 points per wave, eight lanes each, S passes, against the naive DFT.
 template <class R, int S>
 static double run_pks64_case(int Np, int shift, unsigned seed) {
-  constexpr int M = 64, N = S * M, G = 16;
+  constexpr int M = 64, N = S * M, G = 8;
   using E = typename Xch<R>::E;
   std::mt19937_64 gen(seed);
   std::normal_distribution<double> nd(0.0, 1.0);
@@ -441,12 +441,12 @@ static double run_pks64_case(int Np, int shift, unsigned seed) {
   build_tw64<R>(tw.data(), cs_turns);
   build_pcw<R>(pcw.data(), N, S, cs_turns);
   std::vector<E> xbuf(D16_XELEMS);
-  static HostExec<R, 16, 4> ex;
-  pks64_clear<R>(ex);
+  static HostExec<R, 16, 2> ex;
+  pks_clear<R, -1>(ex);
   for (int sp = 0; sp < S; ++sp) {
     for (int l = 0; l < WAVE; ++l)
-      for (int j = 0; j < 16; ++j) {
-        const int g = l / 4, k = sp + S * (l % 4 + 4 * j);
+      for (int j = 0; j < 8; ++j) {
+        const int g = l / 8, k = sp + S * (l % 8 + 8 * j);
         const double sg = (k & 1) ? -1.0 : 1.0;
         ex.regs[l].v[j] = mk<R>((R)(sg * inr[g * N + k]), (R)(sg * ini[g * N + k]));
       }
@@ -454,7 +454,7 @@ static double run_pks64_case(int Np, int shift, unsigned seed) {
   }
   std::vector<double> gr((size_t)G * Np, 1e300), gi((size_t)G * Np, 1e300);
   for (int l = 0; l < WAVE; ++l)
-    pks64_outputs<R>(l, ex.regs[l], N, lo, Np, [&](int oi, R re, R im) { gr[(l / 4) * Np + oi] = re; gi[(l / 4) * Np + oi] = im; });
+    pks_outputs<R, -1>(l, ex.regs[l], N, lo, Np, [&](int oi, R re, R im) { gr[(l / 8) * Np + oi] = re; gi[(l / 8) * Np + oi] = im; });
   double worst = 0.0, scale = 0.0;
   const int h = N / 2;
   for (int g = 0; g < G; ++g)

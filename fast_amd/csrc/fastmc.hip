@@ -852,7 +852,7 @@ static int upload_wave_tables(fastmc_ctx* h) {
     TRY(upload_table<R>(&h->pk_om, omp));
   }
   if (pks_grid(h->N) && !h->pks_tw1) {          // (both tables depend on N only)
-    const int Sp = pks_split(h->N), L = pks_L0(h->N) < 0 ? 4 : pk_lanes(pks_L0(h->N));
+    const int Sp = pks_split(h->N), L = pks_L0(h->N) < 0 ? 4 : pk_lanes(pks_L0(h->N));     // (64-point sub-rows: 8 x 8 = 16 x 4 entries)
     std::vector<cpx<R>> tw((size_t)16 * L), pcw((size_t)Sp * PKS_SPAN);
     if (pks_L0(h->N) < 0) build_tw64<R>(tw.data(), cs_turns);
     else build_tw1_pk<R>(tw.data(), L, cs_turns);
@@ -1116,7 +1116,7 @@ static void launch_cols_wave(fastmc_ctx* h, const ColArgs<R>& A) {
 // rows with MODE = mode, columns with EPI = epi of one (P, NS, S, D) variant
 template <class R, int P, int NS, int S, int DR, int DC = DR>
 static void launch_wave_pair(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
-  if (mode >= 0) {        // (-1: the packed sub-rows have written V already -- dispatch_pks_rows -- and only the column pass is wanted)
+  {
     Span s(h, 0);
     // 256 / 512 draw 16 / 32 streams per row (fmc_core.h: stream_lanes): their device-generator rows are the packed kernels
     // (dispatch_pk) or the direct family, never the one-row-per-wave kernels, so MODE 0 is not instantiated for them; the same
@@ -1176,8 +1176,8 @@ static void dispatch_wave(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>&
     launch_wave_pair<R, 16, NS, S, 7>(h, RA, CA, mode, epi);      // any other window: all sixteen planes
   } else {
     if constexpr (NS == 2 && P > 16 && prune_pays(P, 8, 0)) {
-      if ((mode == 0 || mode == -1) && epi == 0 && (window_planes(h->lo, h->Np, P, 8) & ~centre_planes(P, 8, 0)) == 0) {
-        launch_wave_pair<R, P, 2, S, 3>(h, RA, CA, mode, 0);
+      if (mode == 0 && epi == 0 && (window_planes(h->lo, h->Np, P, 8) & ~centre_planes(P, 8, 0)) == 0) {
+        launch_wave_pair<R, P, 2, S, 3>(h, RA, CA, 0, 0);
         return;
       }
     }
@@ -1253,22 +1253,6 @@ static void launch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
   hipLaunchKernelGGL((k_rows_pks<R, L0, S, MODE>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, B);
   FMC_NOTE(h->last_rows, "k_rows_pks<%s, %d, %d, %d>", rname<R>(), L0, S, MODE);
 }
-template <class R, int S, int MODE>
-static void launch_pks64_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
-  using C = Pks64Cfg<R, S>;
-  const size_t lds = pks64_lds_bytes<R, S>() + (MODE == 2 ? GEN64_TABLE_BYTES : 0);
-  constexpr int BPG = ROWS_PER_WAVE * C::WPB;
-  int blocks = (C::N / C::G) * ((RA.nb + BPG - 1) / BPG);
-  RowArgs<R> B = RA;
-  hipFuncSetAttribute((const void*)k_rows_pks64<R, S, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  static const int persist = getenv("FASTMC_ROWS_PERSIST") ? atoi(getenv("FASTMC_ROWS_PERSIST")) : 1;
-  if (persist) {
-    const int resident = resident_workgroups(h, (const void*)k_rows_pks64<R, S, MODE>, C::WPB * 64, lds);
-    if (blocks >= 8 * resident) { B.tiles = blocks; blocks = resident; }
-  }
-  hipLaunchKernelGGL((k_rows_pks64<R, S, MODE>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, B);
-  FMC_NOTE(h->last_rows, "k_rows_pks64<%s, %d, %d>", rname<R>(), S, MODE);
-}
 template <class R> int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode);
 template <class R, int L0, int S, int EPI>
 static void launch_pks_cols(fastmc_ctx* h, const ColArgs<R>& CA) {
@@ -1284,7 +1268,6 @@ static void launch_pks_cols(fastmc_ctx* h, const ColArgs<R>& CA) {
 template <class R>
 int dispatch_pks(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in, int mode, int epi) {
   TRY(dispatch_pks_rows<R>(h, RA_in, mode));
-  if (pks_L0(h->N) < 0) return 0;      // sub-rows of 64 points: standard V, the caller launches the one-row-per-wave column pass (mode -1)
   Span s(h, 1);
   ColArgs<R> CA = CA_in;
   CA.tw = (const cpx<R>*)h->pks_tw1; CA.cw = (const cpx<R>*)h->pks_cw;
@@ -1295,6 +1278,7 @@ int dispatch_pks(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in
     return 0;                                                                             \
   }
   FMC_PKSC(1, 3) FMC_PKSC(1, 5) FMC_PKSC(1, 6) FMC_PKSC(1, 7) FMC_PKSC(0, 5) FMC_PKSC(0, 7) FMC_PKSC(0, 9)
+  FMC_PKSC(-1, 3) FMC_PKSC(-1, 5) FMC_PKSC(-1, 7) FMC_PKSC(-1, 9)
 #undef FMC_PKSC
   return fail(FASTMC_ESTATE, "no packed sub-row column kernel for this grid");
 }
@@ -1310,14 +1294,9 @@ int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode) {
     if constexpr (sizeof(R) == 8) { if (mode == 2) { launch_pks_rows<R, LL, SS, 2>(h, RA); return 0; } }  \
   }
   FMC_PKS(1, 3) FMC_PKS(1, 5) FMC_PKS(1, 6) FMC_PKS(1, 7) FMC_PKS(0, 5) FMC_PKS(0, 7) FMC_PKS(0, 9)
+  FMC_PKS(-1, 3) FMC_PKS(-1, 5) FMC_PKS(-1, 7) FMC_PKS(-1, 9)
 #undef FMC_PKS
-#define FMC_PKS64(SS)                                                                                  \
-  if (L0 < 0 && S == SS) {                                                                             \
-    if (mode == 0) { launch_pks64_rows<R, SS, 0>(h, RA); return 0; }                                   \
-    if constexpr (sizeof(R) == 8) { if (mode == 2) { launch_pks64_rows<R, SS, 2>(h, RA); return 0; } } \
-  }
-  FMC_PKS64(3) FMC_PKS64(5) FMC_PKS64(7) FMC_PKS64(9)
-#undef FMC_PKS64
+
   return fail(FASTMC_ESTATE, "no packed sub-row kernel for this grid / mode");
 }
 
@@ -1939,8 +1918,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     // packed sub-rows (640 ... 1792, fmc_core.h: pks_split): the device generator's rows, then the column pass of the one-row-per-wave family
     const bool pks = kmode != 1 && pks_variant<R>(h) >= 0;
     bool wave_ok = h->path == 1 && !(pk_grid(h->N) && kmode == 0) && !(pks_grid(h->N) && kmode == 0 && !pks);    // packed grids beyond the packed windows: see pk_variant, pks_variant
-    const bool pks64 = pks && pks_L0(h->N) < 0;            // sub-rows of 64 points: their column pass is the one-row-per-wave kernel's
-    const int wmode = pks64 ? -1 : kmode;
+    const int wmode = kmode;
     // the one-row-per-wave kernels of the N / 16-stream grids exist for host coefficients only (launch_wave_pair): a device draw must
     // never reach them (it would transform whatever `cre` / `cim` hold)
     if (!pks && wave_ok && (pk_grid(h->N) || pks_grid(h->N)) && wmode != 1)
@@ -1964,11 +1942,8 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     CA.tw_global = 0;
     CA.cw = RA.cw;
     if (pks) {
-      // rows with the device generator and -- 128 / 256-point sub-rows -- the column pass, V permuted along ky between them
-      // (fmc_kernels.h: k_rows_pks / k_cols_pks)
+      // rows with the device generator and the column pass, V permuted along ky between them (fmc_kernels.h: k_rows_pks / k_cols_pks)
       TRY(dispatch_pks<R>(h, RA, CA, kmode, S.epi));
-    }
-    if (pks && !pks64) {
     } else if (general_2048 || wave_ok) {
       if (!general_2048 && wave_rt_split(h->N)) {
         if constexpr (sizeof(R) == 8) { TRY(dispatch_ws<R>(h, RA, CA, kmode, S.epi)); }

@@ -472,13 +472,14 @@ FMC_HD constexpr int pks_split(int N) {
   return N == 768 ? 3 : (N == 1280 ? 5 : (N == 1536 ? 6 : (N == 1792 ? 7 : (N == 640 ? 5 : (N == 896 ? 7 : (N == 1152 ? 9 :
          (N == 576 ? 9 : (N == 448 ? 7 : (N == 320 ? 5 : (N == 192 ? 3 : 0))))))))));
 }
-// M = 16 * pk_lanes(L0): 256 (L0 = 1) or 128 (L0 = 0); -1: sub-rows of SIXTY-FOUR points (192, 320, 448, 576 = 3, 5, 7, 9 x 64: sixteen
-// rows per wavefront, fmc_wavefft.h: pks64_pass)
+// M = 16 * pk_lanes(L0): 256 (L0 = 1) or 128 (L0 = 0); -1: sub-rows of SIXTY-FOUR points (192, 320, 448, 576 = 3, 5, 7, 9 x 64: eight
+// rows per wavefront, eight lanes per sub-row, eight draws per generator stream: fmc_wavefft.h: pks64_pass)
 FMC_HD constexpr int pks_L0(int N) { return N % 256 == 0 ? 1 : (N % 128 == 0 ? 0 : -1); }
 FMC_HD constexpr bool pks_grid(int N) { return pks_split(N) != 0; }
 // Generator streams per row: coefficient (ky, kx) is draw kx / SL of stream kx mod SL.
 FMC_HD constexpr int stream_lanes(int N) {
-  return (pk_grid(N) || pks_grid(N)) ? N / 16 : (mr_supported(N) ? MR_LN * mr_split(N) : WAVE * spec_split(N));
+  // the packed grids and the sub-row grids of 256 / 128 points: sixteen draws per stream; the sub-row grids of 64 points: eight
+  return pks_grid(N) && pks_L0(N) < 0 ? N / 8 : ((pk_grid(N) || pks_grid(N)) ? N / 16 : (mr_supported(N) ? MR_LN * mr_split(N) : WAVE * spec_split(N)));
 }
 constexpr uint32_t STREAM_SCREEN = 0;
 constexpr uint32_t STREAM_LOGAMP = 1;   // counter words 2,3 = global iteration index

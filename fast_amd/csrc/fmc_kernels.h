@@ -948,7 +948,7 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPC * 64), (PkCfg<R, L0, D>::CMIN
   }
 }
 
-// ================================================================== packed SUB-ROWS: N = S x 256 (768, 1280, 1536, 1792), S x 128 (640, 896, 1152)
+// ================================================================== packed SUB-ROWS: N = S x 256 (768, 1280, 1536, 1792), S x 128 (640, 896, 1152), S x 64 (192, 320, 448, 576)
 // The row pass of the grids whose one-row-per-wave kernel holds 10 ... 28 values per lane (fmc_wavefft.h: pks_accumulate has the
 // arithmetic): a wavefront owns G = 4 / 8 consecutive rows and transforms them one sub-row index s at a time on the packed
 // pipeline of the 256 / 128-point grid -- sixteen draws per lane and pass from ONE generator stream (t = s + S q of SL = S L =
@@ -962,29 +962,32 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPC * 64), (PkCfg<R, L0, D>::CMIN
 #define FMC_PKS_WPB0 8
 #endif
 template <class R, int L0_, int S> struct PksCfg {
-  static constexpr int L0 = L0_, L = pk_lanes(L0), G = WAVE / L, M = 16 * L, N = S * M, NM = pks_nm<L0>();
-  static constexpr int B0M = pks_plane_mask(L0, S), FIRST = pks_first_plane(L0, S);
+  // L0 = 1 / 0: sub-rows of 256 / 128 points on the packed pipeline (sixteen values per lane, L = 16 / 8 lanes per sub-row);
+  // L0 = -1: sub-rows of SIXTY-FOUR points (192, 320, 448, 576): eight values per lane, eight lanes per sub-row (fmc_wavefft.h: pks64_pass)
+  static constexpr int L0 = L0_, L = L0 < 0 ? 8 : pk_lanes(L0), VPL = L0 < 0 ? 8 : 16, G = WAVE / L, M = VPL * L, N = S * M, NM = pks_nm<L0>();
+  static constexpr int B0M = L0 < 0 ? 0xFF : pks_plane_mask(L0 < 0 ? 0 : L0, S), FIRST = pks_first_plane(L0 < 0 ? 0 : L0, S);
+  static constexpr int TWN = VPL * L;                    // entries of the sub-transform's twiddle table
   // 256-point sub-rows: 155 registers with the float64 generator, twelve waves; 128-point sub-rows carry twelve accumulators (48
-  // more registers for float64): eight waves
-  static constexpr int WPB = L0 == 1 ? FMC_PKS_WPB : (sizeof(R) == 8 ? FMC_PKS_WPB0 : 12);
+  // more registers for float64): eight waves; 64-point sub-rows: twelve accumulators but eight values: twelve waves
+  static constexpr int WPB = L0 == 0 ? (sizeof(R) == 8 ? FMC_PKS_WPB0 : 12) : FMC_PKS_WPB;
 };
 // LDS carve (dynamic): [generator tables (MODE 2)][tw1 16 L cpx][pcw S x 96 cpx][xbuf WPB * D16_XELEMS 8-byte]
 template <class R, int L0, int S>
 __host__ __device__ constexpr size_t pks_lds_bytes() {
-  return (size_t)(16 * PksCfg<R, L0, S>::L + S * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksCfg<R, L0, S>::WPB * D16_XELEMS * 8;
+  return (size_t)(PksCfg<R, L0, S>::TWN + S * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksCfg<R, L0, S>::WPB * D16_XELEMS * 8;
 }
 template <class R, int L0, int S, int MODE>
 __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using C = PksCfg<R, L0, S>;
   using E = typename Xch<R>::E;
-  constexpr int L = C::L, G = C::G, N = C::N, WPB = C::WPB;
+  constexpr int L = C::L, G = C::G, N = C::N, WPB = C::WPB, VPL = C::VPL;
   Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
-  cpx<R>* s_cw = s_tw + 16 * L;
+  cpx<R>* s_cw = s_tw + C::TWN;
   E* s_x = reinterpret_cast<E*>(s_cw + S * PKS_SPAN);
   if constexpr (MODE == 2) { gen64_lds0_check(s_g64); load_gen64_table(s_g64, A.g64); }
-  for (int i = threadIdx.x; i < 16 * L; i += blockDim.x) s_tw[i] = A.tw[i];
+  for (int i = threadIdx.x; i < C::TWN; i += blockDim.x) s_tw[i] = A.tw[i];
   for (int i = threadIdx.x; i < S * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1024,22 +1027,25 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
       if (MODE == 0) {
         const float* ampf = A.ampf + (size_t)ky0 * N + sp;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[lane_in + S * L * j]);
+        for (int j = 0; j < VPL; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[lane_in + S * L * j]);
       } else if constexpr (MODE == 2) {
         static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
         const R* amp = A.amp + (size_t)ky0 * N + sp;
         double an = (double)amp[lane_in];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < VPL; ++j) {
           const double a = an;
-          if (j + 1 < 16) an = (double)amp[lane_in + S * L * (j + 1)];
+          if (j + 1 < VPL) an = (double)amp[lane_in + S * L * (j + 1)];
           ex.loadfence();
           regs.v[j] = draw_coloured_f64(rs, a, Gen64Lds0{});
           asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
         }
       }
-      packed_row_fft<R, L0, C::NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
-      pks_accumulate<R, L0, C::FIRST>(ex, s_cw + sp * PKS_SPAN);
+      if constexpr (L0 < 0) pks64_pass<R>(ex, xbuf, s_tw, s_cw + sp * PKS_SPAN);
+      else {
+        packed_row_fft<R, L0, C::NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
+        pks_accumulate<R, L0, C::FIRST>(ex, s_cw + sp * PKS_SPAN);
+      }
     }
     cpx<R>* out = A.V + (size_t)b * A.Np * N + s_r * M + mu;      // V[b][oi][position of ky]
     pks_outputs<R, L0>(lane, regs, N, A.lo, A.Np, [&](int oi, R re, R im) { out[(uint32_t)(oi * N + gl)] = mk<R>(re, im); });
@@ -1053,22 +1059,22 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
 template <class R, int L0, int S> struct PksColCfg {
   // 122 registers (M = 256) / 152 (M = 128: twelve accumulators) with float64: four / three waves per SIMD; the exchange buffers and
   // the tables of sixteen / twelve waves fit the LDS (150 KB / 117 KB at most)
-  static constexpr int WPC = (L0 == 1 || sizeof(R) == 4) ? 16 : 12;
+  static constexpr int WPC = (L0 != 0 || sizeof(R) == 4) ? 16 : 12;      // (64-point sub-rows: 126 registers)
 };
 template <class R, int L0, int S>
 __host__ __device__ constexpr size_t pks_cols_lds_bytes() {
-  return (size_t)(16 * PksCfg<R, L0, S>::L + S * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksColCfg<R, L0, S>::WPC * D16_XELEMS * 8;
+  return (size_t)(PksCfg<R, L0, S>::TWN + S * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksColCfg<R, L0, S>::WPC * D16_XELEMS * 8;
 }
 template <class R, int L0, int S, int EPI>
 __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using C = PksCfg<R, L0, S>;
   using E = typename Xch<R>::E;
-  constexpr int L = C::L, G = C::G, N = C::N, M = C::M, NM = C::NM, WPC = PksColCfg<R, L0, S>::WPC;
+  constexpr int L = C::L, G = C::G, N = C::N, M = C::M, NM = C::NM, VPL = C::VPL, WPC = PksColCfg<R, L0, S>::WPC;
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
-  cpx<R>* s_cw = s_tw + 16 * L;
+  cpx<R>* s_cw = s_tw + C::TWN;
   E* s_x = reinterpret_cast<E*>(s_cw + S * PKS_SPAN);
-  for (int i = threadIdx.x; i < 16 * L; i += blockDim.x) s_tw[i] = A.tw[i];
+  for (int i = threadIdx.x; i < C::TWN; i += blockDim.x) s_tw[i] = A.tw[i];
   for (int i = threadIdx.x; i < S * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1088,9 +1094,12 @@ __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(Co
 #pragma unroll 1
   for (int sp = 0; sp < S; ++sp) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) regs.v[j] = load_v(col + sp * M + lane_in + L * j);
-    packed_row_fft<R, L0, NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
-    pks_accumulate<R, L0, C::FIRST>(ex, s_cw + sp * PKS_SPAN);
+    for (int j = 0; j < VPL; ++j) regs.v[j] = load_v(col + sp * M + lane_in + L * j);
+    if constexpr (L0 < 0) pks64_pass<R>(ex, xbuf, s_tw, s_cw + sp * PKS_SPAN);
+    else {
+      packed_row_fft<R, L0, NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
+      pks_accumulate<R, L0, C::FIRST>(ex, s_cw + sp * PKS_SPAN);
+    }
   }
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   auto pixel = [&](int yi, R p1, R p2) {
@@ -1113,7 +1122,7 @@ __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(Co
 #pragma unroll
     for (int p = 0; p < 6; ++p) ob[WAVE * p] = regs.omc[m][p];
     ex.sync();
-    const int y0 = N / 2 - 48 + q + 8 * m - A.lo;          // (L0 = 1: m = 0, q = a; L0 = 0: a = q + 8 m)
+    const int y0 = N / 2 - 48 + q + 8 * m - A.lo;          // (L0 = 1: m = 0, q = a; L0 = 0, -1: e = q + 8 m + 16 p)
 #pragma unroll 1
     for (int p = 0; p < 6; ++p) {
       const int yi = y0 + 16 * p;
@@ -1138,85 +1147,6 @@ __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(Co
       double* o = A.partial + ((size_t)b * A.Np + xi) * 4;
       o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
     }
-  }
-}
-
-// Sub-rows of SIXTY-FOUR points (192, 320, 448, 576; fmc_wavefft.h: pks64_pass): SIXTEEN rows per wavefront, four lanes per sub-row, 24
-// accumulators per lane (every output of a sub-transform is needed, a third of them for two window positions).  A unit's sixteen rows
-// are two whole 128-byte lines of every V column; a workgroup owns them for ROWS_PER_WAVE * WPB consecutive realisations.  V in the
-// standard layout: the column pass stays with the one-row-per-wave kernels (dispatch mode -1).
-#ifndef FMC_PKS64_WPB
-#define FMC_PKS64_WPB 8
-#endif
-template <class R, int S> struct Pks64Cfg {
-  static constexpr int M = 64, N = S * M, G = 16;
-  static constexpr int WPB = sizeof(R) == 8 ? FMC_PKS64_WPB : 12;
-};
-template <class R, int S>
-__host__ __device__ constexpr size_t pks64_lds_bytes() {
-  return (size_t)(64 + S * PKS_SPAN) * sizeof(cpx<R>) + (size_t)Pks64Cfg<R, S>::WPB * D16_XELEMS * 8;
-}
-template <class R, int S, int MODE>
-__global__ __launch_bounds__((Pks64Cfg<R, S>::WPB * 64)) void k_rows_pks64(RowArgs<R> A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using C = Pks64Cfg<R, S>;
-  using E = typename Xch<R>::E;
-  constexpr int N = C::N, WPB = C::WPB, G = C::G;
-  Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
-  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
-  cpx<R>* s_cw = s_tw + 64;
-  E* s_x = reinterpret_cast<E*>(s_cw + S * PKS_SPAN);
-  if constexpr (MODE == 2) { gen64_lds0_check(s_g64); load_gen64_table(s_g64, A.g64); }
-  for (int i = threadIdx.x; i < 64; i += blockDim.x) s_tw[i] = A.tw[i];
-  for (int i = threadIdx.x; i < S * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  E* xbuf = s_x + w * D16_XELEMS;
-  LaneRegs<R, 16, 4> regs;
-  GpuExec<R, 16, 4> ex{lane, regs};
-  constexpr int BPG = ROWS_PER_WAVE * WPB;               // realisations per tile
-  const int nbb = (A.nb + BPG - 1) / BPG;
-  const int q = lane & 3, gl = lane >> 2;
-  const int lane_in = gl * N + S * q;                    // this lane's first input of sub-row 0
-  const int tiles = A.tiles ? A.tiles : (int)gridDim.x;
-#pragma unroll 1
-  for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
-  const int b0 = (vb % nbb) * BPG;
-  const int ky0 = (vb / nbb) * G;
-#pragma unroll 1
-  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
-    const int b = b0 + rr * WPB + w;
-    if (b >= A.nb) break;                                // wave-uniform
-    const uint64_t g = A.g0 + (uint64_t)b;
-    pks64_clear<R>(ex);
-#pragma unroll 1
-    for (int sp = 0; sp < S; ++sp) {
-      // sub-row sp of the sixteen rows: kx = sp + S (q + 4 j), stream t = sp + S q of SL = 4 S = N / 16
-      xoshiro128p rs = row_stream(A.key, g, ky0 + gl, sp + S * q, 4 * S);
-      if (MODE == 0) {
-        const float* ampf = A.ampf + (size_t)ky0 * N + sp;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[lane_in + 4 * S * j]);
-      } else if constexpr (MODE == 2) {
-        static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
-        const R* amp = A.amp + (size_t)ky0 * N + sp;
-        double an = (double)amp[lane_in];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const double a = an;
-          if (j + 1 < 16) an = (double)amp[lane_in + 4 * S * (j + 1)];
-          ex.loadfence();
-          regs.v[j] = draw_coloured_f64(rs, a, Gen64Lds0{});
-          asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
-        }
-      }
-      pks64_pass<R>(ex, xbuf, s_tw, s_cw + sp * PKS_SPAN);
-    }
-    cpx<R>* out = A.V + (size_t)b * A.Np * N + ky0;      // V[b][oi][ky] (the standard layout: the column pass is the one-row-per-wave kernel's --
-                                                         // a sixteen-column form of k_cols_pks with its 24 accumulators ran SLOWER: profiles/r06_ab_packed_subrows.txt section 5)
-    pks64_outputs<R>(lane, regs, N, A.lo, A.Np, [&](int oi, R re, R im) { out[(uint32_t)(oi * N + gl)] = mk<R>(re, im); });
-  }
-  if (A.tiles) __syncthreads();
   }
 }
 

@@ -626,7 +626,7 @@ FMC_HD void packed_outputs(int lane, const LaneRegs<R, 16, NSL>& r, int lo, int 
 // in r.omc[m][p] (the one-row kernels' register table is unused here).  Twiddles: pcw[s * 96 + e] = w_N^{s x} -- 96 entries per
 // sub-row that depend on N only (build_pcw); the G groups of a wavefront read the same sixteen.
 constexpr int PKS_SPAN = 96;                                         // outputs of a sub-transform the six planes hold
-template <int L0> constexpr int pks_nm() { return L0 == 0 ? 2 : 1; }        // butterflies (a values) per lane
+template <int L0> constexpr int pks_nm() { return L0 <= 0 ? 2 : 1; }        // a values per lane (L0 = -1: the 64-point form, same accumulator layout as L0 = 0)
 constexpr int pks_first_plane(int L0, int S) { return L0 == 0 ? ((S & 1) ? 1 : 5) : ((S & 1) ? 5 : 13); }
 constexpr int pks_plane_mask(int L0, int S) {
   int m = 0;
@@ -664,7 +664,7 @@ FMC_HD void pks_accumulate(Exec& ex, const cpx<R>* pcw_s) {
 // f(oi, re, im) for every window output this lane holds after the last pks_accumulate; N the full row length
 template <class R, int L0, class F>
 FMC_HD void pks_outputs(int lane, const LaneRegs<R, 16, pks_nm<L0>()>& r, int N, int lo, int Np, F f) {
-  const int a = lane & (L0 == 0 ? 7 : 15);
+  const int a = lane & (L0 <= 0 ? 7 : 15);
 #pragma unroll
   for (int p = 0; p < 6; ++p)
 #pragma unroll
@@ -687,90 +687,69 @@ inline void build_pcw(cpx<R>* pcw, int N, int S, CosSin cs) {
 // ---------------------------------------------------------------- N = S x 64 (192, 320, 448, 576): packed sub-rows of SIXTY-FOUR points
 // The sub-transform is shorter than the window: every one of its 64 outputs is needed, and those whose residue falls twice into the 96
 // window positions x = N / 2 - 48 + e (S odd: N / 2 - 48 = 48 mod 64, so residues 48 ... 63 and 0 ... 15) are needed for BOTH, with
-// different twiddles.  A wavefront transforms SIXTEEN rows at a time, four lanes per sub-row: lane (g, q) holds c_s[q + 4 j], j < 16,
-//   Z_q[a] = sum_j c_s[q + 4 j] w_16^{ja},   T_q[a] = w_64^{qa} Z_q[a]            (radix 16 in registers, twiddle)
-//   exchange inside the four lanes: lane q collects T_{q'}[a_m], a_m = q + 4 m, m < 4, q' < 4
-//   Y_s[a_m + 16 b] = sum_{q'} w_4^{q' b} T_{q'}[a_m], b < 4                       (four radix-4 butterflies per lane)
-//   acc[m][p] += pcw[s][a_m + 16 p] Y_s[a_m + 16 b(p)],  p < 6,  b(p) = (p + 3) mod 4      (e = a_m + 16 p: the window offset)
-// -- the SAME 96-entry table and the same output map as the 256-point sub-rows (e = a + 16 p), 24 accumulators per lane
-// (r.omc[m][p]).  Exchange image E[a][lane] at 65 a + lane in the 8.4 KB buffer of the other packed rows.
+// different twiddles.  A wavefront transforms EIGHT rows at a time, EIGHT lanes per sub-row and eight values per lane (64 = 8 x 8):
+// lane (g, q) holds c_s[q + 8 j], j < 8,
+//   Z_q[a] = sum_j c_s[q + 8 j] w_8^{ja},   T_q[a] = w_64^{qa} Z_q[a]              (radix 8 in registers, twiddle)
+//   exchange inside the eight lanes: lane a collects T_{q'}[a], q' < 8
+//   Y_s[a + 8 b] = sum_{q'} w_8^{q' b} T_{q'}[a], b < 8                            (ONE radix-8 butterfly per lane: all 64 outputs)
+//   acc[e] += pcw[s][e] Y_s[a + 8 b(p')],  e = a + 8 p', p' < 12,  b(p') = (p' + 6) mod 8
+// -- the SAME 96-entry table as the longer sub-rows, and the accumulator layout of the 128-point form (lane i < 8 holds e = i + 8 m +
+// 16 p in r.omc[m][p], m < 2, p < 6: p' = m + 2 p), so pks_clear / pks_outputs and the column kernel's epilogue serve L0 = -1 as they
+// serve L0 = 0.  Twelve accumulators and eight values per lane: three to four waves per SIMD where a sixteen-values form with four
+// lanes per sub-row (24 accumulators, 255 registers) ran two (profiles/r06_ab_packed_subrows.txt section 6).  Exchange image E[a][lane]
+// at 65 a + lane.  The generator draws N / 8 streams of EIGHT advances on these grids (fmc_core.h: stream_lanes).
 constexpr int PKS64_SE = 65;
-template <class R, class Exec>
-FMC_HD void pks64_clear(Exec& ex) {
-  ex.each([&](int, LaneRegs<R, 16, 4>& r) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int p = 0; p < 6; ++p) r.omc[m][p] = mk<R>((R)0, (R)0);
-  });
-}
-// one sub-row pass: r.v[j] = c_s[q + 4 j] (input-side sign folded in) -> the accumulators; tw64[a * 4 + q] = w_64^{q a}
+// one sub-row pass: r.v[j] = c_s[q + 8 j], j < 8 (input-side sign folded in) -> the accumulators; tw64[a * 8 + q] = w_64^{q a}
 template <class R, class Exec>
 FMC_HD void pks64_pass(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw64, const cpx<R>* pcw_s) {
   using X = Xch<R>;
   using E = typename X::E;
   constexpr int NC = X::NC;
-  ex.each([&](int lane, LaneRegs<R, 16, 4>& r) {
-    cpx<R> z[16];
+  ex.each([&](int lane, LaneRegs<R, 16, 2>& r) {
+    cpx<R> z[8];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) z[j] = r.v[j];
-    dft_reg<16, R>(z);
+    for (int j = 0; j < 8; ++j) z[j] = r.v[j];
+    fft_dif<8, R>(z);
     r.v[0] = z[0];
 #pragma unroll
-    for (int a = 1; a < 16; ++a) r.v[a] = cmul(z[a], tw64[a * 4 + (lane & 3)]);
+    for (int a = 1; a < 8; ++a) r.v[a] = cmul(z[brev(a, 3)], tw64[a * 8 + (lane & 7)]);
   });
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    ex.each([&](int lane, LaneRegs<R, 16, 4>& r) {
+    ex.each([&](int lane, LaneRegs<R, 16, 2>& r) {
 #pragma unroll
-      for (int a = 0; a < 16; ++a) ex.st(xbuf + a * PKS64_SE + lane, X::pack(r.v[a], c));
+      for (int a = 0; a < 8; ++a) ex.st(xbuf + a * PKS64_SE + lane, X::pack(r.v[a], c));
     });
     ex.sync();
-    ex.each([&](int lane, LaneRegs<R, 16, 4>& r) {
-      const int q = lane & 3;
+    ex.each([&](int lane, LaneRegs<R, 16, 2>& r) {
+      const int q = lane & 7;
       const E* e = xbuf + q * PKS64_SE + (lane - q);
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) X::unpack(r.v[4 * m + qq], ex.ld(e + 4 * m * PKS64_SE + qq), c);
+      for (int qq = 0; qq < 8; ++qq) X::unpack(r.v[qq], ex.ld(e + qq), c);
     });
     ex.sync();
   }
-  ex.each([&](int lane, LaneRegs<R, 16, 4>& r) {
-    const bool neg = (lane & 1) != 0;            // x = a_m + 16 b (+ 64 k) has the parity of q: the output-side fftshift sign
-    const cpx<R>* w = pcw_s + (lane & 3);
+  ex.each([&](int lane, LaneRegs<R, 16, 2>& r) {
+    const bool neg = (lane & 1) != 0;            // x = a + 8 b (+ 64 k) has the parity of a: the output-side fftshift sign
+    const cpx<R>* w = pcw_s + (lane & 7);
+    cpx<R> t[8];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      cpx<R> t[4];
+    for (int qq = 0; qq < 8; ++qq) t[qq] = r.v[qq];
+    fft_dif<8, R>(t);
+    cpx<R> y[8];
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) t[qq] = r.v[4 * m + qq];
-      fft_dif<4, R>(t);
-      cpx<R> y[4];
+    for (int b = 0; b < 8; ++b) { y[b] = t[brev(b, 3)]; y[b].x = flip_sign(y[b].x, neg); y[b].y = flip_sign(y[b].y, neg); }
 #pragma unroll
-      for (int b = 0; b < 4; ++b) { y[b] = t[brev(b, 2)]; y[b].x = flip_sign(y[b].x, neg); y[b].y = flip_sign(y[b].y, neg); }
-#pragma unroll
-      for (int p = 0; p < 6; ++p) r.omc[m][p] = cfma(ex.ld(w + 4 * m + 16 * p), y[(p + 3) & 3], r.omc[m][p]);
-    }
+    for (int pp = 0; pp < 12; ++pp) r.omc[pp & 1][pp >> 1] = cfma(ex.ld(w + 8 * pp), y[(pp + 6) & 7], r.omc[pp & 1][pp >> 1]);
   });
-}
-template <class R, class F>
-FMC_HD void pks64_outputs(int lane, const LaneRegs<R, 16, 4>& r, int N, int lo, int Np, F f) {
-  const int q = lane & 3;
-#pragma unroll
-  for (int p = 0; p < 6; ++p)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int oi = N / 2 - 48 + q + 4 * m + 16 * p - lo;
-      if (oi >= 0 && oi < Np) f(oi, r.omc[m][p].x, r.omc[m][p].y);
-    }
 }
 template <class R, class CosSin>
 inline void build_tw64(cpx<R>* tw, CosSin cs) {
-  for (int a = 0; a < 16; ++a)
-    for (int q = 0; q < 4; ++q) {
+  for (int a = 0; a < 8; ++a)
+    for (int q = 0; q < 8; ++q) {
       double c, sn;
       cs((double)((q * a) % 64) / 64.0, &c, &sn);
-      tw[a * 4 + q] = mk<R>((R)c, (R)(-sn));
+      tw[a * 8 + q] = mk<R>((R)c, (R)(-sn));
     }
 }
 

@@ -173,7 +173,10 @@ def pks_split(N):
 
 def stream_lanes(N):
     """fmc_core.h: stream_lanes -- generator streams per row: N / 16 on the packed grids (128, 256, 512) and on the grids of
-    the packed sub-rows (192, 320, 448, 576, 640, 768, 896, 1152, 1280, 1536, 1792): sixteen draws per stream; 50 S on the 50-lane grids, else 64 * spec_split(N)."""
+    the packed sub-rows of 256 / 128 points (640, 768, 896, 1152, 1280, 1536, 1792): sixteen draws per stream; N / 8 on those of 64 points
+    (192, 320, 448, 576): eight draws; 50 S on the 50-lane grids, else 64 * spec_split(N)."""
+    if pks_split(N) and N % 128:        # sub-rows of 64 points (192, 320, 448, 576): eight draws per stream
+        return N // 8
     if pk_grid(N) or pks_split(N):
         return N // 16
     return 50 * mr_split(N) if mr_supported(N) else 64 * spec_split(N)

@@ -386,12 +386,12 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (256, 82, None, "k_rows_pk<double, 1, 2, 0>"), (256, 200, None, "k_rows_pk<double, 1, 2, 1>"), (256, 82, 100, "k_rows_pk<double, 1, 2, 1>"),
             (512, 96, None, "k_rows_pk<double, 2, 2, 0>"), (512, 250, 7, "k_rows_pk<double, 2, 2, 1>"),
             # the other one-row-per-wave grids (192 ... 1792): the plain variant, windows of up to 128 / 256 pixels
-            # 192 / 320 / 448 / 576 (round 6): sub-rows of SIXTY-FOUR points, sixteen rows per wavefront (k_rows_pks64); windows the 96
+            # 192 / 320 / 448 / 576 (round 6): sub-rows of SIXTY-FOUR points, eight rows per wavefront (k_rows_pks<R, -1, S, MODE>); windows the 96
             # centred outputs do not hold are staged (MODE 1 rows)
-            (192, 30, None, "k_rows_pks64<double, 3, 2>"), (192, 96, None, "k_rows_pks64<double, 3, 2>"), (320, 82, 3, "k_rows_wave<double, 5, 2, 1, 1, 0>"),
-            (320, 82, None, "k_rows_pks64<double, 5, 2>"), (448, 60, 200, "k_rows_pks64<double, 7, 2>"),
+            (192, 30, None, "k_rows_pks<double, -1, 3, 2>"), (192, 96, None, "k_rows_pks<double, -1, 3, 2>"), (320, 82, 3, "k_rows_wave<double, 5, 2, 1, 1, 0>"),
+            (320, 82, None, "k_rows_pks<double, -1, 5, 2>"), (448, 60, 200, "k_rows_pks<double, -1, 7, 2>"),
             (384, 60, None, "k_rows_wave<double, 6, 2, 2, 1, 0>"), (448, 128, None, "k_rows_wave<double, 7, 2, 1, 1, 0>"),
-            (576, 82, None, "k_rows_pks64<double, 9, 2>"), (576, 96, 240, "k_rows_pks64<double, 9, 2>"), (576, 200, None, "k_rows_wave<double, 9, 4, 1, 1, 0>"),
+            (576, 82, None, "k_rows_pks<double, -1, 9, 2>"), (576, 96, 240, "k_rows_pks<double, -1, 9, 2>"), (576, 200, None, "k_rows_wave<double, 9, 4, 1, 1, 0>"),
             (640, 82, None, "k_rows_pks<double, 0, 5, 2>"), (640, 96, 272, "k_rows_pks<double, 0, 5, 2>"), (640, 250, 11, "k_rows_wave<double, 10, 4, 1, 1, 0>"),
             # 640, 768, 896, 1152, 1280, 1536, 1792 (round 6): the packed sub-rows for centred windows of up to 96 pixels (also shifted inside the six planes);
             # any other window is STAGED (k_gen_coeffs_f64 -> MODE 1 rows: these grids draw N / 16 streams per row)
@@ -450,7 +450,7 @@ def test_fused_float64_generator_rows_match_the_oracle_on_restated_draws(N, Np, 
 
 
 @pytest.mark.parametrize("N,Np,kernel", [(1280, 82, "k_rows_pks<double, 1, 5, 2>"), (896, 60, "k_rows_pks<double, 0, 7, 2>"), (1536, 96, "k_rows_pks<double, 1, 6, 2>"),
-                                         (576, 82, "k_rows_pks64<double, 9, 2>")])
+                                         (576, 82, "k_rows_pks<double, -1, 9, 2>")])
 def test_device_generator_screens_on_the_packed_subrow_grids(N, Np, kernel):
     """`fastmc_screens` (EPI 1: the cropped screens themselves) on the grids of the packed sub-rows: the rows are k_rows_pks, the column
     pass the one-row-per-wave kernel launched alone (dispatch mode -1).  Against the oracle's transform of the restated float64 draws,

@@ -120,7 +120,7 @@ def test_stream_layout_of_the_50_lane_grids():
     # the packed sub-rows (round 6): N = 256 S, S = 3, 5, 7 -- sixteen draws per stream, as on the packed grids
     assert devrng.stream_lanes(768) == 48 and devrng.stream_lanes(1280) == 80 and devrng.stream_lanes(1792) == 112
     assert devrng.stream_lanes(1536) == 96 and devrng.stream_lanes(896) == 56 and devrng.stream_lanes(1152) == 72 and devrng.stream_lanes(640) == 40
-    assert devrng.stream_lanes(576) == 36 and devrng.stream_lanes(448) == 28 and devrng.stream_lanes(320) == 20 and devrng.stream_lanes(192) == 12
+    assert devrng.stream_lanes(576) == 72 and devrng.stream_lanes(448) == 56 and devrng.stream_lanes(320) == 40 and devrng.stream_lanes(192) == 24      # eight draws per stream
     assert devrng.stream_lanes(384) == 64
     # wave-family grids with a run-time sub-row count: 64 S streams per row
     assert [(n, devrng.wave_rt_split(n)) for n in range(2, 4097) if devrng.wave_rt_split(n)] == [

@@ -497,6 +497,7 @@ int main() {
   bad += sweep_pks<double, 1, 5>("f64", 1e-13);
   bad += sweep_pks<double, 1, 6>("f64", 1e-13);
   bad += sweep_pks<double, 1, 7>("f64", 1e-13);
+  bad += sweep_pks<double, 0, 3>("f64", 1e-13);
   bad += sweep_pks<double, 0, 5>("f64", 1e-13);
   bad += sweep_pks<double, 0, 7>("f64", 1e-13);
   bad += sweep_pks<double, 0, 9>("f64", 1e-13);

@@ -1277,7 +1277,7 @@ int dispatch_pks(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in
     if (epi == 0) launch_pks_cols<R, LL, SS, 0>(h, CA); else launch_pks_cols<R, LL, SS, 1>(h, CA); \
     return 0;                                                                             \
   }
-  FMC_PKSC(1, 3) FMC_PKSC(1, 5) FMC_PKSC(1, 6) FMC_PKSC(1, 7) FMC_PKSC(0, 5) FMC_PKSC(0, 7) FMC_PKSC(0, 9)
+  FMC_PKSC(1, 3) FMC_PKSC(1, 5) FMC_PKSC(1, 6) FMC_PKSC(1, 7) FMC_PKSC(0, 3) FMC_PKSC(0, 5) FMC_PKSC(0, 7) FMC_PKSC(0, 9)
   FMC_PKSC(-1, 3) FMC_PKSC(-1, 5) FMC_PKSC(-1, 7) FMC_PKSC(-1, 9)
 #undef FMC_PKSC
   return fail(FASTMC_ESTATE, "no packed sub-row column kernel for this grid");
@@ -1293,7 +1293,7 @@ int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode) {
     if (mode == 0) { launch_pks_rows<R, LL, SS, 0>(h, RA); return 0; }                                    \
     if constexpr (sizeof(R) == 8) { if (mode == 2) { launch_pks_rows<R, LL, SS, 2>(h, RA); return 0; } }  \
   }
-  FMC_PKS(1, 3) FMC_PKS(1, 5) FMC_PKS(1, 6) FMC_PKS(1, 7) FMC_PKS(0, 5) FMC_PKS(0, 7) FMC_PKS(0, 9)
+  FMC_PKS(1, 3) FMC_PKS(1, 5) FMC_PKS(1, 6) FMC_PKS(1, 7) FMC_PKS(0, 3) FMC_PKS(0, 5) FMC_PKS(0, 7) FMC_PKS(0, 9)
   FMC_PKS(-1, 3) FMC_PKS(-1, 5) FMC_PKS(-1, 7) FMC_PKS(-1, 9)
 #undef FMC_PKS
 

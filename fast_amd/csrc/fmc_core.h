@@ -462,7 +462,7 @@ FMC_HD constexpr bool mr_supported(int N) { return mr_split(N) > 0; }
 // block per lane serves the 8 / 4 / 2 rows a wavefront transforms at once.
 FMC_HD constexpr bool pk_grid(int N) { return N == 128 || N == 256 || N == 512; }
 // Grids of the packed SUB-ROWS (round 6; fmc_wavefft.h: pks_accumulate, fmc_kernels.h: k_rows_pks): N = S M with M = 256 (S = 3, 5,
-// 6, 7: 768, 1280, 1536, 1792), M = 128 (S = 5, 7, 9: 640, 896, 1152) or M = 64 (S = 3, 5, 7, 9: 192, 320, 448, 576) -- a row is transformed as S interleaved sub-rows
+// 6, 7: 768, 1280, 1536, 1792), M = 128 (S = 3, 5, 7, 9: 384, 640, 896, 1152) or M = 64 (S = 3, 5, 7, 9: 192, 320, 448, 576) -- a row is transformed as S interleaved sub-rows
 // (kx = s mod S) of M points, FOUR / EIGHT / EIGHT rows at a time on the packed pipeline of the 256 / 128-point grid (64: its own 8 x 8 form), and the window
 // outputs are combined by decimation in time in registers.  They replace the one-row-per-wave kernels with N / 64 = 10 ... 28
 // values per lane for the device generator (up to 338 registers, one or two waves per SIMD: 0.61-0.79 of the 1024-point row's
@@ -470,7 +470,7 @@ FMC_HD constexpr bool pk_grid(int N) { return N == 128 || N == 256 || N == 512; 
 // stream t = kx mod SL: lane q of sub-row s reads ONE stream (t = s + S q) sequentially.
 FMC_HD constexpr int pks_split(int N) {
   return N == 768 ? 3 : (N == 1280 ? 5 : (N == 1536 ? 6 : (N == 1792 ? 7 : (N == 640 ? 5 : (N == 896 ? 7 : (N == 1152 ? 9 :
-         (N == 576 ? 9 : (N == 448 ? 7 : (N == 320 ? 5 : (N == 192 ? 3 : 0))))))))));
+         (N == 576 ? 9 : (N == 448 ? 7 : (N == 320 ? 5 : (N == 192 ? 3 : (N == 384 ? 3 : 0)))))))))));
 }
 // M = 16 * pk_lanes(L0): 256 (L0 = 1) or 128 (L0 = 0); -1: sub-rows of SIXTY-FOUR points (192, 320, 448, 576 = 3, 5, 7, 9 x 64: eight
 // rows per wavefront, eight lanes per sub-row, eight draws per generator stream: fmc_wavefft.h: pks64_pass)

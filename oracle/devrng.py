@@ -166,9 +166,9 @@ def pk_grid(N):
 
 
 def pks_split(N):
-    """fmc_core.h: pks_split -- grids of the packed SUB-ROWS (round 6): N = S * 256 (S = 3, 5, 6, 7), S * 128 (S = 5, 7, 9) or
+    """fmc_core.h: pks_split -- grids of the packed SUB-ROWS (round 6): N = S * 256 (S = 3, 5, 6, 7), S * 128 (S = 3, 5, 7, 9) or
     S * 64 (S = 3, 5, 7, 9); 0 otherwise."""
-    return {768: 3, 1280: 5, 1536: 6, 1792: 7, 640: 5, 896: 7, 1152: 9, 576: 9, 448: 7, 320: 5, 192: 3}.get(N, 0)
+    return {768: 3, 1280: 5, 1536: 6, 1792: 7, 384: 3, 640: 5, 896: 7, 1152: 9, 576: 9, 448: 7, 320: 5, 192: 3}.get(N, 0)
 
 
 def stream_lanes(N):

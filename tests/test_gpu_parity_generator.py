@@ -266,7 +266,7 @@ _VARIANTS = [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, No
              (1152, 82, None), (1280, 82, None), (1536, 82, None), (1792, 82, None), (512, 82, None), (256, 82, None), (768, 152, None),
              (768, 82, None), (768, 96, 333), (1280, 40, None), (1792, 82, 857), (1280, 82, 100),     # packed sub-rows; (768, 152) and (1280, 82, 100): beyond them
              (640, 82, None), (896, 82, None), (896, 96, 401), (1152, 64, None), (1536, 82, 730), (640, 82, 0),
-             (576, 82, None), (576, 40, 250), (448, 82, None), (320, 96, None), (192, 82, None), (576, 82, 100),     # sub-rows of 64 points; the last: beyond them
+             (576, 82, None), (576, 40, 250), (448, 82, None), (320, 96, None), (192, 82, None), (576, 82, 100), (384, 82, None),     # sub-rows of 64 points; the last: beyond them
              (1000, 82, None), (2000, 82, None), (1200, 82, None), (500, 82, None), (3072, 82, None), (1344, 82, None),
              (164, 82, None), (943, 82, None),
              # packed rows (eight / four / two rows per wavefront): six centred planes, all planes, off-centre and wide windows, the whole
@@ -390,7 +390,7 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             # centred outputs do not hold are staged (MODE 1 rows)
             (192, 30, None, "k_rows_pks<double, -1, 3, 2>"), (192, 96, None, "k_rows_pks<double, -1, 3, 2>"), (320, 82, 3, "k_rows_wave<double, 5, 2, 1, 1, 0>"),
             (320, 82, None, "k_rows_pks<double, -1, 5, 2>"), (448, 60, 200, "k_rows_pks<double, -1, 7, 2>"),
-            (384, 60, None, "k_rows_wave<double, 6, 2, 2, 1, 0>"), (448, 128, None, "k_rows_wave<double, 7, 2, 1, 1, 0>"),
+            (384, 60, None, "k_rows_pks<double, 0, 3, 2>"), (384, 128, None, "k_rows_wave<double, 6, 2, 1, 1, 0>"), (448, 128, None, "k_rows_wave<double, 7, 2, 1, 1, 0>"),
             (576, 82, None, "k_rows_pks<double, -1, 9, 2>"), (576, 96, 240, "k_rows_pks<double, -1, 9, 2>"), (576, 200, None, "k_rows_wave<double, 9, 4, 1, 1, 0>"),
             (640, 82, None, "k_rows_pks<double, 0, 5, 2>"), (640, 96, 272, "k_rows_pks<double, 0, 5, 2>"), (640, 250, 11, "k_rows_wave<double, 10, 4, 1, 1, 0>"),
             # 640, 768, 896, 1152, 1280, 1536, 1792 (round 6): the packed sub-rows for centred windows of up to 96 pixels (also shifted inside the six planes);

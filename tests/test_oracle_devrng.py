@@ -116,12 +116,12 @@ def test_stream_layout_of_the_50_lane_grids():
     assert devrng.stream_lanes(2000) == 100 and devrng.stream_lanes(2500) == 250 and devrng.stream_lanes(4000) == 200
     assert devrng.stream_lanes(550) == 64 and devrng.stream_lanes(164) == 64 and devrng.stream_lanes(1100) == 64
     # packed rows (four / two rows per wavefront): sixteen draws per stream
-    assert devrng.stream_lanes(256) == 16 and devrng.stream_lanes(512) == 32 and devrng.stream_lanes(128) == 8 and devrng.stream_lanes(384) == 64
+    assert devrng.stream_lanes(256) == 16 and devrng.stream_lanes(512) == 32 and devrng.stream_lanes(128) == 8 and devrng.stream_lanes(2048) == 128
     # the packed sub-rows (round 6): N = 256 S, S = 3, 5, 7 -- sixteen draws per stream, as on the packed grids
     assert devrng.stream_lanes(768) == 48 and devrng.stream_lanes(1280) == 80 and devrng.stream_lanes(1792) == 112
     assert devrng.stream_lanes(1536) == 96 and devrng.stream_lanes(896) == 56 and devrng.stream_lanes(1152) == 72 and devrng.stream_lanes(640) == 40
     assert devrng.stream_lanes(576) == 72 and devrng.stream_lanes(448) == 56 and devrng.stream_lanes(320) == 40 and devrng.stream_lanes(192) == 24      # eight draws per stream
-    assert devrng.stream_lanes(384) == 64
+    assert devrng.stream_lanes(384) == 24 and devrng.stream_lanes(1024) == 64
     # wave-family grids with a run-time sub-row count: 64 S streams per row
     assert [(n, devrng.wave_rt_split(n)) for n in range(2, 4097) if devrng.wave_rt_split(n)] == [
         (1344, 3), (1728, 3), (1920, 3), (2304, 2), (2560, 2), (2688, 3), (3072, 2), (3456, 3), (3584, 4), (3840, 3)]

@@ -501,6 +501,17 @@ int main() {
   bad += sweep_pks<double, 0, 5>("f64", 1e-13);
   bad += sweep_pks<double, 0, 7>("f64", 1e-13);
   bad += sweep_pks<double, 0, 9>("f64", 1e-13);
+  // the counts the run-time kernels take (fmc_core.h: pks_rt): the arithmetic knows the count's parity only
+  bad += sweep_pks64<double, 21>("f64", 1e-13);
+  bad += sweep_pks64<double, 27>("f64", 1e-13);
+  bad += sweep_pks<double, 0, 15>("f64", 1e-13);
+  bad += sweep_pks<double, 0, 21>("f64", 1e-13);
+  bad += sweep_pks<double, 0, 27>("f64", 1e-13);
+  bad += sweep_pks<double, 1, 9>("f64", 1e-13);
+  bad += sweep_pks<double, 1, 10>("f64", 1e-13);
+  bad += sweep_pks<double, 1, 12>("f64", 1e-13);
+  bad += sweep_pks<double, 1, 14>("f64", 1e-13);
+  bad += sweep_pks<double, 1, 15>("f64", 1e-13);
   bad += sweep_pks<float, 1, 5>("f32", 2e-5);
   bad += sweep_pks<float, 0, 7>("f32", 2e-5);
   bad += sweep_pk<double, 0>("f64", 1e-13);

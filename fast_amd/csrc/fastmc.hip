@@ -100,6 +100,8 @@ struct fastmc_ctx {
 
   void* amp = nullptr;     // R[N*N]  unsigned (direct family)
   void* amp_s = nullptr;   // R[N*N]  with (-1)^(ky+kx)  (wave family)
+  void* amp_p = nullptr;   // grids of the packed sub-rows: amp_s / ampf_s with every row stored sub-row major (fmc_kernels.h: k_make_amp)
+  float* ampf_p = nullptr;
   float* ampf = nullptr;   // amp / amp_s times sqrt(2 ln 2) in float32: colouring of the device generator's draws
   float* ampf_s = nullptr; //   (fmc_kernels.h: box_muller_scaled)
   unsigned int* bad = nullptr;   // count of invalid spectrum entries (k_make_amp)
@@ -571,7 +573,7 @@ static void destroy_now(fastmc_ctx* h) {
   if (h->nps) { nps_free(h->nps); h->nps = nullptr; }
 #endif
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
-  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->pks_tw1, h->pks_cw, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->amp_p, h->ampf_p, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->pks_tw1, h->pks_cw, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers, h->ps_dev, (void*)h->clk};
   for (void* p : ptrs)
@@ -754,9 +756,10 @@ static int make_amp(fastmc_ctx* h, const double* d_ps, double df, hipStream_t st
   if (!h->ampf) HIPCHK(hipMalloc((void**)&h->ampf, sizeof(float) * n));
   if (!h->ampf_s) HIPCHK(hipMalloc((void**)&h->ampf_s, sizeof(float) * n));
   if (!h->bad) HIPCHK(hipMalloc((void**)&h->bad, 8));
+  if (pks_grid(N) && !h->amp_p) { HIPCHK(hipMalloc(&h->amp_p, sizeof(R) * n)); HIPCHK(hipMalloc((void**)&h->ampf_p, sizeof(float) * n)); }
   HIPCHK(hipMemsetAsync(h->bad, 0, 8, stream));
   hipLaunchKernelGGL((k_make_amp<R>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_ps, df, N, (R*)h->amp,
-                     (R*)h->amp_s, h->ampf, h->ampf_s, h->bad);
+                     (R*)h->amp_s, h->ampf, h->ampf_s, h->bad, (R*)h->amp_p, h->ampf_p, pks_grid(N) ? pks_split(N) : 1);
   HIPCHK(hipGetLastError());
   unsigned int bad = 0;
   HIPCHK(hipMemcpyAsync(&bad, h->bad, 4, hipMemcpyDeviceToHost, stream));
@@ -1240,10 +1243,12 @@ int dispatch_pk(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int m
 template <class R, int L0, int S, int MODE>
 static void launch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
   using C = PksCfg<R, L0, S>;
-  const size_t lds = pks_lds_bytes<R, L0, S>() + (MODE == 2 ? GEN64_TABLE_BYTES : 0);
+  const int Sr = S > 0 ? S : pks_split(RA.N);        // S <= 0: the sub-row count at run time (fmc_core.h: pks_rt)
+  const size_t lds = pks_lds_bytes<R, L0, S>(Sr) + (MODE == 2 ? GEN64_TABLE_BYTES : 0);
   constexpr int LR = 128 / (int)sizeof(cpx<R>), LU = LR / C::G, BPG = ROWS_PER_WAVE * C::WPB / LU;
-  int blocks = (C::N / LR) * ((RA.nb + BPG - 1) / BPG);
+  int blocks = (Sr * C::M / LR) * ((RA.nb + BPG - 1) / BPG);
   RowArgs<R> B = RA;
+  B.S = Sr;
   hipFuncSetAttribute((const void*)k_rows_pks<R, L0, S, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   static const int persist = getenv("FASTMC_ROWS_PERSIST") ? atoi(getenv("FASTMC_ROWS_PERSIST")) : 1;
   if (persist) {        // as launch_rows_wave: a launch of many rounds keeps its workgroups, which walk its tiles
@@ -1258,10 +1263,13 @@ template <class R, int L0, int S, int EPI>
 static void launch_pks_cols(fastmc_ctx* h, const ColArgs<R>& CA) {
   using C = PksCfg<R, L0, S>;
   constexpr int WPC = PksColCfg<R, L0, S>::WPC;
-  const size_t lds = pks_cols_lds_bytes<R, L0, S>();
+  const int Sr = S > 0 ? S : pks_split(CA.N);
+  const size_t lds = pks_cols_lds_bytes<R, L0, S>(Sr);
   const int items = CA.nb * ((CA.Np + C::G - 1) / C::G);
+  ColArgs<R> B = CA;
+  B.S = Sr;
   hipFuncSetAttribute((const void*)k_cols_pks<R, L0, S, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_cols_pks<R, L0, S, EPI>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), lds, h->stream, CA);
+  hipLaunchKernelGGL((k_cols_pks<R, L0, S, EPI>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), lds, h->stream, B);
   FMC_NOTE(h->last_cols, "k_cols_pks<%s, %d, %d, %d>", rname<R>(), L0, S, EPI);
 }
 // rows (device generator) and columns of the packed sub-rows: the pair keeps V permuted along ky (fmc_kernels.h: k_rows_pks)
@@ -1271,7 +1279,8 @@ int dispatch_pks(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in
   Span s(h, 1);
   ColArgs<R> CA = CA_in;
   CA.tw = (const cpx<R>*)h->pks_tw1; CA.cw = (const cpx<R>*)h->pks_cw;
-  const int S = pks_split(h->N), L0 = pks_L0(h->N);
+  // (the grids of pks_rt: the kernels with a run-time count -- S = 0 odd, -2 even; float64 pipeline only, fastmc_create)
+  const int S = pks_rt(h->N) ? ((pks_rt(h->N) & 1) ? 0 : -2) : pks_split(h->N), L0 = pks_L0(h->N);
 #define FMC_PKSC(LL, SS)                                                                  \
   if (L0 == LL && S == SS) {                                                              \
     if (epi == 0) launch_pks_cols<R, LL, SS, 0>(h, CA); else launch_pks_cols<R, LL, SS, 1>(h, CA); \
@@ -1279,15 +1288,16 @@ int dispatch_pks(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in
   }
   FMC_PKSC(1, 3) FMC_PKSC(1, 5) FMC_PKSC(1, 6) FMC_PKSC(1, 7) FMC_PKSC(0, 3) FMC_PKSC(0, 5) FMC_PKSC(0, 7) FMC_PKSC(0, 9)
   FMC_PKSC(-1, 3) FMC_PKSC(-1, 5) FMC_PKSC(-1, 7) FMC_PKSC(-1, 9)
+  if constexpr (sizeof(R) == 8) { FMC_PKSC(1, 0) FMC_PKSC(1, -2) FMC_PKSC(0, 0) FMC_PKSC(-1, 0) }
 #undef FMC_PKSC
   return fail(FASTMC_ESTATE, "no packed sub-row column kernel for this grid");
 }
 template <class R>
 int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode) {
   Span s(h, 0);
-  const int S = pks_split(h->N), L0 = pks_L0(h->N);
+  const int S = pks_rt(h->N) ? ((pks_rt(h->N) & 1) ? 0 : -2) : pks_split(h->N), L0 = pks_L0(h->N);
   RowArgs<R> RA = RA_in;      // the family's own tables; the colouring tables with the input-side fftshift sign folded in
-  RA.amp = (const R*)h->amp_s; RA.ampf = h->ampf_s; RA.tw = (const cpx<R>*)h->pks_tw1; RA.cw = (const cpx<R>*)h->pks_cw;
+  RA.amp = (const R*)h->amp_p; RA.ampf = h->ampf_p; RA.tw = (const cpx<R>*)h->pks_tw1; RA.cw = (const cpx<R>*)h->pks_cw;
 #define FMC_PKS(LL, SS)                                                                                   \
   if (L0 == LL && S == SS) {                                                                              \
     if (mode == 0) { launch_pks_rows<R, LL, SS, 0>(h, RA); return 0; }                                    \
@@ -1295,6 +1305,7 @@ int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode) {
   }
   FMC_PKS(1, 3) FMC_PKS(1, 5) FMC_PKS(1, 6) FMC_PKS(1, 7) FMC_PKS(0, 3) FMC_PKS(0, 5) FMC_PKS(0, 7) FMC_PKS(0, 9)
   FMC_PKS(-1, 3) FMC_PKS(-1, 5) FMC_PKS(-1, 7) FMC_PKS(-1, 9)
+  if constexpr (sizeof(R) == 8) { FMC_PKS(1, 0) FMC_PKS(1, -2) FMC_PKS(0, 0) FMC_PKS(-1, 0) }
 #undef FMC_PKS
 
   return fail(FASTMC_ESTATE, "no packed sub-row kernel for this grid / mode");

@@ -468,9 +468,16 @@ FMC_HD constexpr bool pk_grid(int N) { return N == 128 || N == 256 || N == 512; 
 // values per lane for the device generator (up to 338 registers, one or two waves per SIMD: 0.61-0.79 of the 1024-point row's
 // rate per pixel; 1536: 0.93).  Their rows are drawn as N / 16 streams of sixteen advances (64-point sub-rows: N / 8 streams of eight),
 // stream t = kx mod SL: lane q of sub-row s reads ONE stream (t = s + S q) sequentially.
+// The grids of wave_rt_split up to 3840 take the same kernels with the sub-row count at RUN TIME (pks_rt): 2304, 2560, 3072, 3584,
+// 3840 = 9, 10, 12, 14, 15 x 256; 1920, 2688, 3456 = 15, 21, 27 x 128; 1344, 1728 = 21, 27 x 64 (their one-row-per-wave kernels ran
+// 0.58-0.72 of the 1024-point row's rate per pixel with two to four sub-rows of 7 ... 24 values per lane).
+FMC_HD constexpr int pks_rt(int N) {
+  return N == 2304 ? 9 : (N == 2560 ? 10 : (N == 3072 ? 12 : (N == 3584 ? 14 : (N == 3840 ? 15 : (N == 1920 ? 15 : (N == 2688 ? 21 :
+         (N == 3456 ? 27 : (N == 1344 ? 21 : (N == 1728 ? 27 : 0)))))))));
+}
 FMC_HD constexpr int pks_split(int N) {
   return N == 768 ? 3 : (N == 1280 ? 5 : (N == 1536 ? 6 : (N == 1792 ? 7 : (N == 640 ? 5 : (N == 896 ? 7 : (N == 1152 ? 9 :
-         (N == 576 ? 9 : (N == 448 ? 7 : (N == 320 ? 5 : (N == 192 ? 3 : (N == 384 ? 3 : 0)))))))))));
+         (N == 576 ? 9 : (N == 448 ? 7 : (N == 320 ? 5 : (N == 192 ? 3 : (N == 384 ? 3 : pks_rt(N))))))))))));
 }
 // M = 16 * pk_lanes(L0): 256 (L0 = 1) or 128 (L0 = 0); -1: sub-rows of SIXTY-FOUR points (192, 320, 448, 576 = 3, 5, 7, 9 x 64: eight
 // rows per wavefront, eight lanes per sub-row, eight draws per generator stream: fmc_wavefft.h: pks64_pass)

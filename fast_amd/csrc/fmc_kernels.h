@@ -164,6 +164,7 @@ struct RowArgs {
   int N, Np, lo, nb;            // grid size, window size, first window index, realisations in this launch
   int tiles = 0;                // k_rows_wave: tiles of the launch when its workgroups walk them (0: one tile per workgroup)
   int rpw = 0;                  // k_rows_wave / _mr / _blu: rows per wave of this launch (0: ROWS_PER_WAVE); small launches take fewer (pick_rpw)
+  int S = 0;                    // k_rows_pks with a RUN-TIME sub-row count (template S <= 0: the grids beyond 1792): the count
   const R* amp;                 // [N][N] sqrt(powerspec)*df  (wave family: with (-1)^(ky+kx) folded in); host-coefficient mode
   const float* ampf;            // the same table rounded to float32: colouring of the device generator's float32 normals
   const cpx<R>* tw;             // wave: tw1 [P*64];  direct: w_N^e, e < N
@@ -193,6 +194,7 @@ struct SubharmArgs {
 template <class R>
 struct ColArgs {
   int N, Np, lo, nb;
+  int S = 0;                    // k_cols_pks with a run-time sub-row count (see RowArgs)
   const cpx<R>* V;              // [nb][Np][N]
   const cpx<R>* tw;
   const cpx<R>* om;
@@ -964,8 +966,11 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPC * 64), (PkCfg<R, L0, D>::CMIN
 template <class R, int L0_, int S> struct PksCfg {
   // L0 = 1 / 0: sub-rows of 256 / 128 points on the packed pipeline (sixteen values per lane, L = 16 / 8 lanes per sub-row);
   // L0 = -1: sub-rows of SIXTY-FOUR points (192, 320, 448, 576): eight values per lane, eight lanes per sub-row (fmc_wavefft.h: pks64_pass)
-  static constexpr int L0 = L0_, L = L0 < 0 ? 8 : pk_lanes(L0), VPL = L0 < 0 ? 8 : 16, G = WAVE / L, M = VPL * L, N = S * M, NM = pks_nm<L0>();
-  static constexpr int B0M = L0 < 0 ? 0xFF : pks_plane_mask(L0 < 0 ? 0 : L0, S), FIRST = pks_first_plane(L0 < 0 ? 0 : L0, S);
+  // S > 0: the sub-row count at compile time (192 ... 1792); S = 0 / -2: an odd / even count at RUN TIME (RowArgs::S: the grids of
+  // fmc_core.h wave_rt_split up to 3840 -- 2304 = 9 x 256 ... 3840 = 15 x 256, 1920 ... 3456 = 15, 21, 27 x 128, 1344 / 1728 = 21 / 27 x 64)
+  static constexpr int L0 = L0_, L = L0 < 0 ? 8 : pk_lanes(L0), VPL = L0 < 0 ? 8 : 16, G = WAVE / L, M = VPL * L, NM = pks_nm<L0>();
+  static constexpr int SP = S > 0 ? S : (S == 0 ? 3 : 2);        // a count of the same parity: the plane set depends on it only
+  static constexpr int B0M = L0 < 0 ? 0xFF : pks_plane_mask(L0 < 0 ? 0 : L0, SP), FIRST = pks_first_plane(L0 < 0 ? 0 : L0, SP);
   static constexpr int TWN = VPL * L;                    // entries of the sub-transform's twiddle table
   // 256-point sub-rows: 155 registers with the float64 generator, twelve waves; 128-point sub-rows carry twelve accumulators (48
   // more registers for float64): eight waves; 64-point sub-rows: twelve accumulators but eight values: twelve waves
@@ -973,22 +978,23 @@ template <class R, int L0_, int S> struct PksCfg {
 };
 // LDS carve (dynamic): [generator tables (MODE 2)][tw1 16 L cpx][pcw S x 96 cpx][xbuf WPB * D16_XELEMS 8-byte]
 template <class R, int L0, int S>
-__host__ __device__ constexpr size_t pks_lds_bytes() {
-  return (size_t)(PksCfg<R, L0, S>::TWN + S * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksCfg<R, L0, S>::WPB * D16_XELEMS * 8;
+__host__ __device__ constexpr size_t pks_lds_bytes(int Sr) {
+  return (size_t)(PksCfg<R, L0, S>::TWN + Sr * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksCfg<R, L0, S>::WPB * D16_XELEMS * 8;
 }
 template <class R, int L0, int S, int MODE>
 __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using C = PksCfg<R, L0, S>;
   using E = typename Xch<R>::E;
-  constexpr int L = C::L, G = C::G, N = C::N, WPB = C::WPB, VPL = C::VPL;
+  constexpr int L = C::L, G = C::G, WPB = C::WPB, VPL = C::VPL;
+  const int Sr = S > 0 ? S : A.S, N = Sr * C::M;          // (S > 0: constants, folded; else the launch's)
   Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
   cpx<R>* s_cw = s_tw + C::TWN;
-  E* s_x = reinterpret_cast<E*>(s_cw + S * PKS_SPAN);
+  E* s_x = reinterpret_cast<E*>(s_cw + Sr * PKS_SPAN);
   if constexpr (MODE == 2) { gen64_lds0_check(s_g64); load_gen64_table(s_g64, A.g64); }
   for (int i = threadIdx.x; i < C::TWN; i += blockDim.x) s_tw[i] = A.tw[i];
-  for (int i = threadIdx.x; i < S * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
+  for (int i = threadIdx.x; i < Sr * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * D16_XELEMS;
@@ -1004,7 +1010,7 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
   // consecutive POSITIONS, a half / whole 128-byte line), a tile the LR positions of one line of one row class s.
   constexpr int M = C::M, TPS = M / LR;
   static_assert(M % LR == 0, "whole lines per row class");
-  const int lane_in = gl * S * N + S * q;                // this lane's first input of sub-row 0
+  const int lane_in = gl * Sr * N + q;                   // this lane's first input of a sub-row (colouring tables SUB-ROW MAJOR: k_make_amp amp_p)
   const int tiles = A.tiles ? A.tiles : (int)gridDim.x;
 #pragma unroll 1
   for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
@@ -1017,25 +1023,25 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
     const int b = b0 + flat / LU;
     if (b >= A.nb) break;                                // wave-uniform
     const int mu = m0 + (flat % LU) * G;                 // position of the unit's first row within its class
-    const int ky0 = s_r + S * mu;                        // ... and that row
+    const int ky0 = s_r + Sr * mu;                       // ... and that row
     const uint64_t g = A.g0 + (uint64_t)b;
     pks_clear<R, L0>(ex);
 #pragma unroll 1
-    for (int sp = 0; sp < S; ++sp) {
+    for (int sp = 0; sp < Sr; ++sp) {
       // sub-row sp of the G rows: kx = sp + S (q + L j), stream t = sp + S q of SL = S L
-      xoshiro128p rs = row_stream(A.key, g, ky0 + S * gl, sp + S * q, S * L);
+      xoshiro128p rs = row_stream(A.key, g, ky0 + Sr * gl, sp + Sr * q, Sr * L);
       if (MODE == 0) {
-        const float* ampf = A.ampf + (size_t)ky0 * N + sp;
+        const float* ampf = A.ampf + (size_t)ky0 * N + sp * C::M + lane_in;
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[lane_in + S * L * j]);
+        for (int j = 0; j < VPL; ++j) regs.v[j] = draw_coloured<R>(rs, ampf[L * j]);
       } else if constexpr (MODE == 2) {
         static_assert(sizeof(R) == 8, "the float64 generator feeds the float64 pipeline");
-        const R* amp = A.amp + (size_t)ky0 * N + sp;
-        double an = (double)amp[lane_in];
+        const R* amp = A.amp + (size_t)ky0 * N + sp * C::M + lane_in;
+        double an = (double)amp[0];
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
           const double a = an;
-          if (j + 1 < VPL) an = (double)amp[lane_in + S * L * (j + 1)];
+          if (j + 1 < VPL) an = (double)amp[L * (j + 1)];
           ex.loadfence();
           regs.v[j] = draw_coloured_f64(rs, a, Gen64Lds0{});
           asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
@@ -1057,25 +1063,27 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
 // The column pass of the same grids: G window columns per wavefront, S passes over a column's sub-rows (contiguous in the permuted V),
 // the detector as k_cols_pk's rolled loop over the lane's accumulators, the sums reduced over the L lanes of a column by DPP.
 template <class R, int L0, int S> struct PksColCfg {
+  // (a run-time sub-row count, S <= 0, can be 27: 41 KB of twiddles -- twelve waves)
   // 122 registers (M = 256) / 152 (M = 128: twelve accumulators) with float64: four / three waves per SIMD; the exchange buffers and
   // the tables of sixteen / twelve waves fit the LDS (150 KB / 117 KB at most)
-  static constexpr int WPC = (L0 != 0 || sizeof(R) == 4) ? 16 : 12;      // (64-point sub-rows: 126 registers)
+  static constexpr int WPC = S <= 0 ? 12 : ((L0 != 0 || sizeof(R) == 4) ? 16 : 12);      // (64-point sub-rows: 126 registers)
 };
 template <class R, int L0, int S>
-__host__ __device__ constexpr size_t pks_cols_lds_bytes() {
-  return (size_t)(PksCfg<R, L0, S>::TWN + S * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksColCfg<R, L0, S>::WPC * D16_XELEMS * 8;
+__host__ __device__ constexpr size_t pks_cols_lds_bytes(int Sr) {
+  return (size_t)(PksCfg<R, L0, S>::TWN + Sr * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksColCfg<R, L0, S>::WPC * D16_XELEMS * 8;
 }
 template <class R, int L0, int S, int EPI>
 __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using C = PksCfg<R, L0, S>;
   using E = typename Xch<R>::E;
-  constexpr int L = C::L, G = C::G, N = C::N, M = C::M, NM = C::NM, VPL = C::VPL, WPC = PksColCfg<R, L0, S>::WPC;
+  constexpr int L = C::L, G = C::G, M = C::M, NM = C::NM, VPL = C::VPL, WPC = PksColCfg<R, L0, S>::WPC;
+  const int Sr = S > 0 ? S : A.S, N = Sr * M;
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
   cpx<R>* s_cw = s_tw + C::TWN;
-  E* s_x = reinterpret_cast<E*>(s_cw + S * PKS_SPAN);
+  E* s_x = reinterpret_cast<E*>(s_cw + Sr * PKS_SPAN);
   for (int i = threadIdx.x; i < C::TWN; i += blockDim.x) s_tw[i] = A.tw[i];
-  for (int i = threadIdx.x; i < S * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
+  for (int i = threadIdx.x; i < Sr * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * D16_XELEMS;
@@ -1092,7 +1100,7 @@ __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(Co
   const uint32_t lane_in = (live ? gl : 0) * N + q;
   pks_clear<R, L0>(ex);
 #pragma unroll 1
-  for (int sp = 0; sp < S; ++sp) {
+  for (int sp = 0; sp < Sr; ++sp) {
 #pragma unroll
     for (int j = 0; j < VPL; ++j) regs.v[j] = load_v(col + sp * M + lane_in + L * j);
     if constexpr (L0 < 0) pks64_pass<R>(ex, xbuf, s_tw, s_cw + sp * PKS_SPAN);
@@ -1691,8 +1699,13 @@ __global__ __launch_bounds__(DIRECT_THREADS) void k_cols_direct(ColArgs<R> A) {
 // amp = sqrt(powerspec) * df (fast/fast.py:594 and the `rand * df` of funcs.py:213); amp_s carries the
 // input-side fftshift sign (-1)^(ky+kx).  bad[0] counts entries that are negative, NaN or infinite.
 // ampf / ampf_s: the same two tables times sqrt(2 ln 2), rounded to float32: colouring of the device generator's draws.
+// amp_p / ampf_p (grids of the packed sub-rows, else null): amp_s / ampf_s with every row stored SUB-ROW MAJOR -- entry kx = s + S m at
+// s M + m -- so that pass s of k_rows_pks reads M consecutive values of each of its rows.  (Read in place, a pass touches every
+// 128-byte line of the row for an S-th of its bytes: S N^2 x 8 bytes of L1 fills per realisation, 35-42 TB/s at 1792 / 3840 -- the
+// 64 bytes per clock and CU the vector L1 can fill, and the bound of those rows until round 6.)
 template <class R>
-__global__ void k_make_amp(const double* ps, double df, int N, R* amp, R* amp_s, float* ampf, float* ampf_s, unsigned int* bad) {
+__global__ void k_make_amp(const double* ps, double df, int N, R* amp, R* amp_s, float* ampf, float* ampf_s, unsigned int* bad,
+                           R* amp_p, float* ampf_p, int S) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)N * N) return;
   const double p = ps[i];
@@ -1704,6 +1717,11 @@ __global__ void k_make_amp(const double* ps, double df, int N, R* amp, R* amp_s,
   const float vk = (float)(v * 1.1774100225154746910);      // * sqrt(2 ln 2): see box_muller_scaled
   ampf[i] = vk;
   ampf_s[i] = ((ky + kx) & 1) ? -vk : vk;
+  if (amp_p) {
+    const size_t j = (size_t)ky * N + (size_t)(kx % S) * (N / S) + kx / S;
+    amp_p[j] = (R)(((ky + kx) & 1) ? -v : v);
+    ampf_p[j] = ((ky + kx) & 1) ? -vk : vk;
+  }
 }
 
 #if FMC_TU == 0   // non-template kernels: one definition in the library

@@ -268,6 +268,7 @@ _VARIANTS = [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, No
              (640, 82, None), (896, 82, None), (896, 96, 401), (1152, 64, None), (1536, 82, 730), (640, 82, 0),
              (576, 82, None), (576, 40, 250), (448, 82, None), (320, 96, None), (192, 82, None), (576, 82, 100), (384, 82, None),     # sub-rows of 64 points; the last: beyond them
              (1000, 82, None), (2000, 82, None), (1200, 82, None), (500, 82, None), (3072, 82, None), (1344, 82, None),
+             (1920, 82, None), (2304, 96, None), (2560, 60, 1236), (1728, 82, None), (1920, 120, None),     # packed sub-rows with a run-time count (pks_rt); the last: beyond them (direct family)
              (164, 82, None), (943, 82, None),
              # packed rows (eight / four / two rows per wavefront): six centred planes, all planes, off-centre and wide windows, the whole
              # grid, and a window beyond the packed kernels (512, 300: device draws go to the direct family)
@@ -409,8 +410,14 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (500, 82, None, "k_rows_mr<double, 10, 2, 2, false, 50, 0>"), (800, 96, 3, "k_rows_mr<double, 16, 2, 2, false, 50, 0>"),
             (1000, 82, None, "k_rows_mr<double, 20, 2, 2, false, 50, 0>"), (1000, 200, None, "k_rows_mr<double, 20, 4, 2, false, 50, 0>"),
             (1200, 100, None, "k_rows_mr<double, 24, 2, 2, false, 50, 0>"), (2000, 82, None, "k_rows_mr<double, 20, 2, 2, true, 50, 0>"),
-            (1750, 70, None, "k_rows_mr<double, 7, 2, 2, true, 50, 0>"), (1344, 82, None, "k_rows_mr<double, 7, 2, 2, true, 64, 0>"),
-            (2560, 120, None, "k_rows_mr<double, 20, 2, 2, true, 64, 0>"),
+            (1750, 70, None, "k_rows_mr<double, 7, 2, 2, true, 50, 0>"), 
+            # the run-time-split wave grids (1344 ... 3840): packed sub-rows with the count at run time (odd: S = 0, even: S = -2) for the centred
+            # windows, else staged onto the split rows of fmc_mrfft.h on 64 lanes
+            (1344, 82, None, "k_rows_pks<double, -1, 0, 2>"), (1728, 96, None, "k_rows_pks<double, -1, 0, 2>"),
+            (1920, 82, None, "k_rows_pks<double, 0, 0, 2>"), (2688, 40, 1310, "k_rows_pks<double, 0, 0, 2>"), (3456, 82, None, "k_rows_pks<double, 0, 0, 2>"),
+            (2304, 82, None, "k_rows_pks<double, 1, 0, 2>"), (2560, 82, None, "k_rows_pks<double, 1, -2, 2>"), (3072, 96, None, "k_rows_pks<double, 1, -2, 2>"),
+            (3584, 82, 1750, "k_rows_pks<double, 1, -2, 2>"), (3840, 82, None, "k_rows_pks<double, 1, 0, 2>"),
+            (2560, 120, None, "k_rows_mr<double, 20, 2, 1, true, 64, 0>"), (1344, 82, 100, "k_rows_mr<double, 7, 2, 1, true, 64, 0>"),
             # chirp-z family (any other N): one transform of length 64 P, and rows in input blocks beyond 2048
             (164, 60, None, "k_rows_blu<double, 4, 2, 2, false>"), (291, 82, 5, "k_rows_blu<double, 8, 2, 2, false>"),
             (722, 200, None, "k_rows_blu<double, 16, 4, 2, false>"), (1111, 82, None, "k_rows_blu<double, 24, 2, 2, false>"),

@@ -125,7 +125,11 @@ def test_stream_layout_of_the_50_lane_grids():
     # wave-family grids with a run-time sub-row count: 64 S streams per row
     assert [(n, devrng.wave_rt_split(n)) for n in range(2, 4097) if devrng.wave_rt_split(n)] == [
         (1344, 3), (1728, 3), (1920, 3), (2304, 2), (2560, 2), (2688, 3), (3072, 2), (3456, 3), (3584, 4), (3840, 3)]
-    assert devrng.stream_lanes(3072) == 128 and devrng.stream_lanes(1344) == 192 and devrng.stream_lanes(3584) == 256
+    # ... for their host-coefficient rows; their generator layout is the packed sub-rows' (fmc_core.h: pks_rt -- N / 16 streams of
+    # sixteen draws with 256 / 128-point sub-rows, N / 8 of eight with 64-point ones)
+    assert devrng.stream_lanes(3072) == 192 and devrng.stream_lanes(1344) == 168 and devrng.stream_lanes(3584) == 224
+    assert devrng.stream_lanes(1728) == 216 and devrng.stream_lanes(1920) == 120 and devrng.stream_lanes(2688) == 168 and devrng.stream_lanes(3840) == 240
+    assert all(devrng.pks_split(n) for n in range(2, 4096) if devrng.wave_rt_split(n))
     assert devrng.stream_lanes(3200) == 200 and devrng.stream_lanes(1600) == 100 and devrng.stream_lanes(960) == 64
     c2 = devrng.device_coefficients(5, 0, 1400)[:3]
     assert np.isfinite(c2).all() and len(np.unique(c2.ravel())) == 3 * 1400

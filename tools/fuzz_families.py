@@ -32,7 +32,8 @@ for c in range(cases):
     if N > 4096:
         Np = int(rng.integers(1, 200))
     lo = int(rng.choice([0, N - Np, (N - Np) // 2, rng.integers(0, N - Np + 1)]))
-    if N in (192, 320, 384, 448, 576, 640, 768, 896, 1152, 1280, 1536, 1792) and rng.random() < 0.6:
+    if N in (192, 320, 384, 448, 576, 640, 768, 896, 1152, 1280, 1536, 1792,
+             1344, 1728, 1920, 2304, 2560, 2688, 3072, 3456, 3584, 3840) and rng.random() < 0.6:
         # grids of the packed sub-rows (round 6): two cases in three inside the 96 outputs their six planes hold
         Np = int(rng.integers(1, 97))
         lo = int(rng.integers(max(N // 2 - 48, 0), N // 2 + 48 - Np + 1))

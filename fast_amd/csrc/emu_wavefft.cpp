@@ -502,6 +502,10 @@ int main() {
   bad += sweep_pks<double, 0, 7>("f64", 1e-13);
   bad += sweep_pks<double, 0, 9>("f64", 1e-13);
   // the counts the run-time kernels take (fmc_core.h: pks_rt): the arithmetic knows the count's parity only
+  bad += sweep_pks64<double, 11>("f64", 1e-13);
+  bad += sweep_pks64<double, 33>("f64", 1e-13);
+  bad += sweep_pks<double, 0, 31>("f64", 1e-13);
+  bad += sweep_pks<double, 1, 11>("f64", 1e-13);
   bad += sweep_pks64<double, 21>("f64", 1e-13);
   bad += sweep_pks64<double, 27>("f64", 1e-13);
   bad += sweep_pks<double, 0, 15>("f64", 1e-13);

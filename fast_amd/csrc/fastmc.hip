@@ -26,6 +26,9 @@
 #define FMC_TU 0     // see "Translation units" below
 #endif
 #include "fmc_kernels.h"
+#ifndef FMC_PKS_P16_FROM
+#define FMC_PKS_P16_FROM 2048         // (2048 +7 %, 4096 +15 %; 1024 +0.4 %: its dense sixteen-wave row stays -- profiles/r06_ab_packed_subrows.txt section 8)
+#endif
 #if FMC_TU == 0
 #include "fmc_powerspec.h"
 #if FMC_TU == 0
@@ -676,6 +679,7 @@ extern "C" int fastmc_set_batch(fastmc_t* h, int batch) {
 #endif
 
 static int default_batch(const fastmc_ctx* h);
+static int pks_p16_from();
 #if FMC_TU == 0
 extern "C" int fastmc_get_batch(fastmc_t* h, int* batch) {
   if (!h || !batch) return fail(FASTMC_EINVAL, "null argument");
@@ -730,6 +734,25 @@ static int default_batch(const fastmc_ctx* h) {
   const double per = (double)h->N * h->Np * 2 * h->rsz;
   int b = (int)(2048.0 * 1024 * 1024 / per);       // round 2: 1568 realisations per launch +0.9 % over 1176 at 1024^2
   b = std::max(1, std::min(b, 4096));
+  if (h->path != 0 && (pks_grid(h->N) || (h->path == 1 && h->rsz == 8 && pks_p16(h->N) && h->N >= pks_p16_from())) &&
+      h->lo >= h->N / 2 - 48 && h->lo + h->Np <= h->N / 2 + 48 && !(h->rsz == 4 && pks_rt(h->N))) {
+    // packed sub-rows (pks_variant; fmc_kernels.h: k_rows_pks): a tile is one 128-byte line of V positions x BPG realisations, and the
+    // launch's workgroups (one per CU) walk the tiles -- whole groups of BPG realisations, and of the group counts within a quarter of
+    // the slab limit the one whose tiles fill the last round over the 256 CUs best (1856: 10 % of the launch was an almost empty round)
+    const int L0 = pks_L0(h->N), WPB = L0 == 0 ? (h->rsz == 8 ? FMC_PKS_WPB0 : 12) : FMC_PKS_WPB, G = L0 == 1 ? 4 : 8;
+    const int LR = 128 / (2 * h->rsz), BPG = ROWS_PER_WAVE * WPB / (LR / G), nmax = b / BPG;
+    if (nmax >= 1) {
+      int best = nmax;
+      double best_eff = 0.0;
+      for (int nbb = nmax; nbb >= std::max(1, nmax - nmax / 4); --nbb) {
+        const int64_t t = (int64_t)(h->N / LR) * nbb;
+        const double eff = t >= 8 * 256 ? (double)t / (double)(((t + 255) / 256) * 256) : 1.0;      // (fewer tiles: one workgroup each, no walk)
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = nbb; }
+      }
+      return best * BPG;
+    }
+    return b;
+  }
   if (h->path == 1) {
     // whole number of workgroup rounds over the 256 CUs: the row kernel runs one 12-wave (P=32: 4/6)
     // workgroup per CU and has batch * N/8 wave-items
@@ -756,10 +779,10 @@ static int make_amp(fastmc_ctx* h, const double* d_ps, double df, hipStream_t st
   if (!h->ampf) HIPCHK(hipMalloc((void**)&h->ampf, sizeof(float) * n));
   if (!h->ampf_s) HIPCHK(hipMalloc((void**)&h->ampf_s, sizeof(float) * n));
   if (!h->bad) HIPCHK(hipMalloc((void**)&h->bad, 8));
-  if (pks_grid(N) && !h->amp_p) { HIPCHK(hipMalloc(&h->amp_p, sizeof(R) * n)); HIPCHK(hipMalloc((void**)&h->ampf_p, sizeof(float) * n)); }
+  if (pks_count(N) && !h->amp_p) { HIPCHK(hipMalloc(&h->amp_p, sizeof(R) * n)); HIPCHK(hipMalloc((void**)&h->ampf_p, sizeof(float) * n)); }
   HIPCHK(hipMemsetAsync(h->bad, 0, 8, stream));
   hipLaunchKernelGGL((k_make_amp<R>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_ps, df, N, (R*)h->amp,
-                     (R*)h->amp_s, h->ampf, h->ampf_s, h->bad, (R*)h->amp_p, h->ampf_p, pks_grid(N) ? pks_split(N) : 1);
+                     (R*)h->amp_s, h->ampf, h->ampf_s, h->bad, (R*)h->amp_p, h->ampf_p, pks_count(N) ? pks_count(N) : 1);
   HIPCHK(hipGetLastError());
   unsigned int bad = 0;
   HIPCHK(hipMemcpyAsync(&bad, h->bad, 4, hipMemcpyDeviceToHost, stream));
@@ -854,15 +877,20 @@ static int upload_wave_tables(fastmc_ctx* h) {
     TRY(upload_table<R>(&h->pk_tw1, tw));
     TRY(upload_table<R>(&h->pk_om, omp));
   }
-  if (pks_grid(h->N) && !h->pks_tw1) {          // (both tables depend on N only)
-    const int Sp = pks_split(h->N), L = pks_L0(h->N) < 0 ? 4 : pk_lanes(pks_L0(h->N));     // (64-point sub-rows: 8 x 8 = 16 x 4 entries)
-    std::vector<cpx<R>> tw((size_t)16 * L), pcw((size_t)Sp * PKS_SPAN);
-    if (pks_L0(h->N) < 0) build_tw64<R>(tw.data(), cs_turns);
-    else build_tw1_pk<R>(tw.data(), L, cs_turns);
-    build_pcw<R>(pcw.data(), h->N, Sp, cs_turns);
-    TRY(upload_table<R>(&h->pks_tw1, tw));
-    TRY(upload_table<R>(&h->pks_cw, pcw));
-  }
+  return 0;
+}
+// Tables of the packed sub-rows (fmc_core.h: pks_split; they depend on N only).  The grids are those of the wave family and, with a
+// run-time sub-row count, of the chirp-z and 50-lane families too (fmc_core.h: pks_rt): fastmc_set_pupil calls this for every family.
+template <class R>
+static int upload_pks_tables(fastmc_ctx* h) {
+  if (!pks_count(h->N) || h->pks_tw1) return 0;
+  const int Sp = pks_count(h->N), L = pks_L0(h->N) < 0 ? 4 : pk_lanes(pks_L0(h->N));     // (64-point sub-rows: 8 x 8 = 16 x 4 entries)
+  std::vector<cpx<R>> tw((size_t)16 * L), pcw((size_t)Sp * PKS_SPAN);
+  if (pks_L0(h->N) < 0) build_tw64<R>(tw.data(), cs_turns);
+  else build_tw1_pk<R>(tw.data(), L, cs_turns);
+  build_pcw<R>(pcw.data(), h->N, Sp, cs_turns);
+  TRY(upload_table<R>(&h->pks_tw1, tw));
+  TRY(upload_table<R>(&h->pks_cw, pcw));
   return 0;
 }
 
@@ -882,9 +910,16 @@ static int pk_variant(const fastmc_ctx* h) {
 // six centred planes of the sub-transforms; -1: no (host coefficients and the column pass always go to the one-row-per-wave
 // kernels; device draws with any other window are staged (float64 generator) or go to the direct family (float32 draw): the
 // P = 12 / 20 / 28 rows of fmc_wavefft.h do not know the N / 16-stream generator layout of these grids).
+// The smallest grid of the P = 16 rows (1024, 2048, 4096) that the packed sub-rows serve instead (fmc_core.h: pks_p16).
+static int pks_p16_from() {
+  static const int from = getenv("FASTMC_PKS_P16") ? atoi(getenv("FASTMC_PKS_P16")) : FMC_PKS_P16_FROM;
+  return from;
+}
 template <class R>
 static int pks_variant(const fastmc_ctx* h) {
-  if (!pks_grid(h->N) || h->path != 1) return -1;
+  if (!pks_count(h->N) || h->path == 0) return -1;         // (path 0: the direct family was asked for -- fastmc_set_kernel_path)
+  if (pks_p16(h->N) && (h->N < pks_p16_from() || sizeof(R) != 8 || h->path != 1)) return -1;
+  if (sizeof(R) != 8 && pks_rt(h->N)) return -1;           // (run-time counts: float64 pipeline only; fastmc_create never makes such a handle)
   static const bool off = getenv("FASTMC_PKS") && atoi(getenv("FASTMC_PKS")) == 0;     // A/B: staged / direct instead
   if (off) return -1;
   // the six planes of a sub-transform hold x = N / 2 - 48 ... N / 2 + 47 (fmc_wavefft.h: pks_accumulate)
@@ -963,6 +998,7 @@ extern "C" int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, doubl
     TRY(h->precision == FASTMC_F64 ? upload_wave_tables<double>(h) : upload_wave_tables<float>(h));
     h->tables_lo = crop_lo;
   }
+  TRY(h->precision == FASTMC_F64 ? upload_pks_tables<double>(h) : upload_pks_tables<float>(h));
   h->have_pupil = true;
   return 0;
 }
@@ -1243,7 +1279,7 @@ int dispatch_pk(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int m
 template <class R, int L0, int S, int MODE>
 static void launch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
   using C = PksCfg<R, L0, S>;
-  const int Sr = S > 0 ? S : pks_split(RA.N);        // S <= 0: the sub-row count at run time (fmc_core.h: pks_rt)
+  const int Sr = S > 0 ? S : pks_count(RA.N);        // S <= 0: the sub-row count at run time (fmc_core.h: pks_rt, pks_p16)
   const size_t lds = pks_lds_bytes<R, L0, S>(Sr) + (MODE == 2 ? GEN64_TABLE_BYTES : 0);
   constexpr int LR = 128 / (int)sizeof(cpx<R>), LU = LR / C::G, BPG = ROWS_PER_WAVE * C::WPB / LU;
   int blocks = (Sr * C::M / LR) * ((RA.nb + BPG - 1) / BPG);
@@ -1263,7 +1299,7 @@ template <class R, int L0, int S, int EPI>
 static void launch_pks_cols(fastmc_ctx* h, const ColArgs<R>& CA) {
   using C = PksCfg<R, L0, S>;
   constexpr int WPC = PksColCfg<R, L0, S>::WPC;
-  const int Sr = S > 0 ? S : pks_split(CA.N);
+  const int Sr = S > 0 ? S : pks_count(CA.N);
   const size_t lds = pks_cols_lds_bytes<R, L0, S>(Sr);
   const int items = CA.nb * ((CA.Np + C::G - 1) / C::G);
   ColArgs<R> B = CA;
@@ -1280,7 +1316,7 @@ int dispatch_pks(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in
   ColArgs<R> CA = CA_in;
   CA.tw = (const cpx<R>*)h->pks_tw1; CA.cw = (const cpx<R>*)h->pks_cw;
   // (the grids of pks_rt: the kernels with a run-time count -- S = 0 odd, -2 even; float64 pipeline only, fastmc_create)
-  const int S = pks_rt(h->N) ? ((pks_rt(h->N) & 1) ? 0 : -2) : pks_split(h->N), L0 = pks_L0(h->N);
+  const int S = pks_ct(h->N) ? pks_ct(h->N) : ((pks_count(h->N) & 1) ? 0 : -2), L0 = pks_L0(h->N);
 #define FMC_PKSC(LL, SS)                                                                  \
   if (L0 == LL && S == SS) {                                                              \
     if (epi == 0) launch_pks_cols<R, LL, SS, 0>(h, CA); else launch_pks_cols<R, LL, SS, 1>(h, CA); \
@@ -1295,7 +1331,7 @@ int dispatch_pks(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in
 template <class R>
 int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode) {
   Span s(h, 0);
-  const int S = pks_rt(h->N) ? ((pks_rt(h->N) & 1) ? 0 : -2) : pks_split(h->N), L0 = pks_L0(h->N);
+  const int S = pks_ct(h->N) ? pks_ct(h->N) : ((pks_count(h->N) & 1) ? 0 : -2), L0 = pks_L0(h->N);
   RowArgs<R> RA = RA_in;      // the family's own tables; the colouring tables with the input-side fftshift sign folded in
   RA.amp = (const R*)h->amp_p; RA.ampf = h->ampf_p; RA.tw = (const cpx<R>*)h->pks_tw1; RA.cw = (const cpx<R>*)h->pks_cw;
 #define FMC_PKS(LL, SS)                                                                                   \
@@ -1706,7 +1742,8 @@ static bool fused_gen64(fastmc_ctx* h) {
   if constexpr (sizeof(R) != 8) return false;
   if (getenv("FASTMC_GEN64_STAGED")) return false;          // A/B: the round-3 form (k_gen_coeffs_f64 -> cre / cim -> MODE 1 rows)
   if (h->path == 1 && pk_grid(h->N) && pk_variant<R>(h) >= 0) return true;      // 128 / 256 / 512: the packed rows draw it themselves too
-  if (h->path == 1 && pks_grid(h->N)) return pks_variant<R>(h) >= 0;            // 640 ... 1792 (pks_split): the packed sub-rows, else staged
+  if (h->path != 0 && pks_grid(h->N)) return pks_variant<R>(h) >= 0;            // 192 ... 3968 (pks_split): the packed sub-rows, else staged
+  if (pks_p16(h->N) && pks_variant<R>(h) >= 0) return true;                     // 1024 / 2048 / 4096 where the packed sub-rows serve them
   if constexpr (sizeof(R) == 8) {
     if (h->path == 2) {      // chirp-z family: its rows draw it too where the tables fit
       const int ns2 = h->NS <= 2 ? 2 : 4;
@@ -1898,10 +1935,23 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
 #ifdef FMC_ISA_SUBSET   // tools/isa_stats.py: only the kernels whose instruction mix bench.py prices (same code, a tenth of the compile time)
     RA.amp = (const R*)h->amp_s; RA.ampf = h->ampf_s; RA.tw = (const cpx<R>*)h->tw1; CA.tw = RA.tw;
     RA.cw = (const cpx<R>*)h->cw; CA.cw = RA.cw; RA.tw_global = CA.tw_global = 0;
+    if constexpr (sizeof(R) == 8) {
+      if (h->N == 2048 && kmode != 1) {        // (as the full build: 2048 goes to the packed sub-rows with a run-time count)
+        if (kmode == 2) launch_pks_rows<R, 1, -2, 2>(h, RA); else launch_pks_rows<R, 1, -2, 0>(h, RA);
+        launch_pks_cols<R, 1, -2, 0>(h, CA);
+        return 0;
+      }
+    }
     if (h->S == 2) dispatch_wave<R, 16, 2, 2>(h, RA, CA, kmode, S.epi);
     else dispatch_wave<R, 16, 2>(h, RA, CA, kmode, S.epi);
 #else
-    if (h->path == 2) {
+    // packed sub-rows (fmc_core.h: pks_split): rows with the device generator and their own column pass, for the centred windows, on
+    // grids of the wave, chirp-z and 50-lane families alike.  Any other window: the float64 generator is staged onto the family's
+    // host-coefficient rows (fused_gen64 is false there), the float32 draw goes to the direct family -- no other row kernel knows the
+    // N / 16 (N / 8) streams per row of these grids.
+    const bool pks = h->path != 0 && kmode != 1 && pks_variant<R>(h) >= 0;
+    const bool pks_to_direct = !pks && pks_grid(h->N) && kmode == 0 && (h->path == 2 || h->path == 3);
+    if (h->path == 2 && !pks && !pks_to_direct) {
       TRY(upload_blu_tables<R>(h));
       RA.amp = (const R*)h->amp; RA.ampf = h->ampf; RA.tw = (const cpx<R>*)h->blu_tw1; RA.om = (const cpx<R>*)h->blu_om;
       RA.cw = nullptr; RA.tw_global = 0;
@@ -1911,7 +1961,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
       CA.tw = RA.tw; CA.om = RA.om; CA.cw = nullptr; CA.tw_global = 0; CA.blu = RA.blu;
       if constexpr (sizeof(R) == 8) { TRY(dispatch_blu<R>(h, RA, CA, kmode, S.epi)); }
       else return fail(FASTMC_ESTATE, "chirp-z grids run the float64 kernels (fastmc_create)");
-    } else if (h->path == 3) {
+    } else if (h->path == 3 && !pks && !pks_to_direct) {
       TRY(upload_mr_tables<R>(h));
       RA.amp = (const R*)h->amp_s; RA.ampf = h->ampf_s; RA.tw = (const cpx<R>*)h->mr_tw1; RA.om = (const cpx<R>*)h->mr_om;
       RA.cw = (const cpx<R>*)h->mr_cw; RA.tw_global = 0;
@@ -1920,14 +1970,12 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
         if (h->mr_P <= 9) { TRY((dispatch_mr_part<R, 0>(h, RA, CA, kmode, S.epi))); }
         else { TRY((dispatch_mr_part<R, 1>(h, RA, CA, kmode, S.epi))); }
       } else return fail(FASTMC_ESTATE, "50-lane grids run the float64 kernels (fastmc_create)");
-    } else if (pk_variant<R>(h) >= 0) {
+    } else if (!pks && !pks_to_direct && pk_variant<R>(h) >= 0) {
       RA.amp = (const R*)h->amp_s; RA.ampf = h->ampf_s; RA.tw = (const cpx<R>*)h->pk_tw1; RA.om = (const cpx<R>*)h->pk_om;
       RA.cw = nullptr; RA.tw_global = 0;
       CA.tw = RA.tw; CA.om = RA.om; CA.cw = nullptr; CA.tw_global = 0;
       TRY(dispatch_pk<R>(h, RA, CA, kmode, S.epi));
     } else {
-    // packed sub-rows (640 ... 1792, fmc_core.h: pks_split): the device generator's rows, then the column pass of the one-row-per-wave family
-    const bool pks = kmode != 1 && pks_variant<R>(h) >= 0;
     bool wave_ok = h->path == 1 && !(pk_grid(h->N) && kmode == 0) && !(pks_grid(h->N) && kmode == 0 && !pks);    // packed grids beyond the packed windows: see pk_variant, pks_variant
     const int wmode = kmode;
     // the one-row-per-wave kernels of the N / 16-stream grids exist for host coefficients only (launch_wave_pair): a device draw must

@@ -468,17 +468,28 @@ FMC_HD constexpr bool pk_grid(int N) { return N == 128 || N == 256 || N == 512; 
 // values per lane for the device generator (up to 338 registers, one or two waves per SIMD: 0.61-0.79 of the 1024-point row's
 // rate per pixel; 1536: 0.93).  Their rows are drawn as N / 16 streams of sixteen advances (64-point sub-rows: N / 8 streams of eight),
 // stream t = kx mod SL: lane q of sub-row s reads ONE stream (t = s + S q) sequentially.
-// The grids of wave_rt_split up to 3840 take the same kernels with the sub-row count at RUN TIME (pks_rt): 2304, 2560, 3072, 3584,
-// 3840 = 9, 10, 12, 14, 15 x 256; 1920, 2688, 3456 = 15, 21, 27 x 128; 1344, 1728 = 21, 27 x 64 (their one-row-per-wave kernels ran
-// 0.58-0.72 of the 1024-point row's rate per pixel with two to four sub-rows of 7 ... 24 values per lane).
-FMC_HD constexpr int pks_rt(int N) {
-  return N == 2304 ? 9 : (N == 2560 ? 10 : (N == 3072 ? 12 : (N == 3584 ? 14 : (N == 3840 ? 15 : (N == 1920 ? 15 : (N == 2688 ? 21 :
-         (N == 3456 ? 27 : (N == 1344 ? 21 : (N == 1728 ? 27 : 0)))))))));
-}
-FMC_HD constexpr int pks_split(int N) {
+FMC_HD constexpr int pks_ct(int N) {         // the sub-row count is a template argument of these grids' kernels
   return N == 768 ? 3 : (N == 1280 ? 5 : (N == 1536 ? 6 : (N == 1792 ? 7 : (N == 640 ? 5 : (N == 896 ? 7 : (N == 1152 ? 9 :
-         (N == 576 ? 9 : (N == 448 ? 7 : (N == 320 ? 5 : (N == 192 ? 3 : (N == 384 ? 3 : pks_rt(N))))))))))));
+         (N == 576 ? 9 : (N == 448 ? 7 : (N == 320 ? 5 : (N == 192 ? 3 : (N == 384 ? 3 : 0)))))))))));
 }
+// EVERY other multiple of 64 up to 4096 that has no faster form (128, 256, 512: packed rows; 1024, 2048, 4096: the P = 16 rows) takes
+// the same kernels with the sub-row count at RUN TIME: N = S x 256 (2304 ... 3840, S = 9 ... 15, either parity), else S x 128 (odd
+// S = 11 ... 31: 1408 ... 3968), else S x 64 (odd S = 11 ... 33: 704 ... 2112; a longer table of pks_accumulate does not fit the LDS
+// beside twelve exchange buffers, so 2240 ... 4032 stay with the chirp-z rows).  These were the grids of wave_rt_split (two to four
+// one-row-per-wave sub-rows of 7 ... 24 values per lane: 0.58-0.72 of the 1024-point row's rate per pixel), of the chirp-z family
+// (704, 832, 960, 1088, ...: about a third) and 1600 / 3200 of the 50-lane family; those families keep their host-coefficient rows.
+FMC_HD constexpr int pks_rt(int N) {
+  if (N % 64 != 0 || N < 192 || N >= 4096 || pk_grid(N) || N == 1024 || N == 2048 || pks_ct(N)) return 0;
+  if (N % 256 == 0) return N / 256;
+  if (N % 128 == 0) return N / 128;
+  return N / 64 <= 33 ? N / 64 : 0;
+}
+FMC_HD constexpr int pks_split(int N) { return pks_ct(N) ? pks_ct(N) : pks_rt(N); }
+// 1024, 2048, 4096 = 4, 8, 16 x 256: the grids of the P = 16 rows draw 64 S' streams per row (S' = 1, 2, 4) -- exactly the N / 16
+// streams of sixteen draws the packed sub-rows read, stream t = kx mod N / 16 -- so the packed sub-rows can serve them WITHOUT a
+// change of the generator layout (fastmc.hip: pks_p16_from decides which of them they do serve).
+FMC_HD constexpr int pks_p16(int N) { return N == 1024 ? 4 : (N == 2048 ? 8 : (N == 4096 ? 16 : 0)); }
+FMC_HD constexpr int pks_count(int N) { return pks_split(N) ? pks_split(N) : pks_p16(N); }
 // M = 16 * pk_lanes(L0): 256 (L0 = 1) or 128 (L0 = 0); -1: sub-rows of SIXTY-FOUR points (192, 320, 448, 576 = 3, 5, 7, 9 x 64: eight
 // rows per wavefront, eight lanes per sub-row, eight draws per generator stream: fmc_wavefft.h: pks64_pass)
 FMC_HD constexpr int pks_L0(int N) { return N % 256 == 0 ? 1 : (N % 128 == 0 ? 0 : -1); }

@@ -88,7 +88,7 @@ def test_bench_float32_draw_as_the_timed_pass():
 
 
 def test_bench_config3_has_a_roofline():
-    """BASELINE configs[3] (2048^2, 100 000 iterations per step): the split rows have static instruction counts too."""
+    """BASELINE configs[3] (2048^2, 100 000 iterations per step): its rows (packed sub-rows, eight of 256 points) have static instruction counts too."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--workload", "config3",
                           "--no-cpu-baseline", "--no-extras", "--no-sustained", "--no-f32-draw-pass"], capture_output=True, text=True,
@@ -97,7 +97,7 @@ def test_bench_config3_has_a_roofline():
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["scaling"] == "strong" and "2048" in d["metric"]
     r = d["roofline"]
-    assert d["dtype"] == "f64" and r["kernel"] == "k_rows_wave<double, 16, 2, 2, 2, 4>"
+    assert d["dtype"] == "f64" and r["kernel"] == "k_rows_pks<double, 1, -2, 2>"
     assert r["achieved"] is not None and r["frac"] is not None and 0.05 < r["frac"] <= 1.0
     assert r["traffic"] is not None and r["traffic"] > 0
-    assert r["issue"]["valu_instructions_per_row"] > 2400        # two sub-rows of 1024 points with their draws + the combine
+    assert r["issue"]["valu_instructions_per_row"] > 2400        # eight sub-rows of 256 points with their draws + the combine

@@ -269,6 +269,7 @@ _VARIANTS = [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, No
              (576, 82, None), (576, 40, 250), (448, 82, None), (320, 96, None), (192, 82, None), (576, 82, 100), (384, 82, None),     # sub-rows of 64 points; the last: beyond them
              (1000, 82, None), (2000, 82, None), (1200, 82, None), (500, 82, None), (3072, 82, None), (1344, 82, None),
              (1920, 82, None), (2304, 96, None), (2560, 60, 1236), (1728, 82, None), (1920, 120, None),     # packed sub-rows with a run-time count (pks_rt); the last: beyond them (direct family)
+             (704, 82, None), (1088, 40, 530), (1600, 82, None), (1664, 96, None), (832, 82, 5), (1600, 100, None),     # ... on chirp-z and 50-lane grids; the last two: beyond them (direct family)
              (164, 82, None), (943, 82, None),
              # packed rows (eight / four / two rows per wavefront): six centred planes, all planes, off-centre and wide windows, the whole
              # grid, and a window beyond the packed kernels (512, 300: device draws go to the direct family)
@@ -380,8 +381,12 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (1024, 97, None, "k_rows_wave<double, 16, 2, 2, 1, 8>"), (1024, 128, None, "k_rows_wave<double, 16, 2, 2, 1, 8>"),
             (1024, 82, 0, "k_rows_wave<double, 16, 2, 2, 1, 7>"), (1024, 120, 904, "k_rows_wave<double, 16, 2, 2, 1, 7>"),
             (1024, 200, None, "k_rows_wave<double, 16, 4, 2, 1, 7>"), (1024, 400, None, "k_rows_wave<double, 16, 8, 2, 1, 7>"),
-            (2048, 82, None, "k_rows_wave<double, 16, 2, 2, 2, 4>"), (2048, 122, None, "k_rows_wave<double, 16, 2, 2, 2, 6>"),
-            (2048, 402, None, "k_rows_wave<double, 16, 8, 2, 2, 7>"), (4096, 82, None, "k_rows_wave<double, 16, 2, 2, 4, 4>"),
+            (2048, 122, None, "k_rows_wave<double, 16, 2, 2, 2, 6>"),
+            (2048, 402, None, "k_rows_wave<double, 16, 8, 2, 2, 7>"), (4096, 100, None, "k_rows_wave<double, 16, 2, 2, 4, 6>"),
+            # ... whose centred windows of up to 96 pixels go to the packed sub-rows (eight / sixteen sub-rows of 256 points, count at run time:
+            # the same N / 16 streams per row, +7 % / +15 %); 1024 keeps its dense sixteen-wave row (fastmc.hip: pks_p16_from)
+            (2048, 82, None, "k_rows_pks<double, 1, -2, 2>"), (2048, 96, 980, "k_rows_pks<double, 1, -2, 2>"), (4096, 82, None, "k_rows_pks<double, 1, -2, 2>"),
+            (2048, 82, 900, "k_rows_wave<double, 16, 2, 2, 2, 5>"),
             # packed rows (eight / four / two rows per wavefront): centred six planes and all planes
             (128, 82, None, "k_rows_pk<double, 0, 2, 0>"), (128, 128, None, "k_rows_pk<double, 0, 2, 1>"),
             (256, 82, None, "k_rows_pk<double, 1, 2, 0>"), (256, 200, None, "k_rows_pk<double, 1, 2, 1>"), (256, 82, 100, "k_rows_pk<double, 1, 2, 1>"),
@@ -418,6 +423,12 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (2304, 82, None, "k_rows_pks<double, 1, 0, 2>"), (2560, 82, None, "k_rows_pks<double, 1, -2, 2>"), (3072, 96, None, "k_rows_pks<double, 1, -2, 2>"),
             (3584, 82, 1750, "k_rows_pks<double, 1, -2, 2>"), (3840, 82, None, "k_rows_pks<double, 1, 0, 2>"),
             (2560, 120, None, "k_rows_mr<double, 20, 2, 1, true, 64, 0>"), (1344, 82, 100, "k_rows_mr<double, 7, 2, 1, true, 64, 0>"),
+            # ... and of every other multiple of 64 (fmc_core.h: pks_rt): grids whose host-coefficient rows are the chirp-z family's (704 ... 3968)
+            # or the 50-lane family's (1600, 3200); off the centred windows the draws are staged onto those rows
+            (704, 82, None, "k_rows_pks<double, -1, 0, 2>"), (960, 96, None, "k_rows_pks<double, -1, 0, 2>"), (2112, 82, None, "k_rows_pks<double, -1, 0, 2>"),
+            (1408, 82, None, "k_rows_pks<double, 0, 0, 2>"), (3968, 60, 1950, "k_rows_pks<double, 0, 0, 2>"), (2816, 82, None, "k_rows_pks<double, 1, 0, 2>"),
+            (1600, 82, None, "k_rows_pks<double, -1, 0, 2>"), (3200, 82, None, "k_rows_pks<double, 0, 0, 2>"),
+            (832, 120, None, "k_rows_blu<double, 16, 2, 1, false>"), (1600, 82, 3, "k_rows_mr<double, 16, 2, 1, true, 50, 0>"),
             # chirp-z family (any other N): one transform of length 64 P, and rows in input blocks beyond 2048
             (164, 60, None, "k_rows_blu<double, 4, 2, 2, false>"), (291, 82, 5, "k_rows_blu<double, 8, 2, 2, false>"),
             (722, 200, None, "k_rows_blu<double, 16, 4, 2, false>"), (1111, 82, None, "k_rows_blu<double, 24, 2, 2, false>"),

@@ -24,6 +24,8 @@ for c in range(cases):
                           1344, 1728, 1920, 2304, 2560]))
     if c % 32 == 9:                                     # rarely a grid beyond 4096: sub-rows (64 P S, 50 P S) or chirp-z blocks
         N = int(rng.choice([4608, 5000, 5120, 6000, 6144, 6400, 7000, 7168, 7680, 8000, 8192, int(rng.integers(4097, 8192)), int(rng.integers(4097, 8192))]))
+    if c % 8 == 6:                                      # any multiple of 64: the packed sub-rows with a run-time count (fmc_core.h: pks_rt) among them
+        N = 64 * int(rng.integers(3, 64))
     if only:
         N = int(rng.choice(only))
     Np = int(rng.integers(1, min(N, 300 if c % 2 == 0 else 256) + 1))
@@ -32,8 +34,7 @@ for c in range(cases):
     if N > 4096:
         Np = int(rng.integers(1, 200))
     lo = int(rng.choice([0, N - Np, (N - Np) // 2, rng.integers(0, N - Np + 1)]))
-    if N in (192, 320, 384, 448, 576, 640, 768, 896, 1152, 1280, 1536, 1792,
-             1344, 1728, 1920, 2304, 2560, 2688, 3072, 3456, 3584, 3840) and rng.random() < 0.6:
+    if N % 64 == 0 and 192 <= N < 4096 and N not in (256, 512, 1024, 2048) and (N % 128 == 0 or N // 64 <= 33) and rng.random() < 0.6:
         # grids of the packed sub-rows (round 6): two cases in three inside the 96 outputs their six planes hold
         Np = int(rng.integers(1, 97))
         lo = int(rng.integers(max(N // 2 - 48, 0), N // 2 + 48 - Np + 1))

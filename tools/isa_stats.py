@@ -38,14 +38,18 @@ KERNELS = {
     "rows_f32_1024": "void fmc::k_rows_wave<float, 16, 2, 0, 1, 4>(",
     "cols_f32_1024": "void fmc::k_cols_wave<float, 16, 2, 0, 1, 4>(",
     "rows_f64_1024_12waves": "void fmc::k_rows_wave<double, 16, 2, 0, 1, 5>(",
-    "rows_f64_2048": "void fmc::k_rows_wave<double, 16, 2, 0, 2, 4>(",
-    "cols_f64_2048": "void fmc::k_cols_wave<double, 16, 2, 0, 2, 5>(",
+    # 2048^2 (round 6): the packed sub-rows with a run-time count -- eight sub-rows of 256 points, FOUR rows per wavefront
+    "rows_f64_2048": "void fmc::k_rows_pks<double, 1, -2, 0>(",
+    # (its column kernel k_cols_pks<double, 1, -2, 0> holds a loop of eight passes and a rolled detector loop: a static count of the
+    # body is not a count per column, and nothing prices the column pass by instructions -- it is not listed)
     # the float64 generator fused into the row (MODE 2; round 4)
     "rows_f64_1024_gen64": "void fmc::k_rows_wave<double, 16, 2, 2, 1, 4>(",
-    "rows_f64_2048_gen64": "void fmc::k_rows_wave<double, 16, 2, 2, 2, 4>(",
+    "rows_f64_2048_gen64": "void fmc::k_rows_pks<double, 1, -2, 2>(",
 }
 # sub-rows per row of the split-row kernels: their row loop contains the sub-row loop, counted as outer + S x inner
-SUB_ROWS = {"rows_f64_2048": 2, "rows_f64_2048_gen64": 2}
+SUB_ROWS = {"rows_f64_2048": 8, "rows_f64_2048_gen64": 8}
+# rows one pass of the row loop transforms (packed sub-rows: the G = 4 rows of a unit): the counts are divided by it
+ROWS_PER_PASS = {"rows_f64_2048": 4, "rows_f64_2048_gen64": 4}
 
 # --packed: the packed rows of the small grids (translation unit 10; unit = G rows / columns of one wavefront)
 PACKED_KERNELS = {
@@ -225,14 +229,19 @@ def main():
             flops, flops32 = fo + S * fi, f32o + S * f32i
         else:
             mix, by_class, flops, flops32 = count(lines[a:b + 1])
+        G = ROWS_PER_PASS.get(tag, 1)
+        if G > 1:
+            by_class = collections.Counter({k: v / G for k, v in by_class.items()})
+            flops, flops32 = flops / G, flops32 / G
         valu = sum(v for k, v in by_class.items() if k.startswith("valu"))
         result[tag] = {"kernel": prefix.rstrip("(").replace("void fmc::", ""), "unit": "one row (rows) / one column (cols) per wave",
                        "instructions": dict(by_class), "valu_total": valu, "f64_flop_per_lane": flops, "f32_flop_per_lane": flops32,
                        "loop_lines": [a, b], "body_lines": len(lines)}
         if inner:
             result[tag]["sub_rows"] = S
+            result[tag]["rows_per_pass"] = G
             result[tag]["sub_row_loop_lines"] = list(inner)
-        print(f"{tag:16s} VALU {valu:5d}  " + "  ".join(f"{k} {v}" for k, v in sorted(by_class.items())) + f"  f64 flop/lane {flops}")
+        print(f"{tag:16s} VALU {valu:5g}  " + "  ".join(f"{k} {v:g}" for k, v in sorted(by_class.items())) + f"  f64 flop/lane {flops:g}")
         if args.top:
             print("   ", ", ".join(f"{m} {n}" for m, n in mix.most_common(args.top)))
     if args.json:

@@ -474,15 +474,15 @@ FMC_HD constexpr int pks_ct(int N) {         // the sub-row count is a template 
 }
 // EVERY other multiple of 64 up to 4096 that has no faster form (128, 256, 512: packed rows; 1024, 2048, 4096: the P = 16 rows) takes
 // the same kernels with the sub-row count at RUN TIME: N = S x 256 (2304 ... 3840, S = 9 ... 15, either parity), else S x 128 (odd
-// S = 11 ... 31: 1408 ... 3968), else S x 64 (odd S = 11 ... 33: 704 ... 2112; a longer table of pks_accumulate does not fit the LDS
-// beside twelve exchange buffers, so 2240 ... 4032 stay with the chirp-z rows).  These were the grids of wave_rt_split (two to four
+// S = 11 ... 31: 1408 ... 3968), else S x 64 (odd S = 11 ... 63: 704 ... 4032; the table of pks_accumulate goes through the LDS one
+// pass at a time).  These were the grids of wave_rt_split (two to four
 // one-row-per-wave sub-rows of 7 ... 24 values per lane: 0.58-0.72 of the 1024-point row's rate per pixel), of the chirp-z family
 // (704, 832, 960, 1088, ...: about a third) and 1600 / 3200 of the 50-lane family; those families keep their host-coefficient rows.
 FMC_HD constexpr int pks_rt(int N) {
   if (N % 64 != 0 || N < 192 || N >= 4096 || pk_grid(N) || N == 1024 || N == 2048 || pks_ct(N)) return 0;
   if (N % 256 == 0) return N / 256;
   if (N % 128 == 0) return N / 128;
-  return N / 64 <= 33 ? N / 64 : 0;
+  return N / 64;
 }
 FMC_HD constexpr int pks_split(int N) { return pks_ct(N) ? pks_ct(N) : pks_rt(N); }
 // 1024, 2048, 4096 = 4, 8, 16 x 256: the grids of the P = 16 rows draw 64 S' streams per row (S' = 1, 2, 4) -- exactly the N / 16

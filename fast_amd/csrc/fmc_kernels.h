@@ -977,10 +977,22 @@ template <class R, int L0_, int S> struct PksCfg {
   static constexpr int WPB = L0 == 0 ? (sizeof(R) == 8 ? FMC_PKS_WPB0 : 12) : FMC_PKS_WPB;
 };
 // LDS carve (dynamic): [generator tables (MODE 2)][tw1 16 L cpx][pcw S x 96 cpx][xbuf WPB * D16_XELEMS 8-byte]
+// A run-time count (S <= 0) keeps only the CURRENT pass's 96 entries of pcw, one copy per wave (pks_slice): the table of S = 63 sub-rows
+// would be 94 KB; the slice of pass s is loaded while the pass's draws run.
 template <class R, int L0, int S>
 __host__ __device__ constexpr size_t pks_lds_bytes(int Sr) {
-  return (size_t)(PksCfg<R, L0, S>::TWN + Sr * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksCfg<R, L0, S>::WPB * D16_XELEMS * 8;
+  return (size_t)(PksCfg<R, L0, S>::TWN + (S > 0 ? Sr : PksCfg<R, L0, S>::WPB) * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksCfg<R, L0, S>::WPB * D16_XELEMS * 8;
 }
+// The 96 entries of pass sp into the wave's slice by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane to base + 16 lane, no
+// register in between -- the float64 rows have none to spare across their draws): one instruction of the whole wave and one of its
+// lower half.  hipcc waits for it (vmcnt) before the first LDS read that follows.  float64 pipeline only (16-byte entries).
+__device__ __forceinline__ void pks_slice_load(const cpx<double>* cw, cpx<double>* slice, int sp, int lane) {
+  const cpx<double>* src = cw + sp * PKS_SPAN + lane;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)slice, 16, 0, 0);
+  if (lane < 32)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64), (__attribute__((address_space(3))) void*)(slice + 64), 16, 0, 0);
+}
+__device__ __forceinline__ void pks_slice_load(const cpx<float>*, cpx<float>*, int, int) {}      // (never instantiated for a launch: fastmc.hip pks_variant)
 template <class R, int L0, int S, int MODE>
 __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -991,10 +1003,12 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
   Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
   cpx<R>* s_cw = s_tw + C::TWN;
-  E* s_x = reinterpret_cast<E*>(s_cw + Sr * PKS_SPAN);
+  constexpr bool SLICE = S <= 0;                          // pcw by the pass, one copy per wave
+  E* s_x = reinterpret_cast<E*>(s_cw + (SLICE ? WPB : Sr) * PKS_SPAN);
   if constexpr (MODE == 2) { gen64_lds0_check(s_g64); load_gen64_table(s_g64, A.g64); }
   for (int i = threadIdx.x; i < C::TWN; i += blockDim.x) s_tw[i] = A.tw[i];
-  for (int i = threadIdx.x; i < Sr * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
+  if constexpr (!SLICE)
+    for (int i = threadIdx.x; i < Sr * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * D16_XELEMS;
@@ -1030,6 +1044,8 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
     for (int sp = 0; sp < Sr; ++sp) {
       // sub-row sp of the G rows: kx = sp + S (q + L j), stream t = sp + S q of SL = S L
       xoshiro128p rs = row_stream(A.key, g, ky0 + Sr * gl, sp + Sr * q, Sr * L);
+      // (the wave's slice: its reads of the pass before were issued, and waited for, before this -- DS operations of a wave run in order)
+      if constexpr (SLICE) pks_slice_load(A.cw, s_cw + w * PKS_SPAN, sp, lane);
       if (MODE == 0) {
         const float* ampf = A.ampf + (size_t)ky0 * N + sp * C::M + lane_in;
 #pragma unroll
@@ -1047,10 +1063,12 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
           asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs.s0), "+v"(rs.s1), "+v"(rs.s2), "+v"(rs.s3));
         }
       }
-      if constexpr (L0 < 0) pks64_pass<R>(ex, xbuf, s_tw, s_cw + sp * PKS_SPAN);
+      const cpx<R>* cw_s = SLICE ? s_cw + w * PKS_SPAN : s_cw + sp * PKS_SPAN;
+      if constexpr (SLICE) ex.sync();
+      if constexpr (L0 < 0) pks64_pass<R>(ex, xbuf, s_tw, cw_s);
       else {
         packed_row_fft<R, L0, C::NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
-        pks_accumulate<R, L0, C::FIRST>(ex, s_cw + sp * PKS_SPAN);
+        pks_accumulate<R, L0, C::FIRST>(ex, cw_s);
       }
     }
     cpx<R>* out = A.V + (size_t)b * A.Np * N + s_r * M + mu;      // V[b][oi][position of ky]
@@ -1063,14 +1081,14 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
 // The column pass of the same grids: G window columns per wavefront, S passes over a column's sub-rows (contiguous in the permuted V),
 // the detector as k_cols_pk's rolled loop over the lane's accumulators, the sums reduced over the L lanes of a column by DPP.
 template <class R, int L0, int S> struct PksColCfg {
-  // (a run-time sub-row count, S <= 0, can be 27: 41 KB of twiddles -- twelve waves)
+  // (a run-time sub-row count: twelve waves -- sixteen exchange buffers + sixteen table slices would be 163 KB)
   // 122 registers (M = 256) / 152 (M = 128: twelve accumulators) with float64: four / three waves per SIMD; the exchange buffers and
   // the tables of sixteen / twelve waves fit the LDS (150 KB / 117 KB at most)
   static constexpr int WPC = S <= 0 ? 12 : ((L0 != 0 || sizeof(R) == 4) ? 16 : 12);      // (64-point sub-rows: 126 registers)
 };
 template <class R, int L0, int S>
 __host__ __device__ constexpr size_t pks_cols_lds_bytes(int Sr) {
-  return (size_t)(PksCfg<R, L0, S>::TWN + Sr * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksColCfg<R, L0, S>::WPC * D16_XELEMS * 8;
+  return (size_t)(PksCfg<R, L0, S>::TWN + (S > 0 ? Sr : PksColCfg<R, L0, S>::WPC) * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksColCfg<R, L0, S>::WPC * D16_XELEMS * 8;
 }
 template <class R, int L0, int S, int EPI>
 __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(ColArgs<R> A) {
@@ -1081,9 +1099,11 @@ __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(Co
   const int Sr = S > 0 ? S : A.S, N = Sr * M;
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
   cpx<R>* s_cw = s_tw + C::TWN;
-  E* s_x = reinterpret_cast<E*>(s_cw + Sr * PKS_SPAN);
+  constexpr bool SLICE = S <= 0;                          // pcw by the pass, one copy per wave (as k_rows_pks)
+  E* s_x = reinterpret_cast<E*>(s_cw + (SLICE ? WPC : Sr) * PKS_SPAN);
   for (int i = threadIdx.x; i < C::TWN; i += blockDim.x) s_tw[i] = A.tw[i];
-  for (int i = threadIdx.x; i < Sr * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
+  if constexpr (!SLICE)
+    for (int i = threadIdx.x; i < Sr * PKS_SPAN; i += blockDim.x) s_cw[i] = A.cw[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * D16_XELEMS;
@@ -1103,10 +1123,12 @@ __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(Co
   for (int sp = 0; sp < Sr; ++sp) {
 #pragma unroll
     for (int j = 0; j < VPL; ++j) regs.v[j] = load_v(col + sp * M + lane_in + L * j);
-    if constexpr (L0 < 0) pks64_pass<R>(ex, xbuf, s_tw, s_cw + sp * PKS_SPAN);
+    const cpx<R>* cw_s = SLICE ? s_cw + w * PKS_SPAN : s_cw + sp * PKS_SPAN;
+    if constexpr (SLICE) { pks_slice_load(A.cw, s_cw + w * PKS_SPAN, sp, lane); ex.sync(); }
+    if constexpr (L0 < 0) pks64_pass<R>(ex, xbuf, s_tw, cw_s);
     else {
       packed_row_fft<R, L0, NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
-      pks_accumulate<R, L0, C::FIRST>(ex, s_cw + sp * PKS_SPAN);
+      pks_accumulate<R, L0, C::FIRST>(ex, cw_s);
     }
   }
   double acc[4] = {0.0, 0.0, 0.0, 0.0};

@@ -167,21 +167,20 @@ def pk_grid(N):
 
 def pks_split(N):
     """fmc_core.h: pks_split -- grids of the packed SUB-ROWS (round 6): N = S * 256, else S * 128, else S * 64 -- every multiple of
-    64 from 192 to 4032 except the packed grids (128, 256, 512), the grids of the P = 16 rows (1024, 2048, 4096) and the odd
-    multiples of 64 beyond 2112 (S > 33); 0 otherwise."""
+    64 from 192 to 4032 except the packed grids (128, 256, 512) and the grids of the P = 16 rows (1024, 2048, 4096); 0 otherwise."""
     if N % 64 or N < 192 or N >= 4096 or N in (256, 512, 1024, 2048):
         return 0
     if N % 256 == 0:
         return N // 256
     if N % 128 == 0:
         return N // 128
-    return N // 64 if N // 64 <= 33 else 0
+    return N // 64
 
 
 def stream_lanes(N):
     """fmc_core.h: stream_lanes -- generator streams per row: N / 16 on the packed grids (128, 256, 512) and on the grids of
     the packed sub-rows of 256 / 128 points (384, 640, 768, ... 3968: multiples of 128): sixteen draws per stream; N / 8 on those of 64 points
-    (192, 320, 448, ... 2112: odd multiples of 64): eight draws; 50 S on the 50-lane grids, else 64 * spec_split(N)."""
+    (192, 320, 448, ... 4032: odd multiples of 64): eight draws; 50 S on the 50-lane grids, else 64 * spec_split(N)."""
     if pks_split(N) and N % 128:        # sub-rows of 64 points (odd multiples of 64): eight draws per stream
         return N // 8
     if pk_grid(N) or pks_split(N):

@@ -385,8 +385,8 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (2048, 402, None, "k_rows_wave<double, 16, 8, 2, 2, 7>"), (4096, 100, None, "k_rows_wave<double, 16, 2, 2, 4, 6>"),
             # ... whose centred windows of up to 96 pixels go to the packed sub-rows (eight / sixteen sub-rows of 256 points, count at run time:
             # the same N / 16 streams per row, +7 % / +15 %); 1024 keeps its dense sixteen-wave row (fastmc.hip: pks_p16_from)
-            (2048, 82, None, "k_rows_pks<double, 1, -2, 2>"), (2048, 96, 980, "k_rows_pks<double, 1, -2, 2>"), (4096, 82, None, "k_rows_pks<double, 1, -2, 2>"),
-            (2048, 82, 900, "k_rows_wave<double, 16, 2, 2, 2, 5>"),
+            (2048, 82, None, "k_rows_pks<double, 1, -2, 2>"), (2048, 96, 976, "k_rows_pks<double, 1, -2, 2>"), (4096, 82, None, "k_rows_pks<double, 1, -2, 2>"),
+            (2048, 82, 900, "k_rows_wave<double, 16, 2, 2, 2, 7>"),
             # packed rows (eight / four / two rows per wavefront): centred six planes and all planes
             (128, 82, None, "k_rows_pk<double, 0, 2, 0>"), (128, 128, None, "k_rows_pk<double, 0, 2, 1>"),
             (256, 82, None, "k_rows_pk<double, 1, 2, 0>"), (256, 200, None, "k_rows_pk<double, 1, 2, 1>"), (256, 82, 100, "k_rows_pk<double, 1, 2, 1>"),
@@ -428,6 +428,7 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (704, 82, None, "k_rows_pks<double, -1, 0, 2>"), (960, 96, None, "k_rows_pks<double, -1, 0, 2>"), (2112, 82, None, "k_rows_pks<double, -1, 0, 2>"),
             (1408, 82, None, "k_rows_pks<double, 0, 0, 2>"), (3968, 60, 1950, "k_rows_pks<double, 0, 0, 2>"), (2816, 82, None, "k_rows_pks<double, 1, 0, 2>"),
             (1600, 82, None, "k_rows_pks<double, -1, 0, 2>"), (3200, 82, None, "k_rows_pks<double, 0, 0, 2>"),
+            (2240, 82, None, "k_rows_pks<double, -1, 0, 2>"), (4032, 96, None, "k_rows_pks<double, -1, 0, 2>"),      # 35 / 63 sub-rows of 64 points
             (832, 120, None, "k_rows_blu<double, 16, 2, 1, false>"), (1600, 82, 3, "k_rows_mr<double, 16, 2, 1, true, 50, 0>"),
             # chirp-z family (any other N): one transform of length 64 P, and rows in input blocks beyond 2048
             (164, 60, None, "k_rows_blu<double, 4, 2, 2, false>"), (291, 82, 5, "k_rows_blu<double, 8, 2, 2, false>"),

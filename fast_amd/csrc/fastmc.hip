@@ -134,7 +134,7 @@ struct fastmc_ctx {
   void* omg = nullptr;     //   host coefficients: TEMPORAL layer screens, centred_fft2)
   void* pk_tw1 = nullptr;  // N = 256, 512: tables of the packed rows (fmc_wavefft.h: build_tw1_pk / build_om_pk)
   void* pk_om = nullptr;
-  void* pks_tw1 = nullptr; // N = 640 ... 1792 (fmc_core.h: pks_split): tables of the packed sub-rows (fmc_wavefft.h: build_tw1_pk for M = 256, build_pcw)
+  void* pks_tw1 = nullptr; // grids of the packed sub-rows (fmc_core.h: pks_count -- every multiple of 64 from 192 to 4096 but 256, 512): tables of the packed sub-rows (fmc_wavefft.h: build_tw1_pk for M = 256, build_pcw)
   void* pks_cw = nullptr;
   double* W = nullptr;
   void* V = nullptr;
@@ -1274,8 +1274,7 @@ int dispatch_pk(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int m
   return 0;
 }
 
-// Row pass of the packed sub-rows (640 ... 1792; fmc_kernels.h: k_rows_pks); the column pass follows from dispatch_wave_part with
-// mode -1.
+// Row pass of the packed sub-rows (fmc_kernels.h: k_rows_pks; S <= 0: the sub-row count at run time).
 template <class R, int L0, int S, int MODE>
 static void launch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
   using C = PksCfg<R, L0, S>;

@@ -157,7 +157,9 @@ class Fast():
                 raise Exception("GPU_KERNELS must be 'auto', 'wave', 'lanes50', 'chirpz' or 'direct'")
             self._group.each(lambda h, i: h.kernel_path(_lib.KERNEL_PATHS[p['GPU_KERNELS']]))
         self.compute_powerspec()
-        if self._handle.kernel_path() not in (1, 3) and self.Npxls >= 128 and not self.temporal:
+        # (every multiple of 64 from 192 to 4096 has the packed sub-rows for device-generator runs, whatever family holds its other rows)
+        packed_sub_rows = self.Npxls % 64 == 0 and 192 <= self.Npxls <= 4096 and self.rng_mode == 'device'
+        if self._handle.kernel_path() not in (1, 3) and self.Npxls >= 128 and not self.temporal and not packed_sub_rows:
             below = [n for n in host.ROUND_UP_SIZES if n <= self.Npxls][-1:]
             above = [n for n in host.ROUND_UP_SIZES if n >= self.Npxls][:1]
             near = ', '.join(str(n) for n in below + above)

@@ -44,18 +44,21 @@ def big_grid_supported(N):
             if any(q % S == 0 and 7 <= q // S <= 24 and _radix_ok(q // S) for S in range(2, 9)):
                 return True
     return False
-# Measured float64 throughput [k iterations/s, Np = 82, device generator] of every grid size that has an FFT kernel family
-# (tools/sizesweep.sh on one MI355X; profiles/r01k_sizesweep_f64.txt, r02g_sizesweep_lanes50_f64.txt, r03_packed_rows_rates.txt for
-# 128 / 256 / 512):
-# 64 P wave sizes, 64 P S with run-time sub-rows, 50 P S on the 50-lane kernels.  GPU_ROUND_NPXLS rounds an auto-sized grid
-# up to the smallest of these that is within 10 % of the fastest one not smaller than it (896 and 1792, radix-7 stages, lose
-# to 1024 and 2048; 2048 beats everything between 1600 and itself).
+# Measured throughput [k iterations/s, Np = 82, float64 pipeline, float64 device generator] of every grid size that has a pruned-FFT row
+# (tools/sizesweep.sh on one MI355X: profiles/r06y_sizesweep_every_multiple_of_64.txt, round 6): every multiple of
+# 64 (packed rows 128 / 256 / 512, packed sub-rows 192 ... 4096, the dense 1024 row) and the 50 P S grids of the 50-lane kernels.
+# GPU_ROUND_NPXLS (off by default) rounds an auto-sized grid up to the smallest of these that is within 10 % of the fastest one not
+# smaller than it (the 50-lane grids run 0.55-0.69 of the 1024-point row's rate per pixel and lose to the next multiple of 64).
 FAST_SIZE_RATE = {
-    128: 14000, 192: 5600, 256: 7400, 320: 3400, 384: 2700, 448: 2200, 512: 2900, 576: 1400, 640: 1300, 768: 1150, 896: 550,
-    1024: 920, 1152: 460, 1280: 370, 1536: 360, 1792: 145, 2048: 245, 4096: 62,
-    1344: 318, 1728: 174, 1920: 159, 2304: 86, 2560: 75, 3072: 85, 3584: 43, 3840: 35,
-    100: 8060, 150: 6150, 200: 4850, 250: 3900, 300: 3170, 350: 2545, 400: 2490, 450: 1930, 500: 1930, 600: 1490, 700: 830,
-    800: 820, 900: 590, 1000: 580, 1200: 455, 1400: 227, 1500: 249, 1600: 198, 2000: 124, 2500: 91, 3000: 57, 4000: 32,
+    128: 13104, 192: 7811, 256: 5870, 320: 3892, 384: 3015, 448: 2414, 512: 2104, 576: 1624, 640: 1341, 704: 1118,
+    768: 1033, 832: 856, 896: 738, 960: 664, 1024: 617, 1088: 506, 1152: 458, 1216: 420, 1280: 407, 1344: 348, 1408: 318,
+    1472: 293, 1536: 288, 1600: 242, 1664: 223, 1728: 200, 1792: 214, 1856: 169, 1920: 166, 1984: 158, 2048: 168,
+    2112: 125, 2176: 131, 2240: 119, 2304: 130, 2368: 113, 2432: 107, 2496: 95.1, 2560: 105, 2624: 88.9, 2688: 86.8,
+    2752: 81.8, 2816: 85.6, 2880: 68.5, 2944: 71.4, 3008: 65.3, 3072: 73.2, 3136: 62.1, 3200: 61.6, 3264: 60.2, 3328: 62.5,
+    3392: 52.9, 3456: 52.4, 3520: 51.0, 3584: 54.1, 3648: 42.6, 3712: 46.4, 3776: 41.3, 3840: 47.3, 3904: 40.3, 3968: 39.9,
+    4032: 39.1, 4096: 41.8,
+    100: 8395, 150: 6179, 200: 4958, 250: 3865, 300: 3337, 350: 2581, 400: 2264, 450: 1856, 500: 1695, 600: 1239, 700: 726,
+    800: 617, 900: 546, 1000: 415, 1200: 277, 1400: 184, 1500: 199, 2000: 96.7, 2500: 70.2, 3000: 43.7, 4000: 24.8,
 }
 ROUND_UP_SIZES = sorted(FAST_SIZE_RATE)
 _ROUND_WARNED = False

@@ -197,9 +197,12 @@ int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches);
  *   1 = wave-FFT (N = 64 P with P = 2^k times 1, 3, 5, 7 or 9, P <= 32: 128, 192, 256, 320, 384, 448, 512, 576, 640, 768,
  *       896, 1024, 1152, 1280, 1536, 1792, 2048 / 4096 as interleaved sub-rows of 1024, and 1344, 1728, 1920, 2304, 2560,
  *       2688, 3072, 3456, 3584, 3840 as 2 ... 4 interleaved sub-rows of 448 ... 1536).  128, 256, 512 run as packed rows (8 / 4 / 2
- *       rows per wavefront); the device generator's rows of 192, 320, 384, 448, 576, 640, 768, 896, 1152, 1280, 1536, 1792 with a centred
- *       window of up to 96 pixels as packed SUB-ROWS, rows and columns (S interleaved sub-rows of 64 / 128 / 256 points, 8 / 8 / 4 rows per
- *       wavefront; round 6) -- the generator draws N / 16 streams per row on these fifteen grids (N / 8 on the four of 64-point sub-rows);
+ *       rows per wavefront).
+ *       Whatever family a grid belongs to (1, 2 or 3), the device generator's rows of EVERY multiple of 64 from 192 to 4096 except
+ *       256, 512 and 1024, with a centred window of up to 96 pixels, run as packed SUB-ROWS, rows and columns (S interleaved sub-rows
+ *       of 256 / 128 / 64 points, S = N / 256, else N / 128, else N / 64; 4 / 8 / 8 rows per wavefront; round 6) -- the generator draws
+ *       N / 16 streams per row on these grids (N / 8 on the odd multiples of 64), as it always did on 2048 and 4096; the family
+ *       reported here transforms their host coefficients and any other window;
  *   3 = 50-lane FFT (round decimal grids N = 50 P S, P as above and <= 24, S <= 5 interleaved sub-rows: 100, 150, ..., 500,
  *       600, ..., 1000, 1200, 1350, 1400, 1500, 1600, 1750, 1800, 2000, 2100, 2250, 2400, 2500, 2700, 2800, 3000, 3200,
  *       3500, 3600, 4000; Np <= 128, or <= 256 for P = 8, 10, 12, 16, 20, 24).  The device generator draws 50 S streams per

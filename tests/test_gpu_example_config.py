@@ -32,10 +32,10 @@ def shipped_example(**over):
 # to 164 (fast/fast.py:167-189) and so does this repo by default (GPU_ROUND_NPXLS False since round 6: a drop-in keeps the reference's
 # grid; chirp-z kernels); GPU_ROUND_NPXLS 'auto' / True round a device-generator Monte-Carlo run up to the next fast-kernel size.
 VARIANTS = [
-    (dict(FFTW=True), 164), (dict(TEMPORAL=False), 164), (dict(TEMPORAL=False, GPU_ROUND_NPXLS="auto"), 256), (dict(SUBHARM=True, TEMPORAL=False), 164), (dict(OBSC_GROUND=0.1), 164),
+    (dict(FFTW=True), 164), (dict(TEMPORAL=False), 164), (dict(TEMPORAL=False, GPU_ROUND_NPXLS="auto"), 192), (dict(SUBHARM=True, TEMPORAL=False), 164), (dict(OBSC_GROUND=0.1), 164),
     (dict(OBSC_SAT=0.05), 164), (dict(W0=0.1, AXICON=True, OBSC_GROUND=0.1), 164), (dict(L0=25), None), (dict(PROP_DIR="down"), 164),
     (dict(AO_MODE="NOAO"), None), (dict(AO_MODE="TT"), 164), (dict(NOISE=1), 164), (dict(MODAL=True), 164),
-    (dict(TEMPORAL=False, GPU_PRECISION="f32"), 164), (dict(TEMPORAL=False, GPU_PRECISION="f32", GPU_ROUND_NPXLS=True), 256), (dict(TEMPORAL=False, GPU_RNG="host"), 164), (dict(TEMPORAL=False, NPXLS=256), 256),
+    (dict(TEMPORAL=False, GPU_PRECISION="f32"), 164), (dict(TEMPORAL=False, GPU_PRECISION="f32", GPU_ROUND_NPXLS=True), 192), (dict(TEMPORAL=False, GPU_RNG="host"), 164), (dict(TEMPORAL=False, NPXLS=256), 256),
 ]
 
 

@@ -145,21 +145,23 @@ def test_optional_rounding_of_auto_grid_size():
     p["GPU_ROUND_NPXLS"] = False
     assert host.build_problem(dict(p)).N == 164                      # the reference's auto rule
     p["GPU_ROUND_NPXLS"] = True
-    assert host.build_problem(dict(p)).N == 256                      # four rows per wavefront: faster than 192 .. 250
+    assert host.build_problem(dict(p)).N == 192                      # the next multiple of 64: three sub-rows of 64 points, eight rows per wavefront
     p["GPU_ROUND_NPXLS"] = "auto"                                    # (the default of rounds 3-5) round unless the grid is tied to the reference's
-    for rng_mode, temporal, n in (("device", False, 256), ("host", False, 164), ("device", True, None)):
+    for rng_mode, temporal, n in (("device", False, 192), ("host", False, 164), ("device", True, None)):
         q = dict(p, GPU_RNG=rng_mode, TEMPORAL=temporal)
         if n is not None:
             assert host.build_problem(q).N == n
         else:
-            assert host.build_problem(q).N not in (256,) or host.build_problem(dict(q, GPU_ROUND_NPXLS=False)).N == 256
+            assert host.build_problem(q).N not in (192,) or host.build_problem(dict(q, GPU_ROUND_NPXLS=False)).N == 192
     assert host.WAVE_FFT_SIZES == [128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1152, 1280, 1536, 1792, 2048, 4096]
-    # rounding goes to the smallest fast grid within 10 % of the best rate at or above N: slow radices are skipped
+    # rounding goes to the smallest fast grid within 10 % of the best rate at or above N: since round 6 every multiple of 64 is one
+    # (packed sub-rows), so it is the next multiple of 64 nearly everywhere (2048 beats 1856 ... 1984 by less than 10 %)
     assert [host.round_up_size(n) for n in (90, 101, 164, 510, 820, 1030, 1290, 1700, 2050, 2310, 3100, 4097)] == \
-        [128, 128, 256, 512, 1024, 1152, 1536, 2048, 2304, 2500, 4096, None]
+        [128, 128, 192, 512, 832, 1088, 1344, 1728, 2112, 2368, 3136, None]
+    assert all(host.round_up_size(n) - n < 128 for n in range(129, 4096, 7))       # (3072 and 3840, 256-point sub-rows, beat the multiple of 64 below them)
     from oracle import devrng
     for n in host.ROUND_UP_SIZES:       # every listed size has an FFT kernel family in the library
-        assert n in host.WAVE_FFT_SIZES or devrng.wave_rt_split(n) or devrng.mr_supported(n), n
+        assert n in host.WAVE_FFT_SIZES or devrng.pks_split(n) or devrng.mr_supported(n), n
 
 
 def test_comms_host_logic_without_gpu(monkeypatch):

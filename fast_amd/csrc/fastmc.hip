@@ -1415,13 +1415,17 @@ static void launch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA,
   const int blocks = ((RA.N + LR - 1) / LR) * ((RA.nb + BPG - 1) / BPG);
   {
     Span s(h, 0);
+    // (LN = 64: the run-time-split grids are multiples of 64, whose device draws go to the packed sub-rows, staged draws or the direct
+    // family -- they draw N / 16 or N / 8 streams per row -- so their rows exist for host coefficients only; run_impl never asks for more)
     if (mode == 0) {
+      if constexpr (LN != WAVE) {
       hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 0, SPLIT, LN, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((k_rows_mr<R, P, NS, 0, SPLIT, LN, PR>), dim3(blocks), dim3(WPB * 64), lds, h->stream, RB);
       FMC_NOTE(h->last_rows, "k_rows_mr<%s, %d, %d, %d, %s, %d, %d>", rname<R>(), P, NS, 0, SPLIT ? "true" : "false", LN, PR);
+      }
     } else if (mode == 2) {
       // the float64 generator fused into the row (run_impl: fused_gen64 has checked that its tables fit)
-      if constexpr (PR == 0 && sizeof(R) == 8) {
+      if constexpr (PR == 0 && sizeof(R) == 8 && LN != WAVE) {
         const size_t lds2 = lds + GEN64_TABLE_BYTES;
         hipFuncSetAttribute((const void*)k_rows_mr<R, P, NS, 2, SPLIT, LN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         hipLaunchKernelGGL((k_rows_mr<R, P, NS, 2, SPLIT, LN, 0>), dim3(blocks), dim3(WPB * 64), lds2, h->stream, RB);
@@ -1453,7 +1457,7 @@ static void launch_mr(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA,
 template <class R, int P, int NS, bool SPLIT, int LN = MR_LN>
 static void dispatch_mr_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   constexpr int L1 = LN == MR_LN ? 10 : 8;
-  if constexpr (NS == 2 && P >= 16) {
+  if constexpr (NS == 2 && P >= 16 && LN == MR_LN) {      // (64 lanes: host-coefficient rows only -- launch_mr)
     if (mode == 0 && epi == 0) {
       const int S = RA.N / (LN * P);
       const int win = window_planes(h->lo, h->Np, P, L1);

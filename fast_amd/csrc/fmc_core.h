@@ -472,14 +472,14 @@ FMC_HD constexpr int pks_ct(int N) {         // the sub-row count is a template 
   return N == 768 ? 3 : (N == 1280 ? 5 : (N == 1536 ? 6 : (N == 1792 ? 7 : (N == 640 ? 5 : (N == 896 ? 7 : (N == 1152 ? 9 :
          (N == 576 ? 9 : (N == 448 ? 7 : (N == 320 ? 5 : (N == 192 ? 3 : (N == 384 ? 3 : 0)))))))))));
 }
-// EVERY other multiple of 64 below 4096 that has no faster form (128, 256, 512: packed rows; 1024: the dense P = 16 row; 2048 / 4096: pks_p16 below) takes
-// the same kernels with the sub-row count at RUN TIME: N = S x 256 (2304 ... 3840, S = 9 ... 15, either parity), else S x 128 (odd
-// S = 11 ... 31: 1408 ... 3968), else S x 64 (odd S = 11 ... 63: 704 ... 4032; the table of pks_accumulate goes through the LDS one
+// EVERY other multiple of 64 up to 8192 (the library's largest grid) that has no faster form (128, 256, 512: packed rows; 1024: the dense P = 16 row; 2048 / 4096: pks_p16 below) takes
+// the same kernels with the sub-row count at RUN TIME: N = S x 256 (2304 ... 8192, S = 9 ... 32, either parity), else S x 128 (odd
+// S = 11 ... 63: 1408 ... 8064), else S x 64 (odd S = 11 ... 127: 704 ... 8128; the table of pks_accumulate goes through the LDS one
 // pass at a time).  These were the grids of wave_rt_split (two to four
 // one-row-per-wave sub-rows of 7 ... 24 values per lane: 0.58-0.72 of the 1024-point row's rate per pixel), of the chirp-z family
 // (704, 832, 960, 1088, ...: about a third) and 1600 / 3200 of the 50-lane family; those families keep their host-coefficient rows.
 FMC_HD constexpr int pks_rt(int N) {
-  if (N % 64 != 0 || N < 192 || N >= 4096 || pk_grid(N) || N == 1024 || N == 2048 || pks_ct(N)) return 0;
+  if (N % 64 != 0 || N < 192 || N > 8192 || pk_grid(N) || N == 1024 || N == 2048 || N == 4096 || pks_ct(N)) return 0;
   if (N % 256 == 0) return N / 256;
   if (N % 128 == 0) return N / 128;
   return N / 64;

@@ -167,8 +167,8 @@ def pk_grid(N):
 
 def pks_split(N):
     """fmc_core.h: pks_split -- grids of the packed SUB-ROWS (round 6): N = S * 256, else S * 128, else S * 64 -- every multiple of
-    64 from 192 to 4032 except the packed grids (128, 256, 512) and the grids of the P = 16 rows (1024, 2048, 4096); 0 otherwise."""
-    if N % 64 or N < 192 or N >= 4096 or N in (256, 512, 1024, 2048):
+    64 from 192 to 8192 except the packed grids (128, 256, 512) and the grids of the P = 16 rows (1024, 2048, 4096); 0 otherwise."""
+    if N % 64 or N < 192 or N > 8192 or N in (256, 512, 1024, 2048, 4096):
         return 0
     if N % 256 == 0:
         return N // 256

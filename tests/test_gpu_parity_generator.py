@@ -612,15 +612,21 @@ def test_tile_walk_equals_one_tile_per_workgroup(N, n):
 
 
 # ------------------------------------------------------------------ grids beyond 4096 (the reference has no upper limit, fast.py:176-211)
-@pytest.mark.parametrize("N,Np,kernel", [(4608, 60, "k_rows_mr<double, 24, 2, 0, true, 64, 2>"), (5000, 82, "k_rows_mr<double, 20, 2, 0, true, 50, 1>"),
-                                         (7168, 100, "k_rows_mr<double, 16, 2, 0, true, 64, 0>"), (8192, 82, "k_rows_mr<double, 16, 2, 0, true, 64, 2>"),
-                                         (4100, 82, "k_rows_blu<double, 16, 2, 0, true>"), (7003, 200, "k_rows_blu<double, 16, 4, 0, true>")])
-def test_grids_beyond_4096_run_as_up_to_eight_sub_rows(N, Np, kernel):
-    """N = 64 P S / 50 P S with a run-time sub-row count S <= 8 (fmc_core.h: wave_rt_split / mr_split) up to 8192, and any other
-    N <= 8192 on the chirp-z kernels with its rows in up to eleven input blocks: screens from host coefficients against numpy's
-    FFT; the device generator through the family's rows against the oracle on the restated draws (one size: the restatement is
-    Python) and against the direct family on the same seed; the float64 generator fused in the rows against the direct family's
-    staged draws."""
+@pytest.mark.parametrize("N,Np,kernel,kernel64", [
+    # multiples of 64: the packed sub-rows with a run-time count for the centred windows (18 / 32 sub-rows of 256 points, 65 of 64) ...
+    (4608, 60, "k_rows_pks<double, 1, -2, 0>", "k_rows_pks<double, 1, -2, 2>"), (8192, 82, "k_rows_pks<double, 1, -2, 0>", "k_rows_pks<double, 1, -2, 2>"),
+    (4160, 82, "k_rows_pks<double, -1, 0, 0>", "k_rows_pks<double, -1, 0, 2>"),
+    # ... any other window: the float32 draw on the direct family, the float64 generator staged onto the family's host-coefficient rows
+    (7168, 100, "k_rows_direct<double, 0>", "k_rows_mr<double, 16, 2, 1, true, 64, 0>"),
+    (5000, 82, "k_rows_mr<double, 20, 2, 0, true, 50, 1>", "k_rows_mr<double, 20, 2, 2, true, 50, 0>"),
+    (4100, 82, "k_rows_blu<double, 16, 2, 0, true>", "k_rows_blu<double, 16, 2, 2, true>"),
+    (7003, 200, "k_rows_blu<double, 16, 4, 0, true>", "k_rows_blu<double, 16, 4, 2, true>")])
+def test_grids_beyond_4096(N, Np, kernel, kernel64):
+    """Up to 8192: multiples of 64 on the packed sub-rows (fmc_core.h: pks_rt), N = 64 P S / 50 P S with a run-time sub-row count S <= 8
+    (wave_rt_split / mr_split) for their host coefficients and other windows, and any other N on the chirp-z kernels with its rows in up
+    to eleven input blocks: screens from host coefficients against numpy's FFT; the device generator through the rows against the
+    oracle on the restated draws (one size: the restatement is Python) and against the direct family on the same seed; the float64
+    generator against the direct family's staged draws."""
     rng = np.random.default_rng(N)
     ps, df = _vk_spectrum(N, 0.01, 30.0)
     ps = ps * 0.02
@@ -642,7 +648,7 @@ def test_grids_beyond_4096_run_as_up_to_eight_sub_rows(N, Np, kernel):
         np.testing.assert_allclose(got, want, rtol=1e-5)
     h.set_rng_precision("f64")
     got64 = h.run(seed, real0, 1, None, 0.01)
-    assert ", 2, true" in h.last_kernels()[0]                   # MODE 2: the float64 generator inside the row
+    assert h.last_kernels()[0] == kernel64
     h.kernel_path(0)
     np.testing.assert_allclose(got64, h.run(seed, real0, 1, None, 0.01), rtol=1e-9)
     h.set_rng_precision("f32")

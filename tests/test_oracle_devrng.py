@@ -130,9 +130,9 @@ def test_stream_layout_of_the_50_lane_grids():
     assert devrng.stream_lanes(3072) == 192 and devrng.stream_lanes(1344) == 168 and devrng.stream_lanes(3584) == 224
     assert devrng.stream_lanes(1728) == 216 and devrng.stream_lanes(1920) == 120 and devrng.stream_lanes(2688) == 168 and devrng.stream_lanes(3840) == 240
     assert all(devrng.pks_split(n) for n in range(2, 4096) if devrng.wave_rt_split(n))
-    # ... and every other multiple of 64 up to 4032 (chirp-z and 50-lane grids among them)
+    # ... and every other multiple of 64 up to 8192 (chirp-z and 50-lane grids among them)
     assert devrng.stream_lanes(3200) == 200 and devrng.stream_lanes(1600) == 200 and devrng.stream_lanes(960) == 120 and devrng.stream_lanes(704) == 88
-    assert devrng.stream_lanes(2112) == 264 and devrng.stream_lanes(2240) == 280 and devrng.stream_lanes(4032) == 504 and devrng.stream_lanes(3968) == 248 and devrng.stream_lanes(2816) == 176
+    assert devrng.stream_lanes(2112) == 264 and devrng.stream_lanes(2240) == 280 and devrng.stream_lanes(4032) == 504 and devrng.stream_lanes(8192) == 512 and devrng.stream_lanes(4160) == 520 and devrng.stream_lanes(5000) == 250 and devrng.stream_lanes(3968) == 248 and devrng.stream_lanes(2816) == 176
     assert devrng.stream_lanes(1400) == 100 and devrng.stream_lanes(800) == 50 and devrng.stream_lanes(4096) == 256
     c2 = devrng.device_coefficients(5, 0, 1400)[:3]
     assert np.isfinite(c2).all() and len(np.unique(c2.ravel())) == 3 * 1400

@@ -34,7 +34,7 @@ for c in range(cases):
     if N > 4096:
         Np = int(rng.integers(1, 200))
     lo = int(rng.choice([0, N - Np, (N - Np) // 2, rng.integers(0, N - Np + 1)]))
-    if N % 64 == 0 and 192 <= N < 4096 and N not in (256, 512, 1024, 2048) and rng.random() < 0.6:
+    if N % 64 == 0 and 192 <= N <= 8192 and N not in (256, 512, 1024) and rng.random() < 0.6:
         # grids of the packed sub-rows (round 6): two cases in three inside the 96 outputs their six planes hold
         Np = int(rng.integers(1, 97))
         lo = int(rng.integers(max(N // 2 - 48, 0), N // 2 + 48 - Np + 1))

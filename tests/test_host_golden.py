@@ -260,5 +260,5 @@ def test_grids_beyond_4096_that_the_kernels_serve():
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from oracle import devrng
-    for n in yes:      # the restated stream layout knows them too (sub-rows x lanes)
-        assert devrng.stream_lanes(n) in (64 * devrng.spec_split(n), 50 * devrng.mr_split(n)) and devrng.stream_lanes(n) > 64
+    for n in yes:      # the restated stream layout knows them too: N / 16 or N / 8 streams on the multiples of 64 (packed sub-rows), else 50 S
+        assert devrng.stream_lanes(n) == ((n // 16 if n % 128 == 0 else n // 8) if n % 64 == 0 else 50 * devrng.mr_split(n)) and devrng.stream_lanes(n) > 64

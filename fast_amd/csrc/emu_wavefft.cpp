@@ -506,15 +506,10 @@ int main() {
   bad += sweep_pks64<double, 33>("f64", 1e-13);
   bad += sweep_pks<double, 0, 31>("f64", 1e-13);
   bad += sweep_pks<double, 1, 11>("f64", 1e-13);
-  bad += sweep_pks64<double, 21>("f64", 1e-13);
-  bad += sweep_pks64<double, 27>("f64", 1e-13);
   bad += sweep_pks<double, 0, 15>("f64", 1e-13);
-  bad += sweep_pks<double, 0, 21>("f64", 1e-13);
   bad += sweep_pks<double, 0, 27>("f64", 1e-13);
   bad += sweep_pks<double, 1, 9>("f64", 1e-13);
   bad += sweep_pks<double, 1, 10>("f64", 1e-13);
-  bad += sweep_pks<double, 1, 12>("f64", 1e-13);
-  bad += sweep_pks<double, 1, 14>("f64", 1e-13);
   bad += sweep_pks<double, 1, 15>("f64", 1e-13);
   bad += sweep_pks<float, 1, 5>("f32", 2e-5);
   bad += sweep_pks<float, 0, 7>("f32", 2e-5);
@@ -551,6 +546,9 @@ int main() {
   bad += sweep_blu<double, 8, 4>("f64", 1e-12);
   bad += sweep_blu<double, 16, 2>("f64", 1e-12);
   bad += sweep_blu<double, 16, 4>("f64", 1e-12);
+  bad += sweep_blu<double, 12, 2>("f64", 1e-12);
+  bad += sweep_blu<double, 20, 2>("f64", 1e-12);
+  bad += sweep_blu<double, 28, 2>("f64", 1e-12);
   bad += sweep_blu<double, 24, 2>("f64", 1e-12);
   bad += sweep_blu<double, 32, 2>("f64", 1e-12);
   bad += sweep_blu_blocked<double, 2>("f64", 1e-12);

@@ -360,8 +360,13 @@ static int blu_pick_P(int N, int Np, int* SB = nullptr, int* B = nullptr) {
   if (N < 2 || mr_supported(N) || wave_rt_split(N)) return 0;      // 50 P grids are drawn as 50 streams per row: 50-lane or direct family
   const int ns = (Np + 63) / 64;
   if (ns > 4) return 0;
-  for (int P : {4, 8, 16, 24, 32}) {
+  // (12 and 28 -- M = 768, 1792 -- since round 6, windows of up to 128 pixels: +10-13 % over the next of 1024 / 2048; M = 1280 (P = 20)
+  // spills 356 B at eight waves and LOSES 40 % to M = 1536: not built -- profiles/r06_ab_chirpz_sizes.txt; FASTMC_BLU_P=0 keeps the
+  // five sizes of rounds 1-5 for an A/B)
+  static const bool more = !(getenv("FASTMC_BLU_P") && atoi(getenv("FASTMC_BLU_P")) == 0);
+  for (int P : {4, 8, 12, 16, 24, 28, 32}) {
     if (64 * P < N + Np - 1) continue;
+    if ((P == 12 || P == 28) && (!more || ns > 2)) continue;
     if (ns > 2 && !(P == 8 || P == 16 || P == 24)) continue;
     return P;
   }
@@ -1400,6 +1405,7 @@ int dispatch_blu(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int 
   }
 #define FMC_BLU(PP, NN) if (h->blu_P == PP && ns == NN) { dispatch_blu_pn<R, PP, NN>(h, RA, CA, mode, epi); return 0; }
   FMC_BLU(4, 2) FMC_BLU(8, 2) FMC_BLU(8, 4) FMC_BLU(16, 2) FMC_BLU(16, 4) FMC_BLU(24, 2) FMC_BLU(24, 4) FMC_BLU(32, 2)
+  FMC_BLU(12, 2) FMC_BLU(28, 2)
 #undef FMC_BLU
   return fail(FASTMC_ESTATE, "no chirp-z instantiation for this grid / window");
 }
@@ -1754,6 +1760,7 @@ static bool fused_gen64(fastmc_ctx* h) {
 #define FMC_G64_BLU(PP, NN) if (h->blu_P == PP && ns2 == NN) return blu_lds_bytes<R, PP, NN>(omS, BluCfg<R, PP, NN>::WPB) + GEN64_TABLE_BYTES <= LDS_MAX;
       if (h->blu_SB > 1) { FMC_G64_BLU(16, 2) FMC_G64_BLU(16, 4) return false; }
       FMC_G64_BLU(4, 2) FMC_G64_BLU(8, 2) FMC_G64_BLU(8, 4) FMC_G64_BLU(16, 2) FMC_G64_BLU(16, 4) FMC_G64_BLU(24, 2) FMC_G64_BLU(24, 4) FMC_G64_BLU(32, 2)
+      FMC_G64_BLU(12, 2) FMC_G64_BLU(28, 2)
 #undef FMC_G64_BLU
       return false;
     }

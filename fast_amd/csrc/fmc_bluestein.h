@@ -44,7 +44,10 @@ struct BluGeom {
   static constexpr int FBF = (P == 4) ? 46 : 8 * P + 24;
   static constexpr int X1 = G::XELEMS > 8 * FBF ? G::XELEMS : 8 * FBF;
   static constexpr int XELEMS = X1 > M ? X1 : M;
-  static_assert(P == 4 || P == 8 || P == 16 || P == 24 || P == 32, "chirp-z sizes: M = 256, 512, 1024, 1536, 2048");
+  // (round 6: also 12 and 28 -- M = 768, 1792 -- where 1024 / 2048 are a third / a seventh more work; in stage 2 their last group of
+  // eight butterflies runs on 4 of every 8 lanes.  20 (M = 1280) works -- the lane emulator covers it -- but its rows spill at eight
+  // waves and lose to M = 1536: not instantiated in the library)
+  static_assert(P == 4 || P == 8 || P == 12 || P == 16 || P == 20 || P == 24 || P == 28 || P == 32, "chirp-z sizes: M = 256, 512, 768, 1024, (1280,) 1536, 1792, 2048");
   static FMC_HD int swz(int x) {
     if (P == 16) return x ^ (((x >> 3) & 3) << 2);
     if (P == 32) return x ^ (((x >> 4) & 3) << 2);

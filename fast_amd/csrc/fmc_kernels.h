@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(Co
 template <class R, int P, int NS> struct BluCfg {
   static constexpr int W0 = WaveCfg<R, P, NS>::WPB;
   static constexpr int W1 = (NS == 4 && W0 > 8) ? 8 : W0;     // 256-pixel window tables: 8 waves fit the LDS
-  static constexpr int CAP = sizeof(R) == 8 ? (P >= 32 ? 4 : (P >= 16 ? 8 : 12)) : 12;
+  static constexpr int CAP = sizeof(R) == 8 ? (P >= 28 ? 4 : (P >= 16 ? 8 : 12)) : 12;
   static constexpr int WPB = W1 > CAP ? CAP : W1;
   // the column kernel has no generator and fits the 168-VGPR step at P = 16: twelve waves (500^2: 2.59 against 3.08 ms)
   static constexpr int WPB_COLS = (P == 16 && NS == 2) ? W1 : WPB;

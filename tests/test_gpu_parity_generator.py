@@ -270,7 +270,7 @@ _VARIANTS = [(1024, 40, None), (1024, 82, None), (1024, 96, None), (1024, 97, No
              (1000, 82, None), (2000, 82, None), (1200, 82, None), (500, 82, None), (3072, 82, None), (1344, 82, None),
              (1920, 82, None), (2304, 96, None), (2560, 60, 1236), (1728, 82, None), (1920, 120, None),     # packed sub-rows with a run-time count (pks_rt); the last: beyond them (direct family)
              (704, 82, None), (1088, 40, 530), (1600, 82, None), (1664, 96, None), (832, 82, 5), (1600, 100, None),     # ... on chirp-z and 50-lane grids; the last two: beyond them (direct family)
-             (164, 82, None), (943, 82, None),
+             (164, 82, None), (943, 82, None), (650, 82, None), (1502, 60, None),      # chirp-z: M = 256, 1024, 768, 1792
              # packed rows (eight / four / two rows per wavefront): six centred planes, all planes, off-centre and wide windows, the whole
              # grid, and a window beyond the packed kernels (512, 300: device draws go to the direct family)
              (128, 82, None), (128, 96, None), (128, 97, None), (128, 40, 0), (128, 128, None), (128, 60, 68),
@@ -433,6 +433,7 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             # chirp-z family (any other N): one transform of length 64 P, and rows in input blocks beyond 2048
             (164, 60, None, "k_rows_blu<double, 4, 2, 2, false>"), (291, 82, 5, "k_rows_blu<double, 8, 2, 2, false>"),
             (722, 200, None, "k_rows_blu<double, 16, 4, 2, false>"), (1111, 82, None, "k_rows_blu<double, 24, 2, 2, false>"),
+            (502, 82, None, "k_rows_blu<double, 12, 2, 2, false>"), (1650, 96, 3, "k_rows_blu<double, 28, 2, 2, false>"),       # M = 768, 1792 (round 6)
             (1901, 82, None, "k_rows_blu<double, 32, 2, 2, false>"), (3901, 82, None, "k_rows_blu<double, 16, 2, 2, true>")]
 
 

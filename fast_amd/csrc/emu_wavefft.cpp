@@ -156,6 +156,73 @@ static double run_blu_case(int N, int lo, int Np, unsigned seed) {
   return worst / scale;
 }
 
+// Chirp-z rows on the packed 256-point pipeline (fmc_bluestein.h: pbz_block / pbz_finish): four rows of any length N per wavefront in
+// blocks of 128 inputs, against the naive DFT with numpy's fftshift on both sides.
+template <class R, int NPL>
+static double run_pbz_case(int N, int lo, int Np, unsigned seed) {
+  using E = typename Xch<R>::E;
+  std::mt19937_64 gen(seed);
+  std::normal_distribution<double> nd(0.0, 1.0);
+  const int G = 4, SB = (N + PBZ_B - 1) / PBZ_B;
+  std::vector<double> inr((size_t)G * N), ini((size_t)G * N);
+  for (size_t k = 0; k < inr.size(); ++k) { inr[k] = nd(gen); ini[k] = nd(gen); }
+  std::vector<cpx<R>> tw(256), pre((size_t)SB * PBZ_B), vhat((size_t)SB * PBZ_M), post(128);
+  build_tw1_pk<R>(tw.data(), 16, cs_turns);
+  if (!build_pbz_tables<R>(N, Np, lo, pre.data(), vhat.data(), post.data(), cs_turns)) return 1e30;
+  std::vector<E> xbuf(D16_XELEMS);
+  static HostExec<R, 16, 1> ex;
+  static cpx<R> accs[WAVE][16];
+  for (int l = 0; l < WAVE; ++l)
+    for (int b = 0; b < 16; ++b) accs[l][b] = mk<R>((R)0, (R)0);
+  auto acc_of = [&](int l) { return accs[l]; };
+  for (int jb = 0; jb < SB; ++jb) {
+    for (int l = 0; l < WAVE; ++l) {
+      const int g = l >> 4, q = l & 15;
+      for (int j = 0; j < 16; ++j) {
+        const int k = jb * PBZ_B + q + 16 * j;
+        ex.regs[l].v[j] = (j < 8 && k < N) ? cmul(mk<R>((R)inr[(size_t)g * N + k], (R)ini[(size_t)g * N + k]), pre[k]) : mk<R>((R)0, (R)0);
+      }
+    }
+    pbz_block<R>(ex, xbuf.data(), tw.data(), vhat.data() + (size_t)jb * PBZ_M, acc_of);
+  }
+  pbz_finish<R, NPL>(ex, xbuf.data(), tw.data(), acc_of);
+  double worst = 0.0, scale = 0.0;
+  const int h = N / 2;
+  for (int g = 0; g < G; ++g)
+    for (int oi = 0; oi < Np; ++oi) {
+      const int p = lo + oi;
+      long double sr = 0, si = 0;
+      for (int k = 0; k < N; ++k) {
+        const long long e = (((long long)(p - h) * (k + h)) % N + N) % N;
+        const long double a = -2.0L * M_PIl * (long double)e / N;
+        const long double c = cosl(a), s2 = sinl(a);
+        sr += inr[(size_t)g * N + k] * c - ini[(size_t)g * N + k] * s2;
+        si += inr[(size_t)g * N + k] * s2 + ini[(size_t)g * N + k] * c;
+      }
+      const int l = 16 * g + (oi & 15), pl = oi >> 4;
+      const double yr = ex.regs[l].v[pl].x, yi = ex.regs[l].v[pl].y;
+      const double gr = post[oi].x * yr + post[oi].y * yi, gi = post[oi].y * yr - post[oi].x * yi;   // post * conj(Y)
+      worst = std::fmax(worst, std::fmax(std::fabs(gr - (double)sr), std::fabs(gi - (double)si)));
+      scale = std::fmax(scale, std::fmax(std::fabs((double)sr), std::fabs((double)si)));
+    }
+  return worst / scale;
+}
+template <class R, int NPL>
+static int sweep_pbz(const char* name, double tol) {
+  int bad = 0;
+  const int cases[][3] = {{164, 41, 82}, {49, 13, 23}, {100, 0, 64}, {1002, 460, 82}, {998, 902, 96}, {333, 100, 128}, {97, 96, 1}, {1111, 0, 40},
+                          {128, 23, 82}, {129, 0, 96}, {2050, 984, 82}, {640, 500, 128}};
+  for (auto& c : cases) {
+    const int N = c[0], lo = c[1], Np = c[2];
+    if (Np > 16 * NPL || Np < 1 || lo < 0 || lo + Np > N) continue;
+    const double err = run_pbz_case<R, NPL>(N, lo, Np, 31u + N);
+    const bool ok = err <= tol;
+    std::printf("%s packed chirp-z planes=%d N=%d lo=%d Np=%d relerr=%.3e %s\n", name, NPL, N, lo, Np, err, ok ? "ok" : "FAIL");
+    bad += !ok;
+  }
+  return bad;
+}
+
 // The same row cut into input blocks (fmc_bluestein.h header): SB chirp-z rows of B inputs on the M = 1024 pipeline, window
 // sums accumulated over the blocks -- the form grids longer than the largest M take (2200, 2816, ... <= 4096).
 template <class R, int NS>
@@ -541,6 +608,8 @@ int main() {
   bad += sweep_mr<float, 5, 2>("f32", 2e-5);
   bad += sweep_mr<float, 20, 2>("f32", 2e-5);
   bad += sweep_mr<float, 24, 4>("f32", 2e-5);
+  bad += sweep_pbz<double, 6>("f64", 1e-12);
+  bad += sweep_pbz<double, 8>("f64", 1e-12);
   bad += sweep_blu<double, 4, 2>("f64", 1e-12);
   bad += sweep_blu<double, 8, 2>("f64", 1e-12);
   bad += sweep_blu<double, 8, 4>("f64", 1e-12);

@@ -123,6 +123,10 @@ struct fastmc_ctx {
   void* blu_pre = nullptr;
   void* blu_vhat = nullptr;
   void* blu_post = nullptr;
+  void* pbz_tw = nullptr;   // chirp-z rows on the packed 256-point pipeline (fmc_bluestein.h: build_pbz_tables; windows of up to 128 pixels)
+  void* pbz_pre = nullptr;
+  void* pbz_vhat = nullptr;
+  void* pbz_post = nullptr;
   // 50-lane family (path 3: N = 50 P, fmc_mrfft.h)
   int mr_P = 0;            // 0: not eligible (N not 50 P S, or no window instantiation)
   int mr_S = 1;            // sub-rows per row (mr_split(N))
@@ -581,7 +585,7 @@ static void destroy_now(fastmc_ctx* h) {
   if (h->nps) { nps_free(h->nps); h->nps = nullptr; }
 #endif
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
-  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->amp_p, h->ampf_p, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->pks_tw1, h->pks_cw, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->pbz_tw, h->pbz_pre, h->pbz_vhat, h->pbz_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->amp_p, h->ampf_p, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->pks_tw1, h->pks_cw, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers, h->ps_dev, (void*)h->clk};
   for (void* p : ptrs)
@@ -931,6 +935,13 @@ static int pks_variant(const fastmc_ctx* h) {
   return (h->lo >= h->N / 2 - 48 && h->lo + h->Np <= h->N / 2 + 48) ? 0 : -1;
 }
 
+// Do the chirp-z ROWS of this handle run on the packed 256-point pipeline (fmc_kernels.h: k_rows_pbz)?  Windows of up to 128 pixels
+// (a block of 128 inputs and the window must fit 256 points); FASTMC_PBZ=0: the one-row-per-wave chirp-z rows instead (A/B).
+static bool pbz_ok(const fastmc_ctx* h) {
+  static const bool off = getenv("FASTMC_PBZ") && atoi(getenv("FASTMC_PBZ")) == 0;
+  return !off && h->blu_P && h->Np <= 128 && h->precision == FASTMC_F64;
+}
+
 template <class R>
 static int upload_blu_tables(fastmc_ctx* h) {
   if (!h->blu_P || h->blu_lo == h->lo) return 0;
@@ -948,6 +959,17 @@ static int upload_blu_tables(fastmc_ctx* h) {
   TRY(upload_table<R>(&h->blu_pre, pre));
   TRY(upload_table<R>(&h->blu_vhat, vhat));
   TRY(upload_table<R>(&h->blu_post, post));
+  if (pbz_ok(h)) {
+    const int SBp = (h->N + PBZ_B - 1) / PBZ_B;
+    std::vector<cpx<R>> tw(PBZ_M), ppre((size_t)SBp * PBZ_B), pvhat((size_t)SBp * PBZ_M), ppost(128);
+    build_tw1_pk<R>(tw.data(), 16, cs_turns);
+    if (!build_pbz_tables<R>(h->N, h->Np, h->lo, ppre.data(), pvhat.data(), ppost.data(), cs_turns))
+      return fail(FASTMC_ESTATE, "packed chirp-z blocks do not hold the window");
+    TRY(upload_table<R>(&h->pbz_tw, tw));
+    TRY(upload_table<R>(&h->pbz_pre, ppre));
+    TRY(upload_table<R>(&h->pbz_vhat, pvhat));
+    TRY(upload_table<R>(&h->pbz_post, ppost));
+  }
   h->blu_lo = h->lo;
   return 0;
 }
@@ -1352,7 +1374,7 @@ int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode) {
 }
 
 template <class R, int P, int NS, bool BLK = false>
-static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
+static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi, bool rows_done = false) {
   constexpr int WPB = BluCfg<R, P, NS>::WPB, WPC = BLK ? BluCfg<R, P, NS>::WPB : BluCfg<R, P, NS>::WPB_COLS;
   const size_t lds = blu_lds_bytes<R, P, NS>(RA.omS, WPB), ldc = blu_lds_bytes<R, P, NS>(RA.omS, WPC);
   constexpr int LR = 128 / (int)sizeof(cpx<R>);
@@ -1360,7 +1382,7 @@ static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
   RB.rpw = pick_rpw<R>(h, RA.N, RA.nb, WPB);
   const int BPG = RB.rpw * WPB / LR;
   const int blocks = ((RA.N + LR - 1) / LR) * ((RA.nb + BPG - 1) / BPG);
-  {
+  if (!rows_done) {
     Span s(h, 0);
     if (mode == 0) {
       hipFuncSetAttribute((const void*)k_rows_blu<R, P, NS, 0, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1395,15 +1417,43 @@ static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
   }
 }
 
+// Rows of the chirp-z grids on the packed 256-point pipeline (fmc_kernels.h: k_rows_pbz): four rows per wavefront, blocks of 128 inputs.
+template <class R, int NPL, int MODE>
+static void launch_pbz_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
+  Span s(h, 0);
+  const size_t lds = pbz_lds_bytes<R>() + (MODE == 2 ? GEN64_TABLE_BYTES : 0);
+  constexpr int LR = 128 / (int)sizeof(cpx<R>), LU = LR / 4, BPG = ROWS_PER_WAVE * PBZ_WPB / LU;
+  RowArgs<R> B = RA;
+  B.tw = (const cpx<R>*)h->pbz_tw;
+  B.blu.pre = (const cpx<R>*)h->pbz_pre; B.blu.vhat = (const cpx<R>*)h->pbz_vhat; B.blu.post = (const cpx<R>*)h->pbz_post;
+  B.blu.SB = (RA.N + PBZ_B - 1) / PBZ_B; B.blu.B = PBZ_B;
+  int blocks = ((RA.N + LR - 1) / LR) * ((RA.nb + BPG - 1) / BPG);
+  hipFuncSetAttribute((const void*)k_rows_pbz<R, NPL, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static const int persist = getenv("FASTMC_ROWS_PERSIST") ? atoi(getenv("FASTMC_ROWS_PERSIST")) : 1;
+  if (persist) {        // as launch_rows_wave: a launch of many rounds keeps its workgroups, which walk its tiles
+    const int resident = resident_workgroups(h, (const void*)k_rows_pbz<R, NPL, MODE>, PBZ_WPB * 64, lds);
+    if (blocks >= 8 * resident) { B.tiles = blocks; blocks = resident; }
+  }
+  hipLaunchKernelGGL((k_rows_pbz<R, NPL, MODE>), dim3(blocks), dim3(PBZ_WPB * 64), lds, h->stream, B);
+  FMC_NOTE(h->last_rows, "k_rows_pbz<%s, %d, %d>", rname<R>(), NPL, MODE);
+}
 template <class R>
 int dispatch_blu(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   const int ns = h->NS <= 2 ? 2 : 4;
+  bool rows_done = false;
+  if constexpr (sizeof(R) == 8) {
+    if (pbz_ok(h)) {         // windows of up to 128 pixels: the rows on the packed pipeline; the column pass below
+      if (h->Np <= 96) { if (mode == 0) launch_pbz_rows<R, 6, 0>(h, RA); else if (mode == 2) launch_pbz_rows<R, 6, 2>(h, RA); else launch_pbz_rows<R, 6, 1>(h, RA); }
+      else { if (mode == 0) launch_pbz_rows<R, 8, 0>(h, RA); else if (mode == 2) launch_pbz_rows<R, 8, 2>(h, RA); else launch_pbz_rows<R, 8, 1>(h, RA); }
+      rows_done = true;
+    }
+  }
   if (h->blu_SB > 1) {       // rows in input blocks on the M = 1024 pipeline
-    if (ns == 2) dispatch_blu_pn<R, 16, 2, true>(h, RA, CA, mode, epi);
-    else dispatch_blu_pn<R, 16, 4, true>(h, RA, CA, mode, epi);
+    if (ns == 2) dispatch_blu_pn<R, 16, 2, true>(h, RA, CA, mode, epi, rows_done);
+    else dispatch_blu_pn<R, 16, 4, true>(h, RA, CA, mode, epi, rows_done);
     return 0;
   }
-#define FMC_BLU(PP, NN) if (h->blu_P == PP && ns == NN) { dispatch_blu_pn<R, PP, NN>(h, RA, CA, mode, epi); return 0; }
+#define FMC_BLU(PP, NN) if (h->blu_P == PP && ns == NN) { dispatch_blu_pn<R, PP, NN>(h, RA, CA, mode, epi, rows_done); return 0; }
   FMC_BLU(4, 2) FMC_BLU(8, 2) FMC_BLU(8, 4) FMC_BLU(16, 2) FMC_BLU(16, 4) FMC_BLU(24, 2) FMC_BLU(24, 4) FMC_BLU(32, 2)
   FMC_BLU(12, 2) FMC_BLU(28, 2)
 #undef FMC_BLU
@@ -1754,6 +1804,7 @@ static bool fused_gen64(fastmc_ctx* h) {
   if (h->path != 0 && pks_grid(h->N)) return pks_variant<R>(h) >= 0;            // 192 ... 3968 (pks_split): the packed sub-rows, else staged
   if (pks_p16(h->N) && pks_variant<R>(h) >= 0) return true;                     // 1024 / 2048 / 4096 where the packed sub-rows serve them
   if constexpr (sizeof(R) == 8) {
+    if (h->path == 2 && pbz_ok(h)) return true;      // chirp-z rows on the packed pipeline draw it themselves
     if (h->path == 2) {      // chirp-z family: its rows draw it too where the tables fit
       const int ns2 = h->NS <= 2 ? 2 : 4;
       const int omS = h->omS;

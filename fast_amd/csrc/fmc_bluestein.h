@@ -279,6 +279,51 @@ inline bool build_blu_tables(int N, int Np, int lo, int P, cpx<R>* pre, cpx<R>* 
   return true;
 }
 
+// ---------------------------------------------------------------- chirp-z rows on the PACKED 256-point pipeline (round 6)
+// The row above costs 3.4-4.4 plain rows: one wavefront per row, a full forward transform of M >= N + Np - 1 points with P = M / 64
+// values per lane (M from seven sizes), a product, a pruned inverse.  The convolution is linear in the input, so a row can be cut into
+// blocks of PBZ_B = 128 inputs, each a cyclic convolution of length 256 >= 128 + Np - 1 (Np <= 129):
+//     y = IDFT_256( sum_j DFT_256(u_j) . V^_j ),      u_j = the block's pre-chirped inputs, zero-padded;  V^_j = DFT_256(v_j)
+// -- the PRODUCT SPECTRA are accumulated (sixteen complex registers per lane) and ONE inverse transform per row follows.  Forward and
+// inverse are packed_row_fft<L0 = 1>: FOUR rows per wavefront, sixteen lanes per row, sixteen values per lane whatever N; its output
+// layout (lane a, register b: x = a + 16 b) IS its input layout (lane q, register j: k = q + 16 j), so nothing moves between the two.
+// ceil(N / 128) + 1 transforms of 256 points per row: about 2.3 packed rows of work.  packed_row_fft applies the output-side
+// fftshift sign (-1)^x of the plain 256-point grid to the planes it keeps: the tables carry it (build_pbz_tables).
+constexpr int PBZ_B = 128, PBZ_M = 256;
+// one block: on entry r.v[j] = u[k0 + q + 16 j], j < 8, r.v[8 ... 15] = 0;  acc[b] += X[a + 16 b] V^_j[a + 16 b]
+template <class R, class Exec, class AccOf>
+FMC_HD void pbz_block(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw, const cpx<R>* vhat_j, AccOf acc_of) {
+  packed_row_fft<R, 1, 1, 0xFFFF>(ex, xbuf, tw, (const cpx<R>*)nullptr, 0, 0, 0);
+  ex.each([&](int lane, LaneRegs<R, 16, 1>& r) {
+    cpx<R>* acc = acc_of(lane);
+    const cpx<R>* v = vhat_j + (lane & 15);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) acc[b] = cfma(r.v[b], ex.ld(v + 16 * b), acc[b]);
+  });
+}
+// after the last block: r.v[p], p < NPL, of lane (g, a) = Y'[t], t = a + 16 p, with out[lo + t] = post[t] conj(Y'[t])
+template <class R, int NPL, class Exec, class AccOf>
+FMC_HD void pbz_finish(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw, AccOf acc_of) {
+  ex.each([&](int lane, LaneRegs<R, 16, 1>& r) {
+    const cpx<R>* acc = acc_of(lane);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) r.v[b] = mk<R>(acc[b].x, -acc[b].y);
+  });
+  packed_row_fft<R, 1, 1, (1 << NPL) - 1>(ex, xbuf, tw, (const cpx<R>*)nullptr, 0, 0, 0);
+}
+// pre[k] (SB * 128 entries, zero beyond N), vhat [SB][256], post[t] (128 entries): build_blu_tables with M = 256, B = 128, and the
+// plane signs of packed_row_fft folded in.  SB = ceil(N / 128).  false: the window does not fit (Np > 129).
+template <class R, class CosSin>
+inline bool build_pbz_tables(int N, int Np, int lo, cpx<R>* pre, cpx<R>* vhat, cpx<R>* post, CosSin cs) {
+  const int SB = (N + PBZ_B - 1) / PBZ_B;
+  cpx<R> twf[64];
+  if (!build_blu_tables<R>(N, Np, lo, PBZ_M / WAVE, pre, vhat, post, 128, twf, cs, PBZ_B, SB, SB * PBZ_B)) return false;
+  for (int jb = 0; jb < SB; ++jb)
+    for (int x = 1; x < PBZ_M; x += 2) { cpx<R>& v = vhat[(size_t)jb * PBZ_M + x]; v = mk<R>(-v.x, -v.y); }
+  for (int t = 1; t < 128; t += 2) post[t] = mk<R>(-post[t].x, -post[t].y);
+  return true;
+}
+
 // Blocks of the chirp-z row when no single M holds it: the M = 1024 pipeline (P = 16), B = the largest multiple of 64 with
 // B + Np - 1 <= 1024.  Returns the number of blocks (0: Np too wide).
 FMC_HD constexpr int blu_block_len(int Np) { return ((1024 - Np + 1) / 64) * 64; }

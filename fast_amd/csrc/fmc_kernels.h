@@ -1381,6 +1381,98 @@ __global__ __launch_bounds__(((BLK ? BluCfg<R, P, NS>::WPB : BluCfg<R, P, NS>::W
   column_epilogue<R, NS, EPI>(A.sh, A.W, A.partial, A.phs, A.nb, A.Np, b, xi, lane, p1s, p2s);
 }
 
+// ================================================================== chirp-z rows on the packed 256-point pipeline (round 6)
+// The row pass of the chirp-z grids for windows of up to 128 pixels (fmc_bluestein.h: pbz_block / pbz_finish): a wavefront owns FOUR
+// consecutive rows and walks them in blocks of 128 inputs -- eight draws per lane and block, lane q of a row reads the generator
+// streams q, q + 16, q + 32, q + 48 of the 64 its row has (kx = 128 jb + q + 16 j belongs to stream kx mod 64, draw kx / 64: two draws
+// per stream and block, in order), so the draws are those of k_rows_blu and of the direct family.  The column pass stays k_cols_blu
+// (standard V).  NPL: planes of the inverse transform kept (6: windows of up to 96 pixels, 8: up to 128).  float64 pipeline.
+// Tile walk as k_rows_wave; a tile = the LR rows of one 128-byte line of V x BPG realisations.
+constexpr int PBZ_WPB = 8;      // sixteen accumulators + sixteen values + four generator states per lane: two waves per SIMD
+template <class R> __host__ __device__ constexpr size_t pbz_lds_bytes() { return (size_t)PBZ_M * sizeof(cpx<R>) + (size_t)PBZ_WPB * D16_XELEMS * 8; }
+template <class R, int NPL, int MODE>
+__global__ __launch_bounds__(PBZ_WPB * 64) void k_rows_pbz(RowArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using E = typename Xch<R>::E;
+  static_assert(sizeof(R) == 8, "chirp-z grids run the float64 pipeline (fastmc_create)");
+  Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
+  E* s_x = reinterpret_cast<E*>(s_tw + PBZ_M);
+  if constexpr (MODE == 2) { gen64_lds0_check(s_g64); load_gen64_table(s_g64, A.g64); }
+  for (int i = threadIdx.x; i < PBZ_M; i += blockDim.x) s_tw[i] = A.tw[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  E* xbuf = s_x + w * D16_XELEMS;
+  LaneRegs<R, 16, 1> regs;
+  GpuExec<R, 16, 1> ex{lane, regs};
+  constexpr int WPB = PBZ_WPB, G = 4, LR = 128 / (int)sizeof(cpx<R>), LU = LR / G, BPG = ROWS_PER_WAVE * WPB / LU;
+  const int N = A.N, SB = A.blu.SB;
+  const int nbb = (A.nb + BPG - 1) / BPG;
+  const int q = lane & 15, gl = lane >> 4;
+  const int tiles = A.tiles ? A.tiles : (int)gridDim.x;
+#pragma unroll 1
+  for (int vb = blockIdx.x; vb < tiles; vb += gridDim.x) {
+  const int b0 = (vb % nbb) * BPG;
+  const int row0 = (vb / nbb) * LR;
+#pragma unroll 1
+  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+    const int flat = rr * WPB + w;
+    const int b = b0 + flat / LU;
+    if (b >= A.nb) break;                                // wave-uniform
+    const int ky0 = row0 + (flat % LU) * G;
+    if (ky0 >= N) continue;                              // wave-uniform (N need not be a multiple of LR)
+    const int ky = ky0 + gl;
+    const bool live = ky < N;                            // the last unit of a grid may be short
+    const int kyc = live ? ky : N - 1;
+    const uint64_t g = A.g0 + (uint64_t)b;
+    cpx<R> acc[16];
+#pragma unroll
+    for (int bb = 0; bb < 16; ++bb) acc[bb] = mk<R>((R)0, (R)0);
+    auto acc_of = [&](int) { return acc; };
+    xoshiro128p rs[4];
+    if (MODE != 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rs[i] = row_stream(A.key, g, kyc, q + 16 * i, WAVE);
+    }
+    const float* ampf = A.ampf + (size_t)kyc * N;
+    const R* amp = A.amp + (size_t)kyc * N;
+    const size_t base = ((size_t)b * N + kyc) * N;
+#pragma unroll 1
+    for (int jb = 0; jb < SB; ++jb) {
+      const int k0 = jb * PBZ_B + q;
+      const cpx<R>* pre = A.blu.pre + k0;                // (zero beyond N: SB * 128 entries)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int kx = k0 + 16 * j;
+        const bool in = kx < N;                          // draws only for coefficients of the row, in stream order
+        if (MODE == 0) regs.v[j] = in ? cmul(draw_coloured<R>(rs[j & 3], ampf[kx]), pre[16 * j]) : mk<R>((R)0, (R)0);
+        else if constexpr (MODE == 2) {
+          regs.v[j] = in ? cmul(draw_coloured_f64(rs[j & 3], (double)amp[kx], Gen64Lds0{}), pre[16 * j]) : mk<R>((R)0, (R)0);
+          asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs[j & 3].s0), "+v"(rs[j & 3].s1), "+v"(rs[j & 3].s2), "+v"(rs[j & 3].s3));
+        }
+        else regs.v[j] = in ? cmul(cscale(mk<R>((R)FMC_LDC(A.cre + base + kx), (R)FMC_LDC(A.cim + base + kx)), amp[kx]), pre[16 * j]) : mk<R>((R)0, (R)0);
+      }
+#pragma unroll
+      for (int j = 8; j < 16; ++j) regs.v[j] = mk<R>((R)0, (R)0);
+      pbz_block<R>(ex, xbuf, s_tw, A.blu.vhat + (size_t)jb * PBZ_M, acc_of);
+    }
+    pbz_finish<R, NPL>(ex, xbuf, s_tw, acc_of);
+    if (live) {
+      cpx<R>* out = A.V + (size_t)b * A.Np * N + ky;
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        const int t = q + 16 * p;
+        if (t < A.Np) {
+          const cpx<R> pq = A.blu.post[t];
+          out[(size_t)t * N] = mk<R>(pq.x * regs.v[p].x + pq.y * regs.v[p].y, pq.y * regs.v[p].x - pq.x * regs.v[p].y);   // post * conj(Y)
+        }
+      }
+    }
+  }
+  if (A.tiles) __syncthreads();      // (as k_rows_wave: the waves of a workgroup stay within one tile of each other)
+  }
+}
+
 // ================================================================== 50-lane family (N = 50 P: 100, 200, 250, 500, 1000, ...)
 // Round decimal grids (fast/conf.py NPXLS 1000 etc.) on the mixed-radix row of fmc_mrfft.h: the kernels of the wave family
 // with k = lane + 50 j inputs on lanes 0-49 and 50 generator streams per row (stream L = kx mod 50, fmc_core.h

@@ -429,12 +429,14 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (1408, 82, None, "k_rows_pks<double, 0, 0, 2>"), (3968, 60, 1950, "k_rows_pks<double, 0, 0, 2>"), (2816, 82, None, "k_rows_pks<double, 1, 0, 2>"),
             (1600, 82, None, "k_rows_pks<double, -1, 0, 2>"), (3200, 82, None, "k_rows_pks<double, 0, 0, 2>"),
             (2240, 82, None, "k_rows_pks<double, -1, 0, 2>"), (4032, 96, None, "k_rows_pks<double, -1, 0, 2>"),      # 35 / 63 sub-rows of 64 points
-            (832, 120, None, "k_rows_blu<double, 16, 2, 1, false>"), (1600, 82, 3, "k_rows_mr<double, 16, 2, 1, true, 50, 0>"),
+            (832, 120, None, "k_rows_pbz<double, 8, 1>"), (1600, 82, 3, "k_rows_mr<double, 16, 2, 1, true, 50, 0>"),
             # chirp-z family (any other N): one transform of length 64 P, and rows in input blocks beyond 2048
-            (164, 60, None, "k_rows_blu<double, 4, 2, 2, false>"), (291, 82, 5, "k_rows_blu<double, 8, 2, 2, false>"),
-            (722, 200, None, "k_rows_blu<double, 16, 4, 2, false>"), (1111, 82, None, "k_rows_blu<double, 24, 2, 2, false>"),
-            (502, 82, None, "k_rows_blu<double, 12, 2, 2, false>"), (1650, 96, 3, "k_rows_blu<double, 28, 2, 2, false>"),       # M = 768, 1792 (round 6)
-            (1901, 82, None, "k_rows_blu<double, 32, 2, 2, false>"), (3901, 82, None, "k_rows_blu<double, 16, 2, 2, true>")]
+            # (round 6: windows of up to 128 pixels on the PACKED 256-point pipeline, four rows per wavefront in blocks of 128 inputs -- 6 / 8 planes
+            # of the inverse transform; wider windows on the one-row-per-wave chirp-z rows)
+            (164, 60, None, "k_rows_pbz<double, 6, 2>"), (291, 82, 5, "k_rows_pbz<double, 6, 2>"),
+            (722, 200, None, "k_rows_blu<double, 16, 4, 2, false>"), (1111, 82, None, "k_rows_pbz<double, 6, 2>"),
+            (502, 128, 0, "k_rows_pbz<double, 8, 2>"), (1650, 96, 3, "k_rows_pbz<double, 6, 2>"), (129, 97, 32, "k_rows_pbz<double, 8, 2>"),
+            (1901, 82, None, "k_rows_pbz<double, 6, 2>"), (3901, 82, None, "k_rows_pbz<double, 6, 2>")]
 
 
 @pytest.mark.parametrize("N,Np,lo,kernel", _FUSED64)
@@ -620,7 +622,7 @@ def test_tile_walk_equals_one_tile_per_workgroup(N, n):
     # ... any other window: the float32 draw on the direct family, the float64 generator staged onto the family's host-coefficient rows
     (7168, 100, "k_rows_direct<double, 0>", "k_rows_mr<double, 16, 2, 1, true, 64, 0>"),
     (5000, 82, "k_rows_mr<double, 20, 2, 0, true, 50, 1>", "k_rows_mr<double, 20, 2, 2, true, 50, 0>"),
-    (4100, 82, "k_rows_blu<double, 16, 2, 0, true>", "k_rows_blu<double, 16, 2, 2, true>"),
+    (4100, 82, "k_rows_pbz<double, 6, 0>", "k_rows_pbz<double, 6, 2>"),
     (7003, 200, "k_rows_blu<double, 16, 4, 0, true>", "k_rows_blu<double, 16, 4, 2, true>")])
 def test_grids_beyond_4096(N, Np, kernel, kernel64):
     """Up to 8192: multiples of 64 on the packed sub-rows (fmc_core.h: pks_rt), N = 64 P S / 50 P S with a run-time sub-row count S <= 8

@@ -961,7 +961,7 @@ static int upload_blu_tables(fastmc_ctx* h) {
   TRY(upload_table<R>(&h->blu_post, post));
   if (pbz_ok(h)) {
     const int SBp = (h->N + PBZ_B - 1) / PBZ_B;
-    std::vector<cpx<R>> tw(PBZ_M), ppre((size_t)SBp * PBZ_B), pvhat((size_t)SBp * PBZ_M), ppost(128);
+    std::vector<cpx<R>> tw(PBZ_M), ppre((size_t)(SBp + 1) * PBZ_B), pvhat((size_t)SBp * PBZ_M), ppost(128);      // (one block of zeros more: the rows fetch a block ahead)
     build_tw1_pk<R>(tw.data(), 16, cs_turns);
     if (!build_pbz_tables<R>(h->N, h->Np, h->lo, ppre.data(), pvhat.data(), ppost.data(), cs_turns))
       return fail(FASTMC_ESTATE, "packed chirp-z blocks do not hold the window");
@@ -1421,7 +1421,7 @@ static void dispatch_blu_pn(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R
 template <class R, int NPL, int MODE>
 static void launch_pbz_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
   Span s(h, 0);
-  const size_t lds = pbz_lds_bytes<R>() + (MODE == 2 ? GEN64_TABLE_BYTES : 0);
+  const size_t lds = pbz_lds_bytes<R>(PBZ_WPB) + (MODE == 2 ? GEN64_TABLE_BYTES : 0);
   constexpr int LR = 128 / (int)sizeof(cpx<R>), LU = LR / 4, BPG = ROWS_PER_WAVE * PBZ_WPB / LU;
   RowArgs<R> B = RA;
   B.tw = (const cpx<R>*)h->pbz_tw;
@@ -1437,15 +1437,34 @@ static void launch_pbz_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
   hipLaunchKernelGGL((k_rows_pbz<R, NPL, MODE>), dim3(blocks), dim3(PBZ_WPB * 64), lds, h->stream, B);
   FMC_NOTE(h->last_rows, "k_rows_pbz<%s, %d, %d>", rname<R>(), NPL, MODE);
 }
+template <class R, int NPL, int EPI>
+static void launch_pbz_cols(fastmc_ctx* h, const ColArgs<R>& CA) {
+  Span s(h, 1);
+  const size_t lds = pbz_lds_bytes<R>(PBZ_WPC);
+  ColArgs<R> B = CA;
+  B.tw = (const cpx<R>*)h->pbz_tw;
+  B.blu.pre = (const cpx<R>*)h->pbz_pre; B.blu.vhat = (const cpx<R>*)h->pbz_vhat; B.blu.post = (const cpx<R>*)h->pbz_post;
+  B.blu.SB = (CA.N + PBZ_B - 1) / PBZ_B; B.blu.B = PBZ_B;
+  const int items = CA.nb * ((CA.Np + 3) / 4);
+  hipFuncSetAttribute((const void*)k_cols_pbz<R, NPL, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_cols_pbz<R, NPL, EPI>), dim3((items + PBZ_WPC - 1) / PBZ_WPC), dim3(PBZ_WPC * 64), lds, h->stream, B);
+  FMC_NOTE(h->last_cols, "k_cols_pbz<%s, %d, %d>", rname<R>(), NPL, EPI);
+}
 template <class R>
 int dispatch_blu(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int mode, int epi) {
   const int ns = h->NS <= 2 ? 2 : 4;
   bool rows_done = false;
   if constexpr (sizeof(R) == 8) {
-    if (pbz_ok(h)) {         // windows of up to 128 pixels: the rows on the packed pipeline; the column pass below
+    if (pbz_ok(h)) {         // windows of up to 128 pixels: rows and columns on the packed pipeline
+      static const bool cols_too = !(getenv("FASTMC_PBZ_COLS") && atoi(getenv("FASTMC_PBZ_COLS")) == 0);      // A/B: k_cols_blu instead
       if (h->Np <= 96) { if (mode == 0) launch_pbz_rows<R, 6, 0>(h, RA); else if (mode == 2) launch_pbz_rows<R, 6, 2>(h, RA); else launch_pbz_rows<R, 6, 1>(h, RA); }
       else { if (mode == 0) launch_pbz_rows<R, 8, 0>(h, RA); else if (mode == 2) launch_pbz_rows<R, 8, 2>(h, RA); else launch_pbz_rows<R, 8, 1>(h, RA); }
       rows_done = true;
+      if (cols_too) {
+        if (h->Np <= 96) { if (epi == 0) launch_pbz_cols<R, 6, 0>(h, CA); else launch_pbz_cols<R, 6, 1>(h, CA); }
+        else { if (epi == 0) launch_pbz_cols<R, 8, 0>(h, CA); else launch_pbz_cols<R, 8, 1>(h, CA); }
+        return 0;
+      }
     }
   }
   if (h->blu_SB > 1) {       // rows in input blocks on the M = 1024 pipeline

@@ -985,7 +985,12 @@ __host__ __device__ constexpr size_t pks_lds_bytes(int Sr) {
 }
 // The 96 entries of pass sp into the wave's slice by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane to base + 16 lane, no
 // register in between -- the float64 rows have none to spare across their draws): one instruction of the whole wave and one of its
-// lower half.  hipcc waits for it (vmcnt) before the first LDS read that follows.  float64 pipeline only (16-byte entries).
+// lower half.  The reader calls lds_dma_wait() first.  float64 pipeline only (16-byte entries).
+// An LDS-DMA is a pending LDS write on the VECTOR-MEMORY counter: nothing orders it against the wave's DS reads, and hipcc does not
+// wait for it on its own -- neither at a wavefront-scope fence (ex.sync() is a compiler barrier only) nor at an LDS read that aliases its
+// destination (seen in the ISA of k_rows_pbz: no s_waitcnt between the DMA and the read; the draws in between hid it in every test
+// until a read followed the DMA directly).  Every reader of DMA'd data calls this first.
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void pks_slice_load(const cpx<double>* cw, cpx<double>* slice, int sp, int lane) {
   const cpx<double>* src = cw + sp * PKS_SPAN + lane;
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)slice, 16, 0, 0);
@@ -1064,7 +1069,7 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
         }
       }
       const cpx<R>* cw_s = SLICE ? s_cw + w * PKS_SPAN : s_cw + sp * PKS_SPAN;
-      if constexpr (SLICE) ex.sync();
+      if constexpr (SLICE) { lds_dma_wait(); ex.sync(); }      // (the draws' own loads have been consumed: nothing else is outstanding)
       if constexpr (L0 < 0) pks64_pass<R>(ex, xbuf, s_tw, cw_s);
       else {
         packed_row_fft<R, L0, C::NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
@@ -1124,7 +1129,7 @@ __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(Co
 #pragma unroll
     for (int j = 0; j < VPL; ++j) regs.v[j] = load_v(col + sp * M + lane_in + L * j);
     const cpx<R>* cw_s = SLICE ? s_cw + w * PKS_SPAN : s_cw + sp * PKS_SPAN;
-    if constexpr (SLICE) { pks_slice_load(A.cw, s_cw + w * PKS_SPAN, sp, lane); ex.sync(); }
+    if constexpr (SLICE) { pks_slice_load(A.cw, s_cw + w * PKS_SPAN, sp, lane); lds_dma_wait(); ex.sync(); }      // (with the pass's loads of V, needed at once anyway)
     if constexpr (L0 < 0) pks64_pass<R>(ex, xbuf, s_tw, cw_s);
     else {
       packed_row_fft<R, L0, NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
@@ -1385,11 +1390,23 @@ __global__ __launch_bounds__(((BLK ? BluCfg<R, P, NS>::WPB : BluCfg<R, P, NS>::W
 // The row pass of the chirp-z grids for windows of up to 128 pixels (fmc_bluestein.h: pbz_block / pbz_finish): a wavefront owns FOUR
 // consecutive rows and walks them in blocks of 128 inputs -- eight draws per lane and block, lane q of a row reads the generator
 // streams q, q + 16, q + 32, q + 48 of the 64 its row has (kx = 128 jb + q + 16 j belongs to stream kx mod 64, draw kx / 64: two draws
-// per stream and block, in order), so the draws are those of k_rows_blu and of the direct family.  The column pass stays k_cols_blu
+// per stream and block, in order), so the draws are those of k_rows_blu and of the direct family.  The column pass: k_cols_pbz below
 // (standard V).  NPL: planes of the inverse transform kept (6: windows of up to 96 pixels, 8: up to 128).  float64 pipeline.
 // Tile walk as k_rows_wave; a tile = the LR rows of one 128-byte line of V x BPG realisations.
 constexpr int PBZ_WPB = 8;      // sixteen accumulators + sixteen values + four generator states per lane: two waves per SIMD
-template <class R> __host__ __device__ constexpr size_t pbz_lds_bytes() { return (size_t)PBZ_M * sizeof(cpx<R>) + (size_t)PBZ_WPB * D16_XELEMS * 8; }
+// LDS: [generator tables (MODE 2)][tw 256][V^ and pre-chirp of the block in hand, one copy per wave: 256 + 128 entries][exchange buffers]
+template <class R> __host__ __device__ constexpr size_t pbz_lds_bytes(int waves) { return (size_t)(PBZ_M + waves * (PBZ_M + 2 * PBZ_B)) * sizeof(cpx<R>) + (size_t)waves * D16_XELEMS * 8; }
+// V^_j of the block in hand into the wave's LDS copy by LDS-DMA (four instructions of 64 lanes x 16 bytes, no register in between):
+// issued before the block's draws, so the product does not wait for sixteen loads from L2 per lane (fmc_kernels.h: pks_slice_load)
+template <int CHUNKS>      // 64 entries each
+__device__ __forceinline__ void pbz_lds_load(const cpx<double>* src, cpx<double>* dst, int lane) {
+#pragma unroll
+  for (int i = 0; i < CHUNKS; ++i)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * i + lane),
+                                     (__attribute__((address_space(3))) void*)(dst + 64 * i), 16, 0, 0);
+}
+// per wave: V^ of the block (256 entries) and two buffers of 128 pre-chirp factors (the block in hand and the next one)
+constexpr int PBZ_SLICE = PBZ_M + 2 * PBZ_B;
 template <class R, int NPL, int MODE>
 __global__ __launch_bounds__(PBZ_WPB * 64) void k_rows_pbz(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1397,12 +1414,14 @@ __global__ __launch_bounds__(PBZ_WPB * 64) void k_rows_pbz(RowArgs<R> A) {
   static_assert(sizeof(R) == 8, "chirp-z grids run the float64 pipeline (fastmc_create)");
   Gen64Entry* s_g64 = reinterpret_cast<Gen64Entry*>(smem);
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem + (MODE == 2 ? GEN64_TABLE_BYTES : 0));
-  E* s_x = reinterpret_cast<E*>(s_tw + PBZ_M);
+  cpx<R>* s_vh = s_tw + PBZ_M;
+  E* s_x = reinterpret_cast<E*>(s_vh + PBZ_WPB * PBZ_SLICE);
   if constexpr (MODE == 2) { gen64_lds0_check(s_g64); load_gen64_table(s_g64, A.g64); }
   for (int i = threadIdx.x; i < PBZ_M; i += blockDim.x) s_tw[i] = A.tw[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   E* xbuf = s_x + w * D16_XELEMS;
+  cpx<R>* vh = s_vh + w * PBZ_SLICE;
   LaneRegs<R, 16, 1> regs;
   GpuExec<R, 16, 1> ex{lane, regs};
   constexpr int WPB = PBZ_WPB, G = 4, LR = 128 / (int)sizeof(cpx<R>), LU = LR / G, BPG = ROWS_PER_WAVE * WPB / LU;
@@ -1437,10 +1456,19 @@ __global__ __launch_bounds__(PBZ_WPB * 64) void k_rows_pbz(RowArgs<R> A) {
     const float* ampf = A.ampf + (size_t)kyc * N;
     const R* amp = A.amp + (size_t)kyc * N;
     const size_t base = ((size_t)b * N + kyc) * N;
+    // The wave's LDS copies are filled by LDS-DMA a step ahead of their use and retired by lds_dma_wait() where the draws' own loads
+    // have been consumed: V^ of block jb at the start of block jb for the product at its end; the pre-chirp factors of block jb + 1 at
+    // the start of block jb, into the other of two buffers.  A copy is never overwritten under a read of the step before: those reads
+    // have returned (their values were used) before the DMA is issued.
+    pbz_lds_load<2>(A.blu.pre, vh + PBZ_M, lane);        // (pre: zero beyond N, (SB + 1) * 128 entries)
+    lds_dma_wait();
+    ex.sync();
 #pragma unroll 1
     for (int jb = 0; jb < SB; ++jb) {
       const int k0 = jb * PBZ_B + q;
-      const cpx<R>* pre = A.blu.pre + k0;                // (zero beyond N: SB * 128 entries)
+      pbz_lds_load<4>(A.blu.vhat + (size_t)jb * PBZ_M, vh, lane);
+      pbz_lds_load<2>(A.blu.pre + (jb + 1) * PBZ_B, vh + PBZ_M + ((jb + 1) & 1) * PBZ_B, lane);
+      const cpx<R>* pre = vh + PBZ_M + (jb & 1) * PBZ_B + q;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int kx = k0 + 16 * j;
@@ -1454,7 +1482,9 @@ __global__ __launch_bounds__(PBZ_WPB * 64) void k_rows_pbz(RowArgs<R> A) {
       }
 #pragma unroll
       for (int j = 8; j < 16; ++j) regs.v[j] = mk<R>((R)0, (R)0);
-      pbz_block<R>(ex, xbuf, s_tw, A.blu.vhat + (size_t)jb * PBZ_M, acc_of);
+      lds_dma_wait();
+      ex.sync();
+      pbz_block<R>(ex, xbuf, s_tw, vh, acc_of);
     }
     pbz_finish<R, NPL>(ex, xbuf, s_tw, acc_of);
     if (live) {
@@ -1470,6 +1500,114 @@ __global__ __launch_bounds__(PBZ_WPB * 64) void k_rows_pbz(RowArgs<R> A) {
     }
   }
   if (A.tiles) __syncthreads();      // (as k_rows_wave: the waves of a workgroup stay within one tile of each other)
+  }
+}
+
+// The column pass of the same grids on the same pipeline: FOUR window columns per wavefront (sixteen lanes each) in blocks of 128
+// rows of V (standard layout), one pruned inverse per column, then the detector as k_cols_pks has it: the window pixels handed through
+// the lane's own slots of the exchange buffer to a rolled loop, the sums reduced over the sixteen lanes of a column by DPP.
+constexpr int PBZ_WPC = 8;
+template <class R, int NPL, int EPI>
+__global__ __launch_bounds__(PBZ_WPC * 64) void k_cols_pbz(ColArgs<R> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using E = typename Xch<R>::E;
+  static_assert(sizeof(R) == 8, "chirp-z grids run the float64 pipeline (fastmc_create)");
+  cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
+  cpx<R>* s_vh = s_tw + PBZ_M;
+  E* s_x = reinterpret_cast<E*>(s_vh + PBZ_WPC * PBZ_SLICE);
+  for (int i = threadIdx.x; i < PBZ_M; i += blockDim.x) s_tw[i] = A.tw[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  E* xbuf = s_x + w * D16_XELEMS;
+  cpx<R>* vh = s_vh + w * PBZ_SLICE;
+  constexpr int G = 4;
+  const int q = lane & 15, gl = lane >> 4;
+  LaneRegs<R, 16, 1> regs;
+  GpuExec<R, 16, 1> ex{lane, regs};
+  const int N = A.N, SB = A.blu.SB;
+  const int ngrp = (A.Np + G - 1) / G;
+  const int item = blockIdx.x * PBZ_WPC + w;
+  if (item >= A.nb * ngrp) return;                         // wave-uniform; no block barrier follows
+  const int b = item / ngrp;
+  const int xi = (item % ngrp) * G + gl;
+  const bool live = xi < A.Np;                             // the last group of a realisation may be short
+  const cpx<R>* col = A.V + ((size_t)b * A.Np + (live ? xi : (item % ngrp) * G)) * N;
+  cpx<R> acc[16];
+#pragma unroll
+  for (int bb = 0; bb < 16; ++bb) acc[bb] = mk<R>((R)0, (R)0);
+  auto acc_of = [&](int) { return acc; };
+  // the loads of block jb + 1 are issued before block jb is transformed (one wavefront walks its columns block by block: without
+  // this every block waits for its own loads -- the one-column-per-wave kernel has all of a column's loads in flight at once)
+  cpx<R> nxt[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) nxt[j] = (q + 16 * j < N) ? load_v(col + q + 16 * j) : mk<R>((R)0, (R)0);
+#pragma unroll 1
+  for (int jb = 0; jb < SB; ++jb) {
+    const int k0 = jb * PBZ_B + q;
+    pbz_lds_load<4>(A.blu.vhat + (size_t)jb * PBZ_M, vh, lane);      // (as k_rows_pbz)
+    pbz_lds_load<2>(A.blu.pre + jb * PBZ_B, vh + PBZ_M, lane);
+    lds_dma_wait();                                                  // (with the block's loads of V, needed at once anyway)
+    ex.sync();
+    const cpx<R>* pre = vh + PBZ_M + q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) regs.v[j] = cmul(nxt[j], pre[16 * j]);       // (pre is zero beyond N)
+#pragma unroll
+    for (int j = 8; j < 16; ++j) regs.v[j] = mk<R>((R)0, (R)0);
+    if (jb + 1 < SB) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ky = k0 + PBZ_B + 16 * j;
+        nxt[j] = ky < N ? load_v(col + ky) : mk<R>((R)0, (R)0);
+      }
+    }
+    pbz_block<R>(ex, xbuf, s_tw, vh, acc_of);
+  }
+  pbz_finish<R, NPL>(ex, xbuf, s_tw, acc_of);
+  double sums[4] = {0.0, 0.0, 0.0, 0.0};
+  auto pixel = [&](int yi, R p1, R p2) {
+    pixel_phase<R>(A.sh, b, A.Np, yi, xi, p1, p2);
+    if (EPI == 1) {
+      const size_t plane = (size_t)A.Np * A.Np;
+      A.phs[((size_t)b) * plane + (size_t)yi * A.Np + xi] = (double)p1;
+      A.phs[((size_t)(A.nb + b)) * plane + (size_t)yi * A.Np + xi] = (double)p2;
+    } else {
+      const double wgt = A.W[(size_t)yi * A.Np + xi];
+      double s1, c1, s2, c2;
+      sincos_r(p1, s1, c1);
+      sincos_r(p2, s2, c2);
+      sums[0] += wgt * c1; sums[1] += wgt * s1; sums[2] += wgt * c2; sums[3] += wgt * s2;
+    }
+  };
+  cpx<R>* ob = reinterpret_cast<cpx<R>*>(xbuf) + lane;
+#pragma unroll
+  for (int p = 0; p < NPL; ++p) {
+    const int t = q + 16 * p;
+    const cpx<R> pq = A.blu.post[t];                       // (128 entries, zero beyond the window)
+    ob[WAVE * p] = mk<R>(pq.x * regs.v[p].x + pq.y * regs.v[p].y, pq.y * regs.v[p].x - pq.x * regs.v[p].y);      // post * conj(Y)
+  }
+  ex.sync();
+#pragma unroll 1
+  for (int p = 0; p < NPL; ++p) {
+    const int yi = q + 16 * p;
+    if (live && yi < A.Np) {
+      const cpx<R> v = ob[WAVE * p];
+      pixel(yi, v.x, v.y);
+    }
+  }
+  if (EPI == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double v = sums[k];
+      v += dpp_copy<0xB1>(v);     // quad_perm [1,0,3,2]
+      v += dpp_copy<0x4E>(v);     // quad_perm [2,3,0,1]
+      v += dpp_copy<0x141>(v);    // row_half_mirror: every lane holds the sum of its 8 lanes
+      v += dpp_copy<0x140>(v);    // row_mirror: ... of its 16-lane row
+      sums[k] = v;
+    }
+    if (q == 0 && live) {
+      double* o = A.partial + ((size_t)b * A.Np + xi) * 4;
+      o[0] = sums[0]; o[1] = sums[1]; o[2] = sums[2]; o[3] = sums[3];
+    }
   }
 }
 

@@ -689,6 +689,7 @@ extern "C" int fastmc_set_batch(fastmc_t* h, int batch) {
 
 static int default_batch(const fastmc_ctx* h);
 static int pks_p16_from();
+static bool pbz_ok(const fastmc_ctx* h);
 #if FMC_TU == 0
 extern "C" int fastmc_get_batch(fastmc_t* h, int* batch) {
   if (!h || !batch) return fail(FASTMC_EINVAL, "null argument");
@@ -756,6 +757,22 @@ static int default_batch(const fastmc_ctx* h) {
       for (int nbb = nmax; nbb >= std::max(1, nmax - nmax / 4); --nbb) {
         const int64_t t = (int64_t)(h->N / LR) * nbb;
         const double eff = t >= 8 * 256 ? (double)t / (double)(((t + 255) / 256) * 256) : 1.0;      // (fewer tiles: one workgroup each, no walk)
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = nbb; }
+      }
+      return best * BPG;
+    }
+    return b;
+  }
+  if (h->path == 2 && pbz_ok(h)) {
+    // chirp-z rows on the packed pipeline (k_rows_pbz): tiles of one 128-byte line of V (eight rows) x 32 realisations, walked by one
+    // workgroup per CU -- the same rule as for the packed sub-rows
+    const int BPG = ROWS_PER_WAVE * PBZ_WPB / 2, nmax = b / BPG;
+    if (nmax >= 1) {
+      int best = nmax;
+      double best_eff = 0.0;
+      for (int nbb = nmax; nbb >= std::max(1, nmax - nmax / 4); --nbb) {
+        const int64_t t = (int64_t)((h->N + 7) / 8) * nbb;
+        const double eff = t >= 8 * 256 ? (double)t / (double)(((t + 255) / 256) * 256) : 1.0;
         if (eff > best_eff + 1e-9) { best_eff = eff; best = nbb; }
       }
       return best * BPG;

@@ -207,8 +207,10 @@ int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches);
  *       600, ..., 1000, 1200, 1350, 1400, 1500, 1600, 1750, 1800, 2000, 2100, 2250, 2400, 2500, 2700, 2800, 3000, 3200,
  *       3500, 3600, 4000; Np <= 128, or <= 256 for P = 8, 10, 12, 16, 20, 24).  The device generator draws 50 S streams per
  *       row on these grids, whichever family transforms them;
- *   2 = chirp-z (any other N, odd included, with 64 P >= N + Np - 1 for P in {4, 8, 16, 24, 32} and Np <= 256: every 1-D
- *       transform as a Bluestein convolution on the same pipeline; default for N >= 96);
+ *   2 = chirp-z (any other N, odd included, Np <= 256: every 1-D transform as a Bluestein convolution; default for N >= 96).
+ *       Windows of up to 128 pixels (round 6): rows and columns in blocks of 128 inputs on the packed 256-point pipeline, four per
+ *       wavefront, one pruned inverse transform each; wider windows: one wavefront per row / column with 64 P >= N + Np - 1 points,
+ *       P in {4, 8, 12, 16, 24, 28, 32}, rows beyond 2048 points in input blocks;
  *   0 = direct O(N^2 Np) pruned DFT (any N the LDS holds; tiny grids, huge windows, cross-check of the other three).
  * force: -1 query only, 0 / 1 / 2 / 3 select (fails with EINVAL if the family does not serve this (N, Np)). */
 int fastmc_kernel_path(fastmc_t* h, int force);

@@ -37,6 +37,11 @@
  *     sixteen-wave dense-image kernels would run (A/B timing; same results); FASTMC_ROWS_PERSIST=0 (read at the first row launch)
  *     gives every tile of a large row launch a workgroup of its own instead of letting the resident workgroups walk the tiles
  *     (A/B timing; same results); FASTMC_COLS_PERSIST=0: the same for the column launches of the 1024-point pipeline.
+ *   - environment, kernel choice for A/B timing (read once; same results to rounding): FASTMC_PKS=0 keeps the packed sub-rows off
+ *     (staged draws on the grid's one-row-per-wave / chirp-z / 50-lane rows instead); FASTMC_PKS_P16=1024 lets them serve 1024 too
+ *     (default: from 2048); FASTMC_PBZ=0 runs the chirp-z grids one wavefront per row as rounds 1-5 did, FASTMC_PBZ_COLS=0 only their
+ *     column pass; FASTMC_BLU_P=0 keeps that form to its five sizes of rounds 1-5; FASTMC_GEN64_STAGED=1 stages the float64 generator
+ *     through memory everywhere.
  */
 #ifndef FASTMC_H
 #define FASTMC_H

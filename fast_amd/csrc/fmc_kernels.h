@@ -1469,16 +1469,30 @@ __global__ __launch_bounds__(PBZ_WPB * 64) void k_rows_pbz(RowArgs<R> A) {
       pbz_lds_load<4>(A.blu.vhat + (size_t)jb * PBZ_M, vh, lane);
       pbz_lds_load<2>(A.blu.pre + (jb + 1) * PBZ_B, vh + PBZ_M + ((jb + 1) & 1) * PBZ_B, lane);
       const cpx<R>* pre = vh + PBZ_M + (jb & 1) * PBZ_B + q;
+      if constexpr (MODE == 1) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int kx = k0 + 16 * j;
-        const bool in = kx < N;                          // draws only for coefficients of the row, in stream order
-        if (MODE == 0) regs.v[j] = in ? cmul(draw_coloured<R>(rs[j & 3], ampf[kx]), pre[16 * j]) : mk<R>((R)0, (R)0);
-        else if constexpr (MODE == 2) {
-          regs.v[j] = in ? cmul(draw_coloured_f64(rs[j & 3], (double)amp[kx], Gen64Lds0{}), pre[16 * j]) : mk<R>((R)0, (R)0);
-          asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs[j & 3].s0), "+v"(rs[j & 3].s1), "+v"(rs[j & 3].s2), "+v"(rs[j & 3].s3));
+        for (int j = 0; j < 8; ++j) {
+          const int kx = k0 + 16 * j;
+          regs.v[j] = kx < N ? cmul(cscale(mk<R>((R)FMC_LDC(A.cre + base + kx), (R)FMC_LDC(A.cim + base + kx)), amp[kx]), pre[16 * j]) : mk<R>((R)0, (R)0);
         }
-        else regs.v[j] = in ? cmul(cscale(mk<R>((R)FMC_LDC(A.cre + base + kx), (R)FMC_LDC(A.cim + base + kx)), amp[kx]), pre[16 * j]) : mk<R>((R)0, (R)0);
+      } else {
+        // The block's eight colouring factors in ONE batch of loads (index clamped to the row), then eight draws in straight-line
+        // code: beyond the end of the row the draw still runs -- the streams belong to this row only, nothing reads them again -- and
+        // the pre-chirp factor there is zero.  (With a branch per coefficient every draw waited for its own load from L2.)
+        double a8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int kxc = min(k0 + 16 * j, N - 1);
+          a8[j] = MODE == 0 ? (double)ampf[kxc] : (double)amp[kxc];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (MODE == 0) regs.v[j] = cmul(draw_coloured<R>(rs[j & 3], (float)a8[j]), pre[16 * j]);
+          else if constexpr (MODE == 2) {
+            regs.v[j] = cmul(draw_coloured_f64(rs[j & 3], a8[j], Gen64Lds0{}), pre[16 * j]);
+            asm volatile("" : "+v"(regs.v[j].x), "+v"(regs.v[j].y), "+v"(rs[j & 3].s0), "+v"(rs[j & 3].s1), "+v"(rs[j & 3].s2), "+v"(rs[j & 3].s3));
+          }
+        }
       }
 #pragma unroll
       for (int j = 8; j < 16; ++j) regs.v[j] = mk<R>((R)0, (R)0);

@@ -952,6 +952,16 @@ static int pks_variant(const fastmc_ctx* h) {
   return (h->lo >= h->N / 2 - 48 && h->lo + h->Np <= h->N / 2 + 48) ? 0 : -1;
 }
 
+// The chirp-z rows draw 64 generator streams per row and the 50-lane rows 50 S: a grid whose layout is another one (fmc_core.h:
+// stream_lanes -- the packed grids, 2048, 4096 and every grid of the packed sub-rows draw N / 16 or N / 8) reaches those families only
+// when a caller forces them (fastmc_kernel_path) or as the host-coefficient rows of a packed sub-row grid; its device draws must not
+// go through their rows (the float64 generator is staged, the float32 draw goes to the direct family: run_impl, fused_gen64).
+static bool family_streams_ok(const fastmc_ctx* h) {
+  if (h->path == 2) return stream_lanes(h->N) == WAVE;
+  if (h->path == 3) return stream_lanes(h->N) == MR_LN * h->mr_S;
+  return true;
+}
+
 // Do the chirp-z ROWS of this handle run on the packed 256-point pipeline (fmc_kernels.h: k_rows_pbz)?  Windows of up to 128 pixels
 // (a block of 128 inputs and the window must fit 256 points); FASTMC_PBZ=0: the one-row-per-wave chirp-z rows instead (A/B).
 static bool pbz_ok(const fastmc_ctx* h) {
@@ -1840,6 +1850,7 @@ static bool fused_gen64(fastmc_ctx* h) {
   if (h->path != 0 && pks_grid(h->N)) return pks_variant<R>(h) >= 0;            // 192 ... 3968 (pks_split): the packed sub-rows, else staged
   if (pks_p16(h->N) && pks_variant<R>(h) >= 0) return true;                     // 1024 / 2048 / 4096 where the packed sub-rows serve them
   if constexpr (sizeof(R) == 8) {
+    if (!family_streams_ok(h)) return false;         // (a forced family whose rows draw another stream layout: staged)
     if (h->path == 2 && pbz_ok(h)) return true;      // chirp-z rows on the packed pipeline draw it themselves
     if (h->path == 2) {      // chirp-z family: its rows draw it too where the tables fit
       const int ns2 = h->NS <= 2 ? 2 : 4;
@@ -2047,7 +2058,7 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     // host-coefficient rows (fused_gen64 is false there), the float32 draw goes to the direct family -- no other row kernel knows the
     // N / 16 (N / 8) streams per row of these grids.
     const bool pks = h->path != 0 && kmode != 1 && pks_variant<R>(h) >= 0;
-    const bool pks_to_direct = !pks && pks_grid(h->N) && kmode == 0 && (h->path == 2 || h->path == 3);
+    const bool pks_to_direct = !pks && kmode == 0 && !family_streams_ok(h);
     if (h->path == 2 && !pks && !pks_to_direct) {
       TRY(upload_blu_tables<R>(h));
       RA.amp = (const R*)h->amp; RA.ampf = h->ampf; RA.tw = (const cpx<R>*)h->blu_tw1; RA.om = (const cpx<R>*)h->blu_om;

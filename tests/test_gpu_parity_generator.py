@@ -681,3 +681,26 @@ def test_handle_default_generator_is_the_reference_precision():
     assert np.abs(h32.rng_coeffs(3, 1) - devrng.device_coefficients(3, 1, N)).max() < 1e-3
     assert np.abs(h32.rng_coeffs(3, 1) - devrng.device_coefficients_f64(3, 1, N)).max() > 1e-9
     h32.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Np", [(256, 82), (2048, 82), (512, 200)])
+def test_a_forced_family_keeps_the_grids_generator_layout(N, Np):
+    """`fastmc_kernel_path` can force the chirp-z family onto a grid of the wave family whose generator layout is not the 64 streams
+    per row the chirp-z rows draw (packed grids: N / 16; 2048: 128).  Results depend on (seed, realisation) only, never on the kernel
+    family: the forced family must take the same draws (float64 generator staged, float32 draw on the direct family)."""
+    ps, df = _vk_spectrum(N, 0.01, 30.0)
+    ps = ps * 0.02
+    lo = (N - Np) // 2
+    h = f32_draw_handle(N, Np, "f64", 0)
+    h.set_spectrum(ps, df)
+    h.set_pupil(_window_W(Np), lo, 0.01)
+    for prec in ("f64", "f32"):
+        h.kernel_path(1)
+        h.set_rng_precision(prec)
+        want = h.run(11, 5, 2, None, 0.01)
+        assert h.kernel_path(2) == 2
+        got = h.run(11, 5, 2, None, 0.01)
+        assert "blu" in h.last_kernels()[1] or "pbz" in h.last_kernels()[1] or "direct" in h.last_kernels()[1]
+        np.testing.assert_allclose(got, want, rtol=1e-9 if prec == "f64" else 2e-6)
+    h.close()

@@ -433,9 +433,9 @@ static int sweep_pk(const char* name, double tol) {
 }
 
 // Packed sub-rows (fmc_wavefft.h: pks_accumulate): G rows of N = S * M points per wave, S passes, against the naive DFT.
-template <class R, int L0, int S>
+template <class R, int L0, int S, int NPL = 6>
 static double run_pks_case(int Np, int shift, unsigned seed) {
-  constexpr int L = pk_lanes(L0), M = 16 * L, N = S * M, G = WAVE / L, FIRST = pks_first_plane(L0, S);
+  constexpr int L = pk_lanes(L0), M = 16 * L, N = S * M, G = WAVE / L, FIRST = pks_first_plane(L0, S, NPL), SPAN = pks_span(NPL);
   using E = typename Xch<R>::E;
   std::mt19937_64 gen(seed);
   std::normal_distribution<double> nd(0.0, 1.0);
@@ -443,12 +443,12 @@ static double run_pks_case(int Np, int shift, unsigned seed) {
   for (auto& v : inr) v = nd(gen);
   for (auto& v : ini) v = nd(gen);
   const int lo = (N - Np) / 2 + shift;
-  std::vector<cpx<R>> tw1((size_t)16 * L), pcw((size_t)S * PKS_SPAN);
+  std::vector<cpx<R>> tw1((size_t)16 * L), pcw((size_t)S * SPAN);
   build_tw1_pk<R>(tw1.data(), L, cs_turns);
-  build_pcw<R>(pcw.data(), N, S, cs_turns);
+  build_pcw<R>(pcw.data(), N, S, cs_turns, NPL);
   std::vector<E> xbuf(D16_XELEMS);
   static HostExec<R, 16, pks_nm<L0>()> ex;
-  pks_clear<R, L0>(ex);
+  pks_clear<R, L0, NPL>(ex);
   for (int sp = 0; sp < S; ++sp) {
     for (int l = 0; l < WAVE; ++l)
       for (int j = 0; j < 16; ++j) {
@@ -456,12 +456,12 @@ static double run_pks_case(int Np, int shift, unsigned seed) {
         const double sg = (k & 1) ? -1.0 : 1.0;        // the input-side fftshift sign, folded into the colouring table on the device
         ex.regs[l].v[j] = mk<R>((R)(sg * inr[g * N + k]), (R)(sg * ini[g * N + k]));
       }
-    packed_row_fft<R, L0, pks_nm<L0>(), pks_plane_mask(L0, S)>(ex, xbuf.data(), tw1.data(), (const cpx<R>*)nullptr, 0, 0, Np);
-    pks_accumulate<R, L0, FIRST>(ex, pcw.data() + sp * PKS_SPAN);
+    packed_row_fft<R, L0, pks_nm<L0>(), pks_plane_mask(L0, S, NPL)>(ex, xbuf.data(), tw1.data(), (const cpx<R>*)nullptr, 0, 0, Np);
+    pks_accumulate<R, L0, FIRST, NPL>(ex, pcw.data() + sp * SPAN);
   }
   std::vector<double> gr((size_t)G * Np, 1e300), gi((size_t)G * Np, 1e300);
   for (int l = 0; l < WAVE; ++l)
-    pks_outputs<R, L0>(l, ex.regs[l], N, lo, Np, [&](int oi, R re, R im) { gr[(l / L) * Np + oi] = re; gi[(l / L) * Np + oi] = im; });
+    pks_outputs<R, L0, NPL>(l, ex.regs[l], N, lo, Np, [&](int oi, R re, R im) { gr[(l / L) * Np + oi] = re; gi[(l / L) * Np + oi] = im; });
   double worst = 0.0, scale = 0.0;
   const int h = N / 2;
   for (int g = 0; g < G; ++g)
@@ -479,6 +479,19 @@ static double run_pks_case(int Np, int shift, unsigned seed) {
       scale = std::fmax(scale, std::fmax(std::fabs((double)sr), std::fabs((double)si)));
     }
   return worst / scale;
+}
+// eight planes: centred windows of up to 128 pixels
+template <class R, int L0, int S>
+static int sweep_pks8(const char* name, double tol) {
+  int bad = 0;
+  for (int Np : {128, 97, 110, 82, 1})
+    for (int shift : {0, Np < 120 ? 4 : 0, Np < 100 ? -13 : 0}) {
+      const double err = run_pks_case<R, L0, S, 8>(Np, shift, 555u + Np + shift + S);
+      const bool ok = err <= tol;
+      std::printf("%s packed sub-rows, eight planes N=%d (S=%d) shift=%d Np=%d relerr=%.3e %s\n", name, S * 16 * pk_lanes(L0), S, shift, Np, err, ok ? "ok" : "FAIL");
+      bad += !ok;
+    }
+  return bad;
 }
 template <class R, int L0, int S>
 static int sweep_pks(const char* name, double tol) {
@@ -494,7 +507,7 @@ static int sweep_pks(const char* name, double tol) {
 }
 
 // Packed sub-rows of SIXTY-FOUR points (pks64_pass): eight rows of N = S * 64 points per wave, eight lanes each, S passes, against the naive DFT.
-template <class R, int S>
+template <class R, int S, int NPL = 6>
 static double run_pks64_case(int Np, int shift, unsigned seed) {
   constexpr int M = 64, N = S * M, G = 8;
   using E = typename Xch<R>::E;
@@ -504,12 +517,12 @@ static double run_pks64_case(int Np, int shift, unsigned seed) {
   for (auto& v : inr) v = nd(gen);
   for (auto& v : ini) v = nd(gen);
   const int lo = (N - Np) / 2 + shift;
-  std::vector<cpx<R>> tw(64), pcw((size_t)S * PKS_SPAN);
+  std::vector<cpx<R>> tw(64), pcw((size_t)S * pks_span(NPL));
   build_tw64<R>(tw.data(), cs_turns);
-  build_pcw<R>(pcw.data(), N, S, cs_turns);
+  build_pcw<R>(pcw.data(), N, S, cs_turns, NPL);
   std::vector<E> xbuf(D16_XELEMS);
   static HostExec<R, 16, 2> ex;
-  pks_clear<R, -1>(ex);
+  pks_clear<R, -1, NPL>(ex);
   for (int sp = 0; sp < S; ++sp) {
     for (int l = 0; l < WAVE; ++l)
       for (int j = 0; j < 8; ++j) {
@@ -517,11 +530,11 @@ static double run_pks64_case(int Np, int shift, unsigned seed) {
         const double sg = (k & 1) ? -1.0 : 1.0;
         ex.regs[l].v[j] = mk<R>((R)(sg * inr[g * N + k]), (R)(sg * ini[g * N + k]));
       }
-    pks64_pass<R>(ex, xbuf.data(), tw.data(), pcw.data() + sp * PKS_SPAN);
+    pks64_pass<R, NPL>(ex, xbuf.data(), tw.data(), pcw.data() + sp * pks_span(NPL));
   }
   std::vector<double> gr((size_t)G * Np, 1e300), gi((size_t)G * Np, 1e300);
   for (int l = 0; l < WAVE; ++l)
-    pks_outputs<R, -1>(l, ex.regs[l], N, lo, Np, [&](int oi, R re, R im) { gr[(l / 8) * Np + oi] = re; gi[(l / 8) * Np + oi] = im; });
+    pks_outputs<R, -1, NPL>(l, ex.regs[l], N, lo, Np, [&](int oi, R re, R im) { gr[(l / 8) * Np + oi] = re; gi[(l / 8) * Np + oi] = im; });
   double worst = 0.0, scale = 0.0;
   const int h = N / 2;
   for (int g = 0; g < G; ++g)
@@ -539,6 +552,18 @@ static double run_pks64_case(int Np, int shift, unsigned seed) {
       scale = std::fmax(scale, std::fmax(std::fabs((double)sr), std::fabs((double)si)));
     }
   return worst / scale;
+}
+template <class R, int S>
+static int sweep_pks64_8(const char* name, double tol) {
+  int bad = 0;
+  for (int Np : {128, 97, 110, 82, 1})
+    for (int shift : {0, Np < 120 ? 4 : 0, Np < 100 ? -13 : 0}) {
+      const double err = run_pks64_case<R, S, 8>(Np, shift, 8181u + Np + shift + S);
+      const bool ok = err <= tol;
+      std::printf("%s packed sub-rows of 64, eight planes N=%d (S=%d) shift=%d Np=%d relerr=%.3e %s\n", name, S * 64, S, shift, Np, err, ok ? "ok" : "FAIL");
+      bad += !ok;
+    }
+  return bad;
 }
 template <class R, int S>
 static int sweep_pks64(const char* name, double tol) {
@@ -569,6 +594,12 @@ int main() {
   bad += sweep_pks<double, 0, 7>("f64", 1e-13);
   bad += sweep_pks<double, 0, 9>("f64", 1e-13);
   // the counts the run-time kernels take (fmc_core.h: pks_rt): the arithmetic knows the count's parity only
+  bad += sweep_pks8<double, 1, 5>("f64", 1e-13);
+  bad += sweep_pks8<double, 1, 6>("f64", 1e-13);
+  bad += sweep_pks8<double, 0, 7>("f64", 1e-13);
+  bad += sweep_pks8<double, 0, 15>("f64", 1e-13);
+  bad += sweep_pks64_8<double, 9>("f64", 1e-13);
+  bad += sweep_pks64_8<double, 21>("f64", 1e-13);
   bad += sweep_pks64<double, 11>("f64", 1e-13);
   bad += sweep_pks64<double, 33>("f64", 1e-13);
   bad += sweep_pks<double, 0, 31>("f64", 1e-13);

@@ -140,6 +140,7 @@ struct fastmc_ctx {
   void* pk_om = nullptr;
   void* pks_tw1 = nullptr; // grids of the packed sub-rows (fmc_core.h: pks_count -- every multiple of 64 from 192 to 4096 but 256, 512): tables of the packed sub-rows (fmc_wavefft.h: build_tw1_pk for M = 256, build_pcw)
   void* pks_cw = nullptr;
+  void* pks_cw8 = nullptr;  // ... with 128 entries per sub-row: eight planes, centred windows of 97 ... 128 pixels (float64 pipeline)
   double* W = nullptr;
   void* V = nullptr;
   size_t V_cap = 0;        // realisations
@@ -585,7 +586,7 @@ static void destroy_now(fastmc_ctx* h) {
   if (h->nps) { nps_free(h->nps); h->nps = nullptr; }
 #endif
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
-  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->pbz_tw, h->pbz_pre, h->pbz_vhat, h->pbz_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->amp_p, h->ampf_p, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->pks_tw1, h->pks_cw, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->pbz_tw, h->pbz_pre, h->pbz_vhat, h->pbz_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->amp_p, h->ampf_p, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->pks_tw1, h->pks_cw, h->pks_cw8, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers, h->ps_dev, (void*)h->clk};
   for (void* p : ptrs)
@@ -745,11 +746,12 @@ static int default_batch(const fastmc_ctx* h) {
   int b = (int)(2048.0 * 1024 * 1024 / per);       // round 2: 1568 realisations per launch +0.9 % over 1176 at 1024^2
   b = std::max(1, std::min(b, 4096));
   if (h->path != 0 && (pks_grid(h->N) || (h->path == 1 && h->rsz == 8 && pks_p16(h->N) && h->N >= pks_p16_from())) &&
-      h->lo >= h->N / 2 - 48 && h->lo + h->Np <= h->N / 2 + 48 && !(h->rsz == 4 && pks_rt(h->N))) {
+      h->lo >= h->N / 2 - 64 && h->lo + h->Np <= h->N / 2 + 64 && !(h->rsz == 4 && (pks_rt(h->N) || h->lo < h->N / 2 - 48 || h->lo + h->Np > h->N / 2 + 48))) {
     // packed sub-rows (pks_variant; fmc_kernels.h: k_rows_pks): a tile is one 128-byte line of V positions x BPG realisations, and the
     // launch's workgroups (one per CU) walk the tiles -- whole groups of BPG realisations, and of the group counts within a quarter of
     // the slab limit the one whose tiles fill the last round over the 256 CUs best (1856: 10 % of the launch was an almost empty round)
-    const int L0 = pks_L0(h->N), WPB = L0 == 0 ? (h->rsz == 8 ? FMC_PKS_WPB0 : 12) : FMC_PKS_WPB, G = L0 == 1 ? 4 : 8;
+    const bool planes8 = h->lo < h->N / 2 - 48 || h->lo + h->Np > h->N / 2 + 48;
+    const int L0 = pks_L0(h->N), WPB = planes8 ? (L0 == 1 ? 12 : 8) : (L0 == 0 ? (h->rsz == 8 ? FMC_PKS_WPB0 : 12) : FMC_PKS_WPB), G = L0 == 1 ? 4 : 8;
     const int LR = 128 / (2 * h->rsz), BPG = ROWS_PER_WAVE * WPB / (LR / G), nmax = b / BPG;
     if (nmax >= 1) {
       int best = nmax;
@@ -917,6 +919,11 @@ static int upload_pks_tables(fastmc_ctx* h) {
   build_pcw<R>(pcw.data(), h->N, Sp, cs_turns);
   TRY(upload_table<R>(&h->pks_tw1, tw));
   TRY(upload_table<R>(&h->pks_cw, pcw));
+  if constexpr (sizeof(R) == 8) {
+    std::vector<cpx<R>> pcw8((size_t)Sp * pks_span(8));
+    build_pcw<R>(pcw8.data(), h->N, Sp, cs_turns, 8);
+    TRY(upload_table<R>(&h->pks_cw8, pcw8));
+  }
   return 0;
 }
 
@@ -948,8 +955,12 @@ static int pks_variant(const fastmc_ctx* h) {
   if (sizeof(R) != 8 && pks_rt(h->N)) return -1;           // (run-time counts: float64 pipeline only; fastmc_create never makes such a handle)
   static const bool off = getenv("FASTMC_PKS") && atoi(getenv("FASTMC_PKS")) == 0;     // A/B: staged / direct instead
   if (off) return -1;
-  // the six planes of a sub-transform hold x = N / 2 - 48 ... N / 2 + 47 (fmc_wavefft.h: pks_accumulate)
-  return (h->lo >= h->N / 2 - 48 && h->lo + h->Np <= h->N / 2 + 48) ? 0 : -1;
+  // the six planes of a sub-transform hold x = N / 2 - 48 ... N / 2 + 47 (fmc_wavefft.h: pks_accumulate) ...
+  if (h->lo >= h->N / 2 - 48 && h->lo + h->Np <= h->N / 2 + 48) return 0;
+  // ... eight planes N / 2 - 64 ... N / 2 + 63: 1 (float64 pipeline, run-time sub-row counts for every grid; FASTMC_PKS8=0: off)
+  static const bool off8 = getenv("FASTMC_PKS8") && atoi(getenv("FASTMC_PKS8")) == 0;
+  if (sizeof(R) == 8 && !off8 && h->lo >= h->N / 2 - 64 && h->lo + h->Np <= h->N / 2 + 64) return 1;
+  return -1;
 }
 
 // The chirp-z rows draw 64 generator streams per row and the 50-lane rows 50 S: a grid whose layout is another one (fmc_core.h:
@@ -1329,37 +1340,39 @@ int dispatch_pk(fastmc_ctx* h, const RowArgs<R>& RA, const ColArgs<R>& CA, int m
 }
 
 // Row pass of the packed sub-rows (fmc_kernels.h: k_rows_pks; S <= 0: the sub-row count at run time).
-template <class R, int L0, int S, int MODE>
+template <class R, int L0, int S, int MODE, int NPL = 6>
 static void launch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA) {
-  using C = PksCfg<R, L0, S>;
+  using C = PksCfg<R, L0, S, NPL>;
   const int Sr = S > 0 ? S : pks_count(RA.N);        // S <= 0: the sub-row count at run time (fmc_core.h: pks_rt, pks_p16)
-  const size_t lds = pks_lds_bytes<R, L0, S>(Sr) + (MODE == 2 ? GEN64_TABLE_BYTES : 0);
+  const size_t lds = pks_lds_bytes<R, L0, S, NPL>(Sr) + (MODE == 2 ? GEN64_TABLE_BYTES : 0);
   constexpr int LR = 128 / (int)sizeof(cpx<R>), LU = LR / C::G, BPG = ROWS_PER_WAVE * C::WPB / LU;
   int blocks = (Sr * C::M / LR) * ((RA.nb + BPG - 1) / BPG);
   RowArgs<R> B = RA;
   B.S = Sr;
-  hipFuncSetAttribute((const void*)k_rows_pks<R, L0, S, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)k_rows_pks<R, L0, S, MODE, NPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   static const int persist = getenv("FASTMC_ROWS_PERSIST") ? atoi(getenv("FASTMC_ROWS_PERSIST")) : 1;
   if (persist) {        // as launch_rows_wave: a launch of many rounds keeps its workgroups, which walk its tiles
-    const int resident = resident_workgroups(h, (const void*)k_rows_pks<R, L0, S, MODE>, C::WPB * 64, lds);
+    const int resident = resident_workgroups(h, (const void*)k_rows_pks<R, L0, S, MODE, NPL>, C::WPB * 64, lds);
     if (blocks >= 8 * resident) { B.tiles = blocks; blocks = resident; }
   }
-  hipLaunchKernelGGL((k_rows_pks<R, L0, S, MODE>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, B);
-  FMC_NOTE(h->last_rows, "k_rows_pks<%s, %d, %d, %d>", rname<R>(), L0, S, MODE);
+  hipLaunchKernelGGL((k_rows_pks<R, L0, S, MODE, NPL>), dim3(blocks), dim3(C::WPB * 64), lds, h->stream, B);
+  if (NPL == 6) FMC_NOTE(h->last_rows, "k_rows_pks<%s, %d, %d, %d>", rname<R>(), L0, S, MODE);
+  else FMC_NOTE(h->last_rows, "k_rows_pks<%s, %d, %d, %d, %d>", rname<R>(), L0, S, MODE, NPL);
 }
 template <class R> int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode);
-template <class R, int L0, int S, int EPI>
+template <class R, int L0, int S, int EPI, int NPL = 6>
 static void launch_pks_cols(fastmc_ctx* h, const ColArgs<R>& CA) {
-  using C = PksCfg<R, L0, S>;
-  constexpr int WPC = PksColCfg<R, L0, S>::WPC;
+  using C = PksCfg<R, L0, S, NPL>;
+  constexpr int WPC = PksColCfg<R, L0, S, NPL>::WPC;
   const int Sr = S > 0 ? S : pks_count(CA.N);
-  const size_t lds = pks_cols_lds_bytes<R, L0, S>(Sr);
+  const size_t lds = pks_cols_lds_bytes<R, L0, S, NPL>(Sr);
   const int items = CA.nb * ((CA.Np + C::G - 1) / C::G);
   ColArgs<R> B = CA;
   B.S = Sr;
-  hipFuncSetAttribute((const void*)k_cols_pks<R, L0, S, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_cols_pks<R, L0, S, EPI>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), lds, h->stream, B);
-  FMC_NOTE(h->last_cols, "k_cols_pks<%s, %d, %d, %d>", rname<R>(), L0, S, EPI);
+  hipFuncSetAttribute((const void*)k_cols_pks<R, L0, S, EPI, NPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_cols_pks<R, L0, S, EPI, NPL>), dim3((items + WPC - 1) / WPC), dim3(WPC * 64), lds, h->stream, B);
+  if (NPL == 6) FMC_NOTE(h->last_cols, "k_cols_pks<%s, %d, %d, %d>", rname<R>(), L0, S, EPI);
+  else FMC_NOTE(h->last_cols, "k_cols_pks<%s, %d, %d, %d, %d>", rname<R>(), L0, S, EPI, NPL);
 }
 // rows (device generator) and columns of the packed sub-rows: the pair keeps V permuted along ky (fmc_kernels.h: k_rows_pks)
 template <class R>
@@ -1370,6 +1383,16 @@ int dispatch_pks(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in
   CA.tw = (const cpx<R>*)h->pks_tw1; CA.cw = (const cpx<R>*)h->pks_cw;
   // (the grids of pks_rt: the kernels with a run-time count -- S = 0 odd, -2 even; float64 pipeline only, fastmc_create)
   const int S = pks_ct(h->N) ? pks_ct(h->N) : ((pks_count(h->N) & 1) ? 0 : -2), L0 = pks_L0(h->N);
+  if constexpr (sizeof(R) == 8) {
+    if (pks_variant<R>(h) == 1) {      // eight planes: the run-time kernels, whatever the grid
+      CA.cw = (const cpx<R>*)h->pks_cw8;
+      const int S8 = (pks_count(h->N) & 1) ? 0 : -2;
+#define FMC_PKSC8(LL, SS) if (L0 == LL && S8 == SS) { if (epi == 0) launch_pks_cols<R, LL, SS, 0, 8>(h, CA); else launch_pks_cols<R, LL, SS, 1, 8>(h, CA); return 0; }
+      FMC_PKSC8(1, 0) FMC_PKSC8(1, -2) FMC_PKSC8(0, 0) FMC_PKSC8(-1, 0)
+#undef FMC_PKSC8
+      return fail(FASTMC_ESTATE, "no eight-plane packed sub-row column kernel for this grid");
+    }
+  }
 #define FMC_PKSC(LL, SS)                                                                  \
   if (L0 == LL && S == SS) {                                                              \
     if (epi == 0) launch_pks_cols<R, LL, SS, 0>(h, CA); else launch_pks_cols<R, LL, SS, 1>(h, CA); \
@@ -1387,6 +1410,16 @@ int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode) {
   const int S = pks_ct(h->N) ? pks_ct(h->N) : ((pks_count(h->N) & 1) ? 0 : -2), L0 = pks_L0(h->N);
   RowArgs<R> RA = RA_in;      // the family's own tables; the colouring tables with the input-side fftshift sign folded in
   RA.amp = (const R*)h->amp_p; RA.ampf = h->ampf_p; RA.tw = (const cpx<R>*)h->pks_tw1; RA.cw = (const cpx<R>*)h->pks_cw;
+  if constexpr (sizeof(R) == 8) {
+    if (pks_variant<R>(h) == 1) {      // eight planes (centred windows of 97 ... 128 pixels): the run-time kernels, whatever the grid
+      RA.cw = (const cpx<R>*)h->pks_cw8;
+      const int S8 = (pks_count(h->N) & 1) ? 0 : -2;
+#define FMC_PKS8(LL, SS) if (L0 == LL && S8 == SS) { if (mode == 0) launch_pks_rows<R, LL, SS, 0, 8>(h, RA); else launch_pks_rows<R, LL, SS, 2, 8>(h, RA); return 0; }
+      FMC_PKS8(1, 0) FMC_PKS8(1, -2) FMC_PKS8(0, 0) FMC_PKS8(-1, 0)
+#undef FMC_PKS8
+      return fail(FASTMC_ESTATE, "no eight-plane packed sub-row kernel for this grid");
+    }
+  }
 #define FMC_PKS(LL, SS)                                                                                   \
   if (L0 == LL && S == SS) {                                                                              \
     if (mode == 0) { launch_pks_rows<R, LL, SS, 0>(h, RA); return 0; }                                    \

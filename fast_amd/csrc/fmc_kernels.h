@@ -963,25 +963,29 @@ __global__ __launch_bounds__((PkCfg<R, L0, D>::WPC * 64), (PkCfg<R, L0, D>::CMIN
 #ifndef FMC_PKS_WPB0
 #define FMC_PKS_WPB0 8
 #endif
-template <class R, int L0_, int S> struct PksCfg {
+template <class R, int L0_, int S, int NPL = 6> struct PksCfg {
   // L0 = 1 / 0: sub-rows of 256 / 128 points on the packed pipeline (sixteen values per lane, L = 16 / 8 lanes per sub-row);
   // L0 = -1: sub-rows of SIXTY-FOUR points (192, 320, 448, 576): eight values per lane, eight lanes per sub-row (fmc_wavefft.h: pks64_pass)
   // S > 0: the sub-row count at compile time (192 ... 1792); S = 0 / -2: an odd / even count at RUN TIME (RowArgs::S: the grids of
   // fmc_core.h wave_rt_split up to 3840 -- 2304 = 9 x 256 ... 3840 = 15 x 256, 1920 ... 3456 = 15, 21, 27 x 128, 1344 / 1728 = 21 / 27 x 64)
   static constexpr int L0 = L0_, L = L0 < 0 ? 8 : pk_lanes(L0), VPL = L0 < 0 ? 8 : 16, G = WAVE / L, M = VPL * L, NM = pks_nm<L0>();
   static constexpr int SP = S > 0 ? S : (S == 0 ? 3 : 2);        // a count of the same parity: the plane set depends on it only
-  static constexpr int B0M = L0 < 0 ? 0xFF : pks_plane_mask(L0 < 0 ? 0 : L0, SP), FIRST = pks_first_plane(L0 < 0 ? 0 : L0, SP);
+  static constexpr int B0M = L0 < 0 ? 0xFF : pks_plane_mask(L0 < 0 ? 0 : L0, SP, NPL), FIRST = pks_first_plane(L0 < 0 ? 0 : L0, SP, NPL);
+  static constexpr int SPAN = pks_span(NPL);             // table entries per sub-row (NPL = 8: centred windows of up to 128 pixels)
   static constexpr int TWN = VPL * L;                    // entries of the sub-transform's twiddle table
   // 256-point sub-rows: 155 registers with the float64 generator, twelve waves; 128-point sub-rows carry twelve accumulators (48
   // more registers for float64): eight waves; 64-point sub-rows: twelve accumulators but eight values: twelve waves
-  static constexpr int WPB = L0 == 0 ? (sizeof(R) == 8 ? FMC_PKS_WPB0 : 12) : FMC_PKS_WPB;
+  // (eight planes: two / four accumulators more per lane -- 163 registers with 256-point sub-rows: still twelve waves; 209 / 170 with
+  // 128 / 64-point ones: eight)
+  static constexpr int WPB = NPL > 6 ? (L0 == 1 ? 12 : 8) : (L0 == 0 ? (sizeof(R) == 8 ? FMC_PKS_WPB0 : 12) : FMC_PKS_WPB);
 };
 // LDS carve (dynamic): [generator tables (MODE 2)][tw1 16 L cpx][pcw S x 96 cpx][xbuf WPB * D16_XELEMS 8-byte]
 // A run-time count (S <= 0) keeps only the CURRENT pass's 96 entries of pcw, one copy per wave (pks_slice): the table of S = 63 sub-rows
 // would be 94 KB; the slice of pass s is loaded while the pass's draws run.
-template <class R, int L0, int S>
+template <class R, int L0, int S, int NPL = 6>
 __host__ __device__ constexpr size_t pks_lds_bytes(int Sr) {
-  return (size_t)(PksCfg<R, L0, S>::TWN + (S > 0 ? Sr : PksCfg<R, L0, S>::WPB) * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksCfg<R, L0, S>::WPB * D16_XELEMS * 8;
+  using C = PksCfg<R, L0, S, NPL>;
+  return (size_t)(C::TWN + (S > 0 ? Sr : C::WPB) * C::SPAN) * sizeof(cpx<R>) + (size_t)C::WPB * D16_XELEMS * 8;
 }
 // The 96 entries of pass sp into the wave's slice by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane to base + 16 lane, no
 // register in between -- the float64 rows have none to spare across their draws): one instruction of the whole wave and one of its
@@ -991,17 +995,20 @@ __host__ __device__ constexpr size_t pks_lds_bytes(int Sr) {
 // destination (seen in the ISA of k_rows_pbz: no s_waitcnt between the DMA and the read; the draws in between hid it in every test
 // until a read followed the DMA directly).  Every reader of DMA'd data calls this first.
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int SPAN>
 __device__ __forceinline__ void pks_slice_load(const cpx<double>* cw, cpx<double>* slice, int sp, int lane) {
-  const cpx<double>* src = cw + sp * PKS_SPAN + lane;
+  const cpx<double>* src = cw + sp * SPAN + lane;
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)slice, 16, 0, 0);
-  if (lane < 32)
+  if (SPAN == 128 || lane < 32)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64), (__attribute__((address_space(3))) void*)(slice + 64), 16, 0, 0);
 }
+template <int SPAN>
 __device__ __forceinline__ void pks_slice_load(const cpx<float>*, cpx<float>*, int, int) {}      // (never instantiated for a launch: fastmc.hip pks_variant)
-template <class R, int L0, int S, int MODE>
-__global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowArgs<R> A) {
+template <class R, int L0, int S, int MODE, int NPL = 6>
+__global__ __launch_bounds__((PksCfg<R, L0, S, NPL>::WPB * 64)) void k_rows_pks(RowArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using C = PksCfg<R, L0, S>;
+  using C = PksCfg<R, L0, S, NPL>;
+  constexpr int PKS_SPAN = C::SPAN;                       // (shadows the six-plane constant)
   using E = typename Xch<R>::E;
   constexpr int L = C::L, G = C::G, WPB = C::WPB, VPL = C::VPL;
   const int Sr = S > 0 ? S : A.S, N = Sr * C::M;          // (S > 0: constants, folded; else the launch's)
@@ -1044,13 +1051,13 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
     const int mu = m0 + (flat % LU) * G;                 // position of the unit's first row within its class
     const int ky0 = s_r + Sr * mu;                       // ... and that row
     const uint64_t g = A.g0 + (uint64_t)b;
-    pks_clear<R, L0>(ex);
+    pks_clear<R, L0, NPL>(ex);
 #pragma unroll 1
     for (int sp = 0; sp < Sr; ++sp) {
       // sub-row sp of the G rows: kx = sp + S (q + L j), stream t = sp + S q of SL = S L
       xoshiro128p rs = row_stream(A.key, g, ky0 + Sr * gl, sp + Sr * q, Sr * L);
       // (the wave's slice: its reads of the pass before were issued, and waited for, before this -- DS operations of a wave run in order)
-      if constexpr (SLICE) pks_slice_load(A.cw, s_cw + w * PKS_SPAN, sp, lane);
+      if constexpr (SLICE) pks_slice_load<PKS_SPAN>(A.cw, s_cw + w * PKS_SPAN, sp, lane);
       if (MODE == 0) {
         const float* ampf = A.ampf + (size_t)ky0 * N + sp * C::M + lane_in;
 #pragma unroll
@@ -1070,14 +1077,14 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
       }
       const cpx<R>* cw_s = SLICE ? s_cw + w * PKS_SPAN : s_cw + sp * PKS_SPAN;
       if constexpr (SLICE) { lds_dma_wait(); ex.sync(); }      // (the draws' own loads have been consumed: nothing else is outstanding)
-      if constexpr (L0 < 0) pks64_pass<R>(ex, xbuf, s_tw, cw_s);
+      if constexpr (L0 < 0) pks64_pass<R, NPL>(ex, xbuf, s_tw, cw_s);
       else {
         packed_row_fft<R, L0, C::NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
-        pks_accumulate<R, L0, C::FIRST>(ex, cw_s);
+        pks_accumulate<R, L0, C::FIRST, NPL>(ex, cw_s);
       }
     }
     cpx<R>* out = A.V + (size_t)b * A.Np * N + s_r * M + mu;      // V[b][oi][position of ky]
-    pks_outputs<R, L0>(lane, regs, N, A.lo, A.Np, [&](int oi, R re, R im) { out[(uint32_t)(oi * N + gl)] = mk<R>(re, im); });
+    pks_outputs<R, L0, NPL>(lane, regs, N, A.lo, A.Np, [&](int oi, R re, R im) { out[(uint32_t)(oi * N + gl)] = mk<R>(re, im); });
   }
   if (A.tiles) __syncthreads();      // (as k_rows_wave: the waves of a workgroup stay within one tile of each other)
   }
@@ -1085,22 +1092,23 @@ __global__ __launch_bounds__((PksCfg<R, L0, S>::WPB * 64)) void k_rows_pks(RowAr
 
 // The column pass of the same grids: G window columns per wavefront, S passes over a column's sub-rows (contiguous in the permuted V),
 // the detector as k_cols_pk's rolled loop over the lane's accumulators, the sums reduced over the L lanes of a column by DPP.
-template <class R, int L0, int S> struct PksColCfg {
+template <class R, int L0, int S, int NPL = 6> struct PksColCfg {
   // (a run-time sub-row count: twelve waves -- sixteen exchange buffers + sixteen table slices would be 163 KB)
   // 122 registers (M = 256) / 152 (M = 128: twelve accumulators) with float64: four / three waves per SIMD; the exchange buffers and
   // the tables of sixteen / twelve waves fit the LDS (150 KB / 117 KB at most)
-  static constexpr int WPC = S <= 0 ? 12 : ((L0 != 0 || sizeof(R) == 4) ? 16 : 12);      // (64-point sub-rows: 126 registers)
+  static constexpr int WPC = NPL > 6 ? 12 : (S <= 0 ? 12 : ((L0 != 0 || sizeof(R) == 4) ? 16 : 12));      // (64-point sub-rows: 126 registers; eight planes: 128-162)
 };
-template <class R, int L0, int S>
+template <class R, int L0, int S, int NPL = 6>
 __host__ __device__ constexpr size_t pks_cols_lds_bytes(int Sr) {
-  return (size_t)(PksCfg<R, L0, S>::TWN + (S > 0 ? Sr : PksColCfg<R, L0, S>::WPC) * PKS_SPAN) * sizeof(cpx<R>) + (size_t)PksColCfg<R, L0, S>::WPC * D16_XELEMS * 8;
+  return (size_t)(PksCfg<R, L0, S, NPL>::TWN + (S > 0 ? Sr : PksColCfg<R, L0, S, NPL>::WPC) * pks_span(NPL)) * sizeof(cpx<R>) + (size_t)PksColCfg<R, L0, S, NPL>::WPC * D16_XELEMS * 8;
 }
-template <class R, int L0, int S, int EPI>
-__global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(ColArgs<R> A) {
+template <class R, int L0, int S, int EPI, int NPL = 6>
+__global__ __launch_bounds__((PksColCfg<R, L0, S, NPL>::WPC * 64)) void k_cols_pks(ColArgs<R> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using C = PksCfg<R, L0, S>;
+  using C = PksCfg<R, L0, S, NPL>;
   using E = typename Xch<R>::E;
-  constexpr int L = C::L, G = C::G, M = C::M, NM = C::NM, VPL = C::VPL, WPC = PksColCfg<R, L0, S>::WPC;
+  constexpr int PKS_SPAN = C::SPAN;
+  constexpr int L = C::L, G = C::G, M = C::M, NM = C::NM, VPL = C::VPL, WPC = PksColCfg<R, L0, S, NPL>::WPC;
   const int Sr = S > 0 ? S : A.S, N = Sr * M;
   cpx<R>* s_tw = reinterpret_cast<cpx<R>*>(smem);
   cpx<R>* s_cw = s_tw + C::TWN;
@@ -1123,17 +1131,17 @@ __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(Co
   const bool live = xi < A.Np;                             // the last group of a realisation may be short
   const cpx<R>* col = A.V + ((size_t)b * A.Np + (item % ngrp) * G) * N;
   const uint32_t lane_in = (live ? gl : 0) * N + q;
-  pks_clear<R, L0>(ex);
+  pks_clear<R, L0, NPL>(ex);
 #pragma unroll 1
   for (int sp = 0; sp < Sr; ++sp) {
 #pragma unroll
     for (int j = 0; j < VPL; ++j) regs.v[j] = load_v(col + sp * M + lane_in + L * j);
     const cpx<R>* cw_s = SLICE ? s_cw + w * PKS_SPAN : s_cw + sp * PKS_SPAN;
-    if constexpr (SLICE) { pks_slice_load(A.cw, s_cw + w * PKS_SPAN, sp, lane); lds_dma_wait(); ex.sync(); }      // (with the pass's loads of V, needed at once anyway)
-    if constexpr (L0 < 0) pks64_pass<R>(ex, xbuf, s_tw, cw_s);
+    if constexpr (SLICE) { pks_slice_load<PKS_SPAN>(A.cw, s_cw + w * PKS_SPAN, sp, lane); lds_dma_wait(); ex.sync(); }      // (with the pass's loads of V, needed at once anyway)
+    if constexpr (L0 < 0) pks64_pass<R, NPL>(ex, xbuf, s_tw, cw_s);
     else {
       packed_row_fft<R, L0, NM, C::B0M>(ex, xbuf, s_tw, (const cpx<R>*)nullptr, 0, 0, A.Np);
-      pks_accumulate<R, L0, C::FIRST>(ex, cw_s);
+      pks_accumulate<R, L0, C::FIRST, NPL>(ex, cw_s);
     }
   }
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1155,11 +1163,11 @@ __global__ __launch_bounds__((PksColCfg<R, L0, S>::WPC * 64)) void k_cols_pks(Co
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
 #pragma unroll
-    for (int p = 0; p < 6; ++p) ob[WAVE * p] = regs.omc[m][p];
+    for (int p = 0; p < NPL; ++p) ob[WAVE * p] = regs.omc[m][p];
     ex.sync();
-    const int y0 = N / 2 - 48 + q + 8 * m - A.lo;          // (L0 = 1: m = 0, q = a; L0 = 0, -1: e = q + 8 m + 16 p)
+    const int y0 = N / 2 - 8 * NPL + q + 8 * m - A.lo;     // (L0 = 1: m = 0, q = a; L0 = 0, -1: e = q + 8 m + 16 p)
 #pragma unroll 1
-    for (int p = 0; p < 6; ++p) {
+    for (int p = 0; p < NPL; ++p) {
       const int yi = y0 + 16 * p;
       if (live && yi >= 0 && yi < A.Np) {
         const cpx<R> v = ob[WAVE * p];

@@ -626,61 +626,66 @@ FMC_HD void packed_outputs(int lane, const LaneRegs<R, 16, NSL>& r, int lo, int 
 // in r.omc[m][p] (the one-row kernels' register table is unused here).  Twiddles: pcw[s * 96 + e] = w_N^{s x} -- 96 entries per
 // sub-row that depend on N only (build_pcw); the G groups of a wavefront read the same sixteen.
 constexpr int PKS_SPAN = 96;                                         // outputs of a sub-transform the six planes hold
+// NPL = 8 (late round 6): EIGHT planes -- x = N / 2 - 64 + e, e < 128: centred windows of 97 ... 128 pixels, which fell back to staged
+// draws on one-row-per-wave rows at a third to a quarter of the rate.  One plane more on either side: FIRST - 1, eight (sixteen)
+// accumulators per lane, 128 table entries per sub-row.  Run-time sub-row counts only (any S).
+constexpr int pks_span(int NPL) { return 16 * NPL; }
 template <int L0> constexpr int pks_nm() { return L0 <= 0 ? 2 : 1; }        // a values per lane (L0 = -1: the 64-point form, same accumulator layout as L0 = 0)
-constexpr int pks_first_plane(int L0, int S) { return L0 == 0 ? ((S & 1) ? 1 : 5) : ((S & 1) ? 5 : 13); }
-constexpr int pks_plane_mask(int L0, int S) {
+constexpr int pks_first_plane(int L0, int S, int NPL = 6) { return (L0 == 0 ? ((S & 1) ? 1 : 5) : ((S & 1) ? 5 : 13)) - (NPL - 6) / 2; }
+constexpr int pks_plane_mask(int L0, int S, int NPL = 6) {
   int m = 0;
-  for (int p = 0; p < 6; ++p) m |= 1 << ((pks_first_plane(L0, S) + p) & (L0 == 0 ? 7 : 15));
+  for (int p = 0; p < NPL; ++p) m |= 1 << ((pks_first_plane(L0, S, NPL) + p) & (L0 == 0 ? 7 : 15));
   return m;
 }
 static_assert(pks_plane_mask(1, 3) == pk_centre_mask<1>() && pks_plane_mask(0, 5) == pk_centre_mask<0>() && pks_plane_mask(1, 6) == D16R_CENTRE_MASK,
               "the centred planes of the 256 / 128-point grids, and the planes around 0");
-template <class R, int L0, class Exec>
+template <class R, int L0, int NPL = 6, class Exec>
 FMC_HD void pks_clear(Exec& ex) {
   ex.each([&](int, LaneRegs<R, 16, pks_nm<L0>()>& r) {
 #pragma unroll
     for (int m = 0; m < pks_nm<L0>(); ++m)
 #pragma unroll
-      for (int p = 0; p < 6; ++p) r.omc[m][p] = mk<R>((R)0, (R)0);
+      for (int p = 0; p < NPL; ++p) r.omc[m][p] = mk<R>((R)0, (R)0);
   });
 }
 // after packed_row_fft of sub-row s (its planes in r.v, output-side sign applied): acc[m][p] += w_N^{s x} Y_s[x mod M]
-template <class R, int L0, int FIRST, class Exec>
+template <class R, int L0, int FIRST, int NPL = 6, class Exec>
 FMC_HD void pks_accumulate(Exec& ex, const cpx<R>* pcw_s) {
   ex.each([&](int lane, LaneRegs<R, 16, pks_nm<L0>()>& r) {
     if constexpr (L0 == 1) {
       const cpx<R>* w = pcw_s + (lane & 15);
 #pragma unroll
-      for (int p = 0; p < 6; ++p) r.omc[0][p] = cfma(ex.ld(w + 16 * p), r.v[(FIRST + p) & 15], r.omc[0][p]);
+      for (int p = 0; p < NPL; ++p) r.omc[0][p] = cfma(ex.ld(w + 16 * p), r.v[(FIRST + p) & 15], r.omc[0][p]);
     } else {
       const cpx<R>* w = pcw_s + (lane & 7);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int p = 0; p < 6; ++p) r.omc[m][p] = cfma(ex.ld(w + 8 * m + 16 * p), r.v[8 * m + ((FIRST + p) & 7)], r.omc[m][p]);
+        for (int p = 0; p < NPL; ++p) r.omc[m][p] = cfma(ex.ld(w + 8 * m + 16 * p), r.v[8 * m + ((FIRST + p) & 7)], r.omc[m][p]);
     }
   });
 }
 // f(oi, re, im) for every window output this lane holds after the last pks_accumulate; N the full row length
-template <class R, int L0, class F>
+template <class R, int L0, int NPL = 6, class F>
 FMC_HD void pks_outputs(int lane, const LaneRegs<R, 16, pks_nm<L0>()>& r, int N, int lo, int Np, F f) {
   const int a = lane & (L0 <= 0 ? 7 : 15);
 #pragma unroll
-  for (int p = 0; p < 6; ++p)
+  for (int p = 0; p < NPL; ++p)
 #pragma unroll
     for (int m = 0; m < pks_nm<L0>(); ++m) {
-      const int oi = N / 2 - 48 + a + 8 * m + 16 * p - lo;
+      const int oi = N / 2 - 8 * NPL + a + 8 * m + 16 * p - lo;
       if (oi >= 0 && oi < Np) f(oi, r.omc[m][p].x, r.omc[m][p].y);
     }
 }
 template <class R, class CosSin>
-inline void build_pcw(cpx<R>* pcw, int N, int S, CosSin cs) {
+inline void build_pcw(cpx<R>* pcw, int N, int S, CosSin cs, int NPL = 6) {
+  const int span = pks_span(NPL);
   for (int sp = 0; sp < S; ++sp)
-    for (int e = 0; e < PKS_SPAN; ++e) {
-      const long long x = N / 2 - 48 + e;
+    for (int e = 0; e < span; ++e) {
+      const long long x = N / 2 - span / 2 + e;
       double c, sn;
       cs((double)((sp * x) % N) / N, &c, &sn);
-      pcw[sp * PKS_SPAN + e] = mk<R>((R)c, (R)(-sn));
+      pcw[sp * span + e] = mk<R>((R)c, (R)(-sn));
     }
 }
 
@@ -700,7 +705,7 @@ inline void build_pcw(cpx<R>* pcw, int N, int S, CosSin cs) {
 // at 65 a + lane.  The generator draws N / 8 streams of EIGHT advances on these grids (fmc_core.h: stream_lanes).
 constexpr int PKS64_SE = 65;
 // one sub-row pass: r.v[j] = c_s[q + 8 j], j < 8 (input-side sign folded in) -> the accumulators; tw64[a * 8 + q] = w_64^{q a}
-template <class R, class Exec>
+template <class R, int NPL = 6, class Exec>
 FMC_HD void pks64_pass(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw64, const cpx<R>* pcw_s) {
   using X = Xch<R>;
   using E = typename X::E;
@@ -740,7 +745,8 @@ FMC_HD void pks64_pass(Exec& ex, typename Xch<R>::E* xbuf, const cpx<R>* tw64, c
 #pragma unroll
     for (int b = 0; b < 8; ++b) { y[b] = t[brev(b, 3)]; y[b].x = flip_sign(y[b].x, neg); y[b].y = flip_sign(y[b].y, neg); }
 #pragma unroll
-    for (int pp = 0; pp < 12; ++pp) r.omc[pp & 1][pp >> 1] = cfma(ex.ld(w + 8 * pp), y[(pp + 6) & 7], r.omc[pp & 1][pp >> 1]);
+    // (e = a + 8 p', x = N / 2 - 8 NPL + e: N / 2 = 32 mod 64 for odd S, so b(p') = (p' + 12 - NPL) mod 8 -- 6 for six planes, 4 for eight)
+    for (int pp = 0; pp < 2 * NPL; ++pp) r.omc[pp & 1][pp >> 1] = cfma(ex.ld(w + 8 * pp), y[(pp + 12 - NPL) & 7], r.omc[pp & 1][pp >> 1]);
   });
 }
 template <class R, class CosSin>

@@ -362,7 +362,9 @@ static int default_path(int N, int blu_P, int mr_P) { return wave_supported(N) ?
 static int blu_pick_P(int N, int Np, int* SB = nullptr, int* B = nullptr) {
   if (SB) *SB = 1;
   if (B) *B = N;
-  if (N < 2 || mr_supported(N) || wave_rt_split(N)) return 0;      // 50 P grids are drawn as 50 streams per row: 50-lane or direct family
+  // (Every N: the grids of other generator layouts -- 50 P S, the multiples of 64 -- take these rows for host / staged coefficients
+  // only: family_streams_ok.  Rounds 2-5 excluded them here.)
+  if (N < 2) return 0;
   const int ns = (Np + 63) / 64;
   if (ns > 4) return 0;
   // (12 and 28 -- M = 768, 1792 -- since round 6, windows of up to 128 pixels: +10-13 % over the next of 1024 / 2048; M = 1280 (P = 20)
@@ -1050,7 +1052,7 @@ extern "C" int fastmc_set_pupil(fastmc_t* h, const double* W, int crop_lo, doubl
   h->dx = dx;
   if (!h->W) HIPCHK(hipMalloc((void**)&h->W, n * sizeof(double)));
   HIPCHK(hipMemcpy(h->W, W, n * sizeof(double), hipMemcpyHostToDevice));
-  if (!wave_supported(h->N) && h->blu_P) {
+  if (h->path == 2 && h->blu_P) {
     if (h->blu_lo != crop_lo) h->blu_lo = -1;
     TRY(h->precision == FASTMC_F64 ? upload_blu_tables<double>(h) : upload_blu_tables<float>(h));
   }
@@ -2092,7 +2094,19 @@ static int run_impl(fastmc_ctx* h, const RunSpec& S) {
     // N / 16 (N / 8) streams per row of these grids.
     const bool pks = h->path != 0 && kmode != 1 && pks_variant<R>(h) >= 0;
     const bool pks_to_direct = !pks && kmode == 0 && !family_streams_ok(h);
-    if (h->path == 2 && !pks && !pks_to_direct) {
+    // A window the grid's own one-row-per-wave rows have no form for (wider than 128 pixels where the radix has no 256-pixel variant:
+    // 448, 896, 1152, 1344, 1792 ...) went to the direct family -- O(N Np) per row, 9 k it/s at 1344^2 / Np = 129 where Np = 128 runs 284 k.
+    // Host or staged coefficients take the chirp-z rows instead (any N, windows of up to 256 pixels; float64 pipeline).
+    bool blu_fallback = false;
+    if constexpr (sizeof(R) == 8) {
+      if (h->path == 1 && !pks && kmode == 1 && h->blu_P && h->Np > 128) {
+        int ns = 0, wpb_unused = 0;
+        wave_config<R>(h, &ns, &wpb_unused);
+        blu_fallback = ns == 0 && !(h->N == 2048 && wave_lds_bytes<R, 32, 32>(h->omS) <= LDS_MAX);
+        if (blu_fallback && h->blu_lo != h->lo) h->blu_lo = -1;
+      }
+    }
+    if ((h->path == 2 || blu_fallback) && !pks && !pks_to_direct) {
       TRY(upload_blu_tables<R>(h));
       RA.amp = (const R*)h->amp; RA.ampf = h->ampf; RA.tw = (const cpx<R>*)h->blu_tw1; RA.om = (const cpx<R>*)h->blu_om;
       RA.cw = nullptr; RA.tw_global = 0;

@@ -403,7 +403,7 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             # any other window is STAGED (k_gen_coeffs_f64 -> MODE 1 rows: these grids draw N / 16 streams per row)
             (768, 82, None, "k_rows_pks<double, 1, 3, 2>"), (768, 40, None, "k_rows_pks<double, 1, 3, 2>"), (768, 256, None, "k_rows_wave<double, 12, 4, 1, 1, 0>"),
             (768, 82, 0, "k_rows_wave<double, 12, 2, 1, 1, 0>"),
-            (896, 100, None, "k_rows_pks<double, 0, 0, 2, 8>"), (896, 130, None, "k_rows_direct<double, 1>"), (896, 82, None, "k_rows_pks<double, 0, 7, 2>"), (1152, 82, None, "k_rows_pks<double, 0, 9, 2>"),
+            (896, 100, None, "k_rows_pks<double, 0, 0, 2, 8>"), (896, 130, None, "k_rows_blu<double, 24, 4, 1, false>"), (896, 82, None, "k_rows_pks<double, 0, 7, 2>"), (1152, 82, None, "k_rows_pks<double, 0, 9, 2>"),
             (1152, 30, 545, "k_rows_pks<double, 0, 9, 2>"), (1152, 82, 500, "k_rows_wave<double, 18, 2, 1, 1, 0>"),
             (1280, 82, None, "k_rows_pks<double, 1, 5, 2>"), (1280, 96, None, "k_rows_pks<double, 1, 5, 2>"), (1280, 82, 602, "k_rows_pks<double, 1, 5, 2>"),
             (1280, 200, None, "k_rows_wave<double, 20, 4, 1, 1, 0>"),

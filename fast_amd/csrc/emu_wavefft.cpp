@@ -447,7 +447,7 @@ static double run_pks_case(int Np, int shift, unsigned seed) {
   build_tw1_pk<R>(tw1.data(), L, cs_turns);
   build_pcw<R>(pcw.data(), N, S, cs_turns, NPL);
   std::vector<E> xbuf(D16_XELEMS);
-  static HostExec<R, 16, pks_nm<L0>()> ex;
+  static HostExec<R, 16, pks_nm<L0, NPL>()> ex;
   pks_clear<R, L0, NPL>(ex);
   for (int sp = 0; sp < S; ++sp) {
     for (int l = 0; l < WAVE; ++l)
@@ -456,7 +456,7 @@ static double run_pks_case(int Np, int shift, unsigned seed) {
         const double sg = (k & 1) ? -1.0 : 1.0;        // the input-side fftshift sign, folded into the colouring table on the device
         ex.regs[l].v[j] = mk<R>((R)(sg * inr[g * N + k]), (R)(sg * ini[g * N + k]));
       }
-    packed_row_fft<R, L0, pks_nm<L0>(), pks_plane_mask(L0, S, NPL)>(ex, xbuf.data(), tw1.data(), (const cpx<R>*)nullptr, 0, 0, Np);
+    packed_row_fft<R, L0, pks_nm<L0, NPL>(), pks_plane_mask(L0, S, NPL)>(ex, xbuf.data(), tw1.data(), (const cpx<R>*)nullptr, 0, 0, Np);
     pks_accumulate<R, L0, FIRST, NPL>(ex, pcw.data() + sp * SPAN);
   }
   std::vector<double> gr((size_t)G * Np, 1e300), gi((size_t)G * Np, 1e300);
@@ -479,6 +479,19 @@ static double run_pks_case(int Np, int shift, unsigned seed) {
       scale = std::fmax(scale, std::fmax(std::fabs((double)sr), std::fabs((double)si)));
     }
   return worst / scale;
+}
+// all sixteen planes of 256-point sub-rows: centred windows of up to 256 pixels
+template <class R, int S>
+static int sweep_pks16(const char* name, double tol) {
+  int bad = 0;
+  for (int Np : {256, 129, 200, 82, 1})
+    for (int shift : {0, Np < 250 ? 3 : 0, Np < 200 ? -27 : 0}) {
+      const double err = run_pks_case<R, 1, S, 16>(Np, shift, 1616u + Np + shift + S);
+      const bool ok = err <= tol;
+      std::printf("%s packed sub-rows, sixteen planes N=%d (S=%d) shift=%d Np=%d relerr=%.3e %s\n", name, S * 256, S, shift, Np, err, ok ? "ok" : "FAIL");
+      bad += !ok;
+    }
+  return bad;
 }
 // eight planes: centred windows of up to 128 pixels
 template <class R, int L0, int S>
@@ -594,6 +607,8 @@ int main() {
   bad += sweep_pks<double, 0, 7>("f64", 1e-13);
   bad += sweep_pks<double, 0, 9>("f64", 1e-13);
   // the counts the run-time kernels take (fmc_core.h: pks_rt): the arithmetic knows the count's parity only
+  bad += sweep_pks16<double, 5>("f64", 1e-13);
+  bad += sweep_pks16<double, 6>("f64", 1e-13);
   bad += sweep_pks8<double, 1, 5>("f64", 1e-13);
   bad += sweep_pks8<double, 1, 6>("f64", 1e-13);
   bad += sweep_pks8<double, 0, 7>("f64", 1e-13);

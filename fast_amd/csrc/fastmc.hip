@@ -140,6 +140,7 @@ struct fastmc_ctx {
   void* pk_om = nullptr;
   void* pks_tw1 = nullptr; // grids of the packed sub-rows (fmc_core.h: pks_count -- every multiple of 64 from 192 to 4096 but 256, 512): tables of the packed sub-rows (fmc_wavefft.h: build_tw1_pk for M = 256, build_pcw)
   void* pks_cw = nullptr;
+  void* pks_cw16 = nullptr; // ... 256 entries per sub-row: all sixteen planes of 256-point sub-rows, centred windows of 129 ... 256 pixels
   void* pks_cw8 = nullptr;  // ... with 128 entries per sub-row: eight planes, centred windows of 97 ... 128 pixels (float64 pipeline)
   double* W = nullptr;
   void* V = nullptr;
@@ -588,7 +589,7 @@ static void destroy_now(fastmc_ctx* h) {
   if (h->nps) { nps_free(h->nps); h->nps = nullptr; }
 #endif
   if (h->V) { g_slabs.give(h->device, h->V, h->V_bytes); h->V = nullptr; }
-  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->pbz_tw, h->pbz_pre, h->pbz_vhat, h->pbz_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->amp_p, h->ampf_p, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->pks_tw1, h->pks_cw, h->pks_cw8, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
+  void* ptrs[] = {h->mr_tw1, h->mr_om, h->mr_cw, h->blu_tw1, h->blu_om, h->blu_twf, h->blu_pre, h->blu_vhat, h->blu_post, h->pbz_tw, h->pbz_pre, h->pbz_vhat, h->pbz_post, h->bad, h->ampf, h->ampf_s, h->amp, h->amp_s, h->amp_p, h->ampf_p, h->tw, h->tw1, h->om, h->cw, h->tw1g, h->omg, h->pk_tw1, h->pk_om, h->pks_tw1, h->pks_cw, h->pks_cw8, h->pks_cw16, h->W, h->V, h->partial, h->out, h->logamp, h->cre,
                   h->cim, h->phs, h->sh_scale, h->sh_mu, h->sh_ex, h->sh_ey, h->sh_coef, h->sh_mean, h->sh_dcol, h->sh_in_re,
                   h->sh_in_im, h->hist, h->gather_buf, h->layers, h->ps_dev, (void*)h->clk};
   for (void* p : ptrs)
@@ -748,12 +749,13 @@ static int default_batch(const fastmc_ctx* h) {
   int b = (int)(2048.0 * 1024 * 1024 / per);       // round 2: 1568 realisations per launch +0.9 % over 1176 at 1024^2
   b = std::max(1, std::min(b, 4096));
   if (h->path != 0 && (pks_grid(h->N) || (h->path == 1 && h->rsz == 8 && pks_p16(h->N) && h->N >= pks_p16_from())) &&
-      h->lo >= h->N / 2 - 64 && h->lo + h->Np <= h->N / 2 + 64 && !(h->rsz == 4 && (pks_rt(h->N) || h->lo < h->N / 2 - 48 || h->lo + h->Np > h->N / 2 + 48))) {
+      ((h->lo >= h->N / 2 - 64 && h->lo + h->Np <= h->N / 2 + 64) || (h->rsz == 8 && pks_L0(h->N) == 1 && h->lo >= h->N / 2 - 128 && h->lo + h->Np <= h->N / 2 + 128)) &&
+      !(h->rsz == 4 && (pks_rt(h->N) || h->lo < h->N / 2 - 48 || h->lo + h->Np > h->N / 2 + 48))) {
     // packed sub-rows (pks_variant; fmc_kernels.h: k_rows_pks): a tile is one 128-byte line of V positions x BPG realisations, and the
     // launch's workgroups (one per CU) walk the tiles -- whole groups of BPG realisations, and of the group counts within a quarter of
     // the slab limit the one whose tiles fill the last round over the 256 CUs best (1856: 10 % of the launch was an almost empty round)
-    const bool planes8 = h->lo < h->N / 2 - 48 || h->lo + h->Np > h->N / 2 + 48;
-    const int L0 = pks_L0(h->N), WPB = planes8 ? (L0 == 1 ? 12 : 8) : (L0 == 0 ? (h->rsz == 8 ? FMC_PKS_WPB0 : 12) : FMC_PKS_WPB), G = L0 == 1 ? 4 : 8;
+    const bool planes8 = h->lo < h->N / 2 - 48 || h->lo + h->Np > h->N / 2 + 48, planes16 = h->lo < h->N / 2 - 64 || h->lo + h->Np > h->N / 2 + 64;
+    const int L0 = pks_L0(h->N), WPB = planes16 ? 8 : planes8 ? (L0 == 1 ? 12 : 8) : (L0 == 0 ? (h->rsz == 8 ? FMC_PKS_WPB0 : 12) : FMC_PKS_WPB), G = L0 == 1 ? 4 : 8;
     const int LR = 128 / (2 * h->rsz), BPG = ROWS_PER_WAVE * WPB / (LR / G), nmax = b / BPG;
     if (nmax >= 1) {
       int best = nmax;
@@ -925,6 +927,11 @@ static int upload_pks_tables(fastmc_ctx* h) {
     std::vector<cpx<R>> pcw8((size_t)Sp * pks_span(8));
     build_pcw<R>(pcw8.data(), h->N, Sp, cs_turns, 8);
     TRY(upload_table<R>(&h->pks_cw8, pcw8));
+    if (pks_L0(h->N) == 1) {
+      std::vector<cpx<R>> pcw16((size_t)Sp * pks_span(16));
+      build_pcw<R>(pcw16.data(), h->N, Sp, cs_turns, 16);
+      TRY(upload_table<R>(&h->pks_cw16, pcw16));
+    }
   }
   return 0;
 }
@@ -962,6 +969,9 @@ static int pks_variant(const fastmc_ctx* h) {
   // ... eight planes N / 2 - 64 ... N / 2 + 63: 1 (float64 pipeline, run-time sub-row counts for every grid; FASTMC_PKS8=0: off)
   static const bool off8 = getenv("FASTMC_PKS8") && atoi(getenv("FASTMC_PKS8")) == 0;
   if (sizeof(R) == 8 && !off8 && h->lo >= h->N / 2 - 64 && h->lo + h->Np <= h->N / 2 + 64) return 1;
+  // ... all sixteen planes of a 256-point sub-transform, N / 2 - 128 ... N / 2 + 127: 2 (grids N = S x 256 only; FASTMC_PKS16=0: off)
+  static const bool off16 = getenv("FASTMC_PKS16") && atoi(getenv("FASTMC_PKS16")) == 0;
+  if (sizeof(R) == 8 && !off8 && !off16 && pks_L0(h->N) == 1 && h->lo >= h->N / 2 - 128 && h->lo + h->Np <= h->N / 2 + 128) return 2;
   return -1;
 }
 
@@ -1394,6 +1404,12 @@ int dispatch_pks(fastmc_ctx* h, const RowArgs<R>& RA_in, const ColArgs<R>& CA_in
 #undef FMC_PKSC8
       return fail(FASTMC_ESTATE, "no eight-plane packed sub-row column kernel for this grid");
     }
+    if (pks_variant<R>(h) == 2) {      // all sixteen planes (256-point sub-rows)
+      CA.cw = (const cpx<R>*)h->pks_cw16;
+      if (pks_count(h->N) & 1) { if (epi == 0) launch_pks_cols<R, 1, 0, 0, 16>(h, CA); else launch_pks_cols<R, 1, 0, 1, 16>(h, CA); }
+      else { if (epi == 0) launch_pks_cols<R, 1, -2, 0, 16>(h, CA); else launch_pks_cols<R, 1, -2, 1, 16>(h, CA); }
+      return 0;
+    }
   }
 #define FMC_PKSC(LL, SS)                                                                  \
   if (L0 == LL && S == SS) {                                                              \
@@ -1420,6 +1436,12 @@ int dispatch_pks_rows(fastmc_ctx* h, const RowArgs<R>& RA_in, int mode) {
       FMC_PKS8(1, 0) FMC_PKS8(1, -2) FMC_PKS8(0, 0) FMC_PKS8(-1, 0)
 #undef FMC_PKS8
       return fail(FASTMC_ESTATE, "no eight-plane packed sub-row kernel for this grid");
+    }
+    if (pks_variant<R>(h) == 2) {      // all sixteen planes (centred windows of 129 ... 256 pixels, 256-point sub-rows)
+      RA.cw = (const cpx<R>*)h->pks_cw16;
+      if (pks_count(h->N) & 1) { if (mode == 0) launch_pks_rows<R, 1, 0, 0, 16>(h, RA); else launch_pks_rows<R, 1, 0, 2, 16>(h, RA); }
+      else { if (mode == 0) launch_pks_rows<R, 1, -2, 0, 16>(h, RA); else launch_pks_rows<R, 1, -2, 2, 16>(h, RA); }
+      return 0;
     }
   }
 #define FMC_PKS(LL, SS)                                                                                   \

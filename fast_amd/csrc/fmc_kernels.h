@@ -968,7 +968,7 @@ template <class R, int L0_, int S, int NPL = 6> struct PksCfg {
   // L0 = -1: sub-rows of SIXTY-FOUR points (192, 320, 448, 576): eight values per lane, eight lanes per sub-row (fmc_wavefft.h: pks64_pass)
   // S > 0: the sub-row count at compile time (192 ... 1792); S = 0 / -2: an odd / even count at RUN TIME (RowArgs::S: the grids of
   // fmc_core.h wave_rt_split up to 3840 -- 2304 = 9 x 256 ... 3840 = 15 x 256, 1920 ... 3456 = 15, 21, 27 x 128, 1344 / 1728 = 21 / 27 x 64)
-  static constexpr int L0 = L0_, L = L0 < 0 ? 8 : pk_lanes(L0), VPL = L0 < 0 ? 8 : 16, G = WAVE / L, M = VPL * L, NM = pks_nm<L0>();
+  static constexpr int L0 = L0_, L = L0 < 0 ? 8 : pk_lanes(L0), VPL = L0 < 0 ? 8 : 16, G = WAVE / L, M = VPL * L, NM = pks_nm<L0, NPL>();
   static constexpr int SP = S > 0 ? S : (S == 0 ? 3 : 2);        // a count of the same parity: the plane set depends on it only
   static constexpr int B0M = L0 < 0 ? 0xFF : pks_plane_mask(L0 < 0 ? 0 : L0, SP, NPL), FIRST = pks_first_plane(L0 < 0 ? 0 : L0, SP, NPL);
   static constexpr int SPAN = pks_span(NPL);             // table entries per sub-row (NPL = 8: centred windows of up to 128 pixels)
@@ -977,7 +977,8 @@ template <class R, int L0_, int S, int NPL = 6> struct PksCfg {
   // more registers for float64): eight waves; 64-point sub-rows: twelve accumulators but eight values: twelve waves
   // (eight planes: two / four accumulators more per lane -- 163 registers with 256-point sub-rows: still twelve waves; 209 / 170 with
   // 128 / 64-point ones: eight)
-  static constexpr int WPB = NPL > 6 ? (L0 == 1 ? 12 : 8) : (L0 == 0 ? (sizeof(R) == 8 ? FMC_PKS_WPB0 : 12) : FMC_PKS_WPB);
+  // (all sixteen planes, L0 = 1 only: sixteen accumulators -- eight waves)
+  static constexpr int WPB = NPL > 8 ? 8 : (NPL > 6 ? (L0 == 1 ? 12 : 8) : (L0 == 0 ? (sizeof(R) == 8 ? FMC_PKS_WPB0 : 12) : FMC_PKS_WPB));
 };
 // LDS carve (dynamic): [generator tables (MODE 2)][tw1 16 L cpx][pcw S x 96 cpx][xbuf WPB * D16_XELEMS 8-byte]
 // A run-time count (S <= 0) keeps only the CURRENT pass's 96 entries of pcw, one copy per wave (pks_slice): the table of S = 63 sub-rows
@@ -999,8 +1000,12 @@ template <int SPAN>
 __device__ __forceinline__ void pks_slice_load(const cpx<double>* cw, cpx<double>* slice, int sp, int lane) {
   const cpx<double>* src = cw + sp * SPAN + lane;
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)slice, 16, 0, 0);
-  if (SPAN == 128 || lane < 32)
+  if (SPAN >= 128 || lane < 32)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64), (__attribute__((address_space(3))) void*)(slice + 64), 16, 0, 0);
+  if constexpr (SPAN == 256) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 128), (__attribute__((address_space(3))) void*)(slice + 128), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 192), (__attribute__((address_space(3))) void*)(slice + 192), 16, 0, 0);
+  }
 }
 template <int SPAN>
 __device__ __forceinline__ void pks_slice_load(const cpx<float>*, cpx<float>*, int, int) {}      // (never instantiated for a launch: fastmc.hip pks_variant)
@@ -1096,7 +1101,7 @@ template <class R, int L0, int S, int NPL = 6> struct PksColCfg {
   // (a run-time sub-row count: twelve waves -- sixteen exchange buffers + sixteen table slices would be 163 KB)
   // 122 registers (M = 256) / 152 (M = 128: twelve accumulators) with float64: four / three waves per SIMD; the exchange buffers and
   // the tables of sixteen / twelve waves fit the LDS (150 KB / 117 KB at most)
-  static constexpr int WPC = NPL > 6 ? 12 : (S <= 0 ? 12 : ((L0 != 0 || sizeof(R) == 4) ? 16 : 12));      // (64-point sub-rows: 126 registers; eight planes: 128-162)
+  static constexpr int WPC = NPL > 8 ? 8 : (NPL > 6 ? 12 : (S <= 0 ? 12 : ((L0 != 0 || sizeof(R) == 4) ? 16 : 12)));      // (64-point sub-rows: 126 registers; eight planes: 128-162; sixteen: eight waves)
 };
 template <class R, int L0, int S, int NPL = 6>
 __host__ __device__ constexpr size_t pks_cols_lds_bytes(int Sr) {
@@ -1160,14 +1165,15 @@ __global__ __launch_bounds__((PksColCfg<R, L0, S, NPL>::WPC * 64)) void k_cols_p
     }
   };
   cpx<R>* ob = reinterpret_cast<cpx<R>*>(xbuf) + lane;
+  constexpr int PH = NPL > 8 ? 8 : NPL;                   // planes per pass (sixteen planes, L0 = 1: two passes of eight, plane 8 m + p)
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
 #pragma unroll
-    for (int p = 0; p < NPL; ++p) ob[WAVE * p] = regs.omc[m][p];
+    for (int p = 0; p < PH; ++p) ob[WAVE * p] = regs.omc[m][p];
     ex.sync();
-    const int y0 = N / 2 - 8 * NPL + q + 8 * m - A.lo;     // (L0 = 1: m = 0, q = a; L0 = 0, -1: e = q + 8 m + 16 p)
+    const int y0 = N / 2 - 8 * NPL + q + (L0 == 1 ? 128 : 8) * m - A.lo;     // (L0 = 1: q = a, e = a + 16 (8 m + p); L0 = 0, -1: e = q + 8 m + 16 p)
 #pragma unroll 1
-    for (int p = 0; p < NPL; ++p) {
+    for (int p = 0; p < PH; ++p) {
       const int yi = y0 + 16 * p;
       if (live && yi >= 0 && yi < A.Np) {
         const cpx<R> v = ob[WAVE * p];

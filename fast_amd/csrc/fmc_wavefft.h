@@ -630,7 +630,9 @@ constexpr int PKS_SPAN = 96;                                         // outputs 
 // draws on one-row-per-wave rows at a third to a quarter of the rate.  One plane more on either side: FIRST - 1, eight (sixteen)
 // accumulators per lane, 128 table entries per sub-row.  Run-time sub-row counts only (any S).
 constexpr int pks_span(int NPL) { return 16 * NPL; }
-template <int L0> constexpr int pks_nm() { return L0 <= 0 ? 2 : 1; }        // a values per lane (L0 = -1: the 64-point form, same accumulator layout as L0 = 0)
+// a values per lane (L0 = -1: the 64-point form, same accumulator layout as L0 = 0); NPL = 16 (ALL planes of a 256-point sub-transform:
+// centred windows of up to 256 pixels, L0 = 1 only) keeps its sixteen accumulators in both halves of r.omc: plane p in omc[p >> 3][p & 7]
+template <int L0, int NPL = 6> constexpr int pks_nm() { return (L0 <= 0 || NPL > 8) ? 2 : 1; }
 constexpr int pks_first_plane(int L0, int S, int NPL = 6) { return (L0 == 0 ? ((S & 1) ? 1 : 5) : ((S & 1) ? 5 : 13)) - (NPL - 6) / 2; }
 constexpr int pks_plane_mask(int L0, int S, int NPL = 6) {
   int m = 0;
@@ -641,21 +643,22 @@ static_assert(pks_plane_mask(1, 3) == pk_centre_mask<1>() && pks_plane_mask(0, 5
               "the centred planes of the 256 / 128-point grids, and the planes around 0");
 template <class R, int L0, int NPL = 6, class Exec>
 FMC_HD void pks_clear(Exec& ex) {
-  ex.each([&](int, LaneRegs<R, 16, pks_nm<L0>()>& r) {
+  static_assert(NPL <= 8 || L0 == 1, "all sixteen planes: 256-point sub-rows only");
+  ex.each([&](int, LaneRegs<R, 16, pks_nm<L0, NPL>()>& r) {
 #pragma unroll
-    for (int m = 0; m < pks_nm<L0>(); ++m)
+    for (int m = 0; m < pks_nm<L0, NPL>(); ++m)
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) r.omc[m][p] = mk<R>((R)0, (R)0);
+      for (int p = 0; p < (NPL > 8 ? 8 : NPL); ++p) r.omc[m][p] = mk<R>((R)0, (R)0);
   });
 }
 // after packed_row_fft of sub-row s (its planes in r.v, output-side sign applied): acc[m][p] += w_N^{s x} Y_s[x mod M]
 template <class R, int L0, int FIRST, int NPL = 6, class Exec>
 FMC_HD void pks_accumulate(Exec& ex, const cpx<R>* pcw_s) {
-  ex.each([&](int lane, LaneRegs<R, 16, pks_nm<L0>()>& r) {
+  ex.each([&](int lane, LaneRegs<R, 16, pks_nm<L0, NPL>()>& r) {
     if constexpr (L0 == 1) {
       const cpx<R>* w = pcw_s + (lane & 15);
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) r.omc[0][p] = cfma(ex.ld(w + 16 * p), r.v[(FIRST + p) & 15], r.omc[0][p]);
+      for (int p = 0; p < NPL; ++p) r.omc[p >> 3][p & 7] = cfma(ex.ld(w + 16 * p), r.v[(FIRST + p) & 15], r.omc[p >> 3][p & 7]);
     } else {
       const cpx<R>* w = pcw_s + (lane & 7);
 #pragma unroll
@@ -667,15 +670,23 @@ FMC_HD void pks_accumulate(Exec& ex, const cpx<R>* pcw_s) {
 }
 // f(oi, re, im) for every window output this lane holds after the last pks_accumulate; N the full row length
 template <class R, int L0, int NPL = 6, class F>
-FMC_HD void pks_outputs(int lane, const LaneRegs<R, 16, pks_nm<L0>()>& r, int N, int lo, int Np, F f) {
+FMC_HD void pks_outputs(int lane, const LaneRegs<R, 16, pks_nm<L0, NPL>()>& r, int N, int lo, int Np, F f) {
   const int a = lane & (L0 <= 0 ? 7 : 15);
+  if constexpr (L0 == 1) {
 #pragma unroll
-  for (int p = 0; p < NPL; ++p)
-#pragma unroll
-    for (int m = 0; m < pks_nm<L0>(); ++m) {
-      const int oi = N / 2 - 8 * NPL + a + 8 * m + 16 * p - lo;
-      if (oi >= 0 && oi < Np) f(oi, r.omc[m][p].x, r.omc[m][p].y);
+    for (int p = 0; p < NPL; ++p) {
+      const int oi = N / 2 - 8 * NPL + a + 16 * p - lo;
+      if (oi >= 0 && oi < Np) f(oi, r.omc[p >> 3][p & 7].x, r.omc[p >> 3][p & 7].y);
     }
+  } else {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int oi = N / 2 - 8 * NPL + a + 8 * m + 16 * p - lo;
+        if (oi >= 0 && oi < Np) f(oi, r.omc[m][p].x, r.omc[m][p].y);
+      }
+  }
 }
 template <class R, class CosSin>
 inline void build_pcw(cpx<R>* pcw, int N, int S, CosSin cs, int NPL = 6) {

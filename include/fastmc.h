@@ -38,7 +38,7 @@
  *     gives every tile of a large row launch a workgroup of its own instead of letting the resident workgroups walk the tiles
  *     (A/B timing; same results); FASTMC_COLS_PERSIST=0: the same for the column launches of the 1024-point pipeline.
  *   - environment, kernel choice for A/B timing (read once; same results to rounding): FASTMC_PKS=0 keeps the packed sub-rows off
- *     (staged draws on the grid's one-row-per-wave / chirp-z / 50-lane rows instead); FASTMC_PKS8=0 keeps them to windows of 96 pixels; FASTMC_PKS_P16=1024 lets them serve 1024 too
+ *     (staged draws on the grid's one-row-per-wave / chirp-z / 50-lane rows instead); FASTMC_PKS8=0 keeps them to windows of 96 pixels, FASTMC_PKS16=0 to 128; FASTMC_PKS_P16=1024 lets them serve 1024 too
  *     (default: from 2048); FASTMC_PBZ=0 runs the chirp-z grids one wavefront per row as rounds 1-5 did, FASTMC_PBZ_COLS=0 only their
  *     column pass; FASTMC_BLU_P=0 keeps that form to its five sizes of rounds 1-5; FASTMC_GEN64_STAGED=1 stages the float64 generator
  *     through memory everywhere.
@@ -204,7 +204,8 @@ int fastmc_last_timing(fastmc_t* h, double* times_ms, int64_t* launches);
  *       2688, 3072, 3456, 3584, 3840 as 2 ... 4 interleaved sub-rows of 448 ... 1536).  128, 256, 512 run as packed rows (8 / 4 / 2
  *       rows per wavefront).
  *       Whatever family a grid belongs to (1, 2 or 3), the device generator's rows of EVERY multiple of 64 from 192 to 4096 except
- *       256, 512 and 1024, with a centred window of up to 128 pixels (six planes of a sub-transform up to 96, eight beyond), run as
+ *       256, 512 and 1024, with a centred window of up to 128 pixels (six planes of a sub-transform up to 96, eight beyond; up to 256
+ *       pixels with all sixteen planes where 256 divides N), run as
  *       packed SUB-ROWS, rows and columns (S interleaved sub-rows
  *       of 256 / 128 / 64 points, S = N / 256, else N / 128, else N / 64; 4 / 8 / 8 rows per wavefront; round 6) -- the generator draws
  *       N / 16 streams per row on these grids (N / 8 on the odd multiples of 64), as it always did on 2048 and 4096; the family

@@ -381,12 +381,12 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (1024, 97, None, "k_rows_wave<double, 16, 2, 2, 1, 8>"), (1024, 128, None, "k_rows_wave<double, 16, 2, 2, 1, 8>"),
             (1024, 82, 0, "k_rows_wave<double, 16, 2, 2, 1, 7>"), (1024, 120, 904, "k_rows_wave<double, 16, 2, 2, 1, 7>"),
             (1024, 200, None, "k_rows_wave<double, 16, 4, 2, 1, 7>"), (1024, 400, None, "k_rows_wave<double, 16, 8, 2, 1, 7>"),
-            (2048, 122, None, "k_rows_pks<double, 1, -2, 2, 8>"), (2048, 122, 900, "k_rows_wave<double, 16, 2, 2, 2, 7>"),
+            (2048, 122, None, "k_rows_pks<double, 1, -2, 2, 8>"), (2048, 122, 900, "k_rows_pks<double, 1, -2, 2, 16>"), (2048, 122, 600, "k_rows_wave<double, 16, 2, 2, 2, 7>"),
             (2048, 402, None, "k_rows_wave<double, 16, 8, 2, 2, 7>"), (4096, 100, None, "k_rows_pks<double, 1, -2, 2, 8>"),
             # ... whose centred windows of up to 96 pixels go to the packed sub-rows (eight / sixteen sub-rows of 256 points, count at run time:
             # the same N / 16 streams per row, +7 % / +15 %); 1024 keeps its dense sixteen-wave row (fastmc.hip: pks_p16_from)
             (2048, 82, None, "k_rows_pks<double, 1, -2, 2>"), (2048, 96, 976, "k_rows_pks<double, 1, -2, 2>"), (4096, 82, None, "k_rows_pks<double, 1, -2, 2>"),
-            (2048, 82, 900, "k_rows_wave<double, 16, 2, 2, 2, 7>"),
+            (2048, 82, 900, "k_rows_pks<double, 1, -2, 2, 16>"),
             # packed rows (eight / four / two rows per wavefront): centred six planes and all planes
             (128, 82, None, "k_rows_pk<double, 0, 2, 0>"), (128, 128, None, "k_rows_pk<double, 0, 2, 1>"),
             (256, 82, None, "k_rows_pk<double, 1, 2, 0>"), (256, 200, None, "k_rows_pk<double, 1, 2, 1>"), (256, 82, 100, "k_rows_pk<double, 1, 2, 1>"),
@@ -401,15 +401,15 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (640, 82, None, "k_rows_pks<double, 0, 5, 2>"), (640, 96, 272, "k_rows_pks<double, 0, 5, 2>"), (640, 250, 11, "k_rows_wave<double, 10, 4, 1, 1, 0>"),
             # 640, 768, 896, 1152, 1280, 1536, 1792 (round 6): the packed sub-rows for centred windows of up to 96 pixels (also shifted inside the six planes);
             # any other window is STAGED (k_gen_coeffs_f64 -> MODE 1 rows: these grids draw N / 16 streams per row)
-            (768, 82, None, "k_rows_pks<double, 1, 3, 2>"), (768, 40, None, "k_rows_pks<double, 1, 3, 2>"), (768, 256, None, "k_rows_wave<double, 12, 4, 1, 1, 0>"),
+            (768, 82, None, "k_rows_pks<double, 1, 3, 2>"), (768, 40, None, "k_rows_pks<double, 1, 3, 2>"), (768, 256, None, "k_rows_pks<double, 1, 0, 2, 16>"),
             (768, 82, 0, "k_rows_wave<double, 12, 2, 1, 1, 0>"),
             (896, 100, None, "k_rows_pks<double, 0, 0, 2, 8>"), (896, 130, None, "k_rows_blu<double, 24, 4, 1, false>"), (896, 82, None, "k_rows_pks<double, 0, 7, 2>"), (1152, 82, None, "k_rows_pks<double, 0, 9, 2>"),
             (1152, 30, 545, "k_rows_pks<double, 0, 9, 2>"), (1152, 82, 500, "k_rows_wave<double, 18, 2, 1, 1, 0>"),
             (1280, 82, None, "k_rows_pks<double, 1, 5, 2>"), (1280, 96, None, "k_rows_pks<double, 1, 5, 2>"), (1280, 82, 602, "k_rows_pks<double, 1, 5, 2>"),
-            (1280, 200, None, "k_rows_wave<double, 20, 4, 1, 1, 0>"),
-            (1536, 120, 1400, "k_rows_wave<double, 24, 2, 1, 1, 0>"), (1536, 222, None, "k_rows_wave<double, 24, 4, 1, 1, 0>"), (1536, 82, None, "k_rows_pks<double, 1, 6, 2>"),
+            (1280, 200, None, "k_rows_pks<double, 1, 0, 2, 16>"), (1280, 200, 100, "k_rows_wave<double, 20, 4, 1, 1, 0>"),
+            (1536, 120, 1400, "k_rows_wave<double, 24, 2, 1, 1, 0>"), (1536, 222, None, "k_rows_pks<double, 1, -2, 2, 16>"), (1536, 82, None, "k_rows_pks<double, 1, 6, 2>"),
             (1536, 96, 720, "k_rows_pks<double, 1, 6, 2>"),
-            (1792, 82, None, "k_rows_pks<double, 1, 7, 2>"), (1792, 60, 860, "k_rows_pks<double, 1, 7, 2>"), (1792, 97, None, "k_rows_pks<double, 1, 0, 2, 8>"), (1792, 97, 800, "k_rows_wave<double, 28, 2, 1, 1, 0>"),
+            (1792, 82, None, "k_rows_pks<double, 1, 7, 2>"), (1792, 60, 860, "k_rows_pks<double, 1, 7, 2>"), (1792, 97, None, "k_rows_pks<double, 1, 0, 2, 8>"), (1792, 97, 800, "k_rows_pks<double, 1, 0, 2, 16>"), (1792, 97, 300, "k_rows_wave<double, 28, 2, 1, 1, 0>"),
             # 50-lane family (N = 50 P S) and the run-time-split wave grids: the rows of fmc_mrfft.h
             (100, 40, None, "k_rows_mr<double, 2, 2, 2, false, 50, 0>"), (300, 60, None, "k_rows_mr<double, 6, 2, 2, false, 50, 0>"),
             (500, 82, None, "k_rows_mr<double, 10, 2, 2, false, 50, 0>"), (800, 96, 3, "k_rows_mr<double, 16, 2, 2, false, 50, 0>"),
@@ -422,7 +422,7 @@ _FUSED64 = [(1024, 40, None, "k_rows_wave<double, 16, 2, 2, 1, 4>"), (1024, 96, 
             (1920, 82, None, "k_rows_pks<double, 0, 0, 2>"), (2688, 40, 1310, "k_rows_pks<double, 0, 0, 2>"), (3456, 82, None, "k_rows_pks<double, 0, 0, 2>"),
             (2304, 82, None, "k_rows_pks<double, 1, 0, 2>"), (2560, 82, None, "k_rows_pks<double, 1, -2, 2>"), (3072, 96, None, "k_rows_pks<double, 1, -2, 2>"),
             (3584, 82, 1750, "k_rows_pks<double, 1, -2, 2>"), (3840, 82, None, "k_rows_pks<double, 1, 0, 2>"),
-            (2560, 120, None, "k_rows_pks<double, 1, -2, 2, 8>"), (2560, 130, None, "k_rows_mr<double, 20, 4, 1, true, 64, 0>"), (1344, 82, 100, "k_rows_mr<double, 7, 2, 1, true, 64, 0>"),
+            (2560, 120, None, "k_rows_pks<double, 1, -2, 2, 8>"), (2560, 130, None, "k_rows_pks<double, 1, -2, 2, 16>"), (2560, 130, 200, "k_rows_mr<double, 20, 4, 1, true, 64, 0>"), (1344, 82, 100, "k_rows_mr<double, 7, 2, 1, true, 64, 0>"),
             # ... and of every other multiple of 64 (fmc_core.h: pks_rt): grids whose host-coefficient rows are the chirp-z family's (704 ... 3968)
             # or the 50-lane family's (1600, 3200); off the centred windows the draws are staged onto those rows
             (704, 82, None, "k_rows_pks<double, -1, 0, 2>"), (960, 96, None, "k_rows_pks<double, -1, 0, 2>"), (2112, 82, None, "k_rows_pks<double, -1, 0, 2>"),
@@ -621,7 +621,7 @@ def test_tile_walk_equals_one_tile_per_workgroup(N, n):
     (4160, 82, "k_rows_pks<double, -1, 0, 0>", "k_rows_pks<double, -1, 0, 2>"),
     # ... any other window: the float32 draw on the direct family, the float64 generator staged onto the family's host-coefficient rows
     (7168, 100, "k_rows_pks<double, 1, -2, 0, 8>", "k_rows_pks<double, 1, -2, 2, 8>"),
-    (6144, 140, "k_rows_direct<double, 0>", "k_rows_mr<double, 24, 4, 1, true, 64, 0>"),
+    (6144, 140, "k_rows_pks<double, 1, -2, 0, 16>", "k_rows_pks<double, 1, -2, 2, 16>"),
     (5000, 82, "k_rows_mr<double, 20, 2, 0, true, 50, 1>", "k_rows_mr<double, 20, 2, 2, true, 50, 0>"),
     (4100, 82, "k_rows_pbz<double, 6, 0>", "k_rows_pbz<double, 6, 2>"),
     (7003, 200, "k_rows_blu<double, 16, 4, 0, true>", "k_rows_blu<double, 16, 4, 2, true>")])

@@ -36,7 +36,7 @@ for c in range(cases):
     lo = int(rng.choice([0, N - Np, (N - Np) // 2, rng.integers(0, N - Np + 1)]))
     if N % 64 == 0 and 192 <= N <= 8192 and N not in (256, 512, 1024) and rng.random() < 0.6:
         # grids of the packed sub-rows (round 6): two cases in three inside the 96 outputs their six planes hold
-        span = 48 if rng.random() < 0.6 else 64          # six planes, or the eight of the windows of 97 ... 128 pixels
+        span = 48 if rng.random() < 0.5 else (64 if rng.random() < 0.6 or N % 256 else 128)      # six planes; eight (windows of 97 ... 128 pixels); all sixteen (... 256, N = S x 256)
         Np = int(rng.integers(1, 2 * span + 1))
         lo = int(rng.integers(max(N // 2 - span, 0), N // 2 + span - Np + 1))
     prec = "f64" if rng.random() < 0.7 else "f32"
